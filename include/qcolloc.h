@@ -1,0 +1,172 @@
+/*
+ * qcolloc.h — C ABI of libqcolloc_hip.so: MI355X (gfx950) knot-point evaluator for the
+ * direct-collocation unitary dynamics constraint of QuantumCollocation.jl.
+ *
+ * This header IS the drop-in boundary.  Every entry point replaces one observable piece of the
+ * `QuantumDynamics` object that QuantumCollocationCore builds inside
+ * `QuantumControlProblem(traj, J, integrators; ...)`
+ * (reference src/problem_templates/unitary_smooth_pulse_problem.jl:181-190) and that the reference's
+ * own micro-benchmark exercises (reference test/scripts/integrator_test_1qubit.jl:41-52):
+ *
+ *   reference (Julia)                                   this ABI
+ *   -------------------------------------------------   -----------------------------------------
+ *   QuantumSystem(H_drift, H_drives).G_drift/G_drives    qc_generator_from_hamiltonian
+ *       (unitary_smooth_pulse_problem.jl:199)
+ *   operator_to_iso_vec / iso_vec_to_operator            qc_operator_to_iso_vec / qc_iso_vec_to_operator
+ *       (trajectory_initialization.jl:40-41,137,413-418)
+ *   UnitaryPadeIntegrator(state, control, sys, traj;     qc_desc{integrator=QC_PADE, pade_order,...}
+ *       order)  (unitary_smooth_pulse_problem.jl:165-167)
+ *   UnitaryExponentialIntegrator(...)  (:168-170)        qc_desc{integrator=QC_EXPONENTIAL}
+ *   DerivativeIntegrator(x, dx, traj)  (:177-178)        qc_desc.deriv_{x_off,dx_off,dim}[i]
+ *   QuantumDynamics(integrators, traj)                   qc_create
+ *       (integrator_test_1qubit.jl:41)
+ *   dynamics.F(Z.datavec)               (:45)            qc_eval_F        / qc_eval_F_dev
+ *   dynamics.dF(Z.datavec)              (:46)            qc_eval_jac      / qc_eval_F_jac(_dev)
+ *   dynamics.dF_structure               (:46)            qc_jac_structure
+ *   dynamics.mu_d2F(Z.datavec, mu)      (:52)            qc_eval_hess     / qc_eval_hess_dev
+ *   dynamics.mu_d2F_structure           (:52)            qc_hess_structure
+ *   shapes (Z.dims.states*(Z.T-1), Z.dim*Z.T+Z.global_dim)  (:44,48)   qc_dims
+ *
+ * Conventions
+ *   - All matrices are column-major (Julia order).  All arrays are caller-owned; nothing is retained
+ *     after a call returns, except that G_drift/G_drives are copied to the device by qc_create.
+ *   - Return value 0 = QC_OK, negative = error; text via qc_last_error (thread-local for
+ *     handle-less calls).  Nothing throws or exits across this boundary.
+ *   - A handle is bound to ONE HIP device and evaluates the interval range [t_begin, t_end) of the
+ *     T-1 intervals (one process per GPU shards the knots).  A handle is not
+ *     thread-safe.  Non-finite inputs are evaluated, not rejected (Ipopt probes wild points).
+ *   - "_dev" entry points take DEVICE pointers and a hipStream_t (passed as void*) and are
+ *     asynchronous on that stream.  The plain entry points take HOST pointers and return after the
+ *     results are in the caller's buffers.
+ *   - There is no CPU fallback: without a visible gfx950 device qc_create fails with QC_ERR_NO_DEVICE.
+ */
+#ifndef QCOLLOC_H
+#define QCOLLOC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QC_VERSION_MAJOR 0
+#define QC_VERSION_MINOR 1
+
+enum {
+    QC_OK = 0,
+    QC_ERR_INVALID = -1,    /* bad descriptor / argument */
+    QC_ERR_NO_DEVICE = -2,  /* no HIP device, or not gfx950 */
+    QC_ERR_HIP = -3,        /* a HIP runtime call failed */
+    QC_ERR_UNSUPPORTED = -4 /* valid request this build cannot serve (e.g. Hessian of QC_EXPONENTIAL) */
+};
+
+enum { QC_PADE = 0, QC_EXPONENTIAL = 1 };
+
+/* Kernel selection (qc_desc.kernel). AUTO picks the MFMA path when n = 2N is 16 or 32 and the
+ * Pade order is 4, else the LDS/VALU path.  Forcing a path that cannot serve the descriptor is
+ * QC_ERR_UNSUPPORTED. */
+enum { QC_KERNEL_AUTO = 0, QC_KERNEL_LDS = 1, QC_KERNEL_MFMA = 2 };
+
+#define QC_MAX_DERIV 8
+
+typedef struct qc_handle qc_handle;
+
+/* Problem descriptor.  Offsets are 0-based positions inside one knot vector z_t of length zdim
+ * (reference component order [U~, a, da, dda, dt]: trajectory_initialization.jl:357-382; other
+ * templates order differently, e.g. integrator_test_1qubit.jl:24-30, hence parameters). */
+typedef struct qc_desc {
+    int32_t N;           /* Hilbert-space dimension; iso dimension n = 2N; state length s = 2N^2 */
+    int32_t m;           /* number of drives (system.n_drives) */
+    int64_t T;           /* number of knot points (Z.T) */
+    int32_t zdim;        /* knot dimension (Z.dim) */
+    int64_t global_dim;  /* trailing global variables after zdim*T (Z.global_dim); columns only */
+    int32_t off_U;       /* offset of U~ (length s) */
+    int32_t off_a;       /* offset of the control a (length m) */
+    int32_t off_dt;      /* offset of the timestep, or -1 for a fixed timestep */
+    double dt_fixed;     /* timestep when off_dt < 0 */
+    int32_t integrator;  /* QC_PADE | QC_EXPONENTIAL */
+    int32_t pade_order;  /* even, 2..20 (reference uses 4 by default, 12 in unitary_bang_bang_problem.jl:208) */
+    int32_t n_deriv;     /* number of DerivativeIntegrators, rows appended after the unitary rows */
+    int32_t deriv_x_off[QC_MAX_DERIV];
+    int32_t deriv_dx_off[QC_MAX_DERIV];
+    int32_t deriv_dim[QC_MAX_DERIV];
+    const double* G_drift;  /* n*n, column-major:   iso(-i H_drift) */
+    const double* G_drives; /* m matrices of n*n, column-major each */
+    int32_t device;         /* HIP device ordinal this handle is bound to */
+    int32_t kernel;         /* QC_KERNEL_* */
+    int64_t t_begin;        /* first interval (0-based) this handle evaluates */
+    int64_t t_end;          /* one past the last interval; t_begin = t_end = 0 means [0, T-1) */
+} qc_desc;
+
+typedef struct qc_dims_t {
+    int64_t n_rows;          /* ddim*(T-1): rows of dF, length of F and mu (whole problem) */
+    int64_t n_cols;          /* zdim*T + global_dim */
+    int64_t ddim;            /* dynamics rows per interval */
+    int64_t jac_nnz_interval;
+    int64_t hess_nnz_interval;
+    int64_t n_intervals;     /* t_end - t_begin, intervals this handle owns */
+    int64_t F_len;           /* ddim * n_intervals          (this handle's slice) */
+    int64_t jac_nnz;         /* jac_nnz_interval * n_intervals */
+    int64_t hess_nnz;        /* hess_nnz_interval * n_intervals (0 if no analytic Hessian) */
+    int64_t Z_len;           /* zdim*T + global_dim: length of the Z argument (always the full vector) */
+    int32_t kernel;          /* QC_KERNEL_LDS or QC_KERNEL_MFMA actually selected */
+    int32_t reserved;
+} qc_dims_t;
+
+/* ---- host-side helpers (no GPU needed) ------------------------------------------------------ */
+
+/* U (N x N complex, column-major, split re/im planes) -> iso-vec of length 2N^2:
+ * vec(vcat(real(U), imag(U)))  (reference trajectory_initialization.jl:137). */
+int qc_operator_to_iso_vec(int32_t N, const double* U_re, const double* U_im, double* iso_vec);
+int qc_iso_vec_to_operator(int32_t N, const double* iso_vec, double* U_re, double* U_im);
+
+/* H (N x N complex Hermitian, column-major re/im planes) -> G = iso(-iH) = [[Im H, Re H],[-Re H, Im H]]
+ * (2N x 2N, column-major), i.e. QuantumSystem's G_drift / G_drives entries. */
+int qc_generator_from_hamiltonian(int32_t N, const double* H_re, const double* H_im, double* G);
+
+/* Pade coefficients c_0..c_p (p = order/2) of the diagonal approximant. out has p+1 entries. */
+int qc_pade_coefficients(int32_t order, double* out);
+
+/* Sizes implied by a descriptor, without touching a GPU (G pointers may be NULL). */
+int qc_desc_dims(const qc_desc* d, qc_dims_t* out);
+/* Sparsity structure implied by a descriptor, without touching a GPU.  Global COO indices of this
+ * handle's slice, knot-major, in the exact order of the value vectors.  one_based != 0 gives Julia
+ * indices.  rows/cols must hold jac_nnz (resp. hess_nnz) entries.  The Hessian structure is
+ * upper-triangular (row <= col). */
+int qc_desc_jac_structure(const qc_desc* d, int64_t* rows, int64_t* cols, int one_based);
+int qc_desc_hess_structure(const qc_desc* d, int64_t* rows, int64_t* cols, int one_based);
+
+/* ---- handle ----------------------------------------------------------------------------------- */
+
+int qc_create(const qc_desc* d, qc_handle** out);
+void qc_destroy(qc_handle* h);
+/* Message of the last error on this handle (or, with h == NULL, of the last handle-less call on
+ * this thread).  Never NULL. */
+const char* qc_last_error(const qc_handle* h);
+
+int qc_dims(const qc_handle* h, qc_dims_t* out);
+int qc_jac_structure(const qc_handle* h, int64_t* rows, int64_t* cols, int one_based);
+int qc_hess_structure(const qc_handle* h, int64_t* rows, int64_t* cols, int one_based);
+
+/* ---- evaluation, host buffers (what Ipopt's callbacks hand over) ------------------------------ */
+/* Z: full trajectory vector (Z_len doubles).  F: F_len.  vals: jac_nnz.  mu: the FULL multiplier
+ * vector of length n_rows (as MOI passes it); hvals: hess_nnz. */
+int qc_eval_F(qc_handle* h, const double* Z, double* F);
+int qc_eval_jac(qc_handle* h, const double* Z, double* vals);
+int qc_eval_F_jac(qc_handle* h, const double* Z, double* F, double* vals);
+int qc_eval_hess(qc_handle* h, const double* Z, const double* mu, double* hvals);
+
+/* ---- evaluation, device-resident (asynchronous on `stream`, a hipStream_t) --------------------- */
+/* dZ: device pointer to the full Z vector (8-byte aligned).  dF may be NULL (skip residual store);
+ * dvals may be NULL (residual only).  dF/dvals/dhvals point at THIS HANDLE'S slice
+ * (interval t_begin first) and must be 16-byte aligned. */
+int qc_eval_F_jac_dev(qc_handle* h, const double* dZ, double* dF, double* dvals, void* stream);
+int qc_eval_hess_dev(qc_handle* h, const double* dZ, const double* dmu, double* dhvals, void* stream);
+
+/* Library/build identification: "qcolloc-hip 0.1 gfx950 ..." */
+const char* qc_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QCOLLOC_H */

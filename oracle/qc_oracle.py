@@ -1,0 +1,484 @@
+"""CPU ORACLE (test infrastructure, NOT product code) for the knot-point dynamics evaluator.
+
+PARITY UNPINNED.  The arithmetic of this path lives in the un-vendored Julia dependency
+QuantumCollocationCore 0.3 (reference `Project.toml:31`), which is absent from `/root/reference`
+and cannot be run here (no Julia).  The reference's own tests pin no number on this path
+(`SURVEY.md` §8c).  This file therefore restates the *published mathematics* of the path:
+
+* NLP statement / integrator roles ........ reference `src/problem_templates/unitary_smooth_pulse_problem.jl:10-30`
+* Schroedinger step, exponential form ..... reference `README.md:74-80`
+* iso-vec layout vec([Re U; Im U]) ........ reference `src/trajectory_initialization.jl:137`
+* knot component order [U, a, da, dda, dt]  reference `src/trajectory_initialization.jl:357-382`
+* integrator (row) order .................. reference `src/problem_templates/unitary_smooth_pulse_problem.jl:175-179`
+* shapes of F / dF / mu_d2F ............... reference `test/scripts/integrator_test_1qubit.jl:41-52`
+* COO accumulate convention ............... reference `test/test_utils.jl:14-27`
+
+and is pinned against mathematics instead (tests/test_oracle_math.py): complex-step and
+finite-difference derivatives, scipy `expm`, mpmath 50-digit spot checks, Pade order-of-accuracy.
+
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s cpu_baseline leg may import this module.
+
+Everything here is written for clarity, with dense per-interval blocks and explicit Kronecker
+products (the way the reference builds them per knot), not for speed.  All indices are 0-based;
+`structure(..., one_based=True)` converts for the Julia convention.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import List, Sequence, Tuple
+
+import numpy as np
+
+PADE = 0
+EXPONENTIAL = 1
+
+
+# --------------------------------------------------------------------------------------------
+#  Isomorphism (reference trajectory_initialization.jl:137)
+# --------------------------------------------------------------------------------------------
+def operator_to_iso_vec(U: np.ndarray) -> np.ndarray:
+    """vec(vcat(real(U), imag(U))), column-major."""
+    U = np.asarray(U, dtype=complex)
+    return np.vstack([U.real, U.imag]).reshape(-1, order="F").copy()
+
+
+def iso_vec_to_operator(v: np.ndarray) -> np.ndarray:
+    v = np.asarray(v, dtype=float)
+    N = int(round(math.sqrt(v.size / 2)))
+    M = v.reshape(2 * N, N, order="F")
+    return M[:N] + 1j * M[N:]
+
+
+def generator(H: np.ndarray) -> np.ndarray:
+    """G = iso(-iH) = [[Im H, Re H], [-Re H, Im H]]: d/dt [Re U; Im U] = G [Re U; Im U]."""
+    H = np.asarray(H, dtype=complex)
+    return np.block([[H.imag, H.real], [-H.real, H.imag]])
+
+
+# --------------------------------------------------------------------------------------------
+#  Problem description (mirrors the fields of the C descriptor `qc_desc`)
+# --------------------------------------------------------------------------------------------
+@dataclass
+class DerivSpec:
+    """DerivativeIntegrator(x, dx, traj): x_{t+1} - x_t - dt * dx_t = 0
+    (reference unitary_smooth_pulse_problem.jl:15-16,177-178)."""
+    x_off: int
+    dx_off: int
+    dim: int
+
+
+@dataclass
+class Problem:
+    N: int
+    m: int
+    T: int
+    zdim: int
+    off_U: int
+    off_a: int
+    off_dt: int                  # -1 => fixed timestep
+    G_drift: np.ndarray          # (n, n)
+    G_drives: np.ndarray         # (m, n, n)
+    dt_fixed: float = 0.0
+    integrator: int = PADE
+    order: int = 4
+    derivs: List[DerivSpec] = field(default_factory=list)
+    global_dim: int = 0
+
+    @property
+    def n(self) -> int:
+        return 2 * self.N
+
+    @property
+    def s(self) -> int:
+        return 2 * self.N * self.N
+
+    @property
+    def free_time(self) -> bool:
+        return self.off_dt >= 0
+
+    @property
+    def ddim(self) -> int:
+        return self.s + sum(d.dim for d in self.derivs)
+
+    @property
+    def n_vars(self) -> int:
+        return self.zdim * self.T + self.global_dim
+
+    @property
+    def n_rows(self) -> int:
+        return self.ddim * (self.T - 1)
+
+
+def pade_coeffs(order: int) -> List[float]:
+    """Diagonal (p,p) Pade coefficients c_0..c_p of exp, order 2p."""
+    if order % 2 or order < 2:
+        raise ValueError("Pade order must be even and >= 2")
+    p = order // 2
+    f = math.factorial
+    return [f(2 * p - k) * f(p) / (f(2 * p) * f(k) * f(p - k)) for k in range(p + 1)]
+
+
+def _G_of(prob: Problem, a: np.ndarray) -> np.ndarray:
+    return prob.G_drift + np.tensordot(a, prob.G_drives, axes=(0, 0))
+
+
+def _split(prob: Problem, z0: np.ndarray, z1: np.ndarray):
+    n, N = prob.n, prob.N
+    U0 = z0[prob.off_U:prob.off_U + prob.s].reshape(n, N, order="F")
+    U1 = z1[prob.off_U:prob.off_U + prob.s].reshape(n, N, order="F")
+    a = z0[prob.off_a:prob.off_a + prob.m]
+    h = z0[prob.off_dt] if prob.free_time else prob.dt_fixed
+    return U0, U1, a, h
+
+
+def _vec(X: np.ndarray) -> np.ndarray:
+    return X.reshape(-1, order="F")
+
+
+# --------------------------------------------------------------------------------------------
+#  Matrix exponential + Frechet derivative (for the exponential integrator), self-contained:
+#  scaled Taylor + squaring on the block-triangular augmented matrix.
+# --------------------------------------------------------------------------------------------
+def expm_taylor(X: np.ndarray) -> np.ndarray:
+    nrm = np.linalg.norm(X, 1)
+    sq = 0 if nrm <= 0.25 else max(0, int(math.ceil(math.log2(nrm / 0.25))))
+    Y = X / (2.0 ** sq)
+    E = np.eye(X.shape[0], dtype=X.dtype)
+    term = np.eye(X.shape[0], dtype=X.dtype)
+    for k in range(1, 25):
+        term = term @ Y / k
+        E = E + term
+    for _ in range(sq):
+        E = E @ E
+    return E
+
+
+def expm_frechet_block(X: np.ndarray, E: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """(exp(X), L_exp(X; E)) via exp([[X, E], [0, X]]) top-right block."""
+    k = X.shape[0]
+    A = np.zeros((2 * k, 2 * k), dtype=np.result_type(X, E))
+    A[:k, :k] = X
+    A[k:, k:] = X
+    A[:k, k:] = E
+    EA = expm_taylor(A)
+    return EA[:k, :k], EA[:k, k:]
+
+
+# --------------------------------------------------------------------------------------------
+#  Per-interval residual
+# --------------------------------------------------------------------------------------------
+def interval_residual(prob: Problem, z0: np.ndarray, z1: np.ndarray) -> np.ndarray:
+    """delta_t(z_t, z_{t+1}) in R^ddim: unitary rows first, then each derivative integrator."""
+    U0, U1, a, h = _split(prob, z0, z1)
+    G = _G_of(prob, a)
+    out = np.zeros(prob.ddim, dtype=np.result_type(z0, z1, float))
+    if prob.integrator == PADE:
+        c = pade_coeffs(prob.order)
+        B = sum(((-1) ** k) * c[k] * h ** k * np.linalg.matrix_power(G, k) for k in range(len(c)))
+        F = sum(c[k] * h ** k * np.linalg.matrix_power(G, k) for k in range(len(c)))
+        # explicit Kronecker form, as the reference forms it per knot: (I_N (x) B) U1vec - (I_N (x) F) U0vec
+        IN = np.eye(prob.N)
+        out[:prob.s] = np.kron(IN, B) @ _vec(U1) - np.kron(IN, F) @ _vec(U0)
+    else:
+        E = expm_taylor(h * G)
+        out[:prob.s] = _vec(U1) - np.kron(np.eye(prob.N), E) @ _vec(U0)
+    r = prob.s
+    for d in prob.derivs:
+        x0 = z0[d.x_off:d.x_off + d.dim]
+        x1 = z1[d.x_off:d.x_off + d.dim]
+        dx0 = z0[d.dx_off:d.dx_off + d.dim]
+        out[r:r + d.dim] = x1 - x0 - h * dx0
+        r += d.dim
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+#  Per-interval dense Jacobian (ddim x 2*zdim), columns [z_t | z_{t+1}]
+# --------------------------------------------------------------------------------------------
+def _dGpow(G: np.ndarray, Gj: np.ndarray, k: int) -> np.ndarray:
+    """d(G^k)[Gj] = sum_{i=0}^{k-1} G^i Gj G^{k-1-i}."""
+    mp = np.linalg.matrix_power
+    return sum(mp(G, i) @ Gj @ mp(G, k - 1 - i) for i in range(k)) if k > 0 else np.zeros_like(G)
+
+
+def _d2Gpow(G: np.ndarray, Gi: np.ndarray, Gj: np.ndarray, k: int) -> np.ndarray:
+    """d^2(G^k)[Gi, Gj] = sum over ordered insertions of Gi and Gj (both orders)."""
+    mp = np.linalg.matrix_power
+    out = np.zeros_like(G)
+    for al in range(k - 1):
+        for be in range(k - 1 - al):
+            ga = k - 2 - al - be
+            out = out + mp(G, al) @ Gi @ mp(G, be) @ Gj @ mp(G, ga)
+            out = out + mp(G, al) @ Gj @ mp(G, be) @ Gi @ mp(G, ga)
+    return out
+
+
+def interval_jacobian_dense(prob: Problem, z0: np.ndarray, z1: np.ndarray) -> np.ndarray:
+    U0, U1, a, h = _split(prob, z0, z1)
+    G = _G_of(prob, a)
+    n, N, s, m, zd = prob.n, prob.N, prob.s, prob.m, prob.zdim
+    J = np.zeros((prob.ddim, 2 * zd), dtype=np.result_type(z0, z1, float))
+    IN = np.eye(N)
+    mp = np.linalg.matrix_power
+    if prob.integrator == PADE:
+        c = pade_coeffs(prob.order)
+        p = len(c) - 1
+        B = sum(((-1) ** k) * c[k] * h ** k * mp(G, k) for k in range(p + 1))
+        F = sum(c[k] * h ** k * mp(G, k) for k in range(p + 1))
+        J[:s, prob.off_U:prob.off_U + s] = -np.kron(IN, F)
+        J[:s, zd + prob.off_U:zd + prob.off_U + s] = np.kron(IN, B)
+        for j in range(m):
+            dB = sum(((-1) ** k) * c[k] * h ** k * _dGpow(G, prob.G_drives[j], k) for k in range(1, p + 1))
+            dF = sum(c[k] * h ** k * _dGpow(G, prob.G_drives[j], k) for k in range(1, p + 1))
+            J[:s, prob.off_a + j] = _vec(dB @ U1 - dF @ U0)
+        if prob.free_time:
+            dB = sum(((-1) ** k) * c[k] * k * h ** (k - 1) * mp(G, k) for k in range(1, p + 1))
+            dF = sum(c[k] * k * h ** (k - 1) * mp(G, k) for k in range(1, p + 1))
+            J[:s, prob.off_dt] = _vec(dB @ U1 - dF @ U0)
+    else:
+        E = expm_taylor(h * G)
+        J[:s, prob.off_U:prob.off_U + s] = -np.kron(IN, E)
+        J[:s, zd + prob.off_U:zd + prob.off_U + s] = np.eye(s)
+        for j in range(m):
+            _, L = expm_frechet_block(h * G, h * prob.G_drives[j])
+            J[:s, prob.off_a + j] = -_vec(L @ U0)
+        if prob.free_time:
+            J[:s, prob.off_dt] = -_vec(G @ E @ U0)
+    r = s
+    for d in prob.derivs:
+        dx0 = z0[d.dx_off:d.dx_off + d.dim]
+        for i in range(d.dim):
+            J[r + i, d.x_off + i] += -1.0
+            J[r + i, zd + d.x_off + i] += 1.0
+            J[r + i, d.dx_off + i] += -h
+            if prob.free_time:
+                J[r + i, prob.off_dt] += -dx0[i]
+        r += d.dim
+    return J
+
+
+# --------------------------------------------------------------------------------------------
+#  Per-interval dense Hessian of mu^T delta (2*zdim x 2*zdim, full symmetric)
+# --------------------------------------------------------------------------------------------
+def interval_hessian_dense(prob: Problem, z0: np.ndarray, z1: np.ndarray, mu: np.ndarray) -> np.ndarray:
+    if prob.integrator != PADE:
+        raise NotImplementedError("analytic Hessian only for the Pade integrator (SURVEY A.6)")
+    U0, U1, a, h = _split(prob, z0, z1)
+    G = _G_of(prob, a)
+    n, N, s, m, zd = prob.n, prob.N, prob.s, prob.m, prob.zdim
+    M = mu[:s].reshape(n, N, order="F")
+    c = pade_coeffs(prob.order)
+    p = len(c) - 1
+    mp = np.linalg.matrix_power
+    Hs = np.zeros((2 * zd, 2 * zd))
+    Gd = prob.G_drives
+
+    def sym_set(i, j, v):
+        Hs[i, j] += v
+        if i != j:
+            Hs[j, i] += v
+
+    iU0 = prob.off_U
+    iU1 = zd + prob.off_U
+    # (a_i, a_j)
+    for i in range(m):
+        for j in range(i, m):
+            d2B = sum(((-1) ** k) * c[k] * h ** k * _d2Gpow(G, Gd[i], Gd[j], k) for k in range(2, p + 1))
+            d2F = sum(c[k] * h ** k * _d2Gpow(G, Gd[i], Gd[j], k) for k in range(2, p + 1))
+            v = np.sum(M * (d2B @ U1 - d2F @ U0)) if p >= 2 else 0.0
+            sym_set(prob.off_a + i, prob.off_a + j, v)
+    # (U, a_j)
+    for j in range(m):
+        dB = sum(((-1) ** k) * c[k] * h ** k * _dGpow(G, Gd[j], k) for k in range(1, p + 1))
+        dF = sum(c[k] * h ** k * _dGpow(G, Gd[j], k) for k in range(1, p + 1))
+        vB = _vec(dB.T @ M)
+        vF = -_vec(dF.T @ M)
+        for i in range(s):
+            sym_set(iU1 + i, prob.off_a + j, vB[i])
+            sym_set(iU0 + i, prob.off_a + j, vF[i])
+    if prob.free_time:
+        ih = prob.off_dt
+        # (a_j, h)
+        for j in range(m):
+            dB = sum(((-1) ** k) * c[k] * k * h ** (k - 1) * _dGpow(G, Gd[j], k) for k in range(1, p + 1))
+            dF = sum(c[k] * k * h ** (k - 1) * _dGpow(G, Gd[j], k) for k in range(1, p + 1))
+            sym_set(prob.off_a + j, ih, np.sum(M * (dB @ U1 - dF @ U0)))
+        # (h, h)
+        d2B = sum(((-1) ** k) * c[k] * k * (k - 1) * h ** (k - 2) * mp(G, k) for k in range(2, p + 1))
+        d2F = sum(c[k] * k * (k - 1) * h ** (k - 2) * mp(G, k) for k in range(2, p + 1))
+        if p >= 2:
+            sym_set(ih, ih, np.sum(M * (d2B @ U1 - d2F @ U0)))
+        # (U, h)
+        dB = sum(((-1) ** k) * c[k] * k * h ** (k - 1) * mp(G, k) for k in range(1, p + 1))
+        dF = sum(c[k] * k * h ** (k - 1) * mp(G, k) for k in range(1, p + 1))
+        vB = _vec(dB.T @ M)
+        vF = -_vec(dF.T @ M)
+        for i in range(s):
+            sym_set(iU1 + i, ih, vB[i])
+            sym_set(iU0 + i, ih, vF[i])
+        # derivative integrators: d2/d(dx_i) dh = -mu_i
+        r = s
+        for d in prob.derivs:
+            for i in range(d.dim):
+                sym_set(d.dx_off + i, ih, -mu[r + i])
+            r += d.dim
+    return Hs
+
+
+# --------------------------------------------------------------------------------------------
+#  Canonical per-interval sparsity structure.  Local coordinates:
+#  rows 0..ddim-1, cols 0..2*zdim-1 (col >= zdim  <=>  knot t+1).
+# --------------------------------------------------------------------------------------------
+def jac_structure_local(prob: Problem) -> List[Tuple[int, int]]:
+    n, N, s, m, zd = prob.n, prob.N, prob.s, prob.m, prob.zdim
+    st: List[Tuple[int, int]] = []
+    # 1. d/dU_t = -(I_N (x) F): N dense n x n diagonal blocks, column-major inside each block
+    for q in range(N):
+        for cc in range(n):
+            for rr in range(n):
+                st.append((q * n + rr, prob.off_U + q * n + cc))
+    # 2. d/dU_{t+1} = I_N (x) B   (exponential integrator: identity, s diagonal entries)
+    if prob.integrator == PADE:
+        for q in range(N):
+            for cc in range(n):
+                for rr in range(n):
+                    st.append((q * n + rr, zd + prob.off_U + q * n + cc))
+    else:
+        for i in range(s):
+            st.append((i, zd + prob.off_U + i))
+    # 3. d/da_j: dense s x m, column-major
+    for j in range(m):
+        for i in range(s):
+            st.append((i, prob.off_a + j))
+    # 4. d/ddt: dense s x 1
+    if prob.free_time:
+        for i in range(s):
+            st.append((i, prob.off_dt))
+    # 5. derivative integrators
+    r = s
+    for d in prob.derivs:
+        for i in range(d.dim):
+            st.append((r + i, d.x_off + i))
+        for i in range(d.dim):
+            st.append((r + i, zd + d.x_off + i))
+        for i in range(d.dim):
+            st.append((r + i, d.dx_off + i))
+        if prob.free_time:
+            for i in range(d.dim):
+                st.append((r + i, prob.off_dt))
+        r += d.dim
+    return st
+
+
+def hess_structure_local(prob: Problem) -> List[Tuple[int, int]]:
+    """Upper-triangular (row <= col) local pairs over [z_t ; z_{t+1}] (size 2*zdim)."""
+    if prob.integrator != PADE:
+        return []
+    s, m, zd = prob.s, prob.m, prob.zdim
+    st: List[Tuple[int, int]] = []
+
+    def up(i, j):
+        st.append((min(i, j), max(i, j)))
+
+    for j in range(m):                       # 1. (U_t, a_j)
+        for i in range(s):
+            up(prob.off_U + i, prob.off_a + j)
+    for j in range(m):                       # 2. (a_j, U_{t+1})
+        for i in range(s):
+            up(prob.off_a + j, zd + prob.off_U + i)
+    for j in range(m):                       # 3. (a_i, a_j), i <= j
+        for i in range(j + 1):
+            up(prob.off_a + i, prob.off_a + j)
+    if prob.free_time:
+        for j in range(m):                   # 4. (a_j, h)
+            up(prob.off_a + j, prob.off_dt)
+        for i in range(s):                   # 5. (U_t, h)
+            up(prob.off_U + i, prob.off_dt)
+        for i in range(s):                   # 6. (h, U_{t+1})
+            up(prob.off_dt, zd + prob.off_U + i)
+        up(prob.off_dt, prob.off_dt)         # 7. (h, h)
+        for d in prob.derivs:                # 8. (dx_i, h)
+            for i in range(d.dim):
+                up(d.dx_off + i, prob.off_dt)
+    return st
+
+
+def jac_nnz_interval(prob: Problem) -> int:
+    return len(jac_structure_local(prob))
+
+
+def hess_nnz_interval(prob: Problem) -> int:
+    return len(hess_structure_local(prob))
+
+
+def jac_structure(prob: Problem, one_based: bool = False, t_begin: int = 0, t_end: int | None = None):
+    """Global COO (rows, cols) of dF, knot-major; row = t*ddim + r, col = t*zdim + c."""
+    loc = np.array(jac_structure_local(prob), dtype=np.int64).reshape(-1, 2)
+    t_end = prob.T - 1 if t_end is None else t_end
+    ts = np.arange(t_begin, t_end, dtype=np.int64)
+    rows = (ts[:, None] * prob.ddim + loc[None, :, 0]).reshape(-1)
+    cols = (ts[:, None] * prob.zdim + loc[None, :, 1]).reshape(-1)
+    o = 1 if one_based else 0
+    return rows + o, cols + o
+
+
+def hess_structure(prob: Problem, one_based: bool = False, t_begin: int = 0, t_end: int | None = None):
+    loc = np.array(hess_structure_local(prob), dtype=np.int64).reshape(-1, 2)
+    t_end = prob.T - 1 if t_end is None else t_end
+    ts = np.arange(t_begin, t_end, dtype=np.int64)
+    rows = (ts[:, None] * prob.zdim + loc[None, :, 0]).reshape(-1)
+    cols = (ts[:, None] * prob.zdim + loc[None, :, 1]).reshape(-1)
+    o = 1 if one_based else 0
+    return rows + o, cols + o
+
+
+# --------------------------------------------------------------------------------------------
+#  Full-trajectory evaluators (the three closures of QuantumDynamics; reference
+#  test/scripts/integrator_test_1qubit.jl:41-52)
+# --------------------------------------------------------------------------------------------
+def _knots(prob: Problem, Z: np.ndarray, t: int):
+    zd = prob.zdim
+    return Z[t * zd:(t + 1) * zd], Z[(t + 1) * zd:(t + 2) * zd]
+
+
+def F(prob: Problem, Z: np.ndarray, t_begin: int = 0, t_end: int | None = None) -> np.ndarray:
+    t_end = prob.T - 1 if t_end is None else t_end
+    out = np.empty((t_end - t_begin) * prob.ddim)
+    for k, t in enumerate(range(t_begin, t_end)):
+        z0, z1 = _knots(prob, Z, t)
+        out[k * prob.ddim:(k + 1) * prob.ddim] = interval_residual(prob, z0, z1)
+    return out
+
+
+def dF(prob: Problem, Z: np.ndarray, t_begin: int = 0, t_end: int | None = None) -> np.ndarray:
+    t_end = prob.T - 1 if t_end is None else t_end
+    loc = np.array(jac_structure_local(prob), dtype=np.int64).reshape(-1, 2)
+    nnz = loc.shape[0]
+    out = np.empty((t_end - t_begin) * nnz)
+    for k, t in enumerate(range(t_begin, t_end)):
+        z0, z1 = _knots(prob, Z, t)
+        J = interval_jacobian_dense(prob, z0, z1)
+        out[k * nnz:(k + 1) * nnz] = J[loc[:, 0], loc[:, 1]]
+    return out
+
+
+def mu_d2F(prob: Problem, Z: np.ndarray, mu: np.ndarray, t_begin: int = 0, t_end: int | None = None) -> np.ndarray:
+    t_end = prob.T - 1 if t_end is None else t_end
+    loc = np.array(hess_structure_local(prob), dtype=np.int64).reshape(-1, 2)
+    nnz = loc.shape[0]
+    out = np.empty((t_end - t_begin) * nnz)
+    for k, t in enumerate(range(t_begin, t_end)):
+        z0, z1 = _knots(prob, Z, t)
+        Hd = interval_hessian_dense(prob, z0, z1, mu[t * prob.ddim:(t + 1) * prob.ddim])
+        out[k * nnz:(k + 1) * nnz] = Hd[loc[:, 0], loc[:, 1]]
+    return out
+
+
+def dense_from_coo(vals: np.ndarray, rows: np.ndarray, cols: np.ndarray, shape, symmetric=False) -> np.ndarray:
+    """`dense(vals, structure, shape)` of reference test/test_utils.jl:14-27 (0-based here)."""
+    Mx = np.zeros(shape)
+    np.add.at(Mx, (rows, cols), vals)
+    if symmetric:
+        Mx = np.triu(Mx) + np.triu(Mx, 1).T
+    return Mx

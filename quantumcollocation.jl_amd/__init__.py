@@ -1,0 +1,24 @@
+"""MI355X-native knot-point evaluator for QuantumCollocation.jl's direct-collocation NLP.
+
+Host-side mirror of the reference interface for the hot path over the C ABI
+of include/qcolloc.h.  The directory name carries a dot, so load it through
+`__graft_entry__.load_package()` (registers it as module `qcolloc_amd`).
+"""
+from . import _lib
+from ._lib import QCollocError
+from .dynamics import QuantumDynamics, desc_dims, desc_structures, make_desc
+from .gates import GATES, PAULIS, operator_from_string
+from .integrators import DerivativeIntegrator, UnitaryExponentialIntegrator, UnitaryPadeIntegrator
+from .isomorphisms import iso_generator, iso_vec_to_operator, operator_to_iso_vec, pade_coefficients
+from .named_trajectory import NamedTrajectory
+from .problems import CONFIGS, config_inputs, multi_qubit_system, unitary_smooth_pulse_inputs
+from .quantum_systems import QuantumSystem
+from .trajectory_initialization import initialize_trajectory, unitary_geodesic
+
+__all__ = [
+    "QuantumDynamics", "QuantumSystem", "NamedTrajectory", "UnitaryPadeIntegrator",
+    "UnitaryExponentialIntegrator", "DerivativeIntegrator", "operator_to_iso_vec", "iso_vec_to_operator",
+    "iso_generator", "pade_coefficients", "GATES", "PAULIS", "operator_from_string", "config_inputs",
+    "unitary_smooth_pulse_inputs", "multi_qubit_system", "CONFIGS", "initialize_trajectory",
+    "unitary_geodesic", "make_desc", "desc_dims", "desc_structures", "QCollocError",
+]

@@ -1,0 +1,149 @@
+"""ctypes binding of include/qcolloc.h (libqcolloc_hip.so).
+
+This is the only way the Python host layer reaches the evaluator; there is no Python/CPU
+implementation of the path behind it.  If the shared library has not been built the import fails
+loudly (run `python -c "import __graft_entry__ as g; g.build()"` or `make -C
+quantumcollocation.jl_amd/csrc`).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+# torch bundles its own libamdhip64.so (SONAME libamdhip64.so.7).  Import it FIRST so that our
+# library's NEEDED libamdhip64.so.7 resolves to the runtime already in the process; two HIP runtimes
+# in one process cannot share device pointers or streams.
+import torch  # noqa: F401  (device memory, streams, torch.distributed: plumbing only)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libqcolloc_hip.so")
+
+QC_OK = 0
+QC_ERR_INVALID = -1
+QC_ERR_NO_DEVICE = -2
+QC_ERR_HIP = -3
+QC_ERR_UNSUPPORTED = -4
+QC_PADE = 0
+QC_EXPONENTIAL = 1
+QC_KERNEL_AUTO = 0
+QC_KERNEL_LDS = 1
+QC_KERNEL_MFMA = 2
+QC_MAX_DERIV = 8
+
+_c_double_p = C.POINTER(C.c_double)
+_c_int64_p = C.POINTER(C.c_int64)
+
+
+class qc_desc(C.Structure):
+    _fields_ = [
+        ("N", C.c_int32),
+        ("m", C.c_int32),
+        ("T", C.c_int64),
+        ("zdim", C.c_int32),
+        ("global_dim", C.c_int64),
+        ("off_U", C.c_int32),
+        ("off_a", C.c_int32),
+        ("off_dt", C.c_int32),
+        ("dt_fixed", C.c_double),
+        ("integrator", C.c_int32),
+        ("pade_order", C.c_int32),
+        ("n_deriv", C.c_int32),
+        ("deriv_x_off", C.c_int32 * QC_MAX_DERIV),
+        ("deriv_dx_off", C.c_int32 * QC_MAX_DERIV),
+        ("deriv_dim", C.c_int32 * QC_MAX_DERIV),
+        ("G_drift", _c_double_p),
+        ("G_drives", _c_double_p),
+        ("device", C.c_int32),
+        ("kernel", C.c_int32),
+        ("t_begin", C.c_int64),
+        ("t_end", C.c_int64),
+    ]
+
+
+class qc_dims_t(C.Structure):
+    _fields_ = [
+        ("n_rows", C.c_int64),
+        ("n_cols", C.c_int64),
+        ("ddim", C.c_int64),
+        ("jac_nnz_interval", C.c_int64),
+        ("hess_nnz_interval", C.c_int64),
+        ("n_intervals", C.c_int64),
+        ("F_len", C.c_int64),
+        ("jac_nnz", C.c_int64),
+        ("hess_nnz", C.c_int64),
+        ("Z_len", C.c_int64),
+        ("kernel", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+# Every symbol include/qcolloc.h declares: (name, restype, argtypes).  tests/test_abi.py checks this
+# table against the header and against the built library.
+_DESC_P = C.POINTER(qc_desc)
+_DIMS_P = C.POINTER(qc_dims_t)
+_H = C.c_void_p
+SYMBOLS = {
+    "qc_operator_to_iso_vec": (C.c_int, [C.c_int32, _c_double_p, _c_double_p, _c_double_p]),
+    "qc_iso_vec_to_operator": (C.c_int, [C.c_int32, _c_double_p, _c_double_p, _c_double_p]),
+    "qc_generator_from_hamiltonian": (C.c_int, [C.c_int32, _c_double_p, _c_double_p, _c_double_p]),
+    "qc_pade_coefficients": (C.c_int, [C.c_int32, _c_double_p]),
+    "qc_desc_dims": (C.c_int, [_DESC_P, _DIMS_P]),
+    "qc_desc_jac_structure": (C.c_int, [_DESC_P, _c_int64_p, _c_int64_p, C.c_int]),
+    "qc_desc_hess_structure": (C.c_int, [_DESC_P, _c_int64_p, _c_int64_p, C.c_int]),
+    "qc_create": (C.c_int, [_DESC_P, C.POINTER(_H)]),
+    "qc_destroy": (None, [_H]),
+    "qc_last_error": (C.c_char_p, [_H]),
+    "qc_dims": (C.c_int, [_H, _DIMS_P]),
+    "qc_jac_structure": (C.c_int, [_H, _c_int64_p, _c_int64_p, C.c_int]),
+    "qc_hess_structure": (C.c_int, [_H, _c_int64_p, _c_int64_p, C.c_int]),
+    "qc_eval_F": (C.c_int, [_H, _c_double_p, _c_double_p]),
+    "qc_eval_jac": (C.c_int, [_H, _c_double_p, _c_double_p]),
+    "qc_eval_F_jac": (C.c_int, [_H, _c_double_p, _c_double_p, _c_double_p]),
+    "qc_eval_hess": (C.c_int, [_H, _c_double_p, _c_double_p, _c_double_p]),
+    "qc_eval_F_jac_dev": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "qc_eval_hess_dev": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "qc_version": (C.c_char_p, []),
+}
+
+
+class QCollocError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libqcolloc_hip error {code}: {msg}")
+        self.code = code
+
+
+def _load() -> C.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built. "
+            "Run `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). "
+            "There is no CPU fallback for this path."
+        )
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def check(rc: int, handle=None) -> None:
+    if rc != QC_OK:
+        msg = lib.qc_last_error(handle)
+        raise QCollocError(rc, msg.decode() if msg else "unknown error")
+
+
+def dptr(a: np.ndarray):
+    """double* of a C- or F-contiguous float64 numpy array (no copy)."""
+    assert a.dtype == np.float64 and (a.flags.c_contiguous or a.flags.f_contiguous)
+    return a.ctypes.data_as(_c_double_p)
+
+
+def iptr(a: np.ndarray):
+    assert a.dtype == np.int64 and a.flags.c_contiguous
+    return a.ctypes.data_as(_c_int64_p)

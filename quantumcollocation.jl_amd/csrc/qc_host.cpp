@@ -1,0 +1,486 @@
+// Host side of libqcolloc_hip.so: descriptor validation, value-block layout, sparsity structure,
+// handle lifetime, host-buffer staging.  The arithmetic of the path lives in the .hip kernels; there
+// is deliberately no CPU evaluation path in this library.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "qc_internal.h"
+
+static thread_local std::string g_err;
+
+static int fail(std::string* err, int code, const std::string& msg) {
+    if (err) *err = msg;
+    g_err = msg;
+    return code;
+}
+
+#define QC_HIP(h, call)                                                                          \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess) {                                                                  \
+            return fail(&(h)->err, QC_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+        }                                                                                        \
+    } while (0)
+
+extern "C" const char* qc_version(void) { return "qcolloc-hip 0.1 (gfx950, fp64)"; }
+
+extern "C" const char* qc_last_error(const qc_handle* h) { return h ? h->err.c_str() : g_err.c_str(); }
+
+// ------------------------------------------------------------------------------------------------
+//  Isomorphism helpers (reference trajectory_initialization.jl:137)
+// ------------------------------------------------------------------------------------------------
+extern "C" int qc_operator_to_iso_vec(int32_t N, const double* U_re, const double* U_im, double* v) {
+    if (N <= 0 || !U_re || !U_im || !v) return fail(nullptr, QC_ERR_INVALID, "qc_operator_to_iso_vec: bad argument");
+    for (int j = 0; j < N; ++j)
+        for (int i = 0; i < N; ++i) {
+            v[j * 2 * N + i] = U_re[j * N + i];
+            v[j * 2 * N + N + i] = U_im[j * N + i];
+        }
+    return QC_OK;
+}
+
+extern "C" int qc_iso_vec_to_operator(int32_t N, const double* v, double* U_re, double* U_im) {
+    if (N <= 0 || !U_re || !U_im || !v) return fail(nullptr, QC_ERR_INVALID, "qc_iso_vec_to_operator: bad argument");
+    for (int j = 0; j < N; ++j)
+        for (int i = 0; i < N; ++i) {
+            U_re[j * N + i] = v[j * 2 * N + i];
+            U_im[j * N + i] = v[j * 2 * N + N + i];
+        }
+    return QC_OK;
+}
+
+extern "C" int qc_generator_from_hamiltonian(int32_t N, const double* H_re, const double* H_im, double* G) {
+    if (N <= 0 || !H_re || !H_im || !G) return fail(nullptr, QC_ERR_INVALID, "qc_generator_from_hamiltonian: bad argument");
+    const int n = 2 * N;
+    for (int j = 0; j < N; ++j)
+        for (int i = 0; i < N; ++i) {
+            const double re = H_re[j * N + i], im = H_im[j * N + i];
+            G[j * n + i] = im;             // top-left     Im H
+            G[(j + N) * n + i] = re;       // top-right    Re H
+            G[j * n + N + i] = -re;        // bottom-left -Re H
+            G[(j + N) * n + N + i] = im;   // bottom-right Im H
+        }
+    return QC_OK;
+}
+
+extern "C" int qc_pade_coefficients(int32_t order, double* out) {
+    if (order < 2 || (order & 1) || order / 2 > QC_MAX_P || !out)
+        return fail(nullptr, QC_ERR_INVALID, "qc_pade_coefficients: order must be even, 2..20");
+    const int p = order / 2;
+    // c_k = (2p-k)! p! / ((2p)! k! (p-k)!)  ->  c_0 = 1, c_k = c_{k-1} * (p-k+1) / (k (2p-k+1))
+    out[0] = 1.0;
+    for (int k = 1; k <= p; ++k) out[k] = out[k - 1] * (double)(p - k + 1) / ((double)k * (double)(2 * p - k + 1));
+    return QC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+//  Descriptor -> parameters
+// ------------------------------------------------------------------------------------------------
+static bool overlaps(int a0, int a1, int b0, int b1) { return a0 < b1 && b0 < a1; }
+
+int qc_build_params(const qc_desc* d, QcParams* P, qc_dims_t* dims, std::string* err) {
+    if (!d) return fail(err, QC_ERR_INVALID, "descriptor is NULL");
+    if (d->N < 1 || d->N > 64) return fail(err, QC_ERR_INVALID, "N must be in 1..64");
+    if (d->m < 0 || d->m > 64) return fail(err, QC_ERR_INVALID, "m must be in 0..64");
+    if (d->T < 2) return fail(err, QC_ERR_INVALID, "T must be >= 2");
+    if (d->global_dim < 0) return fail(err, QC_ERR_INVALID, "global_dim must be >= 0");
+    memset(P, 0, sizeof(*P));
+    P->N = d->N;
+    P->n = 2 * d->N;
+    P->s = 2 * d->N * d->N;
+    P->m = d->m;
+    P->zdim = d->zdim;
+    P->off_U = d->off_U;
+    P->off_a = d->off_a;
+    P->off_dt = d->off_dt < 0 ? -1 : d->off_dt;
+    P->dt_fixed = d->dt_fixed;
+    if (d->zdim < P->s + P->m + (P->off_dt >= 0 ? 1 : 0)) return fail(err, QC_ERR_INVALID, "zdim too small for U, a (and dt)");
+    if (d->off_U < 0 || d->off_U + P->s > d->zdim) return fail(err, QC_ERR_INVALID, "off_U out of range");
+    if (d->off_a < 0 || d->off_a + P->m > d->zdim) return fail(err, QC_ERR_INVALID, "off_a out of range");
+    if (P->off_dt >= d->zdim) return fail(err, QC_ERR_INVALID, "off_dt out of range");
+    if (P->m > 0 && overlaps(d->off_U, d->off_U + P->s, d->off_a, d->off_a + P->m))
+        return fail(err, QC_ERR_INVALID, "U and a components overlap");
+    if (P->off_dt >= 0 && (overlaps(P->off_dt, P->off_dt + 1, d->off_U, d->off_U + P->s) ||
+                           overlaps(P->off_dt, P->off_dt + 1, d->off_a, d->off_a + P->m)))
+        return fail(err, QC_ERR_INVALID, "dt overlaps U or a");
+    if (d->integrator != QC_PADE && d->integrator != QC_EXPONENTIAL) return fail(err, QC_ERR_INVALID, "unknown integrator");
+    P->integrator = d->integrator;
+    if (d->integrator == QC_PADE) {
+        if (d->pade_order < 2 || (d->pade_order & 1) || d->pade_order / 2 > QC_MAX_P)
+            return fail(err, QC_ERR_INVALID, "pade_order must be even, 2..20");
+        P->p = d->pade_order / 2;
+        qc_pade_coefficients(d->pade_order, P->c);
+    } else {
+        P->p = 0;
+    }
+    if (d->n_deriv < 0 || d->n_deriv > QC_MAX_DERIV) return fail(err, QC_ERR_INVALID, "n_deriv out of range");
+    P->n_deriv = d->n_deriv;
+    P->ddim = P->s;
+    for (int i = 0; i < d->n_deriv; ++i) {
+        const int dim = d->deriv_dim[i], xo = d->deriv_x_off[i], dxo = d->deriv_dx_off[i];
+        if (dim < 1 || xo < 0 || dxo < 0 || xo + dim > d->zdim || dxo + dim > d->zdim)
+            return fail(err, QC_ERR_INVALID, "derivative integrator component out of range");
+        if (overlaps(xo, xo + dim, dxo, dxo + dim)) return fail(err, QC_ERR_INVALID, "derivative integrator x and dx overlap");
+        if (P->off_dt >= 0 && (overlaps(P->off_dt, P->off_dt + 1, xo, xo + dim) || overlaps(P->off_dt, P->off_dt + 1, dxo, dxo + dim)))
+            return fail(err, QC_ERR_INVALID, "derivative integrator component overlaps dt");
+        P->x_off[i] = xo;
+        P->dx_off[i] = dxo;
+        P->ddim_i[i] = dim;
+        P->ddim += dim;
+    }
+    long long tb = d->t_begin, te = d->t_end;
+    if (tb == 0 && te == 0) te = d->T - 1;
+    if (tb < 0 || te > d->T - 1 || tb > te) return fail(err, QC_ERR_INVALID, "interval range [t_begin, t_end) out of [0, T-1)");
+    if (te - tb > 0x7fffffffLL / 2) return fail(err, QC_ERR_INVALID, "too many intervals for one handle");
+    P->t_begin = tb;
+    P->n_int = (int)(te - tb);
+
+    const int n2 = P->n * P->n, s = P->s, m = P->m;
+    const bool ft = P->off_dt >= 0;
+    // Jacobian block offsets
+    int o = 0;
+    P->jo_F = o;  o += P->N * n2;
+    P->jo_B = o;  o += (P->integrator == QC_PADE) ? P->N * n2 : s;
+    P->jo_a = o;  o += s * m;
+    P->jo_h = o;  o += ft ? s : 0;
+    P->jo_d = o;
+    for (int i = 0; i < P->n_deriv; ++i) o += (ft ? 4 : 3) * P->ddim_i[i];
+    P->jac_nnz = o;
+    // Hessian block offsets (analytic Hessian: Pade only)
+    o = 0;
+    if (P->integrator == QC_PADE) {
+        P->ho_Ua = o;  o += s * m;
+        P->ho_aU = o;  o += s * m;
+        P->ho_aa = o;  o += m * (m + 1) / 2;
+        P->ho_ah = o;  o += ft ? m : 0;
+        P->ho_Uh = o;  o += ft ? s : 0;
+        P->ho_hU = o;  o += ft ? s : 0;
+        P->ho_hh = o;  o += ft ? 1 : 0;
+        P->ho_d = o;
+        if (ft) for (int i = 0; i < P->n_deriv; ++i) o += P->ddim_i[i];
+    }
+    P->hess_nnz = o;
+
+    if (dims) {
+        memset(dims, 0, sizeof(*dims));
+        dims->n_rows = (int64_t)P->ddim * (d->T - 1);
+        dims->n_cols = (int64_t)d->zdim * d->T + d->global_dim;
+        dims->ddim = P->ddim;
+        dims->jac_nnz_interval = P->jac_nnz;
+        dims->hess_nnz_interval = P->hess_nnz;
+        dims->n_intervals = P->n_int;
+        dims->F_len = (int64_t)P->ddim * P->n_int;
+        dims->jac_nnz = (int64_t)P->jac_nnz * P->n_int;
+        dims->hess_nnz = (int64_t)P->hess_nnz * P->n_int;
+        dims->Z_len = dims->n_cols;
+        dims->kernel = 0;
+    }
+    return QC_OK;
+}
+
+// Local structure: rows in [0, ddim), cols in [0, 2*zdim) with col >= zdim meaning knot t+1.
+void qc_local_jac_structure(const QcParams& P, std::vector<int32_t>* R, std::vector<int32_t>* C) {
+    R->clear(); C->clear();
+    R->reserve(P.jac_nnz); C->reserve(P.jac_nnz);
+    const int n = P.n, N = P.N, s = P.s, m = P.m, zd = P.zdim;
+    const bool ft = P.off_dt >= 0;
+    for (int q = 0; q < N; ++q)
+        for (int c = 0; c < n; ++c)
+            for (int r = 0; r < n; ++r) { R->push_back(q * n + r); C->push_back(P.off_U + q * n + c); }
+    if (P.integrator == QC_PADE) {
+        for (int q = 0; q < N; ++q)
+            for (int c = 0; c < n; ++c)
+                for (int r = 0; r < n; ++r) { R->push_back(q * n + r); C->push_back(zd + P.off_U + q * n + c); }
+    } else {
+        for (int i = 0; i < s; ++i) { R->push_back(i); C->push_back(zd + P.off_U + i); }
+    }
+    for (int j = 0; j < m; ++j)
+        for (int i = 0; i < s; ++i) { R->push_back(i); C->push_back(P.off_a + j); }
+    if (ft)
+        for (int i = 0; i < s; ++i) { R->push_back(i); C->push_back(P.off_dt); }
+    int r0 = s;
+    for (int d = 0; d < P.n_deriv; ++d) {
+        const int dim = P.ddim_i[d];
+        for (int i = 0; i < dim; ++i) { R->push_back(r0 + i); C->push_back(P.x_off[d] + i); }
+        for (int i = 0; i < dim; ++i) { R->push_back(r0 + i); C->push_back(zd + P.x_off[d] + i); }
+        for (int i = 0; i < dim; ++i) { R->push_back(r0 + i); C->push_back(P.dx_off[d] + i); }
+        if (ft) for (int i = 0; i < dim; ++i) { R->push_back(r0 + i); C->push_back(P.off_dt); }
+        r0 += dim;
+    }
+}
+
+void qc_local_hess_structure(const QcParams& P, std::vector<int32_t>* R, std::vector<int32_t>* C) {
+    R->clear(); C->clear();
+    if (P.integrator != QC_PADE) return;
+    const int s = P.s, m = P.m, zd = P.zdim;
+    const bool ft = P.off_dt >= 0;
+    auto up = [&](int i, int j) { R->push_back(std::min(i, j)); C->push_back(std::max(i, j)); };
+    for (int j = 0; j < m; ++j) for (int i = 0; i < s; ++i) up(P.off_U + i, P.off_a + j);
+    for (int j = 0; j < m; ++j) for (int i = 0; i < s; ++i) up(P.off_a + j, zd + P.off_U + i);
+    for (int j = 0; j < m; ++j) for (int i = 0; i <= j; ++i) up(P.off_a + i, P.off_a + j);
+    if (ft) {
+        for (int j = 0; j < m; ++j) up(P.off_a + j, P.off_dt);
+        for (int i = 0; i < s; ++i) up(P.off_U + i, P.off_dt);
+        for (int i = 0; i < s; ++i) up(P.off_dt, zd + P.off_U + i);
+        up(P.off_dt, P.off_dt);
+        for (int d = 0; d < P.n_deriv; ++d) for (int i = 0; i < P.ddim_i[d]; ++i) up(P.dx_off[d] + i, P.off_dt);
+    }
+}
+
+static void expand_structure(const QcParams& P, const std::vector<int32_t>& lr, const std::vector<int32_t>& lc,
+                             long long row_stride, int64_t* rows, int64_t* cols, int one_based) {
+    const int64_t o = one_based ? 1 : 0;
+    const size_t k = lr.size();
+    for (int b = 0; b < P.n_int; ++b) {
+        const long long t = P.t_begin + b;
+        for (size_t e = 0; e < k; ++e) {
+            rows[(size_t)b * k + e] = t * row_stride + lr[e] + o;
+            cols[(size_t)b * k + e] = t * (long long)P.zdim + lc[e] + o;
+        }
+    }
+}
+
+extern "C" int qc_desc_dims(const qc_desc* d, qc_dims_t* out) {
+    QcParams P;
+    std::string err;
+    if (!out) return fail(nullptr, QC_ERR_INVALID, "qc_desc_dims: out is NULL");
+    return qc_build_params(d, &P, out, &err);
+}
+
+extern "C" int qc_desc_jac_structure(const qc_desc* d, int64_t* rows, int64_t* cols, int one_based) {
+    QcParams P; qc_dims_t dims; std::string err;
+    int rc = qc_build_params(d, &P, &dims, &err);
+    if (rc) return rc;
+    if (!rows || !cols) return fail(nullptr, QC_ERR_INVALID, "qc_desc_jac_structure: NULL output");
+    std::vector<int32_t> lr, lc;
+    qc_local_jac_structure(P, &lr, &lc);
+    expand_structure(P, lr, lc, P.ddim, rows, cols, one_based);
+    return QC_OK;
+}
+
+extern "C" int qc_desc_hess_structure(const qc_desc* d, int64_t* rows, int64_t* cols, int one_based) {
+    QcParams P; qc_dims_t dims; std::string err;
+    int rc = qc_build_params(d, &P, &dims, &err);
+    if (rc) return rc;
+    if (P.hess_nnz == 0) return QC_OK;
+    if (!rows || !cols) return fail(nullptr, QC_ERR_INVALID, "qc_desc_hess_structure: NULL output");
+    std::vector<int32_t> lr, lc;
+    qc_local_hess_structure(P, &lr, &lc);
+    // Hessian rows AND cols are variable indices: both use the zdim stride.
+    expand_structure(P, lr, lc, P.zdim, rows, cols, one_based);
+    return QC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+//  Handle
+// ------------------------------------------------------------------------------------------------
+extern "C" int qc_create(const qc_desc* d, qc_handle** out) {
+    if (!out) return fail(nullptr, QC_ERR_INVALID, "qc_create: out is NULL");
+    *out = nullptr;
+    QcParams P; qc_dims_t dims; std::string err;
+    int rc = qc_build_params(d, &P, &dims, &err);
+    if (rc) return rc;
+    if (!d->G_drift || (d->m > 0 && !d->G_drives)) return fail(nullptr, QC_ERR_INVALID, "qc_create: G_drift/G_drives is NULL");
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, QC_ERR_NO_DEVICE, "qc_create: no HIP device visible (this library has no CPU path)");
+    if (d->device < 0 || d->device >= ndev) return fail(nullptr, QC_ERR_NO_DEVICE, "qc_create: device ordinal out of range");
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, d->device) != hipSuccess) return fail(nullptr, QC_ERR_HIP, "hipGetDeviceProperties failed");
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, QC_ERR_NO_DEVICE, std::string("qc_create: device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+
+    qc_handle* h = new qc_handle();
+    h->desc = *d;
+    h->desc.G_drift = nullptr;
+    h->desc.G_drives = nullptr;
+    h->device = d->device;
+    h->prm = P;
+    h->dims = dims;
+
+    // kernel selection
+    int kernel = d->kernel;
+    const bool mfma_ok = qc_mfma_supported(P);
+    if (kernel == QC_KERNEL_AUTO) kernel = mfma_ok ? QC_KERNEL_MFMA : QC_KERNEL_LDS;
+    if (kernel == QC_KERNEL_MFMA && !mfma_ok) {
+        delete h;
+        return fail(nullptr, QC_ERR_UNSUPPORTED, "qc_create: MFMA kernel needs the Pade integrator of order 4 and 2N in {16, 32}");
+    }
+    if (kernel != QC_KERNEL_MFMA && kernel != QC_KERNEL_LDS) { delete h; return fail(nullptr, QC_ERR_INVALID, "qc_create: unknown kernel id"); }
+    h->kernel = kernel;
+    h->dims.kernel = kernel;
+
+    auto bail = [&](int code, const std::string& msg) { std::string m2 = msg; qc_destroy(h); return fail(nullptr, code, m2); };
+#define QC_HIP_C(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return bail(QC_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
+
+    QC_HIP_C(hipSetDevice(h->device));
+    const size_t n2 = (size_t)P.n * P.n;
+    std::vector<double> G((size_t)(P.m + 1) * n2);
+    memcpy(G.data(), d->G_drift, n2 * sizeof(double));
+    if (P.m) memcpy(G.data() + n2, d->G_drives, (size_t)P.m * n2 * sizeof(double));
+    QC_HIP_C(hipMalloc((void**)&h->dG, G.size() * sizeof(double)));
+    QC_HIP_C(hipMemcpy(h->dG, G.data(), G.size() * sizeof(double), hipMemcpyHostToDevice));
+    h->prm.G = h->dG;
+    if (kernel == QC_KERNEL_MFMA) {
+        std::vector<double> Gx(qc_mfma_gx_doubles(P));
+        qc_mfma_pack_G(P, G.data(), Gx.data());
+        QC_HIP_C(hipMalloc((void**)&h->dGx, Gx.size() * sizeof(double)));
+        QC_HIP_C(hipMemcpy(h->dGx, Gx.data(), Gx.size() * sizeof(double), hipMemcpyHostToDevice));
+        h->prm.Gx = h->dGx;
+    }
+    // LDS budget of the LDS kernels
+    {
+        // choose the j-chunk so the LDS kernel fits in 160 KiB (64 KiB keeps >= 2 blocks per CU when possible)
+        QcParams& Q = h->prm;
+        Q.jchunk = std::max(1, Q.m);
+        while (Q.jchunk > 1 && qc_lds_bytes_jac(Q) > 64 * 1024) Q.jchunk = (Q.jchunk + 1) / 2;
+        h->lds_bytes_jac = qc_lds_bytes_jac(Q);
+        h->lds_bytes_hess = qc_lds_bytes_hess(Q);
+        if (h->lds_bytes_jac > 160 * 1024 || h->lds_bytes_hess > 160 * 1024)
+            return bail(QC_ERR_UNSUPPORTED, "qc_create: problem too large for the LDS kernel (needs > 160 KiB LDS per interval)");
+    }
+    QC_HIP_C(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+#undef QC_HIP_C
+    *out = h;
+    return QC_OK;
+}
+
+extern "C" void qc_destroy(qc_handle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    double* bufs[] = {h->dG, h->dGx, h->dZ, h->dF, h->dJ, h->dMu, h->dH};
+    for (double* b : bufs) if (b) (void)hipFree(b);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+extern "C" int qc_dims(const qc_handle* h, qc_dims_t* out) {
+    if (!h || !out) return fail(nullptr, QC_ERR_INVALID, "qc_dims: NULL argument");
+    *out = h->dims;
+    return QC_OK;
+}
+
+extern "C" int qc_jac_structure(const qc_handle* h, int64_t* rows, int64_t* cols, int one_based) {
+    if (!h || !rows || !cols) return fail(nullptr, QC_ERR_INVALID, "qc_jac_structure: NULL argument");
+    std::vector<int32_t> lr, lc;
+    qc_local_jac_structure(h->prm, &lr, &lc);
+    expand_structure(h->prm, lr, lc, h->prm.ddim, rows, cols, one_based);
+    return QC_OK;
+}
+
+extern "C" int qc_hess_structure(const qc_handle* h, int64_t* rows, int64_t* cols, int one_based) {
+    if (!h) return fail(nullptr, QC_ERR_INVALID, "qc_hess_structure: NULL handle");
+    if (h->prm.hess_nnz == 0) return QC_OK;
+    if (!rows || !cols) return fail(nullptr, QC_ERR_INVALID, "qc_hess_structure: NULL output");
+    std::vector<int32_t> lr, lc;
+    qc_local_hess_structure(h->prm, &lr, &lc);
+    expand_structure(h->prm, lr, lc, h->prm.zdim, rows, cols, one_based);
+    return QC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+//  Device-resident evaluation
+// ------------------------------------------------------------------------------------------------
+static int check_align(qc_handle* h, const void* p, size_t a, const char* what) {
+    if (p && ((uintptr_t)p % a) != 0) return fail(&h->err, QC_ERR_INVALID, std::string(what) + " is not sufficiently aligned");
+    return QC_OK;
+}
+
+extern "C" int qc_eval_F_jac_dev(qc_handle* h, const double* dZ, double* dF, double* dvals, void* stream) {
+    if (!h) return fail(nullptr, QC_ERR_INVALID, "qc_eval_F_jac_dev: NULL handle");
+    if (!dZ || (!dF && !dvals)) return fail(&h->err, QC_ERR_INVALID, "qc_eval_F_jac_dev: NULL buffer");
+    int rc;
+    if ((rc = check_align(h, dZ, 8, "dZ"))) return rc;
+    if ((rc = check_align(h, dF, 16, "dF"))) return rc;
+    if ((rc = check_align(h, dvals, 16, "dvals"))) return rc;
+    if (h->prm.n_int == 0) return QC_OK;
+    hipError_t e;
+    if (h->kernel == QC_KERNEL_MFMA) e = qc_launch_mfma_F_jac(h->prm, dZ, dF, dvals, (hipStream_t)stream);
+    else e = qc_launch_lds_F_jac(h->prm, dZ, dF, dvals, h->lds_bytes_jac, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(&h->err, QC_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    return QC_OK;
+}
+
+extern "C" int qc_eval_hess_dev(qc_handle* h, const double* dZ, const double* dmu, double* dhvals, void* stream) {
+    if (!h) return fail(nullptr, QC_ERR_INVALID, "qc_eval_hess_dev: NULL handle");
+    if (h->prm.hess_nnz == 0)
+        return fail(&h->err, QC_ERR_UNSUPPORTED, "no analytic Hessian for the exponential integrator (upstream has none either; use eval_hessian=false)");
+    if (!dZ || !dmu || !dhvals) return fail(&h->err, QC_ERR_INVALID, "qc_eval_hess_dev: NULL buffer");
+    int rc;
+    if ((rc = check_align(h, dZ, 8, "dZ"))) return rc;
+    if ((rc = check_align(h, dmu, 8, "dmu"))) return rc;
+    if ((rc = check_align(h, dhvals, 16, "dhvals"))) return rc;
+    if (h->prm.n_int == 0) return QC_OK;
+    hipError_t e;
+    if (h->kernel == QC_KERNEL_MFMA) e = qc_launch_mfma_hess(h->prm, dZ, dmu, dhvals, (hipStream_t)stream);
+    else e = qc_launch_lds_hess(h->prm, dZ, dmu, dhvals, h->lds_bytes_hess, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(&h->err, QC_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    return QC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+//  Host-buffer evaluation (H2D -> kernel -> D2H, synchronous)
+// ------------------------------------------------------------------------------------------------
+static int ensure(qc_handle* h, double** p, size_t count) {
+    if (*p || count == 0) return QC_OK;
+    QC_HIP(h, hipMalloc((void**)p, count * sizeof(double)));
+    return QC_OK;
+}
+
+static int eval_host(qc_handle* h, const double* Z, double* F, double* vals) {
+    if (!h) return fail(nullptr, QC_ERR_INVALID, "qc_eval: NULL handle");
+    if (!Z || (!F && !vals)) return fail(&h->err, QC_ERR_INVALID, "qc_eval: NULL buffer");
+    QC_HIP(h, hipSetDevice(h->device));
+    int rc;
+    if ((rc = ensure(h, &h->dZ, (size_t)h->dims.Z_len))) return rc;
+    if (F && (rc = ensure(h, &h->dF, (size_t)h->dims.F_len))) return rc;
+    if (vals && (rc = ensure(h, &h->dJ, (size_t)h->dims.jac_nnz))) return rc;
+    // Only the knots this handle touches need to cross PCIe: [t_begin, t_end] inclusive.
+    const size_t z0 = (size_t)h->prm.t_begin * h->prm.zdim;
+    const size_t zn = (size_t)(h->prm.n_int + 1) * h->prm.zdim;
+    if (h->prm.n_int > 0)
+        QC_HIP(h, hipMemcpyAsync(h->dZ + z0, Z + z0, zn * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if ((rc = qc_eval_F_jac_dev(h, h->dZ, F ? h->dF : nullptr, vals ? h->dJ : nullptr, h->stream))) return rc;
+    if (F && h->dims.F_len) QC_HIP(h, hipMemcpyAsync(F, h->dF, (size_t)h->dims.F_len * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (vals && h->dims.jac_nnz) QC_HIP(h, hipMemcpyAsync(vals, h->dJ, (size_t)h->dims.jac_nnz * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    QC_HIP(h, hipStreamSynchronize(h->stream));
+    return QC_OK;
+}
+
+extern "C" int qc_eval_F(qc_handle* h, const double* Z, double* F) { return eval_host(h, Z, F, nullptr); }
+extern "C" int qc_eval_jac(qc_handle* h, const double* Z, double* vals) { return eval_host(h, Z, nullptr, vals); }
+extern "C" int qc_eval_F_jac(qc_handle* h, const double* Z, double* F, double* vals) {
+    if (h && (!F || !vals)) return fail(&h->err, QC_ERR_INVALID, "qc_eval_F_jac: NULL buffer");
+    return eval_host(h, Z, F, vals);
+}
+
+extern "C" int qc_eval_hess(qc_handle* h, const double* Z, const double* mu, double* hvals) {
+    if (!h) return fail(nullptr, QC_ERR_INVALID, "qc_eval_hess: NULL handle");
+    if (h->prm.hess_nnz == 0)
+        return fail(&h->err, QC_ERR_UNSUPPORTED, "no analytic Hessian for the exponential integrator (upstream has none either; use eval_hessian=false)");
+    if (!Z || !mu || !hvals) return fail(&h->err, QC_ERR_INVALID, "qc_eval_hess: NULL buffer");
+    QC_HIP(h, hipSetDevice(h->device));
+    int rc;
+    if ((rc = ensure(h, &h->dZ, (size_t)h->dims.Z_len))) return rc;
+    if ((rc = ensure(h, &h->dMu, (size_t)h->dims.n_rows))) return rc;
+    if ((rc = ensure(h, &h->dH, (size_t)h->dims.hess_nnz))) return rc;
+    const size_t z0 = (size_t)h->prm.t_begin * h->prm.zdim;
+    const size_t zn = (size_t)(h->prm.n_int + 1) * h->prm.zdim;
+    const size_t m0 = (size_t)h->prm.t_begin * h->prm.ddim;
+    const size_t mn = (size_t)h->prm.n_int * h->prm.ddim;
+    if (h->prm.n_int > 0) {
+        QC_HIP(h, hipMemcpyAsync(h->dZ + z0, Z + z0, zn * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        QC_HIP(h, hipMemcpyAsync(h->dMu + m0, mu + m0, mn * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    }
+    if ((rc = qc_eval_hess_dev(h, h->dZ, h->dMu, h->dH, h->stream))) return rc;
+    if (h->dims.hess_nnz) QC_HIP(h, hipMemcpyAsync(hvals, h->dH, (size_t)h->dims.hess_nnz * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    QC_HIP(h, hipStreamSynchronize(h->stream));
+    return QC_OK;
+}

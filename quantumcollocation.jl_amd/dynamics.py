@@ -1,0 +1,230 @@
+"""`QuantumDynamics(integrators, traj)`: the object the reference's MOI evaluator consumes, with the
+field names and call shapes of reference test/scripts/integrator_test_1qubit.jl:41-52:
+
+    dynamics.F(Z.datavec)                    -> residuals, length Z.dims.states*(Z.T-1)
+    dynamics.dF(Z.datavec)                   -> Jacobian values in dF_structure order      ("∂F")
+    dynamics.mu_d2F(Z.datavec, mu)           -> Hessian-of-Lagrangian values               ("μ∂²F")
+    dynamics.dF_structure / mu_d2F_structure -> (rows, cols) global COO indices
+
+(`getattr(dynamics, "∂F")` etc. resolve to the same members; `∂` is not a Python identifier.)
+Every evaluation is a call into libqcolloc_hip.so; this class only builds the C descriptor.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from .integrators import DerivativeIntegrator, UnitaryExponentialIntegrator, UnitaryPadeIntegrator, _UnitaryIntegrator
+from .named_trajectory import NamedTrajectory
+
+_KERNELS = {"auto": _lib.QC_KERNEL_AUTO, "lds": _lib.QC_KERNEL_LDS, "mfma": _lib.QC_KERNEL_MFMA}
+_ALIASES = {"∂F": "dF", "μ∂²F": "mu_d2F", "∂F_structure": "dF_structure", "μ∂²F_structure": "mu_d2F_structure"}
+
+
+def make_desc(integrators: Sequence, traj: NamedTrajectory, *, device: int = 0, kernel: str = "auto",
+              t_range: Optional[Tuple[int, int]] = None):
+    """Translate (integrators, traj) into a qc_desc.  Returns (desc, keepalive)."""
+    if not integrators or not isinstance(integrators[0], _UnitaryIntegrator):
+        raise NotImplementedError("the first integrator must be the unitary integrator "
+                                  "(row order of reference unitary_smooth_pulse_problem.jl:175-179)")
+    P = integrators[0]
+    derivs = list(integrators[1:])
+    for D in derivs:
+        if not isinstance(D, DerivativeIntegrator):
+            raise NotImplementedError("only DerivativeIntegrators may follow the unitary integrator")
+    if len(derivs) > _lib.QC_MAX_DERIV:
+        raise ValueError("too many derivative integrators")
+    sys = P.system
+    d = _lib.qc_desc()
+    d.N = sys.levels
+    d.m = sys.n_drives
+    d.T = traj.T
+    d.zdim = traj.dim
+    d.global_dim = traj.global_dim
+    d.off_U = traj.offset(P.state_name)
+    d.off_a = traj.offset(P.control_name)
+    if isinstance(traj.timestep, str):
+        d.off_dt = traj.offset(traj.timestep)
+        d.dt_fixed = 0.0
+    else:
+        d.off_dt = -1
+        d.dt_fixed = float(traj.timestep)
+    if isinstance(P, UnitaryPadeIntegrator):
+        d.integrator = _lib.QC_PADE
+        d.pade_order = P.order
+    elif isinstance(P, UnitaryExponentialIntegrator):
+        d.integrator = _lib.QC_EXPONENTIAL
+        d.pade_order = 0
+    else:
+        raise NotImplementedError(type(P).__name__)
+    d.n_deriv = len(derivs)
+    for i, D in enumerate(derivs):
+        d.deriv_x_off[i] = traj.offset(D.x)
+        d.deriv_dx_off[i] = traj.offset(D.dx)
+        d.deriv_dim[i] = D.dim
+    n = 2 * sys.levels
+    G0 = np.asfortranarray(sys.G_drift, dtype=np.float64)
+    Gd = np.empty((max(1, sys.n_drives), n * n))
+    for j, Gj in enumerate(sys.G_drives):
+        Gd[j] = np.asarray(Gj, dtype=np.float64).reshape(-1, order="F")
+    Gd = np.ascontiguousarray(Gd)
+    d.G_drift = _lib.dptr(G0)
+    d.G_drives = _lib.dptr(Gd)
+    d.device = device
+    d.kernel = _KERNELS[kernel]
+    if t_range is None:
+        d.t_begin, d.t_end = 0, 0
+    else:
+        d.t_begin, d.t_end = int(t_range[0]), int(t_range[1])
+        if d.t_begin == 0 and d.t_end == 0:
+            raise ValueError("an empty shard must be expressed with t_begin = t_end > 0 or skipped")
+    return d, (G0, Gd)
+
+
+def desc_dims(desc) -> _lib.qc_dims_t:
+    dims = _lib.qc_dims_t()
+    _lib.check(_lib.lib.qc_desc_dims(C.byref(desc), C.byref(dims)))
+    return dims
+
+
+def desc_structures(desc, one_based: bool = False):
+    """(jac_rows, jac_cols, hess_rows, hess_cols) implied by a descriptor; needs no GPU."""
+    dims = desc_dims(desc)
+    jr = np.empty(dims.jac_nnz, dtype=np.int64)
+    jc = np.empty(dims.jac_nnz, dtype=np.int64)
+    _lib.check(_lib.lib.qc_desc_jac_structure(C.byref(desc), _lib.iptr(jr), _lib.iptr(jc), int(one_based)))
+    hr = np.empty(dims.hess_nnz, dtype=np.int64)
+    hc = np.empty(dims.hess_nnz, dtype=np.int64)
+    if dims.hess_nnz:
+        _lib.check(_lib.lib.qc_desc_hess_structure(C.byref(desc), _lib.iptr(hr), _lib.iptr(hc), int(one_based)))
+    return jr, jc, hr, hc
+
+
+class QuantumDynamics:
+    def __init__(self, integrators: Sequence, traj: NamedTrajectory, *, device: int = 0, kernel: str = "auto",
+                 t_range: Optional[Tuple[int, int]] = None, eval_hessian: bool = True):
+        self.integrators = list(integrators)
+        self.traj = traj
+        self.eval_hessian = eval_hessian
+        self._desc, self._keep = make_desc(integrators, traj, device=device, kernel=kernel, t_range=t_range)
+        self._h = C.c_void_p()
+        _lib.check(_lib.lib.qc_create(C.byref(self._desc), C.byref(self._h)))
+        dims = _lib.qc_dims_t()
+        _lib.check(_lib.lib.qc_dims(self._h, C.byref(dims)), self._h)
+        self.dims = dims
+        self.dim = int(dims.ddim)          # dynamics rows per interval (= Z.dims.states)
+        self.device = device
+        self.kernel = {_lib.QC_KERNEL_LDS: "lds", _lib.QC_KERNEL_MFMA: "mfma"}[dims.kernel]
+        self._structs = None
+
+    # -- lifetime --------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            _lib.lib.qc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __getattr__(self, name):
+        if name in _ALIASES:
+            return getattr(self, _ALIASES[name])
+        raise AttributeError(name)
+
+    # -- structure --------------------------------------------------------------------------------
+    def _structure(self, one_based=False):
+        d = self.dims
+        jr = np.empty(d.jac_nnz, dtype=np.int64)
+        jc = np.empty(d.jac_nnz, dtype=np.int64)
+        _lib.check(_lib.lib.qc_jac_structure(self._h, _lib.iptr(jr), _lib.iptr(jc), int(one_based)), self._h)
+        hr = np.empty(d.hess_nnz, dtype=np.int64)
+        hc = np.empty(d.hess_nnz, dtype=np.int64)
+        if d.hess_nnz:
+            _lib.check(_lib.lib.qc_hess_structure(self._h, _lib.iptr(hr), _lib.iptr(hc), int(one_based)), self._h)
+        return jr, jc, hr, hc
+
+    @property
+    def dF_structure(self):
+        """(rows, cols), 0-based global indices, in value order."""
+        if self._structs is None:
+            self._structs = self._structure(False)
+        return self._structs[0], self._structs[1]
+
+    @property
+    def mu_d2F_structure(self):
+        if self._structs is None:
+            self._structs = self._structure(False)
+        return self._structs[2], self._structs[3]
+
+    def structure_tuples(self, which: str = "dF", one_based: bool = True) -> List[Tuple[int, int]]:
+        """Vector of (row, col) tuples as the reference stores it (1-based by default)."""
+        jr, jc, hr, hc = self._structure(one_based)
+        r, c = (jr, jc) if which in ("dF", "∂F") else (hr, hc)
+        return list(zip(r.tolist(), c.tolist()))
+
+    # -- host-buffer evaluation (what Ipopt's callbacks use) --------------------------------------
+    def _Z(self, Z):
+        Z = np.ascontiguousarray(Z, dtype=np.float64)
+        if Z.size != self.dims.Z_len:
+            raise ValueError(f"Z has length {Z.size}, expected {self.dims.Z_len}")
+        return Z
+
+    def F(self, Z) -> np.ndarray:
+        Z = self._Z(Z)
+        out = np.empty(self.dims.F_len)
+        _lib.check(_lib.lib.qc_eval_F(self._h, _lib.dptr(Z), _lib.dptr(out)), self._h)
+        return out
+
+    def dF(self, Z) -> np.ndarray:
+        Z = self._Z(Z)
+        out = np.empty(self.dims.jac_nnz)
+        _lib.check(_lib.lib.qc_eval_jac(self._h, _lib.dptr(Z), _lib.dptr(out)), self._h)
+        return out
+
+    def F_dF(self, Z):
+        Z = self._Z(Z)
+        F = np.empty(self.dims.F_len)
+        J = np.empty(self.dims.jac_nnz)
+        _lib.check(_lib.lib.qc_eval_F_jac(self._h, _lib.dptr(Z), _lib.dptr(F), _lib.dptr(J)), self._h)
+        return F, J
+
+    def mu_d2F(self, Z, mu) -> np.ndarray:
+        Z = self._Z(Z)
+        mu = np.ascontiguousarray(mu, dtype=np.float64)
+        if mu.size != self.dims.n_rows:
+            raise ValueError(f"mu has length {mu.size}, expected {self.dims.n_rows}")
+        out = np.empty(self.dims.hess_nnz)
+        _lib.check(_lib.lib.qc_eval_hess(self._h, _lib.dptr(Z), _lib.dptr(mu), _lib.dptr(out)), self._h)
+        return out
+
+    # -- device-resident evaluation (torch tensors are only the memory/stream plumbing) -----------
+    def _dev_ptr(self, t: Optional[torch.Tensor], length: int, name: str):
+        if t is None:
+            return None
+        if t.dtype != torch.float64 or not t.is_cuda or not t.is_contiguous():
+            raise ValueError(f"{name} must be a contiguous float64 tensor on the GPU")
+        if t.device.index != self.device:
+            raise ValueError(f"{name} is on {t.device}, handle is bound to cuda:{self.device}")
+        if t.numel() < length:
+            raise ValueError(f"{name} has {t.numel()} elements, needs {length}")
+        return C.c_void_p(t.data_ptr())
+
+    def F_dF_device(self, Z: torch.Tensor, F: Optional[torch.Tensor], J: Optional[torch.Tensor], stream=None) -> None:
+        """Asynchronous on `stream` (default: torch's current stream on the handle's device)."""
+        st = stream if stream is not None else torch.cuda.current_stream(self.device)
+        _lib.check(_lib.lib.qc_eval_F_jac_dev(
+            self._h, self._dev_ptr(Z, self.dims.Z_len, "Z"), self._dev_ptr(F, self.dims.F_len, "F"),
+            self._dev_ptr(J, self.dims.jac_nnz, "J"), C.c_void_p(st.cuda_stream)), self._h)
+
+    def mu_d2F_device(self, Z: torch.Tensor, mu: torch.Tensor, H: torch.Tensor, stream=None) -> None:
+        st = stream if stream is not None else torch.cuda.current_stream(self.device)
+        _lib.check(_lib.lib.qc_eval_hess_dev(
+            self._h, self._dev_ptr(Z, self.dims.Z_len, "Z"), self._dev_ptr(mu, self.dims.n_rows, "mu"),
+            self._dev_ptr(H, self.dims.hess_nnz, "H"), C.c_void_p(st.cuda_stream)), self._h)

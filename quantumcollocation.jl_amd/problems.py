@@ -1,0 +1,92 @@
+"""Inputs to the hot path for the BASELINE.json configurations, built the way
+`UnitarySmoothPulseProblem` builds them (reference unitary_smooth_pulse_problem.jl:70-191): trajectory
+via `initialize_trajectory`, then [unitary integrator, DerivativeIntegrator(a, da),
+DerivativeIntegrator(da, dda)] (:163-179).  Objectives, bounds handling, Ipopt and the problem
+struct stay on the reference side and are out of scope.
+
+Synthetic inputs follow SURVEY.md section 8(d): seed 20250218, drift 0.1 * sum Z_i Z_{i+1}
+(1 qubit: 0.1 Z as in reference test/test_utils.jl:123), drives X_i, Y_i per qubit, geodesic states +
+N(0, 1e-2) noise, a in U(-1,1) with zero ends, da/dda ~ N(0, 0.1^2), dt = 0.2.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional
+
+import numpy as np
+
+from .gates import GATES, operator_from_string
+from .integrators import DerivativeIntegrator, UnitaryExponentialIntegrator, UnitaryPadeIntegrator
+from .named_trajectory import NamedTrajectory
+from .quantum_systems import QuantumSystem
+from .trajectory_initialization import initialize_trajectory
+
+SEED = 20250218
+
+
+@dataclass
+class ConfigSpec:
+    name: str
+    n_qubits: int
+    gate: str
+    T: int
+    description: str
+
+
+CONFIGS = {
+    1: ConfigSpec("config1", 1, "H", 50, "1-qubit Hadamard UnitarySmoothPulseProblem, T=50, dt=0.2, X/Y drives"),
+    2: ConfigSpec("config2", 2, "CNOT", 200, "2-qubit CNOT UnitarySmoothPulseProblem, T=200, 4th-order Pade"),
+    3: ConfigSpec("config3", 3, "TOFFOLI", 1000, "3-qubit Toffoli UnitarySmoothPulseProblem, T=1000"),
+    4: ConfigSpec("config4", 3, "TOFFOLI", 8000, "3-qubit Toffoli T=8000, knot-sharded across GPUs"),
+    5: ConfigSpec("config5", 4, "QFT16", 500, "4-qubit QFT UnitaryMinimumTimeProblem, T=500, free dt"),
+}
+
+
+def multi_qubit_system(n_qubits: int, zz: float = 0.1) -> QuantumSystem:
+    def term(op: str, i: int) -> np.ndarray:
+        return operator_from_string("".join(op if k == i else "I" for k in range(n_qubits)))
+
+    if n_qubits == 1:
+        H_drift = zz * operator_from_string("Z")
+    else:
+        H_drift = sum(zz * operator_from_string("".join("Z" if k in (i, i + 1) else "I" for k in range(n_qubits)))
+                      for i in range(n_qubits - 1))
+    H_drives = []
+    for i in range(n_qubits):
+        H_drives += [term("X", i), term("Y", i)]
+    return QuantumSystem(H_drift, H_drives)
+
+
+@dataclass
+class HotPathInputs:
+    system: QuantumSystem
+    traj: NamedTrajectory
+    integrators: List
+    spec: Optional[ConfigSpec] = None
+
+
+def unitary_smooth_pulse_inputs(system: QuantumSystem, U_goal: np.ndarray, T: int, dt: float = 0.2, *,
+                                free_time: bool = True, integrator: str = "pade", pade_order: int = 4,
+                                a_bound: float = 1.0, dda_bound: float = 1.0, state_noise: float = 1e-2,
+                                seed: int = SEED) -> HotPathInputs:
+    rng = np.random.default_rng(seed)
+    m = system.n_drives
+    traj = initialize_trajectory(
+        U_goal, T, dt, m, ([a_bound] * m, [np.inf] * m, [dda_bound] * m),
+        free_time=free_time, state_noise=state_noise, rng=rng)
+    if integrator == "pade":
+        U_int = UnitaryPadeIntegrator("Ũ⃗", "a", system, traj, order=pade_order)
+    elif integrator == "exponential":
+        U_int = UnitaryExponentialIntegrator("Ũ⃗", "a", system, traj)
+    else:
+        raise ValueError("integrator must be one of ('pade', 'exponential')")
+    integrators = [U_int, DerivativeIntegrator("a", "da", traj), DerivativeIntegrator("da", "dda", traj)]
+    return HotPathInputs(system, traj, integrators)
+
+
+def config_inputs(cfg: int, T: Optional[int] = None, **kw) -> HotPathInputs:
+    spec = CONFIGS[cfg]
+    system = multi_qubit_system(spec.n_qubits)
+    out = unitary_smooth_pulse_inputs(system, GATES[spec.gate], T if T is not None else spec.T, **kw)
+    out.spec = spec
+    return out

@@ -1,0 +1,29 @@
+"""Generates tests/golden/fixture_outputs.npz: outputs of the BUILD'S ORACLE (oracle/qc_oracle.py) on
+the reference's data fixture (named_trajectory_type_1.json, from reference test/test_utils.jl:54-70)
+with the system of test_utils.jl:123 (0.1 Z drift, X/Y drives), order-4 Pade, free time.
+These are NOT outputs of the reference (it cannot be run here: SURVEY.md section 8c)."""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+import oracle.qc_oracle as o  # noqa: E402
+
+fx = json.load(open(os.path.join(HERE, "named_trajectory_type_1.json")))
+data = np.array(fx["data"])
+X = np.array([[0, 1], [1, 0]], dtype=complex)
+Y = np.array([[0, -1j], [1j, 0]])
+Zp = np.array([[1, 0], [0, -1]], dtype=complex)
+prob = o.Problem(N=2, m=2, T=5, zdim=15, off_U=0, off_a=8, off_dt=14, G_drift=o.generator(0.1 * Zp),
+                 G_drives=np.array([o.generator(X), o.generator(Y)]), order=4,
+                 derivs=[o.DerivSpec(8, 10, 2), o.DerivSpec(10, 12, 2)])
+Zv = data.reshape(-1, order="F")
+mu = np.ones(prob.n_rows)            # reference script uses mu = ones (integrator_test_1qubit.jl:50)
+rows, cols = o.jac_structure(prob)
+hr, hc = o.hess_structure(prob)
+np.savez(os.path.join(HERE, "fixture_outputs.npz"), F=o.F(prob, Zv), dF=o.dF(prob, Zv), dF_rows=rows, dF_cols=cols,
+         mu_d2F=o.mu_d2F(prob, Zv, mu), mu_d2F_rows=hr, mu_d2F_cols=hc)
+print("wrote fixture_outputs.npz")

@@ -1,0 +1,66 @@
+"""Test helper: turn the host layer's inputs (integrators + trajectory) into the oracle's Problem.
+Lives under tests/ because only tests, smoke() and bench's cpu_baseline may touch oracle/."""
+from __future__ import annotations
+
+import numpy as np
+
+
+def problem_from_inputs(inp, T=None):
+    import __graft_entry__ as g
+
+    o = g.load_oracle()
+    qc = g.load_package()
+    P = inp.integrators[0]
+    traj = inp.traj
+    sys_ = P.system
+    derivs = [o.DerivSpec(traj.offset(D.x), traj.offset(D.dx), D.dim) for D in inp.integrators[1:]]
+    free = isinstance(traj.timestep, str)
+    is_pade = isinstance(P, qc.UnitaryPadeIntegrator)
+    return o.Problem(
+        N=sys_.levels, m=sys_.n_drives, T=traj.T if T is None else T, zdim=traj.dim,
+        off_U=traj.offset(P.state_name), off_a=traj.offset(P.control_name),
+        off_dt=traj.offset(traj.timestep) if free else -1,
+        G_drift=np.array(sys_.G_drift), G_drives=np.array(sys_.G_drives).reshape(sys_.n_drives, 2 * sys_.levels, 2 * sys_.levels),
+        dt_fixed=0.0 if free else float(traj.timestep),
+        integrator=o.PADE if is_pade else o.EXPONENTIAL,
+        order=P.order if is_pade else 4,
+        derivs=derivs, global_dim=traj.global_dim,
+    )
+
+
+def random_problem(o, N, m, T, order=4, free_time=True, integrator=None, seed=0, layout="standard", hermitian=True):
+    """A random oracle Problem + trajectory vector, independent of the host layer."""
+    rng = np.random.default_rng(seed)
+    n, s = 2 * N, 2 * N * N
+
+    def rand_H():
+        A = rng.standard_normal((N, N)) + 1j * rng.standard_normal((N, N))
+        return (A + A.conj().T) / 2 if hermitian else A
+
+    G0 = o.generator(rand_H())
+    Gd = np.array([o.generator(rand_H()) for _ in range(m)]).reshape(m, n, n)
+    if layout == "standard":      # [U, a, da, dda, dt]
+        off_U, off_a, off_da, off_dda = 0, s, s + m, s + 2 * m
+        zdim = s + 3 * m + (1 if free_time else 0)
+        off_dt = s + 3 * m if free_time else -1
+    elif layout == "script":      # (U, a, g, da, dt) as in integrator_test_1qubit.jl:24-30, one deriv integrator
+        off_U, off_a, off_da = 0, s, s + 2 * m
+        off_dda = None
+        zdim = s + 3 * m + (1 if free_time else 0)
+        off_dt = s + 3 * m if free_time else -1
+    elif layout == "shuffled":    # [dt, a, da, U, dda]
+        off_dt = 0 if free_time else -1
+        b = 1 if free_time else 0
+        off_a, off_da, off_U, off_dda = b, b + m, b + 2 * m, b + 2 * m + s
+        zdim = b + 3 * m + s
+    else:
+        raise ValueError(layout)
+    derivs = [o.DerivSpec(off_a, off_da, m)]
+    if off_dda is not None:
+        derivs.append(o.DerivSpec(off_da, off_dda, m))
+    prob = o.Problem(N=N, m=m, T=T, zdim=zdim, off_U=off_U, off_a=off_a, off_dt=off_dt, G_drift=G0, G_drives=Gd,
+                     dt_fixed=0.17, integrator=o.PADE if integrator is None else integrator, order=order, derivs=derivs)
+    Z = rng.standard_normal(zdim * T) * 0.5
+    if free_time:
+        Z[off_dt::zdim] = rng.uniform(0.1, 0.3, size=T)
+    return prob, Z

@@ -1,0 +1,145 @@
+"""CPU-side checks of the drop-in boundary: the library loads, exports exactly what include/qcolloc.h
+declares, struct layouts agree between C and ctypes, the host-only entry points (layout, structure,
+iso helpers) agree with the oracle, and errors surface as codes + messages.  No compute calls."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from oracle_bridge import problem_from_inputs
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "qcolloc.h")
+
+
+def header_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(qc_[a-z_A-Z0-9]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(qc):
+    declared = header_functions()
+    assert len(declared) >= 20
+    out = subprocess.run(["nm", "-D", "--defined-only", qc._lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (qc_\w+)", out))
+    assert set(declared) <= exported, set(declared) - exported
+    assert set(declared) == set(qc._lib.SYMBOLS), set(declared) ^ set(qc._lib.SYMBOLS)
+    assert b"gfx950" in qc._lib.lib.qc_version()
+
+
+def test_struct_layout_matches_c(qc, tmp_path):
+    src = tmp_path / "sz.c"
+    src.write_text(
+        '#include <stdio.h>\n#include <stddef.h>\n#include "qcolloc.h"\n'
+        'int main(){printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(qc_desc), offsetof(qc_desc, G_drift), '
+        'offsetof(qc_desc, t_begin), offsetof(qc_desc, deriv_dim), offsetof(qc_desc, dt_fixed), '
+        'sizeof(qc_dims_t), offsetof(qc_dims_t, kernel));return 0;}\n')
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = [int(x) for x in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    d, dm = qc._lib.qc_desc, qc._lib.qc_dims_t
+    assert got == [C.sizeof(d), d.G_drift.offset, d.t_begin.offset, d.deriv_dim.offset, d.dt_fixed.offset,
+                   C.sizeof(dm), dm.kernel.offset]
+
+
+def test_iso_helpers_match_oracle(qc, oracle):
+    rng = np.random.default_rng(0)
+    for N in (1, 2, 3, 8):
+        A = rng.standard_normal((N, N)) + 1j * rng.standard_normal((N, N))
+        np.testing.assert_array_equal(qc.operator_to_iso_vec(A), oracle.operator_to_iso_vec(A))
+        np.testing.assert_array_equal(qc.iso_vec_to_operator(qc.operator_to_iso_vec(A)), A)
+        H = (A + A.conj().T) / 2
+        np.testing.assert_array_equal(qc.iso_generator(H), oracle.generator(H))
+    for order in range(2, 21, 2):
+        np.testing.assert_allclose(qc.pade_coefficients(order), oracle.pade_coeffs(order), rtol=1e-15)
+
+
+@pytest.mark.parametrize("cfg,T", [(1, 50), (2, 200), (3, 40), (5, 4)])
+def test_dims_and_structure_match_oracle(qc, oracle, cfg, T):
+    inp = qc.config_inputs(cfg, T=T)
+    desc, keep = qc.make_desc(inp.integrators, inp.traj)
+    dims = qc.desc_dims(desc)
+    prob = problem_from_inputs(inp)
+    assert dims.n_rows == prob.n_rows and dims.n_cols == prob.n_vars and dims.ddim == prob.ddim
+    assert dims.jac_nnz_interval == oracle.jac_nnz_interval(prob)
+    assert dims.hess_nnz_interval == oracle.hess_nnz_interval(prob)
+    assert dims.n_intervals == T - 1
+    jr, jc, hr, hc = qc.desc_structures(desc)
+    orr, oc = oracle.jac_structure(prob)
+    np.testing.assert_array_equal(jr, orr)      # bit-exact, including order
+    np.testing.assert_array_equal(jc, oc)
+    ohr, ohc = oracle.hess_structure(prob)
+    np.testing.assert_array_equal(hr, ohr)
+    np.testing.assert_array_equal(hc, ohc)
+    jr1, jc1, _, _ = qc.desc_structures(desc, one_based=True)
+    np.testing.assert_array_equal(jr1, jr + 1)
+    np.testing.assert_array_equal(jc1, jc + 1)
+
+
+def test_structure_of_a_shard(qc, oracle):
+    inp = qc.config_inputs(2, T=20)
+    desc, keep = qc.make_desc(inp.integrators, inp.traj, t_range=(7, 13))
+    dims = qc.desc_dims(desc)
+    assert dims.n_intervals == 6 and dims.Z_len == inp.traj.dim * 20
+    jr, jc, hr, hc = qc.desc_structures(desc)
+    prob = problem_from_inputs(inp)
+    orr, oc = oracle.jac_structure(prob, t_begin=7, t_end=13)
+    np.testing.assert_array_equal(jr, orr)
+    np.testing.assert_array_equal(jc, oc)
+    ohr, ohc = oracle.hess_structure(prob, t_begin=7, t_end=13)
+    np.testing.assert_array_equal(hr, ohr)
+    np.testing.assert_array_equal(hc, ohc)
+
+
+def test_exponential_and_fixed_time_structure(qc, oracle):
+    sys_ = qc.multi_qubit_system(1)
+    inp = qc.unitary_smooth_pulse_inputs(sys_, qc.GATES["H"], 10, free_time=False, integrator="exponential")
+    desc, keep = qc.make_desc(inp.integrators, inp.traj)
+    prob = problem_from_inputs(inp)
+    jr, jc, hr, hc = qc.desc_structures(desc)
+    orr, oc = oracle.jac_structure(prob)
+    np.testing.assert_array_equal(jr, orr)
+    np.testing.assert_array_equal(jc, oc)
+    assert hr.size == 0 and qc.desc_dims(desc).hess_nnz == 0   # no analytic Hessian
+
+
+def test_invalid_descriptors_are_rejected_with_a_message(qc):
+    inp = qc.config_inputs(1, T=5)
+    lib = qc._lib.lib
+
+    def rc_of(mut):
+        desc, keep = qc.make_desc(inp.integrators, inp.traj)
+        mut(desc)
+        dims = qc._lib.qc_dims_t()
+        rc = lib.qc_desc_dims(C.byref(desc), C.byref(dims))
+        return rc, lib.qc_last_error(None).decode()
+
+    for mut in (lambda d: setattr(d, "T", 1), lambda d: setattr(d, "pade_order", 5), lambda d: setattr(d, "off_U", 12),
+                lambda d: setattr(d, "off_a", 3), lambda d: setattr(d, "integrator", 7), lambda d: setattr(d, "zdim", 9),
+                lambda d: setattr(d, "t_end", 99), lambda d: setattr(d, "n_deriv", 9), lambda d: setattr(d, "N", 0)):
+        rc, msg = rc_of(mut)
+        assert rc == qc._lib.QC_ERR_INVALID and msg
+    assert lib.qc_desc_dims(None, None) == qc._lib.QC_ERR_INVALID
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="this box has a GPU")
+def test_no_cpu_fallback_without_a_gpu(qc):
+    """The product path must fail loudly when there is no device; it never routes through the oracle."""
+    inp = qc.config_inputs(1, T=5)
+    with pytest.raises(qc.QCollocError) as e:
+        qc.QuantumDynamics(inp.integrators, inp.traj)
+    assert e.value.code == qc._lib.QC_ERR_NO_DEVICE
+
+
+def test_product_code_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "quantumcollocation.jl_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".cpp", ".hip", ".h")):
+                txt = open(os.path.join(dirpath, fn)).read()
+                assert "oracle" not in txt.lower().replace("no cpu", ""), f"{fn} mentions the oracle"

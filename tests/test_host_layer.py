@@ -1,0 +1,51 @@
+"""Host-side mirror of the reference interface: trajectory layout, configs, geodesic known answers."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_named_trajectory_layout(qc):
+    with open(os.path.join(GOLD, "named_trajectory_type_1.json")) as f:
+        fx = json.load(f)
+    data = np.array(fx["data"])
+    comps = {"Ũ⃗": data[0:8], "a": data[8:10], "da": data[10:12], "dda": data[12:14], "Δt": data[14:15]}
+    Z = qc.NamedTrajectory(comps, controls=("dda", "Δt"), timestep="Δt")
+    assert Z.dim == 15 and Z.T == 5 and Z.global_dim == 0
+    assert Z.dims.states == 12 and Z.dims.a == 2        # rows of the dynamics per interval
+    np.testing.assert_array_equal(Z.datavec, data.reshape(-1, order="F"))   # knot-major
+    np.testing.assert_array_equal(Z.datavec[15:30], data[:, 1])
+    assert [Z.offset(k) for k in ("Ũ⃗", "a", "da", "dda", "Δt")] == [0, 8, 10, 12, 14]
+    Zf = qc.NamedTrajectory({k: v for k, v in comps.items() if k != "Δt"}, controls=("dda",), timestep=0.2)
+    assert Zf.dim == 14 and Zf.dims.states == 12
+
+
+@pytest.mark.parametrize("cfg,N,m,zdim,ddim", [(1, 2, 2, 15, 12), (2, 4, 4, 45, 40), (3, 8, 6, 147, 140), (5, 16, 8, 537, 528)])
+def test_config_shapes_match_survey_table(qc, cfg, N, m, zdim, ddim):
+    inp = qc.config_inputs(cfg, T=6)
+    assert inp.system.levels == N and inp.system.n_drives == m
+    assert inp.traj.dim == zdim and inp.traj.dims.states == ddim
+    assert inp.traj.names == ("Ũ⃗", "a", "da", "dda", "Δt")      # trajectory_initialization.jl:357-362
+    a = inp.traj["a"]
+    assert not a[:, 0].any() and not a[:, -1].any() and np.abs(a).max() <= 1.0
+    for G in [inp.system.G_drift] + inp.system.G_drives:
+        np.testing.assert_array_equal(G.T, -G)
+
+
+def test_unitary_geodesic_known_answers(qc):
+    # reference trajectory_initialization.jl:588-642: endpoints are the iso-vecs, ||H|| = pi (X gate)
+    X = qc.GATES["X"]
+    geo, H = qc.unitary_geodesic(np.eye(2, dtype=complex), X, 10, return_generator=True)
+    np.testing.assert_allclose(geo[:, 0], qc.operator_to_iso_vec(np.eye(2)), atol=1e-12)
+    np.testing.assert_allclose(geo[:, -1], qc.operator_to_iso_vec(X), atol=1e-12)
+    np.testing.assert_allclose(H, H.conj().T, atol=1e-12)
+    assert abs(np.linalg.norm(H, 2) - np.pi / 2) < 1e-9 or abs(np.linalg.norm(H) - np.pi) < 1e-6
+
+
+def test_dynamics_requires_unitary_integrator_first(qc):
+    inp = qc.config_inputs(1, T=5)
+    with pytest.raises(NotImplementedError):
+        qc.make_desc(inp.integrators[1:], inp.traj)
