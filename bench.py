@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""bench.py — BASELINE.json's metric on MI355X: full-trajectory constraint+Jacobian evaluations per
+second for the 3-qubit Toffoli UnitarySmoothPulseProblem, T = 1000 knots per GPU.
+
+A "step" is ONE pass of the hot path: `qc_eval_F_jac_dev` (== `dynamics.F(Z)` + `dynamics.dF(Z)`,
+reference test/scripts/integrator_test_1qubit.jl:45-46) over every interval of the trajectory, with
+Z already resident in HBM and the residual + Jacobian values left in HBM.
+
+N GPUs: one process per GPU (torch.distributed/RCCL only for the barrier and the max-over-ranks);
+the trajectory has T = 1000*N knots (N = 8 is BASELINE config 4, T = 8000) and each rank evaluates
+its contiguous knot shard — no collective on the data path ("scaling": "weak").  `value` is
+reported in T=1000-equivalent evaluations per second: intervals processed by all ranks / 999 / time.
+
+Each step writes into the next of a ring of output buffers whose total exceeds 2 x 256 MiB, so a
+step's stores cannot be absorbed by the Infinity Cache across steps ("Measurement").
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as g  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+T_PER_GPU = 1000
+RING_BYTES = 640 << 20
+
+
+def cpu_baseline(qc, inp, seconds: float):
+    """The C restatement (oracle/qc_oracle.c, OpenMP over intervals) on the host cores, same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_bridge import problem_from_inputs
+    import oracle.qc_oracle_c as oc
+
+    prob = problem_from_inputs(inp)
+    threads = os.cpu_count() or 1
+    co = oc.COracle(prob, threads=threads)
+    Z = inp.traj.datavec
+    co.F_dF(Z)  # warm-up (thread pool, page faults)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        co.F_dF(Z)
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= seconds and n >= 3:
+            break
+    return {"value": n / el, "unit": "evals/s", "cores": threads, "kind": "port",
+            "sample": f"{n} full F+dF evaluations of the same T={prob.T} workload in {el:.1f} s (oracle/qc_oracle.c, OpenMP)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--config", type=int, default=3, help="BASELINE config id (3 = metric workload)")
+    ap.add_argument("--T", type=int, default=0, help="knots per GPU (default: the config's own T)")
+    ap.add_argument("--kernel", default="auto", choices=["auto", "lds", "mfma"])
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="0 disables the CPU baseline leg")
+    ap.add_argument("--hessian", action="store_true", help="also time mu_d2F and report the ms/Ipopt-iter proxy")
+    ap.add_argument("--allgather", action="store_true", help="also time the RCCL all-gather of the value blocks")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch multi-GPU runs as: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                     "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+        sys.exit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    qc = g.load_package()
+    from qcolloc_amd.sharding import ShardedDynamics
+
+    spec = qc.CONFIGS[args.config]
+    t_per_gpu = args.T or (T_PER_GPU if args.config in (3, 4) else spec.T)
+    T_total = t_per_gpu * world
+    inp = qc.config_inputs(args.config, T=T_total)
+    sd = ShardedDynamics(inp.integrators, inp.traj, rank, world, device=local_rank, kernel=args.kernel)
+    dyn = sd.local
+    dims = dyn.dims
+    n_int = int(dims.n_intervals)
+    zdim, ddim, nnz = inp.traj.dim, int(dims.ddim), int(dims.jac_nnz_interval)
+    bytes_per_launch = 8 * (zdim * (n_int + 1) + ddim * n_int + nnz * n_int)  # each knot once; DESIGN.md
+
+    # inputs resident in HBM before the timed region; a few distinct Z so steps are not identical
+    Zh = inp.traj.datavec
+    rng = np.random.default_rng(1)
+    Zs = [torch.from_numpy(Zh + (1e-3 * rng.standard_normal(Zh.size) if k else 0.0)).to(dev) for k in range(4)]
+    out_bytes = 8 * (ddim + nnz) * n_int
+    nbuf = max(2, -(-RING_BYTES // out_bytes))
+    Fb = [torch.empty(int(dims.F_len), dtype=torch.float64, device=dev) for _ in range(nbuf)]
+    Jb = [torch.empty(int(dims.jac_nnz), dtype=torch.float64, device=dev) for _ in range(nbuf)]
+    stream = torch.cuda.current_stream(dev)
+
+    def step(i):
+        dyn.F_dF_device(Zs[i & 3], Fb[i % nbuf], Jb[i % nbuf], stream)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for i in range(args.steps):
+        step(i)
+    ev1.record(stream)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    stream_ms = ev0.elapsed_time(ev1)
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # kernel duration: HIP event pair around each launch, on the launch stream, same steps
+    kn = min(args.steps, 400)
+    pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(kn)]
+    torch.cuda.synchronize()
+    for i, (a, b) in enumerate(pairs):
+        a.record(stream)
+        step(i)
+        b.record(stream)
+    torch.cuda.synchronize()
+    pair_us = np.array([a.elapsed_time(b) for a, b in pairs]) * 1e3
+    kernel_us_pairs = float(np.median(pair_us))
+    kernel_us_stream = stream_ms * 1e3 / args.steps   # includes the inter-kernel boundary
+
+    extra = {}
+    if args.hessian and dims.hess_nnz:
+        mu = torch.from_numpy(rng.standard_normal(int(dims.n_rows))).to(dev)
+        Hb = torch.empty(int(dims.hess_nnz), dtype=torch.float64, device=dev)
+        for _ in range(50):
+            dyn.mu_d2F_device(Zs[0], mu, Hb, stream)
+        torch.cuda.synchronize()
+        h0, h1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        h0.record(stream)
+        for i in range(500):
+            dyn.mu_d2F_device(Zs[i & 3], mu, Hb, stream)
+        h1.record(stream)
+        torch.cuda.synchronize()
+        hess_us = h0.elapsed_time(h1) * 1e3 / 500
+        f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        f0.record(stream)
+        for i in range(500):
+            dyn.F_dF_device(Zs[i & 3], Fb[0], None, stream)
+        f1.record(stream)
+        torch.cuda.synchronize()
+        F_us = f0.elapsed_time(f1) * 1e3 / 500
+        extra["hess_us"] = hess_us
+        extra["F_only_us"] = F_us
+        # Ipopt iteration proxy: F+dF, mu_d2F, one extra line-search F; solver algebra excluded
+        extra["ms_per_ipopt_iter_proxy_device"] = (kernel_us_stream + hess_us + F_us) / 1e3
+    if args.allgather and world > 1:
+        pad = torch.zeros(sd.padded_len(nnz), dtype=torch.float64, device=dev)
+        pad[:Jb[0].numel()].copy_(Jb[0])
+        full = torch.empty(world * pad.numel(), dtype=torch.float64, device=dev)
+        for _ in range(5):
+            sd.all_gather_values(pad, nnz, out=full)
+        torch.cuda.synchronize()
+        a0 = time.perf_counter()
+        for _ in range(20):
+            sd.all_gather_values(pad, nnz, out=full)
+        torch.cuda.synchronize()
+        extra["allgather_ms"] = (time.perf_counter() - a0) / 20 * 1e3
+
+    total_intervals = (T_total - 1)
+    t1000_equiv = total_intervals / (T_PER_GPU - 1) if args.config in (3, 4) else float(world)
+    value = args.steps * t1000_equiv / elapsed
+    if rank == 0:
+        traffic = None
+        tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tj):
+            try:
+                rec = json.load(open(tj))
+                if rec.get("kernel") == dyn.kernel and rec.get("config") == args.config and rec.get("T") == t_per_gpu:
+                    traffic = rec.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        achieved = bytes_per_launch / (kernel_us_pairs * 1e-6) / 1e9
+        line = {
+            "metric": "full-trajectory constraint+Jacobian evals/s, 3-qubit T=1000" if args.config in (3, 4)
+                      else f"full-trajectory constraint+Jacobian evals/s, {spec.name}",
+            "value": value,
+            "unit": "evals/s (T=1000-equivalent)" if args.config in (3, 4) else "evals/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic (seed 20250218: Toffoli geodesic + N(0,1e-2) noise, a~U(-1,1), da/dda~N(0,0.1^2), dt=0.2)",
+            "config": {"workload": f"{spec.description}; T={T_total} knots ({t_per_gpu}/GPU), Pade order 4, free dt",
+                       "T": T_total, "N": inp.system.levels, "n_drives": inp.system.n_drives,
+                       "kernel": dyn.kernel, "parallelism": f"knot-shard x{world}", "output_ring_buffers": nbuf},
+            "knot_evals_per_s": args.steps * total_intervals / elapsed,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "kernel_us_event_pairs": kernel_us_pairs, "step_us_stream_events": kernel_us_stream},
+        }
+        line.update(extra)
+        if world == 1 and args.cpu_seconds > 0:
+            line["cpu_baseline"] = cpu_baseline(qc, inp, args.cpu_seconds)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    dyn.close()
+
+
+if __name__ == "__main__":
+    main()

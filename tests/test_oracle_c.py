@@ -1,0 +1,68 @@
+"""The C restatement (oracle/qc_oracle.c, bench.py's cpu_baseline) against the numpy oracle, and
+both against the committed golden vectors."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle_bridge import random_problem
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def coracle():
+    import oracle.qc_oracle_c as oc
+    return oc
+
+
+@pytest.mark.parametrize("N,m,order", [(1, 1, 4), (2, 2, 2), (2, 3, 4), (3, 2, 6), (4, 4, 4), (2, 2, 12), (8, 6, 4)])
+@pytest.mark.parametrize("free_time", [True, False])
+def test_c_oracle_matches_numpy_oracle(oracle, coracle, N, m, order, free_time):
+    prob, Z = random_problem(oracle, N=N, m=m, T=4, order=order, free_time=free_time, seed=N * 31 + order)
+    co = coracle.COracle(prob, threads=2)
+    F, J = co.F_dF(Z)
+    np.testing.assert_allclose(F, oracle.F(prob, Z), rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(J, oracle.dF(prob, Z), rtol=1e-12, atol=1e-13)
+    assert co.jac_nnz == oracle.jac_nnz_interval(prob) and co.hess_nnz == oracle.hess_nnz_interval(prob)
+    mu = np.random.default_rng(1).standard_normal(prob.n_rows)
+    np.testing.assert_allclose(co.mu_d2F(Z, mu), oracle.mu_d2F(prob, Z, mu), rtol=1e-11, atol=1e-12)
+
+
+def test_c_oracle_layouts_and_exponential(oracle, coracle):
+    for layout in ("shuffled", "script"):
+        prob, Z = random_problem(oracle, N=2, m=2, T=4, layout=layout, seed=3)
+        F, J = coracle.COracle(prob).F_dF(Z)
+        np.testing.assert_allclose(F, oracle.F(prob, Z), rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(J, oracle.dF(prob, Z), rtol=1e-12, atol=1e-13)
+    for ft in (True, False):
+        prob, Z = random_problem(oracle, N=2, m=2, T=4, free_time=ft, integrator=oracle.EXPONENTIAL, seed=4)
+        F, J = coracle.COracle(prob).F_dF(Z)
+        np.testing.assert_allclose(F, oracle.F(prob, Z), rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(J, oracle.dF(prob, Z), rtol=1e-11, atol=1e-12)
+
+
+def test_oracles_reproduce_the_golden_vectors(oracle, coracle):
+    import json
+    fx = json.load(open(os.path.join(GOLD, "named_trajectory_type_1.json")))
+    gold = np.load(os.path.join(GOLD, "fixture_outputs.npz"))
+    data = np.array(fx["data"])
+    X = np.array([[0, 1], [1, 0]], dtype=complex)
+    Y = np.array([[0, -1j], [1j, 0]])
+    Zp = np.array([[1, 0], [0, -1]], dtype=complex)
+    prob = oracle.Problem(N=2, m=2, T=5, zdim=15, off_U=0, off_a=8, off_dt=14, G_drift=oracle.generator(0.1 * Zp),
+                          G_drives=np.array([oracle.generator(X), oracle.generator(Y)]), order=4,
+                          derivs=[oracle.DerivSpec(8, 10, 2), oracle.DerivSpec(10, 12, 2)])
+    Zv = data.reshape(-1, order="F")
+    mu = np.ones(prob.n_rows)
+    np.testing.assert_allclose(oracle.F(prob, Zv), gold["F"], rtol=1e-14, atol=1e-16)
+    np.testing.assert_allclose(oracle.dF(prob, Zv), gold["dF"], rtol=1e-14, atol=1e-16)
+    np.testing.assert_allclose(oracle.mu_d2F(prob, Zv, mu), gold["mu_d2F"], rtol=1e-13, atol=1e-16)
+    r, c = oracle.jac_structure(prob)
+    np.testing.assert_array_equal(r, gold["dF_rows"])
+    np.testing.assert_array_equal(c, gold["dF_cols"])
+    co = coracle.COracle(prob)
+    F, J = co.F_dF(Zv)
+    np.testing.assert_allclose(F, gold["F"], rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(J, gold["dF"], rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(co.mu_d2F(Zv, mu), gold["mu_d2F"], rtol=1e-12, atol=1e-14)
