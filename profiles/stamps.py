@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Diagnostic timeline of the MFMA kernel (QC_STAMPS=1): per-wave s_memrealtime checkpoints.
+Run on the GPU box:  QC_STAMPS=1 python profiles/stamps.py [T]"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["QC_STAMPS"] = "1"
+import __graft_entry__ as g
+
+qc = g.load_package()
+T = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+inp = qc.config_inputs(3, T=T)
+dyn = qc.QuantumDynamics(inp.integrators, inp.traj)
+Z = torch.from_numpy(inp.traj.datavec).cuda()
+Fs = [torch.empty(dyn.dims.F_len, dtype=torch.float64, device="cuda") for _ in range(20)]
+Js = [torch.empty(dyn.dims.jac_nnz, dtype=torch.float64, device="cuda") for _ in range(20)]
+for i in range(20):
+    dyn.F_dF_device(Z, Fs[i], Js[i])
+torch.cuda.synchronize()
+n = dyn.dims.n_intervals
+out = np.zeros(n * 16, dtype=np.uint64)
+qc._lib.check(qc._lib.lib.qc_debug_read_stamps(dyn._h, out.ctypes.data_as(C.POINTER(C.c_uint64)), out.size), dyn._h)
+st = out.reshape(n, 16).astype(np.int64)
+t0 = st[:, 0].min()
+rel = (st - t0) * 10.0 / 1e3   # microseconds (100 MHz)
+names = ["start", "staged+barrier", "G assembled", "B/F issued", "P1,P2", "E^T stored", "deriv", "pair0", "pair1", "pair2",
+         "pair3", "pair4", "pair5", "pair6", "stores drained"]
+print(f"T={T}: {n} intervals; kernel span (first start -> last drain) = {rel[:, 14].max():.2f} us")
+for k, nm in enumerate(names):
+    col = rel[:, k]
+    col = col[st[:, k] > 0]
+    if col.size:
+        print(f"  {k:2d} {nm:16s} min {col.min():7.2f}  median {np.median(col):7.2f}  max {col.max():7.2f} us")

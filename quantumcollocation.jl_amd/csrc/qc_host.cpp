@@ -3,6 +3,7 @@
 // is deliberately no CPU evaluation path in this library.
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -27,7 +28,7 @@ static int fail(std::string* err, int code, const std::string& msg) {
         }                                                                                        \
     } while (0)
 
-extern "C" const char* qc_version(void) { return "qcolloc-hip 0.1 (gfx950, fp64)"; }
+extern "C" const char* qc_version(void) { return "qcolloc-hip 0.1 (gfx950, fp64; kernels: lds, mfma16)"; }
 
 extern "C" const char* qc_last_error(const qc_handle* h) { return h ? h->err.c_str() : g_err.c_str(); }
 
@@ -327,6 +328,7 @@ extern "C" int qc_create(const qc_desc* d, qc_handle** out) {
     QC_HIP_C(hipMalloc((void**)&h->dG, G.size() * sizeof(double)));
     QC_HIP_C(hipMemcpy(h->dG, G.data(), G.size() * sizeof(double), hipMemcpyHostToDevice));
     h->prm.G = h->dG;
+    if (const char* e = getenv("QC_STORE_MODE")) h->prm.store_mode = atoi(e);   // diagnostic override
     if (kernel == QC_KERNEL_MFMA) {
         std::vector<double> Gx(qc_mfma_gx_doubles(P));
         qc_mfma_pack_G(P, G.data(), Gx.data());

@@ -31,6 +31,7 @@ struct QcParams {
     int jo_F, jo_B, jo_a, jo_h, jo_d;                           // Jacobian sub-block offsets (doubles)
     int ho_Ua, ho_aU, ho_aa, ho_ah, ho_Uh, ho_hU, ho_hh, ho_d;  // Hessian sub-block offsets
     int jchunk;              // LDS kernel: drives processed per phase
+    int store_mode;          // 0 plain, 1 write-through (sc1), 2 non-temporal; see qc_st8
     const double* G;         // device: (m+1) matrices n*n, column-major; index 0 = drift
     const double* Gx;        // device: kernel-specific re-laid-out copy of G (MFMA path), or nullptr
 };
@@ -66,6 +67,20 @@ size_t qc_mfma_gx_doubles(const QcParams& P);
 void qc_mfma_pack_G(const QcParams& P, const double* G_host, double* Gx_host);
 hipError_t qc_launch_mfma_F_jac(const QcParams& P, const double* dZ, double* dF, double* dJ, hipStream_t st);
 hipError_t qc_launch_mfma_hess(const QcParams& P, const double* dZ, const double* dMu, double* dH, hipStream_t st);
+
+// Streaming store of one output value.  The outputs are written once and never re-read by the kernel;
+// mode 1 (sc1, agent-scope relaxed atomic store) writes through the XCD's L2 so the bytes leave for
+// HBM while the wave keeps computing instead of being flushed at the end of the kernel.
+__device__ inline void qc_st8(double* p, double v, int mode) {
+    if (mode == 1) {
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (mode == 2) {
+        __builtin_nontemporal_store(v, p);
+    } else {
+        *p = v;
+    }
+}
 
 // XCD-aware block -> local interval map: blocks b and b+8 share an XCD (round-robin dispatch,
 // MI355X_MICROARCH.md "Workgroup dispatch"), so each XCD gets a contiguous run of intervals and the
