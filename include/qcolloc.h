@@ -163,6 +163,12 @@ int qc_eval_hess(qc_handle* h, const double* Z, const double* mu, double* hvals)
 int qc_eval_F_jac_dev(qc_handle* h, const double* dZ, double* dF, double* dvals, void* stream);
 int qc_eval_hess_dev(qc_handle* h, const double* dZ, const double* dmu, double* dhvals, void* stream);
 
+/* Diagnostic only: when the environment variable QC_STAMPS=1 is set at qc_create, the MFMA kernel
+ * records 16 s_memrealtime (100 MHz) checkpoints per interval; this copies them out (synchronises the
+ * device).  Not part of the evaluated path; a handle created without QC_STAMPS returns
+ * QC_ERR_UNSUPPORTED. */
+int qc_debug_read_stamps(qc_handle* h, uint64_t* out, int64_t count);
+
 /* Library/build identification: "qcolloc-hip 0.1 gfx950 ..." */
 const char* qc_version(void);
 

@@ -144,9 +144,10 @@ static void accumulate_dpow(const qco_ws* w, const double* Gj, int n, int k, dou
                             double* T1, double* T2) {
     const size_t n2 = (size_t)n * n;
     for (int i = 0; i < k; ++i) {
-        mm(T1, w->Gp + (size_t)i * n2, Gj, n, n, n);
-        mm(T2, T1, w->Gp + (size_t)(k - 1 - i) * n2, n, n, n);
-        for (size_t e = 0; e < n2; ++e) { dB[e] += cb * T2[e]; dF[e] += cf * T2[e]; }
+        const double* L = Gj;   /* G^i Gj G^{k-1-i}; products with G^0 = I are skipped */
+        if (i > 0) { mm(T1, w->Gp + (size_t)i * n2, Gj, n, n, n); L = T1; }
+        if (k - 1 - i > 0) { mm(T2, L, w->Gp + (size_t)(k - 1 - i) * n2, n, n, n); L = T2; }
+        for (size_t e = 0; e < n2; ++e) { dB[e] += cb * L[e]; dF[e] += cf * L[e]; }
     }
 }
 

@@ -28,9 +28,11 @@ qc._lib.check(qc._lib.lib.qc_debug_read_stamps(dyn._h, out.ctypes.data_as(C.POIN
 st = out.reshape(n, 16).astype(np.int64)
 t0 = st[:, 0].min()
 rel = (st - t0) * 10.0 / 1e3   # microseconds (100 MHz)
-names = ["start", "staged+barrier", "G assembled", "B/F issued", "P1,P2", "E^T stored", "deriv", "pair0", "pair1", "pair2",
-         "pair3", "pair4", "pair5", "pair6", "stores drained"]
-print(f"T={T}: {n} intervals; kernel span (first start -> last drain) = {rel[:, 14].max():.2f} us")
+names = ["copy: start", "copy: G assembled", "copy: stores issued", "copy: drained", "comp: start", "comp: G assembled",
+         "comp: P1,P2", "comp: E^T stored", "comp: pair0", "comp: pair1", "comp: pair2", "comp: pair3+", "comp: drained"]
+t0 = st[:, :13][st[:, :13] > 0].min()
+rel = (st - t0) * 10.0 / 1e3
+print(f"T={T}: {n} intervals; kernel span (first start -> last drain) = {max(rel[:, 3].max(), rel[:, 12].max()):.2f} us")
 for k, nm in enumerate(names):
     col = rel[:, k]
     col = col[st[:, k] > 0]

@@ -328,7 +328,11 @@ extern "C" int qc_create(const qc_desc* d, qc_handle** out) {
     QC_HIP_C(hipMalloc((void**)&h->dG, G.size() * sizeof(double)));
     QC_HIP_C(hipMemcpy(h->dG, G.data(), G.size() * sizeof(double), hipMemcpyHostToDevice));
     h->prm.G = h->dG;
+    // Outputs are written once and never re-read by the kernel: non-temporal stores measured fastest on
+    // MI355X (profiles/README.md: plain 14.4, sc1 12.8, nt 11.9 us per config-3 evaluation).
+    h->prm.store_mode = 2;
     if (const char* e = getenv("QC_STORE_MODE")) h->prm.store_mode = atoi(e);   // diagnostic override
+    if (const char* e = getenv("QC_DEBUG_SKIP")) h->prm.dbg_skip = atoi(e);     // diagnostic ablation (wrong results)
     if (kernel == QC_KERNEL_MFMA) {
         std::vector<double> Gx(qc_mfma_gx_doubles(P));
         qc_mfma_pack_G(P, G.data(), Gx.data());
@@ -347,6 +351,13 @@ extern "C" int qc_create(const qc_desc* d, qc_handle** out) {
         if (h->lds_bytes_jac > 160 * 1024 || h->lds_bytes_hess > 160 * 1024)
             return bail(QC_ERR_UNSUPPORTED, "qc_create: problem too large for the LDS kernel (needs > 160 KiB LDS per interval)");
     }
+    if (const char* e = getenv("QC_STAMPS")) {
+        if (atoi(e) && P.n_int > 0) {
+            QC_HIP_C(hipMalloc((void**)&h->dStamps, (size_t)P.n_int * 16 * sizeof(unsigned long long)));
+            QC_HIP_C(hipMemset(h->dStamps, 0, (size_t)P.n_int * 16 * sizeof(unsigned long long)));
+            h->prm.stamps = h->dStamps;
+        }
+    }
     QC_HIP_C(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
 #undef QC_HIP_C
     *out = h;
@@ -357,10 +368,20 @@ extern "C" void qc_destroy(qc_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    double* bufs[] = {h->dG, h->dGx, h->dZ, h->dF, h->dJ, h->dMu, h->dH};
+    double* bufs[] = {h->dG, h->dGx, h->dZ, h->dF, h->dJ, h->dMu, h->dH, (double*)h->dStamps};
     for (double* b : bufs) if (b) (void)hipFree(b);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
+}
+
+extern "C" int qc_debug_read_stamps(qc_handle* h, uint64_t* out, int64_t count) {
+    if (!h || !out) return fail(nullptr, QC_ERR_INVALID, "qc_debug_read_stamps: NULL argument");
+    if (!h->dStamps) return fail(&h->err, QC_ERR_UNSUPPORTED, "handle was not created with QC_STAMPS=1");
+    if (count > (int64_t)h->prm.n_int * 16) count = (int64_t)h->prm.n_int * 16;
+    QC_HIP(h, hipSetDevice(h->device));
+    QC_HIP(h, hipDeviceSynchronize());
+    QC_HIP(h, hipMemcpy(out, h->dStamps, (size_t)count * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return QC_OK;
 }
 
 extern "C" int qc_dims(const qc_handle* h, qc_dims_t* out) {

@@ -32,8 +32,10 @@ struct QcParams {
     int ho_Ua, ho_aU, ho_aa, ho_ah, ho_Uh, ho_hU, ho_hh, ho_d;  // Hessian sub-block offsets
     int jchunk;              // LDS kernel: drives processed per phase
     int store_mode;          // 0 plain, 1 write-through (sc1), 2 non-temporal; see qc_st8
+    int dbg_skip;            // diagnostic ablation (QC_DEBUG_SKIP): bit0 skip copy wave, bit1 skip compute wave
     const double* G;         // device: (m+1) matrices n*n, column-major; index 0 = drift
     const double* Gx;        // device: kernel-specific re-laid-out copy of G (MFMA path), or nullptr
+    unsigned long long* stamps;  // diagnostic: 16 s_memrealtime slots per interval, or nullptr (normal)
 };
 
 struct qc_handle {
@@ -47,6 +49,7 @@ struct qc_handle {
     double* dGx = nullptr;
     // staging for the host-pointer entry points
     double *dZ = nullptr, *dF = nullptr, *dJ = nullptr, *dMu = nullptr, *dH = nullptr;
+    unsigned long long* dStamps = nullptr;
     hipStream_t stream = nullptr;
     std::string err;
 };
@@ -67,6 +70,18 @@ size_t qc_mfma_gx_doubles(const QcParams& P);
 void qc_mfma_pack_G(const QcParams& P, const double* G_host, double* Gx_host);
 hipError_t qc_launch_mfma_F_jac(const QcParams& P, const double* dZ, double* dF, double* dJ, hipStream_t st);
 hipError_t qc_launch_mfma_hess(const QcParams& P, const double* dZ, const double* dMu, double* dH, hipStream_t st);
+
+// Diagnostic time stamp (only when the handle was created with QC_STAMPS=1; never in a timed run):
+// slot k of interval b <- s_memrealtime (100 MHz).
+#define QC_STAMP(P, b, lane, k)                                                                  \
+    do {                                                                                         \
+        if ((P).stamps != nullptr) {                                                             \
+            __builtin_amdgcn_sched_barrier(0);                                                   \
+            const unsigned long long t_ = __builtin_amdgcn_s_memrealtime();                     \
+            if ((lane) == 0) (P).stamps[(size_t)(b) * 16 + (k)] = t_;                            \
+            __builtin_amdgcn_sched_barrier(0);                                                   \
+        }                                                                                        \
+    } while (0)
 
 // Streaming store of one output value.  The outputs are written once and never re-read by the kernel;
 // mode 1 (sc1, agent-scope relaxed atomic store) writes through the XCD's L2 so the bytes leave for

@@ -1,7 +1,14 @@
 // Register-resident f64-MFMA kernels (v_mfma_f64_16x16x4_f64) for the order-4 Pade integrator.
 //
-// n = 2N = 16 (3 qubits, BASELINE configs 3 and 4): ONE WAVEFRONT PER INTERVAL.  Every 16x16x16
-// product is 4 MFMAs whose operands never leave the register file:
+// n = 2N = 16 (3 qubits, BASELINE configs 3 and 4): TWO WAVEFRONTS PER INTERVAL, no LDS, no barrier.
+//   wave 1 ("copy wave")    G -> (G^2)^T -> B^T, F^T -> the 2N stores of the I_N (x) B / -I_N (x) F blocks
+//                           (80 % of the interval's bytes; this wave lives in the store queue)
+//   wave 0 ("compute wave") residual, d/dh, the m drive columns, derivative integrators
+// so the bandwidth-bound copies of one wave overlap the MFMA chains of the other on the same SIMDs
+// (profiles/r01_mfma_v2_timeline.txt shows the serial version: 3.4 us prologue, 4.4 us store-bound,
+// 5.3 us MFMA-latency-bound).
+//
+// Every 16x16x16 product is 4 MFMAs whose operands never leave the register file:
 //   * A-operand layout of a 16x16 matrix X:  lane (g = l>>4, i = l&15), reg kk holds X[i][4kk+g]
 //   * B-operand layout == C/D layout:        lane (g, j = l&15),        reg r  holds X[4r+g][j]
 //     so a product's result is directly the B operand of the next left-multiplication, and the
@@ -12,20 +19,18 @@
 //     contiguous bytes of columns 4r..4r+3 in column-major memory, i.e. every global store
 //     instruction writes four whole 128-byte lines.  B^T and F^T come for free from
 //     (G^2)^T = mm16(G_B, G_A); the n x N outputs take one identity product each.
-//   * The constant generators G_0, G_j are staged once per workgroup in LDS, pre-packed in both
-//     operand layouts in lane order (conflict-free ds_read_b128); the knot data of the first
-//     interval is requested before that staging so the two latencies overlap.
+//   * The constant generators G_0, G_j are read from a lane-ordered A-layout image in global memory
+//     (28 KB for m = 6: L2/Infinity-Cache resident), 16 bytes per lane per load.
 //
 // Per interval (S = U1+U0, D = U1-U0, h = dt):                                          MFMAs
-//   (G^2)^T = G^T G^T ;  B^T, F^T = I -+ h/2 G^T + h^2/12 (G^2)^T   (stored N times each)    4
-//   P1 = G [S | D]      = [GS | GD]                                                          4
-//   P2 = G [GD | GS]    = [G^2 D | .]                                                        4
-//   E  = [delta | d/dh] = [D - h/2 GS + h^2/12 G^2 D | -1/2 GS + h/6 G^2 D],  E^T            4
-//   Q  = [ -h/2 S + h^2/12 GD | h^2/12 D ]
-//   per drive pair (j, j+1):  R_j = G_j Q, R_j+1 = G_j+1 Q, T = G [R_j(right) | R_j+1(right)],
-//        Y = [R_j(left) + T(left) | R_j+1(left) + T(right)] = [d/da_j | d/da_j+1],  Y^T     16
-// = 16 + 8 m MFMAs (64 for m = 6).  The B/F copies (80 % of the interval's bytes) are stored first
-// so HBM writes start while the drive columns are still being computed.
+//   copy wave:    G_B = G I ; (G^2)^T = G^T G^T ; B^T, F^T = I -+ h/2 G^T + h^2/12 (G^2)^T      8
+//   compute wave: P1 = G [S | D] = [GS | GD] ;  P2 = G [GD | GS] = [G^2 D | .]                   8
+//                 E  = [delta | d/dh] = [D - h/2 GS + h^2/12 G^2 D | -1/2 GS + h/6 G^2 D],  E^T  4
+//                 Q  = [ -h/2 S + h^2/12 GD | h^2/12 D ]
+//                 per drive pair (j, j+1):  R_j = G_j Q, R_j+1 = G_j+1 Q,
+//                      T = G [R_j(right) | R_j+1(right)],
+//                      Y = [R_j(left) + T(left) | R_j+1(left) + T(right)] = [d/da_j | d/da_j+1], Y^T   16
+// = 20 + 8 m MFMAs per interval (68 for m = 6).
 #include "qc_internal.h"
 
 namespace {
@@ -33,10 +38,8 @@ namespace {
 typedef double v4d __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
 
-constexpr int kWaves = 4;                  // intervals per workgroup
-constexpr int kThreads = 64 * kWaves;
-constexpr int kMaxGrid = 1024;             // persistent beyond this many workgroups
-constexpr int kStage = 8;                  // 16-byte loads in flight per thread while staging
+constexpr int kThreads = 128;              // compute wave + copy wave
+constexpr int kMaxGrid = 4096;             // persistent beyond this many workgroups
 
 __device__ inline double swap8(double x) {  // exchange the two 8-column halves of a 16-column tile
     int lo = __double2loint(x), hi = __double2hiint(x);
@@ -46,21 +49,69 @@ __device__ inline double swap8(double x) {  // exchange the two 8-column halves 
 }
 __device__ inline v4d swap8(v4d x) { return v4d{swap8(x[0]), swap8(x[1]), swap8(x[2]), swap8(x[3])}; }
 
-// D = A * B (16x16x16): A in A-layout regs, B in B-layout regs
+// D = A * B (16x16x16): A in A-layout regs, B in B-layout regs.  Two accumulators halve the
+// dependent-MFMA chain (a dependent f64 MFMA issues every ~100 cycles, an independent one every 64).
 __device__ inline v4d mm16(const v4d& a, const v4d& b) {
-    v4d acc = {0.0, 0.0, 0.0, 0.0};
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b[0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], b[1], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2], b[2], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[3], b[3], acc, 0, 0, 0);
-    return acc;
+    const v4d z = {0.0, 0.0, 0.0, 0.0};
+    v4d acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b[0], z, 0, 0, 0);
+    v4d acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], b[1], z, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2], b[2], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[3], b[3], acc1, 0, 0, 0);
+    return acc0 + acc1;
 }
 
-// LDS image of the constants: [layout(2)][matrix(m+1)][pair(2)][lane(64)][2] doubles
-__device__ inline v4d lds_mat(const double* __restrict__ base, int mat, int lane) {
-    const v2d lo = *reinterpret_cast<const v2d*>(base + ((mat * 2 + 0) * 64 + lane) * 2);
-    const v2d hi = *reinterpret_cast<const v2d*>(base + ((mat * 2 + 1) * 64 + lane) * 2);
+// A-layout image of generator `mat` (0 = drift): [matrix][pair(2)][lane(64)][2] doubles
+__device__ inline v4d load_GA(const double* __restrict__ Gx, int mat, int lane) {
+    const v2d* p = reinterpret_cast<const v2d*>(Gx) + mat * 128 + lane;
+    const v2d lo = p[0], hi = p[64];
     return v4d{lo[0], lo[1], hi[0], hi[1]};
+}
+
+constexpr int kDF = 4;   // derivative integrators handled from registers in the copy wave
+
+// Derivative integrators x_{t+1} - x_t - h dx_t (reference unitary_smooth_pulse_problem.jl:15-16), generic
+// form: any count, any dimension.  `skip_small` skips the integrators the register fast path served.
+__device__ inline void deriv_rows_generic(const QcParams& P, const double* __restrict__ z0, const double* __restrict__ z1,
+                                          double h, double* __restrict__ Fb, double* __restrict__ Jb, int lane, bool skip_small) {
+    const bool ft = P.off_dt >= 0;
+    int r0 = P.s, jo = P.jo_d;
+    for (int d = 0; d < P.n_deriv; ++d) {
+        const int dim = P.ddim_i[d];
+        if (!(skip_small && dim <= 64)) {
+            for (int i = lane; i < dim; i += 64) {
+                const double dx = z0[P.dx_off[d] + i];
+                if (Fb) Fb[r0 + i] = z1[P.x_off[d] + i] - z0[P.x_off[d] + i] - h * dx;
+                if (Jb) {
+                    Jb[jo + i] = -1.0;
+                    Jb[jo + dim + i] = 1.0;
+                    Jb[jo + 2 * dim + i] = -h;
+                    if (ft) Jb[jo + 3 * dim + i] = -dx;
+                }
+            }
+        }
+        r0 += dim;
+        jo += (ft ? 4 : 3) * dim;
+    }
+}
+
+constexpr int kMU = 8;   // generators whose A-images are requested together and kept in registers
+
+// G = G_0 + sum_k a_k G_k (A-layout).  The first kMU drive images and their amplitudes are requested
+// in one batch (no load waits on another) and returned in gk/ak for reuse by the drive-column loop.
+__device__ inline v4d assemble_G(const QcParams& P, const double* __restrict__ Gx, const double* __restrict__ z0,
+                                 int lane, v4d (&gk)[kMU], double (&ak)[kMU]) {
+    const int m = P.m;
+    v4d Ga = load_GA(Gx, 0, lane);
+#pragma unroll
+    for (int u = 0; u < kMU; ++u) {
+        const int k = u < m ? u : (m > 0 ? m - 1 : 0);     // clamped: the load is unconditional
+        gk[u] = load_GA(Gx, m > 0 ? k + 1 : 0, lane);
+        ak[u] = (u < m) ? z0[P.off_a + k] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < kMU; ++u) Ga += ak[u] * gk[u];
+    for (int k = kMU; k < m; ++k) Ga += z0[P.off_a + k] * load_GA(Gx, k + 1, lane);
+    return Ga;
 }
 
 // Store a transposed tile: lane (g, j) reg r holds X[j][4r+g] of a 16 x 16 column-major block at p.
@@ -69,96 +120,43 @@ __device__ inline void store_tile_T(double* __restrict__ p, const v4d& x, int g,
     for (int r = 0; r < 4; ++r) qc_st8(p + (4 * r + g) * 16 + j, x[r], mode);
 }
 
-struct KnotRegs {
-    v4d u0, u1;
-};
-
-__device__ inline KnotRegs load_knots(const QcParams& P, const double* __restrict__ Z, long long t, int g, int jj) {
-    const double* u0p = Z + t * (long long)P.zdim + P.off_U + jj * 16 + g;
-    const double* u1p = u0p + P.zdim;
-    KnotRegs k;
-    k.u0 = v4d{u0p[0], u0p[4], u0p[8], u0p[12]};
-    k.u1 = v4d{u1p[0], u1p[4], u1p[8], u1p[12]};
-    return k;
-}
-
 template <bool JAC>
-__global__ __launch_bounds__(kThreads) void qc_mfma16_pade4_kernel(const QcParams P, const double* __restrict__ Z,
-                                                                   double* __restrict__ F, double* __restrict__ J,
-                                                                   int n_wg) {
-    extern __shared__ __attribute__((aligned(16))) double sm[];
+__global__ __launch_bounds__(kThreads, 2) void qc_mfma16_pade4_kernel(const QcParams P, const double* __restrict__ Z,
+                                                                   double* __restrict__ F, double* __restrict__ J) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int role = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0 compute wave, 1 copy wave
     const int m = P.m;
-    const int matsz = 256;                       // doubles per packed matrix
-    const double* ldsA = sm;                     // A-operand images
-    const double* ldsB = sm + (m + 1) * matsz;   // B/D-operand images
     const int g = lane >> 4, j = lane & 15, jj = j & 7;
     const bool left = j < 8;
     const bool ft = P.off_dt >= 0;
     const double c1 = P.c[1], c2 = P.c[2];
     const int sm_mode = P.store_mode;
-
-    // knot data of the first interval: in flight while the constants are staged
-    int vb = blockIdx.x;
-    int b = qc_xcd_remap(vb, n_wg) * kWaves + wave;
-    KnotRegs kn = load_knots(P, Z, P.t_begin + (b < P.n_int ? b : 0), g, jj);
-
-    {   // stage the constants: 2 (m+1) 256 doubles, kStage 16-byte loads in flight per thread
-        const int total2 = (m + 1) * matsz;
-        const v2d* __restrict__ src = reinterpret_cast<const v2d*>(P.Gx);
-        v2d* dst = reinterpret_cast<v2d*>(sm);
-        for (int base = tid; base < total2; base += kThreads * kStage) {
-            v2d tmp[kStage];
-#pragma unroll
-            for (int u = 0; u < kStage; ++u) {
-                const int i = base + u * kThreads;
-                tmp[u] = i < total2 ? src[i] : v2d{0.0, 0.0};
-            }
-#pragma unroll
-            for (int u = 0; u < kStage; ++u) {
-                const int i = base + u * kThreads;
-                if (i < total2) dst[i] = tmp[u];
-            }
-        }
-    }
-    __syncthreads();
-
+    const double* __restrict__ Gx = P.Gx;
     const v4d IdB = {(g == j) ? 1.0 : 0.0, (4 + g == j) ? 1.0 : 0.0, (8 + g == j) ? 1.0 : 0.0, (12 + g == j) ? 1.0 : 0.0};
 
-    for (; vb < n_wg; vb += gridDim.x) {
-        b = qc_xcd_remap(vb, n_wg) * kWaves + wave;   // local interval of this wave
-        const v4d u0 = kn.u0, u1 = kn.u1;
-        {   // request the next interval's knots now (persistent grids only)
-            const int vn = vb + gridDim.x;
-            if (vn < n_wg) {
-                const int bn = qc_xcd_remap(vn, n_wg) * kWaves + wave;
-                kn = load_knots(P, Z, P.t_begin + (bn < P.n_int ? bn : 0), g, jj);
-            }
-        }
-        if (b >= P.n_int) continue;
+    for (int vb = blockIdx.x; vb < P.n_int; vb += gridDim.x) {
+        const int b = qc_xcd_remap(vb, P.n_int);          // local interval of this workgroup
         const long long t = P.t_begin + b;
         const double* __restrict__ z0 = Z + t * (long long)P.zdim;
         const double* __restrict__ z1 = z0 + P.zdim;
-        const double h = ft ? z0[P.off_dt] : P.dt_fixed;
-
-        // ---- G in both operand layouts ---------------------------------------------------------------
-        v4d Ga = lds_mat(ldsA, 0, lane), Gb = lds_mat(ldsB, 0, lane);
-        for (int k = 0; k < m; ++k) {
-            const double a = z0[P.off_a + k];
-            const v4d xa = lds_mat(ldsA, k + 1, lane), xb = lds_mat(ldsB, k + 1, lane);
-            Ga += a * xa;
-            Gb += a * xb;
-        }
         double* __restrict__ Jb = JAC ? J + (size_t)b * P.jac_nnz : nullptr;
         double* __restrict__ Fb = F ? F + (size_t)b * P.ddim : nullptr;
-        const double hc1 = h * c1, hc2 = h * h * c2;
 
-        if (JAC) {
-            // ---- B^T, F^T and their N copies (issued first: 80 % of the interval's bytes) ------------
-            // A-layout(G^T) = B-layout(G) = Gb;  B-layout(G^T) = A-layout(G) = Ga;  D-layout(G^T) = Ga.
+        if (role == 1) {
+            // ================= copy wave: B^T, F^T and their N copies =================================
+            if (!JAC || (P.dbg_skip & 1)) continue;
+            __builtin_amdgcn_s_setprio(3);   // critical path: nothing reaches HBM before this wave's first store
+            QC_STAMP(P, b, lane, 0);
+            const double h = ft ? z0[P.off_dt] : P.dt_fixed;
+            v4d gk[kMU];
+            double ak[kMU];
+            const v4d Ga = assemble_G(P, Gx, z0, lane, gk, ak);
+            QC_STAMP(P, b, lane, 1);
+            // A-layout(G^T) = B-layout(G) = Gb;  B-layout(G^T) = D-layout(G^T) = A-layout(G) = Ga.
+            const v4d Gb = mm16(Ga, IdB);
             const v4d G2T = mm16(Gb, Ga);
+            const double hc1 = h * c1, hc2 = h * h * c2;
             v4d Fm, Bm;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -169,12 +167,47 @@ __global__ __launch_bounds__(kThreads) void qc_mfma16_pade4_kernel(const QcParam
             double* pF = Jb + P.jo_F;
             double* pB = Jb + P.jo_B;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) store_tile_T(pF + q * 256, Fm, g, j, sm_mode);
-#pragma unroll
-            for (int q = 0; q < 8; ++q) store_tile_T(pB + q * 256, Bm, g, j, sm_mode);
+            for (int q = 0; q < 8; ++q) {
+                store_tile_T(pF + q * 256, Fm, g, j, sm_mode);
+                store_tile_T(pB + q * 256, Bm, g, j, sm_mode);
+            }
+            __builtin_amdgcn_s_setprio(0);
+            QC_STAMP(P, b, lane, 2);
+            if (P.stamps != nullptr) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                QC_STAMP(P, b, lane, 3);
+            }
+            continue;
         }
 
-        // ---- Krylov products -----------------------------------------------------------------------
+        // ===================== compute wave ===========================================================
+        // its MFMA chain goes ahead of a copy wave that is only queueing stores on the same SIMD
+        if (P.dbg_skip & 2) continue;
+        __builtin_amdgcn_s_setprio(1);
+        QC_STAMP(P, b, lane, 4);
+        // knot data: U0, U1 in B-layout (both halves of the tile load the same 8 columns)
+        const double* u0p = z0 + P.off_U + jj * 16 + g;
+        const double* u1p = z1 + P.off_U + jj * 16 + g;
+        const v4d u0 = {u0p[0], u0p[4], u0p[8], u0p[12]};
+        const v4d u1 = {u1p[0], u1p[4], u1p[8], u1p[12]};
+        const double h = ft ? z0[P.off_dt] : P.dt_fixed;
+        // derivative integrators, fast path (<= kDF integrators of <= 64 rows): request their knot data
+        // now, together with the generator images; their few outputs are stored after the copies.
+        double dxv[kDF], dfv[kDF];
+        const bool dfast = P.n_deriv <= kDF;
+#pragma unroll
+        for (int d = 0; d < kDF; ++d) {
+            // unused slots (d >= n_deriv) have zero offsets/dims in QcParams: the loads stay in bounds
+            const int i = lane < P.ddim_i[d] ? lane : 0;
+            dxv[d] = z0[P.dx_off[d] + i];
+            dfv[d] = z1[P.x_off[d] + i] - z0[P.x_off[d] + i];
+        }
+        v4d gk[kMU];
+        double ak[kMU];
+        const v4d Ga = assemble_G(P, Gx, z0, lane, gk, ak);
+        const double hc1 = h * c1, hc2 = h * h * c2;
+        QC_STAMP(P, b, lane, 5);
+
         v4d W, Wsw;                               // W = [S | D], Wsw = [D | S]
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -185,6 +218,7 @@ __global__ __launch_bounds__(kThreads) void qc_mfma16_pade4_kernel(const QcParam
         const v4d P1 = mm16(Ga, W);               // [GS | GD]
         const v4d P1sw = swap8(P1);               // [GD | GS]
         const v4d P2 = mm16(Ga, P1sw);            // [G^2 D | G^2 S]
+        QC_STAMP(P, b, lane, 6);
         {   // E = [delta | d/dh] (values are formed on the left half, d/dh moved to the right half)
             v4d dl, dh;
             const double d1 = -c1, d2 = 2.0 * c2 * h;
@@ -208,36 +242,22 @@ __global__ __launch_bounds__(kThreads) void qc_mfma16_pade4_kernel(const QcParam
                 }
             }
         }
-        // derivative integrators (a few lanes)
-        {
-            int r0 = P.s, jo = P.jo_d;
-            for (int d = 0; d < P.n_deriv; ++d) {
-                const int dim = P.ddim_i[d];
-                for (int i = lane; i < dim; i += 64) {
-                    const double dx = z0[P.dx_off[d] + i];
-                    if (Fb) Fb[r0 + i] = z1[P.x_off[d] + i] - z0[P.x_off[d] + i] - h * dx;
-                    if (JAC) {
-                        Jb[jo + i] = -1.0;
-                        Jb[jo + dim + i] = 1.0;
-                        Jb[jo + 2 * dim + i] = -h;
-                        if (ft) Jb[jo + 3 * dim + i] = -dx;
-                    }
-                }
-                r0 += dim;
-                jo += (ft ? 4 : 3) * dim;
-            }
+        QC_STAMP(P, b, lane, 7);
+        if (!JAC) {   // residual-only launch has no copy wave: derivative residual rows here
+            deriv_rows_generic(P, z0, z1, h, Fb, nullptr, lane, false);
+            continue;
         }
-        if (!JAC) continue;
 
         // ---- drive columns ---------------------------------------------------------------------------
         v4d Q;                                    // [Q0 | Q1] = [-h c1 S + h^2 c2 GD | h^2 c2 D]
 #pragma unroll
         for (int r = 0; r < 4; ++r) Q[r] = left ? (-hc1 * W[r] + hc2 * P1sw[r]) : (hc2 * W[r]);
         double* pa = Jb + P.jo_a;
-        int k = 0;
-        for (; k + 1 < m; k += 2) {
-            const v4d R1 = mm16(lds_mat(ldsA, k + 1, lane), Q);    // [G_k Q0 | G_k Q1]
-            const v4d R2 = mm16(lds_mat(ldsA, k + 2, lane), Q);    // [G_k+1 Q0 | G_k+1 Q1]
+        // drive pair (k, k+1): A-images a1, a2 (a2 ignored when k+1 == m)
+        auto drive_pair = [&](int k, const v4d& a1, const v4d& a2) {
+            const bool two = k + 1 < m;
+            const v4d R1 = mm16(a1, Q);            // [G_k Q0 | G_k Q1]
+            const v4d R2 = mm16(a2, Q);            // [G_k+1 Q0 | G_k+1 Q1]
             const v4d R1sw = swap8(R1), R2sw = swap8(R2);
             v4d X, Y;
 #pragma unroll
@@ -247,15 +267,48 @@ __global__ __launch_bounds__(kThreads) void qc_mfma16_pade4_kernel(const QcParam
             }
             const v4d Tt = mm16(Ga, X);            // [G G_k Q1 | G G_k+1 Q1]
             Y += Tt;                               // [d/da_k | d/da_k+1]
-            store_tile_T(pa + (size_t)k * 128, mm16(Y, IdB), g, j, sm_mode);
-        }
-        if (k < m) {                               // odd drive count: last column alone
-            const v4d R1 = mm16(lds_mat(ldsA, k + 1, lane), Q);
-            const v4d Tt = mm16(Ga, swap8(R1));
-            const v4d YT = mm16(R1 + Tt, IdB);     // left half valid: tile columns 0..7
+            const v4d YT = mm16(Y, IdB);           // lane (g, j) reg r = Y[j][4r+g]
             double* p = pa + (size_t)k * 128;
 #pragma unroll
-            for (int r = 0; r < 2; ++r) qc_st8(p + (4 * r + g) * 16 + j, YT[r], sm_mode);
+            for (int r = 0; r < 4; ++r)
+                if (r < 2 || two) qc_st8(p + (4 * r + g) * 16 + j, YT[r], sm_mode);   // tile columns >= 8 are drive k+1
+        };
+#pragma unroll
+        for (int u = 0; u < kMU; u += 2) {
+            if (u < m) {
+                drive_pair(u, gk[u], gk[u + 1]);
+                QC_STAMP(P, b, lane, 8 + (u >> 1 < 3 ? u >> 1 : 3));
+            }
+        }
+        for (int k = kMU; k < m; k += 2)
+            drive_pair(k, load_GA(Gx, k + 1, lane), load_GA(Gx, k + 2 <= m ? k + 2 : k + 1, lane));
+        {   // derivative integrator rows: residual x_{t+1} - x_t - h dx_t and the 4 (3) diagonal blocks
+            int r0 = P.s, jo = P.jo_d;
+            bool all_fast = dfast;
+#pragma unroll
+            for (int d = 0; d < kDF; ++d) {
+                if (d < P.n_deriv) {
+                    const int dim = P.ddim_i[d];
+                    if (dfast && dim <= 64) {
+                        if (lane < dim) {
+                            if (Fb) Fb[r0 + lane] = dfv[d] - h * dxv[d];
+                            Jb[jo + lane] = -1.0;
+                            Jb[jo + dim + lane] = 1.0;
+                            Jb[jo + 2 * dim + lane] = -h;
+                            if (ft) Jb[jo + 3 * dim + lane] = -dxv[d];
+                        }
+                    } else {
+                        all_fast = false;
+                    }
+                    r0 += dim;
+                    jo += (ft ? 4 : 3) * dim;
+                }
+            }
+            if (!all_fast) deriv_rows_generic(P, z0, z1, h, Fb, Jb, lane, dfast);
+        }
+        if (P.stamps != nullptr) {   // diagnostic: time until this wave's stores have left the CU
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            QC_STAMP(P, b, lane, 12);
         }
     }
 }
@@ -266,31 +319,27 @@ bool qc_mfma_supported(const QcParams& P) {
     return P.integrator == QC_PADE && P.p == 2 && P.n == 16 && P.m <= 32;
 }
 
-size_t qc_mfma_gx_doubles(const QcParams& P) { return (size_t)2 * (P.m + 1) * 256; }
+size_t qc_mfma_gx_doubles(const QcParams& P) { return (size_t)(P.m + 1) * 256; }
 
-// Packs the (m+1) generators (column-major n x n, index 0 = drift) into the LDS image
-// [layout][matrix][pair][lane][2]:  A-layout lane (g, i) reg kk = X[i][4kk+g];  B/D-layout lane (g, j) reg r = X[4r+g][j].
+// Packs the (m+1) generators (column-major n x n, index 0 = drift) into the lane-ordered A-layout
+// image [matrix][pair][lane][2]:  lane (g, i) reg kk = X[i][4kk+g].
 void qc_mfma_pack_G(const QcParams& P, const double* G, double* Gx) {
     const int n = 16, M = P.m + 1;
     for (int mat = 0; mat < M; ++mat) {
         const double* A = G + (size_t)mat * n * n;
-        auto At = [&](int row, int col) { return A[(size_t)col * n + row]; };  // col-major
         for (int pr = 0; pr < 2; ++pr)
             for (int l = 0; l < 64; ++l)
                 for (int e = 0; e < 2; ++e) {
-                    const int g = l >> 4, i = l & 15, r = 2 * pr + e;
-                    Gx[(((size_t)0 * M + mat) * 2 + pr) * 128 + l * 2 + e] = At(i, 4 * r + g);      // A-layout
-                    Gx[(((size_t)1 * M + mat) * 2 + pr) * 128 + l * 2 + e] = At(4 * r + g, i);      // B/D-layout
+                    const int g = l >> 4, i = l & 15, kk = 2 * pr + e;
+                    Gx[((size_t)mat * 2 + pr) * 128 + l * 2 + e] = A[(size_t)(4 * kk + g) * n + i];
                 }
     }
 }
 
 hipError_t qc_launch_mfma_F_jac(const QcParams& P, const double* dZ, double* dF, double* dJ, hipStream_t st) {
-    const int n_wg = (P.n_int + kWaves - 1) / kWaves;
-    const int grid = n_wg < kMaxGrid ? n_wg : kMaxGrid;
-    const size_t lds = qc_mfma_gx_doubles(P) * sizeof(double);
-    if (dJ) hipLaunchKernelGGL(qc_mfma16_pade4_kernel<true>, dim3(grid), dim3(kThreads), lds, st, P, dZ, dF, dJ, n_wg);
-    else hipLaunchKernelGGL(qc_mfma16_pade4_kernel<false>, dim3(grid), dim3(kThreads), lds, st, P, dZ, dF, dJ, n_wg);
+    const int grid = P.n_int < kMaxGrid ? P.n_int : kMaxGrid;
+    if (dJ) hipLaunchKernelGGL(qc_mfma16_pade4_kernel<true>, dim3(grid), dim3(kThreads), 0, st, P, dZ, dF, dJ);
+    else hipLaunchKernelGGL(qc_mfma16_pade4_kernel<false>, dim3(grid), dim3(64), 0, st, P, dZ, dF, dJ);
     return hipGetLastError();
 }
 

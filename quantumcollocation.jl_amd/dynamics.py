@@ -223,6 +223,16 @@ class QuantumDynamics:
             self._h, self._dev_ptr(Z, self.dims.Z_len, "Z"), self._dev_ptr(F, self.dims.F_len, "F"),
             self._dev_ptr(J, self.dims.jac_nnz, "J"), C.c_void_p(st.cuda_stream)), self._h)
 
+    def bind_F_dF_device(self, Z: torch.Tensor, F: Optional[torch.Tensor], J: Optional[torch.Tensor], stream=None):
+        """Pre-validated launcher: returns a zero-argument callable that enqueues one evaluation (returns the
+        C status code).  Keeps Python's per-call argument checking out of launch-bound loops; the tensors must
+        outlive the callable."""
+        import functools
+        st = stream if stream is not None else torch.cuda.current_stream(self.device)
+        return functools.partial(
+            _lib.lib.qc_eval_F_jac_dev, self._h, self._dev_ptr(Z, self.dims.Z_len, "Z"),
+            self._dev_ptr(F, self.dims.F_len, "F"), self._dev_ptr(J, self.dims.jac_nnz, "J"), C.c_void_p(st.cuda_stream))
+
     def mu_d2F_device(self, Z: torch.Tensor, mu: torch.Tensor, H: torch.Tensor, stream=None) -> None:
         st = stream if stream is not None else torch.cuda.current_stream(self.device)
         _lib.check(_lib.lib.qc_eval_hess_dev(
