@@ -442,8 +442,10 @@ extern "C" int qc_eval_hess_dev(qc_handle* h, const double* dZ, const double* dm
     if ((rc = check_align(h, dhvals, 16, "dhvals"))) return rc;
     if (h->prm.n_int == 0) return QC_OK;
     hipError_t e;
-    if (h->kernel == QC_KERNEL_MFMA) e = qc_launch_mfma_hess(h->prm, dZ, dmu, dhvals, (hipStream_t)stream);
-    else e = qc_launch_lds_hess(h->prm, dZ, dmu, dhvals, h->lds_bytes_hess, (hipStream_t)stream);
+    if (h->kernel == QC_KERNEL_MFMA && qc_mfma_hess_supported(h->prm))
+        e = qc_launch_mfma_hess(h->prm, dZ, dmu, dhvals, (hipStream_t)stream);
+    else
+        e = qc_launch_lds_hess(h->prm, dZ, dmu, dhvals, h->lds_bytes_hess, (hipStream_t)stream);
     if (e != hipSuccess) return fail(&h->err, QC_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
     return QC_OK;
 }

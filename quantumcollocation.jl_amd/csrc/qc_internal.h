@@ -66,6 +66,7 @@ hipError_t qc_launch_lds_F_jac(const QcParams& P, const double* dZ, double* dF, 
 hipError_t qc_launch_lds_hess(const QcParams& P, const double* dZ, const double* dMu, double* dH, size_t lds,
                               hipStream_t st);
 bool qc_mfma_supported(const QcParams& P);
+bool qc_mfma_hess_supported(const QcParams& P);
 size_t qc_mfma_gx_doubles(const QcParams& P);
 void qc_mfma_pack_G(const QcParams& P, const double* G_host, double* Gx_host);
 hipError_t qc_launch_mfma_F_jac(const QcParams& P, const double* dZ, double* dF, double* dJ, hipStream_t st);

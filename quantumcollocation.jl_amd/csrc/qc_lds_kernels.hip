@@ -190,6 +190,293 @@ __global__ __launch_bounds__(kThreads) void qc_lds_pade_kernel(const QcParams P,
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+//  Hessian of the Lagrangian  mu_t^T delta_t  (written for general order 2p).
+//  With M = reshape(mu_t[0:s], n, N), M_q = (G^T)^q M, P^(k)_q = G^q W_k (W_k = D for even k, -S odd):
+//    (U1,h)   = sum_k (-1)^k k c_k h^{k-1} M_k            (U0,h) = - sum_k k c_k h^{k-1} M_k
+//    (h,h)    = sum_k k(k-1) c_k h^{k-2} <M, P^(k)_k>
+//    (U1,a_j) = sum_r (G^r)^T G_j^T YB_r,  YB_r = sum_{k>r} (-1)^k c_k h^k M_{k-1-r}
+//    (U0,a_j) = -sum_r (G^r)^T G_j^T YF_r, YF_r = sum_{k>r}        c_k h^k M_{k-1-r}
+//    (a_j,h)  = <Lam', G_j>,  Lam' = sum_i M_i Q'_i^T,  Q'_i = sum_{k>i} k c_k h^{k-1} P^(k)_{k-1-i}
+//    (a_i,a_j)= S_ij + S_ji,  S_ij = sum_{k>=2} c_k h^k sum_{al=0..k-2} <A_i^al, C_j^(par(k), k-2-al)>
+//               A_i^al = G_i^T M_al,   C_j^(s,0) = G_j P^s_0,  C_j^(s,t) = G C_j^(s,t-1) + G_j P^s_t
+//    derivative integrators: d2/d(dx_i) dh = -mu_i
+//  (U,U) blocks vanish.  Checked against complex-step differentiation in tests/test_oracle_math.py via the oracle.
+// ------------------------------------------------------------------------------------------------
+struct LdsHessLayout {
+    int z0, z1, mu, Gp, PD, PS, Mq, YB, YF, Qp, Lam, S, chunk, total;
+    int cj;  // drives per chunk
+};
+
+__host__ __device__ inline LdsHessLayout hess_layout(const QcParams& P, int cj) {
+    LdsHessLayout L;
+    const int n2 = P.n * P.n, nN = P.n * P.N, p = P.p, m = P.m > 0 ? P.m : 1;
+    int o = 0;
+    L.z0 = o; o += even_up(P.zdim);
+    L.z1 = o; o += even_up(P.zdim);
+    L.mu = o; o += even_up(P.ddim);
+    L.Gp = o; o += p * n2;
+    L.PD = o; o += (p + 1) * nN;
+    L.PS = o; o += (p + 1) * nN;
+    L.Mq = o; o += (p + 1) * nN;
+    L.YB = o; o += p * nN;
+    L.YF = o; o += p * nN;
+    L.Qp = o; o += p * nN;
+    L.Lam = o; o += n2;
+    L.S = o; o += even_up(m * m);
+    L.cj = cj;
+    // chunk space: max( RB+RF for cj drives , A for cj drives + C for cj drives )
+    const int pm1 = p > 1 ? p - 1 : 1;
+    const int a = 2 * cj * p * nN, b = cj * pm1 * nN + cj * 2 * pm1 * nN;
+    L.chunk = o; o += a > b ? a : b;
+    L.total = o;
+    return L;
+}
+
+// C (n x ncol) = A^T (A is n x n col-major) * X
+__device__ inline void matmul_T_lds(double* __restrict__ C, const double* __restrict__ A, const double* __restrict__ X,
+                                    int n, int ncol, int tid) {
+    for (int idx = tid; idx < n * ncol; idx += kThreads) {
+        const int r = idx % n, c = idx / n;
+        double acc = 0.0;
+        for (int k = 0; k < n; ++k) acc = fma(A[k + n * r], X[k + n * c], acc);
+        C[idx] = acc;
+    }
+}
+
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(kThreads) void qc_lds_pade_hess_kernel(const QcParams P, const double* __restrict__ Z,
+                                                                    const double* __restrict__ Mu, double* __restrict__ H,
+                                                                    int cj) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = qc_xcd_remap(blockIdx.x, gridDim.x);
+    const long long t = P.t_begin + b;
+    const int n = P.n, N = P.N, s = P.s, m = P.m, p = P.p;
+    const int n2 = n * n, nN = n * N;
+    const LdsHessLayout L = hess_layout(P, cj);
+    double* z0 = sm + L.z0;
+    double* z1 = sm + L.z1;
+    double* mu = sm + L.mu;
+    double* Gp = sm + L.Gp;
+    double* PD = sm + L.PD;
+    double* PS = sm + L.PS;
+    double* Mq = sm + L.Mq;
+    double* YB = sm + L.YB;
+    double* YF = sm + L.YF;
+    double* Qp = sm + L.Qp;
+    double* Lam = sm + L.Lam;
+    double* S = sm + L.S;
+    double* CH = sm + L.chunk;
+    const bool ft = P.off_dt >= 0;
+    double* Hb = H + (size_t)b * P.hess_nnz;
+
+    const double* zt = Z + t * (long long)P.zdim;
+    const double* mut = Mu + t * (long long)P.ddim;
+    for (int i = tid; i < P.zdim; i += kThreads) { z0[i] = zt[i]; z1[i] = zt[P.zdim + i]; }
+    for (int i = tid; i < P.ddim; i += kThreads) mu[i] = mut[i];
+    for (int i = tid; i < m * m; i += kThreads) S[i] = 0.0;
+    __syncthreads();
+    const double h = ft ? z0[P.off_dt] : P.dt_fixed;
+
+    for (int idx = tid; idx < n2; idx += kThreads) {
+        double g = P.G[idx];
+        for (int j = 0; j < m; ++j) g = fma(z0[P.off_a + j], P.G[(size_t)(j + 1) * n2 + idx], g);
+        Gp[idx] = g;
+    }
+    for (int idx = tid; idx < nN; idx += kThreads) {
+        const double u0 = z0[P.off_U + idx], u1 = z1[P.off_U + idx];
+        PD[idx] = u1 - u0;
+        PS[idx] = -(u1 + u0);
+        Mq[idx] = mu[idx];
+    }
+    __syncthreads();
+    for (int k = 1; k <= p; ++k) {
+        if (k < p) matmul_lds(Gp + k * n2, Gp, Gp + (k - 1) * n2, n, n, tid);
+        matmul_lds(PD + k * nN, Gp, PD + (k - 1) * nN, n, N, tid);
+        matmul_lds(PS + k * nN, Gp, PS + (k - 1) * nN, n, N, tid);
+        matmul_T_lds(Mq + k * nN, Gp, Mq + (k - 1) * nN, n, N, tid);
+        __syncthreads();
+    }
+
+    // ---- elementwise blocks: (U,h), YB, YF, Q' ---------------------------------------------------------
+    for (int idx = tid; idx < nN; idx += kThreads) {
+        if (ft) {
+            double vB = 0.0, vF = 0.0, hk1 = 1.0;      // h^{k-1}
+            for (int k = 1; k <= p; ++k) {
+                const double v = P.c[k] * (double)k * hk1 * Mq[k * nN + idx];
+                vF += v;
+                vB += (k & 1) ? -v : v;
+                hk1 *= h;
+            }
+            Hb[P.ho_hU + idx] = vB;
+            Hb[P.ho_Uh + idx] = -vF;
+        }
+        for (int r = 0; r < p; ++r) {
+            double yb = 0.0, yf = 0.0, qp = 0.0, hk = 1.0, hk1 = 1.0;
+            for (int k = 1; k <= p; ++k) {
+                hk1 = hk;          // h^{k-1}
+                hk *= h;           // h^k
+                if (k >= r + 1) {
+                    const double mv = P.c[k] * hk * Mq[(k - 1 - r) * nN + idx];
+                    yf += mv;
+                    yb += (k & 1) ? -mv : mv;
+                    qp = fma(P.c[k] * (double)k * hk1, ((k & 1) ? PS : PD)[(k - 1 - r) * nN + idx], qp);
+                }
+            }
+            YB[r * nN + idx] = yb;
+            YF[r * nN + idx] = yf;
+            Qp[r * nN + idx] = qp;
+        }
+    }
+    // derivative integrators: -mu
+    if (ft) {
+        int r0 = s, o = P.ho_d;
+        for (int d = 0; d < P.n_deriv; ++d) {
+            for (int i = tid; i < P.ddim_i[d]; i += kThreads) Hb[o + i] = -mu[r0 + i];
+            r0 += P.ddim_i[d];
+            o += P.ddim_i[d];
+        }
+    }
+    __syncthreads();
+    if (ft) {
+        // (h,h): one wave reduces
+        if (wave == 0) {
+            double acc = 0.0;
+            for (int e = lane; e < nN; e += 64) {
+                double hk2 = 1.0;   // h^{k-2}
+                for (int k = 2; k <= p; ++k) {
+                    acc = fma(P.c[k] * (double)(k * (k - 1)) * hk2 * Mq[e], ((k & 1) ? PS : PD)[k * nN + e], acc);
+                    hk2 *= h;
+                }
+            }
+            acc = wave_sum(acc);
+            if (lane == 0) Hb[P.ho_hh] = acc;
+        }
+        // Lam' = sum_i M_i Q'_i^T  (n x n)
+        for (int idx = tid; idx < n2; idx += kThreads) {
+            const int r = idx % n, c = idx / n;
+            double acc = 0.0;
+            for (int i = 0; i < p; ++i)
+                for (int col = 0; col < N; ++col) acc = fma(Mq[i * nN + col * n + r], Qp[i * nN + col * n + c], acc);
+            Lam[idx] = acc;
+        }
+        __syncthreads();
+        for (int j = wave; j < m; j += kThreads / 64) {       // (a_j, h) = <Lam', G_j>
+            const double* Gj = P.G + (size_t)(j + 1) * n2;
+            double acc = 0.0;
+            for (int e = lane; e < n2; e += 64) acc = fma(Lam[e], Gj[e], acc);
+            acc = wave_sum(acc);
+            if (lane == 0) Hb[P.ho_ah + j] = acc;
+        }
+    }
+    __syncthreads();
+
+    // ---- (U, a_j) blocks, cj drives per pass ---------------------------------------------------------------
+    double* RB = CH;
+    double* RF = CH + cj * p * nN;
+    for (int j0 = 0; j0 < m; j0 += cj) {
+        const int jc = min(cj, m - j0);
+        for (int idx = tid; idx < jc * p * nN; idx += kThreads) {
+            const int r = idx % n, c = (idx / n) % N, rr = (idx / nN) % p, jj = idx / (nN * p);
+            const double* __restrict__ Gj = P.G + (size_t)(j0 + jj + 1) * n2;     // G_j^T X: sum_k G_j[k][r] X[k][c]
+            double ab = 0.0, af = 0.0;
+            for (int k = 0; k < n; ++k) {
+                const double gv = Gj[k + n * r];
+                ab = fma(gv, YB[rr * nN + c * n + k], ab);
+                af = fma(gv, YF[rr * nN + c * n + k], af);
+            }
+            RB[idx] = ab;
+            RF[idx] = af;
+        }
+        __syncthreads();
+        for (int idx = tid; idx < jc * nN; idx += kThreads) {
+            const int r = idx % n, c = (idx / n) % N, jj = idx / nN;
+            double ab = RB[jj * p * nN + c * n + r], af = RF[jj * p * nN + c * n + r];
+            for (int rr = 1; rr < p; ++rr) {
+                const double* A = Gp + (rr - 1) * n2;                               // (G^rr)^T
+                const double* XB = RB + jj * p * nN + rr * nN + c * n;
+                const double* XF = RF + jj * p * nN + rr * nN + c * n;
+                for (int k = 0; k < n; ++k) {
+                    const double gv = A[k + n * r];
+                    ab = fma(gv, XB[k], ab);
+                    af = fma(gv, XF[k], af);
+                }
+            }
+            Hb[P.ho_aU + (size_t)(j0 + jj) * s + c * n + r] = ab;
+            Hb[P.ho_Ua + (size_t)(j0 + jj) * s + c * n + r] = -af;
+        }
+        __syncthreads();
+    }
+
+    // ---- (a_i, a_j) ---------------------------------------------------------------------------------------
+    if (p >= 2) {
+        const int pm1 = p - 1;
+        double* Ai = CH;                       // [ii][al][nN]
+        double* Cj = CH + cj * pm1 * nN;       // [jj][par(2)][t][nN]
+        for (int j0 = 0; j0 < m; j0 += cj) {
+            const int jc = min(cj, m - j0);
+            // C_j^(s,t), t = 0..p-2, sequential in t
+            for (int tq = 0; tq < pm1; ++tq) {
+                for (int idx = tid; idx < jc * 2 * nN; idx += kThreads) {
+                    const int r = idx % n, c = (idx / n) % N, par = (idx / nN) & 1, jj = idx / (2 * nN);
+                    const double* __restrict__ Gj = P.G + (size_t)(j0 + jj + 1) * n2;
+                    const double* Pt = (par ? PS : PD) + tq * nN + c * n;
+                    double acc = 0.0;
+                    for (int k = 0; k < n; ++k) acc = fma(Gj[r + n * k], Pt[k], acc);
+                    if (tq > 0) {
+                        const double* Cp = Cj + ((jj * 2 + par) * pm1 + tq - 1) * nN + c * n;
+                        for (int k = 0; k < n; ++k) acc = fma(Gp[r + n * k], Cp[k], acc);
+                    }
+                    Cj[((jj * 2 + par) * pm1 + tq) * nN + c * n + r] = acc;
+                }
+                __syncthreads();
+            }
+            for (int i0 = 0; i0 < m; i0 += cj) {
+                const int ic = min(cj, m - i0);
+                for (int idx = tid; idx < ic * pm1 * nN; idx += kThreads) {
+                    const int r = idx % n, c = (idx / n) % N, al = (idx / nN) % pm1, ii = idx / (nN * pm1);
+                    const double* __restrict__ Gi = P.G + (size_t)(i0 + ii + 1) * n2;
+                    const double* Mx = Mq + al * nN + c * n;
+                    double acc = 0.0;
+                    for (int k = 0; k < n; ++k) acc = fma(Gi[k + n * r], Mx[k], acc);   // G_i^T M_al
+                    Ai[idx] = acc;
+                }
+                __syncthreads();
+                for (int pr = wave; pr < ic * jc; pr += kThreads / 64) {
+                    const int ii = pr % ic, jj = pr / ic;
+                    double acc = 0.0;
+                    for (int e = lane; e < nN; e += 64) {
+                        double hk = h;
+                        for (int k = 2; k <= p; ++k) {
+                            hk *= h;
+                            const double ck = P.c[k] * hk;
+                            const double* Cb = Cj + ((jj * 2 + (k & 1)) * pm1) * nN + e;
+                            double tsum = 0.0;
+                            for (int al = 0; al <= k - 2; ++al) tsum = fma(Ai[(ii * pm1 + al) * nN + e], Cb[(k - 2 - al) * nN], tsum);
+                            acc = fma(ck, tsum, acc);
+                        }
+                    }
+                    acc = wave_sum(acc);
+                    if (lane == 0) S[(i0 + ii) * m + (j0 + jj)] = acc;
+                }
+                __syncthreads();
+            }
+        }
+    }
+    for (int idx = tid; idx < m * (m + 1) / 2; idx += kThreads) {
+        int j = 0;
+        while ((j + 1) * (j + 2) / 2 <= idx) ++j;
+        const int i = idx - j * (j + 1) / 2;
+        Hb[P.ho_aa + idx] = (p >= 2) ? S[i * m + j] + S[j * m + i] : 0.0;
+    }
+}
 }  // namespace
 
 size_t qc_lds_bytes_jac(const QcParams& P) { return (size_t)jac_layout(P).total * sizeof(double); }
@@ -215,8 +502,25 @@ hipError_t qc_launch_lds_F_jac(const QcParams& P, const double* dZ, double* dF, 
     return hipGetLastError();
 }
 
-size_t qc_lds_bytes_hess(const QcParams& P) { (void)P; return 0; }
+static int hess_chunk(const QcParams& P) {
+    int cj = P.m > 0 ? P.m : 1;
+    while (cj > 1 && (size_t)hess_layout(P, cj).total * sizeof(double) > 96 * 1024) cj = (cj + 1) / 2;
+    return cj;
+}
 
-hipError_t qc_launch_lds_hess(const QcParams&, const double*, const double*, double*, size_t, hipStream_t) {
-    return hipErrorNotSupported;
+size_t qc_lds_bytes_hess(const QcParams& P) {
+    if (P.integrator != QC_PADE) return 0;
+    return (size_t)hess_layout(P, hess_chunk(P)).total * sizeof(double);
+}
+
+hipError_t qc_launch_lds_hess(const QcParams& P, const double* dZ, const double* dMu, double* dH, size_t lds, hipStream_t st) {
+    if (P.integrator != QC_PADE) return hipErrorNotSupported;
+    const int cj = hess_chunk(P);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qc_lds_pade_hess_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(qc_lds_pade_hess_kernel, dim3(P.n_int), dim3(kThreads), lds, st, P, dZ, dMu, dH, cj);
+    return hipGetLastError();
 }

@@ -319,6 +319,8 @@ bool qc_mfma_supported(const QcParams& P) {
     return P.integrator == QC_PADE && P.p == 2 && P.n == 16 && P.m <= 32;
 }
 
+bool qc_mfma_hess_supported(const QcParams&) { return false; }
+
 size_t qc_mfma_gx_doubles(const QcParams& P) { return (size_t)(P.m + 1) * 256; }
 
 // Packs the (m+1) generators (column-major n x n, index 0 = drift) into the lane-ordered A-layout
