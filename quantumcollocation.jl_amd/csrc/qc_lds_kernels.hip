@@ -49,6 +49,12 @@ __device__ inline void matmul_lds(double* __restrict__ C, const double* __restri
     }
 }
 
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
 template <bool JAC>
 __global__ __launch_bounds__(kThreads) void qc_lds_pade_kernel(const QcParams P, const double* __restrict__ Z,
                                                                double* __restrict__ F, double* __restrict__ J) {
@@ -245,11 +251,6 @@ __device__ inline void matmul_T_lds(double* __restrict__ C, const double* __rest
     }
 }
 
-__device__ inline double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
 
 __global__ __launch_bounds__(kThreads) void qc_lds_pade_hess_kernel(const QcParams P, const double* __restrict__ Z,
                                                                     const double* __restrict__ Mu, double* __restrict__ H,
@@ -477,13 +478,253 @@ __global__ __launch_bounds__(kThreads) void qc_lds_pade_hess_kernel(const QcPara
         Hb[P.ho_aa + idx] = (p >= 2) ? S[i * m + j] + S[j * m + i] : 0.0;
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+//  Exponential integrator (reference unitary_smooth_pulse_problem.jl:168-170, README.md:79):
+//      delta = U1 - E U0,  E = exp(hG)
+//      d/dU1 = I,  d/dU0 = -I_N (x) E,  d/dh = -G E U0,  d/da_j = -L_exp(hG; h G_j) U0      
+//  E and the Frechet derivatives L_j come from ONE scaled Taylor polynomial (degree kExpDeg at
+//  ||Y||_1 <= 1/4, truncation < 3e-18) differentiated term by term,
+//      A_k = A_{k-1} Y / k,     D_k = (D_{k-1} Y + A_{k-1} E_j) / k,     Y = hG / 2^sq, E_j = h G_j / 2^sq
+//  followed by sq squarings  L <- E L + L E,  E <- E E.  No linear solve, no branch on the data
+//  except the squaring count, which is taken from ||hG||_1 (non-finite input: sq = 0, NaNs propagate).
+// ------------------------------------------------------------------------------------------------
+constexpr int kExpDeg = 12;
+
+struct LdsExpLayout {
+    int z0, z1, Gm, Y, A0, A1, E0, Ecur, Etmp, D0, D1, Ls, EU, red, total;
+};
+
+__host__ __device__ inline LdsExpLayout exp_layout(const QcParams& P, int cj) {
+    LdsExpLayout L;
+    const int n2 = P.n * P.n, nN = P.n * P.N;
+    int o = 0;
+    L.z0 = o; o += even_up(P.zdim);
+    L.z1 = o; o += even_up(P.zdim);
+    L.Gm = o; o += n2;
+    L.Y = o; o += n2;
+    L.A0 = o; o += n2;
+    L.A1 = o; o += n2;
+    L.E0 = o; o += n2;
+    L.Ecur = o; o += n2;
+    L.Etmp = o; o += n2;
+    L.D0 = o; o += cj * n2;
+    L.D1 = o; o += cj * n2;
+    L.Ls = o; o += cj * n2;
+    L.EU = o; o += nN;
+    L.red = o; o += 8;
+    L.total = o;
+    return L;
+}
+
+template <bool JAC>
+__global__ __launch_bounds__(kThreads) void qc_lds_exp_kernel(const QcParams P, const double* __restrict__ Z,
+                                                              double* __restrict__ F, double* __restrict__ J, int cj) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = qc_xcd_remap(blockIdx.x, gridDim.x);
+    const long long t = P.t_begin + b;
+    const int n = P.n, N = P.N, s = P.s, m = P.m;
+    const int n2 = n * n, nN = n * N;
+    const LdsExpLayout L = exp_layout(P, cj);
+    double* z0 = sm + L.z0;
+    double* z1 = sm + L.z1;
+    double* Gm = sm + L.Gm;
+    double* Y = sm + L.Y;
+    double* Abuf[2] = {sm + L.A0, sm + L.A1};
+    double* E0 = sm + L.E0;
+    double* Ecur = sm + L.Ecur;
+    double* Etmp = sm + L.Etmp;
+    double* Dbuf[2] = {sm + L.D0, sm + L.D1};
+    double* Ls = sm + L.Ls;
+    double* EU = sm + L.EU;
+    double* red = sm + L.red;
+    const bool ft = P.off_dt >= 0;
+    double* Fb = F ? F + (size_t)b * P.ddim : nullptr;
+    double* Jb = JAC ? J + (size_t)b * P.jac_nnz : nullptr;
+
+    const double* zt = Z + t * (long long)P.zdim;
+    for (int i = tid; i < P.zdim; i += kThreads) { z0[i] = zt[i]; z1[i] = zt[P.zdim + i]; }
+    __syncthreads();
+    const double h = ft ? z0[P.off_dt] : P.dt_fixed;
+    for (int idx = tid; idx < n2; idx += kThreads) {
+        double g = P.G[idx];
+        for (int j = 0; j < m; ++j) g = fma(z0[P.off_a + j], P.G[(size_t)(j + 1) * n2 + idx], g);
+        Gm[idx] = g;
+    }
+    __syncthreads();
+    // ||hG||_1 = max column sum: wave w reduces columns w, w+4, ...
+    {
+        double best = 0.0;
+        for (int c = wave; c < n; c += kThreads / 64) {
+            double acc = 0.0;
+            for (int r = lane; r < n; r += 64) acc += fabs(h * Gm[r + n * c]);
+            acc = wave_sum(acc);
+            best = fmax(best, acc);     // fmax drops NaN: handled below through isfinite(h*G) of the sum
+            if (!(acc == acc)) best = acc;
+        }
+        if (lane == 0) red[wave] = best;
+    }
+    __syncthreads();
+    int sq = 0;
+    {
+        double nrm = 0.0;
+        bool bad = false;
+        for (int w = 0; w < kThreads / 64; ++w) { const double v = red[w]; if (!(v == v) || v > 1e300) bad = true; nrm = fmax(nrm, v); }
+        if (!bad && nrm > 0.25) {
+            int e;
+            (void)frexp(nrm / 0.25, &e);      // nrm/0.25 = f * 2^e, f in [0.5, 1)  ->  ceil(log2) <= e
+            sq = e;
+            if (ldexp(0.25, e - 1) >= nrm) sq = e - 1;
+            if (sq < 0) sq = 0;
+            if (sq > 60) sq = 60;
+        }
+    }
+    const double sc = ldexp(1.0, -sq);
+    for (int idx = tid; idx < n2; idx += kThreads) {
+        Y[idx] = h * sc * Gm[idx];
+        const double id = (idx % n == idx / n) ? 1.0 : 0.0;
+        E0[idx] = id;
+    }
+    __syncthreads();
+
+    const int nchunks = (JAC && m > 0) ? (m + cj - 1) / cj : 1;
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int j0 = ch * cj;
+        const int jc = (JAC && m > 0) ? min(cj, m - j0) : 0;
+        // Taylor polynomial: A_0 = I, D_0 = 0
+        for (int idx = tid; idx < n2; idx += kThreads) Abuf[0][idx] = (idx % n == idx / n) ? 1.0 : 0.0;
+        for (int idx = tid; idx < jc * n2; idx += kThreads) { Dbuf[0][idx] = 0.0; Ls[idx] = 0.0; }
+        __syncthreads();
+        for (int k = 1; k <= kExpDeg; ++k) {
+            const double* Ap = Abuf[(k - 1) & 1];
+            double* An = Abuf[k & 1];
+            const double* Dp = Dbuf[(k - 1) & 1];
+            double* Dn = Dbuf[k & 1];
+            const double inv = 1.0 / (double)k;
+            for (int idx = tid; idx < n2; idx += kThreads) {
+                const int r = idx % n, c = idx / n;
+                double acc = 0.0;
+                for (int q = 0; q < n; ++q) acc = fma(Ap[r + n * q], Y[q + n * c], acc);
+                acc *= inv;
+                An[idx] = acc;
+                if (ch == 0) E0[idx] += acc;
+            }
+            for (int idx = tid; idx < jc * n2; idx += kThreads) {
+                const int r = idx % n, c = (idx / n) % n, jj = idx / n2;
+                const double* __restrict__ Gj = P.G + (size_t)(j0 + jj + 1) * n2;
+                const double* Dj = Dp + jj * n2;
+                double acc = 0.0, acc2 = 0.0;
+                for (int q = 0; q < n; ++q) {
+                    acc = fma(Dj[r + n * q], Y[q + n * c], acc);
+                    acc2 = fma(Ap[r + n * q], Gj[q + n * c], acc2);
+                }
+                acc = (acc + h * sc * acc2) * inv;
+                Dn[idx] = acc;
+                Ls[idx] += acc;
+            }
+            __syncthreads();
+        }
+        // squarings
+        for (int idx = tid; idx < n2; idx += kThreads) Ecur[idx] = E0[idx];
+        __syncthreads();
+        for (int q = 0; q < sq; ++q) {
+            double* Ln = Dbuf[0];
+            for (int idx = tid; idx < jc * n2; idx += kThreads) {
+                const int r = idx % n, c = (idx / n) % n, jj = idx / n2;
+                const double* Lj = Ls + jj * n2;
+                double acc = 0.0;
+                for (int k = 0; k < n; ++k) acc = fma(Ecur[r + n * k], Lj[k + n * c], fma(Lj[r + n * k], Ecur[k + n * c], acc));
+                Ln[idx] = acc;
+            }
+            matmul_lds(Etmp, Ecur, Ecur, n, n, tid);
+            __syncthreads();
+            for (int idx = tid; idx < jc * n2; idx += kThreads) Ls[idx] = Ln[idx];
+            for (int idx = tid; idx < n2; idx += kThreads) Ecur[idx] = Etmp[idx];
+            __syncthreads();
+        }
+        // d/da_j = -L_j U0
+        for (int idx = tid; idx < jc * nN; idx += kThreads) {
+            const int r = idx % n, c = (idx / n) % N, jj = idx / nN;
+            const double* Lj = Ls + jj * n2;
+            double acc = 0.0;
+            for (int k = 0; k < n; ++k) acc = fma(Lj[r + n * k], z0[P.off_U + c * n + k], acc);
+            Jb[P.jo_a + (size_t)(j0 + jj) * s + c * n + r] = -acc;
+        }
+        __syncthreads();
+    }
+    // E U0, residual, -I (x) E, identity block, d/dh
+    for (int idx = tid; idx < nN; idx += kThreads) {
+        const int r = idx % n, c = idx / n;
+        double acc = 0.0;
+        for (int k = 0; k < n; ++k) acc = fma(Ecur[r + n * k], z0[P.off_U + c * n + k], acc);
+        EU[idx] = acc;
+        if (Fb) Fb[idx] = z1[P.off_U + idx] - acc;
+        if (JAC) Jb[P.jo_B + idx] = 1.0;
+    }
+    {
+        int r0 = s, jo = P.jo_d;
+        for (int d = 0; d < P.n_deriv; ++d) {
+            const int dim = P.ddim_i[d];
+            for (int i = tid; i < dim; i += kThreads) {
+                const double dx = z0[P.dx_off[d] + i];
+                if (Fb) Fb[r0 + i] = z1[P.x_off[d] + i] - z0[P.x_off[d] + i] - h * dx;
+                if (JAC) {
+                    Jb[jo + i] = -1.0;
+                    Jb[jo + dim + i] = 1.0;
+                    Jb[jo + 2 * dim + i] = -h;
+                    if (ft) Jb[jo + 3 * dim + i] = -dx;
+                }
+            }
+            r0 += dim;
+            jo += (ft ? 4 : 3) * dim;
+        }
+    }
+    if (!JAC) return;
+    for (int idx = tid; idx < n2; idx += kThreads) {
+        const double v = -Ecur[idx];
+        for (int q = 0; q < N; ++q) Jb[P.jo_F + q * n2 + idx] = v;
+    }
+    __syncthreads();
+    if (ft) {
+        for (int idx = tid; idx < nN; idx += kThreads) {
+            const int r = idx % n, c = idx / n;
+            double acc = 0.0;
+            for (int k = 0; k < n; ++k) acc = fma(Gm[r + n * k], EU[c * n + k], acc);
+            Jb[P.jo_h + idx] = -acc;
+        }
+    }
+}
+
 }  // namespace
 
-size_t qc_lds_bytes_jac(const QcParams& P) { return (size_t)jac_layout(P).total * sizeof(double); }
+static int exp_chunk(const QcParams& P) {
+    int cj = P.m > 0 ? P.m : 1;
+    while (cj > 1 && (size_t)exp_layout(P, cj).total * sizeof(double) > 64 * 1024) cj = (cj + 1) / 2;
+    return cj;
+}
+
+size_t qc_lds_bytes_jac(const QcParams& P) {
+    if (P.integrator == QC_EXPONENTIAL) return (size_t)exp_layout(P, exp_chunk(P)).total * sizeof(double);
+    return (size_t)jac_layout(P).total * sizeof(double);
+}
+
+template <typename K>
+static hipError_t raise_lds_limit(K kernel, size_t lds) {
+    if (lds <= 64 * 1024) return hipSuccess;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
 
 hipError_t qc_launch_lds_F_jac(const QcParams& P, const double* dZ, double* dF, double* dJ, size_t lds, hipStream_t st) {
-    if (P.integrator != QC_PADE) return hipErrorNotSupported;
     const dim3 grid(P.n_int), block(kThreads);
+    if (P.integrator == QC_EXPONENTIAL) {
+        const int cj = exp_chunk(P);
+        hipError_t e = dJ ? raise_lds_limit(&qc_lds_exp_kernel<true>, lds) : raise_lds_limit(&qc_lds_exp_kernel<false>, lds);
+        if (e != hipSuccess) return e;
+        if (dJ) hipLaunchKernelGGL(qc_lds_exp_kernel<true>, grid, block, lds, st, P, dZ, dF, dJ, cj);
+        else hipLaunchKernelGGL(qc_lds_exp_kernel<false>, grid, block, lds, st, P, dZ, dF, dJ, cj);
+        return hipGetLastError();
+    }
     if (dJ) {
         if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qc_lds_pade_kernel<true>),
