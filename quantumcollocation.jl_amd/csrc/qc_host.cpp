@@ -28,7 +28,7 @@ static int fail(std::string* err, int code, const std::string& msg) {
         }                                                                                        \
     } while (0)
 
-extern "C" const char* qc_version(void) { return "qcolloc-hip 0.1 (gfx950, fp64; kernels: lds, mfma16)"; }
+extern "C" const char* qc_version(void) { return "qcolloc-hip 0.1 (gfx950, fp64; kernels: lds, mfma16, mfma32)"; }
 
 extern "C" const char* qc_last_error(const qc_handle* h) { return h ? h->err.c_str() : g_err.c_str(); }
 
@@ -311,7 +311,7 @@ extern "C" int qc_create(const qc_desc* d, qc_handle** out) {
     if (kernel == QC_KERNEL_AUTO) kernel = mfma_ok ? QC_KERNEL_MFMA : QC_KERNEL_LDS;
     if (kernel == QC_KERNEL_MFMA && !mfma_ok) {
         delete h;
-        return fail(nullptr, QC_ERR_UNSUPPORTED, "qc_create: MFMA kernel needs the Pade integrator of order 4 and 2N in {16, 32}");
+        return fail(nullptr, QC_ERR_UNSUPPORTED, "qc_create: MFMA kernels need the Pade integrator of order 4 and 2N in {16, 32}");
     }
     if (kernel != QC_KERNEL_MFMA && kernel != QC_KERNEL_LDS) { delete h; return fail(nullptr, QC_ERR_INVALID, "qc_create: unknown kernel id"); }
     h->kernel = kernel;

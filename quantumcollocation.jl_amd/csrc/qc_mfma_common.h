@@ -1,0 +1,61 @@
+// Shared device helpers of the f64-MFMA kernels (v_mfma_f64_16x16x4_f64 lane maps; see the header
+// comment of qc_mfma_kernels.hip and tests/hip/mfma_f64_probe.hip).
+#pragma once
+#include "qc_internal.h"
+
+namespace qc_mfma {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+__device__ inline double swap8(double x) {  // exchange the two 8-column halves of a 16-column tile
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x128, 0xf, 0xf, false);  // row_ror:8
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x128, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ inline v4d swap8(v4d x) { return v4d{swap8(x[0]), swap8(x[1]), swap8(x[2]), swap8(x[3])}; }
+
+// D = A * B (16x16x16): A in A-layout regs, B in B-layout regs.  Two accumulators halve the
+// dependent-MFMA chain (a dependent f64 MFMA issues every ~100 cycles, an independent one every 64).
+__device__ inline v4d mm16(const v4d& a, const v4d& b) {
+    const v4d z = {0.0, 0.0, 0.0, 0.0};
+    v4d acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b[0], z, 0, 0, 0);
+    v4d acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], b[1], z, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2], b[2], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[3], b[3], acc1, 0, 0, 0);
+    return acc0 + acc1;
+}
+
+
+// Identity in B/D layout: lane (g, j) reg r = (4r + g == j)
+__device__ inline v4d identity_B(int g, int j) {
+    return v4d{(g == j) ? 1.0 : 0.0, (4 + g == j) ? 1.0 : 0.0, (8 + g == j) ? 1.0 : 0.0, (12 + g == j) ? 1.0 : 0.0};
+}
+
+// Derivative integrators x_{t+1} - x_t - h dx_t (reference unitary_smooth_pulse_problem.jl:15-16), generic
+// form: any count, any dimension.  `skip_small` skips the integrators the register fast path served.
+__device__ inline void deriv_rows_generic(const QcParams& P, const double* __restrict__ z0, const double* __restrict__ z1,
+                                          double h, double* __restrict__ Fb, double* __restrict__ Jb, int lane, bool skip_small) {
+    const bool ft = P.off_dt >= 0;
+    int r0 = P.s, jo = P.jo_d;
+    for (int d = 0; d < P.n_deriv; ++d) {
+        const int dim = P.ddim_i[d];
+        if (!(skip_small && dim <= 64)) {
+            for (int i = lane; i < dim; i += 64) {
+                const double dx = z0[P.dx_off[d] + i];
+                if (Fb) Fb[r0 + i] = z1[P.x_off[d] + i] - z0[P.x_off[d] + i] - h * dx;
+                if (Jb) {
+                    Jb[jo + i] = -1.0;
+                    Jb[jo + dim + i] = 1.0;
+                    Jb[jo + 2 * dim + i] = -h;
+                    if (ft) Jb[jo + 3 * dim + i] = -dx;
+                }
+            }
+        }
+        r0 += dim;
+        jo += (ft ? 4 : 3) * dim;
+    }
+}
+
+}  // namespace qc_mfma

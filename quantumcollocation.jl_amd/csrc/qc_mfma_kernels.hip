@@ -31,34 +31,14 @@
 //                      T = G [R_j(right) | R_j+1(right)],
 //                      Y = [R_j(left) + T(left) | R_j+1(left) + T(right)] = [d/da_j | d/da_j+1], Y^T   16
 // = 20 + 8 m MFMAs per interval (68 for m = 6).
-#include "qc_internal.h"
+#include "qc_mfma_common.h"
 
 namespace {
 
-typedef double v4d __attribute__((ext_vector_type(4)));
-typedef double v2d __attribute__((ext_vector_type(2)));
+using namespace qc_mfma;
 
 constexpr int kThreads = 128;              // compute wave + copy wave
 constexpr int kMaxGrid = 4096;             // persistent beyond this many workgroups
-
-__device__ inline double swap8(double x) {  // exchange the two 8-column halves of a 16-column tile
-    int lo = __double2loint(x), hi = __double2hiint(x);
-    lo = __builtin_amdgcn_update_dpp(0, lo, 0x128, 0xf, 0xf, false);  // row_ror:8
-    hi = __builtin_amdgcn_update_dpp(0, hi, 0x128, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-__device__ inline v4d swap8(v4d x) { return v4d{swap8(x[0]), swap8(x[1]), swap8(x[2]), swap8(x[3])}; }
-
-// D = A * B (16x16x16): A in A-layout regs, B in B-layout regs.  Two accumulators halve the
-// dependent-MFMA chain (a dependent f64 MFMA issues every ~100 cycles, an independent one every 64).
-__device__ inline v4d mm16(const v4d& a, const v4d& b) {
-    const v4d z = {0.0, 0.0, 0.0, 0.0};
-    v4d acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b[0], z, 0, 0, 0);
-    v4d acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], b[1], z, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2], b[2], acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[3], b[3], acc1, 0, 0, 0);
-    return acc0 + acc1;
-}
 
 // A-layout image of generator `mat` (0 = drift): [matrix][pair(2)][lane(64)][2] doubles
 __device__ inline v4d load_GA(const double* __restrict__ Gx, int mat, int lane) {
@@ -68,31 +48,6 @@ __device__ inline v4d load_GA(const double* __restrict__ Gx, int mat, int lane) 
 }
 
 constexpr int kDF = 4;   // derivative integrators handled from registers in the copy wave
-
-// Derivative integrators x_{t+1} - x_t - h dx_t (reference unitary_smooth_pulse_problem.jl:15-16), generic
-// form: any count, any dimension.  `skip_small` skips the integrators the register fast path served.
-__device__ inline void deriv_rows_generic(const QcParams& P, const double* __restrict__ z0, const double* __restrict__ z1,
-                                          double h, double* __restrict__ Fb, double* __restrict__ Jb, int lane, bool skip_small) {
-    const bool ft = P.off_dt >= 0;
-    int r0 = P.s, jo = P.jo_d;
-    for (int d = 0; d < P.n_deriv; ++d) {
-        const int dim = P.ddim_i[d];
-        if (!(skip_small && dim <= 64)) {
-            for (int i = lane; i < dim; i += 64) {
-                const double dx = z0[P.dx_off[d] + i];
-                if (Fb) Fb[r0 + i] = z1[P.x_off[d] + i] - z0[P.x_off[d] + i] - h * dx;
-                if (Jb) {
-                    Jb[jo + i] = -1.0;
-                    Jb[jo + dim + i] = 1.0;
-                    Jb[jo + 2 * dim + i] = -h;
-                    if (ft) Jb[jo + 3 * dim + i] = -dx;
-                }
-            }
-        }
-        r0 += dim;
-        jo += (ft ? 4 : 3) * dim;
-    }
-}
 
 constexpr int kMU = 8;   // generators whose A-images are requested together and kept in registers
 
@@ -316,16 +271,17 @@ __global__ __launch_bounds__(kThreads, 2) void qc_mfma16_pade4_kernel(const QcPa
 }  // namespace
 
 bool qc_mfma_supported(const QcParams& P) {
-    return P.integrator == QC_PADE && P.p == 2 && P.n == 16 && P.m <= 32;
+    return P.integrator == QC_PADE && P.p == 2 && (P.n == 16 || P.n == 32) && P.m <= 32;
 }
 
 bool qc_mfma_hess_supported(const QcParams&) { return false; }
 
-size_t qc_mfma_gx_doubles(const QcParams& P) { return (size_t)(P.m + 1) * 256; }
+size_t qc_mfma_gx_doubles(const QcParams& P) { return P.n == 32 ? qc_mfma32_gx_doubles(P) : (size_t)(P.m + 1) * 256; }
 
 // Packs the (m+1) generators (column-major n x n, index 0 = drift) into the lane-ordered A-layout
 // image [matrix][pair][lane][2]:  lane (g, i) reg kk = X[i][4kk+g].
 void qc_mfma_pack_G(const QcParams& P, const double* G, double* Gx) {
+    if (P.n == 32) { qc_mfma32_pack_G(P, G, Gx); return; }
     const int n = 16, M = P.m + 1;
     for (int mat = 0; mat < M; ++mat) {
         const double* A = G + (size_t)mat * n * n;
@@ -339,6 +295,7 @@ void qc_mfma_pack_G(const QcParams& P, const double* G, double* Gx) {
 }
 
 hipError_t qc_launch_mfma_F_jac(const QcParams& P, const double* dZ, double* dF, double* dJ, hipStream_t st) {
+    if (P.n == 32) return qc_launch_mfma32_F_jac(P, dZ, dF, dJ, st);
     const int grid = P.n_int < kMaxGrid ? P.n_int : kMaxGrid;
     if (dJ) hipLaunchKernelGGL(qc_mfma16_pade4_kernel<true>, dim3(grid), dim3(kThreads), 0, st, P, dZ, dF, dJ);
     else hipLaunchKernelGGL(qc_mfma16_pade4_kernel<false>, dim3(grid), dim3(64), 0, st, P, dZ, dF, dJ);
