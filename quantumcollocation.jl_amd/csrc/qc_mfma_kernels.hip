@@ -274,12 +274,11 @@ bool qc_mfma_supported(const QcParams& P) {
     return P.integrator == QC_PADE && P.p == 2 && (P.n == 16 || P.n == 32) && P.m <= 32;
 }
 
-bool qc_mfma_hess_supported(const QcParams&) { return false; }
-
-size_t qc_mfma_gx_doubles(const QcParams& P) { return P.n == 32 ? qc_mfma32_gx_doubles(P) : (size_t)(P.m + 1) * 256; }
+size_t qc_mfma_gx_doubles(const QcParams& P) { return P.n == 32 ? qc_mfma32_gx_doubles(P) : (size_t)2 * (P.m + 1) * 256; }
 
 // Packs the (m+1) generators (column-major n x n, index 0 = drift) into the lane-ordered A-layout
-// image [matrix][pair][lane][2]:  lane (g, i) reg kk = X[i][4kk+g].
+// images [layout][matrix][pair][lane][2]:  layout 0 (A operand of X): lane (g, i) reg kk = X[i][4kk+g];
+// layout 1 (B layout of X = A operand of X^T, used by the Hessian kernel): lane (g, i) reg kk = X[4kk+g][i].
 void qc_mfma_pack_G(const QcParams& P, const double* G, double* Gx) {
     if (P.n == 32) { qc_mfma32_pack_G(P, G, Gx); return; }
     const int n = 16, M = P.m + 1;
@@ -289,7 +288,8 @@ void qc_mfma_pack_G(const QcParams& P, const double* G, double* Gx) {
             for (int l = 0; l < 64; ++l)
                 for (int e = 0; e < 2; ++e) {
                     const int g = l >> 4, i = l & 15, kk = 2 * pr + e;
-                    Gx[((size_t)mat * 2 + pr) * 128 + l * 2 + e] = A[(size_t)(4 * kk + g) * n + i];
+                    Gx[((size_t)mat * 2 + pr) * 128 + l * 2 + e] = A[(size_t)(4 * kk + g) * n + i];                 // X[i][4kk+g]
+                    Gx[((size_t)(M + mat) * 2 + pr) * 128 + l * 2 + e] = A[(size_t)i * n + 4 * kk + g];         // X[4kk+g][i]
                 }
     }
 }
@@ -302,6 +302,3 @@ hipError_t qc_launch_mfma_F_jac(const QcParams& P, const double* dZ, double* dF,
     return hipGetLastError();
 }
 
-hipError_t qc_launch_mfma_hess(const QcParams&, const double*, const double*, double*, hipStream_t) {
-    return hipErrorNotSupported;
-}
