@@ -28,8 +28,8 @@ qc._lib.check(qc._lib.lib.qc_debug_read_stamps(dyn._h, out.ctypes.data_as(C.POIN
 st = out.reshape(n, 16).astype(np.int64)
 t0 = st[:, 0].min()
 rel = (st - t0) * 10.0 / 1e3   # microseconds (100 MHz)
-names = ["copy: start", "copy: G assembled", "copy: stores issued", "copy: drained", "comp: start", "comp: G assembled",
-         "comp: P1,P2", "comp: E^T stored", "comp: pair0", "comp: pair1", "comp: pair2", "comp: pair3+", "comp: drained"]
+names = ["copy: start", "copy: loads done, G assembled", "copy: stores issued", "copy: drained", "comp: start", "comp: hand-off received",
+         "comp: P1,P2", "comp: E^T ready", "comp: pair0 ready", "comp: pair1 ready", "comp: pair2 ready", "comp: pair3 ready", "comp: drained"]
 t0 = st[:, :13][st[:, :13] > 0].min()
 rel = (st - t0) * 10.0 / 1e3
 print(f"T={T}: {n} intervals; kernel span (first start -> last drain) = {max(rel[:, 3].max(), rel[:, 12].max()):.2f} us")
@@ -38,3 +38,11 @@ for k, nm in enumerate(names):
     col = col[st[:, k] > 0]
     if col.size:
         print(f"  {k:2d} {nm:16s} min {col.min():7.2f}  median {np.median(col):7.2f}  max {col.max():7.2f} us")
+
+print("raw stamps of interval 0:", st[0].tolist())
+dt_real = (st[:, 12] - st[:, 4]).astype(float) * 10e-9
+dt_cyc = (st[:, 14] - st[:, 13]).astype(float)
+ok = (dt_real > 0) & (dt_cyc > 0)
+if ok.any():
+    print(f"shader clock over the compute waves: median {np.median(dt_cyc[ok] / dt_real[ok]) / 1e9:.3f} GHz "
+          f"(min {np.min(dt_cyc[ok] / dt_real[ok]) / 1e9:.3f}, max {np.max(dt_cyc[ok] / dt_real[ok]) / 1e9:.3f})")

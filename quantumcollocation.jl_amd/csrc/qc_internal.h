@@ -75,30 +75,53 @@ void qc_mfma32_pack_G(const QcParams& P, const double* G_host, double* Gx_host);
 hipError_t qc_launch_mfma32_F_jac(const QcParams& P, const double* dZ, double* dF, double* dJ, hipStream_t st);
 hipError_t qc_launch_mfma_hess(const QcParams& P, const double* dZ, const double* dMu, double* dH, hipStream_t st);
 
-// Diagnostic time stamp (only when the handle was created with QC_STAMPS=1; never in a timed run):
-// slot k of interval b <- s_memrealtime (100 MHz).
+// Diagnostic time stamps (DIAG instantiations only; handle created with QC_STAMPS=1; never in a timed run).
+// QC_STAMP records s_memrealtime (100 MHz) into a per-wave register array; QC_STAMP_FLUSH writes the slots
+// the wave owns at its very end.  (Writing each stamp to memory where it is taken stalls the wave behind the
+// store queue it is trying to observe.)
+#define QC_STAMP_DECL unsigned long long qc_ts_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
 #define QC_STAMP(P, b, lane, k)                                                                  \
     do {                                                                                         \
-        if ((P).stamps != nullptr) {                                                             \
+        if constexpr (DIAG) {                                                                    \
             __builtin_amdgcn_sched_barrier(0);                                                   \
-            const unsigned long long t_ = __builtin_amdgcn_s_memrealtime();                     \
-            if ((lane) == 0) (P).stamps[(size_t)(b) * 16 + (k)] = t_;                            \
+            qc_ts_[k] = __builtin_amdgcn_s_memrealtime();                                        \
             __builtin_amdgcn_sched_barrier(0);                                                   \
         }                                                                                        \
     } while (0)
+#define QC_STAMP_CYCLES(k)                                                                       \
+    do {                                                                                         \
+        if constexpr (DIAG) qc_ts_[k] = __builtin_amdgcn_s_memtime();                            \
+    } while (0)
+#define QC_STAMP_FLUSH(P, b, lane, first, last)                                                  \
+    do {                                                                                         \
+        if constexpr (DIAG) {                                                                    \
+            if ((P).stamps != nullptr && (lane) == 0) {                                          \
+                _Pragma("unroll") for (int k_ = (first); k_ <= (last); ++k_)                     \
+                    (P).stamps[(size_t)(b) * 16 + k_] = qc_ts_[k_];                              \
+            }                                                                                    \
+        }                                                                                        \
+    } while (0)
 
-// Streaming store of one output value.  The outputs are written once and never re-read by the kernel;
-// mode 1 (sc1, agent-scope relaxed atomic store) writes through the XCD's L2 so the bytes leave for
-// HBM while the wave keeps computing instead of being flushed at the end of the kernel.
-__device__ inline void qc_st8(double* p, double v, int mode) {
-    if (mode == 1) {
+// Streaming store of one output value.  The outputs are written once and never re-read by the kernel.
+// mode 0 plain, 1 write-through (sc1: agent-scope relaxed atomic store), 2 non-temporal (default; measured
+// fastest, profiles/README.md).  The mode is a COMPILE-TIME constant in the MFMA kernels: as a run-time
+// switch it put a scalar branch ladder (and SGPR spills) around each of the ~80 stores of a wave and halved
+// the store issue rate.
+template <int MODE>
+__device__ inline void qc_st8m(double* p, double v) {
+    if constexpr (MODE == 1) {
         __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v),
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else if (mode == 2) {
+    } else if constexpr (MODE == 2) {
         __builtin_nontemporal_store(v, p);
     } else {
         *p = v;
     }
+}
+__device__ inline void qc_st8(double* p, double v, int mode) {
+    if (mode == 1) qc_st8m<1>(p, v);
+    else if (mode == 2) qc_st8m<2>(p, v);
+    else qc_st8m<0>(p, v);
 }
 
 // XCD-aware block -> local interval map: blocks b and b+8 share an XCD (round-robin dispatch,

@@ -28,6 +28,22 @@ __device__ inline v4d mm16(const v4d& a, const v4d& b) {
 }
 
 
+// NQ independent 16x16x16 products with their MFMAs interleaved round-robin: every accumulator chain has NQ-1
+// other MFMAs between two of its own, so (for NQ >= 2) no MFMA waits on its predecessor, and no VALU touches
+// a result until the whole batch is issued (the two-accumulator mm16 above pays ~80 idle cycles of MFMA->VALU
+// wait states after every product: the s_nop 15 / s_nop 2 pairs in the ISA).
+template <int NQ>
+__device__ __forceinline__ void mm16_multi(const v4d (&a)[NQ], const v4d (&b)[NQ], v4d (&d)[NQ]) {
+    const v4d z = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) d[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q][0], b[q][0], z, 0, 0, 0);
+#pragma unroll
+    for (int kk = 1; kk < 4; ++kk) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) d[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q][kk], b[q][kk], d[q], 0, 0, 0);
+    }
+}
+
 // Exchange a value with the neighbouring lane (lane ^ 1): DPP quad_perm [1,0,3,2]
 __device__ inline double swap_pair(double x) {
     int lo = __double2loint(x), hi = __double2hiint(x);

@@ -37,8 +37,14 @@ namespace {
 
 using namespace qc_mfma;
 
-constexpr int kThreads = 128;              // compute wave + copy wave
-constexpr int kMaxGrid = 4096;             // persistent beyond this many workgroups
+#ifndef QC_IPW
+#define QC_IPW 1
+#endif
+constexpr int kIntervalsPerWG = QC_IPW;    // interval pairs per workgroup: waves [0, IPW) compute, [IPW, 2 IPW) copy.
+                                           // Measured on MI355X (bench.py, config 3): IPW 1 -> 11.55 us, 2 -> 11.60 us,
+                                           // 4 -> 12.0 us per evaluation (the wider barrier couples four intervals).
+constexpr int kThreads = 128 * kIntervalsPerWG;
+constexpr int kMaxGrid = 1024;             // persistent beyond this many workgroups
 
 // A-layout image of generator `mat` (0 = drift): [matrix][pair(2)][lane(64)][2] doubles
 __device__ inline v4d load_GA(const double* __restrict__ Gx, int mat, int lane) {
@@ -49,10 +55,10 @@ __device__ inline v4d load_GA(const double* __restrict__ Gx, int mat, int lane) 
 
 constexpr int kDF = 4;   // derivative integrators handled from registers in the copy wave
 
-constexpr int kMU = 8;   // generators whose A-images are requested together and kept in registers
 
 // G = G_0 + sum_k a_k G_k (A-layout).  The first kMU drive images and their amplitudes are requested
 // in one batch (no load waits on another) and returned in gk/ak for reuse by the drive-column loop.
+template <int kMU>
 __device__ inline v4d assemble_G(const QcParams& P, const double* __restrict__ Gx, const double* __restrict__ z0,
                                  int lane, v4d (&gk)[kMU], double (&ak)[kMU]) {
     const int m = P.m;
@@ -70,203 +76,307 @@ __device__ inline v4d assemble_G(const QcParams& P, const double* __restrict__ G
 }
 
 // Store a transposed tile: lane (g, j) reg r holds X[j][4r+g] of a 16 x 16 column-major block at p.
-__device__ inline void store_tile_T(double* __restrict__ p, const v4d& x, int g, int j, int mode) {
+template <int MODE>
+__device__ inline void store_tile_T(double* __restrict__ p, const v4d& x, int g, int j) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) qc_st8(p + (4 * r + g) * 16 + j, x[r], mode);
+    for (int r = 0; r < 4; ++r) qc_st8m<MODE>(p + (4 * r + g) * 16 + j, x[r]);
 }
 
-template <bool JAC>
-__global__ __launch_bounds__(kThreads, 2) void qc_mfma16_pade4_kernel(const QcParams P, const double* __restrict__ Z,
-                                                                   double* __restrict__ F, double* __restrict__ J) {
+// LDS hand-off block of one workgroup (doubles): the copy wave loads everything the interval needs from
+// global memory BEFORE any store of the workgroup is issued, and passes it on; the compute wave issues no
+// global load at all, so its MFMA chain never waits behind the store burst in the memory pipeline.
+constexpr int kLdsGa = 0, kLdsU0 = 256, kLdsU1 = 512, kLdsGk = 768;   // + MU * 256 generator images
+
+__device__ inline void lds_put(double* __restrict__ base, int lane, const v4d& x) {
+    v2d* p = reinterpret_cast<v2d*>(base) + lane;
+    p[0] = v2d{x[0], x[1]};
+    p[64] = v2d{x[2], x[3]};
+}
+__device__ inline v4d lds_get(const double* __restrict__ base, int lane) {
+    const v2d* p = reinterpret_cast<const v2d*>(base) + lane;
+    const v2d lo = p[0], hi = p[64];
+    return v4d{lo[0], lo[1], hi[0], hi[1]};
+}
+
+template <bool JAC, int MODE, bool DIAG, int kMU>
+__global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel(const QcParams P, const double* __restrict__ Z,
+                                                                      double* __restrict__ F, double* __restrict__ J) {
+    constexpr int kLdsBlock = kLdsGk + kMU * 256;
+    __shared__ __attribute__((aligned(16))) double sm_all[JAC ? kIntervalsPerWG * kLdsBlock : 2];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int role = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0 compute wave, 1 copy wave
+    const int wave = JAC ? __builtin_amdgcn_readfirstlane(tid >> 6) : 0;
+    const int role = wave / kIntervalsPerWG;      // 0 compute wave, 1 copy wave
+    const int slot = wave % kIntervalsPerWG;      // which of the workgroup's intervals
+    double* __restrict__ sm = sm_all + (JAC ? slot * kLdsBlock : 0);
+    const int ipw = JAC ? kIntervalsPerWG : 1;
+    const int n_wg = (P.n_int + ipw - 1) / ipw;
     const int m = P.m;
     const int g = lane >> 4, j = lane & 15, jj = j & 7;
     const bool left = j < 8;
     const bool ft = P.off_dt >= 0;
     const double c1 = P.c[1], c2 = P.c[2];
-    const int sm_mode = P.store_mode;
     const double* __restrict__ Gx = P.Gx;
-    const v4d IdB = {(g == j) ? 1.0 : 0.0, (4 + g == j) ? 1.0 : 0.0, (8 + g == j) ? 1.0 : 0.0, (12 + g == j) ? 1.0 : 0.0};
+    const v4d IdB = identity_B(g, j);
 
-    for (int vb = blockIdx.x; vb < P.n_int; vb += gridDim.x) {
-        const int b = qc_xcd_remap(vb, P.n_int);          // local interval of this workgroup
+    for (int vb = blockIdx.x; vb < n_wg; vb += gridDim.x) {
+        const int b_raw = qc_xcd_remap(vb, n_wg) * ipw + slot;   // local interval of this wave pair
+        const bool active = b_raw < P.n_int;                      // the last workgroup may be partly empty;
+        const int b = active ? b_raw : P.n_int - 1;               // its idle waves still take part in the barriers
         const long long t = P.t_begin + b;
         const double* __restrict__ z0 = Z + t * (long long)P.zdim;
         const double* __restrict__ z1 = z0 + P.zdim;
         double* __restrict__ Jb = JAC ? J + (size_t)b * P.jac_nnz : nullptr;
         double* __restrict__ Fb = F ? F + (size_t)b * P.ddim : nullptr;
+        const double h = ft ? z0[P.off_dt] : P.dt_fixed;
+        const double hc1 = h * c1, hc2 = h * h * c2;
+        QC_STAMP_DECL;
 
-        if (role == 1) {
-            // ================= copy wave: B^T, F^T and their N copies =================================
-            if (!JAC || (P.dbg_skip & 1)) continue;
+        if (JAC && role == 1) {
+            // ================= copy wave =====================================================================
+            if (!active) { __syncthreads(); __syncthreads(); continue; }
             __builtin_amdgcn_s_setprio(3);   // critical path: nothing reaches HBM before this wave's first store
             QC_STAMP(P, b, lane, 0);
-            const double h = ft ? z0[P.off_dt] : P.dt_fixed;
+            // every global load of the interval, in one batch
+            const double* u0p = z0 + P.off_U + jj * 16 + g;
+            const double* u1p = z1 + P.off_U + jj * 16 + g;
+            const v4d u0 = {u0p[0], u0p[4], u0p[8], u0p[12]};
+            const v4d u1 = {u1p[0], u1p[4], u1p[8], u1p[12]};
+            double dxv[kDF], dfv[kDF];       // derivative integrators, register fast path (<= kDF of <= 64 rows)
+            const bool dfast = P.n_deriv <= kDF;
+#pragma unroll
+            for (int d = 0; d < kDF; ++d) {
+                // unused slots (d >= n_deriv) have zero offsets/dims in QcParams: the loads stay in bounds
+                const int i = lane < P.ddim_i[d] ? lane : 0;
+                dxv[d] = z0[P.dx_off[d] + i];
+                dfv[d] = z1[P.x_off[d] + i] - z0[P.x_off[d] + i];
+            }
             v4d gk[kMU];
             double ak[kMU];
             const v4d Ga = assemble_G(P, Gx, z0, lane, gk, ak);
             QC_STAMP(P, b, lane, 1);
-            // A-layout(G^T) = B-layout(G) = Gb;  B-layout(G^T) = D-layout(G^T) = A-layout(G) = Ga.
-            const v4d Gb = mm16(Ga, IdB);
-            const v4d G2T = mm16(Gb, Ga);
-            const double hc1 = h * c1, hc2 = h * h * c2;
-            v4d Fm, Bm;
+            // hand-off to the compute wave
+            lds_put(sm + kLdsGa, lane, Ga);
+            lds_put(sm + kLdsU0, lane, u0);
+            lds_put(sm + kLdsU1, lane, u1);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const double ev = IdB[r] + hc2 * G2T[r];
-                Fm[r] = -(ev + hc1 * Ga[r]);       // -F^T
-                Bm[r] = ev - hc1 * Ga[r];          //  B^T
-            }
-            double* pF = Jb + P.jo_F;
-            double* pB = Jb + P.jo_B;
-            // 8 bytes per lane, 512 contiguous bytes per instruction.  (Pairing lanes for 16-byte stores,
-            // qc_mfma_common.h::store_tile_T16, measured 8 % slower: 12.4 vs 11.5 us per evaluation.)
+            for (int u = 0; u < kMU; ++u)
+                if (u < m) lds_put(sm + kLdsGk + u * 256, lane, gk[u]);
+            __syncthreads();
+            bool skip = false;
+            if constexpr (DIAG) skip = (P.dbg_skip & 1) != 0;
+            if (!skip) {
+                // A-layout(G^T) = B-layout(G) = Gb;  B-layout(G^T) = D-layout(G^T) = A-layout(G) = Ga.
+                const v4d Gb = mm16(Ga, IdB);
+                const v4d G2T = mm16(Gb, Ga);
+                v4d Fm, Bm;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                store_tile_T(pF + q * 256, Fm, g, j, sm_mode);
-                store_tile_T(pB + q * 256, Bm, g, j, sm_mode);
+                for (int r = 0; r < 4; ++r) {
+                    const double ev = IdB[r] + hc2 * G2T[r];
+                    Fm[r] = -(ev + hc1 * Ga[r]);       // -F^T
+                    Bm[r] = ev - hc1 * Ga[r];          //  B^T
+                }
+                double* pF = Jb + P.jo_F;
+                double* pB = Jb + P.jo_B;
+                // 8 bytes per lane, 512 contiguous bytes per instruction.  (Pairing lanes for 16-byte stores,
+                // qc_mfma_common.h::store_tile_T16, measured 8 % slower.)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    store_tile_T<MODE>(pF + q * 256, Fm, g, j);
+                    store_tile_T<MODE>(pB + q * 256, Bm, g, j);
+                }
+                __builtin_amdgcn_s_setprio(0);
+                QC_STAMP(P, b, lane, 2);
+                {   // derivative integrator rows: residual x_{t+1} - x_t - h dx_t and the 4 (3) diagonal blocks
+                    int r0 = P.s, jo = P.jo_d;
+                    bool all_fast = dfast;
+#pragma unroll
+                    for (int d = 0; d < kDF; ++d) {
+                        if (d < P.n_deriv) {
+                            const int dim = P.ddim_i[d];
+                            if (dfast && dim <= 64) {
+                                if (lane < dim) {
+                                    if (Fb) Fb[r0 + lane] = dfv[d] - h * dxv[d];
+                                    Jb[jo + lane] = -1.0;
+                                    Jb[jo + dim + lane] = 1.0;
+                                    Jb[jo + 2 * dim + lane] = -h;
+                                    if (ft) Jb[jo + 3 * dim + lane] = -dxv[d];
+                                }
+                            } else {
+                                all_fast = false;
+                            }
+                            r0 += dim;
+                            jo += (ft ? 4 : 3) * dim;
+                        }
+                    }
+                    if (!all_fast) deriv_rows_generic(P, z0, z1, h, Fb, Jb, lane, dfast);
+                }
+                if constexpr (DIAG) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    QC_STAMP(P, b, lane, 3);
+                }
+                QC_STAMP_FLUSH(P, b, lane, 0, 3);
             }
-            __builtin_amdgcn_s_setprio(0);
-            QC_STAMP(P, b, lane, 2);
-            if (P.stamps != nullptr) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                QC_STAMP(P, b, lane, 3);
-            }
+            __syncthreads();   // the hand-off block is rewritten by the next interval of a persistent grid
             continue;
         }
 
         // ===================== compute wave ===========================================================
-        // its MFMA chain goes ahead of a copy wave that is only queueing stores on the same SIMD
-        if (P.dbg_skip & 2) continue;
+        if (!active) { if constexpr (JAC) { __syncthreads(); __syncthreads(); } continue; }
         __builtin_amdgcn_s_setprio(1);
         QC_STAMP(P, b, lane, 4);
-        // knot data: U0, U1 in B-layout (both halves of the tile load the same 8 columns)
-        const double* u0p = z0 + P.off_U + jj * 16 + g;
-        const double* u1p = z1 + P.off_U + jj * 16 + g;
-        const v4d u0 = {u0p[0], u0p[4], u0p[8], u0p[12]};
-        const v4d u1 = {u1p[0], u1p[4], u1p[8], u1p[12]};
-        const double h = ft ? z0[P.off_dt] : P.dt_fixed;
-        // derivative integrators, fast path (<= kDF integrators of <= 64 rows): request their knot data
-        // now, together with the generator images; their few outputs are stored after the copies.
-        double dxv[kDF], dfv[kDF];
-        const bool dfast = P.n_deriv <= kDF;
-#pragma unroll
-        for (int d = 0; d < kDF; ++d) {
-            // unused slots (d >= n_deriv) have zero offsets/dims in QcParams: the loads stay in bounds
-            const int i = lane < P.ddim_i[d] ? lane : 0;
-            dxv[d] = z0[P.dx_off[d] + i];
-            dfv[d] = z1[P.x_off[d] + i] - z0[P.x_off[d] + i];
-        }
+        QC_STAMP_CYCLES(13);
+        v4d u0, u1, Ga;
         v4d gk[kMU];
-        double ak[kMU];
-        const v4d Ga = assemble_G(P, Gx, z0, lane, gk, ak);
-        const double hc1 = h * c1, hc2 = h * h * c2;
+        if constexpr (JAC) {
+            __syncthreads();                      // wait for the copy wave's hand-off
+            Ga = lds_get(sm + kLdsGa, lane);
+            u0 = lds_get(sm + kLdsU0, lane);
+            u1 = lds_get(sm + kLdsU1, lane);
+        } else {                                  // residual-only launch: a single wave, loads for itself
+            const double* u0p = z0 + P.off_U + jj * 16 + g;
+            const double* u1p = z1 + P.off_U + jj * 16 + g;
+            u0 = v4d{u0p[0], u0p[4], u0p[8], u0p[12]};
+            u1 = v4d{u1p[0], u1p[4], u1p[8], u1p[12]};
+            double ak[kMU];
+            Ga = assemble_G(P, Gx, z0, lane, gk, ak);
+        }
         QC_STAMP(P, b, lane, 5);
-
-        v4d W, Wsw;                               // W = [S | D], Wsw = [D | S]
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const double sm_ = u1[r] + u0[r], df = u1[r] - u0[r];
-            W[r] = left ? sm_ : df;
-            Wsw[r] = left ? df : sm_;
-        }
-        const v4d P1 = mm16(Ga, W);               // [GS | GD]
-        const v4d P1sw = swap8(P1);               // [GD | GS]
-        const v4d P2 = mm16(Ga, P1sw);            // [G^2 D | G^2 S]
-        QC_STAMP(P, b, lane, 6);
-        {   // E = [delta | d/dh] (values are formed on the left half, d/dh moved to the right half)
-            v4d dl, dh;
-            const double d1 = -c1, d2 = 2.0 * c2 * h;
+        bool skipc = false;
+        if constexpr (DIAG) skipc = (P.dbg_skip & 2) != 0;
+        if (!skipc) {
+            v4d W, Wsw;                               // W = [S | D], Wsw = [D | S]
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                dl[r] = Wsw[r] - hc1 * P1[r] + hc2 * P2[r];
-                dh[r] = d1 * P1[r] + d2 * P2[r];
+                const double sm_ = u1[r] + u0[r], df = u1[r] - u0[r];
+                W[r] = left ? sm_ : df;
+                Wsw[r] = left ? df : sm_;
             }
-            const v4d dhs = swap8(dh);
-            v4d E;
+            // The products are issued in four dependency stages, each a batch of independent 16x16x16 products
+            // whose MFMAs are interleaved (mm16_multi):  A: P1   B: P2, R_0..R_{MU-1}   C: E^T, T_0..T_{MU/2-1}   D: Y_p^T.
+            const v4d P1 = mm16(Ga, W);               // [GS | GD]
+            const v4d P1sw = swap8(P1);               // [GD | GS]
+            v4d Q;                                    // [Q0 | Q1] = [-h c1 S + h^2 c2 GD | h^2 c2 D]
 #pragma unroll
-            for (int r = 0; r < 4; ++r) E[r] = left ? dl[r] : dhs[r];
-            const v4d ET = mm16(E, IdB);          // lane (g, j) reg r = E[j][4r+g]
+            for (int r = 0; r < 4; ++r) Q[r] = left ? (-hc1 * W[r] + hc2 * P1sw[r]) : (hc2 * W[r]);
+            constexpr int NB = JAC ? kMU + 1 : 1;
+            v4d sB[NB];                               // stage B results: P2 = G P1sw, R_k = G_k Q = [G_k Q0 | G_k Q1]
+            {
+                v4d aB[NB], bB[NB];
+                aB[0] = Ga;
+                bB[0] = P1sw;
+                if constexpr (JAC) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int c = 4 * r + g;          // tile column: < 8 residual column c, >= 8 d/dh column c-8
-                if (c < 8) {
-                    if (Fb) qc_st8(Fb + c * 16 + j, ET[r], sm_mode);
-                } else if (JAC && ft) {
-                    qc_st8(Jb + P.jo_h + (c - 8) * 16 + j, ET[r], sm_mode);
-                }
-            }
-        }
-        QC_STAMP(P, b, lane, 7);
-        if (!JAC) {   // residual-only launch has no copy wave: derivative residual rows here
-            deriv_rows_generic(P, z0, z1, h, Fb, nullptr, lane, false);
-            continue;
-        }
-
-        // ---- drive columns ---------------------------------------------------------------------------
-        v4d Q;                                    // [Q0 | Q1] = [-h c1 S + h^2 c2 GD | h^2 c2 D]
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Q[r] = left ? (-hc1 * W[r] + hc2 * P1sw[r]) : (hc2 * W[r]);
-        double* pa = Jb + P.jo_a;
-        // drive pair (k, k+1): A-images a1, a2 (a2 ignored when k+1 == m)
-        auto drive_pair = [&](int k, const v4d& a1, const v4d& a2) {
-            const bool two = k + 1 < m;
-            const v4d R1 = mm16(a1, Q);            // [G_k Q0 | G_k Q1]
-            const v4d R2 = mm16(a2, Q);            // [G_k+1 Q0 | G_k+1 Q1]
-            const v4d R1sw = swap8(R1), R2sw = swap8(R2);
-            v4d X, Y;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                X[r] = left ? R1sw[r] : R2[r];     // [G_k Q1 | G_k+1 Q1]
-                Y[r] = left ? R1[r] : R2sw[r];     // [G_k Q0 | G_k+1 Q0]
-            }
-            const v4d Tt = mm16(Ga, X);            // [G G_k Q1 | G G_k+1 Q1]
-            Y += Tt;                               // [d/da_k | d/da_k+1]
-            const v4d YT = mm16(Y, IdB);           // lane (g, j) reg r = Y[j][4r+g]
-            double* p = pa + (size_t)k * 128;
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (r < 2 || two) qc_st8(p + (4 * r + g) * 16 + j, YT[r], sm_mode);   // tile columns >= 8 are drive k+1
-        };
-#pragma unroll
-        for (int u = 0; u < kMU; u += 2) {
-            if (u < m) {
-                drive_pair(u, gk[u], gk[u + 1]);
-                QC_STAMP(P, b, lane, 8 + (u >> 1 < 3 ? u >> 1 : 3));
-            }
-        }
-        for (int k = kMU; k < m; k += 2)
-            drive_pair(k, load_GA(Gx, k + 1, lane), load_GA(Gx, k + 2 <= m ? k + 2 : k + 1, lane));
-        {   // derivative integrator rows: residual x_{t+1} - x_t - h dx_t and the 4 (3) diagonal blocks
-            int r0 = P.s, jo = P.jo_d;
-            bool all_fast = dfast;
-#pragma unroll
-            for (int d = 0; d < kDF; ++d) {
-                if (d < P.n_deriv) {
-                    const int dim = P.ddim_i[d];
-                    if (dfast && dim <= 64) {
-                        if (lane < dim) {
-                            if (Fb) Fb[r0 + lane] = dfv[d] - h * dxv[d];
-                            Jb[jo + lane] = -1.0;
-                            Jb[jo + dim + lane] = 1.0;
-                            Jb[jo + 2 * dim + lane] = -h;
-                            if (ft) Jb[jo + 3 * dim + lane] = -dxv[d];
-                        }
-                    } else {
-                        all_fast = false;
+                    for (int u = 0; u < kMU; ++u) {   // an unused slot (u >= m) repeats the last drive; never stored
+                        aB[u + 1] = lds_get(sm + kLdsGk + (u < m ? u : m - 1) * 256, lane);
+                        bB[u + 1] = Q;
                     }
-                    r0 += dim;
-                    jo += (ft ? 4 : 3) * dim;
+                }
+                mm16_multi<NB>(aB, bB, sB);
+            }
+            const v4d P2 = sB[0];                     // [G^2 D | G^2 S]
+            QC_STAMP(P, b, lane, 6);
+            v4d E;                                    // [delta | d/dh]: formed on the left half, d/dh moved to the right
+            {
+                v4d dl, dh;
+                const double d1 = -c1, d2 = 2.0 * c2 * h;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    dl[r] = Wsw[r] - hc1 * P1[r] + hc2 * P2[r];
+                    dh[r] = d1 * P1[r] + d2 * P2[r];
+                }
+                const v4d dhs = swap8(dh);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) E[r] = left ? dl[r] : dhs[r];
+            }
+            constexpr int NC = JAC ? kMU / 2 + 1 : 1;
+            v4d sC[NC];                               // stage C results: E^T, T_p = G [R_2p(right) | R_2p+1(right)]
+            v4d Y[NC];                                // Y[p+1] = [R_2p(left) | R_2p+1(left)]
+            {
+                v4d aC[NC], bC[NC];
+                aC[0] = E;                            // C/D registers read as an A operand are the transpose
+                bC[0] = IdB;
+                if constexpr (JAC) {
+#pragma unroll
+                    for (int p2 = 0; p2 < kMU / 2; ++p2) {
+                        const v4d R1 = sB[2 * p2 + 1], R2 = sB[2 * p2 + 2];
+                        const v4d R1sw = swap8(R1), R2sw = swap8(R2);
+                        aC[p2 + 1] = Ga;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            bC[p2 + 1][r] = left ? R1sw[r] : R2[r];      // [G_k Q1 | G_k+1 Q1]
+                            Y[p2 + 1][r] = left ? R1[r] : R2sw[r];       // [G_k Q0 | G_k+1 Q0]
+                        }
+                    }
+                }
+                mm16_multi<NC>(aC, bC, sC);
+            }
+            const v4d ET = sC[0];                     // lane (g, j) reg r = E[j][4r+g]
+            // The compute wave's few stores are issued AFTER its MFMA chain: a store issued while the copy
+            // waves flood the CU's store queue stalls this wave for microseconds.
+            auto store_ET = [&]() {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int c = 4 * r + g;          // tile column: < 8 residual column c, >= 8 d/dh column c-8
+                    if (c < 8) {
+                        if (Fb) qc_st8m<MODE>(Fb + c * 16 + j, ET[r]);
+                    } else if (JAC && ft) {
+                        qc_st8m<MODE>(Jb + P.jo_h + (c - 8) * 16 + j, ET[r]);
+                    }
+                }
+            };
+            QC_STAMP(P, b, lane, 7);
+            if constexpr (!JAC) {   // residual-only launch has no copy wave: derivative residual rows here
+                store_ET();
+                deriv_rows_generic(P, z0, z1, h, Fb, nullptr, lane, false);
+            } else {
+                // ---- drive columns: d/da_k = G_k Q0 + G (G_k Q1), two drives per tile ----------------------------
+                double* pa = Jb + P.jo_a;
+                auto store_pair = [&](int k, const v4d& YTk) {
+                    const bool two = k + 1 < m;
+                    double* p = pa + (size_t)k * 128;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (r < 2 || two) qc_st8m<MODE>(p + (4 * r + g) * 16 + j, YTk[r]);   // tile columns >= 8 are drive k+1
+                };
+                v4d YT[kMU / 2];                      // stage D: transposes of [d/da_k | d/da_k+1]
+                {
+                    v4d aD[kMU / 2], bD[kMU / 2];
+#pragma unroll
+                    for (int p2 = 0; p2 < kMU / 2; ++p2) {
+                        aD[p2] = Y[p2 + 1] + sC[p2 + 1];
+                        bD[p2] = IdB;
+                    }
+                    mm16_multi<kMU / 2>(aD, bD, YT);
+                }
+                QC_STAMP(P, b, lane, 8);
+                store_ET();
+#pragma unroll
+                for (int u = 0; u < kMU; u += 2)
+                    if (u < m) store_pair(u, YT[u >> 1]);
+                // drives beyond the hand-off block: generator images straight from global memory
+                for (int k = kMU; k < m; k += 2) {
+                    const v4d R1 = mm16(load_GA(Gx, k + 1, lane), Q);
+                    const v4d R2 = mm16(load_GA(Gx, k + 2 <= m ? k + 2 : k + 1, lane), Q);
+                    const v4d R1sw = swap8(R1), R2sw = swap8(R2);
+                    v4d X, Yk;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        X[r] = left ? R1sw[r] : R2[r];
+                        Yk[r] = left ? R1[r] : R2sw[r];
+                    }
+                    Yk += mm16(Ga, X);
+                    store_pair(k, mm16(Yk, IdB));
                 }
             }
-            if (!all_fast) deriv_rows_generic(P, z0, z1, h, Fb, Jb, lane, dfast);
+            if constexpr (DIAG) {   // diagnostic: time until this wave's stores have left the CU
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                QC_STAMP(P, b, lane, 12);
+                QC_STAMP_CYCLES(14);
+            }
+            QC_STAMP_FLUSH(P, b, lane, 4, 14);
         }
-        if (P.stamps != nullptr) {   // diagnostic: time until this wave's stores have left the CU
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            QC_STAMP(P, b, lane, 12);
-        }
+        if constexpr (JAC) __syncthreads();   // pairs with the copy wave's end-of-interval barrier
     }
 }
 
@@ -296,11 +406,31 @@ void qc_mfma_pack_G(const QcParams& P, const double* G, double* Gx) {
     }
 }
 
-hipError_t qc_launch_mfma_F_jac(const QcParams& P, const double* dZ, double* dF, double* dJ, hipStream_t st) {
-    if (P.n == 32) return qc_launch_mfma32_F_jac(P, dZ, dF, dJ, st);
-    const int grid = P.n_int < kMaxGrid ? P.n_int : kMaxGrid;
-    if (dJ) hipLaunchKernelGGL(qc_mfma16_pade4_kernel<true>, dim3(grid), dim3(kThreads), 0, st, P, dZ, dF, dJ);
-    else hipLaunchKernelGGL(qc_mfma16_pade4_kernel<false>, dim3(grid), dim3(64), 0, st, P, dZ, dF, dJ);
-    return hipGetLastError();
+template <bool JAC, bool DIAG, int MU>
+static void launch16m(const QcParams& P, const double* dZ, double* dF, double* dJ, hipStream_t st, int grid, int threads) {
+    switch (P.store_mode) {
+        case 0: hipLaunchKernelGGL((qc_mfma16_pade4_kernel<JAC, 0, DIAG, MU>), dim3(grid), dim3(threads), 0, st, P, dZ, dF, dJ); break;
+        case 1: hipLaunchKernelGGL((qc_mfma16_pade4_kernel<JAC, 1, DIAG, MU>), dim3(grid), dim3(threads), 0, st, P, dZ, dF, dJ); break;
+        default: hipLaunchKernelGGL((qc_mfma16_pade4_kernel<JAC, 2, DIAG, MU>), dim3(grid), dim3(threads), 0, st, P, dZ, dF, dJ); break;
+    }
 }
 
+// The number of drive images held in registers / LDS is a compile-time constant (2, 4, 6 or 8: the next even
+// number >= m, at most 8), so that small systems do not pay the register pressure of the largest.
+template <bool JAC, bool DIAG>
+static void launch16(const QcParams& P, const double* dZ, double* dF, double* dJ, hipStream_t st, int grid, int threads) {
+    if (P.m <= 2) launch16m<JAC, DIAG, 2>(P, dZ, dF, dJ, st, grid, threads);
+    else if (P.m <= 4) launch16m<JAC, DIAG, 4>(P, dZ, dF, dJ, st, grid, threads);
+    else if (P.m <= 6) launch16m<JAC, DIAG, 6>(P, dZ, dF, dJ, st, grid, threads);
+    else launch16m<JAC, DIAG, 8>(P, dZ, dF, dJ, st, grid, threads);
+}
+
+hipError_t qc_launch_mfma_F_jac(const QcParams& P, const double* dZ, double* dF, double* dJ, hipStream_t st) {
+    if (P.n == 32) return qc_launch_mfma32_F_jac(P, dZ, dF, dJ, st);
+    const int n_wg = dJ ? (P.n_int + kIntervalsPerWG - 1) / kIntervalsPerWG : P.n_int;
+    const int grid = n_wg < kMaxGrid ? n_wg : kMaxGrid;
+    const bool diag = P.stamps != nullptr || P.dbg_skip != 0;
+    if (dJ) { if (diag) launch16<true, true>(P, dZ, dF, dJ, st, grid, kThreads); else launch16<true, false>(P, dZ, dF, dJ, st, grid, kThreads); }
+    else    { if (diag) launch16<false, true>(P, dZ, dF, dJ, st, grid, 64); else launch16<false, false>(P, dZ, dF, dJ, st, grid, 64); }
+    return hipGetLastError();
+}
