@@ -17,6 +17,8 @@
  *   UnitaryPadeIntegrator(state, control, sys, traj;     qc_desc{integrator=QC_PADE, pade_order,...}
  *       order)  (unitary_smooth_pulse_problem.jl:165-167)
  *   UnitaryExponentialIntegrator(...)  (:168-170)        qc_desc{integrator=QC_EXPONENTIAL}
+ *   QuantumStatePadeIntegrator(state, control, sys, traj)  qc_desc{state_cols = number of kets}
+ *       (quantum_state_smooth_pulse_problem.jl:146-152)
  *   DerivativeIntegrator(x, dx, traj)  (:177-178)        qc_desc.deriv_{x_off,dx_off,dim}[i]
  *   QuantumDynamics(integrators, traj)                   qc_create
  *       (integrator_test_1qubit.jl:41)
@@ -96,6 +98,11 @@ typedef struct qc_desc {
     int32_t kernel;         /* QC_KERNEL_* */
     int64_t t_begin;        /* first interval (0-based) this handle evaluates */
     int64_t t_end;          /* one past the last interval; t_begin = t_end = 0 means [0, T-1) */
+    int32_t state_cols;     /* columns of the iso state matrix: 0 or N = a unitary U~ (2N x N, length 2N^2);
+                             * K >= 1 = K kets psi~ = [Re psi; Im psi] stored back to back (2N x K, length 2NK), i.e.
+                             * K QuantumStatePadeIntegrators over the same system
+                             * (quantum_state_smooth_pulse_problem.jl:146-152).  off_U is the first ket's offset. */
+    int32_t reserved0;
 } qc_desc;
 
 typedef struct qc_dims_t {

@@ -23,6 +23,7 @@ struct QCDesc
     deriv_x_off::NTuple{QC_MAX_DERIV,Int32}; deriv_dx_off::NTuple{QC_MAX_DERIV,Int32}; deriv_dim::NTuple{QC_MAX_DERIV,Int32}
     G_drift::Ptr{Float64}; G_drives::Ptr{Float64}
     device::Int32; kernel::Int32; t_begin::Int64; t_end::Int64
+    state_cols::Int32; reserved0::Int32     # 0 = unitary iso-vec; K = K ket integrators stored back to back
 end
 
 struct QCDims
@@ -61,7 +62,7 @@ is `first(traj.components[name]) - 1`.
 """
 function dynamics(integrators, traj, system; device::Int=0, eval_hessian::Bool=true,
                   state_name=:Ũ⃗, control_name=:a, pade_order::Int=4, exponential::Bool=false,
-                  derivative_pairs=[(:a, :da), (:da, :dda)])
+                  derivative_pairs=[(:a, :da), (:da, :dda)], n_kets::Int=0)
     off(name) = first(traj.components[name]) - 1
     n = 2 * system.levels
     G0 = Matrix{Float64}(system.G_drift)                       # column-major n x n
@@ -76,7 +77,7 @@ function dynamics(integrators, traj, system; device::Int=0, eval_hessian::Bool=t
                           off(state_name), off(control_name), free_time ? off(traj.timestep) : -1,
                           free_time ? 0.0 : Float64(traj.timestep),
                           exponential ? 1 : 0, exponential ? 0 : pade_order, length(derivative_pairs),
-                          pad8(xs), pad8(dxs), pad8(dms), pointer(G0), pointer(Gd), device, 0, 0, 0))
+                          pad8(xs), pad8(dxs), pad8(dms), pointer(G0), pointer(Gd), device, 0, 0, 0, n_kets, 0))
         check(ccall((:qc_create, LIB[]), Cint, (Ref{QCDesc}, Ref{Ptr{Cvoid}}), desc, h))
     end
     check(ccall((:qc_dims, LIB[]), Cint, (Ptr{Cvoid}, Ref{QCDims}), h[], dims), h[])

@@ -41,7 +41,10 @@ typedef struct {
     int x_off[QCO_MAX_DERIV], dx_off[QCO_MAX_DERIV], ddim[QCO_MAX_DERIV];
     const double* G_drift;  /* n*n col-major */
     const double* G_drives; /* m * n*n */
+    int ncol;               /* columns of the iso state: 0 -> N (unitary), K -> K kets back to back */
 } qco_problem;
+
+static int qco_nc(const qco_problem* P) { return P->ncol > 0 ? P->ncol : P->N; }
 
 /* C (r x c) = A (r x k) * B (k x c), column-major */
 static void mm(double* C, const double* A, const double* B, int r, int k, int c) {
@@ -77,19 +80,19 @@ static void pade_coeffs(int order, double* c) {
 }
 
 int qco_ddim(const qco_problem* P) {
-    int d = 2 * P->N * P->N;
+    int d = 2 * P->N * qco_nc(P);
     for (int i = 0; i < P->n_deriv; ++i) d += P->ddim[i];
     return d;
 }
 int qco_jac_nnz(const qco_problem* P) {
-    const int n = 2 * P->N, s = n * P->N, ft = P->off_dt >= 0;
-    int o = P->N * n * n + (P->integrator == 0 ? P->N * n * n : s) + s * P->m + (ft ? s : 0);
+    const int n = 2 * P->N, nc = qco_nc(P), s = n * nc, ft = P->off_dt >= 0;
+    int o = nc * n * n + (P->integrator == 0 ? nc * n * n : s) + s * P->m + (ft ? s : 0);
     for (int i = 0; i < P->n_deriv; ++i) o += (ft ? 4 : 3) * P->ddim[i];
     return o;
 }
 int qco_hess_nnz(const qco_problem* P) {
     if (P->integrator != 0) return 0;
-    const int n = 2 * P->N, s = n * P->N, m = P->m, ft = P->off_dt >= 0;
+    const int n = 2 * P->N, s = n * qco_nc(P), m = P->m, ft = P->off_dt >= 0;
     int o = 2 * s * m + m * (m + 1) / 2;
     if (ft) {
         o += m + 2 * s + 1;
@@ -152,7 +155,7 @@ static void accumulate_dpow(const qco_ws* w, const double* Gj, int n, int k, dou
 }
 
 static void interval_F_jac(const qco_problem* P, const qco_ws* w, const double* z0, const double* z1, double* Fo, double* Jo) {
-    const int N = P->N, n = 2 * N, s = n * N, m = P->m, ft = P->off_dt >= 0;
+    const int n = 2 * P->N, N = qco_nc(P) /* state columns */, s = n * N, m = P->m, ft = P->off_dt >= 0;
     const size_t n2 = (size_t)n * n;
     const double h = ft ? z0[P->off_dt] : P->dt_fixed;
     const double* U0 = z0 + P->off_U;
@@ -320,7 +323,7 @@ static void d2pow_accumulate(const qco_ws* w, const double* Gi, const double* Gj
 }
 
 static void interval_hess(const qco_problem* P, const qco_ws* w, const double* z0, const double* z1, const double* mu, double* Ho) {
-    const int N = P->N, n = 2 * N, s = n * N, m = P->m, ft = P->off_dt >= 0;
+    const int n = 2 * P->N, N = qco_nc(P) /* state columns */, s = n * N, m = P->m, ft = P->off_dt >= 0;
     const size_t n2 = (size_t)n * n;
     const int p = P->order / 2;
     const double h = ft ? z0[P->off_dt] : P->dt_fixed;

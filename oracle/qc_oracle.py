@@ -84,14 +84,20 @@ class Problem:
     order: int = 4
     derivs: List[DerivSpec] = field(default_factory=list)
     global_dim: int = 0
+    ncol: int = 0                # columns of the iso state: 0 -> N (unitary); K -> K kets stored back to back
+                                 # (QuantumStatePadeIntegrator per ket, reference quantum_state_smooth_pulse_problem.jl:146-152)
 
     @property
     def n(self) -> int:
         return 2 * self.N
 
     @property
+    def nc(self) -> int:
+        return self.ncol if self.ncol > 0 else self.N
+
+    @property
     def s(self) -> int:
-        return 2 * self.N * self.N
+        return 2 * self.N * self.nc
 
     @property
     def free_time(self) -> bool:
@@ -124,7 +130,7 @@ def _G_of(prob: Problem, a: np.ndarray) -> np.ndarray:
 
 
 def _split(prob: Problem, z0: np.ndarray, z1: np.ndarray):
-    n, N = prob.n, prob.N
+    n, N = prob.n, prob.nc
     U0 = z0[prob.off_U:prob.off_U + prob.s].reshape(n, N, order="F")
     U1 = z1[prob.off_U:prob.off_U + prob.s].reshape(n, N, order="F")
     a = z0[prob.off_a:prob.off_a + prob.m]
@@ -178,11 +184,11 @@ def interval_residual(prob: Problem, z0: np.ndarray, z1: np.ndarray) -> np.ndarr
         B = sum(((-1) ** k) * c[k] * h ** k * np.linalg.matrix_power(G, k) for k in range(len(c)))
         F = sum(c[k] * h ** k * np.linalg.matrix_power(G, k) for k in range(len(c)))
         # explicit Kronecker form, as the reference forms it per knot: (I_N (x) B) U1vec - (I_N (x) F) U0vec
-        IN = np.eye(prob.N)
+        IN = np.eye(prob.nc)
         out[:prob.s] = np.kron(IN, B) @ _vec(U1) - np.kron(IN, F) @ _vec(U0)
     else:
         E = expm_taylor(h * G)
-        out[:prob.s] = _vec(U1) - np.kron(np.eye(prob.N), E) @ _vec(U0)
+        out[:prob.s] = _vec(U1) - np.kron(np.eye(prob.nc), E) @ _vec(U0)
     r = prob.s
     for d in prob.derivs:
         x0 = z0[d.x_off:d.x_off + d.dim]
@@ -217,7 +223,7 @@ def _d2Gpow(G: np.ndarray, Gi: np.ndarray, Gj: np.ndarray, k: int) -> np.ndarray
 def interval_jacobian_dense(prob: Problem, z0: np.ndarray, z1: np.ndarray) -> np.ndarray:
     U0, U1, a, h = _split(prob, z0, z1)
     G = _G_of(prob, a)
-    n, N, s, m, zd = prob.n, prob.N, prob.s, prob.m, prob.zdim
+    n, N, s, m, zd = prob.n, prob.nc, prob.s, prob.m, prob.zdim
     J = np.zeros((prob.ddim, 2 * zd), dtype=np.result_type(z0, z1, float))
     IN = np.eye(N)
     mp = np.linalg.matrix_power
@@ -266,7 +272,7 @@ def interval_hessian_dense(prob: Problem, z0: np.ndarray, z1: np.ndarray, mu: np
         raise NotImplementedError("analytic Hessian only for the Pade integrator (SURVEY A.6)")
     U0, U1, a, h = _split(prob, z0, z1)
     G = _G_of(prob, a)
-    n, N, s, m, zd = prob.n, prob.N, prob.s, prob.m, prob.zdim
+    n, N, s, m, zd = prob.n, prob.nc, prob.s, prob.m, prob.zdim
     M = mu[:s].reshape(n, N, order="F")
     c = pade_coeffs(prob.order)
     p = len(c) - 1
@@ -331,7 +337,7 @@ def interval_hessian_dense(prob: Problem, z0: np.ndarray, z1: np.ndarray, mu: np
 #  rows 0..ddim-1, cols 0..2*zdim-1 (col >= zdim  <=>  knot t+1).
 # --------------------------------------------------------------------------------------------
 def jac_structure_local(prob: Problem) -> List[Tuple[int, int]]:
-    n, N, s, m, zd = prob.n, prob.N, prob.s, prob.m, prob.zdim
+    n, N, s, m, zd = prob.n, prob.nc, prob.s, prob.m, prob.zdim
     st: List[Tuple[int, int]] = []
     # 1. d/dU_t = -(I_N (x) F): N dense n x n diagonal blocks, column-major inside each block
     for q in range(N):

@@ -16,7 +16,7 @@ class qco_problem(C.Structure):
     _fields_ = [("N", C.c_int), ("m", C.c_int), ("T", C.c_longlong), ("zdim", C.c_int), ("off_U", C.c_int),
                 ("off_a", C.c_int), ("off_dt", C.c_int), ("dt_fixed", C.c_double), ("integrator", C.c_int),
                 ("order", C.c_int), ("n_deriv", C.c_int), ("x_off", C.c_int * 8), ("dx_off", C.c_int * 8),
-                ("ddim", C.c_int * 8), ("G_drift", _dp), ("G_drives", _dp)]
+                ("ddim", C.c_int * 8), ("G_drift", _dp), ("G_drives", _dp), ("ncol", C.c_int)]
 
 
 def load(build: bool = True) -> C.CDLL:
@@ -53,6 +53,7 @@ class COracle:
         self._Gd = np.ascontiguousarray(np.stack([g.reshape(-1, order="F") for g in prob.G_drives])) if prob.m else np.zeros((1, 1))
         p.G_drift = self._G0.ctypes.data_as(_dp)
         p.G_drives = self._Gd.ctypes.data_as(_dp)
+        p.ncol = getattr(prob, "ncol", 0)
         self.p = p
         self.ddim = self.lib.qco_ddim(C.byref(p))
         self.jac_nnz = self.lib.qco_jac_nnz(C.byref(p))

@@ -59,6 +59,8 @@ class qc_desc(C.Structure):
         ("kernel", C.c_int32),
         ("t_begin", C.c_int64),
         ("t_end", C.c_int64),
+        ("state_cols", C.c_int32),
+        ("reserved0", C.c_int32),
     ]
 
 

@@ -93,7 +93,9 @@ int qc_build_params(const qc_desc* d, QcParams* P, qc_dims_t* dims, std::string*
     memset(P, 0, sizeof(*P));
     P->N = d->N;
     P->n = 2 * d->N;
-    P->s = 2 * d->N * d->N;
+    if (d->state_cols < 0 || d->state_cols > 64) return fail(err, QC_ERR_INVALID, "state_cols must be in 0..64");
+    P->nc = d->state_cols > 0 ? d->state_cols : d->N;
+    P->s = 2 * d->N * P->nc;
     P->m = d->m;
     P->zdim = d->zdim;
     P->off_U = d->off_U;
@@ -145,8 +147,8 @@ int qc_build_params(const qc_desc* d, QcParams* P, qc_dims_t* dims, std::string*
     const bool ft = P->off_dt >= 0;
     // Jacobian block offsets
     int o = 0;
-    P->jo_F = o;  o += P->N * n2;
-    P->jo_B = o;  o += (P->integrator == QC_PADE) ? P->N * n2 : s;
+    P->jo_F = o;  o += P->nc * n2;
+    P->jo_B = o;  o += (P->integrator == QC_PADE) ? P->nc * n2 : s;
     P->jo_a = o;  o += s * m;
     P->jo_h = o;  o += ft ? s : 0;
     P->jo_d = o;
@@ -188,7 +190,7 @@ int qc_build_params(const qc_desc* d, QcParams* P, qc_dims_t* dims, std::string*
 void qc_local_jac_structure(const QcParams& P, std::vector<int32_t>* R, std::vector<int32_t>* C) {
     R->clear(); C->clear();
     R->reserve(P.jac_nnz); C->reserve(P.jac_nnz);
-    const int n = P.n, N = P.N, s = P.s, m = P.m, zd = P.zdim;
+    const int n = P.n, N = P.nc, s = P.s, m = P.m, zd = P.zdim;
     const bool ft = P.off_dt >= 0;
     for (int q = 0; q < N; ++q)
         for (int c = 0; c < n; ++c)

@@ -18,6 +18,7 @@
 //   [ (U_t,a) s*m | (a,U_t+1) s*m | (a,a) upper m(m+1)/2 | (a,h) m | (U_t,h) s | (h,U_t+1) s | (h,h) 1 | (dx,h) ... ]
 struct QcParams {
     int N, n, s, m, zdim, ddim;
+    int nc;                  // columns of the iso state matrix (N for a unitary, K for K kets); s = n * nc
     int off_U, off_a, off_dt;
     double dt_fixed;
     int integrator;

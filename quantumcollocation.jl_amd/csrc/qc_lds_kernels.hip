@@ -24,7 +24,7 @@ __host__ __device__ inline int even_up(int x) { return (x + 1) & ~1; }
 
 __host__ __device__ inline LdsJacLayout jac_layout(const QcParams& P) {
     LdsJacLayout L;
-    const int n2 = P.n * P.n, nN = P.n * P.N;
+    const int n2 = P.n * P.n, nN = P.n * P.nc;
     const int p = P.p > 0 ? P.p : 1;
     int o = 0;
     L.z0 = o; o += even_up(P.zdim);
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(kThreads) void qc_lds_pade_kernel(const QcParams P,
     const int tid = threadIdx.x;
     const int b = qc_xcd_remap(blockIdx.x, gridDim.x);
     const long long t = P.t_begin + b;
-    const int n = P.n, N = P.N, s = P.s, m = P.m, p = P.p;
+    const int n = P.n, N = P.nc, s = P.s, m = P.m, p = P.p;
     const int n2 = n * n, nN = n * N;
     const LdsJacLayout L = jac_layout(P);
     double* z0 = sm + L.z0;
@@ -217,7 +217,7 @@ struct LdsHessLayout {
 
 __host__ __device__ inline LdsHessLayout hess_layout(const QcParams& P, int cj) {
     LdsHessLayout L;
-    const int n2 = P.n * P.n, nN = P.n * P.N, p = P.p, m = P.m > 0 ? P.m : 1;
+    const int n2 = P.n * P.n, nN = P.n * P.nc, p = P.p, m = P.m > 0 ? P.m : 1;
     int o = 0;
     L.z0 = o; o += even_up(P.zdim);
     L.z1 = o; o += even_up(P.zdim);
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(kThreads) void qc_lds_pade_hess_kernel(const QcPara
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = qc_xcd_remap(blockIdx.x, gridDim.x);
     const long long t = P.t_begin + b;
-    const int n = P.n, N = P.N, s = P.s, m = P.m, p = P.p;
+    const int n = P.n, N = P.nc, s = P.s, m = P.m, p = P.p;
     const int n2 = n * n, nN = n * N;
     const LdsHessLayout L = hess_layout(P, cj);
     double* z0 = sm + L.z0;
@@ -497,7 +497,7 @@ struct LdsExpLayout {
 
 __host__ __device__ inline LdsExpLayout exp_layout(const QcParams& P, int cj) {
     LdsExpLayout L;
-    const int n2 = P.n * P.n, nN = P.n * P.N;
+    const int n2 = P.n * P.n, nN = P.n * P.nc;
     int o = 0;
     L.z0 = o; o += even_up(P.zdim);
     L.z1 = o; o += even_up(P.zdim);
@@ -524,7 +524,7 @@ __global__ __launch_bounds__(kThreads) void qc_lds_exp_kernel(const QcParams P, 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = qc_xcd_remap(blockIdx.x, gridDim.x);
     const long long t = P.t_begin + b;
-    const int n = P.n, N = P.N, s = P.s, m = P.m;
+    const int n = P.n, N = P.nc, s = P.s, m = P.m;
     const int n2 = n * n, nN = n * N;
     const LdsExpLayout L = exp_layout(P, cj);
     double* z0 = sm + L.z0;

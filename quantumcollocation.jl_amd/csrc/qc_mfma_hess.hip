@@ -183,7 +183,7 @@ __global__ __launch_bounds__(64) void qc_mfma16_pade4_hess_kernel(const QcParams
 }  // namespace
 
 bool qc_mfma_hess_supported(const QcParams& P) {
-    return P.integrator == QC_PADE && P.p == 2 && P.n == 16 && P.m <= kHM;
+    return P.integrator == QC_PADE && P.p == 2 && P.n == 16 && P.nc == P.N && P.m <= kHM;
 }
 
 hipError_t qc_launch_mfma_hess(const QcParams& P, const double* dZ, const double* dMu, double* dH, hipStream_t st) {

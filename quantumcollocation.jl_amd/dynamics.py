@@ -18,7 +18,8 @@ import numpy as np
 import torch
 
 from . import _lib
-from .integrators import DerivativeIntegrator, UnitaryExponentialIntegrator, UnitaryPadeIntegrator, _UnitaryIntegrator
+from .integrators import (DerivativeIntegrator, QuantumStateExponentialIntegrator, QuantumStatePadeIntegrator,
+                          UnitaryExponentialIntegrator, UnitaryPadeIntegrator, _KetIntegrator, _UnitaryIntegrator)
 from .named_trajectory import NamedTrajectory
 
 _KERNELS = {"auto": _lib.QC_KERNEL_AUTO, "lds": _lib.QC_KERNEL_LDS, "mfma": _lib.QC_KERNEL_MFMA}
@@ -28,11 +29,23 @@ _ALIASES = {"∂F": "dF", "μ∂²F": "mu_d2F", "∂F_structure": "dF_structure"
 def make_desc(integrators: Sequence, traj: NamedTrajectory, *, device: int = 0, kernel: str = "auto",
               t_range: Optional[Tuple[int, int]] = None):
     """Translate (integrators, traj) into a qc_desc.  Returns (desc, keepalive)."""
-    if not integrators or not isinstance(integrators[0], _UnitaryIntegrator):
-        raise NotImplementedError("the first integrator must be the unitary integrator "
+    if not integrators or not isinstance(integrators[0], (_UnitaryIntegrator, _KetIntegrator)):
+        raise NotImplementedError("the first integrator must be the unitary (or the first ket) integrator "
                                   "(row order of reference unitary_smooth_pulse_problem.jl:175-179)")
     P = integrators[0]
-    derivs = list(integrators[1:])
+    n_state = 1
+    if isinstance(P, _KetIntegrator):
+        # K ket integrators over the same system and controls = one 2N x K iso state; their trajectory components
+        # must lie back to back in integrator order (quantum_state_smooth_pulse_problem.jl:146-152)
+        while n_state < len(integrators) and isinstance(integrators[n_state], _KetIntegrator):
+            Q = integrators[n_state]
+            if type(Q) is not type(P) or Q.system is not P.system or Q.control_name != P.control_name or \
+                    getattr(Q, "order", None) != getattr(P, "order", None):
+                raise NotImplementedError("all ket integrators must share the system, the control and the integrator type")
+            if traj.offset(Q.state_name) != traj.offset(P.state_name) + n_state * P.dim:
+                raise NotImplementedError("ket components must be contiguous and in integrator order")
+            n_state += 1
+    derivs = list(integrators[n_state:])
     for D in derivs:
         if not isinstance(D, DerivativeIntegrator):
             raise NotImplementedError("only DerivativeIntegrators may follow the unitary integrator")
@@ -53,10 +66,11 @@ def make_desc(integrators: Sequence, traj: NamedTrajectory, *, device: int = 0, 
     else:
         d.off_dt = -1
         d.dt_fixed = float(traj.timestep)
-    if isinstance(P, UnitaryPadeIntegrator):
+    d.state_cols = n_state if isinstance(P, _KetIntegrator) else 0
+    if isinstance(P, (UnitaryPadeIntegrator, QuantumStatePadeIntegrator)):
         d.integrator = _lib.QC_PADE
         d.pade_order = P.order
-    elif isinstance(P, UnitaryExponentialIntegrator):
+    elif isinstance(P, (UnitaryExponentialIntegrator, QuantumStateExponentialIntegrator)):
         d.integrator = _lib.QC_EXPONENTIAL
         d.pade_order = 0
     else:

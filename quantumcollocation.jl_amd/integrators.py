@@ -50,6 +50,41 @@ class UnitaryExponentialIntegrator(_UnitaryIntegrator):
 
 
 @dataclass
+class _KetIntegrator:
+    """One ket psi~ = [Re psi; Im psi] (length 2N) under the same generators: the 1-column case of the unitary
+    integrator (reference quantum_state_smooth_pulse_problem.jl:146-152, one integrator per state)."""
+    state_name: str
+    control_name: str
+    system: QuantumSystem
+    traj: NamedTrajectory
+
+    def __post_init__(self):
+        if len(self.traj.components[self.state_name]) != 2 * self.system.levels:
+            raise ValueError(f"ket component {self.state_name} must have length 2 N = {2 * self.system.levels}")
+        if len(self.traj.components[self.control_name]) != self.system.n_drives:
+            raise ValueError("control component length must equal system.n_drives")
+
+    @property
+    def dim(self) -> int:
+        return 2 * self.system.levels
+
+
+@dataclass
+class QuantumStatePadeIntegrator(_KetIntegrator):
+    order: int = 4
+
+    def __post_init__(self):
+        super().__post_init__()
+        if self.order < 2 or self.order % 2 or self.order > 20:
+            raise ValueError("Pade order must be even, 2..20")
+
+
+@dataclass
+class QuantumStateExponentialIntegrator(_KetIntegrator):
+    pass
+
+
+@dataclass
 class DerivativeIntegrator:
     x: str
     dx: str

@@ -16,7 +16,8 @@ from typing import List, Optional
 import numpy as np
 
 from .gates import GATES, operator_from_string
-from .integrators import DerivativeIntegrator, UnitaryExponentialIntegrator, UnitaryPadeIntegrator
+from .integrators import (DerivativeIntegrator, QuantumStateExponentialIntegrator, QuantumStatePadeIntegrator,
+                          UnitaryExponentialIntegrator, UnitaryPadeIntegrator)
 from .named_trajectory import NamedTrajectory
 from .quantum_systems import QuantumSystem
 from .trajectory_initialization import initialize_trajectory
@@ -90,3 +91,38 @@ def config_inputs(cfg: int, T: Optional[int] = None, **kw) -> HotPathInputs:
     out = unitary_smooth_pulse_inputs(system, GATES[spec.gate], T if T is not None else spec.T, **kw)
     out.spec = spec
     return out
+
+
+def quantum_state_smooth_pulse_inputs(system: QuantumSystem, psi_inits, psi_goals, T: int, dt: float = 0.2, *,
+                                      free_time: bool = True, integrator: str = "pade", pade_order: int = 4,
+                                      seed: int = SEED) -> HotPathInputs:
+    """Inputs of `QuantumStateSmoothPulseProblem` (reference quantum_state_smooth_pulse_problem.jl:57-208): one
+    trajectory component and one integrator per ket (:146-152), then the two derivative integrators.  States are
+    linear interpolations init -> goal plus noise (the hot path does not care how the guess was made)."""
+    from .named_trajectory import NamedTrajectory
+    rng = np.random.default_rng(seed)
+    m, N = system.n_drives, system.levels
+    comps = {}
+    names = []
+    for k, (p0, p1) in enumerate(zip(psi_inits, psi_goals)):
+        p0 = np.asarray(p0, dtype=complex)
+        p1 = np.asarray(p1, dtype=complex)
+        lam = np.linspace(0.0, 1.0, T)[None, :]
+        iso0 = np.concatenate([p0.real, p0.imag])[:, None]
+        iso1 = np.concatenate([p1.real, p1.imag])[:, None]
+        name = f"ψ̃{k + 1}" if len(psi_inits) > 1 else "ψ̃"
+        comps[name] = iso0 * (1 - lam) + iso1 * lam + 1e-2 * rng.standard_normal((2 * N, T))
+        names.append(name)
+    a = np.zeros((m, T))
+    a[:, 1:T - 1] = rng.uniform(-1, 1, size=(m, T - 2))
+    comps["a"] = a
+    comps["da"] = 0.1 * rng.standard_normal((m, T))
+    comps["dda"] = 0.1 * rng.standard_normal((m, T))
+    if free_time:
+        comps["Δt"] = np.full((1, T), dt)
+    traj = NamedTrajectory(comps, controls=("dda", "Δt") if free_time else ("dda",), timestep="Δt" if free_time else dt)
+    cls = QuantumStatePadeIntegrator if integrator == "pade" else QuantumStateExponentialIntegrator
+    kw = {"order": pade_order} if integrator == "pade" else {}
+    integrators = [cls(nm, "a", system, traj, **kw) for nm in names]
+    integrators += [DerivativeIntegrator("a", "da", traj), DerivativeIntegrator("da", "dda", traj)]
+    return HotPathInputs(system, traj, integrators)

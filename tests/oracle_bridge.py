@@ -13,9 +13,10 @@ def problem_from_inputs(inp, T=None):
     P = inp.integrators[0]
     traj = inp.traj
     sys_ = P.system
-    derivs = [o.DerivSpec(traj.offset(D.x), traj.offset(D.dx), D.dim) for D in inp.integrators[1:]]
+    derivs = [o.DerivSpec(traj.offset(D.x), traj.offset(D.dx), D.dim) for D in inp.integrators if isinstance(D, qc.DerivativeIntegrator)]
     free = isinstance(traj.timestep, str)
-    is_pade = isinstance(P, qc.UnitaryPadeIntegrator)
+    is_pade = isinstance(P, (qc.UnitaryPadeIntegrator, qc.QuantumStatePadeIntegrator))
+    kets = [I for I in inp.integrators if isinstance(I, (qc.QuantumStatePadeIntegrator, qc.QuantumStateExponentialIntegrator))]
     return o.Problem(
         N=sys_.levels, m=sys_.n_drives, T=traj.T if T is None else T, zdim=traj.dim,
         off_U=traj.offset(P.state_name), off_a=traj.offset(P.control_name),
@@ -24,14 +25,14 @@ def problem_from_inputs(inp, T=None):
         dt_fixed=0.0 if free else float(traj.timestep),
         integrator=o.PADE if is_pade else o.EXPONENTIAL,
         order=P.order if is_pade else 4,
-        derivs=derivs, global_dim=traj.global_dim,
+        derivs=derivs, global_dim=traj.global_dim, ncol=len(kets),
     )
 
 
-def random_problem(o, N, m, T, order=4, free_time=True, integrator=None, seed=0, layout="standard", hermitian=True):
+def random_problem(o, N, m, T, order=4, free_time=True, integrator=None, seed=0, layout="standard", hermitian=True, ncol=0):
     """A random oracle Problem + trajectory vector, independent of the host layer."""
     rng = np.random.default_rng(seed)
-    n, s = 2 * N, 2 * N * N
+    n, s = 2 * N, 2 * N * (ncol if ncol > 0 else N)
 
     def rand_H():
         A = rng.standard_normal((N, N)) + 1j * rng.standard_normal((N, N))
@@ -59,7 +60,7 @@ def random_problem(o, N, m, T, order=4, free_time=True, integrator=None, seed=0,
     if off_dda is not None:
         derivs.append(o.DerivSpec(off_da, off_dda, m))
     prob = o.Problem(N=N, m=m, T=T, zdim=zdim, off_U=off_U, off_a=off_a, off_dt=off_dt, G_drift=G0, G_drives=Gd,
-                     dt_fixed=0.17, integrator=o.PADE if integrator is None else integrator, order=order, derivs=derivs)
+                     dt_fixed=0.17, integrator=o.PADE if integrator is None else integrator, order=order, derivs=derivs, ncol=ncol)
     Z = rng.standard_normal(zdim * T) * 0.5
     if free_time:
         Z[off_dt::zdim] = rng.uniform(0.1, 0.3, size=T)

@@ -145,3 +145,22 @@ def test_product_code_never_imports_the_oracle():
                 for pat in (r"import\s+oracle", r"from\s+oracle", r"qc_oracle", r"libqc_oracle", r"oracle/", r"load_oracle",
                             r"dlopen", r"qco_"):
                     assert not re.search(pat, txt), f"{fn} references the oracle ({pat})"
+
+
+def test_ket_integrators_build_a_descriptor(qc, oracle):
+    sys_ = qc.multi_qubit_system(2)
+    psi0 = [np.eye(4)[:, 0], np.eye(4)[:, 1]]
+    psi1 = [np.eye(4)[:, 1], np.eye(4)[:, 0]]
+    inp = qc.quantum_state_smooth_pulse_inputs(sys_, psi0, psi1, 9)
+    desc, keep = qc.make_desc(inp.integrators, inp.traj)
+    assert desc.state_cols == 2 and desc.N == 4 and desc.n_deriv == 2
+    dims = qc.desc_dims(desc)
+    prob = problem_from_inputs(inp)
+    assert prob.ncol == 2 and dims.ddim == prob.ddim == 2 * 8 + 8
+    jr, jc, hr, hc = qc.desc_structures(desc)
+    rr, rc = oracle.jac_structure(prob)
+    np.testing.assert_array_equal(jr, rr)
+    np.testing.assert_array_equal(jc, rc)
+    ohr, ohc = oracle.hess_structure(prob)
+    np.testing.assert_array_equal(hr, ohr)
+    np.testing.assert_array_equal(hc, ohc)

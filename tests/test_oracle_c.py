@@ -66,3 +66,17 @@ def test_oracles_reproduce_the_golden_vectors(oracle, coracle):
     np.testing.assert_allclose(F, gold["F"], rtol=1e-12, atol=1e-14)
     np.testing.assert_allclose(J, gold["dF"], rtol=1e-12, atol=1e-14)
     np.testing.assert_allclose(co.mu_d2F(Zv, mu), gold["mu_d2F"], rtol=1e-12, atol=1e-14)
+
+
+@pytest.mark.parametrize("K", [1, 2, 5])
+def test_c_oracle_kets(oracle, coracle, K):
+    for integ in (oracle.PADE, oracle.EXPONENTIAL):
+        prob, Z = random_problem(oracle, N=3, m=2, T=4, order=4, seed=60 + K, integrator=integ, ncol=K)
+        co = coracle.COracle(prob)
+        F, J = co.F_dF(Z)
+        np.testing.assert_allclose(F, oracle.F(prob, Z), rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(J, oracle.dF(prob, Z), rtol=1e-11, atol=1e-12)
+        assert co.jac_nnz == oracle.jac_nnz_interval(prob)
+        if integ == oracle.PADE:
+            mu = np.random.default_rng(3).standard_normal(prob.n_rows)
+            np.testing.assert_allclose(co.mu_d2F(Z, mu), oracle.mu_d2F(prob, Z, mu), rtol=1e-11, atol=1e-12)

@@ -246,3 +246,23 @@ def test_reference_fixture_layout(oracle):
     np.testing.assert_allclose(fx["initial_U"], oracle.operator_to_iso_vec(np.eye(2)))
     np.testing.assert_allclose(fx["goal_U"], oracle.operator_to_iso_vec(np.array([[0, 1], [1, 0]])))  # file says X
     np.testing.assert_array_equal(data[14], 0.2)
+
+
+@pytest.mark.parametrize("K", [1, 3])
+@pytest.mark.parametrize("integrator", ["pade", "exp"])
+def test_ket_problem_derivatives(oracle, K, integrator):
+    """K kets = an n x K iso state: same formulas, K columns (reference quantum_state_smooth_pulse_problem.jl:146-152)."""
+    integ = oracle.PADE if integrator == "pade" else oracle.EXPONENTIAL
+    prob, Z = random_problem(oracle, N=3, m=2, T=2, order=6, seed=40 + K, integrator=integ, ncol=K)
+    zd = prob.zdim
+    zz = Z[:2 * zd]
+    assert prob.s == 6 * K and prob.ddim == 6 * K + 4
+    J = oracle.interval_jacobian_dense(prob, zz[:zd], zz[zd:])
+    Jcs = complex_step_jac(lambda x: oracle.interval_residual(prob, x[:zd], x[zd:]), zz)
+    np.testing.assert_allclose(J, Jcs, rtol=1e-11, atol=1e-12)
+    assert oracle.jac_nnz_interval(prob) == (2 * K * 36 if integ == oracle.PADE else K * 36 + 6 * K) + 6 * K * 2 + 6 * K + 16
+    if integ == oracle.PADE:
+        mu = np.random.default_rng(1).standard_normal(prob.ddim)
+        Hd = oracle.interval_hessian_dense(prob, zz[:zd], zz[zd:], mu)
+        Hcs = complex_step_jac(lambda x: oracle.interval_jacobian_dense(prob, x[:zd], x[zd:]).T @ mu, zz)
+        np.testing.assert_allclose(Hd, Hcs, rtol=1e-11, atol=1e-12)
