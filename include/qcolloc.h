@@ -170,6 +170,23 @@ int qc_eval_hess(qc_handle* h, const double* Z, const double* mu, double* hvals)
 int qc_eval_F_jac_dev(qc_handle* h, const double* dZ, double* dF, double* dvals, void* stream);
 int qc_eval_hess_dev(qc_handle* h, const double* dZ, const double* dmu, double* dhvals, void* stream);
 
+/* ---- fidelity of the final knot (SURVEY 8f "next" row 1) -------------------------------------------- */
+/* F(U~) = |tr(U_goal' U)| / n over the subspace block (`iso_vec_unitary_fidelity(U_T, U_G, subspace=...)`,
+ * reference unitary_minimum_time_problem.jl:77) and the loss l = |1 - F| of `UnitaryInfidelityObjective`
+ * (docstring unitary_smooth_pulse_problem.jl:23-28); `FinalUnitaryFidelityConstraint` (:80-84) is F - F_min >= 0.
+ * grad: dF/dU~ (length 2N^2); hess: d2F/dU~2, dense upper triangle, column-major (entry (i<=j) at j(j+1)/2 + i).
+ * For the loss: grad l = -sign(1-F) grad F, hess l = -sign(1-F) hess F.  The normalisation (|tr|/n) follows the
+ * docstring; PiccoloQuantumObjects 0.3's own definition could not be inspected. */
+typedef struct qc_fidelity qc_fidelity;
+int qc_fidelity_create(int32_t N, const double* goal_iso, const int32_t* subspace /* 0-based, or NULL */, int32_t n_sub,
+                       int32_t device, qc_fidelity** out);
+void qc_fidelity_destroy(qc_fidelity* h);
+const char* qc_fidelity_last_error(const qc_fidelity* h);
+/* host buffers; any of fidelity / infidelity / grad / hess may be NULL */
+int qc_fidelity_eval(qc_fidelity* h, const double* U_iso, double* fidelity, double* infidelity, double* grad, double* hess);
+/* device buffers, asynchronous on `stream`: dval2 = {F, |1-F|}; dgrad / dhess may be NULL */
+int qc_fidelity_eval_dev(qc_fidelity* h, const double* dU, double* dval2, double* dgrad, double* dhess, void* stream);
+
 /* Diagnostic only: when the environment variable QC_STAMPS=1 is set at qc_create, the MFMA kernel
  * records 16 s_memrealtime (100 MHz) checkpoints per interval; this copies them out (synchronises the
  * device).  Not part of the evaluated path; a handle created without QC_STAMPS returns

@@ -488,3 +488,48 @@ def dense_from_coo(vals: np.ndarray, rows: np.ndarray, cols: np.ndarray, shape, 
     if symmetric:
         Mx = np.triu(Mx) + np.triu(Mx, 1).T
     return Mx
+
+
+# --------------------------------------------------------------------------------------------
+#  fidelity of the final knot (objective / constraint), [DERIVED] from the docstring
+#  reference unitary_smooth_pulse_problem.jl:23-28:  l(U_T, U_goal) = | 1 - |tr(U_goal' U_T)| / N |
+#  and the call site unitary_minimum_time_problem.jl:77 `iso_vec_unitary_fidelity(U_T, U_G, subspace=...)`.
+#  The exact normalisation lives in the un-vendored PiccoloQuantumObjects 0.3 (|tr|/n vs |tr|^2/n^2): UNVERIFIED.
+# --------------------------------------------------------------------------------------------
+def fidelity_vectors(goal_iso: np.ndarray, N: int, subspace=None):
+    """Constant vectors g_r, g_i with tr(U_goal' U) = g_r.u + i g_i.u over the subspace block; n = len(subspace)."""
+    sub = list(range(N)) if subspace is None else list(subspace)
+    G = iso_vec_to_operator(goal_iso)
+    gr = np.zeros(2 * N * N)
+    gi = np.zeros(2 * N * N)
+    for j in sub:
+        for i in sub:
+            re_idx, im_idx = j * 2 * N + i, j * 2 * N + N + i
+            gr[re_idx], gr[im_idx] = G[i, j].real, G[i, j].imag
+            gi[re_idx], gi[im_idx] = -G[i, j].imag, G[i, j].real
+    return gr, gi, len(sub)
+
+
+def iso_vec_unitary_fidelity(u: np.ndarray, goal_iso: np.ndarray, subspace=None):
+    N = int(round(math.sqrt(goal_iso.size / 2)))
+    gr, gi, n = fidelity_vectors(goal_iso, N, subspace)
+    tr, ti = gr @ u, gi @ u
+    return np.sqrt(tr * tr + ti * ti) / n
+
+
+def fidelity_value_grad_hess(u: np.ndarray, goal_iso: np.ndarray, subspace=None):
+    """F, dF/du (s), d2F/du2 (s x s dense)."""
+    N = int(round(math.sqrt(goal_iso.size / 2)))
+    gr, gi, n = fidelity_vectors(goal_iso, N, subspace)
+    tr, ti = gr @ u, gi @ u
+    Fv = np.sqrt(tr * tr + ti * ti) / n
+    grad = (tr * gr + ti * gi) / (n * n * Fv)
+    hess = (np.outer(gr, gr) + np.outer(gi, gi)) / (n * n * Fv) - np.outer(grad, grad) / Fv
+    return Fv, grad, hess
+
+
+def infidelity_value_grad_hess(u: np.ndarray, goal_iso: np.ndarray, subspace=None):
+    """l = |1 - F| with its gradient and Hessian."""
+    Fv, g, Hm = fidelity_value_grad_hess(u, goal_iso, subspace)
+    sg = 1.0 if 1.0 - Fv >= 0 else -1.0
+    return abs(1.0 - Fv), -sg * g, -sg * Hm
