@@ -103,6 +103,16 @@ typedef struct qc_desc {
                              * K QuantumStatePadeIntegrators over the same system
                              * (quantum_state_smooth_pulse_problem.jl:146-152).  off_U is the first ket's offset. */
     int32_t reserved0;
+    /* Composition (all 0 = this handle is the whole dynamics).  A problem whose integrator list holds several
+     * unitary integrators (UnitarySamplingProblem: one per system over a merged trajectory,
+     * unitary_sampling_problem.jl:134-155) is served by one handle per unitary integrator; each handle's rows and
+     * values are placed inside the problem's per-interval blocks.  Only the "_dev" entry points accept composed handles. */
+    int64_t rows_per_interval;  /* dynamics rows of the whole problem per interval (Z.dims.states) */
+    int64_t row_offset;         /* first row of this handle inside that block */
+    int64_t jac_per_interval;   /* Jacobian values of the whole problem per interval */
+    int64_t jac_offset;
+    int64_t hess_per_interval;  /* Hessian values of the whole problem per interval */
+    int64_t hess_offset;
 } qc_desc;
 
 typedef struct qc_dims_t {

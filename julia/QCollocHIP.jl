@@ -24,6 +24,8 @@ struct QCDesc
     G_drift::Ptr{Float64}; G_drives::Ptr{Float64}
     device::Int32; kernel::Int32; t_begin::Int64; t_end::Int64
     state_cols::Int32; reserved0::Int32     # 0 = unitary iso-vec; K = K ket integrators stored back to back
+    rows_per_interval::Int64; row_offset::Int64; jac_per_interval::Int64; jac_offset::Int64   # composition (all 0 =
+    hess_per_interval::Int64; hess_offset::Int64                                               # this handle is the whole dynamics)
 end
 
 struct QCDims
@@ -77,7 +79,7 @@ function dynamics(integrators, traj, system; device::Int=0, eval_hessian::Bool=t
                           off(state_name), off(control_name), free_time ? off(traj.timestep) : -1,
                           free_time ? 0.0 : Float64(traj.timestep),
                           exponential ? 1 : 0, exponential ? 0 : pade_order, length(derivative_pairs),
-                          pad8(xs), pad8(dxs), pad8(dms), pointer(G0), pointer(Gd), device, 0, 0, 0, n_kets, 0))
+                          pad8(xs), pad8(dxs), pad8(dms), pointer(G0), pointer(Gd), device, 0, 0, 0, n_kets, 0, 0, 0, 0, 0, 0, 0))
         check(ccall((:qc_create, LIB[]), Cint, (Ref{QCDesc}, Ref{Ptr{Cvoid}}), desc, h))
     end
     check(ccall((:qc_dims, LIB[]), Cint, (Ptr{Cvoid}, Ref{QCDims}), h[], dims), h[])

@@ -6,7 +6,7 @@ of include/qcolloc.h.  The directory name carries a dot, so load it through
 """
 from . import _lib
 from ._lib import QCollocError
-from .dynamics import QuantumDynamics, desc_dims, desc_structures, make_desc
+from .dynamics import ComposedQuantumDynamics, QuantumDynamics, desc_dims, desc_structures, make_desc, split_groups
 from .gates import GATES, PAULIS, operator_from_string
 from .integrators import (DerivativeIntegrator, QuantumStateExponentialIntegrator, QuantumStatePadeIntegrator,
                           UnitaryExponentialIntegrator, UnitaryPadeIntegrator)
@@ -14,14 +14,14 @@ from .isomorphisms import iso_generator, iso_vec_to_operator, operator_to_iso_ve
 from .named_trajectory import NamedTrajectory
 from .objectives import FinalUnitaryFidelityConstraint, UnitaryInfidelityObjective, iso_vec_unitary_fidelity
 from .problems import (CONFIGS, config_inputs, multi_qubit_system, quantum_state_smooth_pulse_inputs,
-                       unitary_smooth_pulse_inputs)
+                       unitary_sampling_inputs, unitary_smooth_pulse_inputs)
 from .quantum_systems import QuantumSystem
 from .trajectory_initialization import initialize_trajectory, unitary_geodesic
 
 __all__ = [
     "QuantumDynamics", "QuantumSystem", "NamedTrajectory", "UnitaryPadeIntegrator",
     "UnitaryExponentialIntegrator", "DerivativeIntegrator", "QuantumStatePadeIntegrator",
-    "QuantumStateExponentialIntegrator", "quantum_state_smooth_pulse_inputs", "operator_to_iso_vec", "iso_vec_to_operator",
+    "QuantumStateExponentialIntegrator", "quantum_state_smooth_pulse_inputs", "unitary_sampling_inputs", "ComposedQuantumDynamics", "split_groups", "operator_to_iso_vec", "iso_vec_to_operator",
     "iso_generator", "pade_coefficients", "GATES", "PAULIS", "operator_from_string", "config_inputs",
     "unitary_smooth_pulse_inputs", "multi_qubit_system", "CONFIGS", "initialize_trajectory",
     "unitary_geodesic", "iso_vec_unitary_fidelity", "UnitaryInfidelityObjective", "FinalUnitaryFidelityConstraint", "make_desc", "desc_dims", "desc_structures", "QCollocError",

@@ -61,6 +61,12 @@ class qc_desc(C.Structure):
         ("t_end", C.c_int64),
         ("state_cols", C.c_int32),
         ("reserved0", C.c_int32),
+        ("rows_per_interval", C.c_int64),
+        ("row_offset", C.c_int64),
+        ("jac_per_interval", C.c_int64),
+        ("jac_offset", C.c_int64),
+        ("hess_per_interval", C.c_int64),
+        ("hess_offset", C.c_int64),
     ]
 
 

@@ -168,10 +168,21 @@ int qc_build_params(const qc_desc* d, QcParams* P, qc_dims_t* dims, std::string*
         if (ft) for (int i = 0; i < P->n_deriv; ++i) o += P->ddim_i[i];
     }
     P->hess_nnz = o;
+    // placement inside the problem's vectors
+    if (d->rows_per_interval < 0 || d->row_offset < 0 || d->jac_per_interval < 0 || d->jac_offset < 0 || d->hess_per_interval < 0 || d->hess_offset < 0)
+        return fail(err, QC_ERR_INVALID, "composition strides/offsets must be >= 0");
+    P->F_stride = d->rows_per_interval > 0 ? d->rows_per_interval : P->ddim;
+    P->F_off = d->row_offset;
+    P->J_stride = d->jac_per_interval > 0 ? d->jac_per_interval : P->jac_nnz;
+    P->J_off = d->jac_offset;
+    P->H_stride = d->hess_per_interval > 0 ? d->hess_per_interval : P->hess_nnz;
+    P->H_off = d->hess_offset;
+    if (P->F_off + P->ddim > P->F_stride || P->J_off + P->jac_nnz > P->J_stride || (P->hess_nnz && P->H_off + P->hess_nnz > P->H_stride))
+        return fail(err, QC_ERR_INVALID, "composition offset + own size exceeds the per-interval block");
 
     if (dims) {
         memset(dims, 0, sizeof(*dims));
-        dims->n_rows = (int64_t)P->ddim * (d->T - 1);
+        dims->n_rows = (int64_t)P->F_stride * (d->T - 1);
         dims->n_cols = (int64_t)d->zdim * d->T + d->global_dim;
         dims->ddim = P->ddim;
         dims->jac_nnz_interval = P->jac_nnz;
@@ -236,13 +247,13 @@ void qc_local_hess_structure(const QcParams& P, std::vector<int32_t>* R, std::ve
 }
 
 static void expand_structure(const QcParams& P, const std::vector<int32_t>& lr, const std::vector<int32_t>& lc,
-                             long long row_stride, int64_t* rows, int64_t* cols, int one_based) {
+                             long long row_stride, long long row_off, int64_t* rows, int64_t* cols, int one_based) {
     const int64_t o = one_based ? 1 : 0;
     const size_t k = lr.size();
     for (int b = 0; b < P.n_int; ++b) {
         const long long t = P.t_begin + b;
         for (size_t e = 0; e < k; ++e) {
-            rows[(size_t)b * k + e] = t * row_stride + lr[e] + o;
+            rows[(size_t)b * k + e] = t * row_stride + row_off + lr[e] + o;
             cols[(size_t)b * k + e] = t * (long long)P.zdim + lc[e] + o;
         }
     }
@@ -262,7 +273,7 @@ extern "C" int qc_desc_jac_structure(const qc_desc* d, int64_t* rows, int64_t* c
     if (!rows || !cols) return fail(nullptr, QC_ERR_INVALID, "qc_desc_jac_structure: NULL output");
     std::vector<int32_t> lr, lc;
     qc_local_jac_structure(P, &lr, &lc);
-    expand_structure(P, lr, lc, P.ddim, rows, cols, one_based);
+    expand_structure(P, lr, lc, P.F_stride, P.F_off, rows, cols, one_based);
     return QC_OK;
 }
 
@@ -275,7 +286,7 @@ extern "C" int qc_desc_hess_structure(const qc_desc* d, int64_t* rows, int64_t* 
     std::vector<int32_t> lr, lc;
     qc_local_hess_structure(P, &lr, &lc);
     // Hessian rows AND cols are variable indices: both use the zdim stride.
-    expand_structure(P, lr, lc, P.zdim, rows, cols, one_based);
+    expand_structure(P, lr, lc, P.zdim, 0, rows, cols, one_based);
     return QC_OK;
 }
 
@@ -396,7 +407,7 @@ extern "C" int qc_jac_structure(const qc_handle* h, int64_t* rows, int64_t* cols
     if (!h || !rows || !cols) return fail(nullptr, QC_ERR_INVALID, "qc_jac_structure: NULL argument");
     std::vector<int32_t> lr, lc;
     qc_local_jac_structure(h->prm, &lr, &lc);
-    expand_structure(h->prm, lr, lc, h->prm.ddim, rows, cols, one_based);
+    expand_structure(h->prm, lr, lc, h->prm.F_stride, h->prm.F_off, rows, cols, one_based);
     return QC_OK;
 }
 
@@ -406,7 +417,7 @@ extern "C" int qc_hess_structure(const qc_handle* h, int64_t* rows, int64_t* col
     if (!rows || !cols) return fail(nullptr, QC_ERR_INVALID, "qc_hess_structure: NULL output");
     std::vector<int32_t> lr, lc;
     qc_local_hess_structure(h->prm, &lr, &lc);
-    expand_structure(h->prm, lr, lc, h->prm.zdim, rows, cols, one_based);
+    expand_structure(h->prm, lr, lc, h->prm.zdim, 0, rows, cols, one_based);
     return QC_OK;
 }
 
@@ -461,8 +472,14 @@ static int ensure(qc_handle* h, double** p, size_t count) {
     return QC_OK;
 }
 
+static bool is_composed(const qc_handle* h) {
+    const QcParams& P = h->prm;
+    return P.F_stride != P.ddim || P.J_stride != P.jac_nnz || (P.hess_nnz && P.H_stride != P.hess_nnz) || P.F_off || P.J_off || P.H_off;
+}
+
 static int eval_host(qc_handle* h, const double* Z, double* F, double* vals) {
     if (!h) return fail(nullptr, QC_ERR_INVALID, "qc_eval: NULL handle");
+    if (is_composed(h)) return fail(&h->err, QC_ERR_UNSUPPORTED, "composed handles write into shared vectors: use the _dev entry points");
     if (!Z || (!F && !vals)) return fail(&h->err, QC_ERR_INVALID, "qc_eval: NULL buffer");
     QC_HIP(h, hipSetDevice(h->device));
     int rc;
@@ -493,6 +510,7 @@ extern "C" int qc_eval_hess(qc_handle* h, const double* Z, const double* mu, dou
     if (h->prm.hess_nnz == 0)
         return fail(&h->err, QC_ERR_UNSUPPORTED, "no analytic Hessian for the exponential integrator (upstream has none either; use eval_hessian=false)");
     if (!Z || !mu || !hvals) return fail(&h->err, QC_ERR_INVALID, "qc_eval_hess: NULL buffer");
+    if (is_composed(h)) return fail(&h->err, QC_ERR_UNSUPPORTED, "composed handles write into shared vectors: use the _dev entry points");
     QC_HIP(h, hipSetDevice(h->device));
     int rc;
     if ((rc = ensure(h, &h->dZ, (size_t)h->dims.Z_len))) return rc;

@@ -29,6 +29,9 @@ struct QcParams {
     long long t_begin;       // first interval of this handle
     int n_int;               // number of intervals of this handle
     int jac_nnz, hess_nnz;   // per interval
+    // placement of this handle's rows / values inside the problem's vectors (composed problems: several integrator
+    // groups share one row block and one value block per interval; default = own sizes, offset 0)
+    long long F_stride, F_off, J_stride, J_off, H_stride, H_off;
     int jo_F, jo_B, jo_a, jo_h, jo_d;                           // Jacobian sub-block offsets (doubles)
     int ho_Ua, ho_aU, ho_aa, ho_ah, ho_Uh, ho_hU, ho_hh, ho_d;  // Hessian sub-block offsets
     int jchunk;              // LDS kernel: drives processed per phase

@@ -102,8 +102,8 @@ __global__ __launch_bounds__(kThreads) void qc_lds_pade_kernel(const QcParams P,
         __syncthreads();
     }
 
-    double* Fb = F ? F + (size_t)b * P.ddim : nullptr;
-    double* Jb = JAC ? J + (size_t)b * P.jac_nnz : nullptr;
+    double* Fb = F ? F + (size_t)b * P.F_stride + P.F_off : nullptr;
+    double* Jb = JAC ? J + (size_t)b * P.J_stride + P.J_off : nullptr;
 
     // residual and d/dh
     for (int idx = tid; idx < s; idx += kThreads) {
@@ -276,10 +276,10 @@ __global__ __launch_bounds__(kThreads) void qc_lds_pade_hess_kernel(const QcPara
     double* S = sm + L.S;
     double* CH = sm + L.chunk;
     const bool ft = P.off_dt >= 0;
-    double* Hb = H + (size_t)b * P.hess_nnz;
+    double* Hb = H + (size_t)b * P.H_stride + P.H_off;
 
     const double* zt = Z + t * (long long)P.zdim;
-    const double* mut = Mu + t * (long long)P.ddim;
+    const double* mut = Mu + t * P.F_stride + P.F_off;
     for (int i = tid; i < P.zdim; i += kThreads) { z0[i] = zt[i]; z1[i] = zt[P.zdim + i]; }
     for (int i = tid; i < P.ddim; i += kThreads) mu[i] = mut[i];
     for (int i = tid; i < m * m; i += kThreads) S[i] = 0.0;
@@ -540,8 +540,8 @@ __global__ __launch_bounds__(kThreads) void qc_lds_exp_kernel(const QcParams P, 
     double* EU = sm + L.EU;
     double* red = sm + L.red;
     const bool ft = P.off_dt >= 0;
-    double* Fb = F ? F + (size_t)b * P.ddim : nullptr;
-    double* Jb = JAC ? J + (size_t)b * P.jac_nnz : nullptr;
+    double* Fb = F ? F + (size_t)b * P.F_stride + P.F_off : nullptr;
+    double* Jb = JAC ? J + (size_t)b * P.J_stride + P.J_off : nullptr;
 
     const double* zt = Z + t * (long long)P.zdim;
     for (int i = tid; i < P.zdim; i += kThreads) { z0[i] = zt[i]; z1[i] = zt[P.zdim + i]; }

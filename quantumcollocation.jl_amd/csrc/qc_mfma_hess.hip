@@ -51,8 +51,8 @@ __global__ __launch_bounds__(64) void qc_mfma16_pade4_hess_kernel(const QcParams
         const long long t = P.t_begin + b;
         const double* __restrict__ z0 = Z + t * (long long)P.zdim;
         const double* __restrict__ z1 = z0 + P.zdim;
-        const double* __restrict__ mu = Mu + t * (long long)P.ddim;
-        double* __restrict__ Hb = H + (size_t)b * P.hess_nnz;
+        const double* __restrict__ mu = Mu + t * P.F_stride + P.F_off;
+        double* __restrict__ Hb = H + (size_t)b * P.H_stride + P.H_off;
 
         // ---- loads: knots, multipliers, generator images (one batch) ----------------------------------
         const double* u0p = z0 + P.off_U + jj * 16 + g;

@@ -126,8 +126,8 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
         const long long t = P.t_begin + b;
         const double* __restrict__ z0 = Z + t * (long long)P.zdim;
         const double* __restrict__ z1 = z0 + P.zdim;
-        double* __restrict__ Jb = JAC ? J + (size_t)b * P.jac_nnz : nullptr;
-        double* __restrict__ Fb = F ? F + (size_t)b * P.ddim : nullptr;
+        double* __restrict__ Jb = JAC ? J + (size_t)b * P.J_stride + P.J_off : nullptr;
+        double* __restrict__ Fb = F ? F + (size_t)b * P.F_stride + P.F_off : nullptr;
         const double h = ft ? z0[P.off_dt] : P.dt_fixed;
         const double hc1 = h * c1, hc2 = h * h * c2;
         QC_STAMP_DECL;

@@ -26,8 +26,36 @@ _KERNELS = {"auto": _lib.QC_KERNEL_AUTO, "lds": _lib.QC_KERNEL_LDS, "mfma": _lib
 _ALIASES = {"∂F": "dF", "μ∂²F": "mu_d2F", "∂F_structure": "dF_structure", "μ∂²F_structure": "mu_d2F_structure"}
 
 
+def split_groups(integrators: Sequence):
+    """Integrator list -> groups, one per unitary integrator (or run of ket integrators); the derivative integrators
+    (which must come last: unitary_smooth_pulse_problem.jl:175-179, unitary_sampling_problem.jl:149-155) go with the
+    last group so that their rows follow it."""
+    groups, cur = [], []
+    i = 0
+    n = len(integrators)
+    while i < n and isinstance(integrators[i], (_UnitaryIntegrator, _KetIntegrator)):
+        if isinstance(integrators[i], _UnitaryIntegrator):
+            groups.append([integrators[i]])
+            i += 1
+        else:
+            run = [integrators[i]]
+            i += 1
+            while i < n and isinstance(integrators[i], _KetIntegrator) and integrators[i].system is run[0].system:
+                run.append(integrators[i])
+                i += 1
+            groups.append(run)
+    rest = list(integrators[i:])
+    if not groups:
+        raise NotImplementedError("the integrator list must start with a unitary or ket integrator")
+    for D in rest:
+        if not isinstance(D, DerivativeIntegrator):
+            raise NotImplementedError("only DerivativeIntegrators may follow the state integrators")
+    groups[-1] = groups[-1] + rest
+    return groups
+
+
 def make_desc(integrators: Sequence, traj: NamedTrajectory, *, device: int = 0, kernel: str = "auto",
-              t_range: Optional[Tuple[int, int]] = None):
+              t_range: Optional[Tuple[int, int]] = None, placement: Optional[dict] = None):
     """Translate (integrators, traj) into a qc_desc.  Returns (desc, keepalive)."""
     if not integrators or not isinstance(integrators[0], (_UnitaryIntegrator, _KetIntegrator)):
         raise NotImplementedError("the first integrator must be the unitary (or the first ket) integrator "
@@ -90,6 +118,9 @@ def make_desc(integrators: Sequence, traj: NamedTrajectory, *, device: int = 0, 
     d.G_drives = _lib.dptr(Gd)
     d.device = device
     d.kernel = _KERNELS[kernel]
+    if placement:
+        for k, v in placement.items():
+            setattr(d, k, int(v))
     if t_range is None:
         d.t_begin, d.t_end = 0, 0
     else:
@@ -119,6 +150,11 @@ def desc_structures(desc, one_based: bool = False):
 
 
 class QuantumDynamics:
+    def __new__(cls, integrators: Sequence, traj: NamedTrajectory, **kw):
+        if cls is QuantumDynamics and len(split_groups(integrators)) > 1:
+            return super().__new__(ComposedQuantumDynamics)
+        return super().__new__(cls)
+
     def __init__(self, integrators: Sequence, traj: NamedTrajectory, *, device: int = 0, kernel: str = "auto",
                  t_range: Optional[Tuple[int, int]] = None, eval_hessian: bool = True):
         self.integrators = list(integrators)
@@ -252,3 +288,138 @@ class QuantumDynamics:
         _lib.check(_lib.lib.qc_eval_hess_dev(
             self._h, self._dev_ptr(Z, self.dims.Z_len, "Z"), self._dev_ptr(mu, self.dims.n_rows, "mu"),
             self._dev_ptr(H, self.dims.hess_nnz, "H"), C.c_void_p(st.cuda_stream)), self._h)
+
+
+class ComposedQuantumDynamics(QuantumDynamics):
+    """`QuantumDynamics` over an integrator list with SEVERAL unitary integrators (UnitarySamplingProblem: K systems
+    share the controls of a merged trajectory, reference unitary_sampling_problem.jl:134-155).  One HIP handle per
+    unitary integrator; every handle writes its rows / Jacobian values / Hessian values straight into its slot of the
+    problem's per-interval blocks (qc_desc.rows_per_interval / row_offset / jac_* / hess_*), so the value vectors come
+    out in the reference's order: interval-major, integrator-major inside an interval."""
+
+    def __init__(self, integrators: Sequence, traj: NamedTrajectory, *, device: int = 0, kernel: str = "auto",
+                 t_range: Optional[Tuple[int, int]] = None, eval_hessian: bool = True):
+        self.integrators = list(integrators)
+        self.traj = traj
+        self.eval_hessian = eval_hessian
+        self.device = device
+        groups = split_groups(integrators)
+        own = []
+        for g in groups:
+            d0, keep = make_desc(g, traj, device=device, kernel=kernel, t_range=t_range)
+            own.append(desc_dims(d0))
+        rows = sum(int(x.ddim) for x in own)
+        jac = sum(int(x.jac_nnz_interval) for x in own)
+        hess = sum(int(x.hess_nnz_interval) for x in own) if all(x.hess_nnz_interval for x in own) else 0
+        self._parts = []
+        ro = jo = ho = 0
+        for g, x in zip(groups, own):
+            place = dict(rows_per_interval=rows, row_offset=ro, jac_per_interval=jac, jac_offset=jo,
+                         hess_per_interval=hess if hess else 0, hess_offset=ho if hess else 0)
+            desc, keep = make_desc(g, traj, device=device, kernel=kernel, t_range=t_range, placement=place)
+            h = C.c_void_p()
+            _lib.check(_lib.lib.qc_create(C.byref(desc), C.byref(h)))
+            dims = _lib.qc_dims_t()
+            _lib.check(_lib.lib.qc_dims(h, C.byref(dims)), h)
+            self._parts.append((desc, keep, h, dims))
+            ro += int(x.ddim)
+            jo += int(x.jac_nnz_interval)
+            ho += int(x.hess_nnz_interval)
+        n_int = int(self._parts[0][3].n_intervals)
+        d = _lib.qc_dims_t()
+        d.n_rows, d.n_cols, d.ddim = self._parts[0][3].n_rows, self._parts[0][3].n_cols, rows
+        d.jac_nnz_interval, d.hess_nnz_interval, d.n_intervals = jac, hess, n_int
+        d.F_len, d.jac_nnz, d.hess_nnz, d.Z_len = rows * n_int, jac * n_int, hess * n_int, self._parts[0][3].Z_len
+        d.kernel = self._parts[0][3].kernel
+        self.dims = d
+        self.dim = rows
+        self.kernel = "+".join({_lib.QC_KERNEL_LDS: "lds", _lib.QC_KERNEL_MFMA: "mfma"}[p[3].kernel] for p in self._parts)
+        self._h = None
+        self._structs = None
+        self._dev = torch.device("cuda", device)
+        self._bufs = {}
+
+    def close(self):
+        for _, _, h, _ in getattr(self, "_parts", []):
+            if h:
+                _lib.lib.qc_destroy(h)
+        self._parts = []
+
+    def _structure(self, one_based=False):
+        n_int = int(self.dims.n_intervals)
+        jr_l, jc_l, hr_l, hc_l = [], [], [], []
+        for desc, keep, h, dims in self._parts:
+            jr = np.empty(dims.jac_nnz, dtype=np.int64)
+            jc = np.empty(dims.jac_nnz, dtype=np.int64)
+            _lib.check(_lib.lib.qc_jac_structure(h, _lib.iptr(jr), _lib.iptr(jc), int(one_based)), h)
+            jr_l.append(jr.reshape(n_int, -1))
+            jc_l.append(jc.reshape(n_int, -1))
+            if self.dims.hess_nnz:
+                hr = np.empty(dims.hess_nnz, dtype=np.int64)
+                hc = np.empty(dims.hess_nnz, dtype=np.int64)
+                _lib.check(_lib.lib.qc_hess_structure(h, _lib.iptr(hr), _lib.iptr(hc), int(one_based)), h)
+                hr_l.append(hr.reshape(n_int, -1))
+                hc_l.append(hc.reshape(n_int, -1))
+        cat = lambda L: np.ascontiguousarray(np.concatenate(L, axis=1).reshape(-1)) if L else np.empty(0, dtype=np.int64)
+        return cat(jr_l), cat(jc_l), cat(hr_l), cat(hc_l)
+
+    def _buf(self, name, n):
+        t = self._bufs.get(name)
+        if t is None or t.numel() < n:
+            t = torch.empty(max(n, 1), dtype=torch.float64, device=self._dev)
+            self._bufs[name] = t
+        return t
+
+    def F_dF_device(self, Z: torch.Tensor, F: Optional[torch.Tensor], J: Optional[torch.Tensor], stream=None) -> None:
+        st = stream if stream is not None else torch.cuda.current_stream(self.device)
+        for desc, keep, h, dims in self._parts:
+            _lib.check(_lib.lib.qc_eval_F_jac_dev(
+                h, self._dev_ptr(Z, self.dims.Z_len, "Z"), self._dev_ptr(F, self.dims.F_len, "F"),
+                self._dev_ptr(J, self.dims.jac_nnz, "J"), C.c_void_p(st.cuda_stream)), h)
+
+    def mu_d2F_device(self, Z: torch.Tensor, mu: torch.Tensor, H: torch.Tensor, stream=None) -> None:
+        if not self.dims.hess_nnz:
+            raise _lib.QCollocError(_lib.QC_ERR_UNSUPPORTED, "no analytic Hessian for this integrator list")
+        st = stream if stream is not None else torch.cuda.current_stream(self.device)
+        for desc, keep, h, dims in self._parts:
+            _lib.check(_lib.lib.qc_eval_hess_dev(
+                h, self._dev_ptr(Z, self.dims.Z_len, "Z"), self._dev_ptr(mu, self.dims.n_rows, "mu"),
+                self._dev_ptr(H, self.dims.hess_nnz, "H"), C.c_void_p(st.cuda_stream)), h)
+
+    def bind_F_dF_device(self, Z, F, J, stream=None):
+        return lambda: (self.F_dF_device(Z, F, J, stream), 0)[1]
+
+    def F_dF(self, Z):
+        Zh = self._Z(Z)
+        dZ = self._buf("Z", Zh.size)
+        dZ[:Zh.size].copy_(torch.from_numpy(Zh))
+        dF, dJ = self._buf("F", self.dims.F_len), self._buf("J", self.dims.jac_nnz)
+        self.F_dF_device(dZ, dF, dJ)
+        torch.cuda.synchronize(self._dev)
+        return dF[:self.dims.F_len].cpu().numpy(), dJ[:self.dims.jac_nnz].cpu().numpy()
+
+    def F(self, Z):
+        Zh = self._Z(Z)
+        dZ = self._buf("Z", Zh.size)
+        dZ[:Zh.size].copy_(torch.from_numpy(Zh))
+        dF = self._buf("F", self.dims.F_len)
+        self.F_dF_device(dZ, dF, None)
+        torch.cuda.synchronize(self._dev)
+        return dF[:self.dims.F_len].cpu().numpy()
+
+    def dF(self, Z):
+        return self.F_dF(Z)[1]
+
+    def mu_d2F(self, Z, mu):
+        Zh = self._Z(Z)
+        mu = np.ascontiguousarray(mu, dtype=np.float64)
+        if mu.size != self.dims.n_rows:
+            raise ValueError(f"mu has length {mu.size}, expected {self.dims.n_rows}")
+        dZ = self._buf("Z", Zh.size)
+        dZ[:Zh.size].copy_(torch.from_numpy(Zh))
+        dmu = self._buf("mu", mu.size)
+        dmu[:mu.size].copy_(torch.from_numpy(mu))
+        dH = self._buf("H", self.dims.hess_nnz)
+        self.mu_d2F_device(dZ, dmu, dH)
+        torch.cuda.synchronize(self._dev)
+        return dH[:self.dims.hess_nnz].cpu().numpy()

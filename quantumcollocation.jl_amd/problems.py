@@ -126,3 +126,36 @@ def quantum_state_smooth_pulse_inputs(system: QuantumSystem, psi_inits, psi_goal
     integrators = [cls(nm, "a", system, traj, **kw) for nm in names]
     integrators += [DerivativeIntegrator("a", "da", traj), DerivativeIntegrator("da", "dda", traj)]
     return HotPathInputs(system, traj, integrators)
+
+
+def unitary_sampling_inputs(systems, U_goal: np.ndarray, T: int, dt: float = 0.2, *, free_time: bool = True,
+                            integrator: str = "pade", pade_order: int = 4, seed: int = SEED) -> HotPathInputs:
+    """Inputs of `UnitarySamplingProblem` (reference unitary_sampling_problem.jl:44-167): K systems share the
+    controls of one merged trajectory with components `Ũ⃗_system_k` (:103-107), one unitary integrator per system
+    followed by the two derivative integrators (:134-155)."""
+    from .named_trajectory import NamedTrajectory
+    from .trajectory_initialization import unitary_geodesic
+    rng = np.random.default_rng(seed)
+    m = systems[0].n_drives
+    N = systems[0].levels
+    comps = {}
+    names = []
+    for k in range(len(systems)):
+        name = f"Ũ⃗_system_{k + 1}"
+        comps[name] = unitary_geodesic(np.eye(N, dtype=complex), U_goal, T) + 1e-2 * rng.standard_normal((2 * N * N, T))
+        names.append(name)
+    a = np.zeros((m, T))
+    a[:, 1:T - 1] = rng.uniform(-1, 1, size=(m, T - 2))
+    comps["a"] = a
+    comps["da"] = 0.1 * rng.standard_normal((m, T))
+    comps["dda"] = 0.1 * rng.standard_normal((m, T))
+    if free_time:
+        comps["Δt"] = np.full((1, T), dt)
+    from .isomorphisms import operator_to_iso_vec
+    traj = NamedTrajectory(comps, controls=("dda", "Δt") if free_time else ("dda",), timestep="Δt" if free_time else dt,
+                           goal={nm: operator_to_iso_vec(U_goal) for nm in names})
+    cls = UnitaryPadeIntegrator if integrator == "pade" else UnitaryExponentialIntegrator
+    kw = {"order": pade_order} if integrator == "pade" else {}
+    integrators = [cls(nm, "a", sys_, traj, **kw) for nm, sys_ in zip(names, systems)]
+    integrators += [DerivativeIntegrator("a", "da", traj), DerivativeIntegrator("da", "dda", traj)]
+    return HotPathInputs(systems[0], traj, integrators)

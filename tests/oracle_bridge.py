@@ -65,3 +65,54 @@ def random_problem(o, N, m, T, order=4, free_time=True, integrator=None, seed=0,
     if free_time:
         Z[off_dt::zdim] = rng.uniform(0.1, 0.3, size=T)
     return prob, Z
+
+
+def composed_oracle(inp):
+    """Oracle evaluation of an integrator list with several unitary integrators (sampling problem): one oracle
+    Problem per group, outputs interleaved per interval in integrator order."""
+    import __graft_entry__ as g
+    from types import SimpleNamespace
+    o = g.load_oracle()
+    qc = g.load_package()
+    groups = qc.split_groups(inp.integrators)
+    probs = [problem_from_inputs(SimpleNamespace(integrators=grp, traj=inp.traj)) for grp in groups]
+    T = inp.traj.T
+
+    def interleave(parts):
+        return np.concatenate([p.reshape(T - 1, -1) for p in parts], axis=1).reshape(-1)
+
+    rows = sum(p.ddim for p in probs)
+
+    def F(Z):
+        return interleave([o.F(p, Z) for p in probs])
+
+    def dF(Z):
+        return interleave([o.dF(p, Z) for p in probs])
+
+    def structure():
+        rs, cs, ro = [], [], 0
+        for p in probs:
+            loc = np.array(o.jac_structure_local(p), dtype=np.int64).reshape(-1, 2)
+            ts = np.arange(T - 1, dtype=np.int64)
+            rs.append(ts[:, None] * rows + ro + loc[None, :, 0])
+            cs.append(ts[:, None] * p.zdim + loc[None, :, 1])
+            ro += p.ddim
+        return np.concatenate(rs, axis=1).reshape(-1), np.concatenate(cs, axis=1).reshape(-1)
+
+    def mu_d2F(Z, mu):
+        mus = mu.reshape(T - 1, rows)
+        out, ro = [], 0
+        for p in probs:
+            out.append(o.mu_d2F(p, Z, np.ascontiguousarray(mus[:, ro:ro + p.ddim]).reshape(-1)))
+            ro += p.ddim
+        return interleave(out)
+
+    def hess_structure():
+        rs, cs = [], []
+        for p in probs:
+            r, c = o.hess_structure(p)
+            rs.append(r.reshape(T - 1, -1))
+            cs.append(c.reshape(T - 1, -1))
+        return np.concatenate(rs, axis=1).reshape(-1), np.concatenate(cs, axis=1).reshape(-1)
+
+    return SimpleNamespace(F=F, dF=dF, structure=structure, mu_d2F=mu_d2F, hess_structure=hess_structure, rows=rows, probs=probs)

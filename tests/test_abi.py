@@ -164,3 +164,28 @@ def test_ket_integrators_build_a_descriptor(qc, oracle):
     ohr, ohc = oracle.hess_structure(prob)
     np.testing.assert_array_equal(hr, ohr)
     np.testing.assert_array_equal(hc, ohc)
+
+
+def test_sampling_problem_groups_and_placement(qc, oracle):
+    """Several unitary integrators: one descriptor per integrator, rows/values placed inside shared blocks."""
+    base = qc.multi_qubit_system(1)
+    systems = [qc.QuantumSystem(base.H_drift * f, base.H_drives) for f in (0.9, 1.0, 1.1)]
+    inp = qc.unitary_sampling_inputs(systems, qc.GATES["H"], 7)
+    groups = qc.split_groups(inp.integrators)
+    assert [len(g) for g in groups] == [1, 1, 3]
+    assert inp.traj.names[:3] == ("Ũ⃗_system_1", "Ũ⃗_system_2", "Ũ⃗_system_3") and inp.traj.dims.states == 3 * 8 + 4
+    own = [qc.desc_dims(qc.make_desc(g, inp.traj)[0]) for g in groups]
+    rows = sum(x.ddim for x in own)
+    jac = sum(x.jac_nnz_interval for x in own)
+    assert rows == 28
+    desc, keep = qc.make_desc(groups[1], inp.traj, placement=dict(rows_per_interval=rows, row_offset=8, jac_per_interval=jac,
+                                                                   jac_offset=own[0].jac_nnz_interval))
+    d = qc.desc_dims(desc)
+    assert d.n_rows == rows * 6 and d.ddim == 8
+    jr, jc, _, _ = qc.desc_structures(desc)
+    assert jr.min() == 8 and jr.max() == 5 * rows + 15          # rows 8..15 of every interval block
+    assert jc.min() == inp.traj.offset("Ũ⃗_system_2")
+    # an offset that does not fit is rejected
+    bad, keep2 = qc.make_desc(groups[1], inp.traj, placement=dict(rows_per_interval=10, row_offset=8))
+    dims = qc._lib.qc_dims_t()
+    assert qc._lib.lib.qc_desc_dims(C.byref(bad), C.byref(dims)) == qc._lib.QC_ERR_INVALID
