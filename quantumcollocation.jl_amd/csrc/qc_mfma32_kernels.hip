@@ -55,9 +55,9 @@ __device__ inline v4d mm16x2(const v4d& a0, const v4d& b0, const v4d& a1, const 
 
 // Store transposed tile I of a 32 x 16 matrix (or tile (I, J) of a 32 x 32 one with colbase = 16 J... see callers):
 // lane (g, j) reg r holds X[rowbase + j][colbase + 4r + g]; column-major with 32 rows per column.
-__device__ inline void store_T32(double* __restrict__ p, const v4d& x, int rowbase, int colbase, int g, int j, int mode) {
+__device__ inline void store_T32(double* __restrict__ p, const v4d& x, int rowbase, int colbase, int g, int j) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) qc_st8(p + (colbase + 4 * r + g) * 32 + rowbase + j, x[r], mode);
+    for (int r = 0; r < 4; ++r) qc_st8m<2>(p + (colbase + 4 * r + g) * 32 + rowbase + j, x[r]);   // non-temporal, compile-time
 }
 
 template <bool JAC>
@@ -71,7 +71,6 @@ __global__ __launch_bounds__(kThreads32, 2) void qc_mfma32_pade4_kernel(const Qc
     const int g = lane >> 4, j = lane & 15;
     const bool ft = P.off_dt >= 0;
     const double c1 = P.c[1], c2 = P.c[2];
-    const int mode = P.store_mode;
     const double* __restrict__ Gx = P.Gx;
     const v4d IdB = identity_B(g, j);
 
@@ -135,8 +134,8 @@ __global__ __launch_bounds__(kThreads32, 2) void qc_mfma32_pade4_kernel(const Qc
                 double* pF = Jb + P.jo_F;
                 double* pB = Jb + P.jo_B;
                 for (int q = 0; q < 16; ++q) {
-                    store_T32(pF + q * 1024, Fm, 16 * Jt, 16 * I, g, j, mode);
-                    store_T32(pB + q * 1024, Bm, 16 * Jt, 16 * I, g, j, mode);
+                    store_T32(pF + q * 1024, Fm, 16 * Jt, 16 * I, g, j);
+                    store_T32(pB + q * 1024, Bm, 16 * Jt, 16 * I, g, j);
                 }
                 if (w == 4) deriv_rows_generic(P, z0, z1, h, Fb, Jb, lane, false);
             }
@@ -158,10 +157,10 @@ __global__ __launch_bounds__(kThreads32, 2) void qc_mfma32_pade4_kernel(const Qc
 #pragma unroll
                 for (int I = 0; I < 2; ++I) {
                     const v4d dl = D[I] - hc1 * GS[I] + hc2 * G2D[I];
-                    if (Fb) store_T32(Fb, mm16(dl, IdB), 16 * I, 0, g, j, mode);
+                    if (Fb) store_T32(Fb, mm16(dl, IdB), 16 * I, 0, g, j);
                     if (JAC && ft) {
                         const v4d dh = (-c1) * GS[I] + (2.0 * c2 * h) * G2D[I];
-                        store_T32(Jb + P.jo_h, mm16(dh, IdB), 16 * I, 0, g, j, mode);
+                        store_T32(Jb + P.jo_h, mm16(dh, IdB), 16 * I, 0, g, j);
                     }
                 }
                 if (!JAC) deriv_rows_generic(P, z0, z1, h, Fb, nullptr, lane, false);
@@ -187,7 +186,7 @@ __global__ __launch_bounds__(kThreads32, 2) void qc_mfma32_pade4_kernel(const Qc
 #pragma unroll
                     for (int I = 0; I < 2; ++I) {
                         const v4d Y = R0[I] + mm16x2(Ga[2 * I], R1[0], Ga[2 * I + 1], R1[1]);
-                        store_T32(pa, mm16(Y, IdB), 16 * I, 0, g, j, mode);
+                        store_T32(pa, mm16(Y, IdB), 16 * I, 0, g, j);
                     }
                 }
             }

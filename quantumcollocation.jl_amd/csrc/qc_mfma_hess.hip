@@ -17,8 +17,8 @@ namespace {
 
 using namespace qc_mfma;
 
-constexpr int kHM = 8;                        // drives held in registers
-constexpr int kHVals = kHM * (kHM + 1) / 2 + kHM + 1;
+constexpr int kHMmax = 8;                     // at most this many drives (held in registers)
+constexpr int kHVals = kHMmax * (kHMmax + 1) / 2 + kHMmax + 1;
 constexpr int kHStride = 65;                  // LDS row stride (doubles) of the reduction scratch
 
 __device__ inline v4d load_img(const double* __restrict__ Gx, int mat, int lane) {
@@ -31,6 +31,7 @@ __device__ inline v4d sel(bool c, const v4d& a, const v4d& b) {
     return v4d{c ? a[0] : b[0], c ? a[1] : b[1], c ? a[2] : b[2], c ? a[3] : b[3]};
 }
 
+template <int kHM>
 __global__ __launch_bounds__(64) void qc_mfma16_pade4_hess_kernel(const QcParams P, const double* __restrict__ Z,
                                                                   const double* __restrict__ Mu, double* __restrict__ H) {
     __shared__ double red[kHVals * kHStride];
@@ -40,7 +41,6 @@ __global__ __launch_bounds__(64) void qc_mfma16_pade4_hess_kernel(const QcParams
     const bool left = j < 8;
     const bool ft = P.off_dt >= 0;
     const double c1 = P.c[1], c2 = P.c[2];
-    const int mode = P.store_mode;
     const double* __restrict__ GxA = P.Gx;                          // A-layout images
     const double* __restrict__ GxB = P.Gx + (size_t)(m + 1) * 256;  // B-layout images (= A-layout of the transposes)
     const v4d IdB = identity_B(g, j);
@@ -76,11 +76,10 @@ __global__ __launch_bounds__(64) void qc_mfma16_pade4_hess_kernel(const QcParams
         for (int u = 0; u < kHM; ++u) Ga += ak[u] * gA[u];
         const double hc1 = h * c1, hc2 = h * h * c2, c2h2 = 2.0 * c2 * h;
 
-        // ---- shared products -----------------------------------------------------------------------------
+        // ---- products in five dependency stages, each a batch of independent 16x16x16 products whose MFMAs are
+        //      interleaved (mm16_multi):  1: G_B   2: M1, [GS|GD]   3: M2, [N_k|N'_k], [V_k|.]   4: (U,h)^T, N''   5: (U,a)^T
         const v4d Gb = mm16(Ga, IdB);                       // B-layout of G = A-layout of G^T
         const v4d TM0 = sel(left, mv, zero);                // [M | 0]
-        const v4d Y1 = mm16(Gb, TM0);                       // [M1 | 0]
-        const v4d Y2 = mm16(Gb, Y1);                        // [M2 | 0]
         v4d W, Wsw;                                         // [S | D], [D | S]
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -88,46 +87,83 @@ __global__ __launch_bounds__(64) void qc_mfma16_pade4_hess_kernel(const QcParams
             W[r] = left ? sm_ : df;
             Wsw[r] = left ? df : sm_;
         }
-        const v4d P1sw = swap8(mm16(Ga, W));                // [GD | GS]
+        v4d Y1, P1sw;
+        {
+            v4d a2[2] = {Gb, Ga}, b2[2] = {TM0, W}, d2[2];
+            mm16_multi<2>(a2, b2, d2);
+            Y1 = d2[0];                                     // [M1 | 0]
+            P1sw = swap8(d2[1]);                            // [GD | GS]
+        }
         const v4d TM = sel(left, TM0, swap8(Y1));           // [M | M1]
-
-        if (ft) {   // (U_t, h) on the left half, (h, U_t+1) on the right half, transposed store
+        v4d Y2, NN[kHM], VV[kHM];                           // [M2 | 0], [N_k | N'_k], [V_k | .]
+        {
+            constexpr int N3 = 1 + 2 * kHM;
+            v4d a3[N3], b3[N3], d3[N3];
+            a3[0] = Gb;
+            b3[0] = Y1;
+#pragma unroll
+            for (int u = 0; u < kHM; ++u) {                 // unused slots (u >= m) repeat the last drive; zeroed below
+                a3[1 + u] = gB[u];
+                b3[1 + u] = TM;
+                a3[1 + kHM + u] = gA[u];
+                b3[1 + kHM + u] = Wsw;
+            }
+            mm16_multi<N3>(a3, b3, d3);
+            Y2 = d3[0];
+#pragma unroll
+            for (int u = 0; u < kHM; ++u) {
+                NN[u] = (u < m) ? d3[1 + u] : zero;
+                VV[u] = (u < m) ? d3[1 + kHM + u] : zero;
+            }
+        }
+        v4d PN[kHM / 2], PN1[kHM / 2], PN2[kHM / 2], ET;
+        {
+            constexpr int N4 = 1 + kHM / 2;
+            v4d a4[N4], b4[N4], d4[N4];
             const v4d uh = -(c1 * Y1 + c2h2 * Y2), hu = (-c1) * Y1 + c2h2 * Y2;
-            const v4d ET = mm16(sel(left, uh, swap8(hu)), IdB);
+            a4[0] = sel(left, uh, swap8(hu));               // (U_t, h) left, (h, U_t+1) right; read as A operand = transposed
+            b4[0] = IdB;
+#pragma unroll
+            for (int p2 = 0; p2 < kHM / 2; ++p2) {
+                PN[p2] = sel(left, NN[2 * p2], swap8(NN[2 * p2 + 1]));      // [N_k | N_k+1]
+                PN1[p2] = sel(left, swap8(NN[2 * p2]), NN[2 * p2 + 1]);     // [N'_k | N'_k+1]
+                a4[1 + p2] = Gb;
+                b4[1 + p2] = PN[p2];
+            }
+            mm16_multi<N4>(a4, b4, d4);
+            ET = d4[0];
+#pragma unroll
+            for (int p2 = 0; p2 < kHM / 2; ++p2) PN2[p2] = d4[1 + p2];      // [N''_k | N''_k+1]
+        }
+        v4d XT[kHM];                                        // (U_t, a) and (a, U_t+1) tiles, transposed
+        {
+            v4d a5[kHM], b5[kHM];
+#pragma unroll
+            for (int p2 = 0; p2 < kHM / 2; ++p2) {
+                const v4d q = hc2 * (PN2[p2] + PN1[p2]), lin = (-hc1) * PN[p2];
+                a5[2 * p2] = lin - q;
+                a5[2 * p2 + 1] = lin + q;
+                b5[2 * p2] = IdB;
+                b5[2 * p2 + 1] = IdB;
+            }
+            mm16_multi<kHM>(a5, b5, XT);
+        }
+        if (ft) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int c = 4 * r + g;
-                qc_st8(Hb + (c < 8 ? P.ho_Uh + c * 16 : P.ho_hU + (c - 8) * 16) + j, ET[r], mode);
+                qc_st8m<2>(Hb + (c < 8 ? P.ho_Uh + c * 16 : P.ho_hU + (c - 8) * 16) + j, ET[r]);
             }
         }
-
-        // ---- per drive: [N_k | N'_k] and [V_k | .] -------------------------------------------------------
-        v4d NN[kHM], VV[kHM];
-#pragma unroll
-        for (int u = 0; u < kHM; ++u) {
-            if (u < m) {
-                NN[u] = mm16(gB[u], TM);
-                VV[u] = mm16(gA[u], Wsw);
-            } else {
-                NN[u] = zero;
-                VV[u] = zero;
-            }
-        }
-        // ---- (U, a) blocks, two drives per tile ------------------------------------------------------------
 #pragma unroll
         for (int u = 0; u < kHM; u += 2) {
             if (u < m) {
                 const bool two = u + 1 < m;
-                const v4d PN = sel(left, NN[u], swap8(NN[u + 1]));      // [N_k | N_k+1]
-                const v4d PN1 = sel(left, swap8(NN[u]), NN[u + 1]);     // [N'_k | N'_k+1]
-                const v4d PN2 = mm16(Gb, PN);                           // [N''_k | N''_k+1]
-                const v4d q = hc2 * (PN2 + PN1), lin = (-hc1) * PN;
-                const v4d X0T = mm16(lin - q, IdB), X1T = mm16(lin + q, IdB);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     if (r < 2 || two) {
-                        qc_st8(Hb + P.ho_Ua + (size_t)u * 128 + (4 * r + g) * 16 + j, X0T[r], mode);
-                        qc_st8(Hb + P.ho_aU + (size_t)u * 128 + (4 * r + g) * 16 + j, X1T[r], mode);
+                        qc_st8m<2>(Hb + P.ho_Ua + (size_t)u * 128 + (4 * r + g) * 16 + j, XT[u][r]);
+                        qc_st8m<2>(Hb + P.ho_aU + (size_t)u * 128 + (4 * r + g) * 16 + j, XT[u + 1][r]);
                     }
                 }
             }
@@ -183,11 +219,14 @@ __global__ __launch_bounds__(64) void qc_mfma16_pade4_hess_kernel(const QcParams
 }  // namespace
 
 bool qc_mfma_hess_supported(const QcParams& P) {
-    return P.integrator == QC_PADE && P.p == 2 && P.n == 16 && P.nc == P.N && P.m <= kHM;
+    return P.integrator == QC_PADE && P.p == 2 && P.n == 16 && P.nc == P.N && P.m <= kHMmax;
 }
 
 hipError_t qc_launch_mfma_hess(const QcParams& P, const double* dZ, const double* dMu, double* dH, hipStream_t st) {
     const int grid = P.n_int < 4096 ? P.n_int : 4096;
-    hipLaunchKernelGGL(qc_mfma16_pade4_hess_kernel, dim3(grid), dim3(64), 0, st, P, dZ, dMu, dH);
+    if (P.m <= 2) hipLaunchKernelGGL(qc_mfma16_pade4_hess_kernel<2>, dim3(grid), dim3(64), 0, st, P, dZ, dMu, dH);
+    else if (P.m <= 4) hipLaunchKernelGGL(qc_mfma16_pade4_hess_kernel<4>, dim3(grid), dim3(64), 0, st, P, dZ, dMu, dH);
+    else if (P.m <= 6) hipLaunchKernelGGL(qc_mfma16_pade4_hess_kernel<6>, dim3(grid), dim3(64), 0, st, P, dZ, dMu, dH);
+    else hipLaunchKernelGGL(qc_mfma16_pade4_hess_kernel<8>, dim3(grid), dim3(64), 0, st, P, dZ, dMu, dH);
     return hipGetLastError();
 }
