@@ -2,16 +2,23 @@
 // matrix is 2 x 2 tiles of 16 x 16, every n x N (32 x 16) matrix two full-width tiles, all products
 // v_mfma_f64_16x16x4_f64 with register operands (lane maps: qc_mfma_kernels.hip header).
 //
-// One 512-thread workgroup (8 wavefronts) per interval:
-//   waves 0-3  assemble one tile each of G = G_0 + sum_k a_k G_k from the lane-ordered generator image
-//              (72 KB for m = 8, read ONCE per interval) and publish it in LDS (8 KB); one barrier.
-//   waves 4-7  "copy waves": wave 4+c owns tile (I, J) = (c>>1, c&1) of B^T and F^T:
-//              G_B tiles by identity products, (G^2)^T[I][J] = sum_K G_B[K][I] * G_A[J][K]  (16 MFMAs),
-//              then the 2N = 32 tile stores of the I_N (x) B / -I_N (x) F copies (84 % of the bytes).
-//   waves 0-3  "compute waves": G D, Q_0 = -h/2 S + h^2/12 G D, Q_1 = h^2/12 D (16 MFMAs, each wave),
-//              then drives k = w, w+4, ...:  d/da_k = G_k Q_0 + G (G_k Q_1), transposed for the store
-//              (56 MFMAs per drive).  Wave 0 also produces the residual and d/dh (48 MFMAs).
-// Outputs are stored transposed (lane <-> row): each store instruction writes four whole 128-byte lines.
+// One 512-thread workgroup (8 wavefronts) per PAIR of intervals, one workgroup per CU.  The hardware deals a
+// workgroup's waves round-robin over the 4 SIMDs, so with waves 0-3 = compute and waves 4-7 = copy every SIMD
+// hosts exactly one MFMA-heavy wave and one store-heavy wave (two 4-wave workgroups per CU put two compute
+// waves on one SIMD about half the time: their MFMA chains then ran 1.7x longer and became the tail).
+//   phase 1     the 8 waves share the (m+1) x 4 tiles of the generator images (72 KB for m = 8): each tile is
+//               requested ONCE per workgroup and parked in LDS; the compute waves also request their knot data,
+//               wave 4 / 6 the derivative-integrator data of their interval.  Barrier.
+//   phase 2     wave w assembles tile w&3 of G = G_0 + sum_k a_k G_k for interval w>>2 from the LDS images.  Barrier.
+//               After it no wave issues a global load (a load issued during the store burst waits microseconds).
+//   waves 4-7   "copy waves": wave 4 + 2 s + I owns block row I of B^T and F^T of interval s (two tiles):
+//               G_B tiles by identity products, (G^2)^T[I][J] = sum_K G_B[K][I] * G_A[J][K]  (24 MFMAs),
+//               then the 2N = 32 tile stores x 2 tiles x 2 matrices of the I_N (x) B / -I_N (x) F copies.
+//   waves 0-3   "compute waves": wave 2 s + c of interval s:  G D, Q_0 = -h/2 S + h^2/12 G D (16 MFMAs), then
+//               drives k = c, c+2, ...:  d/da_k = G_k Q_0 + h^2/12 G (G_k D), transposed for the store (56 MFMAs
+//               per drive).  Wave 2 s also produces the residual and d/dh (48 MFMAs).
+// Outputs are stored transposed (lane <-> row): each store instruction writes four whole 128-byte lines;
+// stores are non-temporal and compile-time (a run-time store-mode switch halves the store issue rate).
 #include "qc_mfma_common.h"
 
 namespace {
@@ -20,7 +27,8 @@ using namespace qc_mfma;
 
 constexpr int kThreads32 = 512;
 constexpr int kMaxGrid32 = 1024;
-constexpr int kMU32 = 8;
+constexpr int kMU32 = 8;            // drives whose images live in the LDS block (more: fetched from global memory)
+constexpr int kDF32 = 4;            // derivative integrators served from registers
 
 // A-layout image of tile `tile` (= 2 I + K) of generator `mat`: [mat][tile][pair][lane][2]
 __device__ inline v4d load_GA32(const double* __restrict__ Gx, int mat, int tile, int lane) {
@@ -53,29 +61,37 @@ __device__ inline v4d mm16x2(const v4d& a0, const v4d& b0, const v4d& a1, const 
     return acc0 + acc1;
 }
 
-// Store transposed tile I of a 32 x 16 matrix (or tile (I, J) of a 32 x 32 one with colbase = 16 J... see callers):
-// lane (g, j) reg r holds X[rowbase + j][colbase + 4r + g]; column-major with 32 rows per column.
+// Store a transposed tile: lane (g, j) reg r holds X[rowbase + j][colbase + 4r + g]; column-major, 32 rows per column.
 __device__ inline void store_T32(double* __restrict__ p, const v4d& x, int rowbase, int colbase, int g, int j) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) qc_st8m<2>(p + (colbase + 4 * r + g) * 32 + rowbase + j, x[r]);   // non-temporal, compile-time
 }
 
-template <bool JAC>
+template <bool JAC, bool DIAG>
 __global__ __launch_bounds__(kThreads32, 2) void qc_mfma32_pade4_kernel(const QcParams P, const double* __restrict__ Z,
                                                                        double* __restrict__ F, double* __restrict__ J) {
-    __shared__ __attribute__((aligned(16))) double GaL[4 * 256];
+    __shared__ __attribute__((aligned(16))) double GaL[2 * 4 * 256];                    // G tiles of the two intervals
+    __shared__ __attribute__((aligned(16))) double ImgL[(kMU32 + 1) * 4 * 256];        // image tile t of matrix k at (k * 4 + t) * 256
+    __shared__ double DerL[2 * 2 * kDF32 * 64];                                          // derivative-integrator data parked until the end
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool copy_role = w >= 4;
+    const int slot = (w & 3) >> 1;      // which interval of the pair
+    const int sub = w & 1;              // compute: drive parity; copy: block row I
     const int m = P.m;
+    const int mL = m < kMU32 ? m : kMU32;
     const int g = lane >> 4, j = lane & 15;
     const bool ft = P.off_dt >= 0;
     const double c1 = P.c[1], c2 = P.c[2];
     const double* __restrict__ Gx = P.Gx;
     const v4d IdB = identity_B(g, j);
+    const int n_wg = (P.n_int + 1) / 2;
 
-    for (int vb = blockIdx.x; vb < P.n_int; vb += gridDim.x) {
-        const int b = qc_xcd_remap(vb, P.n_int);
+    for (int vb = blockIdx.x; vb < n_wg; vb += gridDim.x) {
+        const int b_raw = 2 * qc_xcd_remap(vb, n_wg) + slot;
+        const bool active = b_raw < P.n_int;                  // an odd interval count leaves the last slot empty;
+        const int b = active ? b_raw : P.n_int - 1;           // its waves still load images and take part in the barriers
         const long long t = P.t_begin + b;
         const double* __restrict__ z0 = Z + t * (long long)P.zdim;
         const double* __restrict__ z1 = z0 + P.zdim;
@@ -83,10 +99,26 @@ __global__ __launch_bounds__(kThreads32, 2) void qc_mfma32_pade4_kernel(const Qc
         double* __restrict__ Fb = F ? F + (size_t)b * P.F_stride + P.F_off : nullptr;
         const double h = ft ? z0[P.off_dt] : P.dt_fixed;
         const double hc1 = h * c1, hc2 = h * h * c2;
+        QC_STAMP_DECL;
+        QC_STAMP(P, b, lane, 0);
 
-        // knot data for the compute waves (requested before the assembly barrier)
+        // ---- phase 1: every global load of the pair of intervals -------------------------------------------------
+        {   // image tiles: matrix parity by wave half, tile by w & 3  ->  each of the (mL+1) x 4 tiles exactly once
+            constexpr int kPer = (kMU32 + 2) / 2;             // matrices per wave (5 for kMU32 = 8)
+            v4d img[kPer];
+#pragma unroll
+            for (int u = 0; u < kPer; ++u) {
+                const int mat = 2 * u + (w >> 2);
+                img[u] = load_GA32(Gx, mat <= mL ? mat : mL, w & 3, lane);
+            }
+#pragma unroll
+            for (int u = 0; u < kPer; ++u) {
+                const int mat = 2 * u + (w >> 2);
+                if (mat <= mL) lds_put_tile(ImgL, mat * 4 + (w & 3), lane, img[u]);
+            }
+        }
         v4d S[2], D[2];
-        if (w < 4) {
+        if (!copy_role) {
 #pragma unroll
             for (int I = 0; I < 2; ++I) {
                 const double* u0p = z0 + P.off_U + j * 32 + 16 * I + g;
@@ -96,58 +128,106 @@ __global__ __launch_bounds__(kThreads32, 2) void qc_mfma32_pade4_kernel(const Qc
                 S[I] = u1 + u0;
                 D[I] = u1 - u0;
             }
-            // ---- assemble tile w of G and publish it -------------------------------------------------
-            v4d Gt = load_GA32(Gx, 0, w, lane);
-            for (int k0 = 0; k0 < m; k0 += kMU32) {
-                v4d gk[kMU32];
-                double ak[kMU32];
+        }
+        const bool dfast = P.n_deriv <= kDF32;
+        const bool deriv_wave = copy_role && sub == 0;        // waves 4 and 6
+        double* __restrict__ derl = DerL + slot * (2 * kDF32 * 64);
+        if (deriv_wave) {   // requested now (before any store of the workgroup), parked in LDS, used after the copies
 #pragma unroll
-                for (int u = 0; u < kMU32; ++u) {
-                    const int k = (k0 + u < m) ? k0 + u : m - 1;
-                    gk[u] = load_GA32(Gx, k + 1, w, lane);
-                    ak[u] = (k0 + u < m) ? z0[P.off_a + k] : 0.0;
-                }
-#pragma unroll
-                for (int u = 0; u < kMU32; ++u) Gt += ak[u] * gk[u];
+            for (int d = 0; d < kDF32; ++d) {   // unused slots have zero offsets/dims: the loads stay in bounds
+                const int i = lane < P.ddim_i[d] ? lane : 0;
+                derl[(2 * d) * 64 + lane] = z0[P.dx_off[d] + i];
+                derl[(2 * d + 1) * 64 + lane] = z1[P.x_off[d] + i] - z0[P.x_off[d] + i];
             }
-            lds_put_tile(GaL, w, lane, Gt);
+        }
+        double ak[kMU32];                                     // amplitudes of this wave's interval (scalar loads)
+#pragma unroll
+        for (int u = 0; u < kMU32; ++u) ak[u] = (u < m) ? z0[P.off_a + (u < m ? u : 0)] : 0.0;
+        __syncthreads();
+        QC_STAMP(P, b, lane, 1);
+
+        // ---- phase 2: tile w & 3 of G for interval (w >> 2) ... the copy half assembles for slot of (w-4)>>1 --------
+        {
+            // waves 0-3 assemble the 4 tiles of slot 0's G?  No: wave w assembles tile (w & 3) of the interval whose
+            // amplitudes it holds; waves {0,1} and {4,5} hold slot 0, waves {2,3} and {6,7} slot 1.  Tiles of slot s:
+            // compute waves 2s, 2s+1 take tiles 0,1; copy waves 4+2s, 5+2s take tiles 2,3.
+            const int tile = (copy_role ? 2 : 0) + sub;
+            v4d Gt = lds_tile(ImgL, tile, lane);
+#pragma unroll
+            for (int u = 0; u < kMU32; ++u) {
+                if (u < m) Gt += ak[u] * lds_tile(ImgL, (u + 1) * 4 + tile, lane);
+                if ((u & 1) == 1) __builtin_amdgcn_sched_barrier(0);   // two tiles in flight, not all eight (register pressure)
+            }
+            for (int k = kMU32; k < m; ++k) Gt += z0[P.off_a + k] * load_GA32(Gx, k + 1, tile, lane);
+            lds_put_tile(GaL + slot * 1024, tile, lane, Gt);
         }
         __syncthreads();
+        QC_STAMP(P, b, lane, 2);
+        const double* __restrict__ GaS = GaL + slot * 1024;
 
-        if (w >= 4) {
-            // ================= copy wave: tile (I, Jt) of B^T and F^T, N copies each =====================
-            if (JAC) {
-                const int c = w - 4, I = c >> 1, Jt = c & 1;
+        if (copy_role) {
+            // ================= copy wave: block row I of B^T and F^T (tiles (I,0), (I,1)), N copies each ========
+            if (JAC && active && !(P.dbg_skip & 1)) {
+                const int I = sub;
                 // (G^T)[I][K] as A operand = B-layout of G[K][I] = G[K][I] * Id;  (G^T)[K][Jt] as B operand = A-layout of G[Jt][K]
-                const v4d GbK0 = mm16(lds_tile(GaL, 0 * 2 + I, lane), IdB);
-                const v4d GbK1 = mm16(lds_tile(GaL, 1 * 2 + I, lane), IdB);
-                const v4d G2T = mm16x2(GbK0, lds_tile(GaL, Jt * 2 + 0, lane), GbK1, lds_tile(GaL, Jt * 2 + 1, lane));
-                const v4d GT = lds_tile(GaL, Jt * 2 + I, lane);      // D-layout of (G^T)[I][Jt] = A-layout of G[Jt][I]
-                v4d Fm, Bm;
+                const v4d GbK0 = mm16(lds_tile(GaS, 0 * 2 + I, lane), IdB);
+                const v4d GbK1 = mm16(lds_tile(GaS, 1 * 2 + I, lane), IdB);
+                v4d Fm[2], Bm[2];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const double ev = (I == Jt ? IdB[r] : 0.0) + hc2 * G2T[r];
-                    Fm[r] = -(ev + hc1 * GT[r]);
-                    Bm[r] = ev - hc1 * GT[r];
+                for (int Jt = 0; Jt < 2; ++Jt) {
+                    const v4d G2T = mm16x2(GbK0, lds_tile(GaS, Jt * 2 + 0, lane), GbK1, lds_tile(GaS, Jt * 2 + 1, lane));
+                    const v4d GT = lds_tile(GaS, Jt * 2 + I, lane);      // D-layout of (G^T)[I][Jt] = A-layout of G[Jt][I]
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const double ev = (I == Jt ? IdB[r] : 0.0) + hc2 * G2T[r];
+                        Fm[Jt][r] = -(ev + hc1 * GT[r]);
+                        Bm[Jt][r] = ev - hc1 * GT[r];
+                    }
                 }
                 // lane (g, j) reg r = B^T[16I+4r+g][16Jt+j] = B[16Jt+j][16I+4r+g]
                 double* pF = Jb + P.jo_F;
                 double* pB = Jb + P.jo_B;
                 for (int q = 0; q < 16; ++q) {
-                    store_T32(pF + q * 1024, Fm, 16 * Jt, 16 * I, g, j);
-                    store_T32(pB + q * 1024, Bm, 16 * Jt, 16 * I, g, j);
+                    store_T32(pF + q * 1024, Fm[0], 0, 16 * I, g, j);
+                    store_T32(pF + q * 1024, Fm[1], 16, 16 * I, g, j);
+                    store_T32(pB + q * 1024, Bm[0], 0, 16 * I, g, j);
+                    store_T32(pB + q * 1024, Bm[1], 16, 16 * I, g, j);
                 }
-                if (w == 4) deriv_rows_generic(P, z0, z1, h, Fb, Jb, lane, false);
+                if (deriv_wave) {   // derivative integrator rows
+                    int r0 = P.s, jo = P.jo_d;
+                    bool all_fast = dfast;
+#pragma unroll
+                    for (int d = 0; d < kDF32; ++d) {
+                        if (d < P.n_deriv) {
+                            const int dim = P.ddim_i[d];
+                            if (dfast && dim <= 64) {
+                                if (lane < dim) {
+                                    const double dx = derl[(2 * d) * 64 + lane], df = derl[(2 * d + 1) * 64 + lane];
+                                    if (Fb) Fb[r0 + lane] = df - h * dx;
+                                    Jb[jo + lane] = -1.0;
+                                    Jb[jo + dim + lane] = 1.0;
+                                    Jb[jo + 2 * dim + lane] = -h;
+                                    if (ft) Jb[jo + 3 * dim + lane] = -dx;
+                                }
+                            } else {
+                                all_fast = false;
+                            }
+                            r0 += dim;
+                            jo += (ft ? 4 : 3) * dim;
+                        }
+                    }
+                    if (!all_fast) deriv_rows_generic(P, z0, z1, h, Fb, Jb, lane, dfast);
+                }
             }
-        } else {
+        } else if (active) {
             // ===================== compute waves ===========================================================
             v4d Ga[4];
 #pragma unroll
-            for (int tI = 0; tI < 4; ++tI) Ga[tI] = lds_tile(GaL, tI, lane);
+            for (int tI = 0; tI < 4; ++tI) Ga[tI] = lds_tile(GaS, tI, lane);
             v4d GD[2];
 #pragma unroll
             for (int I = 0; I < 2; ++I) GD[I] = mm16x2(Ga[2 * I], D[0], Ga[2 * I + 1], D[1]);
-            if (w == 0) {
+            if (sub == 0) {
                 v4d GS[2], G2D[2];
 #pragma unroll
                 for (int I = 0; I < 2; ++I) {
@@ -165,33 +245,39 @@ __global__ __launch_bounds__(kThreads32, 2) void qc_mfma32_pade4_kernel(const Qc
                 }
                 if (!JAC) deriv_rows_generic(P, z0, z1, h, Fb, nullptr, lane, false);
             }
-            if (JAC) {
-                v4d Q0[2], Q1[2];
+            if (JAC && !(P.dbg_skip & 2)) {
+                v4d Q0[2];                          // Q_1 = h^2 c2 D is applied as a scale on G (G_k D) below
 #pragma unroll
-                for (int I = 0; I < 2; ++I) {
-                    Q0[I] = (-hc1) * S[I] + hc2 * GD[I];
-                    Q1[I] = hc2 * D[I];
-                }
-                for (int k = w; k < m; k += 4) {
+                for (int I = 0; I < 2; ++I) Q0[I] = (-hc1) * S[I] + hc2 * GD[I];
+                for (int k = sub; k < m; k += 2) {
                     v4d Gk[4];
 #pragma unroll
-                    for (int tI = 0; tI < 4; ++tI) Gk[tI] = load_GA32(Gx, k + 1, tI, lane);
-                    v4d R0[2], R1[2];
+                    for (int tI = 0; tI < 4; ++tI)   // LDS image block for the first kMU32 drives, global memory beyond
+                        Gk[tI] = k < kMU32 ? lds_tile(ImgL, (k + 1) * 4 + tI, lane) : load_GA32(Gx, k + 1, tI, lane);
+                    v4d R1[2];                      // G_k D
 #pragma unroll
-                    for (int I = 0; I < 2; ++I) {
-                        R0[I] = mm16x2(Gk[2 * I], Q0[0], Gk[2 * I + 1], Q0[1]);
-                        R1[I] = mm16x2(Gk[2 * I], Q1[0], Gk[2 * I + 1], Q1[1]);
-                    }
+                    for (int I = 0; I < 2; ++I) R1[I] = mm16x2(Gk[2 * I], D[0], Gk[2 * I + 1], D[1]);
                     double* pa = Jb + P.jo_a + (size_t)k * 512;
 #pragma unroll
                     for (int I = 0; I < 2; ++I) {
-                        const v4d Y = R0[I] + mm16x2(Ga[2 * I], R1[0], Ga[2 * I + 1], R1[1]);
+                        const v4d R0 = mm16x2(Gk[2 * I], Q0[0], Gk[2 * I + 1], Q0[1]);          // G_k Q_0
+                        const v4d Y = R0 + hc2 * mm16x2(Ga[2 * I], R1[0], Ga[2 * I + 1], R1[1]);   // + h^2 c2 G (G_k D)
                         store_T32(pa, mm16(Y, IdB), 16 * I, 0, g, j);
                     }
                 }
             }
         }
-        __syncthreads();   // GaL is rewritten by the next interval of a persistent grid
+        if constexpr (DIAG) {
+            QC_STAMP(P, b, lane, 3);                       // everything issued
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            QC_STAMP(P, b, lane, 4);                       // everything acknowledged
+            if (P.stamps != nullptr && lane == 0 && active) {   // 4 waves x 4 slots per interval: [compute 0, compute 1, copy 0, copy 1]
+                const int wi = (copy_role ? 2 : 0) + sub;
+#pragma unroll
+                for (int k_ = 0; k_ < 4; ++k_) P.stamps[(size_t)b * 16 + wi * 4 + k_] = qc_ts_[k_ == 3 ? 4 : (k_ == 0 ? 1 : k_ + 1)];
+            }
+        }
+        __syncthreads();   // the LDS blocks are rewritten by the next pair of a persistent grid
     }
 }
 
@@ -217,8 +303,11 @@ void qc_mfma32_pack_G(const QcParams& P, const double* G, double* Gx) {
 }
 
 hipError_t qc_launch_mfma32_F_jac(const QcParams& P, const double* dZ, double* dF, double* dJ, hipStream_t st) {
-    const int grid = P.n_int < kMaxGrid32 ? P.n_int : kMaxGrid32;
-    if (dJ) hipLaunchKernelGGL(qc_mfma32_pade4_kernel<true>, dim3(grid), dim3(kThreads32), 0, st, P, dZ, dF, dJ);
-    else hipLaunchKernelGGL(qc_mfma32_pade4_kernel<false>, dim3(grid), dim3(kThreads32), 0, st, P, dZ, dF, dJ);
+    const int n_wg = (P.n_int + 1) / 2;
+    const int grid = n_wg < kMaxGrid32 ? n_wg : kMaxGrid32;
+    const bool diag = P.stamps != nullptr;
+    if (dJ && diag) hipLaunchKernelGGL((qc_mfma32_pade4_kernel<true, true>), dim3(grid), dim3(kThreads32), 0, st, P, dZ, dF, dJ);
+    else if (dJ) hipLaunchKernelGGL((qc_mfma32_pade4_kernel<true, false>), dim3(grid), dim3(kThreads32), 0, st, P, dZ, dF, dJ);
+    else hipLaunchKernelGGL((qc_mfma32_pade4_kernel<false, false>), dim3(grid), dim3(kThreads32), 0, st, P, dZ, dF, dJ);
     return hipGetLastError();
 }
