@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="0 disables the CPU baseline leg")
     ap.add_argument("--hessian", action="store_true", help="also time mu_d2F and report the ms/Ipopt-iter proxy")
     ap.add_argument("--allgather", action="store_true", help="also time the RCCL all-gather of the value blocks")
+    ap.add_argument("--host-visible", action="store_true", help="also time qc_eval_F_jac with host buffers (PCIe-inclusive; never `value`)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -192,6 +193,16 @@ def main():
         extra["F_only_us"] = F_us
         # Ipopt iteration proxy: F+dF, mu_d2F, one extra line-search F; solver algebra excluded
         extra["ms_per_ipopt_iter_proxy_device"] = (kernel_us_stream + hess_us + F_us) / 1e3
+    if args.host_visible and world == 1:
+        # PCIe-inclusive rate of the host-buffer entry point (what a CPU Ipopt consumer sees); reported beside, never as, `value`.
+        # (Page-locking the caller's arrays with hipHostRegister was tried: 0.80 vs 0.82 ms, not worth an API.)
+        Fh, Jh = np.empty(int(dims.F_len)), np.empty(int(dims.jac_nnz))
+        for _ in range(3):
+            dyn.F_dF_into(Zh, Fh, Jh)
+        h0 = time.perf_counter()
+        for _ in range(20):
+            dyn.F_dF_into(Zh, Fh, Jh)
+        extra["host_visible_ms_per_eval"] = (time.perf_counter() - h0) / 20 * 1e3
     if args.allgather and world > 1:
         pad = torch.zeros(sd.padded_len(nnz), dtype=torch.float64, device=dev)
         pad[:Jb[0].numel()].copy_(Jb[0])

@@ -219,6 +219,10 @@ class QuantumDynamics:
         r, c = (jr, jc) if which in ("dF", "∂F") else (hr, hc)
         return list(zip(r.tolist(), c.tolist()))
 
+    def F_dF_into(self, Z: np.ndarray, F: np.ndarray, J: np.ndarray) -> None:
+        """qc_eval_F_jac into caller-owned arrays (no allocation): the call shape of an MOI callback."""
+        _lib.check(_lib.lib.qc_eval_F_jac(self._h, _lib.dptr(Z), _lib.dptr(F), _lib.dptr(J)), self._h)
+
     # -- host-buffer evaluation (what Ipopt's callbacks use) --------------------------------------
     def _Z(self, Z):
         Z = np.ascontiguousarray(Z, dtype=np.float64)
