@@ -446,8 +446,9 @@ extern "C" int qc_eval_F_jac_dev(qc_handle* h, const double* dZ, double* dF, dou
 
 extern "C" int qc_eval_hess_dev(qc_handle* h, const double* dZ, const double* dmu, double* dhvals, void* stream) {
     if (!h) return fail(nullptr, QC_ERR_INVALID, "qc_eval_hess_dev: NULL handle");
-    if (h->prm.hess_nnz == 0)
+    if (h->prm.integrator != QC_PADE)
         return fail(&h->err, QC_ERR_UNSUPPORTED, "no analytic Hessian for the exponential integrator (upstream has none either; use eval_hessian=false)");
+    if (h->prm.hess_nnz == 0) return QC_OK;   // no drives and a fixed timestep: the constraint is linear
     if (!dZ || !dmu || !dhvals) return fail(&h->err, QC_ERR_INVALID, "qc_eval_hess_dev: NULL buffer");
     int rc;
     if ((rc = check_align(h, dZ, 8, "dZ"))) return rc;
@@ -507,8 +508,9 @@ extern "C" int qc_eval_F_jac(qc_handle* h, const double* Z, double* F, double* v
 
 extern "C" int qc_eval_hess(qc_handle* h, const double* Z, const double* mu, double* hvals) {
     if (!h) return fail(nullptr, QC_ERR_INVALID, "qc_eval_hess: NULL handle");
-    if (h->prm.hess_nnz == 0)
+    if (h->prm.integrator != QC_PADE)
         return fail(&h->err, QC_ERR_UNSUPPORTED, "no analytic Hessian for the exponential integrator (upstream has none either; use eval_hessian=false)");
+    if (h->prm.hess_nnz == 0) return QC_OK;   // no drives and a fixed timestep: the constraint is linear
     if (!Z || !mu || !hvals) return fail(&h->err, QC_ERR_INVALID, "qc_eval_hess: NULL buffer");
     if (is_composed(h)) return fail(&h->err, QC_ERR_UNSUPPORTED, "composed handles write into shared vectors: use the _dev entry points");
     QC_HIP(h, hipSetDevice(h->device));
