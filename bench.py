@@ -80,6 +80,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="0 disables the CPU baseline leg")
     ap.add_argument("--hessian", action="store_true", help="also time mu_d2F and report the ms/Ipopt-iter proxy")
     ap.add_argument("--allgather", action="store_true", help="also time the RCCL all-gather of the value blocks")
+    ap.add_argument("--streams", type=int, default=0, help="also time the same steps issued round-robin on S streams "
+                    "(independent evaluations overlapping their launch/drain phases; reported as an extra field, never `value`)")
     ap.add_argument("--host-visible", action="store_true", help="also time qc_eval_F_jac with host buffers (PCIe-inclusive; never `value`)")
     args = ap.parse_args()
 
@@ -193,6 +195,20 @@ def main():
         extra["F_only_us"] = F_us
         # Ipopt iteration proxy: F+dF, mu_d2F, one extra line-search F; solver algebra excluded
         extra["ms_per_ipopt_iter_proxy_device"] = (kernel_us_stream + hess_us + F_us) / 1e3
+    if args.streams > 1:
+        # Independent evaluations (e.g. the systems of a sampling problem, or several line-search points) may overlap the
+        # ~4 us of dispatch + write-back of one launch with the store phase of the next.  A serial Ipopt loop cannot.
+        sts = [torch.cuda.Stream(device=dev) for _ in range(args.streams)]
+        ln = [dyn.bind_F_dF_device(Zs[i & 3], Fb[i % nbuf], Jb[i % nbuf], sts[i % args.streams]) for i in range(period * args.streams)]
+        for i in range(args.warmup):
+            ln[i % len(ln)]()
+        torch.cuda.synchronize()
+        p0 = time.perf_counter()
+        for i in range(args.steps):
+            ln[i % len(ln)]()
+        torch.cuda.synchronize()
+        extra["pipelined_streams"] = args.streams
+        extra["pipelined_ms_per_step"] = (time.perf_counter() - p0) / args.steps * 1e3
     if args.host_visible and world == 1:
         # PCIe-inclusive rate of the host-buffer entry point (what a CPU Ipopt consumer sees); reported beside, never as, `value`.
         # (Page-locking the caller's arrays with hipHostRegister was tried: 0.80 vs 0.82 ms, not worth an API.)
