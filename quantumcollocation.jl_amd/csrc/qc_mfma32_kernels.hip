@@ -167,7 +167,9 @@ __global__ __launch_bounds__(kThreads32, 2) void qc_mfma32_pade4_kernel(const Qc
 
         if (copy_role) {
             // ================= copy wave: block row I of B^T and F^T (tiles (I,0), (I,1)), N copies each ========
-            if (JAC && active && !(P.dbg_skip & 1)) {
+            bool skip_copy = false;
+            if constexpr (DIAG) skip_copy = (P.dbg_skip & 1) != 0;
+            if (JAC && active && !skip_copy) {
                 const int I = sub;
                 // (G^T)[I][K] as A operand = B-layout of G[K][I] = G[K][I] * Id;  (G^T)[K][Jt] as B operand = A-layout of G[Jt][K]
                 const v4d GbK0 = mm16(lds_tile(GaS, 0 * 2 + I, lane), IdB);
@@ -245,7 +247,9 @@ __global__ __launch_bounds__(kThreads32, 2) void qc_mfma32_pade4_kernel(const Qc
                 }
                 if (!JAC) deriv_rows_generic(P, z0, z1, h, Fb, nullptr, lane, false);
             }
-            if (JAC && !(P.dbg_skip & 2)) {
+            bool skip_drives = false;
+            if constexpr (DIAG) skip_drives = (P.dbg_skip & 2) != 0;
+            if (JAC && !skip_drives) {
                 v4d Q0[2];                          // Q_1 = h^2 c2 D is applied as a scale on G (G_k D) below
 #pragma unroll
                 for (int I = 0; I < 2; ++I) Q0[I] = (-hc1) * S[I] + hc2 * GD[I];
@@ -305,7 +309,7 @@ void qc_mfma32_pack_G(const QcParams& P, const double* G, double* Gx) {
 hipError_t qc_launch_mfma32_F_jac(const QcParams& P, const double* dZ, double* dF, double* dJ, hipStream_t st) {
     const int n_wg = (P.n_int + 1) / 2;
     const int grid = n_wg < kMaxGrid32 ? n_wg : kMaxGrid32;
-    const bool diag = P.stamps != nullptr;
+    const bool diag = P.stamps != nullptr || P.dbg_skip != 0;
     if (dJ && diag) hipLaunchKernelGGL((qc_mfma32_pade4_kernel<true, true>), dim3(grid), dim3(kThreads32), 0, st, P, dZ, dF, dJ);
     else if (dJ) hipLaunchKernelGGL((qc_mfma32_pade4_kernel<true, false>), dim3(grid), dim3(kThreads32), 0, st, P, dZ, dF, dJ);
     else hipLaunchKernelGGL((qc_mfma32_pade4_kernel<false, false>), dim3(grid), dim3(kThreads32), 0, st, P, dZ, dF, dJ);

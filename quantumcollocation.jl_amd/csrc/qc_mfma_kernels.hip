@@ -1,12 +1,16 @@
 // Register-resident f64-MFMA kernels (v_mfma_f64_16x16x4_f64) for the order-4 Pade integrator.
 //
-// n = 2N = 16 (3 qubits, BASELINE configs 3 and 4): TWO WAVEFRONTS PER INTERVAL, no LDS, no barrier.
-//   wave 1 ("copy wave")    G -> (G^2)^T -> B^T, F^T -> the 2N stores of the I_N (x) B / -I_N (x) F blocks
-//                           (80 % of the interval's bytes; this wave lives in the store queue)
-//   wave 0 ("compute wave") residual, d/dh, the m drive columns, derivative integrators
-// so the bandwidth-bound copies of one wave overlap the MFMA chains of the other on the same SIMDs
-// (profiles/r01_mfma_v2_timeline.txt shows the serial version: 3.4 us prologue, 4.4 us store-bound,
-// 5.3 us MFMA-latency-bound).
+// n = 2N = 16 (3 qubits, BASELINE configs 3 and 4): TWO WAVEFRONTS PER INTERVAL, one LDS hand-off, one barrier.
+//   wave 1 ("copy wave")    issues EVERY global load of the interval in one batch (generator images, both knots,
+//                           derivative-integrator data), assembles G, hands G / U_t / U_t+1 / the G_j images to the
+//                           compute wave through LDS, then G -> (G^2)^T -> B^T, F^T -> the 2N tile stores of the
+//                           I_N (x) B / -I_N (x) F blocks (80 % of the interval's bytes: this wave lives in the store queue)
+//   wave 0 ("compute wave") no global loads (one issued during the copy burst waits > 3 us); residual, d/dh and the m
+//                           drive columns as four batches of independent, interleaved MFMA products; its 16 stores are
+//                           issued only after the whole chain (a store issued mid-burst stalls the wave for microseconds)
+// so the bandwidth-bound copies of one wave overlap the MFMA chains of the other
+// (profiles/r01_mfma_v2_timeline.txt shows the serial one-wave version: 3.4 us prologue, 4.4 us store-bound,
+// 5.3 us MFMA-latency-bound; profiles/r01_mfma_v4_timeline.txt this one).
 //
 // Every 16x16x16 product is 4 MFMAs whose operands never leave the register file:
 //   * A-operand layout of a 16x16 matrix X:  lane (g = l>>4, i = l&15), reg kk holds X[i][4kk+g]
@@ -20,7 +24,9 @@
 //     instruction writes four whole 128-byte lines.  B^T and F^T come for free from
 //     (G^2)^T = mm16(G_B, G_A); the n x N outputs take one identity product each.
 //   * The constant generators G_0, G_j are read from a lane-ordered A-layout image in global memory
-//     (28 KB for m = 6: L2/Infinity-Cache resident), 16 bytes per lane per load.
+//     (14 KB for m = 6: L2/Infinity-Cache resident), 16 bytes per lane per load, once per interval.
+//   * Store flavour (non-temporal) and diagnostics are template parameters: as run-time switches they put a scalar
+//     branch ladder around every store and halved the store issue rate.
 //
 // Per interval (S = U1+U0, D = U1-U0, h = dt):                                          MFMAs
 //   copy wave:    G_B = G I ; (G^2)^T = G^T G^T ; B^T, F^T = I -+ h/2 G^T + h^2/12 (G^2)^T      8
