@@ -197,6 +197,47 @@ int qc_fidelity_eval(qc_fidelity* h, const double* U_iso, double* fidelity, doub
 /* device buffers, asynchronous on `stream`: dval2 = {F, |1-F|}; dgrad / dhess may be NULL */
 int qc_fidelity_eval_dev(qc_fidelity* h, const double* dU, double* dval2, double* dgrad, double* dhess, void* stream);
 
+/* ---- trajectory cost terms (SURVEY 8f "next" row 3) ----------------------------------------------- */
+/* J(Z) = sum_t 1/2 sum_k R_k (sc_t (v_tk - b_tk))^2 + D sum_{t < min_time_knots} dt_t,   sc_t = dt_t or 1:
+ * the `QuadraticRegularizer(name, traj, R; baseline, timestep_name)` terms on a / da / dda (reference call sites
+ * unitary_smooth_pulse_problem.jl:151-153) flattened into one list of regularised scalar entries of a knot, plus
+ * `MinimumTimeObjective(traj; D)` (unitary_minimum_time_problem.jl:67-69; the last knot's timestep drives no
+ * interval, hence min_time_knots = T-1 there).  The dt-scaling inside the square is how QuantumCollocationCore 0.3
+ * is recalled to define the regulariser (not vendored); QC_REG_PLAIN removes it.
+ * Gradient: dense, Z_len entries (zeros included).  Hessian: upper triangle, per knot
+ * [ (v_k,v_k) k=0..n_reg-1 | (v_k,dt) k=0..n_reg-1 | (dt,dt) ]; the last two groups exist only for QC_REG_DT_SCALED
+ * with a free timestep. */
+#define QC_REG_DT_SCALED 0
+#define QC_REG_PLAIN 1
+typedef struct qc_terms_desc {
+    int64_t T;
+    int32_t zdim;
+    int32_t off_dt;              /* offset of the timestep inside a knot, -1: fixed */
+    int64_t global_dim;
+    double dt_fixed;
+    int32_t n_reg;               /* number of regularised scalar entries of a knot */
+    int32_t weighting;           /* QC_REG_DT_SCALED | QC_REG_PLAIN */
+    const int32_t* reg_index;    /* n_reg offsets inside a knot, strictly increasing, != off_dt */
+    const double* reg_R;         /* n_reg weights */
+    const double* reg_baseline;  /* NULL, or n_reg x T (entry-fastest) values subtracted before squaring */
+    double min_time_D;           /* 0: no minimum-time term */
+    int64_t min_time_knots;      /* timesteps of knots 0..min_time_knots-1 are summed */
+    int32_t device;
+    int32_t reserved0;
+} qc_terms_desc;
+typedef struct qc_terms qc_terms;
+int qc_terms_desc_hess_nnz(const qc_terms_desc* d, int64_t* nnz);
+int qc_terms_desc_hess_structure(const qc_terms_desc* d, int64_t* rows, int64_t* cols, int one_based);
+int qc_terms_create(const qc_terms_desc* d, qc_terms** out);
+void qc_terms_destroy(qc_terms* h);
+const char* qc_terms_last_error(const qc_terms* h);
+int qc_terms_hess_nnz(const qc_terms* h, int64_t* nnz);
+int qc_terms_hess_structure(const qc_terms* h, int64_t* rows, int64_t* cols, int one_based);
+/* host buffers; J / grad / hvals may be NULL */
+int qc_terms_eval(qc_terms* h, const double* Z, double* J, double* grad, double* hvals);
+/* device buffers, asynchronous on `stream`; dgrad / dhvals may be NULL */
+int qc_terms_eval_dev(qc_terms* h, const double* dZ, double* dJ, double* dgrad, double* dhvals, void* stream);
+
 /* Diagnostic only: when the environment variable QC_STAMPS=1 is set at qc_create, the MFMA kernel
  * records 16 s_memrealtime (100 MHz) checkpoints per interval; this copies them out (synchronises the
  * device).  Not part of the evaluated path; a handle created without QC_STAMPS returns

@@ -533,3 +533,90 @@ def infidelity_value_grad_hess(u: np.ndarray, goal_iso: np.ndarray, subspace=Non
     Fv, g, Hm = fidelity_value_grad_hess(u, goal_iso, subspace)
     sg = 1.0 if 1.0 - Fv >= 0 else -1.0
     return abs(1.0 - Fv), -sg * g, -sg * Hm
+
+
+# --------------------------------------------------------------------------------------------
+#  Trajectory cost terms: quadratic regularisers + minimum-time term
+#  J = sum_t 1/2 sum_k R_k (sc_t (v_tk - b_tk))^2 + D sum_{t < n_mt} dt_t, sc_t = dt_t (dt_scaled) or 1.
+#  Reference call sites: unitary_smooth_pulse_problem.jl:151-153 (QuadraticRegularizer on a, da, dda),
+#  unitary_minimum_time_problem.jl:67-69 (MinimumTimeObjective).  Definitions live in QuantumCollocationCore 0.3
+#  (not vendored): the dt-scaling is recalled, not verified -- "parity unpinned" applies here as well.
+# --------------------------------------------------------------------------------------------
+@dataclass
+class Terms:
+    T: int
+    zdim: int
+    off_dt: int                       # -1: fixed timestep
+    reg_index: np.ndarray             # offsets inside a knot
+    reg_R: np.ndarray
+    baseline: np.ndarray | None = None   # (T, n_reg)
+    dt_scaled: bool = True
+    dt_fixed: float = 0.0
+    D: float = 0.0
+    n_mt: int = 0
+    global_dim: int = 0
+
+    @property
+    def cross(self) -> bool:
+        return self.dt_scaled and self.off_dt >= 0 and len(self.reg_index) > 0
+
+
+def _terms_knot(tm: Terms, Z, t):
+    z = Z[t * tm.zdim:(t + 1) * tm.zdim]
+    dt = z[tm.off_dt] if tm.off_dt >= 0 else tm.dt_fixed
+    dv = z[np.asarray(tm.reg_index, dtype=int)] if len(tm.reg_index) else np.zeros(0, dtype=Z.dtype)
+    if tm.baseline is not None:
+        dv = dv - tm.baseline[t]
+    return dt, dv
+
+
+def terms_value(tm: Terms, Z):
+    """Works on complex Z too (no abs / conj), so complex-step differentiation applies."""
+    J = 0.0
+    for t in range(tm.T):
+        dt, dv = _terms_knot(tm, Z, t)
+        sc = dt if tm.dt_scaled else 1.0
+        J = J + 0.5 * np.sum(tm.reg_R * (sc * dv) ** 2)
+        if tm.off_dt >= 0 and t < tm.n_mt:
+            J = J + tm.D * dt
+    return J
+
+
+def terms_grad(tm: Terms, Z: np.ndarray) -> np.ndarray:
+    g = np.zeros(tm.T * tm.zdim + tm.global_dim)
+    for t in range(tm.T):
+        dt, dv = _terms_knot(tm, Z, t)
+        sc = dt if tm.dt_scaled else 1.0
+        base = t * tm.zdim
+        for k, j in enumerate(tm.reg_index):
+            g[base + j] = tm.reg_R[k] * sc * sc * dv[k]
+        if tm.off_dt >= 0:
+            q = float(np.sum(tm.reg_R * dv * dv))
+            g[base + tm.off_dt] = (dt * q if tm.dt_scaled else 0.0) + (tm.D if t < tm.n_mt else 0.0)
+    return g
+
+
+def terms_hess_structure(tm: Terms, one_based: bool = False):
+    rows, cols = [], []
+    b = 1 if one_based else 0
+    for t in range(tm.T):
+        c0 = t * tm.zdim + b
+        for j in tm.reg_index:
+            rows.append(c0 + j); cols.append(c0 + j)
+        if tm.cross:
+            for j in tm.reg_index:
+                rows.append(c0 + min(j, tm.off_dt)); cols.append(c0 + max(j, tm.off_dt))
+            rows.append(c0 + tm.off_dt); cols.append(c0 + tm.off_dt)
+    return np.asarray(rows, dtype=np.int64), np.asarray(cols, dtype=np.int64)
+
+
+def terms_hess(tm: Terms, Z: np.ndarray) -> np.ndarray:
+    out = []
+    for t in range(tm.T):
+        dt, dv = _terms_knot(tm, Z, t)
+        sc = dt if tm.dt_scaled else 1.0
+        out.extend(tm.reg_R * sc * sc)
+        if tm.cross:
+            out.extend(2.0 * dt * tm.reg_R * dv)
+            out.append(float(np.sum(tm.reg_R * dv * dv)))
+    return np.asarray(out, dtype=np.float64)

@@ -12,7 +12,8 @@ from .integrators import (DerivativeIntegrator, QuantumStateExponentialIntegrato
                           UnitaryExponentialIntegrator, UnitaryPadeIntegrator)
 from .isomorphisms import iso_generator, iso_vec_to_operator, operator_to_iso_vec, pade_coefficients
 from .named_trajectory import NamedTrajectory
-from .objectives import FinalUnitaryFidelityConstraint, UnitaryInfidelityObjective, iso_vec_unitary_fidelity
+from .objectives import (FinalUnitaryFidelityConstraint, MinimumTimeObjective, QuadraticRegularizer, TimeStepsAllEqualConstraint,
+                         TrajectoryObjective, UnitaryInfidelityObjective, iso_vec_unitary_fidelity)
 from .problems import (CONFIGS, config_inputs, multi_qubit_system, quantum_state_smooth_pulse_inputs,
                        unitary_sampling_inputs, unitary_smooth_pulse_inputs)
 from .quantum_systems import QuantumSystem
@@ -24,5 +25,6 @@ __all__ = [
     "QuantumStateExponentialIntegrator", "quantum_state_smooth_pulse_inputs", "unitary_sampling_inputs", "ComposedQuantumDynamics", "split_groups", "operator_to_iso_vec", "iso_vec_to_operator",
     "iso_generator", "pade_coefficients", "GATES", "PAULIS", "operator_from_string", "config_inputs",
     "unitary_smooth_pulse_inputs", "multi_qubit_system", "CONFIGS", "initialize_trajectory",
-    "unitary_geodesic", "iso_vec_unitary_fidelity", "UnitaryInfidelityObjective", "FinalUnitaryFidelityConstraint", "make_desc", "desc_dims", "desc_structures", "QCollocError",
+    "unitary_geodesic", "iso_vec_unitary_fidelity", "UnitaryInfidelityObjective", "FinalUnitaryFidelityConstraint", "QuadraticRegularizer", "MinimumTimeObjective", "TrajectoryObjective", "TimeStepsAllEqualConstraint",
+    "make_desc", "desc_dims", "desc_structures", "QCollocError",
 ]

@@ -31,6 +31,8 @@ QC_KERNEL_AUTO = 0
 QC_KERNEL_LDS = 1
 QC_KERNEL_MFMA = 2
 QC_MAX_DERIV = 8
+QC_REG_DT_SCALED = 0
+QC_REG_PLAIN = 1
 
 _c_double_p = C.POINTER(C.c_double)
 _c_int64_p = C.POINTER(C.c_int64)
@@ -87,11 +89,31 @@ class qc_dims_t(C.Structure):
     ]
 
 
+class qc_terms_desc(C.Structure):
+    _fields_ = [
+        ("T", C.c_int64),
+        ("zdim", C.c_int32),
+        ("off_dt", C.c_int32),
+        ("global_dim", C.c_int64),
+        ("dt_fixed", C.c_double),
+        ("n_reg", C.c_int32),
+        ("weighting", C.c_int32),
+        ("reg_index", C.POINTER(C.c_int32)),
+        ("reg_R", _c_double_p),
+        ("reg_baseline", _c_double_p),
+        ("min_time_D", C.c_double),
+        ("min_time_knots", C.c_int64),
+        ("device", C.c_int32),
+        ("reserved0", C.c_int32),
+    ]
+
+
 # Every symbol include/qcolloc.h declares: (name, restype, argtypes).  tests/test_abi.py checks this
 # table against the header and against the built library.
 _DESC_P = C.POINTER(qc_desc)
 _DIMS_P = C.POINTER(qc_dims_t)
 _H = C.c_void_p
+_TDESC_P = C.POINTER(qc_terms_desc)
 SYMBOLS = {
     "qc_operator_to_iso_vec": (C.c_int, [C.c_int32, _c_double_p, _c_double_p, _c_double_p]),
     "qc_iso_vec_to_operator": (C.c_int, [C.c_int32, _c_double_p, _c_double_p, _c_double_p]),
@@ -117,6 +139,15 @@ SYMBOLS = {
     "qc_fidelity_last_error": (C.c_char_p, [_H]),
     "qc_fidelity_eval": (C.c_int, [_H, _c_double_p, _c_double_p, _c_double_p, _c_double_p, _c_double_p]),
     "qc_fidelity_eval_dev": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "qc_terms_desc_hess_nnz": (C.c_int, [_TDESC_P, _c_int64_p]),
+    "qc_terms_desc_hess_structure": (C.c_int, [_TDESC_P, _c_int64_p, _c_int64_p, C.c_int]),
+    "qc_terms_create": (C.c_int, [_TDESC_P, C.POINTER(_H)]),
+    "qc_terms_destroy": (None, [_H]),
+    "qc_terms_last_error": (C.c_char_p, [_H]),
+    "qc_terms_hess_nnz": (C.c_int, [_H, _c_int64_p]),
+    "qc_terms_hess_structure": (C.c_int, [_H, _c_int64_p, _c_int64_p, C.c_int]),
+    "qc_terms_eval": (C.c_int, [_H, _c_double_p, _c_double_p, _c_double_p, _c_double_p]),
+    "qc_terms_eval_dev": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "qc_debug_read_stamps": (C.c_int, [_H, C.POINTER(C.c_uint64), C.c_int64]),
     "qc_version": (C.c_char_p, []),
 }

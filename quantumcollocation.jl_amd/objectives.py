@@ -8,6 +8,9 @@
 Loss per the reference docstring (unitary_smooth_pulse_problem.jl:23-28): l = |1 - |tr(U_goal' U_T)| / N|.
 Only the last knot's state enters; gradients/Hessians are returned on those `2N^2` variables together with
 their global indices.
+
+Whole-trajectory terms through `qc_terms_*`: `QuadraticRegularizer`, `MinimumTimeObjective`
+(summed into one `TrajectoryObjective`) and the constant `TimeStepsAllEqualConstraint`.
 """
 from __future__ import annotations
 
@@ -15,6 +18,7 @@ import ctypes as C
 from typing import Optional, Sequence
 
 import numpy as np
+import torch
 
 from . import _lib
 from .named_trajectory import NamedTrajectory
@@ -136,3 +140,188 @@ class FinalUnitaryFidelityConstraint(_FinalKnotTerm):
 
     def mu_d2g(self, Z, mu) -> np.ndarray:
         return float(np.asarray(mu).ravel()[0]) * self._f.eval(self._u(Z), grad=False, hess=True)[3]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+#  Whole-trajectory cost terms through `qc_terms_*`
+# ---------------------------------------------------------------------------------------------------------------
+class QuadraticRegularizer:
+    """`QuadraticRegularizer(name, traj, R; baseline, timestep_name)` (reference call sites
+    unitary_smooth_pulse_problem.jl:151-153): 1/2 sum_t sum_i R_i (dt_t (x_ti - b_ti))^2.  A description only; add it
+    to a `TrajectoryObjective` to evaluate it."""
+
+    def __init__(self, name: str, traj: NamedTrajectory, R, baseline: Optional[np.ndarray] = None, timestep_name: Optional[str] = None):
+        self.name = name
+        self.dim = len(traj.components[name])
+        R = np.asarray(R, dtype=np.float64)
+        self.R = np.full(self.dim, float(R)) if R.ndim == 0 else R.copy()
+        if self.R.shape != (self.dim,):
+            raise ValueError(f"R has shape {self.R.shape}, expected ({self.dim},)")
+        self.baseline = None if baseline is None else np.asarray(baseline, dtype=np.float64).reshape(self.dim, traj.T)
+        self.timestep_name = timestep_name if timestep_name is not None else (traj.timestep if isinstance(traj.timestep, str) else None)
+
+    def __add__(self, other):
+        return TrajectoryObjectiveSpec([self]) + other
+
+
+class MinimumTimeObjective:
+    """`MinimumTimeObjective(traj; D)` (reference unitary_minimum_time_problem.jl:67-69): D * sum_{t=1}^{T-1} dt_t."""
+
+    def __init__(self, traj: NamedTrajectory, D: float = 1.0, timestep_name: Optional[str] = None):
+        self.D = float(D)
+        self.timestep_name = timestep_name if timestep_name is not None else traj.timestep
+        if not isinstance(self.timestep_name, str):
+            raise ValueError("a minimum-time objective needs a free timestep component")
+
+    def __add__(self, other):
+        return TrajectoryObjectiveSpec([self]) + other
+
+
+class TrajectoryObjectiveSpec:
+    def __init__(self, terms):
+        self.terms = list(terms)
+
+    def __add__(self, other):
+        more = other.terms if isinstance(other, TrajectoryObjectiveSpec) else [other]
+        return TrajectoryObjectiveSpec(self.terms + list(more))
+
+
+class TrajectoryObjective:
+    """Sum of `QuadraticRegularizer` / `MinimumTimeObjective` terms evaluated in one pass over the knots on the GPU.
+    `L(Z)`, `grad_L(Z)` (dense, length `len(Z)`), `hess_L(Z)` (values on `hess_structure`); `"∇L"`, `"∂²L"`,
+    `"∂²L_structure"` resolve to the same members."""
+    _ALIASES = {"∇L": "grad_L", "∂²L": "hess_L", "∂²L_structure": "hess_structure"}
+
+    def __init__(self, terms, traj: NamedTrajectory, dt_scaled: bool = True, device: int = 0):
+        if isinstance(terms, TrajectoryObjectiveSpec):
+            terms = terms.terms
+        elif isinstance(terms, (QuadraticRegularizer, MinimumTimeObjective)):
+            terms = [terms]
+        self.traj = traj
+        w = np.zeros(traj.dim)
+        used = np.zeros(traj.dim, dtype=bool)
+        base = np.zeros((traj.dim, traj.T))
+        any_base = False
+        D = 0.0
+        ts_names = set()
+        for term in terms:
+            if isinstance(term, QuadraticRegularizer):
+                idx = np.asarray(traj.components[term.name])
+                w[idx] += term.R
+                if term.baseline is not None:
+                    if used[idx].any():
+                        raise ValueError(f"{term.name}: a baseline cannot be combined with another regulariser on the same component")
+                    base[idx, :] = term.baseline
+                    any_base = True
+                used[idx] = True
+                if term.timestep_name is not None:
+                    ts_names.add(term.timestep_name)
+            elif isinstance(term, MinimumTimeObjective):
+                D += term.D
+                ts_names.add(term.timestep_name)
+            else:
+                raise TypeError(f"unsupported term {type(term).__name__}")
+        if len(ts_names) > 1:
+            raise ValueError(f"terms disagree on the timestep component: {sorted(ts_names)}")
+        free = isinstance(traj.timestep, str)
+        self._index = np.ascontiguousarray(np.nonzero(used)[0], dtype=np.int32)
+        self._R = np.ascontiguousarray(w[self._index])
+        self._base = np.ascontiguousarray(base[self._index, :].T) if any_base else None      # (T, n_reg): entry-fastest
+        d = _lib.qc_terms_desc()
+        d.T = traj.T
+        d.zdim = traj.dim
+        d.off_dt = traj.offset(traj.timestep) if free else -1
+        d.global_dim = traj.global_dim
+        d.dt_fixed = 0.0 if free else float(traj.timestep)
+        d.n_reg = self._index.size
+        d.weighting = _lib.QC_REG_DT_SCALED if dt_scaled else _lib.QC_REG_PLAIN
+        d.reg_index = self._index.ctypes.data_as(C.POINTER(C.c_int32))
+        d.reg_R = _lib.dptr(self._R) if self._R.size else None
+        d.reg_baseline = _lib.dptr(self._base) if self._base is not None else None
+        d.min_time_D = D
+        d.min_time_knots = traj.T - 1 if D != 0.0 else 0
+        d.device = device
+        self._desc = d
+        self.Z_len = traj.T * traj.dim + traj.global_dim
+        self._h = C.c_void_p()
+        rc = _lib.lib.qc_terms_create(C.byref(d), C.byref(self._h))
+        if rc != _lib.QC_OK:
+            raise _lib.QCollocError(rc, _lib.lib.qc_terms_last_error(None).decode())
+        nnz = C.c_int64()
+        _lib.lib.qc_terms_hess_nnz(self._h, C.byref(nnz))
+        self.hess_nnz = nnz.value
+        r = np.empty(self.hess_nnz, dtype=np.int64)
+        c = np.empty(self.hess_nnz, dtype=np.int64)
+        _lib.lib.qc_terms_hess_structure(self._h, _lib.iptr(r), _lib.iptr(c), 0)
+        self.hess_structure = (r, c)
+
+    def _eval(self, Z, grad: bool, hess: bool):
+        Z = np.ascontiguousarray(Z, dtype=np.float64)
+        if Z.size != self.Z_len:
+            raise ValueError(f"Z has length {Z.size}, expected {self.Z_len}")
+        J = C.c_double()
+        g = np.empty(self.Z_len) if grad else None
+        H = np.empty(self.hess_nnz) if hess else None
+        rc = _lib.lib.qc_terms_eval(self._h, _lib.dptr(Z), C.byref(J), _lib.dptr(g) if grad else None, _lib.dptr(H) if hess else None)
+        if rc != _lib.QC_OK:
+            raise _lib.QCollocError(rc, _lib.lib.qc_terms_last_error(self._h).decode())
+        return J.value, g, H
+
+    def L(self, Z) -> float:
+        return self._eval(Z, False, False)[0]
+
+    def grad_L(self, Z) -> np.ndarray:
+        return self._eval(Z, True, False)[1]
+
+    def hess_L(self, Z) -> np.ndarray:
+        return self._eval(Z, False, True)[2]
+
+    def L_grad_hess(self, Z):
+        return self._eval(Z, True, True)
+
+    def eval_device(self, dZ, dJ, dgrad=None, dhess=None, stream=None):
+        """Device-resident evaluation on torch CUDA tensors (float64), asynchronous on `stream`."""
+        s = stream.cuda_stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        rc = _lib.lib.qc_terms_eval_dev(self._h, dZ.data_ptr(), dJ.data_ptr(), dgrad.data_ptr() if dgrad is not None else None,
+                                        dhess.data_ptr() if dhess is not None else None, s)
+        if rc != _lib.QC_OK:
+            raise _lib.QCollocError(rc, _lib.lib.qc_terms_last_error(self._h).decode())
+
+    def __getattr__(self, name):
+        al = type(self)._ALIASES
+        if name in al:
+            return getattr(self, al[name])
+        raise AttributeError(name)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib.qc_terms_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class TimeStepsAllEqualConstraint:
+    """`TimeStepsAllEqualConstraint(timestep_name, traj)` (reference _problem_templates.jl:57-63): the T-1 linear rows
+    dt_t - dt_T = 0.  Constant Jacobian (+1, -1), no Hessian: nothing to evaluate on a device; provided so that the
+    whole constraint set of a problem template can be described on this side of the boundary."""
+
+    def __init__(self, timestep_name: str, traj: NamedTrajectory):
+        off = traj.offset(timestep_name)
+        self.dim = traj.T - 1
+        self.indices = np.arange(traj.T, dtype=np.int64) * traj.dim + off
+        rows = np.repeat(np.arange(self.dim, dtype=np.int64), 2)
+        cols = np.stack([self.indices[:-1], np.full(self.dim, self.indices[-1])], axis=1).ravel()
+        self.jac_structure = (rows, cols)
+        self.jac_values = np.tile([1.0, -1.0], self.dim)
+
+    def g(self, Z) -> np.ndarray:
+        Z = np.asarray(Z, dtype=np.float64)
+        return Z[self.indices[:-1]] - Z[self.indices[-1]]
+
+    def dg(self, Z=None) -> np.ndarray:
+        return self.jac_values

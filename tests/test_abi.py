@@ -36,15 +36,16 @@ def test_struct_layout_matches_c(qc, tmp_path):
     src = tmp_path / "sz.c"
     src.write_text(
         '#include <stdio.h>\n#include <stddef.h>\n#include "qcolloc.h"\n'
-        'int main(){printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(qc_desc), offsetof(qc_desc, G_drift), '
+        'int main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(qc_desc), offsetof(qc_desc, G_drift), '
         'offsetof(qc_desc, t_begin), offsetof(qc_desc, deriv_dim), offsetof(qc_desc, dt_fixed), '
-        'sizeof(qc_dims_t), offsetof(qc_dims_t, kernel));return 0;}\n')
+        'sizeof(qc_dims_t), offsetof(qc_dims_t, kernel), sizeof(qc_terms_desc), offsetof(qc_terms_desc, reg_baseline), '
+        'offsetof(qc_terms_desc, device));return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
     got = [int(x) for x in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
-    d, dm = qc._lib.qc_desc, qc._lib.qc_dims_t
+    d, dm, td = qc._lib.qc_desc, qc._lib.qc_dims_t, qc._lib.qc_terms_desc
     assert got == [C.sizeof(d), d.G_drift.offset, d.t_begin.offset, d.deriv_dim.offset, d.dt_fixed.offset,
-                   C.sizeof(dm), dm.kernel.offset]
+                   C.sizeof(dm), dm.kernel.offset, C.sizeof(td), td.reg_baseline.offset, td.device.offset]
 
 
 def test_iso_helpers_match_oracle(qc, oracle):
