@@ -287,11 +287,26 @@ __global__ __launch_bounds__(kThreads32, 2) void qc_mfma32_pade4_kernel(const Qc
 
 }  // namespace
 
-size_t qc_mfma32_gx_doubles(const QcParams& P) { return (size_t)(P.m + 1) * 4 * 256; }
+size_t qc_mfma32_gx_doubles(const QcParams& P) { return (size_t)2 * (P.m + 1) * 4 * 256; }
 
-// [matrix][tile = 2I+K][pair][lane][2]:  lane (g, i) reg kk = X[16I + i][16K + 4kk + g]  (X column-major 32 x 32)
+// A-layout images [matrix][tile = 2I+K][pair][lane][2]:  lane (g, i) reg kk = X[16I + i][16K + 4kk + g]  (X column-major
+// 32 x 32), followed by the B-layout images [matrix][tile = 2K+J][pair][lane][2]: lane (g, j) reg kk = X[16K + 4kk + g][16J + j]
+// (= A-layout images of the transposes; used by the Hessian kernel).
 void qc_mfma32_pack_G(const QcParams& P, const double* G, double* Gx) {
     const int n = 32, M = P.m + 1;
+    double* GxB = Gx + (size_t)M * 1024;
+    for (int mat = 0; mat < M; ++mat) {
+        const double* A = G + (size_t)mat * n * n;
+        for (int tile = 0; tile < 4; ++tile) {
+            const int K = tile >> 1, J = tile & 1;
+            for (int pr = 0; pr < 2; ++pr)
+                for (int l = 0; l < 64; ++l)
+                    for (int e = 0; e < 2; ++e) {
+                        const int g = l >> 4, j = l & 15, kk = 2 * pr + e;
+                        GxB[(((size_t)mat * 4 + tile) * 2 + pr) * 128 + l * 2 + e] = A[(size_t)(16 * J + j) * n + 16 * K + 4 * kk + g];
+                    }
+        }
+    }
     for (int mat = 0; mat < M; ++mat) {
         const double* A = G + (size_t)mat * n * n;
         for (int tile = 0; tile < 4; ++tile) {

@@ -219,10 +219,12 @@ __global__ __launch_bounds__(64) void qc_mfma16_pade4_hess_kernel(const QcParams
 }  // namespace
 
 bool qc_mfma_hess_supported(const QcParams& P) {
+    if (qc_mfma32_hess_supported(P)) return true;
     return P.integrator == QC_PADE && P.p == 2 && P.n == 16 && P.nc == P.N && P.m <= kHMmax;
 }
 
 hipError_t qc_launch_mfma_hess(const QcParams& P, const double* dZ, const double* dMu, double* dH, hipStream_t st) {
+    if (P.n == 32) return qc_launch_mfma32_hess(P, dZ, dMu, dH, st);
     const int grid = P.n_int < 4096 ? P.n_int : 4096;
     if (P.m <= 2) hipLaunchKernelGGL(qc_mfma16_pade4_hess_kernel<2>, dim3(grid), dim3(64), 0, st, P, dZ, dMu, dH);
     else if (P.m <= 4) hipLaunchKernelGGL(qc_mfma16_pade4_hess_kernel<4>, dim3(grid), dim3(64), 0, st, P, dZ, dMu, dH);
