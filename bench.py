@@ -261,7 +261,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f64",
-            "data": "synthetic (seed 20250218: Toffoli geodesic + N(0,1e-2) noise, a~U(-1,1), da/dda~N(0,0.1^2), dt=0.2)",
+            "data": f"synthetic (seed 20250218: I -> {spec.gate} geodesic + N(0,1e-2) noise, a~U(-1,1), da/dda~N(0,0.1^2), dt=0.2)",
             "config": {"workload": f"{spec.description}; T={T_total} knots ({t_per_gpu}/GPU), Pade order 4, free dt",
                        "T": T_total, "N": inp.system.levels, "n_drives": inp.system.n_drives,
                        "kernel": dyn.kernel, "parallelism": f"knot-shard x{world}", "output_ring_buffers": nbuf},

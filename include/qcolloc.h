@@ -197,6 +197,16 @@ int qc_fidelity_eval(qc_fidelity* h, const double* U_iso, double* fidelity, doub
 /* device buffers, asynchronous on `stream`: dval2 = {F, |1-F|}; dgrad / dhess may be NULL */
 int qc_fidelity_eval_dev(qc_fidelity* h, const double* dU, double* dval2, double* dgrad, double* dhess, void* stream);
 
+/* ---- rollouts (SURVEY 8f "next" row 4) -------------------------------------------------------------- */
+/* x_{t+1} = exp(dt_t G(a_t)) x_t for t = 0 .. T-2 from x_0 = init (2N x cols, column-major), controls and timesteps read
+ * from Z at the handle's offsets; out receives the (2N cols) x T state matrix, one column per knot: `unitary_rollout`,
+ * `rollout`, `open_rollout` (reference call sites trajectory_initialization.jl:426,493,547; `unitary_rollout_fidelity`,
+ * unitary_smooth_pulse_problem.jl:218, is this followed by qc_fidelity_eval on the last column).  The propagator is the
+ * matrix exponential whatever integrator the handle was created with (the reference's default `expv`); the whole
+ * trajectory is covered whatever the handle's shard.  2N <= 64. */
+int qc_rollout(qc_handle* h, const double* Z, const double* init, double* out);
+int qc_rollout_dev(qc_handle* h, const double* dZ, const double* dinit, double* dout, void* stream);
+
 /* ---- trajectory cost terms (SURVEY 8f "next" row 3) ----------------------------------------------- */
 /* J(Z) = sum_t 1/2 sum_k R_k (sc_t (v_tk - b_tk))^2 + D sum_{t < min_time_knots} dt_t,   sc_t = dt_t or 1:
  * the `QuadraticRegularizer(name, traj, R; baseline, timestep_name)` terms on a / da / dda (reference call sites

@@ -620,3 +620,21 @@ def terms_hess(tm: Terms, Z: np.ndarray) -> np.ndarray:
             out.extend(2.0 * dt * tm.reg_R * dv)
             out.append(float(np.sum(tm.reg_R * dv * dv)))
     return np.asarray(out, dtype=np.float64)
+
+
+# --------------------------------------------------------------------------------------------
+#  Rollout: x_{t+1} = exp(dt_t G(a_t)) x_t  (`unitary_rollout` / `rollout` / `open_rollout`,
+#  reference call sites trajectory_initialization.jl:426,493,547).  Returns the (n nc) x T state matrix.
+# --------------------------------------------------------------------------------------------
+def rollout(prob: Problem, Z: np.ndarray, init: np.ndarray) -> np.ndarray:
+    n, nc = prob.n, prob.nc
+    X = np.asarray(init, dtype=np.float64).reshape(n, nc, order="F")
+    out = np.empty((n * nc, prob.T))
+    out[:, 0] = _vec(X)
+    for t in range(prob.T - 1):
+        z = Z[t * prob.zdim:(t + 1) * prob.zdim]
+        a = z[prob.off_a:prob.off_a + prob.m]
+        h = z[prob.off_dt] if prob.free_time else prob.dt_fixed
+        X = expm_taylor(h * _G_of(prob, a)) @ X
+        out[:, t + 1] = _vec(X)
+    return out

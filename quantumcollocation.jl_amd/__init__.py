@@ -8,15 +8,17 @@ from . import _lib
 from ._lib import QCollocError
 from .dynamics import ComposedQuantumDynamics, QuantumDynamics, desc_dims, desc_structures, make_desc, split_groups
 from .gates import GATES, PAULIS, operator_from_string
-from .integrators import (DerivativeIntegrator, QuantumStateExponentialIntegrator, QuantumStatePadeIntegrator,
+from .integrators import (DensityOperatorExponentialIntegrator, DerivativeIntegrator, QuantumStateExponentialIntegrator, QuantumStatePadeIntegrator,
                           UnitaryExponentialIntegrator, UnitaryPadeIntegrator)
-from .isomorphisms import iso_generator, iso_vec_to_operator, operator_to_iso_vec, pade_coefficients
+from .isomorphisms import (density_to_iso_vec, iso_generator, iso_operator, iso_vec_to_density, iso_vec_to_operator,
+                           operator_to_iso_vec, pade_coefficients)
 from .named_trajectory import NamedTrajectory
 from .objectives import (FinalUnitaryFidelityConstraint, MinimumTimeObjective, QuadraticRegularizer, TimeStepsAllEqualConstraint,
                          TrajectoryObjective, UnitaryInfidelityObjective, iso_vec_unitary_fidelity)
-from .problems import (CONFIGS, config_inputs, multi_qubit_system, quantum_state_smooth_pulse_inputs,
+from .problems import (CONFIGS, config_inputs, density_operator_smooth_pulse_inputs, multi_qubit_system, quantum_state_smooth_pulse_inputs,
                        unitary_sampling_inputs, unitary_smooth_pulse_inputs)
-from .quantum_systems import QuantumSystem
+from .quantum_systems import OpenQuantumSystem, QuantumSystem
+from .rollouts import open_rollout, rollout, unitary_rollout, unitary_rollout_fidelity
 from .trajectory_initialization import initialize_trajectory, unitary_geodesic
 
 __all__ = [
@@ -26,5 +28,6 @@ __all__ = [
     "iso_generator", "pade_coefficients", "GATES", "PAULIS", "operator_from_string", "config_inputs",
     "unitary_smooth_pulse_inputs", "multi_qubit_system", "CONFIGS", "initialize_trajectory",
     "unitary_geodesic", "iso_vec_unitary_fidelity", "UnitaryInfidelityObjective", "FinalUnitaryFidelityConstraint", "QuadraticRegularizer", "MinimumTimeObjective", "TrajectoryObjective", "TimeStepsAllEqualConstraint",
-    "make_desc", "desc_dims", "desc_structures", "QCollocError",
+    "OpenQuantumSystem", "DensityOperatorExponentialIntegrator", "density_operator_smooth_pulse_inputs",
+    "density_to_iso_vec", "iso_vec_to_density", "iso_operator", "unitary_rollout", "rollout", "open_rollout", "unitary_rollout_fidelity", "make_desc", "desc_dims", "desc_structures", "QCollocError",
 ]

@@ -139,6 +139,8 @@ SYMBOLS = {
     "qc_fidelity_last_error": (C.c_char_p, [_H]),
     "qc_fidelity_eval": (C.c_int, [_H, _c_double_p, _c_double_p, _c_double_p, _c_double_p, _c_double_p]),
     "qc_fidelity_eval_dev": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "qc_rollout": (C.c_int, [_H, _c_double_p, _c_double_p, _c_double_p]),
+    "qc_rollout_dev": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "qc_terms_desc_hess_nnz": (C.c_int, [_TDESC_P, _c_int64_p]),
     "qc_terms_desc_hess_structure": (C.c_int, [_TDESC_P, _c_int64_p, _c_int64_p, C.c_int]),
     "qc_terms_create": (C.c_int, [_TDESC_P, C.POINTER(_H)]),

@@ -388,7 +388,7 @@ extern "C" void qc_destroy(qc_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    double* bufs[] = {h->dG, h->dGx, h->dZ, h->dF, h->dJ, h->dMu, h->dH, (double*)h->dStamps};
+    double* bufs[] = {h->dG, h->dGx, h->dZ, h->dF, h->dJ, h->dMu, h->dH, (double*)h->dStamps, h->dRE, h->dRQ, h->dRS, h->dRinit, h->dRout};
     for (double* b : bufs) if (b) (void)hipFree(b);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -535,6 +535,43 @@ extern "C" int qc_eval_hess(qc_handle* h, const double* Z, const double* mu, dou
     }
     if ((rc = qc_eval_hess_dev(h, h->dZ, h->dMu, h->dH, h->stream))) return rc;
     if (h->dims.hess_nnz) QC_HIP(h, hipMemcpyAsync(hvals, h->dH, (size_t)h->dims.hess_nnz * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    QC_HIP(h, hipStreamSynchronize(h->stream));
+    return QC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+//  Rollouts
+// ------------------------------------------------------------------------------------------------
+extern "C" int qc_rollout_dev(qc_handle* h, const double* dZ, const double* dinit, double* dout, void* stream) {
+    if (!h) return fail(nullptr, QC_ERR_INVALID, "qc_rollout_dev: NULL handle");
+    if (!dZ || !dinit || !dout) return fail(&h->err, QC_ERR_INVALID, "qc_rollout_dev: NULL buffer");
+    if (!qc_rollout_supported(h->prm)) return fail(&h->err, QC_ERR_UNSUPPORTED, "qc_rollout: state dimension 2N > 64");
+    QC_HIP(h, hipSetDevice(h->device));
+    size_t nE, nQ, nS;
+    int chunk, n_chunks;
+    qc_rollout_scratch(h->prm, h->desc.T, &nE, &nQ, &nS, &chunk, &n_chunks);
+    int rc;
+    if ((rc = ensure(h, &h->dRE, nE))) return rc;
+    if ((rc = ensure(h, &h->dRQ, nQ))) return rc;
+    if ((rc = ensure(h, &h->dRS, nS))) return rc;
+    hipError_t e = qc_launch_rollout(h->prm, h->desc.T, dZ, dinit, dout, h->dRE, h->dRQ, h->dRS, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(&h->err, QC_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    return QC_OK;
+}
+
+extern "C" int qc_rollout(qc_handle* h, const double* Z, const double* init, double* out) {
+    if (!h) return fail(nullptr, QC_ERR_INVALID, "qc_rollout: NULL handle");
+    if (!Z || !init || !out) return fail(&h->err, QC_ERR_INVALID, "qc_rollout: NULL buffer");
+    QC_HIP(h, hipSetDevice(h->device));
+    const size_t ns = (size_t)h->prm.n * h->prm.nc, T = (size_t)h->desc.T;
+    int rc;
+    if ((rc = ensure(h, &h->dZ, (size_t)h->dims.Z_len))) return rc;
+    if ((rc = ensure(h, &h->dRinit, ns))) return rc;
+    if ((rc = ensure(h, &h->dRout, ns * T))) return rc;
+    QC_HIP(h, hipMemcpyAsync(h->dZ, Z, (size_t)h->dims.Z_len * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    QC_HIP(h, hipMemcpyAsync(h->dRinit, init, ns * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if ((rc = qc_rollout_dev(h, h->dZ, h->dRinit, h->dRout, h->stream))) return rc;
+    QC_HIP(h, hipMemcpyAsync(out, h->dRout, ns * T * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     QC_HIP(h, hipStreamSynchronize(h->stream));
     return QC_OK;
 }

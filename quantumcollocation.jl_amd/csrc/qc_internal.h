@@ -56,6 +56,7 @@ struct qc_handle {
     // staging for the host-pointer entry points
     double *dZ = nullptr, *dF = nullptr, *dJ = nullptr, *dMu = nullptr, *dH = nullptr;
     unsigned long long* dStamps = nullptr;
+    double *dRE = nullptr, *dRQ = nullptr, *dRS = nullptr, *dRinit = nullptr, *dRout = nullptr;   // rollout scratch / staging
     hipStream_t stream = nullptr;
     std::string err;
 };
@@ -82,6 +83,11 @@ hipError_t qc_launch_mfma32_F_jac(const QcParams& P, const double* dZ, double* d
 bool qc_mfma32_hess_supported(const QcParams& P);
 hipError_t qc_launch_mfma32_hess(const QcParams& P, const double* dZ, const double* dMu, double* dH, hipStream_t st);
 hipError_t qc_launch_mfma_hess(const QcParams& P, const double* dZ, const double* dMu, double* dH, hipStream_t st);
+
+bool qc_rollout_supported(const QcParams& P);
+void qc_rollout_scratch(const QcParams& P, long long T, size_t* nE, size_t* nQ, size_t* nS, int* chunk, int* n_chunks);
+hipError_t qc_launch_rollout(const QcParams& P, long long T, const double* dZ, const double* dinit, double* dout, double* dE, double* dQ,
+                             double* dS, hipStream_t st);
 
 // Diagnostic time stamps (DIAG instantiations only; handle created with QC_STAMPS=1; never in a timed run).
 // QC_STAMP records s_memrealtime (100 MHz) into a per-wave register array; QC_STAMP_FLUSH writes the slots

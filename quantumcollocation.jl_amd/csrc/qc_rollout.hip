@@ -1,0 +1,226 @@
+// Rollouts: x_{t+1} = exp(dt_t G(a_t)) x_t for every knot of a trajectory, from a given x_0
+// (`unitary_rollout`, `rollout`, `open_rollout`; reference call sites trajectory_initialization.jl:426,493,547 and
+// `unitary_rollout_fidelity`, unitary_smooth_pulse_problem.jl:218).  Unlike the constraint path this is a sequential
+// recurrence; it is evaluated as a three-level scan of matrix products:
+//   1. propagators   one workgroup per interval: E_t = exp(dt_t G(a_t)) by a scaled Taylor polynomial (degree 12 at
+//                    ||Y||_1 <= 1/4) and repeated squaring, all in LDS  ->  scratch, (T-1) n^2 doubles
+//   2. chunk totals  one workgroup per chunk of ~sqrt(T) intervals: Q_c = E_last ... E_first
+//   3. chunk starts  one workgroup: x at the first knot of every chunk, S_{c+1} = Q_c S_c
+//   4. states        one workgroup per chunk: x_{t+1} = E_t x_t from S_c, written to the output
+// so the dependent chain is ~3 sqrt(T) small products instead of T.  FP64 VALU/LDS throughout (n = 2N <= 64); this is a
+// few MFLOP per trajectory and runs once per solve or callback, not per Ipopt iteration.
+#include <string>
+
+#include "qc_internal.h"
+
+namespace {
+
+constexpr int kRT = 256;
+constexpr int kRDeg = 12;
+
+struct RollParams {
+    int n, nc, m, zdim, off_a, off_dt, n_int, chunk, n_chunks;
+    double dt_fixed;
+    const double* G;
+};
+
+// C (n x p) = A (n x n) * B (n x p), all column-major in LDS; C must not alias A or B
+__device__ inline void mm_lds(double* __restrict__ C, const double* __restrict__ A, const double* __restrict__ B, int n, int p, int tid) {
+    for (int idx = tid; idx < n * p; idx += kRT) {
+        const int r = idx % n, c = idx / n;
+        double acc = 0.0;
+        for (int q = 0; q < n; ++q) acc = fma(A[r + n * q], B[q + n * c], acc);
+        C[idx] = acc;
+    }
+}
+
+__global__ __launch_bounds__(kRT) void qc_rollout_prop_kernel(RollParams R, const double* __restrict__ Z, double* __restrict__ E) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    __shared__ double red[kRT / 64];
+    const int tid = threadIdx.x, n = R.n, n2 = n * n;
+    double* Y = sm;
+    double* A0 = sm + n2;
+    double* A1 = sm + 2 * n2;
+    double* Em = sm + 3 * n2;
+    const long long t = blockIdx.x;
+    const double* z = Z + t * (long long)R.zdim;
+    const double h = R.off_dt >= 0 ? z[R.off_dt] : R.dt_fixed;
+    for (int idx = tid; idx < n2; idx += kRT) {
+        double g = R.G[idx];
+        for (int k = 0; k < R.m; ++k) g = fma(z[R.off_a + k], R.G[(size_t)(k + 1) * n2 + idx], g);
+        Y[idx] = h * g;
+    }
+    __syncthreads();
+    // ||h G||_1 = largest column sum (thread c sums column c)
+    double cs = 0.0;
+    if (tid < n) for (int r = 0; r < n; ++r) cs += fabs(Y[r + n * tid]);
+    bool bad = !(cs == cs) || cs > 1e300;
+    for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_xor(cs, off, 64);
+        cs = fmax(cs, o);
+        bad = bad || __shfl_xor((int)bad, off, 64);
+    }
+    if ((tid & 63) == 0) red[tid >> 6] = bad ? -1.0 : cs;
+    __syncthreads();
+    double nrm = 0.0;
+    bool anybad = false;
+    for (int w = 0; w < kRT / 64; ++w) { if (red[w] < 0.0) anybad = true; nrm = fmax(nrm, red[w]); }
+    int sq = 0;
+    if (!anybad && nrm > 0.25) {
+        int e;
+        (void)frexp(nrm / 0.25, &e);
+        sq = e;
+        if (ldexp(0.25, e - 1) >= nrm) sq = e - 1;
+        sq = sq < 0 ? 0 : (sq > 60 ? 60 : sq);
+    }
+    const double sc = ldexp(1.0, -sq);
+    for (int idx = tid; idx < n2; idx += kRT) {
+        Y[idx] *= sc;
+        const double id = (idx % n == idx / n) ? 1.0 : 0.0;
+        A0[idx] = id;
+        Em[idx] = id;
+    }
+    __syncthreads();
+    for (int k = 1; k <= kRDeg; ++k) {
+        const double* Ap = (k & 1) ? A0 : A1;
+        double* An = (k & 1) ? A1 : A0;
+        const double inv = 1.0 / (double)k;
+        for (int idx = tid; idx < n2; idx += kRT) {
+            const int r = idx % n, c = idx / n;
+            double acc = 0.0;
+            for (int q = 0; q < n; ++q) acc = fma(Ap[r + n * q], Y[q + n * c], acc);
+            acc *= inv;
+            An[idx] = acc;
+            Em[idx] += acc;
+        }
+        __syncthreads();
+    }
+    for (int q = 0; q < sq; ++q) {
+        mm_lds(A0, Em, Em, n, n, tid);
+        __syncthreads();
+        for (int idx = tid; idx < n2; idx += kRT) Em[idx] = A0[idx];
+        __syncthreads();
+    }
+    double* Eo = E + (size_t)t * n2;
+    for (int idx = tid; idx < n2; idx += kRT) Eo[idx] = Em[idx];
+}
+
+// Q_c = E_{last} ... E_{first} of chunk c
+__global__ __launch_bounds__(kRT) void qc_rollout_total_kernel(RollParams R, const double* __restrict__ E, double* __restrict__ Q) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int tid = threadIdx.x, n = R.n, n2 = n * n;
+    double* Qa = sm;
+    double* Qb = sm + n2;
+    double* Et = sm + 2 * n2;
+    const int c = blockIdx.x;
+    const int t0 = c * R.chunk, t1 = min(R.n_int, t0 + R.chunk);
+    for (int idx = tid; idx < n2; idx += kRT) Qa[idx] = E[(size_t)t0 * n2 + idx];
+    __syncthreads();
+    double* cur = Qa;
+    double* nxt = Qb;
+    for (int t = t0 + 1; t < t1; ++t) {
+        for (int idx = tid; idx < n2; idx += kRT) Et[idx] = E[(size_t)t * n2 + idx];
+        __syncthreads();
+        mm_lds(nxt, Et, cur, n, n, tid);
+        __syncthreads();
+        double* tmp = cur; cur = nxt; nxt = tmp;
+    }
+    for (int idx = tid; idx < n2; idx += kRT) Q[(size_t)c * n2 + idx] = cur[idx];
+}
+
+// S_0 = init, S_{c+1} = Q_c S_c
+__global__ __launch_bounds__(kRT) void qc_rollout_starts_kernel(RollParams R, const double* __restrict__ Q, const double* __restrict__ init,
+                                                                double* __restrict__ S) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int tid = threadIdx.x, n = R.n, n2 = n * n, ns = n * R.nc;
+    double* Xa = sm;
+    double* Xb = sm + ns;
+    double* Qt = sm + 2 * ns;
+    for (int idx = tid; idx < ns; idx += kRT) { Xa[idx] = init[idx]; S[idx] = init[idx]; }
+    __syncthreads();
+    double* cur = Xa;
+    double* nxt = Xb;
+    for (int c = 0; c + 1 < R.n_chunks; ++c) {
+        for (int idx = tid; idx < n2; idx += kRT) Qt[idx] = Q[(size_t)c * n2 + idx];
+        __syncthreads();
+        mm_lds(nxt, Qt, cur, n, R.nc, tid);
+        __syncthreads();
+        for (int idx = tid; idx < ns; idx += kRT) S[(size_t)(c + 1) * ns + idx] = nxt[idx];
+        double* tmp = cur; cur = nxt; nxt = tmp;
+    }
+}
+
+// x at every knot of chunk c from its start state; out is (n nc) x T, one column per knot
+__global__ __launch_bounds__(kRT) void qc_rollout_states_kernel(RollParams R, const double* __restrict__ E, const double* __restrict__ S,
+                                                                double* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int tid = threadIdx.x, n = R.n, n2 = n * n, ns = n * R.nc;
+    double* Xa = sm;
+    double* Xb = sm + ns;
+    double* Et = sm + 2 * ns;
+    const int c = blockIdx.x;
+    const int t0 = c * R.chunk, t1 = min(R.n_int, t0 + R.chunk);
+    for (int idx = tid; idx < ns; idx += kRT) {
+        const double v = S[(size_t)c * ns + idx];
+        Xa[idx] = v;
+        out[(size_t)t0 * ns + idx] = v;
+    }
+    __syncthreads();
+    double* cur = Xa;
+    double* nxt = Xb;
+    for (int t = t0; t < t1; ++t) {
+        for (int idx = tid; idx < n2; idx += kRT) Et[idx] = E[(size_t)t * n2 + idx];
+        __syncthreads();
+        mm_lds(nxt, Et, cur, n, R.nc, tid);
+        __syncthreads();
+        for (int idx = tid; idx < ns; idx += kRT) out[(size_t)(t + 1) * ns + idx] = nxt[idx];
+        double* tmp = cur; cur = nxt; nxt = tmp;
+    }
+}
+
+}  // namespace
+
+bool qc_rollout_supported(const QcParams& P) { return P.n <= 64; }
+
+void qc_rollout_scratch(const QcParams& P, long long T, size_t* nE, size_t* nQ, size_t* nS, int* chunk, int* n_chunks) {
+    const long long n_int = T - 1;
+    int ch = 1;
+    while ((long long)ch * ch < n_int) ++ch;
+    const int nch = (int)((n_int + ch - 1) / ch);
+    *chunk = ch;
+    *n_chunks = nch;
+    *nE = (size_t)n_int * P.n * P.n;
+    *nQ = (size_t)nch * P.n * P.n;
+    *nS = (size_t)nch * P.n * P.nc;
+}
+
+hipError_t qc_launch_rollout(const QcParams& P, long long T, const double* dZ, const double* dinit, double* dout, double* dE, double* dQ,
+                             double* dS, hipStream_t st) {
+    RollParams R;
+    R.n = P.n; R.nc = P.nc; R.m = P.m; R.zdim = P.zdim; R.off_a = P.off_a; R.off_dt = P.off_dt; R.dt_fixed = P.dt_fixed; R.G = P.G;
+    R.n_int = (int)(T - 1);
+    size_t nE, nQ, nS;
+    qc_rollout_scratch(P, T, &nE, &nQ, &nS, &R.chunk, &R.n_chunks);
+    const size_t n2 = (size_t)P.n * P.n, ns = (size_t)P.n * P.nc;
+    const size_t lds_prop = 4 * n2 * 8, lds_tot = 3 * n2 * 8, lds_st = (2 * ns + n2) * 8;
+    hipError_t e;
+    if (lds_prop > 64 * 1024) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qc_rollout_prop_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_prop);
+        if (e != hipSuccess) return e;
+    }
+    if (lds_tot > 64 * 1024) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qc_rollout_total_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tot);
+        if (e != hipSuccess) return e;
+    }
+    if (lds_st > 64 * 1024) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qc_rollout_starts_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_st);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qc_rollout_states_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_st);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(qc_rollout_prop_kernel, dim3(R.n_int), dim3(kRT), lds_prop, st, R, dZ, dE);
+    if (R.n_chunks > 1) hipLaunchKernelGGL(qc_rollout_total_kernel, dim3(R.n_chunks - 1), dim3(kRT), lds_tot, st, R, dE, dQ);
+    hipLaunchKernelGGL(qc_rollout_starts_kernel, dim3(1), dim3(kRT), lds_st, st, R, dQ, dinit, dS);
+    hipLaunchKernelGGL(qc_rollout_states_kernel, dim3(R.n_chunks), dim3(kRT), lds_st, st, R, dE, dS, dout);
+    return hipGetLastError();
+}

@@ -18,7 +18,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .integrators import (DerivativeIntegrator, QuantumStateExponentialIntegrator, QuantumStatePadeIntegrator,
+from .integrators import (DensityOperatorExponentialIntegrator, DerivativeIntegrator, QuantumStateExponentialIntegrator, QuantumStatePadeIntegrator,
                           UnitaryExponentialIntegrator, UnitaryPadeIntegrator, _KetIntegrator, _UnitaryIntegrator)
 from .named_trajectory import NamedTrajectory
 
@@ -33,8 +33,8 @@ def split_groups(integrators: Sequence):
     groups, cur = [], []
     i = 0
     n = len(integrators)
-    while i < n and isinstance(integrators[i], (_UnitaryIntegrator, _KetIntegrator)):
-        if isinstance(integrators[i], _UnitaryIntegrator):
+    while i < n and isinstance(integrators[i], (_UnitaryIntegrator, _KetIntegrator, DensityOperatorExponentialIntegrator)):
+        if isinstance(integrators[i], (_UnitaryIntegrator, DensityOperatorExponentialIntegrator)):
             groups.append([integrators[i]])
             i += 1
         else:
@@ -57,7 +57,7 @@ def split_groups(integrators: Sequence):
 def make_desc(integrators: Sequence, traj: NamedTrajectory, *, device: int = 0, kernel: str = "auto",
               t_range: Optional[Tuple[int, int]] = None, placement: Optional[dict] = None):
     """Translate (integrators, traj) into a qc_desc.  Returns (desc, keepalive)."""
-    if not integrators or not isinstance(integrators[0], (_UnitaryIntegrator, _KetIntegrator)):
+    if not integrators or not isinstance(integrators[0], (_UnitaryIntegrator, _KetIntegrator, DensityOperatorExponentialIntegrator)):
         raise NotImplementedError("the first integrator must be the unitary (or the first ket) integrator "
                                   "(row order of reference unitary_smooth_pulse_problem.jl:175-179)")
     P = integrators[0]
@@ -81,7 +81,7 @@ def make_desc(integrators: Sequence, traj: NamedTrajectory, *, device: int = 0, 
         raise ValueError("too many derivative integrators")
     sys = P.system
     d = _lib.qc_desc()
-    d.N = sys.levels
+    d.N = sys.state_levels
     d.m = sys.n_drives
     d.T = traj.T
     d.zdim = traj.dim
@@ -94,11 +94,11 @@ def make_desc(integrators: Sequence, traj: NamedTrajectory, *, device: int = 0, 
     else:
         d.off_dt = -1
         d.dt_fixed = float(traj.timestep)
-    d.state_cols = n_state if isinstance(P, _KetIntegrator) else 0
+    d.state_cols = n_state if isinstance(P, (_KetIntegrator, DensityOperatorExponentialIntegrator)) else 0
     if isinstance(P, (UnitaryPadeIntegrator, QuantumStatePadeIntegrator)):
         d.integrator = _lib.QC_PADE
         d.pade_order = P.order
-    elif isinstance(P, (UnitaryExponentialIntegrator, QuantumStateExponentialIntegrator)):
+    elif isinstance(P, (UnitaryExponentialIntegrator, QuantumStateExponentialIntegrator, DensityOperatorExponentialIntegrator)):
         d.integrator = _lib.QC_EXPONENTIAL
         d.pade_order = 0
     else:
@@ -108,7 +108,7 @@ def make_desc(integrators: Sequence, traj: NamedTrajectory, *, device: int = 0, 
         d.deriv_x_off[i] = traj.offset(D.x)
         d.deriv_dx_off[i] = traj.offset(D.dx)
         d.deriv_dim[i] = D.dim
-    n = 2 * sys.levels
+    n = 2 * sys.state_levels
     G0 = np.asfortranarray(sys.G_drift, dtype=np.float64)
     Gd = np.empty((max(1, sys.n_drives), n * n))
     for j, Gj in enumerate(sys.G_drives):
@@ -218,6 +218,20 @@ class QuantumDynamics:
         jr, jc, hr, hc = self._structure(one_based)
         r, c = (jr, jc) if which in ("dF", "∂F") else (hr, hc)
         return list(zip(r.tolist(), c.tolist()))
+
+    def rollout(self, Z: np.ndarray, init: np.ndarray) -> np.ndarray:
+        """States x_{t+1} = exp(dt_t G(a_t)) x_t for every knot, controls and timesteps taken from Z, x_0 = init:
+        the (2N cols) x T matrix of `unitary_rollout` / `rollout` / `open_rollout` (trajectory_initialization.jl:426)."""
+        Z = np.ascontiguousarray(Z, dtype=np.float64)
+        init = np.ascontiguousarray(init, dtype=np.float64).ravel()
+        if Z.size != self.dims.Z_len:
+            raise ValueError(f"Z has length {Z.size}, expected {self.dims.Z_len}")
+        s = 2 * self._desc.N * (self._desc.state_cols or self._desc.N)
+        if init.size != s:
+            raise ValueError(f"initial state has length {init.size}, expected {s}")
+        out = np.empty((self._desc.T, s))
+        _lib.check(_lib.lib.qc_rollout(self._h, _lib.dptr(Z), _lib.dptr(init), _lib.dptr(out)), self._h)
+        return np.ascontiguousarray(out.T)
 
     def F_dF_into(self, Z: np.ndarray, F: np.ndarray, J: np.ndarray) -> None:
         """qc_eval_F_jac into caller-owned arrays (no allocation): the call shape of an MOI callback."""

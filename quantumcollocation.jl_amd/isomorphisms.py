@@ -46,3 +46,26 @@ def pade_coefficients(order: int) -> np.ndarray:
     out = np.empty(order // 2 + 1)
     _lib.check(_lib.lib.qc_pade_coefficients(order, _lib.dptr(out)))
     return out
+
+
+def iso_operator(A: np.ndarray) -> np.ndarray:
+    """Real isomorphism [[Re A, -Im A], [Im A, Re A]] of a complex matrix acting on [Re v; Im v]
+    (`iso_generator(H)` is `iso_operator(-1j * H)`)."""
+    A = np.asarray(A, dtype=complex)
+    return np.asfortranarray(np.block([[A.real, -A.imag], [A.imag, A.real]]))
+
+
+def density_to_iso_vec(rho: np.ndarray) -> np.ndarray:
+    """[vec(Re rho); vec(Im rho)], column-major vec: the state of `DensityOperatorExponentialIntegrator`
+    (reference density_operator_smooth_pulse_problem.jl:38-51, component `ρ⃗̃`); length 2 N^2."""
+    rho = np.asarray(rho, dtype=complex)
+    v = rho.reshape(-1, order="F")
+    return np.concatenate([v.real, v.imag])
+
+
+def iso_vec_to_density(v: np.ndarray) -> np.ndarray:
+    v = np.asarray(v, dtype=np.float64)
+    N = int(round((v.size / 2) ** 0.5))
+    if 2 * N * N != v.size:
+        raise ValueError("iso-vec length must be 2 N^2")
+    return (v[:N * N] + 1j * v[N * N:]).reshape(N, N, order="F")

@@ -16,7 +16,7 @@ from typing import List, Optional
 import numpy as np
 
 from .gates import GATES, operator_from_string
-from .integrators import (DerivativeIntegrator, QuantumStateExponentialIntegrator, QuantumStatePadeIntegrator,
+from .integrators import (DensityOperatorExponentialIntegrator, DerivativeIntegrator, QuantumStateExponentialIntegrator, QuantumStatePadeIntegrator,
                           UnitaryExponentialIntegrator, UnitaryPadeIntegrator)
 from .named_trajectory import NamedTrajectory
 from .quantum_systems import QuantumSystem
@@ -125,6 +125,34 @@ def quantum_state_smooth_pulse_inputs(system: QuantumSystem, psi_inits, psi_goal
     kw = {"order": pade_order} if integrator == "pade" else {}
     integrators = [cls(nm, "a", system, traj, **kw) for nm in names]
     integrators += [DerivativeIntegrator("a", "da", traj), DerivativeIntegrator("da", "dda", traj)]
+    return HotPathInputs(system, traj, integrators)
+
+
+def density_operator_smooth_pulse_inputs(system, rho_init: np.ndarray, psi_goal: np.ndarray, T: int, dt: float = 0.2, *,
+                                         free_time: bool = True, seed: int = SEED) -> HotPathInputs:
+    """Inputs of `DensityOperatorSmoothPulseProblem` (reference density_operator_smooth_pulse_problem.jl:3-124): state
+    component `ρ⃗̃` = iso-vec of vec(rho), the density-operator exponential integrator (:104-106) followed by the two
+    derivative integrators (:108-112).  The guess interpolates rho_init -> |psi_goal><psi_goal| linearly plus noise."""
+    from .isomorphisms import density_to_iso_vec
+    from .named_trajectory import NamedTrajectory
+    rng = np.random.default_rng(seed)
+    m, N = system.n_drives, system.levels
+    psi_goal = np.asarray(psi_goal, dtype=complex)
+    r0 = density_to_iso_vec(rho_init)[:, None]
+    r1 = density_to_iso_vec(np.outer(psi_goal, psi_goal.conj()))[:, None]
+    lam = np.linspace(0.0, 1.0, T)[None, :]
+    comps = {"ρ⃗̃": r0 * (1 - lam) + r1 * lam + 1e-2 * rng.standard_normal((2 * N * N, T))}
+    a = np.zeros((m, T))
+    a[:, 1:T - 1] = rng.uniform(-1, 1, size=(m, T - 2))
+    comps["a"] = a
+    comps["da"] = 0.1 * rng.standard_normal((m, T))
+    comps["dda"] = 0.1 * rng.standard_normal((m, T))
+    if free_time:
+        comps["Δt"] = np.full((1, T), dt)
+    traj = NamedTrajectory(comps, controls=("dda", "Δt") if free_time else ("dda",), timestep="Δt" if free_time else dt,
+                           goal={"ρ⃗̃": r1[:, 0]})
+    integrators = [DensityOperatorExponentialIntegrator("ρ⃗̃", "a", system, traj),
+                   DerivativeIntegrator("a", "da", traj), DerivativeIntegrator("da", "dda", traj)]
     return HotPathInputs(system, traj, integrators)
 
 

@@ -16,12 +16,13 @@ def problem_from_inputs(inp, T=None):
     derivs = [o.DerivSpec(traj.offset(D.x), traj.offset(D.dx), D.dim) for D in inp.integrators if isinstance(D, qc.DerivativeIntegrator)]
     free = isinstance(traj.timestep, str)
     is_pade = isinstance(P, (qc.UnitaryPadeIntegrator, qc.QuantumStatePadeIntegrator))
-    kets = [I for I in inp.integrators if isinstance(I, (qc.QuantumStatePadeIntegrator, qc.QuantumStateExponentialIntegrator))]
+    kets = [I for I in inp.integrators if isinstance(I, (qc.QuantumStatePadeIntegrator, qc.QuantumStateExponentialIntegrator,
+                                                         qc.DensityOperatorExponentialIntegrator))]
     return o.Problem(
-        N=sys_.levels, m=sys_.n_drives, T=traj.T if T is None else T, zdim=traj.dim,
+        N=sys_.state_levels, m=sys_.n_drives, T=traj.T if T is None else T, zdim=traj.dim,
         off_U=traj.offset(P.state_name), off_a=traj.offset(P.control_name),
         off_dt=traj.offset(traj.timestep) if free else -1,
-        G_drift=np.array(sys_.G_drift), G_drives=np.array(sys_.G_drives).reshape(sys_.n_drives, 2 * sys_.levels, 2 * sys_.levels),
+        G_drift=np.array(sys_.G_drift), G_drives=np.array(sys_.G_drives).reshape(sys_.n_drives, 2 * sys_.state_levels, 2 * sys_.state_levels),
         dt_fixed=0.0 if free else float(traj.timestep),
         integrator=o.PADE if is_pade else o.EXPONENTIAL,
         order=P.order if is_pade else 4,
