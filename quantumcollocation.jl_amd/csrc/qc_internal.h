@@ -44,6 +44,9 @@ struct QcParams {
     unsigned long long* stamps;  // diagnostic: 16 s_memrealtime slots per interval, or nullptr (normal)
 };
 
+struct qc_host_pool;
+void qc_host_pool_destroy(qc_host_pool* p);
+
 struct qc_handle {
     qc_desc desc;  // G pointers nulled after create
     QcParams prm;
@@ -56,6 +59,10 @@ struct qc_handle {
     // staging for the host-pointer entry points
     double *dZ = nullptr, *dF = nullptr, *dJ = nullptr, *dMu = nullptr, *dH = nullptr;
     unsigned long long* dStamps = nullptr;
+    double* hJc = nullptr;     // compact Jacobian values (one copy of the replicated blocks): pinned host staging, device-visible
+    struct qc_host_pool* pool = nullptr;       // worker threads of the compact transfer (created on first use)
+    std::vector<hipEvent_t> chunk_events;
+    int host_compact = 1;      // QC_HOST_COMPACT=0 disables the compact D2H path of the host-buffer entry points
     double *dRE = nullptr, *dRQ = nullptr, *dRS = nullptr, *dRinit = nullptr, *dRout = nullptr;   // rollout scratch / staging
     hipStream_t stream = nullptr;
     std::string err;
@@ -84,6 +91,8 @@ bool qc_mfma32_hess_supported(const QcParams& P);
 hipError_t qc_launch_mfma32_hess(const QcParams& P, const double* dZ, const double* dMu, double* dH, hipStream_t st);
 hipError_t qc_launch_mfma_hess(const QcParams& P, const double* dZ, const double* dMu, double* dH, hipStream_t st);
 
+hipError_t qc_launch_pack_jac(const double* dJ, double* dJc, int n_int, int jac_nnz, int comp_len, int n2, int jo_F, int jo_B, int head2,
+                              int tail_src, hipStream_t st);
 bool qc_rollout_supported(const QcParams& P);
 void qc_rollout_scratch(const QcParams& P, long long T, size_t* nE, size_t* nQ, size_t* nS, int* chunk, int* n_chunks);
 hipError_t qc_launch_rollout(const QcParams& P, long long T, const double* dZ, const double* dinit, double* dout, double* dE, double* dQ,

@@ -178,7 +178,28 @@ __global__ __launch_bounds__(kRT) void qc_rollout_states_kernel(RollParams R, co
     }
 }
 
+// Gather of the non-replicated part of the Jacobian values for the host-buffer entry points (qc_host.cpp, "compact
+// transfer"): per interval [first -F block | first B block (Pade) | everything from the drive columns on].
+__global__ __launch_bounds__(256) void qc_pack_jac_kernel(const double* __restrict__ J, double* __restrict__ C, int n_int, int jac_nnz,
+                                                          int comp_len, int n2, int jo_F, int jo_B, int head2, int tail_src) {
+    for (int b = blockIdx.x; b < n_int; b += gridDim.x) {
+        const double* __restrict__ src = J + (size_t)b * jac_nnz;
+        double* __restrict__ dst = C + (size_t)b * comp_len;
+        for (int e = threadIdx.x; e < comp_len; e += 256) {
+            const int o = e < n2 ? jo_F + e : (e < head2 ? jo_B + (e - n2) : tail_src + (e - head2));
+            dst[e] = src[o];
+        }
+    }
+}
+
 }  // namespace
+
+hipError_t qc_launch_pack_jac(const double* dJ, double* dJc, int n_int, int jac_nnz, int comp_len, int n2, int jo_F, int jo_B, int head2,
+                              int tail_src, hipStream_t st) {
+    const int grid = n_int < 4096 ? n_int : 4096;
+    hipLaunchKernelGGL(qc_pack_jac_kernel, dim3(grid), dim3(256), 0, st, dJ, dJc, n_int, jac_nnz, comp_len, n2, jo_F, jo_B, head2, tail_src);
+    return hipGetLastError();
+}
 
 bool qc_rollout_supported(const QcParams& P) { return P.n <= 64; }
 
