@@ -78,11 +78,13 @@ def main():
     ap.add_argument("--T", type=int, default=0, help="knots per GPU (default: the config's own T)")
     ap.add_argument("--kernel", default="auto", choices=["auto", "lds", "mfma"])
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="0 disables the CPU baseline leg")
-    ap.add_argument("--hessian", action="store_true", help="also time mu_d2F and report the ms/Ipopt-iter proxy")
+    ap.add_argument("--hessian", action=argparse.BooleanOptionalAction, default=True,
+                    help="also time mu_d2F and F alone and report the ms/Ipopt-iter proxy of the metric (extra fields)")
     ap.add_argument("--allgather", action="store_true", help="also time the RCCL all-gather of the value blocks")
     ap.add_argument("--streams", type=int, default=0, help="also time the same steps issued round-robin on S streams "
                     "(independent evaluations overlapping their launch/drain phases; reported as an extra field, never `value`)")
-    ap.add_argument("--host-visible", action="store_true", help="also time qc_eval_F_jac with host buffers (PCIe-inclusive; never `value`)")
+    ap.add_argument("--host-visible", action=argparse.BooleanOptionalAction, default=True,
+                    help="also time qc_eval_F_jac with host buffers (PCIe-inclusive; an extra field, never `value`)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -113,4 +113,82 @@ function dynamics(integrators, traj, system; device::Int=0, eval_hessian::Bool=t
     return dyn
 end
 
+# ---------------------------------------------------------------------------------------------------------------
+#  Objective terms and rollouts (SURVEY.md 8f): the same `ccall` pattern over qc_terms_* / qc_fidelity_* / qc_rollout
+# ---------------------------------------------------------------------------------------------------------------
+
+# mirror of `qc_terms_desc`
+struct QCTermsDesc
+    T::Int64; zdim::Int32; off_dt::Int32; global_dim::Int64; dt_fixed::Float64
+    n_reg::Int32; weighting::Int32; reg_index::Ptr{Int32}; reg_R::Ptr{Float64}; reg_baseline::Ptr{Float64}
+    min_time_D::Float64; min_time_knots::Int64; device::Int32; reserved0::Int32
+end
+
+"""
+    regularizers(traj, names_and_R; D=0.0, device=0, dt_scaled=true)
+
+`names_and_R = [(:a, R_a), (:da, R_da), (:dda, R_dda)]` (scalars or vectors, unitary_smooth_pulse_problem.jl:151-153);
+`D` adds `MinimumTimeObjective(traj; D)` (unitary_minimum_time_problem.jl:67-69).  Returns `(L, ∇L, ∂²L, ∂²L_structure)`
+closures over one device handle.
+"""
+function regularizers(traj, names_and_R; D::Float64=0.0, device::Int=0, dt_scaled::Bool=true)
+    idx = Int32[]; R = Float64[]
+    for (name, r) in names_and_R
+        comps = collect(traj.components[name]) .- 1
+        append!(idx, Int32.(comps)); append!(R, r isa Number ? fill(Float64(r), length(comps)) : Float64.(r))
+    end
+    p = sortperm(idx); idx = idx[p]; R = R[p]
+    free_time = traj.timestep isa Symbol
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve idx R begin
+        desc = Ref(QCTermsDesc(traj.T, traj.dim, free_time ? first(traj.components[traj.timestep]) - 1 : -1, traj.global_dim,
+                               free_time ? 0.0 : Float64(traj.timestep), length(idx), dt_scaled ? 0 : 1,
+                               pointer(idx), pointer(R), C_NULL, D, D == 0.0 ? 0 : traj.T - 1, device, 0))
+        rc = ccall((:qc_terms_create, LIB[]), Cint, (Ref{QCTermsDesc}, Ref{Ptr{Cvoid}}), desc, h)
+        rc == 0 || error("qc_terms_create: " * unsafe_string(ccall((:qc_terms_last_error, LIB[]), Cstring, (Ptr{Cvoid},), C_NULL)))
+    end
+    nnz = Ref{Int64}(0)
+    ccall((:qc_terms_hess_nnz, LIB[]), Cint, (Ptr{Cvoid}, Ref{Int64}), h[], nnz)
+    hr = Vector{Int64}(undef, nnz[]); hc = similar(hr)
+    ccall((:qc_terms_hess_structure, LIB[]), Cint, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}, Cint), h[], hr, hc, 1)
+    Zlen = traj.dim * traj.T + traj.global_dim
+    gbuf = Vector{Float64}(undef, Zlen); Hbuf = Vector{Float64}(undef, nnz[])
+    ev(Z⃗, J, g, H) = ccall((:qc_terms_eval, LIB[]), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), h[], Z⃗, J, g, H)
+    L(Z⃗) = (J = Ref(0.0); GC.@preserve Z⃗ ev(Z⃗, J, C_NULL, C_NULL); J[])
+    ∇L(Z⃗) = (GC.@preserve Z⃗ gbuf ev(Z⃗, C_NULL, gbuf, C_NULL); gbuf)
+    ∂²L(Z⃗) = (GC.@preserve Z⃗ Hbuf ev(Z⃗, C_NULL, C_NULL, Hbuf); Hbuf)
+    return L, ∇L, ∂²L, collect(zip(Int.(hr), Int.(hc)))
+end
+
+"""
+    unitary_rollout(dyn::HIPDynamics, Z⃗, Ũ⃗_init)  ->  Ũ⃗ (2N² × T)
+
+`unitary_rollout` / `rollout` / `open_rollout` (trajectory_initialization.jl:426,493,547) with the controls and timesteps of `Z⃗`.
+"""
+function unitary_rollout(dyn::HIPDynamics, Z⃗::AbstractVector{Float64}, init::AbstractVector{Float64}, T::Int)
+    out = Matrix{Float64}(undef, length(init), T)
+    GC.@preserve Z⃗ init out check(ccall((:qc_rollout, LIB[]), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+                                        dyn.handle, Z⃗, init, out), dyn.handle)
+    return out
+end
+
+"""
+    iso_vec_unitary_fidelity(Ũ⃗, Ũ⃗_goal; subspace=nothing, device=0)   (unitary_minimum_time_problem.jl:77)
+"""
+function iso_vec_unitary_fidelity(Ũ⃗::AbstractVector{Float64}, Ũ⃗_goal::AbstractVector{Float64}; subspace=nothing, device::Int=0)
+    N = isqrt(length(Ũ⃗_goal) ÷ 2)
+    sub = isnothing(subspace) ? Int32[] : Int32.(collect(subspace) .- 1)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve Ũ⃗_goal sub begin
+        rc = ccall((:qc_fidelity_create, LIB[]), Cint, (Int32, Ptr{Float64}, Ptr{Int32}, Int32, Int32, Ref{Ptr{Cvoid}}),
+                   N, Ũ⃗_goal, isempty(sub) ? C_NULL : pointer(sub), length(sub), device, h)
+        rc == 0 || error("qc_fidelity_create failed")
+    end
+    F = Ref(0.0)
+    GC.@preserve Ũ⃗ ccall((:qc_fidelity_eval, LIB[]), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ref{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+                          h[], Ũ⃗, F, C_NULL, C_NULL, C_NULL)
+    ccall((:qc_fidelity_destroy, LIB[]), Cvoid, (Ptr{Cvoid},), h[])
+    return F[]
+end
+
 end # module
