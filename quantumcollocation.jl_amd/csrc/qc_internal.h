@@ -87,6 +87,8 @@ hipError_t qc_launch_mfma_F_jac(const QcParams& P, const double* dZ, double* dF,
 size_t qc_mfma32_gx_doubles(const QcParams& P);
 void qc_mfma32_pack_G(const QcParams& P, const double* G_host, double* Gx_host);
 hipError_t qc_launch_mfma32_F_jac(const QcParams& P, const double* dZ, double* dF, double* dJ, hipStream_t st);
+bool qc_mfma_exp_supported(const QcParams& P);
+hipError_t qc_launch_mfma_exp(const QcParams& P, const double* dZ, double* dF, double* dJ, hipStream_t st);
 bool qc_mfma32_hess_supported(const QcParams& P);
 hipError_t qc_launch_mfma32_hess(const QcParams& P, const double* dZ, const double* dMu, double* dH, hipStream_t st);
 hipError_t qc_launch_mfma_hess(const QcParams& P, const double* dZ, const double* dMu, double* dH, hipStream_t st);

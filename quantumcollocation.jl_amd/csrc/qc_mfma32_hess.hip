@@ -92,22 +92,6 @@ __device__ __forceinline__ void mm16x2_multi(const v4d (&a0)[NQ], const v4d (&b0
     }
 }
 
-// D-layout(X) -> D-layout(X^T) of a 16 x 16 tile through a padded (17-double rows) per-wave LDS scratch: four 8-byte writes
-// and reads per lane, conflict-free up to 2-way; replaces a transposing identity product (4 MFMAs = 256 cycles of the pipe).
-// LDS operations of one wave execute in order, so no barrier is needed.
-__device__ inline v4d lds_transpose16(double* __restrict__ scr, const v4d& x, int g, int j) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) scr[(4 * r + g) * 17 + j] = x[r];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    v4d y;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) y[r] = scr[j * 17 + 4 * r + g];
-    __builtin_amdgcn_wave_barrier();
-    return y;
-}
-
 // lane (g, j) reg r = X[16 J + j][4 r + g] of a column-major 32-row block at p  (a transposed-land tile)
 __device__ inline void store_T(double* __restrict__ p, const v4d& x, int J, int g, int j) {
 #pragma unroll

@@ -82,6 +82,22 @@ __device__ inline void store_tile_T16(double* __restrict__ p, const TileT16& t, 
     qc_st16(p + (c0 + 4) * ld + row, t.a1, t.b1, mode);
 }
 
+// D-layout(X) -> D-layout(X^T) of a 16 x 16 tile through a padded (17-double rows) per-wave LDS scratch: four 8-byte writes
+// and reads per lane, conflict-free up to 2-way; replaces a transposing identity product (4 MFMAs = 256 cycles of the pipe).
+// LDS operations of one wave execute in order, so no barrier is needed.
+__device__ inline v4d lds_transpose16(double* __restrict__ scr, const v4d& x, int g, int j) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) scr[(4 * r + g) * 17 + j] = x[r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    v4d y;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) y[r] = scr[j * 17 + 4 * r + g];
+    __builtin_amdgcn_wave_barrier();
+    return y;
+}
+
 // Identity in B/D layout: lane (g, j) reg r = (4r + g == j)
 __device__ inline v4d identity_B(int g, int j) {
     return v4d{(g == j) ? 1.0 : 0.0, (4 + g == j) ? 1.0 : 0.0, (8 + g == j) ? 1.0 : 0.0, (12 + g == j) ? 1.0 : 0.0};

@@ -1,0 +1,258 @@
+// f64-MFMA kernel for the EXPONENTIAL integrator at 2N = 16 (3 qubits), up to 8 drives: residual
+//     delta = U_t+1 - exp(h G(a_t)) U_t                                          (reference README.md:79)
+// and its Jacobian blocks  d/dU_t = -I_N (x) E,  d/dU_t+1 = I,  d/da_j = -L_j U_t,  d/dh = -G E U_t,
+// with E = exp(h G), L_j = L_exp(h G; h G_j) the Frechet derivative.  ONE wavefront per interval; every matrix is one
+// 16 x 16 tile in registers (lane maps: qc_mfma_kernels.hip header).
+//
+// Scaling and squaring, Y = h G / 2^sq with ||Y||_1 <= 1/4 (same rule as the LDS kernel), degree-12 Taylor polynomial
+// in Horner form on R_k = P_k / (k-1)!  (P_k = I + Y/k P_k+1):
+//     R_k  = Y R_k+1 + I/(k-1)!          R'_k,j = G_j R_k+1 + Y R'_k+1,j           k = 12 .. 1,   R_13 = I/12!,  R'_13 = 0
+// so a step is 4 + 8 m MFMAs with the constant A-layout tiles Y, G_j as A operands and the previous outputs as B
+// operands (D layout = B layout): nothing but MFMAs touches the accumulators, the identity enters as the C operand.
+// R_1 = exp(Y), R'_1,j = L_exp(Y; G_j).  Squarings  E <- E E,  L_j <- E L_j + L_j E  need E and L_j as LEFT factors:
+// a D-layout tile read as the A operand acts as its transpose, so E^T and L_j^T are made by LDS transposes (8 LDS
+// operations each, no MFMA) and used as A operands.  L_j is linear in its direction, so the factor h / 2^sq is applied
+// once to the outputs.  Outputs leave transposed (lane <-> row, whole 128-byte lines per store): the copies of -E
+// from E^T, the drive columns as (L_j U_t)^T = U_t^T L_j^T (A = U_t tile, B = L_j^T), residual and d/dh through LDS.
+// MFMAs per interval (m = 6, 3 squarings): 12 x 52 + 3 x 52 + 8 + 24 = 812;  the LDS kernel spends 463 us on config 3.
+#include "qc_mfma_common.h"
+
+namespace {
+
+using namespace qc_mfma;
+
+constexpr int kXDeg = 12;
+constexpr int kXMmax = 8;
+
+__device__ inline v4d ximg(const double* __restrict__ Gx, int mat, int lane) {
+    const v2d* p = reinterpret_cast<const v2d*>(Gx) + mat * 128 + lane;
+    const v2d lo = p[0], hi = p[64];
+    return v4d{lo[0], lo[1], hi[0], hi[1]};
+}
+template <int CTRL>
+__device__ inline double xdpp(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ inline double xreadlane(double x, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
+}
+
+// one Horner step (or, with c = 0, one squaring with A operands (Et, Et, Kt_j) in place of (Y, G_j, Y)):
+//   R <- A0 R + c I,   Q_j <- A1_j R + A2 Q_j       (A2_j per drive when PER_DRIVE_A2, the squaring's  L_j^T-as-A E term)
+template <int M, bool JAC>
+__device__ __forceinline__ void horner_step(const v4d& Y, const v4d (&Gj)[M], v4d& R, v4d (&Q)[M], const v4d& cI) {
+    v4d accR = cI;
+    v4d acc[M];
+    const v4d z = {0.0, 0.0, 0.0, 0.0};
+    accR = __builtin_amdgcn_mfma_f64_16x16x4f64(Y[0], R[0], accR, 0, 0, 0);
+    if constexpr (JAC) {
+#pragma unroll
+        for (int q = 0; q < M; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(Gj[q][0], R[0], z, 0, 0, 0);
+    }
+#pragma unroll
+    for (int kk = 1; kk < 4; ++kk) {
+        accR = __builtin_amdgcn_mfma_f64_16x16x4f64(Y[kk], R[kk], accR, 0, 0, 0);
+        if constexpr (JAC) {
+#pragma unroll
+            for (int q = 0; q < M; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(Gj[q][kk], R[kk], acc[q], 0, 0, 0);
+        }
+    }
+    if constexpr (JAC) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+            for (int q = 0; q < M; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(Y[kk], Q[q][kk], acc[q], 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < M; ++q) Q[q] = acc[q];
+    }
+    R = accR;
+}
+
+// squaring: E <- Et^T E (= E E),  L_j <- Et^T L_j + Kt_j^T E (= E L_j + L_j E);  Et, Kt_j are the transposed tiles
+template <int M, bool JAC>
+__device__ __forceinline__ void square_step(const v4d& Et, const v4d (&Kt)[M], v4d& E, v4d (&L)[M]) {
+    const v4d z = {0.0, 0.0, 0.0, 0.0};
+    v4d accE = z, acc[M];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        accE = __builtin_amdgcn_mfma_f64_16x16x4f64(Et[kk], E[kk], accE, 0, 0, 0);
+        if constexpr (JAC) {
+#pragma unroll
+            for (int q = 0; q < M; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(Et[kk], L[q][kk], kk == 0 ? z : acc[q], 0, 0, 0);
+        }
+    }
+    if constexpr (JAC) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+            for (int q = 0; q < M; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(Kt[q][kk], E[kk], acc[q], 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < M; ++q) L[q] = acc[q];
+    }
+    E = accE;
+}
+
+template <bool JAC, int kMU>
+__global__ __launch_bounds__(64, 1) void qc_mfma16_exp_kernel(const QcParams P, const double* __restrict__ Z, double* __restrict__ F,
+                                                              double* __restrict__ J) {
+    __shared__ double scr[16 * 17];
+    const int lane = threadIdx.x;
+    const int m = P.m;
+    const int g = lane >> 4, j = lane & 15, jj = j & 7;
+    const bool ft = P.off_dt >= 0;
+    const double* __restrict__ Gx = P.Gx;            // A-layout images [mat][pair][lane][2]
+    const v4d IdB = identity_B(g, j);
+    const v4d zero = {0.0, 0.0, 0.0, 0.0};
+
+    {   // one interval per workgroup: a grid-stride loop lets the compiler hoist interval-invariant tiles (the twelve scaled
+        // identities, 96 VGPRs) out of the body and spill
+        const int b = qc_xcd_remap((int)blockIdx.x, P.n_int);
+        const long long t = P.t_begin + b;
+        const double* __restrict__ z0 = Z + t * (long long)P.zdim;
+        const double* __restrict__ z1 = z0 + P.zdim;
+        double* __restrict__ Jb = JAC ? J + (size_t)b * P.J_stride + P.J_off : nullptr;
+        double* __restrict__ Fb = F ? F + (size_t)b * P.F_stride + P.F_off : nullptr;
+        const double h = ft ? z0[P.off_dt] : P.dt_fixed;
+
+        // ---- loads (one batch): knots, generator images --------------------------------------------------------
+        const double* u0p = z0 + P.off_U + jj * 16 + g;
+        const double* u1p = z1 + P.off_U + jj * 16 + g;
+        const v4d u0 = {u0p[0], u0p[4], u0p[8], u0p[12]};       // [U_t | U_t]  (both 8-column halves hold the same matrix)
+        const v4d u1 = {u1p[0], u1p[4], u1p[8], u1p[12]};
+        v4d Gj[kMU];
+        double ak[kMU];
+        v4d Ga = ximg(Gx, 0, lane);
+#pragma unroll
+        for (int u = 0; u < kMU; ++u) {
+            const int k = u < m ? u : (m > 0 ? m - 1 : 0);       // clamped: the load is unconditional
+            Gj[u] = ximg(Gx, m > 0 ? k + 1 : 0, lane);
+            ak[u] = (u < m) ? z0[P.off_a + k] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < kMU; ++u) Ga += ak[u] * Gj[u];
+#pragma unroll
+        for (int u = 0; u < kMU; ++u) if (u >= m) Gj[u] = zero;   // unused drive slots: their chains stay zero
+
+        // ---- ||h G||_1 = largest column sum: lane (g, i) reg kk holds G[i][4kk+g]; rows of 16 lanes share a column ------
+        int sq = 0;
+        {
+            double best = 0.0;
+            bool bad = false;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                double c = fabs(h * Ga[kk]);
+                c += xdpp<0x128>(c);
+                c += xdpp<0x124>(c);
+                c += xdpp<0x122>(c);
+                c += xdpp<0x121>(c);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double v = xreadlane(c, 16 * r);
+                    if (!(v == v) || v > 1e300) bad = true;
+                    best = fmax(best, v);
+                }
+            }
+            if (!bad && best > 0.25) {
+                int e;
+                (void)frexp(best / 0.25, &e);
+                sq = e;
+                if (ldexp(0.25, e - 1) >= best) sq = e - 1;
+                sq = sq < 0 ? 0 : (sq > 60 ? 60 : sq);
+            }
+        }
+        const double sc = ldexp(1.0, -sq);
+        const v4d Y = (h * sc) * Ga;
+
+        // ---- Horner: R_13 = I/12!, R'_13 = 0 ----------------------------------------------------------------------
+        double fact = 1.0;
+#pragma unroll
+        for (int k = 2; k <= kXDeg; ++k) fact *= (double)k;        // 12!
+        double ck = 1.0 / fact;                                     // 1/12!
+        v4d R = ck * IdB;
+        v4d Q[kMU];
+#pragma unroll
+        for (int u = 0; u < kMU; ++u) Q[u] = zero;
+#pragma unroll 1
+        for (int k = kXDeg; k >= 1; --k) {
+            ck *= (double)k;                                        // 1/(k-1)!
+            horner_step<kMU, JAC>(Y, Gj, R, Q, ck * IdB);
+        }
+        // ---- squarings ------------------------------------------------------------------------------------------------
+        for (int q = 0; q < sq; ++q) {
+            const v4d Et = lds_transpose16(scr, R, g, j);
+            v4d Kt[kMU];
+            if constexpr (JAC) {
+#pragma unroll
+                for (int u = 0; u < kMU; ++u) Kt[u] = u < m ? lds_transpose16(scr, Q[u], g, j) : zero;
+            }
+            square_step<kMU, JAC>(Et, Kt, R, Q);
+        }
+        // ---- outputs --------------------------------------------------------------------------------------------------
+        const v4d Et = lds_transpose16(scr, R, g, j);              // E^T: A operand acting as E, and the tile to store
+        const v4d EU = mm16(Et, u0);                                // [E U_t | E U_t]
+        if (Fb) {
+            const v4d dT = lds_transpose16(scr, u1 - EU, g, j);     // delta^T: lane j <-> row
+#pragma unroll
+            for (int r = 0; r < 2; ++r) qc_st8m<2>(Fb + (4 * r + g) * 16 + j, dT[r]);
+        }
+        if constexpr (JAC) {
+            double* pF = Jb + P.jo_F;
+            const v4d mE = -Et;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) qc_st8m<2>(pF + q * 256 + (4 * r + g) * 16 + j, mE[r]);
+            }
+            for (int i = lane; i < P.s; i += 64) Jb[P.jo_B + i] = 1.0;
+            // d/da_j = -(h/2^sq) L_j U_t, transposed:  U_t^T L_j^T  (A = U_t tile, B = L_j^T)
+            const double fac = -(h * sc);
+            v4d Kt[kMU], XT[kMU], ua[kMU];
+#pragma unroll
+            for (int u = 0; u < kMU; ++u) {
+                Kt[u] = u < m ? lds_transpose16(scr, Q[u], g, j) : zero;
+                ua[u] = u0;
+            }
+            mm16_multi<kMU>(ua, Kt, XT);
+#pragma unroll
+            for (int u = 0; u < kMU; ++u) {
+                if (u < m) {
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) qc_st8m<2>(Jb + P.jo_a + (size_t)u * 128 + (4 * r + g) * 16 + j, fac * XT[u][r]);
+                }
+            }
+            if (ft) {   // d/dh = -G E U_t
+                const v4d GEU = mm16(Ga, EU);
+                const v4d hT = lds_transpose16(scr, -GEU, g, j);
+#pragma unroll
+                for (int r = 0; r < 2; ++r) qc_st8m<2>(Jb + P.jo_h + (4 * r + g) * 16 + j, hT[r]);
+            }
+        }
+        deriv_rows_generic(P, z0, z1, h, Fb, Jb, lane, false);
+    }
+}
+
+}  // namespace
+
+bool qc_mfma_exp_supported(const QcParams& P) {
+    return P.integrator == QC_EXPONENTIAL && P.n == 16 && P.nc == P.N && P.m <= kXMmax;
+}
+
+template <bool JAC>
+static void launch_exp(const QcParams& P, const double* dZ, double* dF, double* dJ, hipStream_t st) {
+    const int grid = P.n_int;
+    if (P.m <= 2) hipLaunchKernelGGL((qc_mfma16_exp_kernel<JAC, 2>), dim3(grid), dim3(64), 0, st, P, dZ, dF, dJ);
+    else if (P.m <= 4) hipLaunchKernelGGL((qc_mfma16_exp_kernel<JAC, 4>), dim3(grid), dim3(64), 0, st, P, dZ, dF, dJ);
+    else if (P.m <= 6) hipLaunchKernelGGL((qc_mfma16_exp_kernel<JAC, 6>), dim3(grid), dim3(64), 0, st, P, dZ, dF, dJ);
+    else hipLaunchKernelGGL((qc_mfma16_exp_kernel<JAC, 8>), dim3(grid), dim3(64), 0, st, P, dZ, dF, dJ);
+}
+
+hipError_t qc_launch_mfma_exp(const QcParams& P, const double* dZ, double* dF, double* dJ, hipStream_t st) {
+    if (dJ) launch_exp<true>(P, dZ, dF, dJ, st);
+    else launch_exp<false>(P, dZ, dF, dJ, st);
+    return hipGetLastError();
+}
