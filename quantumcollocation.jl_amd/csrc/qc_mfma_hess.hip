@@ -10,7 +10,8 @@
 //   (h, h)         = 2 c2 <M1, G D>
 //   (dx_i, h)      = -mu_i   (derivative integrators)
 // Left multiplication by a transpose uses the B-layout image as the A operand
-// (A-layout(X^T) = B-layout(X)); G_B = G I.  MFMAs per interval: 16 + 8 m + 12 ceil(m/2) + 4 (104 for m = 6).
+// (A-layout(X^T) = B-layout(X)); the B-layout tile of G is assembled from the B-layout images like the A-layout one, and
+// the transposes for the stores go through LDS.  MFMAs per interval: 12 + 8 m + 4 ceil(m/2) (72 for m = 6).
 #include "qc_mfma_common.h"
 
 namespace {
@@ -35,6 +36,7 @@ template <int kHM>
 __global__ __launch_bounds__(64) void qc_mfma16_pade4_hess_kernel(const QcParams P, const double* __restrict__ Z,
                                                                   const double* __restrict__ Mu, double* __restrict__ H) {
     __shared__ double red[kHVals * kHStride];
+    __shared__ double tscr[16 * 17];
     const int lane = threadIdx.x;
     const int m = P.m;
     const int g = lane >> 4, j = lane & 15, jj = j & 7;
@@ -43,7 +45,6 @@ __global__ __launch_bounds__(64) void qc_mfma16_pade4_hess_kernel(const QcParams
     const double c1 = P.c[1], c2 = P.c[2];
     const double* __restrict__ GxA = P.Gx;                          // A-layout images
     const double* __restrict__ GxB = P.Gx + (size_t)(m + 1) * 256;  // B-layout images (= A-layout of the transposes)
-    const v4d IdB = identity_B(g, j);
     const v4d zero = {0.0, 0.0, 0.0, 0.0};
 
     for (int vb = blockIdx.x; vb < P.n_int; vb += gridDim.x) {
@@ -65,6 +66,7 @@ __global__ __launch_bounds__(64) void qc_mfma16_pade4_hess_kernel(const QcParams
         v4d gA[kHM], gB[kHM];
         double ak[kHM];
         v4d Ga = load_img(GxA, 0, lane);
+        v4d Gb = load_img(GxB, 0, lane);                    // B-layout of G = A-layout of G^T, assembled like Ga (no identity product)
 #pragma unroll
         for (int u = 0; u < kHM; ++u) {
             const int k = u < m ? u : (m > 0 ? m - 1 : 0);
@@ -73,12 +75,14 @@ __global__ __launch_bounds__(64) void qc_mfma16_pade4_hess_kernel(const QcParams
             ak[u] = (u < m) ? z0[P.off_a + k] : 0.0;
         }
 #pragma unroll
-        for (int u = 0; u < kHM; ++u) Ga += ak[u] * gA[u];
+        for (int u = 0; u < kHM; ++u) {
+            Ga += ak[u] * gA[u];
+            Gb += ak[u] * gB[u];
+        }
         const double hc1 = h * c1, hc2 = h * h * c2, c2h2 = 2.0 * c2 * h;
 
         // ---- products in five dependency stages, each a batch of independent 16x16x16 products whose MFMAs are
         //      interleaved (mm16_multi):  1: G_B   2: M1, [GS|GD]   3: M2, [N_k|N'_k], [V_k|.]   4: (U,h)^T, N''   5: (U,a)^T
-        const v4d Gb = mm16(Ga, IdB);                       // B-layout of G = A-layout of G^T
         const v4d TM0 = sel(left, mv, zero);                // [M | 0]
         v4d W, Wsw;                                         // [S | D], [D | S]
 #pragma unroll
@@ -116,37 +120,28 @@ __global__ __launch_bounds__(64) void qc_mfma16_pade4_hess_kernel(const QcParams
                 VV[u] = (u < m) ? d3[1 + kHM + u] : zero;
             }
         }
-        v4d PN[kHM / 2], PN1[kHM / 2], PN2[kHM / 2], ET;
+        v4d PN[kHM / 2], PN1[kHM / 2], PN2[kHM / 2];
         {
-            constexpr int N4 = 1 + kHM / 2;
-            v4d a4[N4], b4[N4], d4[N4];
-            const v4d uh = -(c1 * Y1 + c2h2 * Y2), hu = (-c1) * Y1 + c2h2 * Y2;
-            a4[0] = sel(left, uh, swap8(hu));               // (U_t, h) left, (h, U_t+1) right; read as A operand = transposed
-            b4[0] = IdB;
+            constexpr int N4 = kHM / 2;
+            v4d a4[N4], b4[N4];
 #pragma unroll
             for (int p2 = 0; p2 < kHM / 2; ++p2) {
                 PN[p2] = sel(left, NN[2 * p2], swap8(NN[2 * p2 + 1]));      // [N_k | N_k+1]
                 PN1[p2] = sel(left, swap8(NN[2 * p2]), NN[2 * p2 + 1]);     // [N'_k | N'_k+1]
-                a4[1 + p2] = Gb;
-                b4[1 + p2] = PN[p2];
+                a4[p2] = Gb;
+                b4[p2] = PN[p2];
             }
-            mm16_multi<N4>(a4, b4, d4);
-            ET = d4[0];
-#pragma unroll
-            for (int p2 = 0; p2 < kHM / 2; ++p2) PN2[p2] = d4[1 + p2];      // [N''_k | N''_k+1]
+            mm16_multi<N4>(a4, b4, PN2);                                    // [N''_k | N''_k+1]
         }
+        // transposes for the line-wide stores go through the padded LDS scratch (an identity product costs 4 MFMAs each)
+        const v4d uh = -(c1 * Y1 + c2h2 * Y2), hu = (-c1) * Y1 + c2h2 * Y2;
+        const v4d ET = lds_transpose16(tscr, sel(left, uh, swap8(hu)), g, j);   // (U_t, h) left, (h, U_t+1) right
         v4d XT[kHM];                                        // (U_t, a) and (a, U_t+1) tiles, transposed
-        {
-            v4d a5[kHM], b5[kHM];
 #pragma unroll
-            for (int p2 = 0; p2 < kHM / 2; ++p2) {
-                const v4d q = hc2 * (PN2[p2] + PN1[p2]), lin = (-hc1) * PN[p2];
-                a5[2 * p2] = lin - q;
-                a5[2 * p2 + 1] = lin + q;
-                b5[2 * p2] = IdB;
-                b5[2 * p2 + 1] = IdB;
-            }
-            mm16_multi<kHM>(a5, b5, XT);
+        for (int p2 = 0; p2 < kHM / 2; ++p2) {
+            const v4d q = hc2 * (PN2[p2] + PN1[p2]), lin = (-hc1) * PN[p2];
+            XT[2 * p2] = lds_transpose16(tscr, lin - q, g, j);
+            XT[2 * p2 + 1] = lds_transpose16(tscr, lin + q, g, j);
         }
         if (ft) {
 #pragma unroll
