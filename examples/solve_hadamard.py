@@ -2,9 +2,11 @@
 """End-to-end plumbing check in the spirit of the reference's solve-and-compare tests
 (reference src/problem_templates/unitary_smooth_pulse_problem.jl:205-222: build the problem, solve a few iterations,
 assert that the rollout fidelity improved): BASELINE config 1 — 1-qubit Hadamard UnitarySmoothPulseProblem, T = 50,
-dt = 0.2, X/Y drives — with the dynamics constraint, its Jacobian and the Hessian of the Lagrangian served by the
-MI355X library and the NLP driven by a CPU solver.  Ipopt is not available in this image, so scipy's
-`trust-constr` (sparse equality constraints, exact Hessian) stands in for it; the solver is not part of the build.
+dt = 0.2, X/Y drives — with the dynamics constraint, its Jacobian and Lagrangian Hessian, the infidelity objective,
+the regularisers and the rollout fidelity all served by the MI355X library and the NLP driven by a CPU solver.
+Ipopt is not available in this image, so scipy's SLSQP (default; 0.61 -> 0.9999 rollout fidelity in 60 iterations) or
+`trust-constr` (sparse equality constraints, exact Hessian; it stalls on this problem) stands in for it; the solver
+is not part of the build.
 
     python examples/solve_hadamard.py [max_iter]
 """
@@ -14,7 +16,6 @@ import os
 import sys
 
 import numpy as np
-import scipy.linalg as sla
 import scipy.sparse as sp
 from scipy.optimize import Bounds, NonlinearConstraint, minimize
 
@@ -22,16 +23,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as g
 
 
-def rollout_fidelity(qc, system, traj_data, comps, U_goal):
-    """unitary_rollout_fidelity: propagate U with exp(dt G(a_t)) and compare with the goal (host post-processing)."""
-    a = traj_data[comps["a"].start:comps["a"].stop]
-    dt = traj_data[comps["Δt"].start]
-    N = system.levels
-    U = np.vstack([np.eye(N), np.zeros((N, N))])
-    for t in range(traj_data.shape[1] - 1):
-        U = sla.expm(dt[t] * system.G(a[:, t])) @ U
-    Uc = U[:N] + 1j * U[N:]
-    return abs(np.trace(U_goal.conj().T @ Uc)) / N
+def rollout_fidelity(qc, dyn, z, U_goal):
+    """unitary_rollout_fidelity (reference unitary_smooth_pulse_problem.jl:218): roll U out with exp(dt G(a_t)) on the
+    device (`qc_rollout`) and compare the last knot with the goal (`qc_fidelity_eval`)."""
+    N = U_goal.shape[0]
+    states = dyn.rollout(z, qc.operator_to_iso_vec(np.eye(N, dtype=complex)))
+    return qc.iso_vec_unitary_fidelity(states[:, -1], qc.operator_to_iso_vec(U_goal))
 
 
 def solve(max_iter: int = 60, T: int = 50, verbose: bool = True, method: str = "SLSQP", _debug_hook=None):
@@ -44,9 +41,10 @@ def solve(max_iter: int = 60, T: int = 50, verbose: bool = True, method: str = "
     nv = int(dyn.dims.Z_len)
     zdim = traj.dim
     comps = traj.components
-    R = 1e-2
-    reg_idx = np.concatenate([np.arange(t * zdim + comps[nm].start, t * zdim + comps[nm].stop)
-                              for t in range(T) for nm in ("a", "da", "dda")])
+    R = 1e-2   # R_a = R_da = R_dda (reference unitary_smooth_pulse_problem.jl:151-153), evaluated by qc_terms_*
+    reg = qc.TrajectoryObjective(qc.QuadraticRegularizer("a", traj, R) + qc.QuadraticRegularizer("da", traj, R)
+                                 + qc.QuadraticRegularizer("dda", traj, R), traj)
+    rhr, rhc = reg.hess_structure
     jr, jc = dyn.dF_structure
     hr, hc = dyn.mu_d2F_structure
     ohr, ohc = obj.hess_structure
@@ -72,20 +70,19 @@ def solve(max_iter: int = 60, T: int = 50, verbose: bool = True, method: str = "
 
     def fun(x):
         z = full(x)
-        return obj.L(z) + 0.5 * R * float(z[reg_idx] @ z[reg_idx])
+        return obj.L(z) + reg.L(z)
 
     def grad(x):
         z = full(x)
-        gvec = np.zeros(nv)
-        gvec[obj.state_indices] = obj.grad_L(z)
-        gvec[reg_idx] += R * z[reg_idx]
+        gvec = reg.grad_L(z).copy()
+        gvec[obj.state_indices] += obj.grad_L(z)
         return gvec[free]
 
     def hess_obj(x):
         z = full(x)
         Hu = sp.coo_matrix((obj.hess_L(z), (ohr, ohc)), shape=(nv, nv)).tocsr()
+        Hu = Hu + sp.coo_matrix((reg.hess_L(z), (rhr, rhc)), shape=(nv, nv)).tocsr()
         Hm = Hu + sp.triu(Hu, 1).T
-        Hm = Hm + sp.coo_matrix((np.full(reg_idx.size, R), (reg_idx, reg_idx)), shape=(nv, nv)).tocsr()
         return Hm[free][:, free]
 
     def cons(x):
@@ -109,7 +106,7 @@ def solve(max_iter: int = 60, T: int = 50, verbose: bool = True, method: str = "
     x0 = z_full[free]
     if _debug_hook is not None:
         _debug_hook(fun, grad, hess_obj, cons, cons_jac, cons_hess, x0, lb[free], ub[free])
-    f_before = rollout_fidelity(qc, system, z_full.reshape(T, zdim).T, comps, U_goal)
+    f_before = rollout_fidelity(qc, dyn, z_full, U_goal)
     if method == "trust-constr":      # sparse Jacobian + exact Hessian of the Lagrangian (F, dF, mu_d2F all exercised)
         res = minimize(fun, x0, jac=grad, hess=hess_obj, method="trust-constr", bounds=Bounds(lb[free], ub[free]),
                        constraints=[NonlinearConstraint(cons, 0.0, 0.0, jac=cons_jac, hess=cons_hess)],
@@ -120,13 +117,14 @@ def solve(max_iter: int = 60, T: int = 50, verbose: bool = True, method: str = "
                        options={"maxiter": max_iter, "ftol": 1e-10})
         res.constr_nfev = [res.nfev]
     res.x = full(res.x)
-    f_after = rollout_fidelity(qc, system, res.x.reshape(T, zdim).T, comps, U_goal)
+    f_after = rollout_fidelity(qc, dyn, res.x, U_goal)
     viol = float(np.max(np.abs(dyn.F(res.x))))
     if verbose:
         print(f"iterations {res.nit}  constraint evaluations {res.constr_nfev}  rollout fidelity {f_before:.6f} -> {f_after:.6f}  "
               f"max |dynamics residual| {viol:.2e}")
     dyn.close()
     obj.close()
+    reg.close()
     return f_before, f_after, viol
 
 
