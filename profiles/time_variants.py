@@ -59,7 +59,8 @@ time_dyn("config 2 Pade-4 (lds)", qc.config_inputs(2))
 time_dyn("config 2 exponential (lds)", qc.unitary_smooth_pulse_inputs(s2, qc.GATES["CX"], 200, integrator="exponential"))
 kets0 = [np.eye(8)[:, k] for k in range(4)]
 kets1 = [np.eye(8)[:, (k + 1) % 8] for k in range(4)]
-time_dyn("4 kets on 3 qubits, T=1000, Pade-4 (lds)", qc.quantum_state_smooth_pulse_inputs(s3, kets0, kets1, 1000))
+time_dyn("4 kets on 3 qubits, T=1000, Pade-4 (mfma16, masked)", qc.quantum_state_smooth_pulse_inputs(s3, kets0, kets1, 1000))
+time_dyn("4 kets on 3 qubits, T=1000, Pade-4 (lds)", qc.quantum_state_smooth_pulse_inputs(s3, kets0, kets1, 1000), kernel="lds")
 systems = [qc.QuantumSystem(s3.H_drift * f, s3.H_drives) for f in (0.95, 1.0, 1.05)]
 time_dyn("sampling problem: 3 systems x config 3 (3 launches)", qc.unitary_sampling_inputs(systems, qc.GATES["TOFFOLI"], 1000))
 

@@ -32,7 +32,7 @@ __device__ inline v4d sel(bool c, const v4d& a, const v4d& b) {
     return v4d{c ? a[0] : b[0], c ? a[1] : b[1], c ? a[2] : b[2], c ? a[3] : b[3]};
 }
 
-template <int kHM>
+template <int kHM, bool KET>
 __global__ __launch_bounds__(64) void qc_mfma16_pade4_hess_kernel(const QcParams P, const double* __restrict__ Z,
                                                                   const double* __restrict__ Mu, double* __restrict__ H) {
     __shared__ double red[kHVals * kHStride];
@@ -56,12 +56,16 @@ __global__ __launch_bounds__(64) void qc_mfma16_pade4_hess_kernel(const QcParams
         double* __restrict__ Hb = H + (size_t)b * P.H_stride + P.H_off;
 
         // ---- loads: knots, multipliers, generator images (one batch) ----------------------------------
-        const double* u0p = z0 + P.off_U + jj * 16 + g;
-        const double* u1p = z1 + P.off_U + jj * 16 + g;
-        const double* mp = mu + jj * 16 + g;
+        // K kets (nc < 8): the tile columns >= nc re-read column 0; the multipliers there are zeroed, which zeroes every
+        // quantity derived from M in those columns (the scalar blocks sum over whole tiles), and they are never stored
+        const int nc = KET ? P.nc : 8, jc = (!KET || jj < nc) ? jj : 0;     // KET = false: the masks fold away at compile time
+        const double* u0p = z0 + P.off_U + jc * 16 + g;
+        const double* u1p = z1 + P.off_U + jc * 16 + g;
+        const double* mp = mu + jc * 16 + g;
         const v4d u0 = {u0p[0], u0p[4], u0p[8], u0p[12]};
         const v4d u1 = {u1p[0], u1p[4], u1p[8], u1p[12]};
-        const v4d mv = {mp[0], mp[4], mp[8], mp[12]};
+        const v4d mraw = {mp[0], mp[4], mp[8], mp[12]};
+        const v4d mv = (!KET || jj < nc) ? mraw : v4d{0.0, 0.0, 0.0, 0.0};
         const double h = ft ? z0[P.off_dt] : P.dt_fixed;
         v4d gA[kHM], gB[kHM];
         double ak[kHM];
@@ -147,7 +151,7 @@ __global__ __launch_bounds__(64) void qc_mfma16_pade4_hess_kernel(const QcParams
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int c = 4 * r + g;
-                qc_st8m<2>(Hb + (c < 8 ? P.ho_Uh + c * 16 : P.ho_hU + (c - 8) * 16) + j, ET[r]);
+                if (!KET || (c & 7) < nc) qc_st8m<2>(Hb + (c < 8 ? P.ho_Uh + c * 16 : P.ho_hU + (c - 8) * 16) + j, ET[r]);
             }
         }
 #pragma unroll
@@ -156,9 +160,11 @@ __global__ __launch_bounds__(64) void qc_mfma16_pade4_hess_kernel(const QcParams
                 const bool two = u + 1 < m;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    if (r < 2 || two) {
-                        qc_st8m<2>(Hb + P.ho_Ua + (size_t)u * 128 + (4 * r + g) * 16 + j, XT[u][r]);
-                        qc_st8m<2>(Hb + P.ho_aU + (size_t)u * 128 + (4 * r + g) * 16 + j, XT[u + 1][r]);
+                    const int c = 4 * r + g;           // tile columns < 8: drive u column c; >= 8: drive u+1 column c-8
+                    if ((r < 2 || two) && (!KET || (c & 7) < nc)) {
+                        const size_t o = (size_t)(u + (r < 2 ? 0 : 1)) * (KET ? P.s : 128) + (c & 7) * 16 + j;
+                        qc_st8m<2>(Hb + P.ho_Ua + o, XT[u][r]);
+                        qc_st8m<2>(Hb + P.ho_aU + o, XT[u + 1][r]);
                     }
                 }
             }
@@ -215,15 +221,22 @@ __global__ __launch_bounds__(64) void qc_mfma16_pade4_hess_kernel(const QcParams
 
 bool qc_mfma_hess_supported(const QcParams& P) {
     if (qc_mfma32_hess_supported(P)) return true;
-    return P.integrator == QC_PADE && P.p == 2 && P.n == 16 && P.nc == P.N && P.m <= kHMmax;
+    return P.integrator == QC_PADE && P.p == 2 && P.n == 16 && P.nc <= 8 && P.m <= kHMmax;
 }
 
 hipError_t qc_launch_mfma_hess(const QcParams& P, const double* dZ, const double* dMu, double* dH, hipStream_t st) {
     if (P.n == 32) return qc_launch_mfma32_hess(P, dZ, dMu, dH, st);
     const int grid = P.n_int < 4096 ? P.n_int : 4096;
-    if (P.m <= 2) hipLaunchKernelGGL(qc_mfma16_pade4_hess_kernel<2>, dim3(grid), dim3(64), 0, st, P, dZ, dMu, dH);
-    else if (P.m <= 4) hipLaunchKernelGGL(qc_mfma16_pade4_hess_kernel<4>, dim3(grid), dim3(64), 0, st, P, dZ, dMu, dH);
-    else if (P.m <= 6) hipLaunchKernelGGL(qc_mfma16_pade4_hess_kernel<6>, dim3(grid), dim3(64), 0, st, P, dZ, dMu, dH);
-    else hipLaunchKernelGGL(qc_mfma16_pade4_hess_kernel<8>, dim3(grid), dim3(64), 0, st, P, dZ, dMu, dH);
+    if (P.nc != 8) {
+        if (P.m <= 2) hipLaunchKernelGGL((qc_mfma16_pade4_hess_kernel<2, true>), dim3(grid), dim3(64), 0, st, P, dZ, dMu, dH);
+        else if (P.m <= 4) hipLaunchKernelGGL((qc_mfma16_pade4_hess_kernel<4, true>), dim3(grid), dim3(64), 0, st, P, dZ, dMu, dH);
+        else if (P.m <= 6) hipLaunchKernelGGL((qc_mfma16_pade4_hess_kernel<6, true>), dim3(grid), dim3(64), 0, st, P, dZ, dMu, dH);
+        else hipLaunchKernelGGL((qc_mfma16_pade4_hess_kernel<8, true>), dim3(grid), dim3(64), 0, st, P, dZ, dMu, dH);
+        return hipGetLastError();
+    }
+    if (P.m <= 2) hipLaunchKernelGGL((qc_mfma16_pade4_hess_kernel<2, false>), dim3(grid), dim3(64), 0, st, P, dZ, dMu, dH);
+    else if (P.m <= 4) hipLaunchKernelGGL((qc_mfma16_pade4_hess_kernel<4, false>), dim3(grid), dim3(64), 0, st, P, dZ, dMu, dH);
+    else if (P.m <= 6) hipLaunchKernelGGL((qc_mfma16_pade4_hess_kernel<6, false>), dim3(grid), dim3(64), 0, st, P, dZ, dMu, dH);
+    else hipLaunchKernelGGL((qc_mfma16_pade4_hess_kernel<8, false>), dim3(grid), dim3(64), 0, st, P, dZ, dMu, dH);
     return hipGetLastError();
 }

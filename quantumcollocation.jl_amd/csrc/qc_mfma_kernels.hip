@@ -104,7 +104,7 @@ __device__ inline v4d lds_get(const double* __restrict__ base, int lane) {
     return v4d{lo[0], lo[1], hi[0], hi[1]};
 }
 
-template <bool JAC, int MODE, bool DIAG, int kMU>
+template <bool JAC, int MODE, bool DIAG, int kMU, bool KET>
 __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel(const QcParams P, const double* __restrict__ Z,
                                                                       double* __restrict__ F, double* __restrict__ J) {
     constexpr int kLdsBlock = kLdsGk + kMU * 256;
@@ -119,6 +119,10 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
     const int n_wg = (P.n_int + ipw - 1) / ipw;
     const int m = P.m;
     const int g = lane >> 4, j = lane & 15, jj = j & 7;
+    // state columns: N = 8 for a unitary (KET = false: every `< nc` below folds away at compile time; as run-time tests
+    // they cost the headline kernel 0.8 us per launch), K <= 8 for K kets
+    const int nc = KET ? P.nc : 8;
+    const int jc = (!KET || jj < nc) ? jj : 0;
     const bool left = j < 8;
     const bool ft = P.off_dt >= 0;
     const double c1 = P.c[1], c2 = P.c[2];
@@ -144,8 +148,8 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
             __builtin_amdgcn_s_setprio(3);   // critical path: nothing reaches HBM before this wave's first store
             QC_STAMP(P, b, lane, 0);
             // every global load of the interval, in one batch
-            const double* u0p = z0 + P.off_U + jj * 16 + g;
-            const double* u1p = z1 + P.off_U + jj * 16 + g;
+            const double* u0p = z0 + P.off_U + jc * 16 + g;      // columns >= nc (kets: nc < 8) re-read column 0; never stored
+            const double* u1p = z1 + P.off_U + jc * 16 + g;
             const v4d u0 = {u0p[0], u0p[4], u0p[8], u0p[12]};
             const v4d u1 = {u1p[0], u1p[4], u1p[8], u1p[12]};
             double dxv[kDF], dfv[kDF];       // derivative integrators, register fast path (<= kDF of <= 64 rows)
@@ -188,8 +192,10 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
                 // qc_mfma_common.h::store_tile_T16, measured 8 % slower.)
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
-                    store_tile_T<MODE>(pF + q * 256, Fm, g, j);
-                    store_tile_T<MODE>(pB + q * 256, Bm, g, j);
+                    if (!KET || q < nc) {
+                        store_tile_T<MODE>(pF + q * 256, Fm, g, j);
+                        store_tile_T<MODE>(pB + q * 256, Bm, g, j);
+                    }
                 }
                 __builtin_amdgcn_s_setprio(0);
                 QC_STAMP(P, b, lane, 2);
@@ -240,8 +246,8 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
             u0 = lds_get(sm + kLdsU0, lane);
             u1 = lds_get(sm + kLdsU1, lane);
         } else {                                  // residual-only launch: a single wave, loads for itself
-            const double* u0p = z0 + P.off_U + jj * 16 + g;
-            const double* u1p = z1 + P.off_U + jj * 16 + g;
+            const double* u0p = z0 + P.off_U + jc * 16 + g;      // columns >= nc (kets: nc < 8) re-read column 0; never stored
+            const double* u1p = z1 + P.off_U + jc * 16 + g;
             u0 = v4d{u0p[0], u0p[4], u0p[8], u0p[12]};
             u1 = v4d{u1p[0], u1p[4], u1p[8], u1p[12]};
             double ak[kMU];
@@ -325,8 +331,8 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
                 for (int r = 0; r < 4; ++r) {
                     const int c = 4 * r + g;          // tile column: < 8 residual column c, >= 8 d/dh column c-8
                     if (c < 8) {
-                        if (Fb) qc_st8m<MODE>(Fb + c * 16 + j, ET[r]);
-                    } else if (JAC && ft) {
+                        if (Fb && (!KET || c < nc)) qc_st8m<MODE>(Fb + c * 16 + j, ET[r]);
+                    } else if (JAC && ft && (!KET || c - 8 < nc)) {
                         qc_st8m<MODE>(Jb + P.jo_h + (c - 8) * 16 + j, ET[r]);
                     }
                 }
@@ -340,10 +346,14 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
                 double* pa = Jb + P.jo_a;
                 auto store_pair = [&](int k, const v4d& YTk) {
                     const bool two = k + 1 < m;
-                    double* p = pa + (size_t)k * 128;
+                    const int sk = KET ? P.s : 128;
+                    double* p = pa + (size_t)k * sk;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (r < 2 || two) qc_st8m<MODE>(p + (4 * r + g) * 16 + j, YTk[r]);   // tile columns >= 8 are drive k+1
+                    for (int r = 0; r < 4; ++r) {
+                        const int c = 4 * r + g;      // tile columns < 8: drive k column c; >= 8: drive k+1 column c-8
+                        if (r < 2) { if (!KET || c < nc) qc_st8m<MODE>(p + c * 16 + j, YTk[r]); }
+                        else if (two && (!KET || c - 8 < nc)) qc_st8m<MODE>(p + sk + (c - 8) * 16 + j, YTk[r]);
+                    }
                 };
                 v4d YT[kMU / 2];                      // stage D: transposes of [d/da_k | d/da_k+1]
                 {
@@ -390,7 +400,7 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
 
 bool qc_mfma_supported(const QcParams& P) {
     if (qc_mfma_exp_supported(P)) return true;
-    return P.integrator == QC_PADE && P.p == 2 && (P.n == 16 || P.n == 32) && P.nc == P.N && P.m <= 32;
+    return P.integrator == QC_PADE && P.p == 2 && ((P.n == 16 && P.nc <= 8) || (P.n == 32 && P.nc == P.N)) && P.m <= 32;
 }
 
 size_t qc_mfma_gx_doubles(const QcParams& P) { return P.n == 32 ? qc_mfma32_gx_doubles(P) : (size_t)2 * (P.m + 1) * 256; }
@@ -415,10 +425,14 @@ void qc_mfma_pack_G(const QcParams& P, const double* G, double* Gx) {
 
 template <bool JAC, bool DIAG, int MU>
 static void launch16m(const QcParams& P, const double* dZ, double* dF, double* dJ, hipStream_t st, int grid, int threads) {
+    if (P.nc != 8) {   // K < 8 kets: the column-masked instantiation (non-temporal stores, no diagnostics)
+        hipLaunchKernelGGL((qc_mfma16_pade4_kernel<JAC, 2, false, MU, true>), dim3(grid), dim3(threads), 0, st, P, dZ, dF, dJ);
+        return;
+    }
     switch (P.store_mode) {
-        case 0: hipLaunchKernelGGL((qc_mfma16_pade4_kernel<JAC, 0, DIAG, MU>), dim3(grid), dim3(threads), 0, st, P, dZ, dF, dJ); break;
-        case 1: hipLaunchKernelGGL((qc_mfma16_pade4_kernel<JAC, 1, DIAG, MU>), dim3(grid), dim3(threads), 0, st, P, dZ, dF, dJ); break;
-        default: hipLaunchKernelGGL((qc_mfma16_pade4_kernel<JAC, 2, DIAG, MU>), dim3(grid), dim3(threads), 0, st, P, dZ, dF, dJ); break;
+        case 0: hipLaunchKernelGGL((qc_mfma16_pade4_kernel<JAC, 0, DIAG, MU, false>), dim3(grid), dim3(threads), 0, st, P, dZ, dF, dJ); break;
+        case 1: hipLaunchKernelGGL((qc_mfma16_pade4_kernel<JAC, 1, DIAG, MU, false>), dim3(grid), dim3(threads), 0, st, P, dZ, dF, dJ); break;
+        default: hipLaunchKernelGGL((qc_mfma16_pade4_kernel<JAC, 2, DIAG, MU, false>), dim3(grid), dim3(threads), 0, st, P, dZ, dF, dJ); break;
     }
 }
 
