@@ -180,6 +180,13 @@ int qc_eval_hess(qc_handle* h, const double* Z, const double* mu, double* hvals)
 int qc_eval_F_jac_dev(qc_handle* h, const double* dZ, double* dF, double* dvals, void* stream);
 int qc_eval_hess_dev(qc_handle* h, const double* dZ, const double* dmu, double* dhvals, void* stream);
 
+/* Several handles over the same trajectory in ONE launch: the K unitary integrators of a `UnitarySamplingProblem`
+ * (reference unitary_sampling_problem.jl:134-155), each created with its slot of the shared per-interval blocks
+ * (rows_per_interval / row_offset / ...).  dF / dvals / dhvals point at the SHARED vectors.  Handles whose shapes or
+ * kernels differ are evaluated one launch each, with the same result. */
+int qc_eval_F_jac_dev_multi(qc_handle* const* hs, int32_t count, const double* dZ, double* dF, double* dvals, void* stream);
+int qc_eval_hess_dev_multi(qc_handle* const* hs, int32_t count, const double* dZ, const double* dmu, double* dhvals, void* stream);
+
 /* ---- fidelity of the final knot (SURVEY 8f "next" row 1) -------------------------------------------- */
 /* F(U~) = |tr(U_goal' U)| / n over the subspace block (`iso_vec_unitary_fidelity(U_T, U_G, subspace=...)`,
  * reference unitary_minimum_time_problem.jl:77) and the loss l = |1 - F| of `UnitaryInfidelityObjective`

@@ -62,7 +62,7 @@ kets1 = [np.eye(8)[:, (k + 1) % 8] for k in range(4)]
 time_dyn("4 kets on 3 qubits, T=1000, Pade-4 (mfma16, masked)", qc.quantum_state_smooth_pulse_inputs(s3, kets0, kets1, 1000))
 time_dyn("4 kets on 3 qubits, T=1000, Pade-4 (lds)", qc.quantum_state_smooth_pulse_inputs(s3, kets0, kets1, 1000), kernel="lds")
 systems = [qc.QuantumSystem(s3.H_drift * f, s3.H_drives) for f in (0.95, 1.0, 1.05)]
-time_dyn("sampling problem: 3 systems x config 3 (3 launches)", qc.unitary_sampling_inputs(systems, qc.GATES["TOFFOLI"], 1000))
+time_dyn("sampling problem: 3 systems x config 3 (1 batched launch)", qc.unitary_sampling_inputs(systems, qc.GATES["TOFFOLI"], 1000))
 
 # trajectory cost terms
 inp = qc.config_inputs(3)

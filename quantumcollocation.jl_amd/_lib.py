@@ -134,6 +134,8 @@ SYMBOLS = {
     "qc_eval_hess": (C.c_int, [_H, _c_double_p, _c_double_p, _c_double_p]),
     "qc_eval_F_jac_dev": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "qc_eval_hess_dev": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "qc_eval_F_jac_dev_multi": (C.c_int, [C.POINTER(_H), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "qc_eval_hess_dev_multi": (C.c_int, [C.POINTER(_H), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "qc_fidelity_create": (C.c_int, [C.c_int32, _c_double_p, C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.POINTER(_H)]),
     "qc_fidelity_destroy": (None, [_H]),
     "qc_fidelity_last_error": (C.c_char_p, [_H]),

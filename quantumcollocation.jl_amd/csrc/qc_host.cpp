@@ -396,6 +396,7 @@ extern "C" void qc_destroy(qc_handle* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     double* bufs[] = {h->dG, h->dGx, h->dZ, h->dF, h->dJ, h->dMu, h->dH, (double*)h->dStamps, h->dRE, h->dRQ, h->dRS, h->dRinit, h->dRout};
     if (h->hJc) (void)hipHostFree(h->hJc);
+    if (h->dBatch) (void)hipFree(h->dBatch);
     for (hipEvent_t ev : h->chunk_events) if (ev) (void)hipEventDestroy(ev);
     if (h->pool) qc_host_pool_destroy(h->pool);
     for (double* b : bufs) if (b) (void)hipFree(b);
@@ -457,6 +458,74 @@ extern "C" int qc_eval_F_jac_dev(qc_handle* h, const double* dZ, double* dF, dou
     if (h->kernel == QC_KERNEL_MFMA) e = qc_launch_mfma_F_jac(h->prm, dZ, dF, dvals, (hipStream_t)stream);
     else e = qc_launch_lds_F_jac(h->prm, dZ, dF, dvals, h->lds_bytes_jac, (hipStream_t)stream);
     if (e != hipSuccess) return fail(&h->err, QC_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    return QC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+//  Several handles in one launch (the systems of a sampling problem)
+// ------------------------------------------------------------------------------------------------
+// Returns 1 when the handles can share a launch (and hs[0]->dBatch holds their parameter blocks), 0 when not, < 0 on error.
+static int prepare_batch(qc_handle* const* hs, int32_t count, bool hessian) {
+    qc_handle* h0 = hs[0];
+    if (count < 2 || count > 65535) return 0;
+    for (int i = 0; i < count; ++i) {
+        const qc_handle* h = hs[i];
+        if (h->kernel != QC_KERNEL_MFMA || h->device != h0->device || !qc_mfma16_batchable(h->prm)) return 0;
+        if (h->prm.m > 8 && hessian) return 0;
+        if (h->prm.n_int != h0->prm.n_int || h->prm.t_begin != h0->prm.t_begin || h->prm.zdim != h0->prm.zdim || h->prm.m != h0->prm.m) return 0;
+    }
+    bool same = h0->dBatch != nullptr && (int)h0->batch_members.size() == count;
+    for (int i = 0; same && i < count; ++i) same = h0->batch_members[i] == hs[i];
+    if (same) return 1;
+    QC_HIP(h0, hipSetDevice(h0->device));
+    if (h0->dBatch) { (void)hipFree(h0->dBatch); h0->dBatch = nullptr; }
+    std::vector<QcParams> blocks(count);
+    for (int i = 0; i < count; ++i) blocks[i] = hs[i]->prm;
+    QC_HIP(h0, hipMalloc((void**)&h0->dBatch, sizeof(QcParams) * count));
+    QC_HIP(h0, hipMemcpy(h0->dBatch, blocks.data(), sizeof(QcParams) * count, hipMemcpyHostToDevice));
+    h0->batch_members.assign(hs, hs + count);
+    return 1;
+}
+
+extern "C" int qc_eval_F_jac_dev_multi(qc_handle* const* hs, int32_t count, const double* dZ, double* dF, double* dvals, void* stream) {
+    if (!hs || count < 1) return fail(nullptr, QC_ERR_INVALID, "qc_eval_F_jac_dev_multi: no handles");
+    for (int i = 0; i < count; ++i) if (!hs[i]) return fail(nullptr, QC_ERR_INVALID, "qc_eval_F_jac_dev_multi: NULL handle");
+    qc_handle* h0 = hs[0];
+    if (!dZ || (!dF && !dvals)) return fail(&h0->err, QC_ERR_INVALID, "qc_eval_F_jac_dev_multi: NULL buffer");
+    int rc;
+    if ((rc = check_align(h0, dZ, 8, "dZ"))) return rc;
+    if ((rc = check_align(h0, dF, 16, "dF"))) return rc;
+    if ((rc = check_align(h0, dvals, 16, "dvals"))) return rc;
+    const int ok = prepare_batch(hs, count, false);
+    if (ok < 0) return ok;
+    if (ok == 0 || h0->prm.n_int == 0) {   // shapes differ or not the batchable kernel: one launch per handle
+        for (int i = 0; i < count; ++i) if ((rc = qc_eval_F_jac_dev(hs[i], dZ, dF, dvals, stream))) return rc;
+        return QC_OK;
+    }
+    hipError_t e = qc_launch_mfma16_F_jac_batch(h0->prm, h0->dBatch, count, dZ, dF, dvals, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(&h0->err, QC_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    return QC_OK;
+}
+
+extern "C" int qc_eval_hess_dev_multi(qc_handle* const* hs, int32_t count, const double* dZ, const double* dmu, double* dhvals, void* stream) {
+    if (!hs || count < 1) return fail(nullptr, QC_ERR_INVALID, "qc_eval_hess_dev_multi: no handles");
+    for (int i = 0; i < count; ++i) if (!hs[i]) return fail(nullptr, QC_ERR_INVALID, "qc_eval_hess_dev_multi: NULL handle");
+    qc_handle* h0 = hs[0];
+    if (!dZ || !dmu || !dhvals) return fail(&h0->err, QC_ERR_INVALID, "qc_eval_hess_dev_multi: NULL buffer");
+    int rc;
+    if ((rc = check_align(h0, dZ, 8, "dZ"))) return rc;
+    if ((rc = check_align(h0, dmu, 8, "dmu"))) return rc;
+    if ((rc = check_align(h0, dhvals, 16, "dhvals"))) return rc;
+    const int ok = prepare_batch(hs, count, true);
+    if (ok < 0) return ok;
+    bool hess_ok = ok == 1 && h0->prm.n_int > 0;
+    for (int i = 0; hess_ok && i < count; ++i) hess_ok = hs[i]->prm.hess_nnz > 0 && qc_mfma_hess_supported(hs[i]->prm);
+    if (!hess_ok) {
+        for (int i = 0; i < count; ++i) if ((rc = qc_eval_hess_dev(hs[i], dZ, dmu, dhvals, stream))) return rc;
+        return QC_OK;
+    }
+    hipError_t e = qc_launch_mfma16_hess_batch(h0->prm, h0->dBatch, count, dZ, dmu, dhvals, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(&h0->err, QC_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
     return QC_OK;
 }
 

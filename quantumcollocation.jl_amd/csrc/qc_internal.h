@@ -60,6 +60,8 @@ struct qc_handle {
     double *dZ = nullptr, *dF = nullptr, *dJ = nullptr, *dMu = nullptr, *dH = nullptr;
     unsigned long long* dStamps = nullptr;
     double* hJc = nullptr;     // compact Jacobian values (one copy of the replicated blocks): pinned host staging, device-visible
+    QcParams* dBatch = nullptr;                // device copy of the parameter blocks of a batched launch led by this handle
+    std::vector<const qc_handle*> batch_members;
     struct qc_host_pool* pool = nullptr;       // worker threads of the compact transfer (created on first use)
     std::vector<hipEvent_t> chunk_events;
     int host_compact = 1;      // QC_HOST_COMPACT=0 disables the compact D2H path of the host-buffer entry points
@@ -87,6 +89,11 @@ hipError_t qc_launch_mfma_F_jac(const QcParams& P, const double* dZ, double* dF,
 size_t qc_mfma32_gx_doubles(const QcParams& P);
 void qc_mfma32_pack_G(const QcParams& P, const double* G_host, double* Gx_host);
 hipError_t qc_launch_mfma32_F_jac(const QcParams& P, const double* dZ, double* dF, double* dJ, hipStream_t st);
+bool qc_mfma16_batchable(const QcParams& P);
+hipError_t qc_launch_mfma16_F_jac_batch(const QcParams& P0, const QcParams* dPb, int count, const double* dZ, double* dF, double* dJ,
+                                        hipStream_t st);
+hipError_t qc_launch_mfma16_hess_batch(const QcParams& P0, const QcParams* dPb, int count, const double* dZ, const double* dMu, double* dH,
+                                       hipStream_t st);
 bool qc_mfma_exp_supported(const QcParams& P);
 hipError_t qc_launch_mfma_exp(const QcParams& P, const double* dZ, double* dF, double* dJ, hipStream_t st);
 bool qc_mfma32_hess_supported(const QcParams& P);

@@ -32,9 +32,11 @@ __device__ inline v4d sel(bool c, const v4d& a, const v4d& b) {
     return v4d{c ? a[0] : b[0], c ? a[1] : b[1], c ? a[2] : b[2], c ? a[3] : b[3]};
 }
 
-template <int kHM, bool KET>
-__global__ __launch_bounds__(64) void qc_mfma16_pade4_hess_kernel(const QcParams P, const double* __restrict__ Z,
-                                                                  const double* __restrict__ Mu, double* __restrict__ H) {
+template <int kHM, bool KET, bool BATCH>
+__global__ __launch_bounds__(64) void qc_mfma16_pade4_hess_kernel(const QcParams Pk, const double* __restrict__ Z,
+                                                                  const double* __restrict__ Mu, double* __restrict__ H,
+                                                                  const QcParams* __restrict__ Pb) {
+    const QcParams& P = BATCH ? Pb[blockIdx.y] : Pk;      // BATCH: one launch for several handles (qc_mfma_kernels.hip)
     __shared__ double red[kHVals * kHStride];
     __shared__ double tscr[16 * 17];
     const int lane = threadIdx.x;
@@ -224,19 +226,28 @@ bool qc_mfma_hess_supported(const QcParams& P) {
     return P.integrator == QC_PADE && P.p == 2 && P.n == 16 && P.nc <= 8 && P.m <= kHMmax;
 }
 
+hipError_t qc_launch_mfma16_hess_batch(const QcParams& P0, const QcParams* dPb, int count, const double* dZ, const double* dMu, double* dH,
+                                       hipStream_t st) {
+    const int grid = P0.n_int < 4096 ? P0.n_int : 4096;
+#define QC_B(HM_) hipLaunchKernelGGL((qc_mfma16_pade4_hess_kernel<HM_, false, true>), dim3(grid, count), dim3(64), 0, st, P0, dZ, dMu, dH, dPb)
+    if (P0.m <= 2) QC_B(2); else if (P0.m <= 4) QC_B(4); else if (P0.m <= 6) QC_B(6); else QC_B(8);
+#undef QC_B
+    return hipGetLastError();
+}
+
 hipError_t qc_launch_mfma_hess(const QcParams& P, const double* dZ, const double* dMu, double* dH, hipStream_t st) {
     if (P.n == 32) return qc_launch_mfma32_hess(P, dZ, dMu, dH, st);
     const int grid = P.n_int < 4096 ? P.n_int : 4096;
     if (P.nc != 8) {
-        if (P.m <= 2) hipLaunchKernelGGL((qc_mfma16_pade4_hess_kernel<2, true>), dim3(grid), dim3(64), 0, st, P, dZ, dMu, dH);
-        else if (P.m <= 4) hipLaunchKernelGGL((qc_mfma16_pade4_hess_kernel<4, true>), dim3(grid), dim3(64), 0, st, P, dZ, dMu, dH);
-        else if (P.m <= 6) hipLaunchKernelGGL((qc_mfma16_pade4_hess_kernel<6, true>), dim3(grid), dim3(64), 0, st, P, dZ, dMu, dH);
-        else hipLaunchKernelGGL((qc_mfma16_pade4_hess_kernel<8, true>), dim3(grid), dim3(64), 0, st, P, dZ, dMu, dH);
+        if (P.m <= 2) hipLaunchKernelGGL((qc_mfma16_pade4_hess_kernel<2, true, false>), dim3(grid), dim3(64), 0, st, P, dZ, dMu, dH, nullptr);
+        else if (P.m <= 4) hipLaunchKernelGGL((qc_mfma16_pade4_hess_kernel<4, true, false>), dim3(grid), dim3(64), 0, st, P, dZ, dMu, dH, nullptr);
+        else if (P.m <= 6) hipLaunchKernelGGL((qc_mfma16_pade4_hess_kernel<6, true, false>), dim3(grid), dim3(64), 0, st, P, dZ, dMu, dH, nullptr);
+        else hipLaunchKernelGGL((qc_mfma16_pade4_hess_kernel<8, true, false>), dim3(grid), dim3(64), 0, st, P, dZ, dMu, dH, nullptr);
         return hipGetLastError();
     }
-    if (P.m <= 2) hipLaunchKernelGGL((qc_mfma16_pade4_hess_kernel<2, false>), dim3(grid), dim3(64), 0, st, P, dZ, dMu, dH);
-    else if (P.m <= 4) hipLaunchKernelGGL((qc_mfma16_pade4_hess_kernel<4, false>), dim3(grid), dim3(64), 0, st, P, dZ, dMu, dH);
-    else if (P.m <= 6) hipLaunchKernelGGL((qc_mfma16_pade4_hess_kernel<6, false>), dim3(grid), dim3(64), 0, st, P, dZ, dMu, dH);
-    else hipLaunchKernelGGL((qc_mfma16_pade4_hess_kernel<8, false>), dim3(grid), dim3(64), 0, st, P, dZ, dMu, dH);
+    if (P.m <= 2) hipLaunchKernelGGL((qc_mfma16_pade4_hess_kernel<2, false, false>), dim3(grid), dim3(64), 0, st, P, dZ, dMu, dH, nullptr);
+    else if (P.m <= 4) hipLaunchKernelGGL((qc_mfma16_pade4_hess_kernel<4, false, false>), dim3(grid), dim3(64), 0, st, P, dZ, dMu, dH, nullptr);
+    else if (P.m <= 6) hipLaunchKernelGGL((qc_mfma16_pade4_hess_kernel<6, false, false>), dim3(grid), dim3(64), 0, st, P, dZ, dMu, dH, nullptr);
+    else hipLaunchKernelGGL((qc_mfma16_pade4_hess_kernel<8, false, false>), dim3(grid), dim3(64), 0, st, P, dZ, dMu, dH, nullptr);
     return hipGetLastError();
 }

@@ -104,9 +104,14 @@ __device__ inline v4d lds_get(const double* __restrict__ base, int lane) {
     return v4d{lo[0], lo[1], hi[0], hi[1]};
 }
 
-template <bool JAC, int MODE, bool DIAG, int kMU, bool KET>
-__global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel(const QcParams P, const double* __restrict__ Z,
-                                                                      double* __restrict__ F, double* __restrict__ J) {
+// BATCH: blockIdx.y selects one of several handles' parameter blocks in device memory (the systems of a sampling
+// problem: same shapes, different generators and output slots) so that they share ONE launch; the parameters are then
+// read with scalar loads from global memory instead of the kernarg segment, everything else is identical.
+template <bool JAC, int MODE, bool DIAG, int kMU, bool KET, bool BATCH>
+__global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel(const QcParams Pk, const double* __restrict__ Z,
+                                                                      double* __restrict__ F, double* __restrict__ J,
+                                                                      const QcParams* __restrict__ Pb) {
+    const QcParams& P = BATCH ? Pb[blockIdx.y] : Pk;
     constexpr int kLdsBlock = kLdsGk + kMU * 256;
     __shared__ __attribute__((aligned(16))) double sm_all[JAC ? kIntervalsPerWG * kLdsBlock : 2];
     const int tid = threadIdx.x;
@@ -426,13 +431,13 @@ void qc_mfma_pack_G(const QcParams& P, const double* G, double* Gx) {
 template <bool JAC, bool DIAG, int MU>
 static void launch16m(const QcParams& P, const double* dZ, double* dF, double* dJ, hipStream_t st, int grid, int threads) {
     if (P.nc != 8) {   // K < 8 kets: the column-masked instantiation (non-temporal stores, no diagnostics)
-        hipLaunchKernelGGL((qc_mfma16_pade4_kernel<JAC, 2, false, MU, true>), dim3(grid), dim3(threads), 0, st, P, dZ, dF, dJ);
+        hipLaunchKernelGGL((qc_mfma16_pade4_kernel<JAC, 2, false, MU, true, false>), dim3(grid), dim3(threads), 0, st, P, dZ, dF, dJ, nullptr);
         return;
     }
     switch (P.store_mode) {
-        case 0: hipLaunchKernelGGL((qc_mfma16_pade4_kernel<JAC, 0, DIAG, MU, false>), dim3(grid), dim3(threads), 0, st, P, dZ, dF, dJ); break;
-        case 1: hipLaunchKernelGGL((qc_mfma16_pade4_kernel<JAC, 1, DIAG, MU, false>), dim3(grid), dim3(threads), 0, st, P, dZ, dF, dJ); break;
-        default: hipLaunchKernelGGL((qc_mfma16_pade4_kernel<JAC, 2, DIAG, MU, false>), dim3(grid), dim3(threads), 0, st, P, dZ, dF, dJ); break;
+        case 0: hipLaunchKernelGGL((qc_mfma16_pade4_kernel<JAC, 0, DIAG, MU, false, false>), dim3(grid), dim3(threads), 0, st, P, dZ, dF, dJ, nullptr); break;
+        case 1: hipLaunchKernelGGL((qc_mfma16_pade4_kernel<JAC, 1, DIAG, MU, false, false>), dim3(grid), dim3(threads), 0, st, P, dZ, dF, dJ, nullptr); break;
+        default: hipLaunchKernelGGL((qc_mfma16_pade4_kernel<JAC, 2, DIAG, MU, false, false>), dim3(grid), dim3(threads), 0, st, P, dZ, dF, dJ, nullptr); break;
     }
 }
 
@@ -444,6 +449,30 @@ static void launch16(const QcParams& P, const double* dZ, double* dF, double* dJ
     else if (P.m <= 4) launch16m<JAC, DIAG, 4>(P, dZ, dF, dJ, st, grid, threads);
     else if (P.m <= 6) launch16m<JAC, DIAG, 6>(P, dZ, dF, dJ, st, grid, threads);
     else launch16m<JAC, DIAG, 8>(P, dZ, dF, dJ, st, grid, threads);
+}
+
+// One launch for `count` handles (gridDim.y = count).  The caller has checked qc_mfma16_batchable for every handle.
+bool qc_mfma16_batchable(const QcParams& P) {
+    return P.integrator == QC_PADE && P.p == 2 && P.n == 16 && P.nc == 8 && P.m <= 32 && P.store_mode == 2 && P.stamps == nullptr &&
+           P.dbg_skip == 0 && P.Gx != nullptr;
+}
+
+template <bool JAC, int MU>
+static void launch16_batch(const QcParams& P0, const QcParams* dPb, int count, const double* dZ, double* dF, double* dJ, hipStream_t st, int grid,
+                           int threads) {
+    hipLaunchKernelGGL((qc_mfma16_pade4_kernel<JAC, 2, false, MU, false, true>), dim3(grid, count), dim3(threads), 0, st, P0, dZ, dF, dJ, dPb);
+}
+
+hipError_t qc_launch_mfma16_F_jac_batch(const QcParams& P0, const QcParams* dPb, int count, const double* dZ, double* dF, double* dJ,
+                                        hipStream_t st) {
+    const int n_wg = dJ ? (P0.n_int + kIntervalsPerWG - 1) / kIntervalsPerWG : P0.n_int;
+    const int grid = n_wg < kMaxGrid ? n_wg : kMaxGrid;
+    const int threads = dJ ? kThreads : 64;
+#define QC_B(J_, MU_) launch16_batch<J_, MU_>(P0, dPb, count, dZ, dF, dJ, st, grid, threads)
+    if (dJ) { if (P0.m <= 2) QC_B(true, 2); else if (P0.m <= 4) QC_B(true, 4); else if (P0.m <= 6) QC_B(true, 6); else QC_B(true, 8); }
+    else    { if (P0.m <= 2) QC_B(false, 2); else if (P0.m <= 4) QC_B(false, 4); else if (P0.m <= 6) QC_B(false, 6); else QC_B(false, 8); }
+#undef QC_B
+    return hipGetLastError();
 }
 
 hipError_t qc_launch_mfma_F_jac(const QcParams& P, const double* dZ, double* dF, double* dJ, hipStream_t st) {

@@ -343,6 +343,7 @@ class ComposedQuantumDynamics(QuantumDynamics):
             ro += int(x.ddim)
             jo += int(x.jac_nnz_interval)
             ho += int(x.hess_nnz_interval)
+        self._handles = (C.c_void_p * len(self._parts))(*[p[2] for p in self._parts])
         n_int = int(self._parts[0][3].n_intervals)
         d = _lib.qc_dims_t()
         d.n_rows, d.n_cols, d.ddim = self._parts[0][3].n_rows, self._parts[0][3].n_cols, rows
@@ -390,19 +391,18 @@ class ComposedQuantumDynamics(QuantumDynamics):
 
     def F_dF_device(self, Z: torch.Tensor, F: Optional[torch.Tensor], J: Optional[torch.Tensor], stream=None) -> None:
         st = stream if stream is not None else torch.cuda.current_stream(self.device)
-        for desc, keep, h, dims in self._parts:
-            _lib.check(_lib.lib.qc_eval_F_jac_dev(
-                h, self._dev_ptr(Z, self.dims.Z_len, "Z"), self._dev_ptr(F, self.dims.F_len, "F"),
-                self._dev_ptr(J, self.dims.jac_nnz, "J"), C.c_void_p(st.cuda_stream)), h)
+        # one launch for all systems when their shapes allow it (qc_eval_F_jac_dev_multi falls back to one per handle)
+        _lib.check(_lib.lib.qc_eval_F_jac_dev_multi(
+            self._handles, len(self._parts), self._dev_ptr(Z, self.dims.Z_len, "Z"), self._dev_ptr(F, self.dims.F_len, "F"),
+            self._dev_ptr(J, self.dims.jac_nnz, "J"), C.c_void_p(st.cuda_stream)), self._parts[0][2])
 
     def mu_d2F_device(self, Z: torch.Tensor, mu: torch.Tensor, H: torch.Tensor, stream=None) -> None:
         if not self.dims.hess_nnz:
             raise _lib.QCollocError(_lib.QC_ERR_UNSUPPORTED, "no analytic Hessian for this integrator list")
         st = stream if stream is not None else torch.cuda.current_stream(self.device)
-        for desc, keep, h, dims in self._parts:
-            _lib.check(_lib.lib.qc_eval_hess_dev(
-                h, self._dev_ptr(Z, self.dims.Z_len, "Z"), self._dev_ptr(mu, self.dims.n_rows, "mu"),
-                self._dev_ptr(H, self.dims.hess_nnz, "H"), C.c_void_p(st.cuda_stream)), h)
+        _lib.check(_lib.lib.qc_eval_hess_dev_multi(
+            self._handles, len(self._parts), self._dev_ptr(Z, self.dims.Z_len, "Z"), self._dev_ptr(mu, self.dims.n_rows, "mu"),
+            self._dev_ptr(H, self.dims.hess_nnz, "H"), C.c_void_p(st.cuda_stream)), self._parts[0][2])
 
     def bind_F_dF_device(self, Z, F, J, stream=None):
         return lambda: (self.F_dF_device(Z, F, J, stream), 0)[1]
