@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
 #include <mutex>
 #include <thread>
@@ -333,6 +334,8 @@ extern "C" int qc_create(const qc_desc* d, qc_handle** out) {
         return fail(nullptr, QC_ERR_UNSUPPORTED, "qc_create: MFMA kernels need the Pade integrator of order 4 and 2N in {16, 32}");
     }
     if (kernel != QC_KERNEL_MFMA && kernel != QC_KERNEL_LDS) { delete h; return fail(nullptr, QC_ERR_INVALID, "qc_create: unknown kernel id"); }
+    static std::atomic<unsigned long long> next_serial{1};
+    h->serial = next_serial.fetch_add(1);
     h->kernel = kernel;
     h->dims.kernel = kernel;
 
@@ -475,7 +478,7 @@ static int prepare_batch(qc_handle* const* hs, int32_t count, bool hessian) {
         if (h->prm.n_int != h0->prm.n_int || h->prm.t_begin != h0->prm.t_begin || h->prm.zdim != h0->prm.zdim || h->prm.m != h0->prm.m) return 0;
     }
     bool same = h0->dBatch != nullptr && (int)h0->batch_members.size() == count;
-    for (int i = 0; same && i < count; ++i) same = h0->batch_members[i] == hs[i];
+    for (int i = 0; same && i < count; ++i) same = h0->batch_members[i] == hs[i]->serial;
     if (same) return 1;
     QC_HIP(h0, hipSetDevice(h0->device));
     if (h0->dBatch) { (void)hipFree(h0->dBatch); h0->dBatch = nullptr; }
@@ -483,7 +486,8 @@ static int prepare_batch(qc_handle* const* hs, int32_t count, bool hessian) {
     for (int i = 0; i < count; ++i) blocks[i] = hs[i]->prm;
     QC_HIP(h0, hipMalloc((void**)&h0->dBatch, sizeof(QcParams) * count));
     QC_HIP(h0, hipMemcpy(h0->dBatch, blocks.data(), sizeof(QcParams) * count, hipMemcpyHostToDevice));
-    h0->batch_members.assign(hs, hs + count);
+    h0->batch_members.clear();
+    for (int i = 0; i < count; ++i) h0->batch_members.push_back(hs[i]->serial);
     return 1;
 }
 

@@ -61,7 +61,8 @@ struct qc_handle {
     unsigned long long* dStamps = nullptr;
     double* hJc = nullptr;     // compact Jacobian values (one copy of the replicated blocks): pinned host staging, device-visible
     QcParams* dBatch = nullptr;                // device copy of the parameter blocks of a batched launch led by this handle
-    std::vector<const qc_handle*> batch_members;
+    std::vector<unsigned long long> batch_members;   // serial numbers of the handles the cached blocks belong to
+    unsigned long long serial = 0;             // unique per created handle (a recycled address is not the same handle)
     struct qc_host_pool* pool = nullptr;       // worker threads of the compact transfer (created on first use)
     std::vector<hipEvent_t> chunk_events;
     int host_compact = 1;      // QC_HOST_COMPACT=0 disables the compact D2H path of the host-buffer entry points
