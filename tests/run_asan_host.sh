@@ -1,0 +1,19 @@
+#!/bin/bash
+# Host-side AddressSanitizer pass (CPU only: GPU ASan is not available on this pool).  Rebuilds qc_host.cpp with
+# -fsanitize=address (the device objects are reused), runs the tests that exercise the host-only entry points
+# (descriptor validation, dims, structures, iso helpers, terms descriptors) and restores the normal library.
+set -eu
+R=$(cd "$(dirname "$0")/.." && pwd)
+C=$R/quantumcollocation.jl_amd/csrc
+W=$(mktemp -d)
+make -C "$C" >/dev/null
+cp "$C/libqcolloc_hip.so" "$W/orig.so"
+trap 'cp "$W/orig.so" "$C/libqcolloc_hip.so"; rm -rf "$W"' EXIT
+/opt/rocm/bin/hipcc -O1 -g -std=c++17 -fPIC --offload-arch=gfx950 -I"$R/include" -fsanitize=address -fno-omit-frame-pointer \
+    -x hip -c "$C/qc_host.cpp" -o "$W/qc_host.o" 2>/dev/null
+OBJS=$(ls "$C"/*.o | grep -v qc_host.o)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -fsanitize=address -o "$C/libqcolloc_hip.so" "$W/qc_host.o" $OBJS
+ASAN=$(/opt/rocm/lib/llvm/bin/clang -print-file-name=libclang_rt.asan-x86_64.so)
+cd "$R"
+LD_PRELOAD=$ASAN ASAN_OPTIONS=detect_leaks=0:verify_asan_link_order=0 python -m pytest tests/test_abi.py tests/test_terms.py tests/test_density.py \
+    -q -m "not gpu" -p no:cacheprovider
