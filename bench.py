@@ -96,11 +96,18 @@ def main():
                      "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
         sys.exit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # QC_BENCH_BACKEND=gloo lets several ranks share one GPU: a functional check of the sharded path on a 1-GPU box
+    # (RCCL refuses two ranks on one device); the driver's multi-GPU runs use the default, nccl = RCCL.
+    backend = os.environ.get("QC_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     qc = g.load_package()
     from qcolloc_amd.sharding import ShardedDynamics
@@ -109,7 +116,7 @@ def main():
     t_per_gpu = args.T or (T_PER_GPU if args.config in (3, 4) else spec.T)
     T_total = t_per_gpu * world
     inp = qc.config_inputs(args.config, T=T_total)
-    sd = ShardedDynamics(inp.integrators, inp.traj, rank, world, device=local_rank, kernel=args.kernel)
+    sd = ShardedDynamics(inp.integrators, inp.traj, rank, world, device=dev_index, kernel=args.kernel)
     dyn = sd.local
     dims = dyn.dims
     n_int = int(dims.n_intervals)
@@ -155,7 +162,7 @@ def main():
     assert status[0] == 0, "qc_eval_F_jac_dev reported an error during the timed loop"
     stream_ms = ev0.elapsed_time(ev1)
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
