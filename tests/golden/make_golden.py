@@ -27,3 +27,19 @@ hr, hc = o.hess_structure(prob)
 np.savez(os.path.join(HERE, "fixture_outputs.npz"), F=o.F(prob, Zv), dF=o.dF(prob, Zv), dF_rows=rows, dF_cols=cols,
          mu_d2F=o.mu_d2F(prob, Zv, mu), mu_d2F_rows=hr, mu_d2F_cols=hc)
 print("wrote fixture_outputs.npz")
+
+# Rows 8f of the scope table on the same fixture: exponential integrator, rollout, final-knot fidelity against the
+# fixture's goal, and the regularisers on a / da plus a minimum-time term.  Build-oracle outputs as well.
+pe = o.Problem(N=2, m=2, T=5, zdim=15, off_U=0, off_a=8, off_dt=14, G_drift=o.generator(0.1 * Zp),
+               G_drives=np.array([o.generator(X), o.generator(Y)]), integrator=o.EXPONENTIAL,
+               derivs=[o.DerivSpec(8, 10, 2), o.DerivSpec(10, 12, 2)])
+init = np.array(fx["initial_U"], dtype=float)      # the fixture's own initial / goal iso-vecs (test_utils.jl:102-107)
+goal = np.array(fx["goal_U"], dtype=float)
+roll = o.rollout(pe, Zv, init)
+fid, gfid, hfid = o.fidelity_value_grad_hess(roll[:, -1], goal)
+tm = o.Terms(T=5, zdim=15, off_dt=14, reg_index=np.arange(8, 12), reg_R=np.array([1e-2, 1e-2, 2e-2, 3e-2]), D=1.5, n_mt=4)
+thr, thc = o.terms_hess_structure(tm)
+np.savez(os.path.join(HERE, "fixture_outputs_8f.npz"), exp_F=o.F(pe, Zv), exp_dF=o.dF(pe, Zv), rollout=roll, init=init, goal=goal,
+         fidelity=fid, fidelity_grad=gfid, fidelity_hess=hfid, terms_J=o.terms_value(tm, Zv), terms_grad=o.terms_grad(tm, Zv),
+         terms_hess=o.terms_hess(tm, Zv), terms_hess_rows=thr, terms_hess_cols=thc, terms_R=tm.reg_R, terms_index=tm.reg_index)
+print("wrote fixture_outputs_8f.npz")

@@ -80,3 +80,29 @@ def test_c_oracle_kets(oracle, coracle, K):
         if integ == oracle.PADE:
             mu = np.random.default_rng(3).standard_normal(prob.n_rows)
             np.testing.assert_allclose(co.mu_d2F(Z, mu), oracle.mu_d2F(prob, Z, mu), rtol=1e-11, atol=1e-12)
+
+
+def test_oracle_reproduces_the_8f_golden_vectors(oracle):
+    """tests/golden/fixture_outputs_8f.npz (build-oracle outputs on the reference's data fixture for the §8f rows:
+    exponential integrator, rollout, fidelity, regularisers + minimum-time term) is reproducible from the oracle."""
+    import json
+    fx = json.load(open(os.path.join(GOLD, "named_trajectory_type_1.json")))
+    gold = np.load(os.path.join(GOLD, "fixture_outputs_8f.npz"))
+    Zv = np.array(fx["data"]).reshape(-1, order="F")
+    X = np.array([[0, 1], [1, 0]], dtype=complex)
+    Y = np.array([[0, -1j], [1j, 0]])
+    Zp = np.array([[1, 0], [0, -1]], dtype=complex)
+    pe = oracle.Problem(N=2, m=2, T=5, zdim=15, off_U=0, off_a=8, off_dt=14, G_drift=oracle.generator(0.1 * Zp),
+                        G_drives=np.array([oracle.generator(X), oracle.generator(Y)]), integrator=oracle.EXPONENTIAL,
+                        derivs=[oracle.DerivSpec(8, 10, 2), oracle.DerivSpec(10, 12, 2)])
+    np.testing.assert_allclose(oracle.F(pe, Zv), gold["exp_F"], rtol=1e-13, atol=1e-15)
+    np.testing.assert_allclose(oracle.dF(pe, Zv), gold["exp_dF"], rtol=1e-13, atol=1e-15)
+    roll = oracle.rollout(pe, Zv, gold["init"])
+    np.testing.assert_allclose(roll, gold["rollout"], rtol=1e-13, atol=1e-15)
+    f, g, H = oracle.fidelity_value_grad_hess(roll[:, -1], gold["goal"])
+    assert abs(f - float(gold["fidelity"])) < 1e-14
+    np.testing.assert_allclose(g, gold["fidelity_grad"], rtol=1e-12, atol=1e-14)
+    tm = oracle.Terms(T=5, zdim=15, off_dt=14, reg_index=gold["terms_index"], reg_R=gold["terms_R"], D=1.5, n_mt=4)
+    assert abs(oracle.terms_value(tm, Zv) - float(gold["terms_J"])) < 1e-15
+    np.testing.assert_allclose(oracle.terms_grad(tm, Zv), gold["terms_grad"], rtol=1e-14, atol=1e-16)
+    np.testing.assert_allclose(oracle.terms_hess(tm, Zv), gold["terms_hess"], rtol=1e-14, atol=1e-16)
