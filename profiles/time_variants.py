@@ -54,6 +54,8 @@ time_dyn("config 3 Pade-6 (lds)", qc.unitary_smooth_pulse_inputs(s3, qc.GATES["T
 time_dyn("config 3 exponential (mfma16-exp)", qc.unitary_smooth_pulse_inputs(s3, qc.GATES["TOFFOLI"], 1000, integrator="exponential"))
 time_dyn("config 3 exponential (lds)", qc.unitary_smooth_pulse_inputs(s3, qc.GATES["TOFFOLI"], 1000, integrator="exponential"), reps=30, kernel="lds")
 time_dyn("config 5 Pade-4 (mfma32)", qc.config_inputs(5))
+time_dyn("config 5 exponential (mfma32-exp)", qc.unitary_smooth_pulse_inputs(qc.multi_qubit_system(4), qc.GATES["QFT16"], 500, integrator="exponential"), reps=50)
+time_dyn("config 5 exponential (lds)", qc.unitary_smooth_pulse_inputs(qc.multi_qubit_system(4), qc.GATES["QFT16"], 500, integrator="exponential"), reps=5, kernel="lds")
 s2 = qc.multi_qubit_system(2)
 time_dyn("config 2 Pade-4 (lds)", qc.config_inputs(2))
 time_dyn("config 2 exponential (lds)", qc.unitary_smooth_pulse_inputs(s2, qc.GATES["CX"], 200, integrator="exponential"))

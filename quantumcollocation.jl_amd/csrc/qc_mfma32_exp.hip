@@ -1,0 +1,302 @@
+// f64-MFMA kernel for the EXPONENTIAL integrator at 2N = 32 (4 qubits), up to 8 drives: residual
+//     delta = U_t+1 - exp(h G(a_t)) U_t                                          (reference README.md:79)
+// and the Jacobian blocks  d/dU_t = -I_N (x) E,  d/dU_t+1 = I,  d/da_j = -L_j U_t,  d/dh = -G E U_t   (E = exp(h G),
+// L_j = L_exp(h G; h G_j)).  The 2N = 16 kernel (qc_mfma_exp.hip) explains the algorithm: scaling and squaring with
+// ||Y||_1 <= 1/4, a degree-10 Taylor polynomial and its Frechet derivatives in Horner form on R_k = P_k / (k-1)!,
+//     R_k = Y R_k+1 + I/(k-1)!          R'_k,j = G_j R_k+1 + Y R'_k+1,j,
+// squarings E <- E E, L_j <- E L_j + L_j E with the left factors obtained as LDS-transposed tiles (a D-layout tile read
+// as the A operand acts as its transpose), the factor h / 2^sq applied to the outputs once.
+//
+// Here every matrix is 2 x 2 tiles of 16 x 16 and one 512-thread workgroup (8 wavefronts) serves one interval:
+//   wave k      owns drive k: its four A-layout image tiles of G_j and its chain R'_j (4 tiles) stay in registers;
+//   waves 0-3   additionally own one tile of the shared chain R (and of E in the squarings), published through a
+//               double-buffered LDS block; one barrier per Horner step / squaring.
+// Per step a drive wave issues 64 MFMAs (16 products), the R owners 8 more.  Outputs leave transposed (lane <-> row,
+// whole 128-byte lines): wave w stores copies w and w + 8 of -E from the transposed tiles of E, its drive's columns as
+// (L_j U_t)^T = U_t^T L_j^T; wave 0 the residual and d/dh.  About 7200 MFMAs per interval at m = 8 with 3 squarings:
+// MFMA-pipe-bound (~110 us floor for config 5 at T = 500); the LDS kernel needs 4.1 ms for the same problem.
+#include "qc_mfma_common.h"
+
+namespace {
+
+using namespace qc_mfma;
+
+constexpr int kE32Deg = 10;
+constexpr int kE32Mmax = 8;
+constexpr int kE32Threads = 512;
+
+__device__ inline v4d e32_tile(const double* __restrict__ base, int tile, int lane) {   // [tile][pair][lane][2], global or LDS
+    const v2d* p = reinterpret_cast<const v2d*>(base) + tile * 128 + lane;
+    const v2d lo = p[0], hi = p[64];
+    return v4d{lo[0], lo[1], hi[0], hi[1]};
+}
+__device__ inline void e32_put(double* __restrict__ base, int tile, int lane, const v4d& x) {
+    v2d* p = reinterpret_cast<v2d*>(base) + tile * 128 + lane;
+    p[0] = v2d{x[0], x[1]};
+    p[64] = v2d{x[2], x[3]};
+}
+template <int CTRL>
+__device__ inline double e32_dpp(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ inline double e32_readlane(double x, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
+}
+
+// acc (+)= A0 * B0 + A1 * B1 for one output tile: one chain of 8 MFMAs on top of `c`
+__device__ __forceinline__ v4d e32_mac2(const v4d& a0, const v4d& b0, const v4d& a1, const v4d& b1, v4d c) {
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) c = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[kk], b0[kk], c, 0, 0, 0);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) c = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[kk], b1[kk], c, 0, 0, 0);
+    return c;
+}
+
+// Q'[I][J] = sum_K ( A1[I][K] R[K][J] + A2[I][K] Q[K][J] )   for the four output tiles, MFMAs interleaved over the tiles.
+// Tiles of a 32 x 32 matrix are indexed 2 * (row block) + (column block).
+__device__ __forceinline__ void e32_chain4(const v4d (&A1)[4], const v4d (&R)[4], const v4d (&A2)[4], const v4d (&Q)[4], v4d (&out)[4]) {
+    const v4d z = {0.0, 0.0, 0.0, 0.0};
+    v4d acc[4] = {z, z, z, z};
+#pragma unroll
+    for (int K = 0; K < 2; ++K) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int I = t >> 1, J = t & 1;
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(A1[2 * I + K][kk], R[2 * K + J][kk], acc[t], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int K = 0; K < 2; ++K) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int I = t >> 1, J = t & 1;
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(A2[2 * I + K][kk], Q[2 * K + J][kk], acc[t], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) out[t] = acc[t];
+}
+
+// lane (g, j) reg r = X[rowbase + j][colbase + 4 r + g] of a column-major block with `ld` rows per column at p
+__device__ inline void e32_store_T(double* __restrict__ p, const v4d& x, int ld, int rowbase, int colbase, int g, int j) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) qc_st8m<2>(p + (size_t)(colbase + 4 * r + g) * ld + rowbase + j, x[r]);
+}
+
+template <bool JAC>
+__global__ __launch_bounds__(kE32Threads, 1) void qc_mfma32_exp_kernel(const QcParams P, const double* __restrict__ Z,
+                                                                       double* __restrict__ F, double* __restrict__ J) {
+    __shared__ __attribute__((aligned(16))) double GL[4 * 256];          // G (unscaled), A-layout tiles 2I+K
+    __shared__ __attribute__((aligned(16))) double RL[2][4 * 256];       // the shared chain R / E, D-layout tiles 2K+J, double-buffered
+    __shared__ double TS[8 * 16 * 17];                                   // per-wave transpose scratch
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = P.m;
+    const int g = lane >> 4, j = lane & 15;
+    const bool ft = P.off_dt >= 0;
+    const bool drive = JAC && w < m;
+    const double* __restrict__ GxA = P.Gx;                               // A-layout images [mat][2I+K]
+    const v4d IdB = identity_B(g, j);
+    const v4d zero = {0.0, 0.0, 0.0, 0.0};
+    double* __restrict__ scr = TS + w * (16 * 17);
+
+    const int b = qc_xcd_remap((int)blockIdx.x, P.n_int);
+    const long long t = P.t_begin + b;
+    const double* __restrict__ z0 = Z + t * (long long)P.zdim;
+    const double* __restrict__ z1 = z0 + P.zdim;
+    double* __restrict__ Jb = JAC ? J + (size_t)b * P.J_stride + P.J_off : nullptr;
+    double* __restrict__ Fb = F ? F + (size_t)b * P.F_stride + P.F_off : nullptr;
+    const double h = ft ? z0[P.off_dt] : P.dt_fixed;
+
+    // ---- loads: this wave's half tile of the generator images (assembly), its drive's images, U_t ---------------------
+    v4d Gj[4];
+    {
+        const int kmat = drive ? w + 1 : 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Gj[q] = e32_tile(GxA + (size_t)kmat * 1024, q, lane);
+    }
+    v4d U[2];
+#pragma unroll
+    for (int I = 0; I < 2; ++I) {
+        const double* up = z0 + P.off_U + j * 32 + 16 * I + g;
+        U[I] = v4d{up[0], up[4], up[8], up[12]};
+    }
+    {
+        const v2d* __restrict__ ab = reinterpret_cast<const v2d*>(GxA) + (w >> 1) * 128 + (w & 1) * 64 + lane;
+        v2d img[kE32Mmax + 1];
+        double ak[kE32Mmax];
+#pragma unroll
+        for (int u = 0; u <= kE32Mmax; ++u) img[u] = ab[(size_t)(u <= m ? u : 0) * 512];
+#pragma unroll
+        for (int u = 0; u < kE32Mmax; ++u) ak[u] = z0[P.off_a + (u < m ? u : 0)];
+        v2d Gh = img[0];
+#pragma unroll
+        for (int u = 0; u < kE32Mmax; ++u) Gh += (u < m ? ak[u] : 0.0) * img[u + 1];
+        reinterpret_cast<v2d*>(GL)[(w >> 1) * 128 + (w & 1) * 64 + lane] = Gh;
+    }
+    __syncthreads();
+
+    // ---- ||h G||_1 (every wave, redundantly): lane (g, i) reg kk of tile (I, K) holds G[16I+i][16K+4kk+g] ---------------
+    v4d Y[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) Y[q] = e32_tile(GL, q, lane);
+    int sq = 0;
+    {
+        double best = 0.0;
+        bool bad = false;
+#pragma unroll
+        for (int K = 0; K < 2; ++K) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                double c = fabs(h * Y[K][kk]) + fabs(h * Y[2 + K][kk]);
+                c += e32_dpp<0x128>(c);
+                c += e32_dpp<0x124>(c);
+                c += e32_dpp<0x122>(c);
+                c += e32_dpp<0x121>(c);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double v = e32_readlane(c, 16 * r);
+                    if (!(v == v) || v > 1e300) bad = true;
+                    best = fmax(best, v);
+                }
+            }
+        }
+        if (!bad && best > 0.25) {
+            int e;
+            (void)frexp(best / 0.25, &e);
+            sq = e;
+            if (ldexp(0.25, e - 1) >= best) sq = e - 1;
+            sq = sq < 0 ? 0 : (sq > 60 ? 60 : sq);
+        }
+    }
+    const double sc = ldexp(1.0, -sq);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) Y[q] = (h * sc) * Y[q];
+
+    // ---- Horner: R_deg+1 = I/deg!, R' = 0 --------------------------------------------------------------------------------
+    double fact = 1.0;
+#pragma unroll
+    for (int k = 2; k <= kE32Deg; ++k) fact *= (double)k;
+    double ck = 1.0 / fact;
+    v4d R[4] = {ck * IdB, zero, zero, ck * IdB};          // tiles (0,0), (0,1), (1,0), (1,1)
+    v4d Q[4] = {zero, zero, zero, zero};
+    int cur = 0;
+#pragma unroll 1
+    for (int k = kE32Deg; k >= 1; --k) {
+        ck *= (double)k;                                   // 1/(k-1)!
+        if (w < 4) {                                       // tile (I, J) of R_k = Y R_k+1 + ck I
+            const int I = w >> 1, Jt = w & 1;
+            const v4d c0 = I == Jt ? ck * IdB : zero;
+            const v4d rn = e32_mac2(Y[2 * I], R[Jt], Y[2 * I + 1], R[2 + Jt], c0);
+            e32_put(RL[cur ^ 1], w, lane, rn);
+        }
+        if (drive) e32_chain4(Gj, R, Y, Q, Q);
+        __syncthreads();
+        cur ^= 1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) R[q] = e32_tile(RL[cur], q, lane);
+    }
+    // ---- squarings: E <- E E, L_j <- E L_j + L_j E (left factors = LDS-transposed tiles) -------------------------------------
+    for (int s = 0; s < sq; ++s) {
+        v4d Et[4], Lt[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Et[q] = lds_transpose16(scr, R[q], g, j);     // Et[2I+K] read as A acts as E[I][K]
+        if (drive) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Lt[q] = lds_transpose16(scr, Q[q], g, j);
+        }
+        if (w < 4) {
+            const int I = w >> 1, Jt = w & 1;
+            const v4d en = e32_mac2(Et[2 * I], R[Jt], Et[2 * I + 1], R[2 + Jt], zero);
+            e32_put(RL[cur ^ 1], w, lane, en);
+        }
+        if (drive) {
+            v4d Ln[4];
+            e32_chain4(Et, Q, Lt, R, Ln);                  // E L_j + L_j E
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Q[q] = Ln[q];
+        }
+        __syncthreads();
+        cur ^= 1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) R[q] = e32_tile(RL[cur], q, lane);
+    }
+
+    // ---- outputs -----------------------------------------------------------------------------------------------------------
+    v4d Et[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) Et[q] = lds_transpose16(scr, R[q], g, j);         // transposed tiles: A operands acting as E[I][K], and what is stored
+    if constexpr (JAC) {
+        // copies w and w + 8 of -E:  Et[2K+J] lane (g, j) reg r = E[16K+j][16J+4r+g]
+        double* pF = Jb + P.jo_F;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            double* p = pF + (size_t)(w + 8 * c) * 1024;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) e32_store_T(p, -Et[q], 32, 16 * (q >> 1), 16 * (q & 1), g, j);
+        }
+        if (w == 7) for (int i = lane; i < P.s; i += 64) Jb[P.jo_B + i] = 1.0;
+        if (drive) {
+            // d/da_j = -(h/2^sq) L_j U_t, transposed: (L_j U_t)^T[.., 16J..] = sum_K U_t[K]^T (L_j^T)[K][J],  (L_j^T)[K][J] = (L_j[J][K])^T
+            v4d Lt[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Lt[q] = lds_transpose16(scr, Q[q], g, j);     // Lt[2I+K] = (L_j[I][K])^T in D layout
+            const double fac = -(h * sc);
+            double* pa = Jb + P.jo_a + (size_t)w * 512;
+#pragma unroll
+            for (int Jt = 0; Jt < 2; ++Jt) {
+                const v4d x = e32_mac2(U[0], Lt[2 * Jt], U[1], Lt[2 * Jt + 1], zero);   // K = 0: (L_j[J][0])^T, K = 1: (L_j[J][1])^T
+#pragma unroll
+                for (int r = 0; r < 4; ++r) qc_st8m<2>(pa + (4 * r + g) * 32 + 16 * Jt + j, fac * x[r]);
+            }
+        }
+    }
+    if (w == 0) {
+        // E U_t, the residual, d/dh = -G E U_t (transposed for the stores through the LDS scratch)
+        v4d EU[2];
+#pragma unroll
+        for (int I = 0; I < 2; ++I) EU[I] = e32_mac2(Et[2 * I], U[0], Et[2 * I + 1], U[1], zero);
+        if (Fb) {
+#pragma unroll
+            for (int I = 0; I < 2; ++I) {
+                const double* up = z1 + P.off_U + j * 32 + 16 * I + g;
+                const v4d u1 = {up[0], up[4], up[8], up[12]};
+                const v4d dT = lds_transpose16(scr, u1 - EU[I], g, j);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) qc_st8m<2>(Fb + (4 * r + g) * 32 + 16 * I + j, dT[r]);
+            }
+        }
+        if (JAC && ft) {
+#pragma unroll
+            for (int I = 0; I < 2; ++I) {
+                const v4d ge = e32_mac2(e32_tile(GL, 2 * I, lane), EU[0], e32_tile(GL, 2 * I + 1, lane), EU[1], zero);
+                const v4d hT = lds_transpose16(scr, -ge, g, j);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) qc_st8m<2>(Jb + P.jo_h + (4 * r + g) * 32 + 16 * I + j, hT[r]);
+            }
+        }
+    }
+    if (w == 6) deriv_rows_generic(P, z0, z1, h, Fb, Jb, lane, false);
+}
+
+}  // namespace
+
+bool qc_mfma32_exp_supported(const QcParams& P) {
+    return P.integrator == QC_EXPONENTIAL && P.n == 32 && P.nc == P.N && P.m <= kE32Mmax;
+}
+
+hipError_t qc_launch_mfma32_exp(const QcParams& P, const double* dZ, double* dF, double* dJ, hipStream_t st) {
+    if (dJ) hipLaunchKernelGGL(qc_mfma32_exp_kernel<true>, dim3(P.n_int), dim3(kE32Threads), 0, st, P, dZ, dF, dJ);
+    else hipLaunchKernelGGL(qc_mfma32_exp_kernel<false>, dim3(P.n_int), dim3(kE32Threads), 0, st, P, dZ, dF, dJ);
+    return hipGetLastError();
+}
