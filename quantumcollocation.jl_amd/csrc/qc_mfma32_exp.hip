@@ -125,10 +125,13 @@ __global__ __launch_bounds__(kE32Threads, 1) void qc_mfma32_exp_kernel(const QcP
 #pragma unroll
         for (int q = 0; q < 4; ++q) Gj[q] = e32_tile(GxA + (size_t)kmat * 1024, q, lane);
     }
+    // state columns: N = 16 for a unitary, K <= 16 for K kets, 1 for a density operator (N^2 = 16 levels).  Tile columns
+    // >= nc re-read column 0 and are never stored (the kernel is MFMA-bound: the run-time masks cost nothing here).
+    const int nc = P.nc, jc = j < nc ? j : 0;
     v4d U[2];
 #pragma unroll
     for (int I = 0; I < 2; ++I) {
-        const double* up = z0 + P.off_U + j * 32 + 16 * I + g;
+        const double* up = z0 + P.off_U + jc * 32 + 16 * I + g;
         U[I] = v4d{up[0], up[4], up[8], up[12]};
     }
     {
@@ -241,9 +244,11 @@ __global__ __launch_bounds__(kE32Threads, 1) void qc_mfma32_exp_kernel(const QcP
         double* pF = Jb + P.jo_F;
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            double* p = pF + (size_t)(w + 8 * c) * 1024;
+            if (w + 8 * c < nc) {
+                double* p = pF + (size_t)(w + 8 * c) * 1024;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) e32_store_T(p, -Et[q], 32, 16 * (q >> 1), 16 * (q & 1), g, j);
+                for (int q = 0; q < 4; ++q) e32_store_T(p, -Et[q], 32, 16 * (q >> 1), 16 * (q & 1), g, j);
+            }
         }
         if (w == 7) for (int i = lane; i < P.s; i += 64) Jb[P.jo_B + i] = 1.0;
         if (drive) {
@@ -252,12 +257,12 @@ __global__ __launch_bounds__(kE32Threads, 1) void qc_mfma32_exp_kernel(const QcP
 #pragma unroll
             for (int q = 0; q < 4; ++q) Lt[q] = lds_transpose16(scr, Q[q], g, j);     // Lt[2I+K] = (L_j[I][K])^T in D layout
             const double fac = -(h * sc);
-            double* pa = Jb + P.jo_a + (size_t)w * 512;
+            double* pa = Jb + P.jo_a + (size_t)w * P.s;
 #pragma unroll
             for (int Jt = 0; Jt < 2; ++Jt) {
                 const v4d x = e32_mac2(U[0], Lt[2 * Jt], U[1], Lt[2 * Jt + 1], zero);   // K = 0: (L_j[J][0])^T, K = 1: (L_j[J][1])^T
 #pragma unroll
-                for (int r = 0; r < 4; ++r) qc_st8m<2>(pa + (4 * r + g) * 32 + 16 * Jt + j, fac * x[r]);
+                for (int r = 0; r < 4; ++r) if (4 * r + g < nc) qc_st8m<2>(pa + (4 * r + g) * 32 + 16 * Jt + j, fac * x[r]);
             }
         }
     }
@@ -269,11 +274,11 @@ __global__ __launch_bounds__(kE32Threads, 1) void qc_mfma32_exp_kernel(const QcP
         if (Fb) {
 #pragma unroll
             for (int I = 0; I < 2; ++I) {
-                const double* up = z1 + P.off_U + j * 32 + 16 * I + g;
+                const double* up = z1 + P.off_U + jc * 32 + 16 * I + g;
                 const v4d u1 = {up[0], up[4], up[8], up[12]};
                 const v4d dT = lds_transpose16(scr, u1 - EU[I], g, j);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) qc_st8m<2>(Fb + (4 * r + g) * 32 + 16 * I + j, dT[r]);
+                for (int r = 0; r < 4; ++r) if (4 * r + g < nc) qc_st8m<2>(Fb + (4 * r + g) * 32 + 16 * I + j, dT[r]);
             }
         }
         if (JAC && ft) {
@@ -282,7 +287,7 @@ __global__ __launch_bounds__(kE32Threads, 1) void qc_mfma32_exp_kernel(const QcP
                 const v4d ge = e32_mac2(e32_tile(GL, 2 * I, lane), EU[0], e32_tile(GL, 2 * I + 1, lane), EU[1], zero);
                 const v4d hT = lds_transpose16(scr, -ge, g, j);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) qc_st8m<2>(Jb + P.jo_h + (4 * r + g) * 32 + 16 * I + j, hT[r]);
+                for (int r = 0; r < 4; ++r) if (4 * r + g < nc) qc_st8m<2>(Jb + P.jo_h + (4 * r + g) * 32 + 16 * I + j, hT[r]);
             }
         }
     }
@@ -292,7 +297,7 @@ __global__ __launch_bounds__(kE32Threads, 1) void qc_mfma32_exp_kernel(const QcP
 }  // namespace
 
 bool qc_mfma32_exp_supported(const QcParams& P) {
-    return P.integrator == QC_EXPONENTIAL && P.n == 32 && P.nc == P.N && P.m <= kE32Mmax;
+    return P.integrator == QC_EXPONENTIAL && P.n == 32 && P.nc <= 16 && P.m <= kE32Mmax;
 }
 
 hipError_t qc_launch_mfma32_exp(const QcParams& P, const double* dZ, double* dF, double* dJ, hipStream_t st) {
