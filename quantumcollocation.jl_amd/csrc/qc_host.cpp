@@ -97,7 +97,6 @@ int qc_build_params(const qc_desc* d, QcParams* P, qc_dims_t* dims, std::string*
     if (d->T < 2) return fail(err, QC_ERR_INVALID, "T must be >= 2");
     if (d->global_dim < 0) return fail(err, QC_ERR_INVALID, "global_dim must be >= 0");
     memset(P, 0, sizeof(*P));
-    P->gx_replicas = 1;
     P->N = d->N;
     P->n = 2 * d->N;
     if (d->state_cols < 0 || d->state_cols > 64) return fail(err, QC_ERR_INVALID, "state_cols must be in 0..64");
@@ -358,15 +357,9 @@ extern "C" int qc_create(const qc_desc* d, qc_handle** out) {
     if (kernel == QC_KERNEL_MFMA) {
         std::vector<double> Gx(qc_mfma_gx_doubles(P));
         qc_mfma_pack_G(P, G.data(), Gx.data());
-        int reps = 1;
-        if (const char* e = getenv("QC_GX_REPLICAS")) reps = std::max(1, std::min(64, atoi(e)));
-        const size_t stride = Gx.size() + 17 * 32;      // doubles; an odd number of 256-byte units past the block
-        QC_HIP_C(hipMalloc((void**)&h->dGx, (size_t)reps * stride * sizeof(double)));
-        for (int r = 0; r < reps; ++r)
-            QC_HIP_C(hipMemcpy(h->dGx + (size_t)r * stride, Gx.data(), Gx.size() * sizeof(double), hipMemcpyHostToDevice));
+        QC_HIP_C(hipMalloc((void**)&h->dGx, Gx.size() * sizeof(double)));
+        QC_HIP_C(hipMemcpy(h->dGx, Gx.data(), Gx.size() * sizeof(double), hipMemcpyHostToDevice));
         h->prm.Gx = h->dGx;
-        h->prm.gx_replicas = reps;
-        h->prm.gx_stride = (long long)stride;
     }
     // LDS budget of the LDS kernels
     {

@@ -39,8 +39,6 @@ struct QcParams {
     int dbg_skip;            // diagnostic ablation (QC_DEBUG_SKIP): bit0 skip copy wave, bit1 skip compute wave
     const double* G;         // device: (m+1) matrices n*n, column-major; index 0 = drift
     const double* Gx;        // device: kernel-specific re-laid-out copy of G (MFMA path), or nullptr
-    int gx_replicas;         // copies of the Gx block (>= 1), gx_stride doubles apart: spreads the hot image lines over L2 channels
-    long long gx_stride;
     unsigned long long* stamps;  // diagnostic: 16 s_memrealtime slots per interval, or nullptr (normal)
 };
 
