@@ -98,6 +98,25 @@ __device__ inline v4d lds_transpose16(double* __restrict__ scr, const v4d& x, in
     return y;
 }
 
+// N tiles at once (scratch of N * 16 * 17 doubles): all writes, one wait, all reads -- one LDS round trip instead of N
+template <int N>
+__device__ __forceinline__ void lds_transpose16_multi(double* __restrict__ scr, const v4d (&x)[N], v4d (&y)[N], int g, int j) {
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) scr[q * 272 + (4 * r + g) * 17 + j] = x[q][r];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) y[q][r] = scr[q * 272 + j * 17 + 4 * r + g];
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
 // Identity in B/D layout: lane (g, j) reg r = (4r + g == j)
 __device__ inline v4d identity_B(int g, int j) {
     return v4d{(g == j) ? 1.0 : 0.0, (4 + g == j) ? 1.0 : 0.0, (8 + g == j) ? 1.0 : 0.0, (12 + g == j) ? 1.0 : 0.0};

@@ -100,7 +100,7 @@ __device__ __forceinline__ void square_step(const v4d& Et, const v4d (&Kt)[M], v
 template <bool JAC, int kMU>
 __global__ __launch_bounds__(64, 1) void qc_mfma16_exp_kernel(const QcParams P, const double* __restrict__ Z, double* __restrict__ F,
                                                               double* __restrict__ J) {
-    __shared__ double scr[16 * 17];
+    __shared__ double scr[(kMU + 1) * 16 * 17];      // transpose scratch: E and the kMU L_j tiles in one LDS round trip
     const int lane = threadIdx.x;
     const int m = P.m;
     const int g = lane >> 4, j = lane & 15, jj = j & 7;
@@ -185,11 +185,18 @@ __global__ __launch_bounds__(64, 1) void qc_mfma16_exp_kernel(const QcParams P, 
         }
         // ---- squarings ------------------------------------------------------------------------------------------------
         for (int q = 0; q < sq; ++q) {
-            const v4d Et = lds_transpose16(scr, R, g, j);
-            v4d Kt[kMU];
+            v4d Et, Kt[kMU];
             if constexpr (JAC) {
+                v4d in[kMU + 1], out[kMU + 1];
+                in[0] = R;
 #pragma unroll
-                for (int u = 0; u < kMU; ++u) Kt[u] = u < m ? lds_transpose16(scr, Q[u], g, j) : zero;
+                for (int u = 0; u < kMU; ++u) in[u + 1] = Q[u];          // unused drive slots hold zeros
+                lds_transpose16_multi<kMU + 1>(scr, in, out, g, j);
+                Et = out[0];
+#pragma unroll
+                for (int u = 0; u < kMU; ++u) Kt[u] = out[u + 1];
+            } else {
+                Et = lds_transpose16(scr, R, g, j);
             }
             square_step<kMU, JAC>(Et, Kt, R, Q);
         }
@@ -215,11 +222,9 @@ __global__ __launch_bounds__(64, 1) void qc_mfma16_exp_kernel(const QcParams P, 
             // d/da_j = -(h/2^sq) L_j U_t, transposed:  U_t^T L_j^T  (A = U_t tile, B = L_j^T)
             const double fac = -(h * sc);
             v4d Kt[kMU], XT[kMU], ua[kMU];
+            lds_transpose16_multi<kMU>(scr, Q, Kt, g, j);
 #pragma unroll
-            for (int u = 0; u < kMU; ++u) {
-                Kt[u] = u < m ? lds_transpose16(scr, Q[u], g, j) : zero;
-                ua[u] = u0;
-            }
+            for (int u = 0; u < kMU; ++u) ua[u] = u0;
             mm16_multi<kMU>(ua, Kt, XT);
 #pragma unroll
             for (int u = 0; u < kMU; ++u) {
