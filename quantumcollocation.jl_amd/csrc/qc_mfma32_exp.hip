@@ -2,7 +2,7 @@
 //     delta = U_t+1 - exp(h G(a_t)) U_t                                          (reference README.md:79)
 // and the Jacobian blocks  d/dU_t = -I_N (x) E,  d/dU_t+1 = I,  d/da_j = -L_j U_t,  d/dh = -G E U_t   (E = exp(h G),
 // L_j = L_exp(h G; h G_j)).  The 2N = 16 kernel (qc_mfma_exp.hip) explains the algorithm: scaling and squaring with
-// ||Y||_1 <= 1/4, a degree-10 Taylor polynomial and its Frechet derivatives in Horner form on R_k = P_k / (k-1)!,
+// ||Y||_1 <= 1/8, a degree-8 Taylor polynomial and its Frechet derivatives in Horner form on R_k = P_k / (k-1)!,
 //     R_k = Y R_k+1 + I/(k-1)!          R'_k,j = G_j R_k+1 + Y R'_k+1,j,
 // squarings E <- E E, L_j <- E L_j + L_j E with the left factors obtained as LDS-transposed tiles (a D-layout tile read
 // as the A operand acts as its transpose), the factor h / 2^sq applied to the outputs once.
@@ -21,7 +21,8 @@ namespace {
 
 using namespace qc_mfma;
 
-constexpr int kE32Deg = 10;
+constexpr int kE32Deg = 8;          // with ||Y||_1 <= 1/8: truncation (1/8)^9 / 9! = 4e-14; one step fewer than degree 10 at 1/4
+constexpr double kE32Th = 0.125;
 constexpr int kE32Mmax = 8;
 constexpr int kE32Threads = 512;
 
@@ -174,11 +175,11 @@ __global__ __launch_bounds__(kE32Threads, 1) void qc_mfma32_exp_kernel(const QcP
                 }
             }
         }
-        if (!bad && best > 0.25) {
+        if (!bad && best > kE32Th) {
             int e;
-            (void)frexp(best / 0.25, &e);
+            (void)frexp(best / kE32Th, &e);
             sq = e;
-            if (ldexp(0.25, e - 1) >= best) sq = e - 1;
+            if (ldexp(kE32Th, e - 1) >= best) sq = e - 1;
             sq = sq < 0 ? 0 : (sq > 60 ? 60 : sq);
         }
     }

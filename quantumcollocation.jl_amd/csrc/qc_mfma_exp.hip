@@ -4,9 +4,9 @@
 // with E = exp(h G), L_j = L_exp(h G; h G_j) the Frechet derivative.  ONE wavefront per interval; every matrix is one
 // 16 x 16 tile in registers (lane maps: qc_mfma_kernels.hip header).
 //
-// Scaling and squaring, Y = h G / 2^sq with ||Y||_1 <= 1/4 (same rule as the LDS kernel), degree-10 Taylor polynomial
+// Scaling and squaring, Y = h G / 2^sq with ||Y||_1 <= 1/8, degree-8 Taylor polynomial (truncation 4e-14)
 // in Horner form on R_k = P_k / (k-1)!  (P_k = I + Y/k P_k+1):
-//     R_k  = Y R_k+1 + I/(k-1)!          R'_k,j = G_j R_k+1 + Y R'_k+1,j           k = 10 .. 1,   R_11 = I/10!,  R'_11 = 0
+//     R_k  = Y R_k+1 + I/(k-1)!          R'_k,j = G_j R_k+1 + Y R'_k+1,j           k = 8 .. 1,   R_9 = I/8!,  R'_9 = 0
 // so a step is 4 + 8 m MFMAs with the constant A-layout tiles Y, G_j as A operands and the previous outputs as B
 // operands (D layout = B layout): nothing but MFMAs touches the accumulators, the identity enters as the C operand.
 // R_1 = exp(Y), R'_1,j = L_exp(Y; G_j).  Squarings  E <- E E,  L_j <- E L_j + L_j E  need E and L_j as LEFT factors:
@@ -14,14 +14,15 @@
 // operations each, no MFMA) and used as A operands.  L_j is linear in its direction, so the factor h / 2^sq is applied
 // once to the outputs.  Outputs leave transposed (lane <-> row, whole 128-byte lines per store): the copies of -E
 // from E^T, the drive columns as (L_j U_t)^T = U_t^T L_j^T (A = U_t tile, B = L_j^T), residual and d/dh through LDS.
-// MFMAs per interval (m = 6, 3 squarings): 10 x 52 + 3 x 52 + 8 + 24 = 708;  the LDS kernel spends 463 us on config 3.
+// MFMAs per interval (m = 6, 4 squarings): 8 x 52 + 4 x 52 + 8 + 24 = 656;  the LDS kernel spends 463 us on config 3.
 #include "qc_mfma_common.h"
 
 namespace {
 
 using namespace qc_mfma;
 
-constexpr int kXDeg = 10;   // truncation 0.25^11/11! = 6e-15 at the scaling threshold (the LDS kernel keeps 12)
+constexpr int kXDeg = 8;          // with ||Y||_1 <= 1/8: truncation (1/8)^9 / 9! = 4e-14; one step fewer than degree 10 at 1/4
+constexpr double kXTh = 0.125;
 constexpr int kXMmax = 8;
 
 __device__ inline v4d ximg(const double* __restrict__ Gx, int mat, int lane) {
@@ -158,11 +159,11 @@ __global__ __launch_bounds__(64, 1) void qc_mfma16_exp_kernel(const QcParams P, 
                     best = fmax(best, v);
                 }
             }
-            if (!bad && best > 0.25) {
+            if (!bad && best > kXTh) {
                 int e;
-                (void)frexp(best / 0.25, &e);
+                (void)frexp(best / kXTh, &e);
                 sq = e;
-                if (ldexp(0.25, e - 1) >= best) sq = e - 1;
+                if (ldexp(kXTh, e - 1) >= best) sq = e - 1;
                 sq = sq < 0 ? 0 : (sq > 60 ? 60 : sq);
             }
         }
