@@ -66,8 +66,14 @@ __device__ inline void store_T32(double* __restrict__ p, const v4d& x, int rowba
 #pragma unroll
     for (int r = 0; r < 4; ++r) qc_st8m<2>(p + (colbase + 4 * r + g) * 32 + rowbase + j, x[r]);   // non-temporal, compile-time
 }
+// the same for an n x nc state block (K < 16 kets): only the columns < nc exist
+__device__ inline void store_T32_cols(double* __restrict__ p, const v4d& x, int rowbase, int nc, int g, int j) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) if (4 * r + g < nc) qc_st8m<2>(p + (4 * r + g) * 32 + rowbase + j, x[r]);
+}
 
-template <bool JAC, bool DIAG>
+// KET: K < 16 ket states (column-masked loads and stores); false = unitary, every mask folds away at compile time
+template <bool JAC, bool DIAG, bool KET>
 __global__ __launch_bounds__(kThreads32, 2) void qc_mfma32_pade4_kernel(const QcParams P, const double* __restrict__ Z,
                                                                        double* __restrict__ F, double* __restrict__ J) {
     __shared__ __attribute__((aligned(16))) double GaL[2 * 4 * 256];                    // G tiles of the two intervals
@@ -82,6 +88,8 @@ __global__ __launch_bounds__(kThreads32, 2) void qc_mfma32_pade4_kernel(const Qc
     const int m = P.m;
     const int mL = m < kMU32 ? m : kMU32;
     const int g = lane >> 4, j = lane & 15;
+    const int nc = KET ? P.nc : 16;
+    const int jc = (!KET || j < nc) ? j : 0;
     const bool ft = P.off_dt >= 0;
     const double c1 = P.c[1], c2 = P.c[2];
     const double* __restrict__ Gx = P.Gx;
@@ -121,8 +129,8 @@ __global__ __launch_bounds__(kThreads32, 2) void qc_mfma32_pade4_kernel(const Qc
         if (!copy_role) {
 #pragma unroll
             for (int I = 0; I < 2; ++I) {
-                const double* u0p = z0 + P.off_U + j * 32 + 16 * I + g;
-                const double* u1p = z1 + P.off_U + j * 32 + 16 * I + g;
+                const double* u0p = z0 + P.off_U + jc * 32 + 16 * I + g;    // columns >= nc re-read column 0; never stored
+                const double* u1p = z1 + P.off_U + jc * 32 + 16 * I + g;
                 const v4d u0 = {u0p[0], u0p[4], u0p[8], u0p[12]};
                 const v4d u1 = {u1p[0], u1p[4], u1p[8], u1p[12]};
                 S[I] = u1 + u0;
@@ -189,7 +197,7 @@ __global__ __launch_bounds__(kThreads32, 2) void qc_mfma32_pade4_kernel(const Qc
                 // lane (g, j) reg r = B^T[16I+4r+g][16Jt+j] = B[16Jt+j][16I+4r+g]
                 double* pF = Jb + P.jo_F;
                 double* pB = Jb + P.jo_B;
-                for (int q = 0; q < 16; ++q) {
+                for (int q = 0; q < (KET ? nc : 16); ++q) {
                     store_T32(pF + q * 1024, Fm[0], 0, 16 * I, g, j);
                     store_T32(pF + q * 1024, Fm[1], 16, 16 * I, g, j);
                     store_T32(pB + q * 1024, Bm[0], 0, 16 * I, g, j);
@@ -239,10 +247,10 @@ __global__ __launch_bounds__(kThreads32, 2) void qc_mfma32_pade4_kernel(const Qc
 #pragma unroll
                 for (int I = 0; I < 2; ++I) {
                     const v4d dl = D[I] - hc1 * GS[I] + hc2 * G2D[I];
-                    if (Fb) store_T32(Fb, mm16(dl, IdB), 16 * I, 0, g, j);
+                    if (Fb) { if constexpr (KET) store_T32_cols(Fb, mm16(dl, IdB), 16 * I, nc, g, j); else store_T32(Fb, mm16(dl, IdB), 16 * I, 0, g, j); }
                     if (JAC && ft) {
                         const v4d dh = (-c1) * GS[I] + (2.0 * c2 * h) * G2D[I];
-                        store_T32(Jb + P.jo_h, mm16(dh, IdB), 16 * I, 0, g, j);
+                        if constexpr (KET) store_T32_cols(Jb + P.jo_h, mm16(dh, IdB), 16 * I, nc, g, j); else store_T32(Jb + P.jo_h, mm16(dh, IdB), 16 * I, 0, g, j);
                     }
                 }
                 if (!JAC) deriv_rows_generic(P, z0, z1, h, Fb, nullptr, lane, false);
@@ -261,12 +269,12 @@ __global__ __launch_bounds__(kThreads32, 2) void qc_mfma32_pade4_kernel(const Qc
                     v4d R1[2];                      // G_k D
 #pragma unroll
                     for (int I = 0; I < 2; ++I) R1[I] = mm16x2(Gk[2 * I], D[0], Gk[2 * I + 1], D[1]);
-                    double* pa = Jb + P.jo_a + (size_t)k * 512;
+                    double* pa = Jb + P.jo_a + (size_t)k * (KET ? P.s : 512);
 #pragma unroll
                     for (int I = 0; I < 2; ++I) {
                         const v4d R0 = mm16x2(Gk[2 * I], Q0[0], Gk[2 * I + 1], Q0[1]);          // G_k Q_0
                         const v4d Y = R0 + hc2 * mm16x2(Ga[2 * I], R1[0], Ga[2 * I + 1], R1[1]);   // + h^2 c2 G (G_k D)
-                        store_T32(pa, mm16(Y, IdB), 16 * I, 0, g, j);
+                        if constexpr (KET) store_T32_cols(pa, mm16(Y, IdB), 16 * I, nc, g, j); else store_T32(pa, mm16(Y, IdB), 16 * I, 0, g, j);
                     }
                 }
             }
@@ -325,8 +333,13 @@ hipError_t qc_launch_mfma32_F_jac(const QcParams& P, const double* dZ, double* d
     const int n_wg = (P.n_int + 1) / 2;
     const int grid = n_wg < kMaxGrid32 ? n_wg : kMaxGrid32;
     const bool diag = P.stamps != nullptr || P.dbg_skip != 0;
-    if (dJ && diag) hipLaunchKernelGGL((qc_mfma32_pade4_kernel<true, true>), dim3(grid), dim3(kThreads32), 0, st, P, dZ, dF, dJ);
-    else if (dJ) hipLaunchKernelGGL((qc_mfma32_pade4_kernel<true, false>), dim3(grid), dim3(kThreads32), 0, st, P, dZ, dF, dJ);
-    else hipLaunchKernelGGL((qc_mfma32_pade4_kernel<false, false>), dim3(grid), dim3(kThreads32), 0, st, P, dZ, dF, dJ);
+    if (P.nc != 16) {
+        if (dJ) hipLaunchKernelGGL((qc_mfma32_pade4_kernel<true, false, true>), dim3(grid), dim3(kThreads32), 0, st, P, dZ, dF, dJ);
+        else hipLaunchKernelGGL((qc_mfma32_pade4_kernel<false, false, true>), dim3(grid), dim3(kThreads32), 0, st, P, dZ, dF, dJ);
+        return hipGetLastError();
+    }
+    if (dJ && diag) hipLaunchKernelGGL((qc_mfma32_pade4_kernel<true, true, false>), dim3(grid), dim3(kThreads32), 0, st, P, dZ, dF, dJ);
+    else if (dJ) hipLaunchKernelGGL((qc_mfma32_pade4_kernel<true, false, false>), dim3(grid), dim3(kThreads32), 0, st, P, dZ, dF, dJ);
+    else hipLaunchKernelGGL((qc_mfma32_pade4_kernel<false, false, false>), dim3(grid), dim3(kThreads32), 0, st, P, dZ, dF, dJ);
     return hipGetLastError();
 }
