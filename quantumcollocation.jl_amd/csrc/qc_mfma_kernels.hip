@@ -117,7 +117,7 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = JAC ? __builtin_amdgcn_readfirstlane(tid >> 6) : 0;
-    const int role = wave / kIntervalsPerWG;      // 0 compute wave, 1 copy wave
+    const int role = JAC ? 1 - wave / kIntervalsPerWG : 0;      // 0 compute wave, 1 copy wave (the first wave of the workgroup)
     const int slot = wave % kIntervalsPerWG;      // which of the workgroup's intervals
     double* __restrict__ sm = sm_all + (JAC ? slot * kLdsBlock : 0);
     const int ipw = JAC ? kIntervalsPerWG : 1;
