@@ -121,11 +121,16 @@ __global__ __launch_bounds__(64, 1) void qc_mfma16_exp_kernel(const QcParams P, 
         const double h = ft ? z0[P.off_dt] : P.dt_fixed;
 
         // ---- loads (one batch): knots, generator images --------------------------------------------------------
-        const int nc = P.nc, jc = jj < nc ? jj : 0;            // K kets: columns >= nc re-read column 0 and are never stored
-        const double* u0p = z0 + P.off_U + jc * 16 + g;
-        const double* u1p = z1 + P.off_U + jc * 16 + g;
-        const v4d u0 = {u0p[0], u0p[4], u0p[8], u0p[12]};       // [U_t | U_t]  (both 8-column halves hold the same matrix)
-        const v4d u1 = {u1p[0], u1p[4], u1p[8], u1p[12]};
+        // K kets: columns >= nc re-read column 0 and are never stored; N < 8 levels: nr = 2N < 16 rows, zero-padded to the tile
+        // (the exponential of the padded generator is the exponential of the true one plus an identity block that is not stored)
+        const int nc = P.nc, jc = jj < nc ? jj : 0, nr = P.n;
+        v4d u0, u1;                                              // [U_t | U_t]  (both 8-column halves hold the same matrix)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * r + g;
+            u0[r] = row < nr ? z0[P.off_U + jc * nr + row] : 0.0;
+            u1[r] = row < nr ? z1[P.off_U + jc * nr + row] : 0.0;
+        }
         v4d Gj[kMU];
         double ak[kMU];
         v4d Ga = ximg(Gx, 0, lane);
@@ -207,7 +212,7 @@ __global__ __launch_bounds__(64, 1) void qc_mfma16_exp_kernel(const QcParams P, 
         if (Fb) {
             const v4d dT = lds_transpose16(scr, u1 - EU, g, j);     // delta^T: lane j <-> row
 #pragma unroll
-            for (int r = 0; r < 2; ++r) if (4 * r + g < nc) qc_st8m<2>(Fb + (4 * r + g) * 16 + j, dT[r]);
+            for (int r = 0; r < 2; ++r) if (4 * r + g < nc && j < nr) qc_st8m<2>(Fb + (4 * r + g) * nr + j, dT[r]);
         }
         if constexpr (JAC) {
             double* pF = Jb + P.jo_F;
@@ -216,7 +221,7 @@ __global__ __launch_bounds__(64, 1) void qc_mfma16_exp_kernel(const QcParams P, 
             for (int q = 0; q < 8; ++q) {
                 if (q < nc) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) qc_st8m<2>(pF + q * 256 + (4 * r + g) * 16 + j, mE[r]);
+                    for (int r = 0; r < 4; ++r) if (4 * r + g < nr && j < nr) qc_st8m<2>(pF + q * nr * nr + (4 * r + g) * nr + j, mE[r]);
                 }
             }
             for (int i = lane; i < P.s; i += 64) Jb[P.jo_B + i] = 1.0;
@@ -232,14 +237,14 @@ __global__ __launch_bounds__(64, 1) void qc_mfma16_exp_kernel(const QcParams P, 
                 if (u < m) {
 #pragma unroll
                     for (int r = 0; r < 2; ++r)
-                        if (4 * r + g < nc) qc_st8m<2>(Jb + P.jo_a + (size_t)u * P.s + (4 * r + g) * 16 + j, fac * XT[u][r]);
+                        if (4 * r + g < nc && j < nr) qc_st8m<2>(Jb + P.jo_a + (size_t)u * P.s + (4 * r + g) * nr + j, fac * XT[u][r]);
                 }
             }
             if (ft) {   // d/dh = -G E U_t
                 const v4d GEU = mm16(Ga, EU);
                 const v4d hT = lds_transpose16(scr, -GEU, g, j);
 #pragma unroll
-                for (int r = 0; r < 2; ++r) if (4 * r + g < nc) qc_st8m<2>(Jb + P.jo_h + (4 * r + g) * 16 + j, hT[r]);
+                for (int r = 0; r < 2; ++r) if (4 * r + g < nc && j < nr) qc_st8m<2>(Jb + P.jo_h + (4 * r + g) * nr + j, hT[r]);
             }
         }
         deriv_rows_generic(P, z0, z1, h, Fb, Jb, lane, false);
@@ -249,7 +254,7 @@ __global__ __launch_bounds__(64, 1) void qc_mfma16_exp_kernel(const QcParams P, 
 }  // namespace
 
 bool qc_mfma_exp_supported(const QcParams& P) {
-    return P.integrator == QC_EXPONENTIAL && P.n == 16 && P.nc <= 8 && P.m <= kXMmax;
+    return P.integrator == QC_EXPONENTIAL && P.n <= 16 && P.nc <= 8 && P.m <= kXMmax;
 }
 
 template <bool JAC>

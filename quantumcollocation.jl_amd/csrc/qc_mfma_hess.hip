@@ -61,12 +61,25 @@ __global__ __launch_bounds__(64) void qc_mfma16_pade4_hess_kernel(const QcParams
         // K kets (nc < 8): the tile columns >= nc re-read column 0; the multipliers there are zeroed, which zeroes every
         // quantity derived from M in those columns (the scalar blocks sum over whole tiles), and they are never stored
         const int nc = KET ? P.nc : 8, jc = (!KET || jj < nc) ? jj : 0;     // KET = false: the masks fold away at compile time
-        const double* u0p = z0 + P.off_U + jc * 16 + g;
-        const double* u1p = z1 + P.off_U + jc * 16 + g;
-        const double* mp = mu + jc * 16 + g;
-        const v4d u0 = {u0p[0], u0p[4], u0p[8], u0p[12]};
-        const v4d u1 = {u1p[0], u1p[4], u1p[8], u1p[12]};
-        const v4d mraw = {mp[0], mp[4], mp[8], mp[12]};
+        const int nr = KET ? P.n : 16;                                      // rows per column (N < 8 levels: zero-padded tile)
+        v4d u0, u1, mraw;
+        if constexpr (!KET) {
+            const double* u0p = z0 + P.off_U + jc * 16 + g;
+            const double* u1p = z1 + P.off_U + jc * 16 + g;
+            const double* mp = mu + jc * 16 + g;
+            u0 = v4d{u0p[0], u0p[4], u0p[8], u0p[12]};
+            u1 = v4d{u1p[0], u1p[4], u1p[8], u1p[12]};
+            mraw = v4d{mp[0], mp[4], mp[8], mp[12]};
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 4 * r + g;
+                const bool in = row < nr;
+                u0[r] = in ? z0[P.off_U + jc * nr + row] : 0.0;
+                u1[r] = in ? z1[P.off_U + jc * nr + row] : 0.0;
+                mraw[r] = in ? mu[jc * nr + row] : 0.0;
+            }
+        }
         const v4d mv = (!KET || jj < nc) ? mraw : v4d{0.0, 0.0, 0.0, 0.0};
         const double h = ft ? z0[P.off_dt] : P.dt_fixed;
         v4d gA[kHM], gB[kHM];
@@ -153,7 +166,7 @@ __global__ __launch_bounds__(64) void qc_mfma16_pade4_hess_kernel(const QcParams
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int c = 4 * r + g;
-                if (!KET || (c & 7) < nc) qc_st8m<2>(Hb + (c < 8 ? P.ho_Uh + c * 16 : P.ho_hU + (c - 8) * 16) + j, ET[r]);
+                if (!KET || ((c & 7) < nc && j < nr)) qc_st8m<2>(Hb + (c < 8 ? P.ho_Uh + c * nr : P.ho_hU + (c - 8) * nr) + j, ET[r]);
             }
         }
 #pragma unroll
@@ -163,8 +176,8 @@ __global__ __launch_bounds__(64) void qc_mfma16_pade4_hess_kernel(const QcParams
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int c = 4 * r + g;           // tile columns < 8: drive u column c; >= 8: drive u+1 column c-8
-                    if ((r < 2 || two) && (!KET || (c & 7) < nc)) {
-                        const size_t o = (size_t)(u + (r < 2 ? 0 : 1)) * (KET ? P.s : 128) + (c & 7) * 16 + j;
+                    if ((r < 2 || two) && (!KET || ((c & 7) < nc && j < nr))) {
+                        const size_t o = (size_t)(u + (r < 2 ? 0 : 1)) * (KET ? P.s : 128) + (c & 7) * nr + j;
                         qc_st8m<2>(Hb + P.ho_Ua + o, XT[u][r]);
                         qc_st8m<2>(Hb + P.ho_aU + o, XT[u + 1][r]);
                     }
@@ -223,7 +236,7 @@ __global__ __launch_bounds__(64) void qc_mfma16_pade4_hess_kernel(const QcParams
 
 bool qc_mfma_hess_supported(const QcParams& P) {
     if (qc_mfma32_hess_supported(P)) return true;
-    return P.integrator == QC_PADE && P.p == 2 && P.n == 16 && P.nc <= 8 && P.m <= kHMmax;
+    return P.integrator == QC_PADE && P.p == 2 && P.n <= 16 && P.nc <= 8 && P.m <= kHMmax;
 }
 
 hipError_t qc_launch_mfma16_hess_batch(const QcParams& P0, const QcParams* dPb, int count, const double* dZ, const double* dMu, double* dH,
@@ -236,9 +249,9 @@ hipError_t qc_launch_mfma16_hess_batch(const QcParams& P0, const QcParams* dPb, 
 }
 
 hipError_t qc_launch_mfma_hess(const QcParams& P, const double* dZ, const double* dMu, double* dH, hipStream_t st) {
-    if (P.n == 32) return qc_launch_mfma32_hess(P, dZ, dMu, dH, st);
+    if (P.n > 16) return qc_launch_mfma32_hess(P, dZ, dMu, dH, st);
     const int grid = P.n_int < 4096 ? P.n_int : 4096;
-    if (P.nc != 8) {
+    if (P.nc != 8 || P.n != 16) {
         if (P.m <= 2) hipLaunchKernelGGL((qc_mfma16_pade4_hess_kernel<2, true, false>), dim3(grid), dim3(64), 0, st, P, dZ, dMu, dH, nullptr);
         else if (P.m <= 4) hipLaunchKernelGGL((qc_mfma16_pade4_hess_kernel<4, true, false>), dim3(grid), dim3(64), 0, st, P, dZ, dMu, dH, nullptr);
         else if (P.m <= 6) hipLaunchKernelGGL((qc_mfma16_pade4_hess_kernel<6, true, false>), dim3(grid), dim3(64), 0, st, P, dZ, dMu, dH, nullptr);

@@ -91,6 +91,28 @@ __device__ inline void store_tile_T(double* __restrict__ p, const v4d& x, int g,
 // LDS hand-off block of one workgroup (doubles): the copy wave loads everything the interval needs from
 // global memory BEFORE any store of the workgroup is issued, and passes it on; the compute wave issues no
 // global load at all, so its MFMA chain never waits behind the store burst in the memory pipeline.
+// The same for the masked instantiation (KET): an nr x nr block (nr <= 16 rows per column), only rows / columns < nr
+template <int MODE>
+__device__ inline void store_tile_T_masked(double* __restrict__ p, const v4d& x, int nr, int g, int j) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) if (4 * r + g < nr && j < nr) qc_st8m<MODE>(p + (4 * r + g) * nr + j, x[r]);
+}
+// State tile [U | U] (both 8-column halves): lane (g, j) reg r = U[4r+g][col].  MASK: the state has nr <= 16 rows per column
+// (systems with N < 8 levels are zero-padded to the 16 x 16 tile) and columns >= nc re-read column 0 (never stored).
+template <bool MASK>
+__device__ inline v4d load_state_tile(const double* __restrict__ zU, int col, int nr, int g) {
+    if constexpr (!MASK) {
+        const double* p = zU + col * 16 + g;
+        return v4d{p[0], p[4], p[8], p[12]};
+    } else {
+        const double* p = zU + col * nr;
+        v4d v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (4 * r + g < nr) ? p[4 * r + g] : 0.0;
+        return v;
+    }
+}
+
 constexpr int kLdsGa = 0, kLdsU0 = 256, kLdsU1 = 512, kLdsGk = 768;   // + MU * 256 generator images
 
 __device__ inline void lds_put(double* __restrict__ base, int lane, const v4d& x) {
@@ -124,9 +146,11 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
     const int n_wg = (P.n_int + ipw - 1) / ipw;
     const int m = P.m;
     const int g = lane >> 4, j = lane & 15, jj = j & 7;
-    // state columns: N = 8 for a unitary (KET = false: every `< nc` below folds away at compile time; as run-time tests
-    // they cost the headline kernel 0.8 us per launch), K <= 8 for K kets
+    // KET = false: a unitary on N = 8 levels, every mask below folds away at compile time (as run-time tests they cost the
+    // headline kernel 0.8 us per launch).  KET = true: the masked instantiation -- K <= 8 state columns (kets) and / or
+    // N < 8 levels (2N = nr < 16 rows, zero-padded to the tile).
     const int nc = KET ? P.nc : 8;
+    const int nr = KET ? P.n : 16;
     const int jc = (!KET || jj < nc) ? jj : 0;
     const bool left = j < 8;
     const bool ft = P.off_dt >= 0;
@@ -153,10 +177,8 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
             __builtin_amdgcn_s_setprio(3);   // critical path: nothing reaches HBM before this wave's first store
             QC_STAMP(P, b, lane, 0);
             // every global load of the interval, in one batch
-            const double* u0p = z0 + P.off_U + jc * 16 + g;      // columns >= nc (kets: nc < 8) re-read column 0; never stored
-            const double* u1p = z1 + P.off_U + jc * 16 + g;
-            const v4d u0 = {u0p[0], u0p[4], u0p[8], u0p[12]};
-            const v4d u1 = {u1p[0], u1p[4], u1p[8], u1p[12]};
+            const v4d u0 = load_state_tile<KET>(z0 + P.off_U, jc, nr, g);
+            const v4d u1 = load_state_tile<KET>(z1 + P.off_U, jc, nr, g);
             double dxv[kDF], dfv[kDF];       // derivative integrators, register fast path (<= kDF of <= 64 rows)
             const bool dfast = P.n_deriv <= kDF;
 #pragma unroll
@@ -197,9 +219,12 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
                 // qc_mfma_common.h::store_tile_T16, measured 8 % slower.)
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
-                    if (!KET || q < nc) {
+                    if constexpr (!KET) {
                         store_tile_T<MODE>(pF + q * 256, Fm, g, j);
                         store_tile_T<MODE>(pB + q * 256, Bm, g, j);
+                    } else if (q < nc) {
+                        store_tile_T_masked<MODE>(pF + q * nr * nr, Fm, nr, g, j);
+                        store_tile_T_masked<MODE>(pB + q * nr * nr, Bm, nr, g, j);
                     }
                 }
                 __builtin_amdgcn_s_setprio(0);
@@ -251,10 +276,8 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
             u0 = lds_get(sm + kLdsU0, lane);
             u1 = lds_get(sm + kLdsU1, lane);
         } else {                                  // residual-only launch: a single wave, loads for itself
-            const double* u0p = z0 + P.off_U + jc * 16 + g;      // columns >= nc (kets: nc < 8) re-read column 0; never stored
-            const double* u1p = z1 + P.off_U + jc * 16 + g;
-            u0 = v4d{u0p[0], u0p[4], u0p[8], u0p[12]};
-            u1 = v4d{u1p[0], u1p[4], u1p[8], u1p[12]};
+            u0 = load_state_tile<KET>(z0 + P.off_U, jc, nr, g);
+            u1 = load_state_tile<KET>(z1 + P.off_U, jc, nr, g);
             double ak[kMU];
             Ga = assemble_G(P, Gx, z0, lane, gk, ak);
         }
@@ -336,9 +359,9 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
                 for (int r = 0; r < 4; ++r) {
                     const int c = 4 * r + g;          // tile column: < 8 residual column c, >= 8 d/dh column c-8
                     if (c < 8) {
-                        if (Fb && (!KET || c < nc)) qc_st8m<MODE>(Fb + c * 16 + j, ET[r]);
-                    } else if (JAC && ft && (!KET || c - 8 < nc)) {
-                        qc_st8m<MODE>(Jb + P.jo_h + (c - 8) * 16 + j, ET[r]);
+                        if (Fb && (!KET || (c < nc && j < nr))) qc_st8m<MODE>(Fb + c * nr + j, ET[r]);
+                    } else if (JAC && ft && (!KET || (c - 8 < nc && j < nr))) {
+                        qc_st8m<MODE>(Jb + P.jo_h + (c - 8) * nr + j, ET[r]);
                     }
                 }
             };
@@ -356,8 +379,8 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int c = 4 * r + g;      // tile columns < 8: drive k column c; >= 8: drive k+1 column c-8
-                        if (r < 2) { if (!KET || c < nc) qc_st8m<MODE>(p + c * 16 + j, YTk[r]); }
-                        else if (two && (!KET || c - 8 < nc)) qc_st8m<MODE>(p + sk + (c - 8) * 16 + j, YTk[r]);
+                        if (r < 2) { if (!KET || (c < nc && j < nr)) qc_st8m<MODE>(p + c * nr + j, YTk[r]); }
+                        else if (two && (!KET || (c - 8 < nc && j < nr))) qc_st8m<MODE>(p + sk + (c - 8) * nr + j, YTk[r]);
                     }
                 };
                 v4d YT[kMU / 2];                      // stage D: transposes of [d/da_k | d/da_k+1]
@@ -405,32 +428,33 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
 
 bool qc_mfma_supported(const QcParams& P) {
     if (qc_mfma_exp_supported(P) || qc_mfma32_exp_supported(P)) return true;
-    return P.integrator == QC_PADE && P.p == 2 && ((P.n == 16 && P.nc <= 8) || (P.n == 32 && P.nc <= 16)) && P.m <= 32;
+    return P.integrator == QC_PADE && P.p == 2 && ((P.n <= 16 && P.nc <= 8) || (P.n == 32 && P.nc <= 16)) && P.m <= 32;
 }
 
-size_t qc_mfma_gx_doubles(const QcParams& P) { return P.n == 32 ? qc_mfma32_gx_doubles(P) : (size_t)2 * (P.m + 1) * 256; }
+size_t qc_mfma_gx_doubles(const QcParams& P) { return P.n > 16 ? qc_mfma32_gx_doubles(P) : (size_t)2 * (P.m + 1) * 256; }
 
 // Packs the (m+1) generators (column-major n x n, index 0 = drift) into the lane-ordered A-layout
 // images [layout][matrix][pair][lane][2]:  layout 0 (A operand of X): lane (g, i) reg kk = X[i][4kk+g];
 // layout 1 (B layout of X = A operand of X^T, used by the Hessian kernel): lane (g, i) reg kk = X[4kk+g][i].
 void qc_mfma_pack_G(const QcParams& P, const double* G, double* Gx) {
-    if (P.n == 32) { qc_mfma32_pack_G(P, G, Gx); return; }
-    const int n = 16, M = P.m + 1;
+    if (P.n > 16) { qc_mfma32_pack_G(P, G, Gx); return; }
+    const int n = P.n, M = P.m + 1;      // n < 16: the images are zero-padded to the 16 x 16 tile
     for (int mat = 0; mat < M; ++mat) {
         const double* A = G + (size_t)mat * n * n;
         for (int pr = 0; pr < 2; ++pr)
             for (int l = 0; l < 64; ++l)
                 for (int e = 0; e < 2; ++e) {
-                    const int g = l >> 4, i = l & 15, kk = 2 * pr + e;
-                    Gx[((size_t)mat * 2 + pr) * 128 + l * 2 + e] = A[(size_t)(4 * kk + g) * n + i];                 // X[i][4kk+g]
-                    Gx[((size_t)(M + mat) * 2 + pr) * 128 + l * 2 + e] = A[(size_t)i * n + 4 * kk + g];         // X[4kk+g][i]
+                    const int g = l >> 4, i = l & 15, kk = 2 * pr + e, c = 4 * kk + g;
+                    const bool in = i < n && c < n;
+                    Gx[((size_t)mat * 2 + pr) * 128 + l * 2 + e] = in ? A[(size_t)c * n + i] : 0.0;                 // X[i][4kk+g]
+                    Gx[((size_t)(M + mat) * 2 + pr) * 128 + l * 2 + e] = in ? A[(size_t)i * n + c] : 0.0;         // X[4kk+g][i]
                 }
     }
 }
 
 template <bool JAC, bool DIAG, int MU>
 static void launch16m(const QcParams& P, const double* dZ, double* dF, double* dJ, hipStream_t st, int grid, int threads) {
-    if (P.nc != 8) {   // K < 8 kets: the column-masked instantiation (non-temporal stores, no diagnostics)
+    if (P.nc != 8 || P.n != 16) {   // K < 8 kets and / or N < 8 levels: the masked instantiation (non-temporal stores, no diagnostics)
         hipLaunchKernelGGL((qc_mfma16_pade4_kernel<JAC, 2, false, MU, true, false>), dim3(grid), dim3(threads), 0, st, P, dZ, dF, dJ, nullptr);
         return;
     }
@@ -476,8 +500,8 @@ hipError_t qc_launch_mfma16_F_jac_batch(const QcParams& P0, const QcParams* dPb,
 }
 
 hipError_t qc_launch_mfma_F_jac(const QcParams& P, const double* dZ, double* dF, double* dJ, hipStream_t st) {
-    if (P.integrator == QC_EXPONENTIAL) return P.n == 32 ? qc_launch_mfma32_exp(P, dZ, dF, dJ, st) : qc_launch_mfma_exp(P, dZ, dF, dJ, st);
-    if (P.n == 32) return qc_launch_mfma32_F_jac(P, dZ, dF, dJ, st);
+    if (P.integrator == QC_EXPONENTIAL) return P.n > 16 ? qc_launch_mfma32_exp(P, dZ, dF, dJ, st) : qc_launch_mfma_exp(P, dZ, dF, dJ, st);
+    if (P.n > 16) return qc_launch_mfma32_F_jac(P, dZ, dF, dJ, st);
     const int n_wg = dJ ? (P.n_int + kIntervalsPerWG - 1) / kIntervalsPerWG : P.n_int;
     const int grid = n_wg < kMaxGrid ? n_wg : kMaxGrid;
     const bool diag = P.stamps != nullptr || P.dbg_skip != 0;

@@ -94,7 +94,7 @@ def test_density_kernel_matches_oracle(qc, oracle, nq, T, free_time):
     prob = problem_from_inputs(inp)
     Z = inp.traj.datavec
     dyn = qc.QuantumDynamics(inp.integrators, inp.traj)
-    assert dyn.kernel == ("mfma" if nq == 2 else "lds")      # 2 qubits: N^2 = 16 levels -> the 2N = 32 MFMA exponential kernel
+    assert dyn.kernel == "mfma"      # 1 qubit: N^2 = 4 levels, padded 2N = 16 tile; 2 qubits: 16 levels, the 2N = 32 kernel
     F, J = dyn.F_dF(Z)
     Fr, Jr = oracle.F(prob, Z), oracle.dF(prob, Z)
     np.testing.assert_allclose(F, Fr, rtol=1e-10, atol=1e-11 * max(1.0, np.abs(Fr).max()))
