@@ -90,7 +90,8 @@ __device__ __forceinline__ void e32_chain4(const v4d (&A1)[4], const v4d (&R)[4]
 // lane (g, j) reg r = X[rowbase + j][colbase + 4 r + g] of a column-major block with `ld` rows per column at p
 __device__ inline void e32_store_T(double* __restrict__ p, const v4d& x, int ld, int rowbase, int colbase, int g, int j) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) qc_st8m<2>(p + (size_t)(colbase + 4 * r + g) * ld + rowbase + j, x[r]);
+    for (int r = 0; r < 4; ++r)
+        if (colbase + 4 * r + g < ld && rowbase + j < ld) qc_st8m<2>(p + (size_t)(colbase + 4 * r + g) * ld + rowbase + j, x[r]);
 }
 
 template <bool JAC>
@@ -128,12 +129,14 @@ __global__ __launch_bounds__(kE32Threads, 1) void qc_mfma32_exp_kernel(const QcP
     }
     // state columns: N = 16 for a unitary, K <= 16 for K kets, 1 for a density operator (N^2 = 16 levels).  Tile columns
     // >= nc re-read column 0 and are never stored (the kernel is MFMA-bound: the run-time masks cost nothing here).
-    const int nc = P.nc, jc = j < nc ? j : 0;
+    // Systems with 9 .. 15 levels: nr = 2N < 32 rows, zero-padded to the 2 x 2 tiles (the exponential of the padded generator is
+    // the exponential of the true one plus an identity block that is never stored).
+    const int nc = P.nc, jc = j < nc ? j : 0, nr = P.n;
     v4d U[2];
 #pragma unroll
     for (int I = 0; I < 2; ++I) {
-        const double* up = z0 + P.off_U + jc * 32 + 16 * I + g;
-        U[I] = v4d{up[0], up[4], up[8], up[12]};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int row = 16 * I + 4 * r + g; U[I][r] = row < nr ? z0[P.off_U + jc * nr + row] : 0.0; }
     }
     {
         const v2d* __restrict__ ab = reinterpret_cast<const v2d*>(GxA) + (w >> 1) * 128 + (w & 1) * 64 + lane;
@@ -246,9 +249,9 @@ __global__ __launch_bounds__(kE32Threads, 1) void qc_mfma32_exp_kernel(const QcP
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             if (w + 8 * c < nc) {
-                double* p = pF + (size_t)(w + 8 * c) * 1024;
+                double* p = pF + (size_t)(w + 8 * c) * nr * nr;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) e32_store_T(p, -Et[q], 32, 16 * (q >> 1), 16 * (q & 1), g, j);
+                for (int q = 0; q < 4; ++q) e32_store_T(p, -Et[q], nr, 16 * (q >> 1), 16 * (q & 1), g, j);
             }
         }
         if (w == 7) for (int i = lane; i < P.s; i += 64) Jb[P.jo_B + i] = 1.0;
@@ -263,7 +266,7 @@ __global__ __launch_bounds__(kE32Threads, 1) void qc_mfma32_exp_kernel(const QcP
             for (int Jt = 0; Jt < 2; ++Jt) {
                 const v4d x = e32_mac2(U[0], Lt[2 * Jt], U[1], Lt[2 * Jt + 1], zero);   // K = 0: (L_j[J][0])^T, K = 1: (L_j[J][1])^T
 #pragma unroll
-                for (int r = 0; r < 4; ++r) if (4 * r + g < nc) qc_st8m<2>(pa + (4 * r + g) * 32 + 16 * Jt + j, fac * x[r]);
+                for (int r = 0; r < 4; ++r) if (4 * r + g < nc && 16 * Jt + j < nr) qc_st8m<2>(pa + (4 * r + g) * nr + 16 * Jt + j, fac * x[r]);
             }
         }
     }
@@ -275,11 +278,12 @@ __global__ __launch_bounds__(kE32Threads, 1) void qc_mfma32_exp_kernel(const QcP
         if (Fb) {
 #pragma unroll
             for (int I = 0; I < 2; ++I) {
-                const double* up = z1 + P.off_U + jc * 32 + 16 * I + g;
-                const v4d u1 = {up[0], up[4], up[8], up[12]};
+                v4d u1;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const int row = 16 * I + 4 * r + g; u1[r] = row < nr ? z1[P.off_U + jc * nr + row] : 0.0; }
                 const v4d dT = lds_transpose16(scr, u1 - EU[I], g, j);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) if (4 * r + g < nc) qc_st8m<2>(Fb + (4 * r + g) * 32 + 16 * I + j, dT[r]);
+                for (int r = 0; r < 4; ++r) if (4 * r + g < nc && 16 * I + j < nr) qc_st8m<2>(Fb + (4 * r + g) * nr + 16 * I + j, dT[r]);
             }
         }
         if (JAC && ft) {
@@ -288,7 +292,7 @@ __global__ __launch_bounds__(kE32Threads, 1) void qc_mfma32_exp_kernel(const QcP
                 const v4d ge = e32_mac2(e32_tile(GL, 2 * I, lane), EU[0], e32_tile(GL, 2 * I + 1, lane), EU[1], zero);
                 const v4d hT = lds_transpose16(scr, -ge, g, j);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) if (4 * r + g < nc) qc_st8m<2>(Jb + P.jo_h + (4 * r + g) * 32 + 16 * I + j, hT[r]);
+                for (int r = 0; r < 4; ++r) if (4 * r + g < nc && 16 * I + j < nr) qc_st8m<2>(Jb + P.jo_h + (4 * r + g) * nr + 16 * I + j, hT[r]);
             }
         }
     }
@@ -298,7 +302,7 @@ __global__ __launch_bounds__(kE32Threads, 1) void qc_mfma32_exp_kernel(const QcP
 }  // namespace
 
 bool qc_mfma32_exp_supported(const QcParams& P) {
-    return P.integrator == QC_EXPONENTIAL && P.n == 32 && P.nc <= 16 && P.m <= kE32Mmax;
+    return P.integrator == QC_EXPONENTIAL && P.n > 16 && P.n <= 32 && P.nc <= 16 && P.m <= kE32Mmax;
 }
 
 hipError_t qc_launch_mfma32_exp(const QcParams& P, const double* dZ, double* dF, double* dJ, hipStream_t st) {

@@ -93,9 +93,9 @@ __device__ __forceinline__ void mm16x2_multi(const v4d (&a0)[NQ], const v4d (&b0
 }
 
 // lane (g, j) reg r = X[16 J + j][4 r + g] of a column-major 32-row block at p  (a transposed-land tile)
-__device__ inline void store_T(double* __restrict__ p, const v4d& x, int J, int g, int j, int nc) {
+__device__ inline void store_T(double* __restrict__ p, const v4d& x, int J, int g, int j, int nc, int nr) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) if (4 * r + g < nc) qc_st8m<2>(p + (4 * r + g) * 32 + 16 * J + j, x[r]);
+    for (int r = 0; r < 4; ++r) if (4 * r + g < nc && 16 * J + j < nr) qc_st8m<2>(p + (4 * r + g) * nr + 16 * J + j, x[r]);
 }
 
 template <bool DIAG>
@@ -164,17 +164,21 @@ __global__ __launch_bounds__(kHThreads32, 1) void qc_mfma32_pade4_hess_kernel(co
             if (w >= 4) {
                 // K < 16 kets: tile columns >= nc re-read column 0; the multipliers there are zeroed (the scalar blocks sum over
                 // whole tiles) and nothing of them is stored.  The kernel is MFMA-bound: run-time masks cost nothing here.
+                // Systems with 9 .. 15 levels: nr = 2N < 32 rows per column, zero-padded to the 2 x 2 tiles.
                 const int I = w & 1;
-                const int o = (j < P.nc ? j : 0) * 32 + 16 * I + g;
+                const int nr = P.n, cb = (j < P.nc ? j : 0) * nr;
+                auto ld4 = [&](const double* base) {
+                    v4d v;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { const int row = 16 * I + 4 * r + g; v[r] = row < nr ? base[cb + row] : 0.0; }
+                    return v;
+                };
                 if (w < 6) {
-                    const double* mp = mu + o;
-                    const v4d mraw = {mp[0], mp[4], mp[8], mp[12]};
+                    const v4d mraw = ld4(mu);
                     put_tile(ML, I, lane, j < P.nc ? mraw : v4d{0.0, 0.0, 0.0, 0.0});
                 } else {
-                    const double* u0p = z0 + P.off_U + o;
-                    const double* u1p = z1 + P.off_U + o;
-                    const v4d u0 = {u0p[0], u0p[4], u0p[8], u0p[12]};
-                    const v4d u1 = {u1p[0], u1p[4], u1p[8], u1p[12]};
+                    const v4d u0 = ld4(z0 + P.off_U);
+                    const v4d u1 = ld4(z1 + P.off_U);
                     put_tile(SL, I, lane, u1 + u0);
                     put_tile(DL, I, lane, u1 - u0);
                 }
@@ -246,8 +250,8 @@ __global__ __launch_bounds__(kHThreads32, 1) void qc_mfma32_pade4_hess_kernel(co
 #pragma unroll
                 for (int J = 0; J < 2; ++J) {
                     const v4d lin = (-hc1) * NkT[J], q = hc2 * (x0[J] + x1[J]);
-                    store_T(pUa, lin - q, J, g, j, P.nc);
-                    store_T(paU, lin + q, J, g, j, P.nc);
+                    store_T(pUa, lin - q, J, g, j, P.nc, P.n);
+                    store_T(paU, lin + q, J, g, j, P.nc, P.n);
                 }
             };
             // scalar blocks of this drive from registers + the partner's tiles in LDS: (a_k,h), (a_k,a_k), and the pairs
@@ -293,8 +297,8 @@ __global__ __launch_bounds__(kHThreads32, 1) void qc_mfma32_pade4_hess_kernel(co
                 v4d a0[1] = {M1a}, b0[1] = {gb0}, a1[1] = {M1b}, b1[1] = {gb1}, d[1];
                 mm16x2_multi<1>(a0, b0, a1, b1, d);      // M2^T[J] = sum_K M1[K]^T G[K][J]
                 const v4d m1t = lds_transpose16(scr, J == 0 ? M1a : M1b, g, j);   // M1^T[J] = (M1[J])^T
-                store_T(Hb + P.ho_Uh, -(c1 * m1t + c2h2 * d[0]), J, g, j, P.nc);
-                store_T(Hb + P.ho_hU, (-c1) * m1t + c2h2 * d[0], J, g, j, P.nc);
+                store_T(Hb + P.ho_Uh, -(c1 * m1t + c2h2 * d[0]), J, g, j, P.nc, P.n);
+                store_T(Hb + P.ho_hU, (-c1) * m1t + c2h2 * d[0], J, g, j, P.nc, P.n);
             } else if (w == 6) {      // (h, h)
                 const double sum = wave_sum(dot4(M1a, g_tile(GDL, 0, lane)) + dot4(M1b, g_tile(GDL, 1, lane)));
                 if (lane == 0) Hb[P.ho_hh] = 2.0 * c2 * sum;
@@ -314,7 +318,7 @@ __global__ __launch_bounds__(kHThreads32, 1) void qc_mfma32_pade4_hess_kernel(co
 }  // namespace
 
 bool qc_mfma32_hess_supported(const QcParams& P) {
-    return P.integrator == QC_PADE && P.p == 2 && P.n == 32 && P.nc <= 16 && P.m <= kHMax32 && P.Gx != nullptr;
+    return P.integrator == QC_PADE && P.p == 2 && P.n > 16 && P.n <= 32 && P.nc <= 16 && P.m <= kHMax32 && P.Gx != nullptr;
 }
 
 hipError_t qc_launch_mfma32_hess(const QcParams& P, const double* dZ, const double* dMu, double* dH, hipStream_t st) {

@@ -66,10 +66,16 @@ __device__ inline void store_T32(double* __restrict__ p, const v4d& x, int rowba
 #pragma unroll
     for (int r = 0; r < 4; ++r) qc_st8m<2>(p + (colbase + 4 * r + g) * 32 + rowbase + j, x[r]);   // non-temporal, compile-time
 }
-// the same for an n x nc state block (K < 16 kets): only the columns < nc exist
-__device__ inline void store_T32_cols(double* __restrict__ p, const v4d& x, int rowbase, int nc, int g, int j) {
+// the masked forms (KET instantiation): the state block has nr <= 32 rows per column and nc <= 16 columns; the operator
+// blocks are nr x nr (systems with 9 .. 15 levels are zero-padded to the 2 x 2 tiles)
+__device__ inline void store_T32_cols(double* __restrict__ p, const v4d& x, int rowbase, int nc, int nr, int g, int j) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) if (4 * r + g < nc) qc_st8m<2>(p + (4 * r + g) * 32 + rowbase + j, x[r]);
+    for (int r = 0; r < 4; ++r) if (4 * r + g < nc && rowbase + j < nr) qc_st8m<2>(p + (4 * r + g) * nr + rowbase + j, x[r]);
+}
+__device__ inline void store_T32_masked(double* __restrict__ p, const v4d& x, int rowbase, int colbase, int nr, int g, int j) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (colbase + 4 * r + g < nr && rowbase + j < nr) qc_st8m<2>(p + (colbase + 4 * r + g) * nr + rowbase + j, x[r]);
 }
 
 // KET: K < 16 ket states (column-masked loads and stores); false = unitary, every mask folds away at compile time
@@ -89,6 +95,7 @@ __global__ __launch_bounds__(kThreads32, 2) void qc_mfma32_pade4_kernel(const Qc
     const int mL = m < kMU32 ? m : kMU32;
     const int g = lane >> 4, j = lane & 15;
     const int nc = KET ? P.nc : 16;
+    const int nr = KET ? P.n : 32;
     const int jc = (!KET || j < nc) ? j : 0;
     const bool ft = P.off_dt >= 0;
     const double c1 = P.c[1], c2 = P.c[2];
@@ -129,10 +136,20 @@ __global__ __launch_bounds__(kThreads32, 2) void qc_mfma32_pade4_kernel(const Qc
         if (!copy_role) {
 #pragma unroll
             for (int I = 0; I < 2; ++I) {
-                const double* u0p = z0 + P.off_U + jc * 32 + 16 * I + g;    // columns >= nc re-read column 0; never stored
-                const double* u1p = z1 + P.off_U + jc * 32 + 16 * I + g;
-                const v4d u0 = {u0p[0], u0p[4], u0p[8], u0p[12]};
-                const v4d u1 = {u1p[0], u1p[4], u1p[8], u1p[12]};
+                v4d u0, u1;
+                if constexpr (!KET) {
+                    const double* u0p = z0 + P.off_U + jc * 32 + 16 * I + g;
+                    const double* u1p = z1 + P.off_U + jc * 32 + 16 * I + g;
+                    u0 = v4d{u0p[0], u0p[4], u0p[8], u0p[12]};
+                    u1 = v4d{u1p[0], u1p[4], u1p[8], u1p[12]};
+                } else {   // columns >= nc re-read column 0 (never stored); rows >= nr are the zero padding
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 16 * I + 4 * r + g;
+                        u0[r] = row < nr ? z0[P.off_U + jc * nr + row] : 0.0;
+                        u1[r] = row < nr ? z1[P.off_U + jc * nr + row] : 0.0;
+                    }
+                }
                 S[I] = u1 + u0;
                 D[I] = u1 - u0;
             }
@@ -198,6 +215,14 @@ __global__ __launch_bounds__(kThreads32, 2) void qc_mfma32_pade4_kernel(const Qc
                 double* pF = Jb + P.jo_F;
                 double* pB = Jb + P.jo_B;
                 for (int q = 0; q < (KET ? nc : 16); ++q) {
+                    if constexpr (KET) {
+                        const size_t o = (size_t)q * nr * nr;
+                        store_T32_masked(pF + o, Fm[0], 0, 16 * I, nr, g, j);
+                        store_T32_masked(pF + o, Fm[1], 16, 16 * I, nr, g, j);
+                        store_T32_masked(pB + o, Bm[0], 0, 16 * I, nr, g, j);
+                        store_T32_masked(pB + o, Bm[1], 16, 16 * I, nr, g, j);
+                        continue;
+                    }
                     store_T32(pF + q * 1024, Fm[0], 0, 16 * I, g, j);
                     store_T32(pF + q * 1024, Fm[1], 16, 16 * I, g, j);
                     store_T32(pB + q * 1024, Bm[0], 0, 16 * I, g, j);
@@ -247,10 +272,10 @@ __global__ __launch_bounds__(kThreads32, 2) void qc_mfma32_pade4_kernel(const Qc
 #pragma unroll
                 for (int I = 0; I < 2; ++I) {
                     const v4d dl = D[I] - hc1 * GS[I] + hc2 * G2D[I];
-                    if (Fb) { if constexpr (KET) store_T32_cols(Fb, mm16(dl, IdB), 16 * I, nc, g, j); else store_T32(Fb, mm16(dl, IdB), 16 * I, 0, g, j); }
+                    if (Fb) { if constexpr (KET) store_T32_cols(Fb, mm16(dl, IdB), 16 * I, nc, nr, g, j); else store_T32(Fb, mm16(dl, IdB), 16 * I, 0, g, j); }
                     if (JAC && ft) {
                         const v4d dh = (-c1) * GS[I] + (2.0 * c2 * h) * G2D[I];
-                        if constexpr (KET) store_T32_cols(Jb + P.jo_h, mm16(dh, IdB), 16 * I, nc, g, j); else store_T32(Jb + P.jo_h, mm16(dh, IdB), 16 * I, 0, g, j);
+                        if constexpr (KET) store_T32_cols(Jb + P.jo_h, mm16(dh, IdB), 16 * I, nc, nr, g, j); else store_T32(Jb + P.jo_h, mm16(dh, IdB), 16 * I, 0, g, j);
                     }
                 }
                 if (!JAC) deriv_rows_generic(P, z0, z1, h, Fb, nullptr, lane, false);
@@ -274,7 +299,7 @@ __global__ __launch_bounds__(kThreads32, 2) void qc_mfma32_pade4_kernel(const Qc
                     for (int I = 0; I < 2; ++I) {
                         const v4d R0 = mm16x2(Gk[2 * I], Q0[0], Gk[2 * I + 1], Q0[1]);          // G_k Q_0
                         const v4d Y = R0 + hc2 * mm16x2(Ga[2 * I], R1[0], Ga[2 * I + 1], R1[1]);   // + h^2 c2 G (G_k D)
-                        if constexpr (KET) store_T32_cols(pa, mm16(Y, IdB), 16 * I, nc, g, j); else store_T32(pa, mm16(Y, IdB), 16 * I, 0, g, j);
+                        if constexpr (KET) store_T32_cols(pa, mm16(Y, IdB), 16 * I, nc, nr, g, j); else store_T32(pa, mm16(Y, IdB), 16 * I, 0, g, j);
                     }
                 }
             }
@@ -301,7 +326,7 @@ size_t qc_mfma32_gx_doubles(const QcParams& P) { return (size_t)2 * (P.m + 1) * 
 // 32 x 32), followed by the B-layout images [matrix][tile = 2K+J][pair][lane][2]: lane (g, j) reg kk = X[16K + 4kk + g][16J + j]
 // (= A-layout images of the transposes; used by the Hessian kernel).
 void qc_mfma32_pack_G(const QcParams& P, const double* G, double* Gx) {
-    const int n = 32, M = P.m + 1;
+    const int n = P.n, M = P.m + 1;      // n < 32: zero-padded to the 2 x 2 tiles
     double* GxB = Gx + (size_t)M * 1024;
     for (int mat = 0; mat < M; ++mat) {
         const double* A = G + (size_t)mat * n * n;
@@ -311,7 +336,8 @@ void qc_mfma32_pack_G(const QcParams& P, const double* G, double* Gx) {
                 for (int l = 0; l < 64; ++l)
                     for (int e = 0; e < 2; ++e) {
                         const int g = l >> 4, j = l & 15, kk = 2 * pr + e;
-                        GxB[(((size_t)mat * 4 + tile) * 2 + pr) * 128 + l * 2 + e] = A[(size_t)(16 * J + j) * n + 16 * K + 4 * kk + g];
+                        const int rr = 16 * K + 4 * kk + g, cc = 16 * J + j;
+                        GxB[(((size_t)mat * 4 + tile) * 2 + pr) * 128 + l * 2 + e] = (rr < n && cc < n) ? A[(size_t)cc * n + rr] : 0.0;
                     }
         }
     }
@@ -323,7 +349,8 @@ void qc_mfma32_pack_G(const QcParams& P, const double* G, double* Gx) {
                 for (int l = 0; l < 64; ++l)
                     for (int e = 0; e < 2; ++e) {
                         const int g = l >> 4, i = l & 15, kk = 2 * pr + e;
-                        Gx[(((size_t)mat * 4 + tile) * 2 + pr) * 128 + l * 2 + e] = A[(size_t)(16 * K + 4 * kk + g) * n + 16 * I + i];
+                        const int rr = 16 * I + i, cc = 16 * K + 4 * kk + g;
+                        Gx[(((size_t)mat * 4 + tile) * 2 + pr) * 128 + l * 2 + e] = (rr < n && cc < n) ? A[(size_t)cc * n + rr] : 0.0;
                     }
         }
     }
@@ -333,7 +360,7 @@ hipError_t qc_launch_mfma32_F_jac(const QcParams& P, const double* dZ, double* d
     const int n_wg = (P.n_int + 1) / 2;
     const int grid = n_wg < kMaxGrid32 ? n_wg : kMaxGrid32;
     const bool diag = P.stamps != nullptr || P.dbg_skip != 0;
-    if (P.nc != 16) {
+    if (P.nc != 16 || P.n != 32) {
         if (dJ) hipLaunchKernelGGL((qc_mfma32_pade4_kernel<true, false, true>), dim3(grid), dim3(kThreads32), 0, st, P, dZ, dF, dJ);
         else hipLaunchKernelGGL((qc_mfma32_pade4_kernel<false, false, true>), dim3(grid), dim3(kThreads32), 0, st, P, dZ, dF, dJ);
         return hipGetLastError();

@@ -428,7 +428,7 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
 
 bool qc_mfma_supported(const QcParams& P) {
     if (qc_mfma_exp_supported(P) || qc_mfma32_exp_supported(P)) return true;
-    return P.integrator == QC_PADE && P.p == 2 && ((P.n <= 16 && P.nc <= 8) || (P.n == 32 && P.nc <= 16)) && P.m <= 32;
+    return P.integrator == QC_PADE && P.p == 2 && ((P.n <= 16 && P.nc <= 8) || (P.n <= 32 && P.nc <= 16)) && P.m <= 32;
 }
 
 size_t qc_mfma_gx_doubles(const QcParams& P) { return P.n > 16 ? qc_mfma32_gx_doubles(P) : (size_t)2 * (P.m + 1) * 256; }
