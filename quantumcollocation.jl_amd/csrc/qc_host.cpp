@@ -369,8 +369,21 @@ extern "C" int qc_create(const qc_desc* d, qc_handle** out) {
         while (Q.jchunk > 1 && qc_lds_bytes_jac(Q) > 64 * 1024) Q.jchunk = (Q.jchunk + 1) / 2;
         h->lds_bytes_jac = qc_lds_bytes_jac(Q);
         h->lds_bytes_hess = qc_lds_bytes_hess(Q);
-        if (h->lds_bytes_jac > 160 * 1024 || h->lds_bytes_hess > 160 * 1024)
-            return bail(QC_ERR_UNSUPPORTED, "qc_create: problem too large for the LDS kernel (needs > 160 KiB LDS per interval)");
+        if (h->lds_bytes_jac > 160 * 1024 || h->lds_bytes_hess > 160 * 1024) {
+            // Too large for LDS: the same kernels run with their scratch in a global-memory workspace (slow, but the
+            // library does not refuse the problem: 5 qubits, N = 32, are 2 N = 64 rows).
+            Q.use_ws = 1;
+            Q.jchunk = std::min(std::max(1, Q.m), 2);
+            h->lds_bytes_jac = qc_lds_bytes_jac(Q);
+            h->lds_bytes_hess = qc_lds_bytes_hess(Q);
+            const size_t per = (std::max(h->lds_bytes_jac, h->lds_bytes_hess) / sizeof(double) + 1) & ~(size_t)1;
+            const size_t total = per * (size_t)std::max(1, Q.n_int);
+            if (total * sizeof(double) > ((size_t)16 << 30))
+                return bail(QC_ERR_UNSUPPORTED, "qc_create: the global workspace for this system would exceed 16 GiB");
+            QC_HIP_C(hipMalloc((void**)&h->dWs, total * sizeof(double)));
+            Q.ws = h->dWs;
+            Q.ws_stride = (long long)per;
+        }
     }
     if (const char* e = getenv("QC_HOST_COMPACT")) h->host_compact = atoi(e);
     if (const char* e = getenv("QC_STAMPS")) {
@@ -390,7 +403,7 @@ extern "C" void qc_destroy(qc_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    double* bufs[] = {h->dG, h->dGx, h->dZ, h->dF, h->dJ, h->dMu, h->dH, (double*)h->dStamps, h->dRE, h->dRQ, h->dRS, h->dRinit, h->dRout};
+    double* bufs[] = {h->dG, h->dGx, h->dZ, h->dF, h->dJ, h->dMu, h->dH, (double*)h->dStamps, h->dRE, h->dRQ, h->dRS, h->dRinit, h->dRout, h->dWs};
     if (h->hJc) (void)hipHostFree(h->hJc);
     if (h->dBatch) (void)hipFree(h->dBatch);
     for (hipEvent_t ev : h->chunk_events) if (ev) (void)hipEventDestroy(ev);

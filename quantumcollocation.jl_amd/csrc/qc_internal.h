@@ -39,6 +39,9 @@ struct QcParams {
     int dbg_skip;            // diagnostic ablation (QC_DEBUG_SKIP): bit0 skip copy wave, bit1 skip compute wave
     const double* G;         // device: (m+1) matrices n*n, column-major; index 0 = drift
     const double* Gx;        // device: kernel-specific re-laid-out copy of G (MFMA path), or nullptr
+    int use_ws;              // LDS kernels: per-interval scratch in the global workspace `ws` (system too large for LDS)
+    double* ws;              // device: n_int * ws_stride doubles, or nullptr
+    long long ws_stride;
     unsigned long long* stamps;  // diagnostic: 16 s_memrealtime slots per interval, or nullptr (normal)
 };
 
@@ -64,6 +67,7 @@ struct qc_handle {
     struct qc_host_pool* pool = nullptr;       // worker threads of the compact transfer (created on first use)
     std::vector<hipEvent_t> chunk_events;
     int host_compact = 1;      // QC_HOST_COMPACT=0 disables the compact D2H path of the host-buffer entry points
+    double* dWs = nullptr;     // global workspace of the LDS kernels for systems beyond the LDS budget
     double *dRE = nullptr, *dRQ = nullptr, *dRS = nullptr, *dRinit = nullptr, *dRout = nullptr;   // rollout scratch / staging
     hipStream_t stream = nullptr;
     std::string err;

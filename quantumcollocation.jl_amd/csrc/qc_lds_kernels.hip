@@ -55,10 +55,14 @@ __device__ inline double wave_sum(double v) {
     return v;
 }
 
-template <bool JAC>
+// GWS: the per-interval scratch lives in a global-memory workspace instead of LDS (systems too large for 160 KB of LDS per
+// interval: N >= ~18 levels).  Same code, one workgroup per interval; __syncthreads orders the workgroup's global accesses.
+template <bool JAC, bool GWS>
 __global__ __launch_bounds__(kThreads) void qc_lds_pade_kernel(const QcParams P, const double* __restrict__ Z,
                                                                double* __restrict__ F, double* __restrict__ J) {
-    extern __shared__ __attribute__((aligned(16))) double sm[];
+    extern __shared__ __attribute__((aligned(16))) double lds_sm[];
+    double* sm;
+    if constexpr (GWS) sm = P.ws + (size_t)blockIdx.x * P.ws_stride; else sm = lds_sm;
     const int tid = threadIdx.x;
     const int b = qc_xcd_remap(blockIdx.x, gridDim.x);
     const long long t = P.t_begin + b;
@@ -252,10 +256,13 @@ __device__ inline void matmul_T_lds(double* __restrict__ C, const double* __rest
 }
 
 
+template <bool GWS>
 __global__ __launch_bounds__(kThreads) void qc_lds_pade_hess_kernel(const QcParams P, const double* __restrict__ Z,
                                                                     const double* __restrict__ Mu, double* __restrict__ H,
                                                                     int cj) {
-    extern __shared__ __attribute__((aligned(16))) double sm[];
+    extern __shared__ __attribute__((aligned(16))) double lds_sm[];
+    double* sm;
+    if constexpr (GWS) sm = P.ws + (size_t)blockIdx.x * P.ws_stride; else sm = lds_sm;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = qc_xcd_remap(blockIdx.x, gridDim.x);
     const long long t = P.t_begin + b;
@@ -517,10 +524,12 @@ __host__ __device__ inline LdsExpLayout exp_layout(const QcParams& P, int cj) {
     return L;
 }
 
-template <bool JAC>
+template <bool JAC, bool GWS>
 __global__ __launch_bounds__(kThreads) void qc_lds_exp_kernel(const QcParams P, const double* __restrict__ Z,
                                                               double* __restrict__ F, double* __restrict__ J, int cj) {
-    extern __shared__ __attribute__((aligned(16))) double sm[];
+    extern __shared__ __attribute__((aligned(16))) double lds_sm[];
+    double* sm;
+    if constexpr (GWS) sm = P.ws + (size_t)blockIdx.x * P.ws_stride; else sm = lds_sm;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = qc_xcd_remap(blockIdx.x, gridDim.x);
     const long long t = P.t_begin + b;
@@ -700,6 +709,7 @@ __global__ __launch_bounds__(kThreads) void qc_lds_exp_kernel(const QcParams P, 
 
 static int exp_chunk(const QcParams& P) {
     int cj = P.m > 0 ? P.m : 1;
+    if (P.use_ws) return cj < 2 ? cj : 2;       // global workspace: small chunks keep the workspace small
     while (cj > 1 && (size_t)exp_layout(P, cj).total * sizeof(double) > 64 * 1024) cj = (cj + 1) / 2;
     return cj;
 }
@@ -717,34 +727,41 @@ static hipError_t raise_lds_limit(K kernel, size_t lds) {
 
 hipError_t qc_launch_lds_F_jac(const QcParams& P, const double* dZ, double* dF, double* dJ, size_t lds, hipStream_t st) {
     const dim3 grid(P.n_int), block(kThreads);
+    if (P.use_ws) {   // scratch in the global workspace, no dynamic LDS
+        if (P.integrator == QC_EXPONENTIAL) {
+            const int cj = exp_chunk(P);
+            if (dJ) hipLaunchKernelGGL((qc_lds_exp_kernel<true, true>), grid, block, 0, st, P, dZ, dF, dJ, cj);
+            else hipLaunchKernelGGL((qc_lds_exp_kernel<false, true>), grid, block, 0, st, P, dZ, dF, dJ, cj);
+        } else if (dJ) {
+            hipLaunchKernelGGL((qc_lds_pade_kernel<true, true>), grid, block, 0, st, P, dZ, dF, dJ);
+        } else {
+            hipLaunchKernelGGL((qc_lds_pade_kernel<false, true>), grid, block, 0, st, P, dZ, dF, dJ);
+        }
+        return hipGetLastError();
+    }
     if (P.integrator == QC_EXPONENTIAL) {
         const int cj = exp_chunk(P);
-        hipError_t e = dJ ? raise_lds_limit(&qc_lds_exp_kernel<true>, lds) : raise_lds_limit(&qc_lds_exp_kernel<false>, lds);
+        hipError_t e = dJ ? raise_lds_limit(&qc_lds_exp_kernel<true, false>, lds) : raise_lds_limit(&qc_lds_exp_kernel<false, false>, lds);
         if (e != hipSuccess) return e;
-        if (dJ) hipLaunchKernelGGL(qc_lds_exp_kernel<true>, grid, block, lds, st, P, dZ, dF, dJ, cj);
-        else hipLaunchKernelGGL(qc_lds_exp_kernel<false>, grid, block, lds, st, P, dZ, dF, dJ, cj);
+        if (dJ) hipLaunchKernelGGL((qc_lds_exp_kernel<true, false>), grid, block, lds, st, P, dZ, dF, dJ, cj);
+        else hipLaunchKernelGGL((qc_lds_exp_kernel<false, false>), grid, block, lds, st, P, dZ, dF, dJ, cj);
         return hipGetLastError();
     }
     if (dJ) {
-        if (lds > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qc_lds_pade_kernel<true>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-        }
-        hipLaunchKernelGGL(qc_lds_pade_kernel<true>, grid, block, lds, st, P, dZ, dF, dJ);
+        hipError_t e = raise_lds_limit(&qc_lds_pade_kernel<true, false>, lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((qc_lds_pade_kernel<true, false>), grid, block, lds, st, P, dZ, dF, dJ);
     } else {
-        if (lds > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qc_lds_pade_kernel<false>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-        }
-        hipLaunchKernelGGL(qc_lds_pade_kernel<false>, grid, block, lds, st, P, dZ, dF, dJ);
+        hipError_t e = raise_lds_limit(&qc_lds_pade_kernel<false, false>, lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((qc_lds_pade_kernel<false, false>), grid, block, lds, st, P, dZ, dF, dJ);
     }
     return hipGetLastError();
 }
 
 static int hess_chunk(const QcParams& P) {
     int cj = P.m > 0 ? P.m : 1;
+    if (P.use_ws) return cj < 2 ? cj : 2;
     while (cj > 1 && (size_t)hess_layout(P, cj).total * sizeof(double) > 96 * 1024) cj = (cj + 1) / 2;
     return cj;
 }
@@ -757,11 +774,12 @@ size_t qc_lds_bytes_hess(const QcParams& P) {
 hipError_t qc_launch_lds_hess(const QcParams& P, const double* dZ, const double* dMu, double* dH, size_t lds, hipStream_t st) {
     if (P.integrator != QC_PADE) return hipErrorNotSupported;
     const int cj = hess_chunk(P);
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qc_lds_pade_hess_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
+    if (P.use_ws) {
+        hipLaunchKernelGGL(qc_lds_pade_hess_kernel<true>, dim3(P.n_int), dim3(kThreads), 0, st, P, dZ, dMu, dH, cj);
+        return hipGetLastError();
     }
-    hipLaunchKernelGGL(qc_lds_pade_hess_kernel, dim3(P.n_int), dim3(kThreads), lds, st, P, dZ, dMu, dH, cj);
+    hipError_t e = raise_lds_limit(&qc_lds_pade_hess_kernel<false>, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(qc_lds_pade_hess_kernel<false>, dim3(P.n_int), dim3(kThreads), lds, st, P, dZ, dMu, dH, cj);
     return hipGetLastError();
 }
