@@ -190,3 +190,61 @@ def test_sampling_problem_groups_and_placement(qc, oracle):
     bad, keep2 = qc.make_desc(groups[1], inp.traj, placement=dict(rows_per_interval=10, row_offset=8))
     dims = qc._lib.qc_dims_t()
     assert qc._lib.lib.qc_desc_dims(C.byref(bad), C.byref(dims)) == qc._lib.QC_ERR_INVALID
+
+
+def test_random_descriptors_structure_properties(qc, oracle):
+    """Host-only property sweep over random layouts: the structure vectors are duplicate-free, in range, upper-triangular
+    (Hessian), equal to the oracle's bit for bit, shard-wise concatenable, and their 1-based form is the 0-based one plus 1."""
+    from oracle_bridge import random_problem
+    rng = np.random.default_rng(2025)
+    L = qc._lib
+    for trial in range(40):
+        N = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 12, 16, 20]))
+        m = int(rng.integers(0, 5))
+        T = int(rng.integers(2, 7))
+        order = int(rng.choice([2, 4, 6]))
+        free_time = bool(rng.integers(0, 2))
+        integ = oracle.EXPONENTIAL if rng.random() < 0.25 else oracle.PADE
+        ncol = int(rng.integers(1, N + 1)) if rng.random() < 0.3 else 0
+        prob, _ = random_problem(oracle, N=N, m=max(m, 1), T=T, order=order, free_time=free_time, integrator=integ,
+                                 seed=int(rng.integers(1 << 30)), ncol=ncol, layout=str(rng.choice(["standard", "shuffled"])))
+        if m == 0:
+            prob.m = 0
+            prob.G_drives = prob.G_drives[:0]
+            prob.derivs = []
+        d = L.qc_desc()
+        d.N, d.m, d.T, d.zdim, d.global_dim = prob.N, prob.m, prob.T, prob.zdim, 0
+        d.off_U, d.off_a, d.off_dt, d.dt_fixed = prob.off_U, prob.off_a, prob.off_dt, prob.dt_fixed
+        d.integrator, d.pade_order, d.n_deriv, d.state_cols = prob.integrator, prob.order, len(prob.derivs), ncol
+        for i, dv in enumerate(prob.derivs):
+            d.deriv_x_off[i], d.deriv_dx_off[i], d.deriv_dim[i] = dv.x_off, dv.dx_off, dv.dim
+        tag = f"trial {trial}: N={N} m={m} T={T} order={order} ft={free_time} integ={integ} ncol={ncol}"
+        dims = qc.desc_dims(d)
+        assert dims.n_rows == prob.n_rows and dims.n_cols == prob.n_vars, tag
+        jr, jc, hr, hc = qc.desc_structures(d)
+        orr, oc = oracle.jac_structure(prob)
+        np.testing.assert_array_equal(jr, orr, err_msg=tag)
+        np.testing.assert_array_equal(jc, oc, err_msg=tag)
+        assert jr.size == dims.jac_nnz and len(set(zip(jr.tolist(), jc.tolist()))) == jr.size, tag
+        assert jr.min() >= 0 and jr.max() < dims.n_rows and jc.min() >= 0 and jc.max() < dims.n_cols, tag
+        if integ == oracle.PADE:
+            ohr, ohc = oracle.hess_structure(prob)
+            np.testing.assert_array_equal(hr, ohr, err_msg=tag)
+            np.testing.assert_array_equal(hc, ohc, err_msg=tag)
+            if hr.size:
+                assert np.all(hr <= hc) and len(set(zip(hr.tolist(), hc.tolist()))) == hr.size and hc.max() < dims.n_cols, tag
+        else:
+            assert hr.size == 0, tag
+        jr1, jc1, hr1, hc1 = qc.desc_structures(d, one_based=True)
+        np.testing.assert_array_equal(jr1, jr + 1)
+        np.testing.assert_array_equal(hc1, hc + 1)
+        if T >= 4:      # two shards concatenate to the whole
+            cut = int(rng.integers(1, T - 1))
+            parts = []
+            for tb, te in ((0, cut), (cut, T - 1)):
+                d.t_begin, d.t_end = tb, te
+                parts.append(qc.desc_structures(d))
+            d.t_begin, d.t_end = 0, 0
+            np.testing.assert_array_equal(np.concatenate([p[0] for p in parts]), jr, err_msg=tag)
+            np.testing.assert_array_equal(np.concatenate([p[1] for p in parts]), jc, err_msg=tag)
+            np.testing.assert_array_equal(np.concatenate([p[2] for p in parts]), hr, err_msg=tag)
