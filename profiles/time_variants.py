@@ -57,8 +57,8 @@ time_dyn("config 5 Pade-4 (mfma32)", qc.config_inputs(5))
 time_dyn("config 5 exponential (mfma32-exp)", qc.unitary_smooth_pulse_inputs(qc.multi_qubit_system(4), qc.GATES["QFT16"], 500, integrator="exponential"), reps=50)
 time_dyn("config 5 exponential (lds)", qc.unitary_smooth_pulse_inputs(qc.multi_qubit_system(4), qc.GATES["QFT16"], 500, integrator="exponential"), reps=5, kernel="lds")
 s2 = qc.multi_qubit_system(2)
-time_dyn("config 2 Pade-4 (lds)", qc.config_inputs(2))
-time_dyn("config 2 exponential (lds)", qc.unitary_smooth_pulse_inputs(s2, qc.GATES["CX"], 200, integrator="exponential"))
+time_dyn("config 2 Pade-4 (mfma16, padded)", qc.config_inputs(2))
+time_dyn("config 2 exponential (mfma16-exp, padded)", qc.unitary_smooth_pulse_inputs(s2, qc.GATES["CX"], 200, integrator="exponential"))
 kets0 = [np.eye(8)[:, k] for k in range(4)]
 kets1 = [np.eye(8)[:, (k + 1) % 8] for k in range(4)]
 time_dyn("4 kets on 3 qubits, T=1000, Pade-4 (mfma16, masked)", qc.quantum_state_smooth_pulse_inputs(s3, kets0, kets1, 1000))
