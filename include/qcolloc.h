@@ -197,6 +197,16 @@ int qc_eval_hess_dev_multi(qc_handle* const* hs, int32_t count, const double* dZ
 typedef struct qc_fidelity qc_fidelity;
 int qc_fidelity_create(int32_t N, const double* goal_iso, const int32_t* subspace /* 0-based, or NULL */, int32_t n_sub,
                        int32_t device, qc_fidelity** out);
+/* Ket and density-operator states (quantum_state_smooth_pulse_problem.jl:133 `QuantumStateObjective`,
+ * quantum_state_minimum_time_problem.jl:50-62 `iso_fidelity` / `FinalQuantumStateFidelityConstraint`,
+ * density_operator_smooth_pulse_problem.jl:55 `DensityOperatorPureStateInfidelityObjective`):
+ *   QC_FID_KET      state psi~ (2N),      F = |<psi_goal|psi>|^2
+ *   QC_FID_DENSITY  state rho~ (2N^2),    F = psi_goal' rho psi_goal   (linear)
+ * goal_ket_iso = [Re psi_goal; Im psi_goal] in both cases; loss |1 - F|, gradients / Hessians as for the unitary kind. */
+#define QC_FID_UNITARY 0
+#define QC_FID_KET 1
+#define QC_FID_DENSITY 2
+int qc_fidelity_create_kind(int32_t kind, int32_t N, const double* goal_ket_iso, int32_t device, qc_fidelity** out);
 void qc_fidelity_destroy(qc_fidelity* h);
 const char* qc_fidelity_last_error(const qc_fidelity* h);
 /* host buffers; any of fidelity / infidelity / grad / hess may be NULL */

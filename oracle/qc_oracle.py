@@ -638,3 +638,26 @@ def rollout(prob: Problem, Z: np.ndarray, init: np.ndarray) -> np.ndarray:
         X = expm_taylor(h * _G_of(prob, a)) @ X
         out[:, t + 1] = _vec(X)
     return out
+
+
+# --------------------------------------------------------------------------------------------
+#  Ket and density-operator fidelities of the final knot (reference quantum_state_minimum_time_problem.jl:50 `iso_fidelity`,
+#  quantum_state_smooth_pulse_problem.jl:133, density_operator_smooth_pulse_problem.jl:55).  The definitions
+#  (|<g|psi>|^2, psi' rho psi) are recalled from PiccoloQuantumObjects 0.3, which is not vendored.
+# --------------------------------------------------------------------------------------------
+def ket_fidelity_value_grad_hess(psi_iso: np.ndarray, goal_iso: np.ndarray):
+    N = goal_iso.size // 2
+    g = goal_iso[:N] + 1j * goal_iso[N:]
+    gr = np.concatenate([g.real, g.imag])
+    gi = np.concatenate([-g.imag, g.real])
+    tr, ti = gr @ psi_iso, gi @ psi_iso
+    F = tr * tr + ti * ti
+    return F, 2.0 * (tr * gr + ti * gi), 2.0 * (np.outer(gr, gr) + np.outer(gi, gi))
+
+
+def density_fidelity_value_grad(rho_iso: np.ndarray, goal_ket_iso: np.ndarray):
+    N = goal_ket_iso.size // 2
+    g = goal_ket_iso[:N] + 1j * goal_ket_iso[N:]
+    P = np.outer(g, g.conj())
+    gr = np.concatenate([P.real.reshape(-1, order="F"), P.imag.reshape(-1, order="F")])
+    return float(gr @ rho_iso), gr

@@ -31,6 +31,7 @@ QC_KERNEL_AUTO = 0
 QC_KERNEL_LDS = 1
 QC_KERNEL_MFMA = 2
 QC_MAX_DERIV = 8
+QC_FID_UNITARY, QC_FID_KET, QC_FID_DENSITY = 0, 1, 2
 QC_REG_DT_SCALED = 0
 QC_REG_PLAIN = 1
 
@@ -137,6 +138,7 @@ SYMBOLS = {
     "qc_eval_F_jac_dev_multi": (C.c_int, [C.POINTER(_H), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "qc_eval_hess_dev_multi": (C.c_int, [C.POINTER(_H), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "qc_fidelity_create": (C.c_int, [C.c_int32, _c_double_p, C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.POINTER(_H)]),
+    "qc_fidelity_create_kind": (C.c_int, [C.c_int32, C.c_int32, _c_double_p, C.c_int32, C.POINTER(_H)]),
     "qc_fidelity_destroy": (None, [_H]),
     "qc_fidelity_last_error": (C.c_char_p, [_H]),
     "qc_fidelity_eval": (C.c_int, [_H, _c_double_p, _c_double_p, _c_double_p, _c_double_p, _c_double_p]),

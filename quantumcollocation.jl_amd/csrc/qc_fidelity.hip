@@ -12,7 +12,7 @@
 #include "qc_internal.h"
 
 struct qc_fidelity {
-    int N = 0, s = 0, n_sub = 0, device = 0;
+    int N = 0, s = 0, n_sub = 0, device = 0, kind = QC_FID_UNITARY;
     double *dgr = nullptr, *dgi = nullptr, *dU = nullptr, *dOut = nullptr;   // dOut: [value(2: F, l) | gradF (s) | hessF (s(s+1)/2)]
     hipStream_t stream = nullptr;
     std::string err;
@@ -21,7 +21,7 @@ struct qc_fidelity {
 namespace {
 
 __global__ __launch_bounds__(256) void qc_fidelity_kernel(const double* __restrict__ u, const double* __restrict__ gr,
-                                                          const double* __restrict__ gi, int s, int n_sub,
+                                                          const double* __restrict__ gi, int s, int n_sub, int kind,
                                                           double* __restrict__ val, double* __restrict__ grad,
                                                           double* __restrict__ hess) {
     __shared__ double red[2][4];
@@ -43,11 +43,27 @@ __global__ __launch_bounds__(256) void qc_fidelity_kernel(const double* __restri
     const double tr = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
     const double ti = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
     const double n = (double)n_sub;
-    const double Fv = sqrt(tr * tr + ti * ti) / n;
+    // unitary: F = |t| / n;   ket: F = |t|^2 (iso_fidelity);   density operator against a pure goal: F = Re t = psi' rho psi
+    const double Fv = kind == QC_FID_UNITARY ? sqrt(tr * tr + ti * ti) / n : (kind == QC_FID_KET ? tr * tr + ti * ti : tr);
     const double inv = 1.0 / (n * n * Fv);
     if (tid == 0) {
         val[0] = Fv;
         val[1] = fabs(1.0 - Fv);
+    }
+    if (kind != QC_FID_UNITARY) {
+        for (int i = tid; i < s; i += 256) {
+            if (grad) grad[i] = kind == QC_FID_KET ? 2.0 * (tr * gr[i] + ti * gi[i]) : gr[i];
+        }
+        if (!hess) return;
+        const long long nh2 = (long long)s * (s + 1) / 2;
+        for (long long e = tid; e < nh2; e += 256) {
+            int j = (int)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
+            while ((long long)(j + 1) * (j + 2) / 2 <= e) ++j;
+            while ((long long)j * (j + 1) / 2 > e) --j;
+            const int i = (int)(e - (long long)j * (j + 1) / 2);
+            hess[e] = kind == QC_FID_KET ? 2.0 * (gr[i] * gr[j] + gi[i] * gi[j]) : 0.0;
+        }
+        return;
     }
     const bool stage = s <= 1024;
     for (int i = tid; i < s; i += 256) {
@@ -134,6 +150,56 @@ extern "C" int qc_fidelity_create(int32_t N, const double* goal_iso, const int32
     return QC_OK;
 }
 
+// Ket and density-operator fidelities share the handle: only the constant vectors g_r, g_i and the formula differ.
+extern "C" int qc_fidelity_create_kind(int32_t kind, int32_t N, const double* goal_ket_iso, int32_t device, qc_fidelity** out) {
+    if (!out) return ffail(nullptr, QC_ERR_INVALID, "qc_fidelity_create_kind: out is NULL");
+    *out = nullptr;
+    if (kind != QC_FID_KET && kind != QC_FID_DENSITY) return ffail(nullptr, QC_ERR_INVALID, "qc_fidelity_create_kind: kind must be QC_FID_KET or QC_FID_DENSITY");
+    if (N < 1 || N > 64 || !goal_ket_iso) return ffail(nullptr, QC_ERR_INVALID, "qc_fidelity_create_kind: bad N or goal");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return ffail(nullptr, QC_ERR_NO_DEVICE, "qc_fidelity_create_kind: no HIP device visible");
+    if (device < 0 || device >= ndev) return ffail(nullptr, QC_ERR_NO_DEVICE, "qc_fidelity_create_kind: device ordinal out of range");
+    qc_fidelity* h = new qc_fidelity();
+    h->N = N;
+    h->kind = kind;
+    h->n_sub = 1;
+    h->device = device;
+    h->s = kind == QC_FID_KET ? 2 * N : 2 * N * N;
+    std::vector<double> gr(h->s, 0.0), gi(h->s, 0.0);
+    const double* gre = goal_ket_iso;        // [Re psi_goal; Im psi_goal]
+    const double* gim = goal_ket_iso + N;
+    if (kind == QC_FID_KET) {
+        // <g|psi> = (g_re . p_re + g_im . p_im) + i (g_re . p_im - g_im . p_re)
+        for (int i = 0; i < N; ++i) {
+            gr[i] = gre[i];  gr[N + i] = gim[i];
+            gi[i] = -gim[i]; gi[N + i] = gre[i];
+        }
+    } else {
+        // psi' rho psi = sum_ij conj(psi_i) rho_ij psi_j = <P, rho>_F with P = psi psi'; real for Hermitian rho:
+        // Re <P, rho> = sum Re P_ij Re rho_ij + Im P_ij Im rho_ij on the iso-vec [vec(Re rho); vec(Im rho)] (column-major)
+        for (int j = 0; j < N; ++j)
+            for (int i = 0; i < N; ++i) {
+                const double pre = gre[i] * gre[j] + gim[i] * gim[j];       // Re (psi_i conj(psi_j))
+                const double pim = gim[i] * gre[j] - gre[i] * gim[j];       // Im (psi_i conj(psi_j))
+                gr[j * N + i] = pre;
+                gr[N * N + j * N + i] = pim;
+            }
+    }
+    auto bail = [&](hipError_t e, const char* what) { std::string m = std::string(what) + ": " + hipGetErrorString(e); qc_fidelity_destroy(h); return ffail(nullptr, QC_ERR_HIP, m); };
+    hipError_t e;
+    if ((e = hipSetDevice(device)) != hipSuccess) return bail(e, "hipSetDevice");
+    const size_t nout = 2 + (size_t)h->s + (size_t)h->s * (h->s + 1) / 2;
+    if ((e = hipMalloc((void**)&h->dgr, h->s * 8)) != hipSuccess) return bail(e, "hipMalloc");
+    if ((e = hipMalloc((void**)&h->dgi, h->s * 8)) != hipSuccess) return bail(e, "hipMalloc");
+    if ((e = hipMalloc((void**)&h->dU, h->s * 8)) != hipSuccess) return bail(e, "hipMalloc");
+    if ((e = hipMalloc((void**)&h->dOut, nout * 8)) != hipSuccess) return bail(e, "hipMalloc");
+    if ((e = hipMemcpy(h->dgr, gr.data(), h->s * 8, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy");
+    if ((e = hipMemcpy(h->dgi, gi.data(), h->s * 8, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy");
+    if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
+    *out = h;
+    return QC_OK;
+}
+
 extern "C" void qc_fidelity_destroy(qc_fidelity* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
@@ -145,7 +211,7 @@ extern "C" void qc_fidelity_destroy(qc_fidelity* h) {
 extern "C" int qc_fidelity_eval_dev(qc_fidelity* h, const double* dU, double* dval2, double* dgrad, double* dhess, void* stream) {
     if (!h) return ffail(nullptr, QC_ERR_INVALID, "qc_fidelity_eval_dev: NULL handle");
     if (!dU || !dval2) return ffail(h, QC_ERR_INVALID, "qc_fidelity_eval_dev: NULL buffer");
-    hipLaunchKernelGGL(qc_fidelity_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, dU, h->dgr, h->dgi, h->s, h->n_sub, dval2, dgrad, dhess);
+    hipLaunchKernelGGL(qc_fidelity_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, dU, h->dgr, h->dgi, h->s, h->n_sub, h->kind, dval2, dgrad, dhess);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return ffail(h, QC_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
     return QC_OK;

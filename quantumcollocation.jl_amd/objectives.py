@@ -25,16 +25,26 @@ from .named_trajectory import NamedTrajectory
 
 
 class _Fidelity:
-    def __init__(self, goal_iso: np.ndarray, subspace: Optional[Sequence[int]] = None, device: int = 0):
+    def __init__(self, goal_iso: np.ndarray, subspace: Optional[Sequence[int]] = None, device: int = 0, kind: str = "unitary"):
         goal_iso = np.ascontiguousarray(goal_iso, dtype=np.float64)
-        self.N = int(round((goal_iso.size / 2) ** 0.5))
-        self.s = 2 * self.N * self.N
-        if goal_iso.size != self.s:
-            raise ValueError("goal must be an iso-vec of length 2 N^2")
-        sub = None if subspace is None else np.ascontiguousarray(subspace, dtype=np.int32)
         self._h = C.c_void_p()
-        rc = _lib.lib.qc_fidelity_create(self.N, _lib.dptr(goal_iso), None if sub is None else sub.ctypes.data_as(C.POINTER(C.c_int32)),
-                                         0 if sub is None else sub.size, device, C.byref(self._h))
+        if kind == "unitary":
+            self.N = int(round((goal_iso.size / 2) ** 0.5))
+            self.s = 2 * self.N * self.N
+            if goal_iso.size != self.s:
+                raise ValueError("goal must be an iso-vec of length 2 N^2")
+            sub = None if subspace is None else np.ascontiguousarray(subspace, dtype=np.int32)
+            rc = _lib.lib.qc_fidelity_create(self.N, _lib.dptr(goal_iso), None if sub is None else sub.ctypes.data_as(C.POINTER(C.c_int32)),
+                                             0 if sub is None else sub.size, device, C.byref(self._h))
+        else:   # "ket": state psi~ (2N);  "density": state rho~ (2N^2) against the pure goal |psi_goal><psi_goal|
+            if subspace is not None:
+                raise ValueError("subspace applies to unitary fidelities only")
+            if goal_iso.size % 2:
+                raise ValueError("the goal ket must be an iso-vec [Re psi; Im psi]")
+            self.N = goal_iso.size // 2
+            self.s = 2 * self.N if kind == "ket" else 2 * self.N * self.N
+            rc = _lib.lib.qc_fidelity_create_kind(_lib.QC_FID_KET if kind == "ket" else _lib.QC_FID_DENSITY, self.N, _lib.dptr(goal_iso),
+                                                  device, C.byref(self._h))
         if rc != _lib.QC_OK:
             raise _lib.QCollocError(rc, _lib.lib.qc_fidelity_last_error(None).decode())
 
@@ -73,15 +83,18 @@ def iso_vec_unitary_fidelity(U_T: np.ndarray, U_G: np.ndarray, subspace: Optiona
 
 class _FinalKnotTerm:
     _ALIASES = {}
+    _KIND = "unitary"
 
-    def __init__(self, state_name: str, traj: NamedTrajectory, subspace, device):
+    def __init__(self, state_name: str, traj: NamedTrajectory, subspace, device, goal=None):
         self.traj = traj
         self.s = len(traj.components[state_name])
         self.first = (traj.T - 1) * traj.dim + traj.offset(state_name)     # 0-based global index of the final state
-        goal = traj.goal.get(state_name)
+        goal = traj.goal.get(state_name) if goal is None else goal
         if goal is None:
             raise ValueError(f"trajectory has no goal for {state_name}")
-        self._f = _Fidelity(np.asarray(goal, dtype=np.float64), subspace, device)
+        self._f = _Fidelity(np.asarray(goal, dtype=np.float64), subspace, device, kind=type(self)._KIND)
+        if self._f.s != self.s:
+            raise ValueError(f"component {state_name} has length {self.s}, the goal implies {self._f.s}")
         self.state_indices = np.arange(self.first, self.first + self.s)
         r, c = np.triu_indices(self.s)
         # column-major upper triangle: entry (i <= j) at j(j+1)/2 + i
@@ -140,6 +153,44 @@ class FinalUnitaryFidelityConstraint(_FinalKnotTerm):
 
     def mu_d2g(self, Z, mu) -> np.ndarray:
         return float(np.asarray(mu).ravel()[0]) * self._f.eval(self._u(Z), grad=False, hess=True)[3]
+
+
+def iso_fidelity(psi_iso: np.ndarray, psi_goal_iso: np.ndarray, device: int = 0) -> float:
+    """|<psi_goal|psi>|^2 on ket iso-vecs (reference quantum_state_minimum_time_problem.jl:50)."""
+    f = _Fidelity(psi_goal_iso, None, device, kind="ket")
+    try:
+        return f.eval(psi_iso, grad=False, hess=False)[0]
+    finally:
+        f.close()
+
+
+class QuantumStateObjective(UnitaryInfidelityObjective):
+    """Q * |1 - |<psi_goal|psi_T>|^2| on the final ket (reference quantum_state_smooth_pulse_problem.jl:133)."""
+    _KIND = "ket"
+
+    def __init__(self, state_name: str, traj: NamedTrajectory, Q: float = 100.0, device: int = 0):
+        _FinalKnotTerm.__init__(self, state_name, traj, None, device)
+        self.Q = float(Q)
+
+
+class FinalQuantumStateFidelityConstraint(FinalUnitaryFidelityConstraint):
+    """g(Z) = |<psi_goal|psi_T>|^2 - value >= 0 (reference quantum_state_minimum_time_problem.jl:55-62)."""
+    _KIND = "ket"
+
+    def __init__(self, state_name: str, value: float, traj: NamedTrajectory, device: int = 0):
+        _FinalKnotTerm.__init__(self, state_name, traj, None, device)
+        self.value = float(value)
+        self.dim = 1
+
+
+class DensityOperatorPureStateInfidelityObjective(UnitaryInfidelityObjective):
+    """Q * |1 - psi_goal' rho_T psi_goal| on the final density iso-vec (reference density_operator_smooth_pulse_problem.jl:55)."""
+    _KIND = "density"
+
+    def __init__(self, state_name: str, psi_goal: np.ndarray, traj: NamedTrajectory, Q: float = 100.0, device: int = 0):
+        psi_goal = np.asarray(psi_goal, dtype=complex)
+        _FinalKnotTerm.__init__(self, state_name, traj, None, device, goal=np.concatenate([psi_goal.real, psi_goal.imag]))
+        self.Q = float(Q)
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -97,3 +97,91 @@ def test_objective_and_constraint_mirror(qc, oracle):
     np.testing.assert_allclose(con.mu_d2g(Z, [2.5]), 2.5 * HF[np.triu_indices(32)][np.lexsort((np.triu_indices(32)[0], np.triu_indices(32)[1]))], rtol=1e-9, atol=1e-11)
     obj.close()
     con.close()
+
+
+def test_ket_and_density_fidelity_known_answers(oracle):
+    rng = np.random.default_rng(3)
+    for N in (2, 3, 8):
+        g = rng.standard_normal(N) + 1j * rng.standard_normal(N)
+        g /= np.linalg.norm(g)
+        p = rng.standard_normal(N) + 1j * rng.standard_normal(N)
+        p /= np.linalg.norm(p)
+        giso, piso = np.concatenate([g.real, g.imag]), np.concatenate([p.real, p.imag])
+        F, grad, H = oracle.ket_fidelity_value_grad_hess(piso, giso)
+        assert abs(F - abs(np.vdot(g, p)) ** 2) < 1e-14
+        assert abs(oracle.ket_fidelity_value_grad_hess(giso, giso)[0] - 1.0) < 1e-14
+        eps = 1e-6
+        gfd = np.array([(oracle.ket_fidelity_value_grad_hess(piso + eps * e, giso)[0] - oracle.ket_fidelity_value_grad_hess(piso - eps * e, giso)[0]) / (2 * eps)
+                        for e in np.eye(2 * N)])
+        np.testing.assert_allclose(grad, gfd, rtol=1e-7, atol=1e-9)
+        Hfd = np.array([(oracle.ket_fidelity_value_grad_hess(piso + eps * e, giso)[1] - oracle.ket_fidelity_value_grad_hess(piso - eps * e, giso)[1]) / (2 * eps)
+                        for e in np.eye(2 * N)])
+        np.testing.assert_allclose(H, Hfd, rtol=1e-6, atol=1e-8)
+        # density: psi' rho psi for a mixed state, and 1 for rho = |g><g|
+        A = rng.standard_normal((N, N)) + 1j * rng.standard_normal((N, N))
+        rho = A @ A.conj().T
+        rho /= np.trace(rho)
+        riso = np.concatenate([rho.real.reshape(-1, order="F"), rho.imag.reshape(-1, order="F")])
+        Fd, gd = oracle.density_fidelity_value_grad(riso, giso)
+        assert abs(Fd - np.real(np.vdot(g, rho @ g))) < 1e-14
+        P = np.outer(g, g.conj())
+        assert abs(oracle.density_fidelity_value_grad(np.concatenate([P.real.reshape(-1, order="F"), P.imag.reshape(-1, order="F")]), giso)[0] - 1) < 1e-14
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N", [2, 3, 8, 16])
+def test_ket_and_density_fidelity_kernels(qc, oracle, N):
+    from qcolloc_amd.objectives import _Fidelity
+    rng = np.random.default_rng(20 + N)
+    g = rng.standard_normal(N) + 1j * rng.standard_normal(N)
+    g /= np.linalg.norm(g)
+    giso = np.concatenate([g.real, g.imag])
+    p = rng.standard_normal(2 * N)
+    f = _Fidelity(giso, kind="ket")
+    F, L, grad, H = f.eval(p)
+    Fr, gr, Hr = oracle.ket_fidelity_value_grad_hess(p, giso)
+    assert abs(F - Fr) < 1e-13 * max(1, abs(Fr)) and abs(L - abs(1 - Fr)) < 1e-13 * max(1, abs(Fr))
+    np.testing.assert_allclose(grad, gr, rtol=1e-13, atol=1e-14)
+    r, c = np.triu_indices(2 * N)
+    order = np.lexsort((r, c))
+    np.testing.assert_allclose(H, Hr[r[order], c[order]], rtol=1e-13, atol=1e-14)
+    assert abs(qc.iso_fidelity(p, giso) - Fr) < 1e-13 * max(1, abs(Fr))
+    f.close()
+    rho = rng.standard_normal(2 * N * N)
+    fd = _Fidelity(giso, kind="density")
+    F, L, grad, H = fd.eval(rho)
+    Fr, gr = oracle.density_fidelity_value_grad(rho, giso)
+    assert abs(F - Fr) < 1e-13 * max(1, abs(Fr))
+    np.testing.assert_allclose(grad, gr, rtol=1e-14, atol=1e-15)
+    assert not H.any()
+    fd.close()
+
+
+@pytest.mark.gpu
+def test_ket_and_density_objectives_through_the_host_mirror(qc, oracle):
+    sys_ = qc.multi_qubit_system(2)
+    psi0, psi1 = np.eye(4)[:, 0].astype(complex), (np.eye(4)[:, 1] + 1j * np.eye(4)[:, 2]) / np.sqrt(2)
+    inp = qc.quantum_state_smooth_pulse_inputs(sys_, [psi0], [psi1], 7)
+    traj = inp.traj
+    name = [n for n in traj.names if n.startswith("ψ̃")][0]
+    traj.goal[name] = np.concatenate([psi1.real, psi1.imag])
+    obj = qc.QuantumStateObjective(name, traj, Q=50.0)
+    con = qc.FinalQuantumStateFidelityConstraint(name, 0.9, traj)
+    Z = traj.datavec
+    u = Z[obj.state_indices]
+    Fr, gr, Hr = oracle.ket_fidelity_value_grad_hess(u, traj.goal[name])
+    assert abs(obj.L(Z) - 50.0 * abs(1 - Fr)) < 1e-12
+    np.testing.assert_allclose(obj.grad_L(Z), -np.sign(1 - Fr) * 50.0 * gr, rtol=1e-12, atol=1e-13)
+    assert abs(con.g(Z)[0] - (Fr - 0.9)) < 1e-13
+    np.testing.assert_allclose(con.dg(Z), gr, rtol=1e-12, atol=1e-13)
+    import test_density
+    osys = test_density.open_system(qc, 1)
+    psi = np.array([0.6, 0.8j])
+    dinp = qc.density_operator_smooth_pulse_inputs(osys, np.eye(2) / 2, psi, 6)
+    dobj = qc.DensityOperatorPureStateInfidelityObjective("ρ⃗̃", psi, dinp.traj, Q=10.0)
+    Zd = dinp.traj.datavec
+    Fd, gd = oracle.density_fidelity_value_grad(Zd[dobj.state_indices], np.concatenate([psi.real, psi.imag]))
+    assert abs(dobj.L(Zd) - 10.0 * abs(1 - Fd)) < 1e-12
+    np.testing.assert_allclose(dobj.grad_L(Zd), -np.sign(1 - Fd) * 10.0 * gd, rtol=1e-12, atol=1e-13)
+    for o in (obj, con, dobj):
+        o.close()
