@@ -98,11 +98,18 @@ __device__ __forceinline__ void square_step(const v4d& Et, const v4d (&Kt)[M], v
     E = accE;
 }
 
-template <bool JAC, int kMU>
-__global__ __launch_bounds__(64, 1) void qc_mfma16_exp_kernel(const QcParams P, const double* __restrict__ Z, double* __restrict__ F,
-                                                              double* __restrict__ J) {
-    __shared__ double scr[(kMU + 1) * 16 * 17];      // transpose scratch: E and the kMU L_j tiles in one LDS round trip
-    const int lane = threadIdx.x;
+// kW wavefronts per interval, each with its own kMU drives (and, redundantly, the shared chain R: 4 MFMAs per step).  The
+// waves never exchange data: no barrier.  Two waves per interval fill the chip on short trajectories (T = 200: 18.3 -> 11.9 us);
+// at T = 1000 one wave per interval already occupies every SIMD and the kernel is bound by MFMA issue at the clock the
+// device sustains under FP64 matrix load (two waves there: 30.8 vs 30.3 us, the redundant R chain costs what the overlap gains).
+template <bool JAC, int kMU, int kW>
+__global__ __launch_bounds__(64 * kW, kW) void qc_mfma16_exp_kernel(const QcParams P, const double* __restrict__ Z, double* __restrict__ F,
+                                                                    double* __restrict__ J) {
+    __shared__ double scr_all[kW * (kMU + 1) * 16 * 17];      // per-wave transpose scratch: E and the kMU L_j tiles in one LDS round trip
+    const int lane = threadIdx.x & 63;
+    const int wv = kW > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
+    double* __restrict__ scr = scr_all + wv * ((kMU + 1) * 16 * 17);
+    const int d0 = wv * kMU;                          // first drive of this wave
     const int m = P.m;
     const int g = lane >> 4, j = lane & 15, jj = j & 7;
     const bool ft = P.off_dt >= 0;
@@ -132,18 +139,27 @@ __global__ __launch_bounds__(64, 1) void qc_mfma16_exp_kernel(const QcParams P, 
             u1[r] = row < nr ? z1[P.off_U + jc * nr + row] : 0.0;
         }
         v4d Gj[kMU];
-        double ak[kMU];
         v4d Ga = ximg(Gx, 0, lane);
+        {   // G = G_0 + sum over ALL drives (every wave assembles it); unconditional clamped loads, one batch
+            constexpr int kMA = kXMmax;       // every drive enters G, whatever subset this wave differentiates
+            v4d img[kMA];
+            double ak[kMA];
 #pragma unroll
-        for (int u = 0; u < kMU; ++u) {
-            const int k = u < m ? u : (m > 0 ? m - 1 : 0);       // clamped: the load is unconditional
-            Gj[u] = ximg(Gx, m > 0 ? k + 1 : 0, lane);
-            ak[u] = (u < m) ? z0[P.off_a + k] : 0.0;
+            for (int u = 0; u < kMA; ++u) {
+                const int k = u < m ? u : (m > 0 ? m - 1 : 0);
+                img[u] = ximg(Gx, m > 0 ? k + 1 : 0, lane);
+                ak[u] = (u < m) ? z0[P.off_a + k] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < kMU; ++u) {
+                const int k = d0 + u;                              // this wave's drives (their own loads: no dynamic register index)
+                Gj[u] = ximg(Gx, k < m ? k + 1 : 0, lane);
+            }
+#pragma unroll
+            for (int u = 0; u < kMA; ++u) Ga += ak[u] * img[u];
         }
 #pragma unroll
-        for (int u = 0; u < kMU; ++u) Ga += ak[u] * Gj[u];
-#pragma unroll
-        for (int u = 0; u < kMU; ++u) if (u >= m) Gj[u] = zero;   // unused drive slots: their chains stay zero
+        for (int u = 0; u < kMU; ++u) if (d0 + u >= m) Gj[u] = zero;   // unused drive slots: their chains stay zero
 
         // ---- ||h G||_1 = largest column sum: lane (g, i) reg kk holds G[i][4kk+g]; rows of 16 lanes share a column ------
         int sq = 0;
@@ -209,7 +225,7 @@ __global__ __launch_bounds__(64, 1) void qc_mfma16_exp_kernel(const QcParams P, 
         // ---- outputs --------------------------------------------------------------------------------------------------
         const v4d Et = lds_transpose16(scr, R, g, j);              // E^T: A operand acting as E, and the tile to store
         const v4d EU = mm16(Et, u0);                                // [E U_t | E U_t]
-        if (Fb) {
+        if (Fb && wv == 0) {
             const v4d dT = lds_transpose16(scr, u1 - EU, g, j);     // delta^T: lane j <-> row
 #pragma unroll
             for (int r = 0; r < 2; ++r) if (4 * r + g < nc && j < nr) qc_st8m<2>(Fb + (4 * r + g) * nr + j, dT[r]);
@@ -218,13 +234,13 @@ __global__ __launch_bounds__(64, 1) void qc_mfma16_exp_kernel(const QcParams P, 
             double* pF = Jb + P.jo_F;
             const v4d mE = -Et;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
+            for (int q = wv * (8 / kW); q < (wv + 1) * (8 / kW); ++q) {
                 if (q < nc) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) if (4 * r + g < nr && j < nr) qc_st8m<2>(pF + q * nr * nr + (4 * r + g) * nr + j, mE[r]);
                 }
             }
-            for (int i = lane; i < P.s; i += 64) Jb[P.jo_B + i] = 1.0;
+            if (wv == kW - 1) for (int i = lane; i < P.s; i += 64) Jb[P.jo_B + i] = 1.0;
             // d/da_j = -(h/2^sq) L_j U_t, transposed:  U_t^T L_j^T  (A = U_t tile, B = L_j^T)
             const double fac = -(h * sc);
             v4d Kt[kMU], XT[kMU], ua[kMU];
@@ -234,20 +250,20 @@ __global__ __launch_bounds__(64, 1) void qc_mfma16_exp_kernel(const QcParams P, 
             mm16_multi<kMU>(ua, Kt, XT);
 #pragma unroll
             for (int u = 0; u < kMU; ++u) {
-                if (u < m) {
+                if (d0 + u < m) {
 #pragma unroll
                     for (int r = 0; r < 2; ++r)
-                        if (4 * r + g < nc && j < nr) qc_st8m<2>(Jb + P.jo_a + (size_t)u * P.s + (4 * r + g) * nr + j, fac * XT[u][r]);
+                        if (4 * r + g < nc && j < nr) qc_st8m<2>(Jb + P.jo_a + (size_t)(d0 + u) * P.s + (4 * r + g) * nr + j, fac * XT[u][r]);
                 }
             }
-            if (ft) {   // d/dh = -G E U_t
+            if (ft && wv == 0) {   // d/dh = -G E U_t
                 const v4d GEU = mm16(Ga, EU);
                 const v4d hT = lds_transpose16(scr, -GEU, g, j);
 #pragma unroll
                 for (int r = 0; r < 2; ++r) if (4 * r + g < nc && j < nr) qc_st8m<2>(Jb + P.jo_h + (4 * r + g) * nr + j, hT[r]);
             }
         }
-        deriv_rows_generic(P, z0, z1, h, Fb, Jb, lane, false);
+        if (wv == kW - 1) deriv_rows_generic(P, z0, z1, h, Fb, Jb, lane, false);
     }
 }
 
@@ -257,17 +273,23 @@ bool qc_mfma_exp_supported(const QcParams& P) {
     return P.integrator == QC_EXPONENTIAL && P.n <= 16 && P.nc <= 8 && P.m <= kXMmax;
 }
 
-template <bool JAC>
-static void launch_exp(const QcParams& P, const double* dZ, double* dF, double* dJ, hipStream_t st) {
-    const int grid = P.n_int;
-    if (P.m <= 2) hipLaunchKernelGGL((qc_mfma16_exp_kernel<JAC, 2>), dim3(grid), dim3(64), 0, st, P, dZ, dF, dJ);
-    else if (P.m <= 4) hipLaunchKernelGGL((qc_mfma16_exp_kernel<JAC, 4>), dim3(grid), dim3(64), 0, st, P, dZ, dF, dJ);
-    else if (P.m <= 6) hipLaunchKernelGGL((qc_mfma16_exp_kernel<JAC, 6>), dim3(grid), dim3(64), 0, st, P, dZ, dF, dJ);
-    else hipLaunchKernelGGL((qc_mfma16_exp_kernel<JAC, 8>), dim3(grid), dim3(64), 0, st, P, dZ, dF, dJ);
-}
-
 hipError_t qc_launch_mfma_exp(const QcParams& P, const double* dZ, double* dF, double* dJ, hipStream_t st) {
-    if (dJ) launch_exp<true>(P, dZ, dF, dJ, st);
-    else launch_exp<false>(P, dZ, dF, dJ, st);
+    const int grid = P.n_int;
+    if (!dJ) {   // residual only: no Frechet chains, one wave
+        hipLaunchKernelGGL((qc_mfma16_exp_kernel<false, 1, 1>), dim3(grid), dim3(64), 0, st, P, dZ, dF, dJ);
+    } else if (P.m <= 1) {
+        hipLaunchKernelGGL((qc_mfma16_exp_kernel<true, 1, 1>), dim3(grid), dim3(64), 0, st, P, dZ, dF, dJ);
+    } else if (P.n_int >= 768) {   // enough intervals to put a wave on (nearly) every SIMD: one wave per interval, no redundant R chain
+        if (P.m <= 2) hipLaunchKernelGGL((qc_mfma16_exp_kernel<true, 2, 1>), dim3(grid), dim3(64), 0, st, P, dZ, dF, dJ);
+        else if (P.m <= 4) hipLaunchKernelGGL((qc_mfma16_exp_kernel<true, 4, 1>), dim3(grid), dim3(64), 0, st, P, dZ, dF, dJ);
+        else if (P.m <= 6) hipLaunchKernelGGL((qc_mfma16_exp_kernel<true, 6, 1>), dim3(grid), dim3(64), 0, st, P, dZ, dF, dJ);
+        else hipLaunchKernelGGL((qc_mfma16_exp_kernel<true, 8, 1>), dim3(grid), dim3(64), 0, st, P, dZ, dF, dJ);
+    } else {     // short trajectories: two waves per interval, ceil(m/2) drives each (config 2, T = 200: 18.3 -> 11.9 us)
+        const int mh = (P.m + 1) / 2;
+        if (mh == 1) hipLaunchKernelGGL((qc_mfma16_exp_kernel<true, 1, 2>), dim3(grid), dim3(128), 0, st, P, dZ, dF, dJ);
+        else if (mh == 2) hipLaunchKernelGGL((qc_mfma16_exp_kernel<true, 2, 2>), dim3(grid), dim3(128), 0, st, P, dZ, dF, dJ);
+        else if (mh == 3) hipLaunchKernelGGL((qc_mfma16_exp_kernel<true, 3, 2>), dim3(grid), dim3(128), 0, st, P, dZ, dF, dJ);
+        else hipLaunchKernelGGL((qc_mfma16_exp_kernel<true, 4, 2>), dim3(grid), dim3(128), 0, st, P, dZ, dF, dJ);
+    }
     return hipGetLastError();
 }
