@@ -38,7 +38,7 @@ __global__ __launch_bounds__(64) void qc_mfma16_pade4_hess_kernel(const QcParams
                                                                   const QcParams* __restrict__ Pb) {
     const QcParams& P = BATCH ? Pb[blockIdx.y] : Pk;      // BATCH: one launch for several handles (qc_mfma_kernels.hip)
     __shared__ double red[kHVals * kHStride];
-    __shared__ double tscr[16 * 17];
+    __shared__ double tscr[(kHM + 1) * 16 * 17];
     const int lane = threadIdx.x;
     const int m = P.m;
     const int g = lane >> 4, j = lane & 15, jj = j & 7;
@@ -152,15 +152,23 @@ __global__ __launch_bounds__(64) void qc_mfma16_pade4_hess_kernel(const QcParams
             }
             mm16_multi<N4>(a4, b4, PN2);                                    // [N''_k | N''_k+1]
         }
-        // transposes for the line-wide stores go through the padded LDS scratch (an identity product costs 4 MFMAs each)
+        // transposes for the line-wide stores go through the padded LDS scratch (an identity product costs 4 MFMAs each), all
+        // kHM + 1 tiles in ONE LDS round trip
         const v4d uh = -(c1 * Y1 + c2h2 * Y2), hu = (-c1) * Y1 + c2h2 * Y2;
-        const v4d ET = lds_transpose16(tscr, sel(left, uh, swap8(hu)), g, j);   // (U_t, h) left, (h, U_t+1) right
-        v4d XT[kHM];                                        // (U_t, a) and (a, U_t+1) tiles, transposed
+        v4d ET, XT[kHM];                                    // (U_t, h) | (h, U_t+1);  (U_t, a) and (a, U_t+1) tiles, transposed
+        {
+            v4d tin[kHM + 1], tout[kHM + 1];
+            tin[0] = sel(left, uh, swap8(hu));
 #pragma unroll
-        for (int p2 = 0; p2 < kHM / 2; ++p2) {
-            const v4d q = hc2 * (PN2[p2] + PN1[p2]), lin = (-hc1) * PN[p2];
-            XT[2 * p2] = lds_transpose16(tscr, lin - q, g, j);
-            XT[2 * p2 + 1] = lds_transpose16(tscr, lin + q, g, j);
+            for (int p2 = 0; p2 < kHM / 2; ++p2) {
+                const v4d q = hc2 * (PN2[p2] + PN1[p2]), lin = (-hc1) * PN[p2];
+                tin[1 + 2 * p2] = lin - q;
+                tin[2 + 2 * p2] = lin + q;
+            }
+            lds_transpose16_multi<kHM + 1>(tscr, tin, tout, g, j);
+            ET = tout[0];
+#pragma unroll
+            for (int u = 0; u < kHM; ++u) XT[u] = tout[1 + u];
         }
         if (ft) {
 #pragma unroll
