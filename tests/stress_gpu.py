@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""One-off randomized stress run (not collected by pytest): python tests/stress_gpu.py [trials] [seed]
+Random systems up to 24 levels, drives 0..8, Pade orders 2/4/6 and the exponential integrator, ket columns, layouts,
+non-Hermitian generators, every kernel that accepts the problem, against the oracle."""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import __graft_entry__ as g
+from oracle_bridge import random_problem
+from test_gpu_parity import RawHandle, kernels_for
+
+qc, o = g.load_package(), g.load_oracle()
+trials = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
+t0 = time.time()
+worst = {"F": 0.0, "dF": 0.0, "H": 0.0}
+count = {}
+for trial in range(trials):
+    N = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 8, 9, 10, 12, 13, 15, 16, 16, 17, 20, 24]))
+    m = int(rng.integers(0, 9))
+    order = int(rng.choice([4, 4, 4, 2, 6]))
+    integ = o.EXPONENTIAL if rng.random() < 0.3 else o.PADE
+    T = int(rng.integers(2, 6))
+    free_time = bool(rng.integers(0, 2))
+    ncol = int(rng.integers(1, min(N, 16) + 1)) if rng.random() < 0.3 else 0
+    prob, Z = random_problem(o, N=N, m=max(m, 1), T=T, order=order, free_time=free_time, integrator=integ, seed=int(rng.integers(1 << 30)),
+                             ncol=ncol, layout=str(rng.choice(["standard", "shuffled"])), hermitian=bool(rng.random() < 0.7))
+    if m == 0:
+        prob.m = 0
+        prob.G_drives = prob.G_drives[:0]
+        prob.derivs = []
+    if free_time and rng.random() < 0.3:
+        Z[prob.off_dt::prob.zdim] *= rng.choice([0.01, 3.0, 10.0])
+    tag = f"trial {trial}: N={N} m={m} order={order} integ={integ} T={T} ft={free_time} ncol={ncol}"
+    Fr, Jr = o.F(prob, Z), o.dF(prob, Z)
+    do_h = integ == o.PADE and N <= 12
+    if do_h:
+        mu = rng.standard_normal(prob.n_rows)
+        Hr = o.mu_d2F(prob, Z, mu)
+    for kernel in kernels_for(qc, prob):
+        h = RawHandle(qc, prob, kernel=kernel)
+        F, J = h.F_jac(Z)
+        eF = np.abs(F - Fr).max() / max(1.0, np.abs(Fr).max())
+        eJ = np.abs(J - Jr).max() / max(1.0, np.abs(Jr).max())
+        assert eF < 1e-9 and eJ < 1e-9, (tag, kernel, eF, eJ)
+        Fo = h.F(Z)
+        dFo = np.abs(Fo - F).max() / max(1.0, np.abs(Fr).max())
+        assert dFo < 1e-12, (tag, kernel, "F-only differs", dFo)
+        worst["F_only_vs_fused"] = max(worst.get("F_only_vs_fused", 0.0), dFo)
+        worst["F"], worst["dF"] = max(worst["F"], eF), max(worst["dF"], eJ)
+        if do_h and (kernel == "lds" or prob.m <= 8):
+            H = h.hess(Z, mu)
+            eH = np.abs(H - Hr).max() / max(1.0, np.abs(Hr).max()) if Hr.size else 0.0
+            assert eH < 1e-9, (tag, kernel, eH)
+            worst["H"] = max(worst["H"], eH)
+        count[kernel] = count.get(kernel, 0) + 1
+        h.close()
+print(f"{trials} trials ok in {time.time() - t0:.0f} s; handles per kernel {count}; worst relative errors {worst}")
