@@ -44,43 +44,7 @@ __device__ __forceinline__ void mm16_multi(const v4d (&a)[NQ], const v4d (&b)[NQ
     }
 }
 
-// Exchange a value with the neighbouring lane (lane ^ 1): DPP quad_perm [1,0,3,2]
-__device__ inline double swap_pair(double x) {
-    int lo = __double2loint(x), hi = __double2hiint(x);
-    lo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-
-// 16-byte streaming store of two consecutive doubles (p must be 16-byte aligned)
-__device__ inline void qc_st16(double* p, double a, double b, int mode) {
-    const v2d v = {a, b};
-    if (mode == 2) __builtin_nontemporal_store(v, reinterpret_cast<v2d*>(p));
-    else if (mode == 1) { qc_st8(p, a, 1); qc_st8(p + 1, b, 1); }
-    else *reinterpret_cast<v2d*>(p) = v;
-}
-
-// A transposed 16 x 16 tile (lane (g, j) reg r = X[j][4r+g], column-major block with `ld` rows per column at p,
-// 16-byte aligned, rows rowbase.. rowbase+15) stored with 16 bytes per lane: lanes pair up (j, j^1) so that each
-// lane owns two consecutive rows of two columns; every instruction still writes whole 128-byte lines.
-struct TileT16 {
-    double a0, b0, a1, b1;   // two 16-byte pieces
-};
-__device__ inline TileT16 pair_tile_T(const v4d& x, int lane) {
-    const bool even = !(lane & 1);
-    const double s0 = even ? x[2] : x[0], s1 = even ? x[3] : x[1];
-    const double r0 = swap_pair(s0), r1 = swap_pair(s1);
-    TileT16 t;
-    if (even) { t.a0 = x[0]; t.b0 = r0; t.a1 = x[1]; t.b1 = r1; }      // rows j, j+1 of columns g, 4+g
-    else      { t.a0 = r0; t.b0 = x[2]; t.a1 = r1; t.b1 = x[3]; }      // rows j-1, j of columns 8+g, 12+g
-    return t;
-}
-__device__ inline void store_tile_T16(double* __restrict__ p, const TileT16& t, int ld, int rowbase, int colbase, int g, int j, int mode) {
-    const bool even = !(j & 1);
-    const int c0 = colbase + (even ? g : 8 + g), row = rowbase + (even ? j : j - 1);
-    qc_st16(p + c0 * ld + row, t.a0, t.b0, mode);
-    qc_st16(p + (c0 + 4) * ld + row, t.a1, t.b1, mode);
-}
+// (A 16-byte-per-lane paired-lane store of transposed tiles was tried for the copy waves and removed: 12.4 vs 11.5 us.)
 
 // D-layout(X) -> D-layout(X^T) of a 16 x 16 tile through a padded (17-double rows) per-wave LDS scratch: four 8-byte writes
 // and reads per lane, conflict-free up to 2-way; replaces a transposing identity product (4 MFMAs = 256 cycles of the pipe).

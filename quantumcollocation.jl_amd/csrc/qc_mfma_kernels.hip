@@ -215,8 +215,7 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
                 }
                 double* pF = Jb + P.jo_F;
                 double* pB = Jb + P.jo_B;
-                // 8 bytes per lane, 512 contiguous bytes per instruction.  (Pairing lanes for 16-byte stores,
-                // qc_mfma_common.h::store_tile_T16, measured 8 % slower.)
+                // 8 bytes per lane, 512 contiguous bytes per instruction.  (Pairing lanes for 16-byte stores measured 8 % slower.)
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     if constexpr (!KET) {
