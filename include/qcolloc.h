@@ -28,6 +28,18 @@
  *   dynamics.mu_d2F(Z.datavec, mu)      (:52)            qc_eval_hess     / qc_eval_hess_dev
  *   dynamics.mu_d2F_structure           (:52)            qc_hess_structure
  *   shapes (Z.dims.states*(Z.T-1), Z.dim*Z.T+Z.global_dim)  (:44,48)   qc_dims
+ *   K unitary integrators of a UnitarySamplingProblem    qc_eval_F_jac_dev_multi / qc_eval_hess_dev_multi
+ *       (unitary_sampling_problem.jl:134-155)                (one handle per integrator, qc_desc.rows_per_interval ...)
+ *   DensityOperatorExponentialIntegrator                 qc_desc{N = levels^2, state_cols = 1, QC_EXPONENTIAL}
+ *       (density_operator_smooth_pulse_problem.jl:104-106)   with the Lindblad generators as G_drift / G_drives
+ *   iso_vec_unitary_fidelity, UnitaryInfidelityObjective,  qc_fidelity_create / qc_fidelity_eval(_dev)
+ *   FinalUnitaryFidelityConstraint                           (unitary_minimum_time_problem.jl:77-84)
+ *   iso_fidelity, QuantumStateObjective,                 qc_fidelity_create_kind(QC_FID_KET | QC_FID_DENSITY)
+ *   DensityOperatorPureStateInfidelityObjective
+ *   QuadraticRegularizer, MinimumTimeObjective           qc_terms_create / qc_terms_eval(_dev)
+ *       (unitary_smooth_pulse_problem.jl:151-153, unitary_minimum_time_problem.jl:67-69)
+ *   unitary_rollout / rollout / open_rollout             qc_rollout / qc_rollout_dev
+ *       (trajectory_initialization.jl:426,493,547)
  *
  * Conventions
  *   - All matrices are column-major (Julia order).  All arrays are caller-owned; nothing is retained
@@ -64,8 +76,9 @@ enum {
 
 enum { QC_PADE = 0, QC_EXPONENTIAL = 1 };
 
-/* Kernel selection (qc_desc.kernel). AUTO picks the MFMA path when n = 2N is 16 or 32 and the
- * Pade order is 4, else the LDS/VALU path.  Forcing a path that cannot serve the descriptor is
+/* Kernel selection (qc_desc.kernel). AUTO picks the MFMA path for systems with N <= 16 levels (sizes other than 8 / 16
+ * levels zero-padded to the tiles) with the Pade order 4 or the exponential integrator, else the generic LDS/VALU path
+ * (its scratch in a global workspace when it exceeds the LDS).  Forcing a path that cannot serve the descriptor is
  * QC_ERR_UNSUPPORTED. */
 enum { QC_KERNEL_AUTO = 0, QC_KERNEL_LDS = 1, QC_KERNEL_MFMA = 2 };
 
