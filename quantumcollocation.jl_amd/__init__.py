@@ -16,7 +16,7 @@ from .named_trajectory import NamedTrajectory
 from .objectives import (DensityOperatorPureStateInfidelityObjective, FinalQuantumStateFidelityConstraint, FinalUnitaryFidelityConstraint,
                          QuantumStateObjective, iso_fidelity, MinimumTimeObjective, QuadraticRegularizer, TimeStepsAllEqualConstraint,
                          TrajectoryObjective, UnitaryInfidelityObjective, iso_vec_unitary_fidelity)
-from .problems import (CONFIGS, config_inputs, density_operator_smooth_pulse_inputs, multi_qubit_system, quantum_state_smooth_pulse_inputs,
+from .problems import (CONFIGS, config_inputs, density_operator_smooth_pulse_inputs, multi_qubit_system, quantum_state_sampling_inputs, quantum_state_smooth_pulse_inputs,
                        unitary_sampling_inputs, unitary_smooth_pulse_inputs)
 from .quantum_systems import OpenQuantumSystem, QuantumSystem
 from .rollouts import open_rollout, rollout, unitary_rollout, unitary_rollout_fidelity
@@ -25,7 +25,7 @@ from .trajectory_initialization import initialize_trajectory, unitary_geodesic
 __all__ = [
     "QuantumDynamics", "QuantumSystem", "NamedTrajectory", "UnitaryPadeIntegrator",
     "UnitaryExponentialIntegrator", "DerivativeIntegrator", "QuantumStatePadeIntegrator",
-    "QuantumStateExponentialIntegrator", "quantum_state_smooth_pulse_inputs", "unitary_sampling_inputs", "ComposedQuantumDynamics", "split_groups", "operator_to_iso_vec", "iso_vec_to_operator",
+    "QuantumStateExponentialIntegrator", "quantum_state_smooth_pulse_inputs", "quantum_state_sampling_inputs", "unitary_sampling_inputs", "ComposedQuantumDynamics", "split_groups", "operator_to_iso_vec", "iso_vec_to_operator",
     "iso_generator", "pade_coefficients", "GATES", "PAULIS", "operator_from_string", "config_inputs",
     "unitary_smooth_pulse_inputs", "multi_qubit_system", "CONFIGS", "initialize_trajectory",
     "unitary_geodesic", "iso_vec_unitary_fidelity", "UnitaryInfidelityObjective", "FinalUnitaryFidelityConstraint", "QuantumStateObjective", "FinalQuantumStateFidelityConstraint", "DensityOperatorPureStateInfidelityObjective", "iso_fidelity",

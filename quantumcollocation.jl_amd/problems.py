@@ -187,3 +187,38 @@ def unitary_sampling_inputs(systems, U_goal: np.ndarray, T: int, dt: float = 0.2
     integrators = [cls(nm, "a", sys_, traj, **kw) for nm, sys_ in zip(names, systems)]
     integrators += [DerivativeIntegrator("a", "da", traj), DerivativeIntegrator("da", "dda", traj)]
     return HotPathInputs(systems[0], traj, integrators)
+
+
+def quantum_state_sampling_inputs(systems, psi_inits, psi_goals, T: int, dt: float = 0.2, *, free_time: bool = True,
+                                  integrator: str = "pade", pade_order: int = 4, seed: int = SEED) -> HotPathInputs:
+    """Inputs of `QuantumStateSamplingProblem` (reference quantum_state_sampling_problem.jl:5-120): K systems share the
+    controls; system j carries its own copies of the kets, components `ψ̃{i}_system_{j}` (:40-43), one ket integrator per
+    (state, system) in system-major order (:98-110), then the two derivative integrators."""
+    from .named_trajectory import NamedTrajectory
+    rng = np.random.default_rng(seed)
+    m, N = systems[0].n_drives, systems[0].levels
+    comps, names = {}, []
+    lam = np.linspace(0.0, 1.0, T)[None, :]
+    for jsys in range(len(systems)):
+        row = []
+        for i, (p0, p1) in enumerate(zip(psi_inits, psi_goals)):
+            p0, p1 = np.asarray(p0, dtype=complex), np.asarray(p1, dtype=complex)
+            iso0 = np.concatenate([p0.real, p0.imag])[:, None]
+            iso1 = np.concatenate([p1.real, p1.imag])[:, None]
+            name = f"ψ̃{i + 1}_system_{jsys + 1}"
+            comps[name] = iso0 * (1 - lam) + iso1 * lam + 1e-2 * rng.standard_normal((2 * N, T))
+            row.append(name)
+        names.append(row)
+    a = np.zeros((m, T))
+    a[:, 1:T - 1] = rng.uniform(-1, 1, size=(m, T - 2))
+    comps["a"] = a
+    comps["da"] = 0.1 * rng.standard_normal((m, T))
+    comps["dda"] = 0.1 * rng.standard_normal((m, T))
+    if free_time:
+        comps["Δt"] = np.full((1, T), dt)
+    traj = NamedTrajectory(comps, controls=("dda", "Δt") if free_time else ("dda",), timestep="Δt" if free_time else dt)
+    cls = QuantumStatePadeIntegrator if integrator == "pade" else QuantumStateExponentialIntegrator
+    kw = {"order": pade_order} if integrator == "pade" else {}
+    integrators = [cls(nm, "a", sys_, traj, **kw) for row, sys_ in zip(names, systems) for nm in row]
+    integrators += [DerivativeIntegrator("a", "da", traj), DerivativeIntegrator("da", "dda", traj)]
+    return HotPathInputs(systems[0], traj, integrators)
