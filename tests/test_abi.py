@@ -298,3 +298,70 @@ def test_c_example_matches_the_python_mirror(qc, tmp_path):
     jr, jc = dyn.dF_structure
     assert (int(m.group(4)), int(m.group(5))) == (int(jr[0]) + 1, int(jc[0]) + 1)
     dyn.close()
+
+
+def test_descriptor_fuzz_never_crashes(qc):
+    """3000 descriptors with random (often nonsensical) fields through the host-only entry points: every call returns QC_OK or
+    QC_ERR_INVALID with a message; accepted descriptors produce structures of exactly the announced size and range.
+    (tests/run_asan_host.sh runs this file under AddressSanitizer.)"""
+    L = qc._lib
+    rng = np.random.default_rng(31337)
+    ok = 0
+    for trial in range(3000):
+        # a valid smooth-pulse layout [U, a, da, dda, dt] ...
+        d = L.qc_desc()
+        N = int(rng.choice([1, 2, 3, 4, 8]))
+        m = int(rng.choice([0, 1, 2, 6]))
+        T = int(rng.choice([2, 3, 7]))
+        s = 2 * N * N
+        zdim = s + 3 * m + 1
+        d.N, d.m, d.T, d.zdim, d.global_dim = N, m, T, zdim, int(rng.choice([0, 3]))
+        d.off_U, d.off_a, d.off_dt, d.dt_fixed = 0, s, s + 3 * m, 0.0
+        d.integrator, d.pade_order = int(rng.choice([0, 0, 1])), int(rng.choice([2, 4, 6]))
+        d.n_deriv = 2 if m else 0
+        if m:
+            d.deriv_x_off[0], d.deriv_dx_off[0], d.deriv_dim[0] = s, s + m, m
+            d.deriv_x_off[1], d.deriv_dx_off[1], d.deriv_dim[1] = s + m, s + 2 * m, m
+        # ... with zero to three fields corrupted
+        for _ in range(int(rng.integers(0, 4))):
+            f = str(rng.choice(["N", "m", "T", "zdim", "global_dim", "off_U", "off_a", "off_dt", "integrator", "pade_order", "n_deriv", "deriv",
+                                "state_cols", "t_range", "placement", "dt_fixed"]))
+            if f == "deriv":
+                i = int(rng.integers(0, 8))
+                d.deriv_x_off[i] = int(rng.integers(-2, zdim + 3))
+                d.deriv_dx_off[i] = int(rng.integers(-2, zdim + 3))
+                d.deriv_dim[i] = int(rng.choice([0, 1, max(m, 1), zdim, -1]))
+            elif f == "t_range":
+                d.t_begin, d.t_end = int(rng.choice([0, 1, -1, T])), int(rng.choice([0, T - 1, T + 3, -2]))
+            elif f == "placement":
+                d.rows_per_interval, d.row_offset = int(rng.integers(-5, 60)), int(rng.integers(-5, 60))
+                d.jac_per_interval, d.jac_offset = int(rng.integers(-5, 600)), int(rng.integers(-5, 600))
+            elif f == "dt_fixed":
+                d.dt_fixed = float(rng.choice([0.2, -1.0, np.nan]))
+                d.off_dt = -1
+            else:
+                setattr(d, f, int(rng.choice([0, 1, 2, 3, 5, 8, 9, 17, 33, 70, -1, -4, zdim, zdim - 1, s])))
+        dims = L.qc_dims_t()
+        rc = L.lib.qc_desc_dims(C.byref(d), C.byref(dims))
+        assert rc in (L.QC_OK, L.QC_ERR_INVALID), rc
+        if rc != L.QC_OK:
+            assert L.lib.qc_last_error(None)
+            continue
+        ok += 1
+        assert dims.n_rows >= 0 and dims.jac_nnz >= 0 and dims.hess_nnz >= 0
+        if dims.jac_nnz > 2_000_000:
+            continue
+        jr = np.full(dims.jac_nnz + 8, -77, dtype=np.int64)
+        jc = np.full(dims.jac_nnz + 8, -77, dtype=np.int64)
+        assert L.lib.qc_desc_jac_structure(C.byref(d), L.iptr(jr), L.iptr(jc), 0) == L.QC_OK
+        assert np.all(jr[dims.jac_nnz:] == -77) and np.all(jc[dims.jac_nnz:] == -77)          # nothing written past the end
+        if dims.jac_nnz:
+            assert jr[:dims.jac_nnz].min() >= 0 and jr[:dims.jac_nnz].max() < dims.n_rows
+            assert jc[:dims.jac_nnz].min() >= 0 and jc[:dims.jac_nnz].max() < dims.n_cols
+        hr = np.full(dims.hess_nnz + 8, -77, dtype=np.int64)
+        hc = np.full(dims.hess_nnz + 8, -77, dtype=np.int64)
+        assert L.lib.qc_desc_hess_structure(C.byref(d), L.iptr(hr), L.iptr(hc), 0) == L.QC_OK
+        assert np.all(hr[dims.hess_nnz:] == -77)
+        if dims.hess_nnz:
+            assert hr[:dims.hess_nnz].min() >= 0 and hc[:dims.hess_nnz].max() < dims.n_cols and np.all(hr[:dims.hess_nnz] <= hc[:dims.hess_nnz])
+    assert ok > 20      # the generator does produce valid descriptors too
