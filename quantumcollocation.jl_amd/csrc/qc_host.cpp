@@ -481,7 +481,9 @@ static int prepare_batch(qc_handle* const* hs, int32_t count, bool hessian) {
         const qc_handle* h = hs[i];
         if (h->kernel != QC_KERNEL_MFMA || h->device != h0->device || !qc_mfma16_batchable(h->prm)) return 0;
         if (h->prm.m > 8 && hessian) return 0;
-        if (h->prm.n_int != h0->prm.n_int || h->prm.t_begin != h0->prm.t_begin || h->prm.zdim != h0->prm.zdim || h->prm.m != h0->prm.m) return 0;
+        if (h->prm.n_int != h0->prm.n_int || h->prm.t_begin != h0->prm.t_begin || h->prm.zdim != h0->prm.zdim || h->prm.m != h0->prm.m ||
+            h->prm.n != h0->prm.n || h->prm.nc != h0->prm.nc)
+            return 0;
     }
     bool same = h0->dBatch != nullptr && (int)h0->batch_members.size() == count;
     for (int i = 0; same && i < count; ++i) same = h0->batch_members[i] == hs[i]->serial;

@@ -250,7 +250,13 @@ bool qc_mfma_hess_supported(const QcParams& P) {
 hipError_t qc_launch_mfma16_hess_batch(const QcParams& P0, const QcParams* dPb, int count, const double* dZ, const double* dMu, double* dH,
                                        hipStream_t st) {
     const int grid = P0.n_int < 4096 ? P0.n_int : 4096;
-#define QC_B(HM_) hipLaunchKernelGGL((qc_mfma16_pade4_hess_kernel<HM_, false, true>), dim3(grid, count), dim3(64), 0, st, P0, dZ, dMu, dH, dPb)
+#define QC_B(HM_)                                                                                                                      \
+    do {                                                                                                                            \
+        if (P0.nc != 8 || P0.n != 16)                                                                                               \
+            hipLaunchKernelGGL((qc_mfma16_pade4_hess_kernel<HM_, true, true>), dim3(grid, count), dim3(64), 0, st, P0, dZ, dMu, dH, dPb); \
+        else                                                                                                                        \
+            hipLaunchKernelGGL((qc_mfma16_pade4_hess_kernel<HM_, false, true>), dim3(grid, count), dim3(64), 0, st, P0, dZ, dMu, dH, dPb); \
+    } while (0)
     if (P0.m <= 2) QC_B(2); else if (P0.m <= 4) QC_B(4); else if (P0.m <= 6) QC_B(6); else QC_B(8);
 #undef QC_B
     return hipGetLastError();

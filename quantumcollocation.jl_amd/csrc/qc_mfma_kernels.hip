@@ -476,14 +476,17 @@ static void launch16(const QcParams& P, const double* dZ, double* dF, double* dJ
 
 // One launch for `count` handles (gridDim.y = count).  The caller has checked qc_mfma16_batchable for every handle.
 bool qc_mfma16_batchable(const QcParams& P) {
-    return P.integrator == QC_PADE && P.p == 2 && P.n == 16 && P.nc == 8 && P.m <= 32 && P.store_mode == 2 && P.stamps == nullptr &&
+    return P.integrator == QC_PADE && P.p == 2 && P.n <= 16 && P.nc <= 8 && P.m <= 32 && P.store_mode == 2 && P.stamps == nullptr &&
            P.dbg_skip == 0 && P.Gx != nullptr;
 }
 
 template <bool JAC, int MU>
 static void launch16_batch(const QcParams& P0, const QcParams* dPb, int count, const double* dZ, double* dF, double* dJ, hipStream_t st, int grid,
                            int threads) {
-    hipLaunchKernelGGL((qc_mfma16_pade4_kernel<JAC, 2, false, MU, false, true>), dim3(grid, count), dim3(threads), 0, st, P0, dZ, dF, dJ, dPb);
+    if (P0.nc != 8 || P0.n != 16)   // kets / padded systems: the masked instantiation
+        hipLaunchKernelGGL((qc_mfma16_pade4_kernel<JAC, 2, false, MU, true, true>), dim3(grid, count), dim3(threads), 0, st, P0, dZ, dF, dJ, dPb);
+    else
+        hipLaunchKernelGGL((qc_mfma16_pade4_kernel<JAC, 2, false, MU, false, true>), dim3(grid, count), dim3(threads), 0, st, P0, dZ, dF, dJ, dPb);
 }
 
 hipError_t qc_launch_mfma16_F_jac_batch(const QcParams& P0, const QcParams* dPb, int count, const double* dZ, double* dF, double* dJ,
