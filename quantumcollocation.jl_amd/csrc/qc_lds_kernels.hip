@@ -14,7 +14,8 @@
 
 namespace {
 
-constexpr int kThreads = 256;
+constexpr int kThreadsLds = 256;     // workgroup size with the scratch in LDS
+constexpr int kThreadsGws = 1024;    // ... and with the scratch in the global workspace (large systems, few intervals: use the whole CU)
 
 struct LdsJacLayout {
     int z0, z1, Gp, PD, PS, Q, R, total;  // offsets in doubles
@@ -39,9 +40,10 @@ __host__ __device__ inline LdsJacLayout jac_layout(const QcParams& P) {
 }
 
 // C (n x ncol, col-major) = A (n x n, col-major) * X (n x ncol, col-major); all in LDS unless noted.
+template <int NT>
 __device__ inline void matmul_lds(double* __restrict__ C, const double* __restrict__ A, const double* __restrict__ X,
                                   int n, int ncol, int tid) {
-    for (int idx = tid; idx < n * ncol; idx += kThreads) {
+    for (int idx = tid; idx < n * ncol; idx += NT) {
         const int r = idx % n, c = idx / n;
         double acc = 0.0;
         for (int k = 0; k < n; ++k) acc = fma(A[r + n * k], X[k + n * c], acc);
@@ -58,8 +60,9 @@ __device__ inline double wave_sum(double v) {
 // GWS: the per-interval scratch lives in a global-memory workspace instead of LDS (systems too large for 160 KB of LDS per
 // interval: N >= ~18 levels).  Same code, one workgroup per interval; __syncthreads orders the workgroup's global accesses.
 template <bool JAC, bool GWS>
-__global__ __launch_bounds__(kThreads) void qc_lds_pade_kernel(const QcParams P, const double* __restrict__ Z,
+__global__ __launch_bounds__(GWS ? kThreadsGws : kThreadsLds) void qc_lds_pade_kernel(const QcParams P, const double* __restrict__ Z,
                                                                double* __restrict__ F, double* __restrict__ J) {
+    constexpr int kThreads = GWS ? kThreadsGws : kThreadsLds;
     extern __shared__ __attribute__((aligned(16))) double lds_sm[];
     double* sm;
     if constexpr (GWS) sm = P.ws + (size_t)blockIdx.x * P.ws_stride; else sm = lds_sm;
@@ -100,9 +103,9 @@ __global__ __launch_bounds__(kThreads) void qc_lds_pade_kernel(const QcParams P,
     __syncthreads();
     // powers G^{k+1}, and the two Krylov streams G^k D, G^k (-S)
     for (int k = 1; k <= p; ++k) {
-        if (k < p) matmul_lds(Gp + k * n2, Gp, Gp + (k - 1) * n2, n, n, tid);
-        matmul_lds(PD + k * nN, Gp, PD + (k - 1) * nN, n, N, tid);
-        matmul_lds(PS + k * nN, Gp, PS + (k - 1) * nN, n, N, tid);
+        if (k < p) matmul_lds<kThreads>(Gp + k * n2, Gp, Gp + (k - 1) * n2, n, n, tid);
+        matmul_lds<kThreads>(PD + k * nN, Gp, PD + (k - 1) * nN, n, N, tid);
+        matmul_lds<kThreads>(PS + k * nN, Gp, PS + (k - 1) * nN, n, N, tid);
         __syncthreads();
     }
 
@@ -245,9 +248,10 @@ __host__ __device__ inline LdsHessLayout hess_layout(const QcParams& P, int cj) 
 }
 
 // C (n x ncol) = A^T (A is n x n col-major) * X
+template <int NT>
 __device__ inline void matmul_T_lds(double* __restrict__ C, const double* __restrict__ A, const double* __restrict__ X,
                                     int n, int ncol, int tid) {
-    for (int idx = tid; idx < n * ncol; idx += kThreads) {
+    for (int idx = tid; idx < n * ncol; idx += NT) {
         const int r = idx % n, c = idx / n;
         double acc = 0.0;
         for (int k = 0; k < n; ++k) acc = fma(A[k + n * r], X[k + n * c], acc);
@@ -257,9 +261,10 @@ __device__ inline void matmul_T_lds(double* __restrict__ C, const double* __rest
 
 
 template <bool GWS>
-__global__ __launch_bounds__(kThreads) void qc_lds_pade_hess_kernel(const QcParams P, const double* __restrict__ Z,
+__global__ __launch_bounds__(GWS ? kThreadsGws : kThreadsLds) void qc_lds_pade_hess_kernel(const QcParams P, const double* __restrict__ Z,
                                                                     const double* __restrict__ Mu, double* __restrict__ H,
                                                                     int cj) {
+    constexpr int kThreads = GWS ? kThreadsGws : kThreadsLds;
     extern __shared__ __attribute__((aligned(16))) double lds_sm[];
     double* sm;
     if constexpr (GWS) sm = P.ws + (size_t)blockIdx.x * P.ws_stride; else sm = lds_sm;
@@ -306,10 +311,10 @@ __global__ __launch_bounds__(kThreads) void qc_lds_pade_hess_kernel(const QcPara
     }
     __syncthreads();
     for (int k = 1; k <= p; ++k) {
-        if (k < p) matmul_lds(Gp + k * n2, Gp, Gp + (k - 1) * n2, n, n, tid);
-        matmul_lds(PD + k * nN, Gp, PD + (k - 1) * nN, n, N, tid);
-        matmul_lds(PS + k * nN, Gp, PS + (k - 1) * nN, n, N, tid);
-        matmul_T_lds(Mq + k * nN, Gp, Mq + (k - 1) * nN, n, N, tid);
+        if (k < p) matmul_lds<kThreads>(Gp + k * n2, Gp, Gp + (k - 1) * n2, n, n, tid);
+        matmul_lds<kThreads>(PD + k * nN, Gp, PD + (k - 1) * nN, n, N, tid);
+        matmul_lds<kThreads>(PS + k * nN, Gp, PS + (k - 1) * nN, n, N, tid);
+        matmul_T_lds<kThreads>(Mq + k * nN, Gp, Mq + (k - 1) * nN, n, N, tid);
         __syncthreads();
     }
 
@@ -519,14 +524,15 @@ __host__ __device__ inline LdsExpLayout exp_layout(const QcParams& P, int cj) {
     L.D1 = o; o += cj * n2;
     L.Ls = o; o += cj * n2;
     L.EU = o; o += nN;
-    L.red = o; o += 8;
+    L.red = o; o += 16;          // one slot per wave (up to 16 waves in the global-workspace mode)
     L.total = o;
     return L;
 }
 
 template <bool JAC, bool GWS>
-__global__ __launch_bounds__(kThreads) void qc_lds_exp_kernel(const QcParams P, const double* __restrict__ Z,
+__global__ __launch_bounds__(GWS ? kThreadsGws : kThreadsLds) void qc_lds_exp_kernel(const QcParams P, const double* __restrict__ Z,
                                                               double* __restrict__ F, double* __restrict__ J, int cj) {
+    constexpr int kThreads = GWS ? kThreadsGws : kThreadsLds;
     extern __shared__ __attribute__((aligned(16))) double lds_sm[];
     double* sm;
     if constexpr (GWS) sm = P.ws + (size_t)blockIdx.x * P.ws_stride; else sm = lds_sm;
@@ -646,7 +652,7 @@ __global__ __launch_bounds__(kThreads) void qc_lds_exp_kernel(const QcParams P, 
                 for (int k = 0; k < n; ++k) acc = fma(Ecur[r + n * k], Lj[k + n * c], fma(Lj[r + n * k], Ecur[k + n * c], acc));
                 Ln[idx] = acc;
             }
-            matmul_lds(Etmp, Ecur, Ecur, n, n, tid);
+            matmul_lds<kThreads>(Etmp, Ecur, Ecur, n, n, tid);
             __syncthreads();
             for (int idx = tid; idx < jc * n2; idx += kThreads) Ls[idx] = Ln[idx];
             for (int idx = tid; idx < n2; idx += kThreads) Ecur[idx] = Etmp[idx];
@@ -726,7 +732,7 @@ static hipError_t raise_lds_limit(K kernel, size_t lds) {
 }
 
 hipError_t qc_launch_lds_F_jac(const QcParams& P, const double* dZ, double* dF, double* dJ, size_t lds, hipStream_t st) {
-    const dim3 grid(P.n_int), block(kThreads);
+    const dim3 grid(P.n_int), block(P.use_ws ? kThreadsGws : kThreadsLds);
     if (P.use_ws) {   // scratch in the global workspace, no dynamic LDS
         if (P.integrator == QC_EXPONENTIAL) {
             const int cj = exp_chunk(P);
@@ -775,11 +781,11 @@ hipError_t qc_launch_lds_hess(const QcParams& P, const double* dZ, const double*
     if (P.integrator != QC_PADE) return hipErrorNotSupported;
     const int cj = hess_chunk(P);
     if (P.use_ws) {
-        hipLaunchKernelGGL(qc_lds_pade_hess_kernel<true>, dim3(P.n_int), dim3(kThreads), 0, st, P, dZ, dMu, dH, cj);
+        hipLaunchKernelGGL(qc_lds_pade_hess_kernel<true>, dim3(P.n_int), dim3(kThreadsGws), 0, st, P, dZ, dMu, dH, cj);
         return hipGetLastError();
     }
     hipError_t e = raise_lds_limit(&qc_lds_pade_hess_kernel<false>, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(qc_lds_pade_hess_kernel<false>, dim3(P.n_int), dim3(kThreads), lds, st, P, dZ, dMu, dH, cj);
+    hipLaunchKernelGGL(qc_lds_pade_hess_kernel<false>, dim3(P.n_int), dim3(kThreadsLds), lds, st, P, dZ, dMu, dH, cj);
     return hipGetLastError();
 }
