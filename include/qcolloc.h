@@ -189,7 +189,7 @@ int qc_eval_hess(qc_handle* h, const double* Z, const double* mu, double* hvals)
 /* ---- evaluation, device-resident (asynchronous on `stream`, a hipStream_t) --------------------- */
 /* dZ: device pointer to the full Z vector (8-byte aligned).  dF may be NULL (skip residual store);
  * dvals may be NULL (residual only).  dF/dvals/dhvals point at THIS HANDLE'S slice
- * (interval t_begin first) and must be 16-byte aligned. */
+ * (interval t_begin first) and must be 8-byte aligned (the kernels issue 8-byte stores only). */
 int qc_eval_F_jac_dev(qc_handle* h, const double* dZ, double* dF, double* dvals, void* stream);
 int qc_eval_hess_dev(qc_handle* h, const double* dZ, const double* dmu, double* dhvals, void* stream);
 

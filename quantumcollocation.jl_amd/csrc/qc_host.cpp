@@ -460,8 +460,8 @@ extern "C" int qc_eval_F_jac_dev(qc_handle* h, const double* dZ, double* dF, dou
     if (!dZ || (!dF && !dvals)) return fail(&h->err, QC_ERR_INVALID, "qc_eval_F_jac_dev: NULL buffer");
     int rc;
     if ((rc = check_align(h, dZ, 8, "dZ"))) return rc;
-    if ((rc = check_align(h, dF, 16, "dF"))) return rc;
-    if ((rc = check_align(h, dvals, 16, "dvals"))) return rc;
+    if ((rc = check_align(h, dF, 8, "dF"))) return rc;
+    if ((rc = check_align(h, dvals, 8, "dvals"))) return rc;
     if (h->prm.n_int == 0) return QC_OK;
     hipError_t e;
     if (h->kernel == QC_KERNEL_MFMA) e = qc_launch_mfma_F_jac(h->prm, dZ, dF, dvals, (hipStream_t)stream);
@@ -506,8 +506,8 @@ extern "C" int qc_eval_F_jac_dev_multi(qc_handle* const* hs, int32_t count, cons
     if (!dZ || (!dF && !dvals)) return fail(&h0->err, QC_ERR_INVALID, "qc_eval_F_jac_dev_multi: NULL buffer");
     int rc;
     if ((rc = check_align(h0, dZ, 8, "dZ"))) return rc;
-    if ((rc = check_align(h0, dF, 16, "dF"))) return rc;
-    if ((rc = check_align(h0, dvals, 16, "dvals"))) return rc;
+    if ((rc = check_align(h0, dF, 8, "dF"))) return rc;
+    if ((rc = check_align(h0, dvals, 8, "dvals"))) return rc;
     const int ok = prepare_batch(hs, count, false);
     if (ok < 0) return ok;
     if (ok == 0 || h0->prm.n_int == 0) {   // shapes differ or not the batchable kernel: one launch per handle
@@ -527,7 +527,7 @@ extern "C" int qc_eval_hess_dev_multi(qc_handle* const* hs, int32_t count, const
     int rc;
     if ((rc = check_align(h0, dZ, 8, "dZ"))) return rc;
     if ((rc = check_align(h0, dmu, 8, "dmu"))) return rc;
-    if ((rc = check_align(h0, dhvals, 16, "dhvals"))) return rc;
+    if ((rc = check_align(h0, dhvals, 8, "dhvals"))) return rc;
     const int ok = prepare_batch(hs, count, true);
     if (ok < 0) return ok;
     bool hess_ok = ok == 1 && h0->prm.n_int > 0;
@@ -550,7 +550,7 @@ extern "C" int qc_eval_hess_dev(qc_handle* h, const double* dZ, const double* dm
     int rc;
     if ((rc = check_align(h, dZ, 8, "dZ"))) return rc;
     if ((rc = check_align(h, dmu, 8, "dmu"))) return rc;
-    if ((rc = check_align(h, dhvals, 16, "dhvals"))) return rc;
+    if ((rc = check_align(h, dhvals, 8, "dhvals"))) return rc;
     if (h->prm.n_int == 0) return QC_OK;
     hipError_t e;
     if (h->kernel == QC_KERNEL_MFMA && qc_mfma_hess_supported(h->prm))
