@@ -353,7 +353,17 @@ extern "C" int qc_create(const qc_desc* d, qc_handle** out) {
     // MI355X (profiles/README.md: plain 14.4, sc1 12.8, nt 11.9 us per config-3 evaluation).
     h->prm.store_mode = 2;
     if (const char* e = getenv("QC_STORE_MODE")) h->prm.store_mode = atoi(e);   // diagnostic override
-    if (const char* e = getenv("QC_DEBUG_SKIP")) h->prm.dbg_skip = atoi(e);     // diagnostic ablation (wrong results)
+    // Diagnostic ablation for the profiling scripts: it produces WRONG results, so it needs the explicit opt-in
+    // QC_DIAGNOSTICS=1 next to it and says so on stderr every time a handle is created with it.
+    if (const char* e = getenv("QC_DEBUG_SKIP")) {
+        const char* opt = getenv("QC_DIAGNOSTICS");
+        if (atoi(e) != 0 && opt && atoi(opt) == 1) {
+            h->prm.dbg_skip = atoi(e);
+            fprintf(stderr, "qcolloc: QC_DEBUG_SKIP=%d is active: outputs of this handle are NOT valid results\n", h->prm.dbg_skip);
+        } else if (atoi(e) != 0) {
+            fprintf(stderr, "qcolloc: QC_DEBUG_SKIP ignored (set QC_DIAGNOSTICS=1 to enable the ablation)\n");
+        }
+    }
     if (kernel == QC_KERNEL_MFMA) {
         std::vector<double> Gx(qc_mfma_gx_doubles(P));
         qc_mfma_pack_G(P, G.data(), Gx.data());
