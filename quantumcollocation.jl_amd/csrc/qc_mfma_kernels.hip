@@ -426,16 +426,20 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
 }  // namespace
 
 bool qc_mfma_supported(const QcParams& P) {
-    if (qc_mfma_exp_supported(P) || qc_mfma32_exp_supported(P)) return true;
+    if (qc_mfma_exp_supported(P) || qc_mfma32_exp_supported(P) || qc_mfma64_supported(P)) return true;
     return P.integrator == QC_PADE && P.p == 2 && ((P.n <= 16 && P.nc <= 8) || (P.n <= 32 && P.nc <= 16)) && P.m <= 32;
 }
 
-size_t qc_mfma_gx_doubles(const QcParams& P) { return P.n > 16 ? qc_mfma32_gx_doubles(P) : (size_t)2 * (P.m + 1) * 256; }
+size_t qc_mfma_gx_doubles(const QcParams& P) {
+    if (P.n > 32) return qc_mfma64_gx_doubles(P);
+    return P.n > 16 ? qc_mfma32_gx_doubles(P) : (size_t)2 * (P.m + 1) * 256;
+}
 
 // Packs the (m+1) generators (column-major n x n, index 0 = drift) into the lane-ordered A-layout
 // images [layout][matrix][pair][lane][2]:  layout 0 (A operand of X): lane (g, i) reg kk = X[i][4kk+g];
 // layout 1 (B layout of X = A operand of X^T, used by the Hessian kernel): lane (g, i) reg kk = X[4kk+g][i].
 void qc_mfma_pack_G(const QcParams& P, const double* G, double* Gx) {
+    if (P.n > 32) { qc_mfma64_pack_G(P, G, Gx); return; }
     if (P.n > 16) { qc_mfma32_pack_G(P, G, Gx); return; }
     const int n = P.n, M = P.m + 1;      // n < 16: the images are zero-padded to the 16 x 16 tile
     for (int mat = 0; mat < M; ++mat) {
@@ -503,6 +507,7 @@ hipError_t qc_launch_mfma16_F_jac_batch(const QcParams& P0, const QcParams* dPb,
 
 hipError_t qc_launch_mfma_F_jac(const QcParams& P, const double* dZ, double* dF, double* dJ, hipStream_t st) {
     if (P.integrator == QC_EXPONENTIAL) return P.n > 16 ? qc_launch_mfma32_exp(P, dZ, dF, dJ, st) : qc_launch_mfma_exp(P, dZ, dF, dJ, st);
+    if (P.n > 32) return qc_launch_mfma64_F_jac(P, dZ, dF, dJ, st);
     if (P.n > 16) return qc_launch_mfma32_F_jac(P, dZ, dF, dJ, st);
     const int n_wg = dJ ? (P.n_int + kIntervalsPerWG - 1) / kIntervalsPerWG : P.n_int;
     const int grid = n_wg < kMaxGrid ? n_wg : kMaxGrid;
