@@ -413,7 +413,7 @@ extern "C" void qc_destroy(qc_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    double* bufs[] = {h->dG, h->dGx, h->dZ, h->dF, h->dJ, h->dMu, h->dH, (double*)h->dStamps, h->dRE, h->dRQ, h->dRS, h->dRinit, h->dRout, h->dWs};
+    double* bufs[] = {h->dG, h->dGx, h->dZ, h->dF, h->dJ, h->dMu, h->dH, (double*)h->dStamps, h->dRE, h->dRQ, h->dRS, h->dRinit, h->dRout, h->dWs, h->dHs};
     if (h->hJc) (void)hipHostFree(h->hJc);
     if (h->dBatch) (void)hipFree(h->dBatch);
     for (hipEvent_t ev : h->chunk_events) if (ev) (void)hipEventDestroy(ev);
@@ -563,6 +563,11 @@ extern "C" int qc_eval_hess_dev(qc_handle* h, const double* dZ, const double* dm
     if ((rc = check_align(h, dhvals, 8, "dhvals"))) return rc;
     if (h->prm.n_int == 0) return QC_OK;
     hipError_t e;
+    if (h->kernel == QC_KERNEL_MFMA && qc_mfma64_hess_supported(h->prm) && !h->dHs) {   // 128 MiB of scratch, first Hessian call only
+        QC_HIP(h, hipSetDevice(h->device));
+        QC_HIP(h, hipMalloc((void**)&h->dHs, qc_mfma64_hess_scratch_doubles(h->prm) * sizeof(double)));
+        h->prm.hs = h->dHs;
+    }
     if (h->kernel == QC_KERNEL_MFMA && qc_mfma_hess_supported(h->prm))
         e = qc_launch_mfma_hess(h->prm, dZ, dmu, dhvals, (hipStream_t)stream);
     else

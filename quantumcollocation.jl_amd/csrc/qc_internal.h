@@ -42,6 +42,7 @@ struct QcParams {
     int use_ws;              // LDS kernels: per-interval scratch in the global workspace `ws` (system too large for LDS)
     double* ws;              // device: n_int * ws_stride doubles, or nullptr
     long long ws_stride;
+    double* hs;              // device: scratch of the 4 x 4-tile Hessian kernel (qc_mfma64_hess.hip), allocated on first use
     unsigned long long* stamps;  // diagnostic: 16 s_memrealtime slots per interval, or nullptr (normal)
 };
 
@@ -68,6 +69,7 @@ struct qc_handle {
     std::vector<hipEvent_t> chunk_events;
     int host_compact = 1;      // QC_HOST_COMPACT=0 disables the compact D2H path of the host-buffer entry points
     double* dWs = nullptr;     // global workspace of the LDS kernels for systems beyond the LDS budget
+    double* dHs = nullptr;     // scratch of the 4 x 4-tile Hessian kernel (first Hessian call)
     double *dRE = nullptr, *dRQ = nullptr, *dRS = nullptr, *dRinit = nullptr, *dRout = nullptr;   // rollout scratch / staging
     hipStream_t stream = nullptr;
     std::string err;
@@ -96,6 +98,9 @@ bool qc_mfma64_supported(const QcParams& P);
 size_t qc_mfma64_gx_doubles(const QcParams& P);
 void qc_mfma64_pack_G(const QcParams& P, const double* G_host, double* Gx_host);
 hipError_t qc_launch_mfma64_F_jac(const QcParams& P, const double* dZ, double* dF, double* dJ, hipStream_t st);
+bool qc_mfma64_hess_supported(const QcParams& P);
+size_t qc_mfma64_hess_scratch_doubles(const QcParams& P);
+hipError_t qc_launch_mfma64_hess(const QcParams& P, const double* dZ, const double* dMu, double* dH, hipStream_t st);
 bool qc_mfma16_batchable(const QcParams& P);
 hipError_t qc_launch_mfma16_F_jac_batch(const QcParams& P0, const QcParams* dPb, int count, const double* dZ, double* dF, double* dJ,
                                         hipStream_t st);

@@ -268,15 +268,18 @@ __global__ __launch_bounds__(kThreads64, 1) void qc_mfma64_pade4_kernel(const Qc
 
 }  // namespace
 
-size_t qc_mfma64_gx_doubles(const QcParams& P) { return (size_t)(P.m + 1) * 4096; }
+size_t qc_mfma64_gx_doubles(const QcParams& P) { return (size_t)2 * (P.m + 1) * 4096; }
 
-// Zero-padded 64 x 64 column-major copies of the (m+1) generators.
+// Zero-padded 64 x 64 column-major copies of the (m+1) generators, followed by those of their transposes (Hessian kernel).
 void qc_mfma64_pack_G(const QcParams& P, const double* G, double* Gx) {
     const int n = P.n, M = P.m + 1;
     for (int mat = 0; mat < M; ++mat)
         for (int c = 0; c < 64; ++c)
-            for (int r = 0; r < 64; ++r)
-                Gx[(size_t)mat * 4096 + c * 64 + r] = (r < n && c < n) ? G[(size_t)mat * n * n + (size_t)c * n + r] : 0.0;
+            for (int r = 0; r < 64; ++r) {
+                const bool in = r < n && c < n;
+                Gx[(size_t)mat * 4096 + c * 64 + r] = in ? G[(size_t)mat * n * n + (size_t)c * n + r] : 0.0;
+                Gx[(size_t)(M + mat) * 4096 + c * 64 + r] = in ? G[(size_t)mat * n * n + (size_t)r * n + c] : 0.0;
+            }
 }
 
 bool qc_mfma64_supported(const QcParams& P) {
