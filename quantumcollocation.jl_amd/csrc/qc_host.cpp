@@ -34,7 +34,7 @@ static int fail(std::string* err, int code, const std::string& msg) {
         }                                                                                        \
     } while (0)
 
-extern "C" const char* qc_version(void) { return "qcolloc-hip 0.1 (gfx950, fp64; kernels: lds, mfma16, mfma32, mfma16-exp, mfma32-exp)"; }
+extern "C" const char* qc_version(void) { return "qcolloc-hip 0.1 (gfx950, fp64; kernels: lds, mfma16, mfma32, mfma64, mfma16-exp, mfma32-exp)"; }
 
 extern "C" const char* qc_last_error(const qc_handle* h) { return h ? h->err.c_str() : g_err.c_str(); }
 
