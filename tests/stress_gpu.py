@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One-off randomized stress run (not collected by pytest): python tests/stress_gpu.py [trials] [seed]
-Random systems up to 24 levels, drives 0..8, Pade orders 2/4/6 and the exponential integrator, ket columns, layouts,
+Random systems up to 32 levels, drives 0..8 (0..12 above 16 levels), Pade orders 2/4/6 and the exponential integrator, ket columns, layouts,
 non-Hermitian generators, every kernel that accepts the problem, against the oracle."""
 import os
 import sys
@@ -21,8 +21,8 @@ t0 = time.time()
 worst = {"F": 0.0, "dF": 0.0, "H": 0.0}
 count = {}
 for trial in range(trials):
-    N = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 8, 9, 10, 12, 13, 15, 16, 16, 17, 20, 24]))
-    m = int(rng.integers(0, 9))
+    N = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 8, 9, 10, 12, 13, 15, 16, 16, 17, 20, 24, 27, 32]))
+    m = int(rng.integers(0, 13 if N > 16 else 9))
     order = int(rng.choice([4, 4, 4, 2, 6]))
     integ = o.EXPONENTIAL if rng.random() < 0.3 else o.PADE
     T = int(rng.integers(2, 6))
@@ -39,9 +39,12 @@ for trial in range(trials):
     tag = f"trial {trial}: N={N} m={m} order={order} integ={integ} T={T} ft={free_time} ncol={ncol}"
     Fr, Jr = o.F(prob, Z), o.dF(prob, Z)
     do_h = integ == o.PADE and N <= 12
-    if do_h:
+    cross_h = integ == o.PADE and order == 4 and N > 16       # 4 x 4-tile Hessian kernel against the global-workspace kernel
+    if do_h or cross_h:
         mu = rng.standard_normal(prob.n_rows)
+    if do_h:
         Hr = o.mu_d2F(prob, Z, mu)
+    Hk = {}
     for kernel in kernels_for(qc, prob):
         h = RawHandle(qc, prob, kernel=kernel)
         F, J = h.F_jac(Z)
@@ -58,6 +61,12 @@ for trial in range(trials):
             eH = np.abs(H - Hr).max() / max(1.0, np.abs(Hr).max()) if Hr.size else 0.0
             assert eH < 1e-9, (tag, kernel, eH)
             worst["H"] = max(worst["H"], eH)
+        if cross_h and int(h.dims.hess_nnz):
+            Hk[kernel] = h.hess(Z, mu)
         count[kernel] = count.get(kernel, 0) + 1
         h.close()
+    if len(Hk) == 2:
+        eH = np.abs(Hk["mfma"] - Hk["lds"]).max() / max(1.0, np.abs(Hk["lds"]).max())
+        assert eH < 1e-9, (tag, "mfma64 hessian vs lds", eH)
+        worst["H_mfma64_vs_lds"] = max(worst.get("H_mfma64_vs_lds", 0.0), eH)
 print(f"{trials} trials ok in {time.time() - t0:.0f} s; handles per kernel {count}; worst relative errors {worst}")
