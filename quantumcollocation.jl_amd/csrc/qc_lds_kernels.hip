@@ -46,6 +46,7 @@ __device__ inline void matmul_lds(double* __restrict__ C, const double* __restri
     for (int idx = tid; idx < n * ncol; idx += NT) {
         const int r = idx % n, c = idx / n;
         double acc = 0.0;
+#pragma unroll 8
         for (int k = 0; k < n; ++k) acc = fma(A[r + n * k], X[k + n * c], acc);
         C[idx] = acc;
     }
@@ -182,6 +183,7 @@ __global__ __launch_bounds__(GWS ? kThreadsGws : kThreadsLds) void qc_lds_pade_k
             const double* __restrict__ Gj = P.G + (size_t)(j0 + jj + 1) * n2;
             const double* __restrict__ X = Q + i * nN + c * n;
             double acc = 0.0;
+#pragma unroll 8
             for (int k = 0; k < n; ++k) acc = fma(Gj[r + n * k], X[k], acc);
             R[idx] = acc;
         }
@@ -195,6 +197,7 @@ __global__ __launch_bounds__(GWS ? kThreadsGws : kThreadsLds) void qc_lds_pade_k
             for (int i = 1; i < p; ++i) {
                 const double* A = Gp + (i - 1) * n2;
                 const double* X = Rj + i * nN + c * n;
+#pragma unroll 8
                 for (int k = 0; k < n; ++k) acc = fma(A[r + n * k], X[k], acc);
             }
             Jb[P.jo_a + (size_t)(j0 + jj) * s + c * n + r] = acc;
@@ -254,6 +257,7 @@ __device__ inline void matmul_T_lds(double* __restrict__ C, const double* __rest
     for (int idx = tid; idx < n * ncol; idx += NT) {
         const int r = idx % n, c = idx / n;
         double acc = 0.0;
+#pragma unroll 8
         for (int k = 0; k < n; ++k) acc = fma(A[k + n * r], X[k + n * c], acc);
         C[idx] = acc;
     }
@@ -400,6 +404,7 @@ __global__ __launch_bounds__(GWS ? kThreadsGws : kThreadsLds) void qc_lds_pade_h
             const int r = idx % n, c = (idx / n) % N, rr = (idx / nN) % p, jj = idx / (nN * p);
             const double* __restrict__ Gj = P.G + (size_t)(j0 + jj + 1) * n2;     // G_j^T X: sum_k G_j[k][r] X[k][c]
             double ab = 0.0, af = 0.0;
+#pragma unroll 8
             for (int k = 0; k < n; ++k) {
                 const double gv = Gj[k + n * r];
                 ab = fma(gv, YB[rr * nN + c * n + k], ab);
@@ -416,6 +421,7 @@ __global__ __launch_bounds__(GWS ? kThreadsGws : kThreadsLds) void qc_lds_pade_h
                 const double* A = Gp + (rr - 1) * n2;                               // (G^rr)^T
                 const double* XB = RB + jj * p * nN + rr * nN + c * n;
                 const double* XF = RF + jj * p * nN + rr * nN + c * n;
+#pragma unroll 8
                 for (int k = 0; k < n; ++k) {
                     const double gv = A[k + n * r];
                     ab = fma(gv, XB[k], ab);
@@ -442,9 +448,11 @@ __global__ __launch_bounds__(GWS ? kThreadsGws : kThreadsLds) void qc_lds_pade_h
                     const double* __restrict__ Gj = P.G + (size_t)(j0 + jj + 1) * n2;
                     const double* Pt = (par ? PS : PD) + tq * nN + c * n;
                     double acc = 0.0;
+#pragma unroll 8
                     for (int k = 0; k < n; ++k) acc = fma(Gj[r + n * k], Pt[k], acc);
                     if (tq > 0) {
                         const double* Cp = Cj + ((jj * 2 + par) * pm1 + tq - 1) * nN + c * n;
+#pragma unroll 8
                         for (int k = 0; k < n; ++k) acc = fma(Gp[r + n * k], Cp[k], acc);
                     }
                     Cj[((jj * 2 + par) * pm1 + tq) * nN + c * n + r] = acc;
@@ -458,6 +466,7 @@ __global__ __launch_bounds__(GWS ? kThreadsGws : kThreadsLds) void qc_lds_pade_h
                     const double* __restrict__ Gi = P.G + (size_t)(i0 + ii + 1) * n2;
                     const double* Mx = Mq + al * nN + c * n;
                     double acc = 0.0;
+#pragma unroll 8
                     for (int k = 0; k < n; ++k) acc = fma(Gi[k + n * r], Mx[k], acc);   // G_i^T M_al
                     Ai[idx] = acc;
                 }
@@ -649,6 +658,7 @@ __global__ __launch_bounds__(GWS ? kThreadsGws : kThreadsLds) void qc_lds_exp_ke
                 const int r = idx % n, c = (idx / n) % n, jj = idx / n2;
                 const double* Lj = Ls + jj * n2;
                 double acc = 0.0;
+#pragma unroll 8
                 for (int k = 0; k < n; ++k) acc = fma(Ecur[r + n * k], Lj[k + n * c], fma(Lj[r + n * k], Ecur[k + n * c], acc));
                 Ln[idx] = acc;
             }
@@ -663,6 +673,7 @@ __global__ __launch_bounds__(GWS ? kThreadsGws : kThreadsLds) void qc_lds_exp_ke
             const int r = idx % n, c = (idx / n) % N, jj = idx / nN;
             const double* Lj = Ls + jj * n2;
             double acc = 0.0;
+#pragma unroll 8
             for (int k = 0; k < n; ++k) acc = fma(Lj[r + n * k], z0[P.off_U + c * n + k], acc);
             Jb[P.jo_a + (size_t)(j0 + jj) * s + c * n + r] = -acc;
         }
@@ -672,6 +683,7 @@ __global__ __launch_bounds__(GWS ? kThreadsGws : kThreadsLds) void qc_lds_exp_ke
     for (int idx = tid; idx < nN; idx += kThreads) {
         const int r = idx % n, c = idx / n;
         double acc = 0.0;
+#pragma unroll 8
         for (int k = 0; k < n; ++k) acc = fma(Ecur[r + n * k], z0[P.off_U + c * n + k], acc);
         EU[idx] = acc;
         if (Fb) Fb[idx] = z1[P.off_U + idx] - acc;
@@ -705,6 +717,7 @@ __global__ __launch_bounds__(GWS ? kThreadsGws : kThreadsLds) void qc_lds_exp_ke
         for (int idx = tid; idx < nN; idx += kThreads) {
             const int r = idx % n, c = idx / n;
             double acc = 0.0;
+#pragma unroll 8
             for (int k = 0; k < n; ++k) acc = fma(Gm[r + n * k], EU[c * n + k], acc);
             Jb[P.jo_h + idx] = -acc;
         }
