@@ -426,7 +426,7 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
 }  // namespace
 
 bool qc_mfma_supported(const QcParams& P) {
-    if (qc_mfma_exp_supported(P) || qc_mfma32_exp_supported(P) || qc_mfma64_supported(P)) return true;
+    if (qc_mfma_exp_supported(P) || qc_mfma32_exp_supported(P) || qc_mfma64_supported(P) || qc_mfma16_padeP_supported(P)) return true;
     return P.integrator == QC_PADE && P.p == 2 && ((P.n <= 16 && P.nc <= 8) || (P.n <= 32 && P.nc <= 16)) && P.m <= 32;
 }
 
@@ -507,6 +507,7 @@ hipError_t qc_launch_mfma16_F_jac_batch(const QcParams& P0, const QcParams* dPb,
 
 hipError_t qc_launch_mfma_F_jac(const QcParams& P, const double* dZ, double* dF, double* dJ, hipStream_t st) {
     if (P.integrator == QC_EXPONENTIAL) return P.n > 16 ? qc_launch_mfma32_exp(P, dZ, dF, dJ, st) : qc_launch_mfma_exp(P, dZ, dF, dJ, st);
+    if (qc_mfma16_padeP_supported(P)) return qc_launch_mfma16_padeP(P, dZ, dF, dJ, st);
     if (P.n > 32) return qc_launch_mfma64_F_jac(P, dZ, dF, dJ, st);
     if (P.n > 16) return qc_launch_mfma32_F_jac(P, dZ, dF, dJ, st);
     const int n_wg = dJ ? (P.n_int + kIntervalsPerWG - 1) / kIntervalsPerWG : P.n_int;

@@ -83,6 +83,8 @@ def kernels_for(qc, prob):
     if prob.integrator == 0 and prob.order == 4 and ((prob.n <= 16 and prob.nc <= 8) or (16 < prob.n <= 32 and prob.nc <= 16)
                                                      or (32 < prob.n <= 64 and prob.nc <= 32)):
         ks.append("mfma")
+    if prob.integrator == 0 and prob.order != 4 and prob.n <= 16 and prob.nc <= 8:      # any-order kernel (qc_mfma_padeP.hip)
+        ks.append("mfma")
     if prob.integrator == 1 and prob.m <= 8 and ((prob.n <= 16 and prob.nc <= 8) or (16 < prob.n <= 32 and prob.nc <= 16)):
         ks.append("mfma")
     return ks
@@ -1022,6 +1024,29 @@ def test_mfma64_kernel_long_trajectory_and_poisoned_outputs(qc, oracle):
     assert float((hs[0] - hs[1]).abs().max()) <= 1e-11 * scale
     h.close()
     hl.close()
+
+
+@pytest.mark.parametrize("order", [2, 6, 8, 10, 12, 20])
+@pytest.mark.parametrize("N,m,ncol,free_time", [(8, 6, 0, True), (8, 5, 0, False), (8, 9, 3, True), (5, 2, 0, True), (3, 1, 2, True), (8, 0, 0, True)])
+def test_any_order_mfma_kernel_matches_oracle(qc, oracle, order, N, m, ncol, free_time):
+    """Pade orders other than 4 at up to 8 levels: the register-resident any-order MFMA kernel (qc_mfma_padeP.hip) -- F, dF
+    and the residual-only launch against the oracle; mu_d2F of such a handle is served by the LDS kernel."""
+    prob, Z = random_problem(oracle, N=N, m=max(m, 1), T=4, order=order, free_time=free_time, ncol=ncol, seed=order * 100 + N + m)
+    if m == 0:
+        prob.m = 0
+        prob.G_drives = prob.G_drives[:0]
+        prob.derivs = []
+    h = RawHandle(qc, prob)
+    assert h.dims.kernel == qc._lib.QC_KERNEL_MFMA
+    F, J = h.F_jac(Z)
+    Fr, Jr = oracle.F(prob, Z), oracle.dF(prob, Z)
+    np.testing.assert_allclose(F, Fr, rtol=1e-10, atol=1e-12 * max(1.0, np.abs(Fr).max()))
+    np.testing.assert_allclose(J, Jr, rtol=1e-10, atol=1e-12 * max(1.0, np.abs(Jr).max()))
+    np.testing.assert_allclose(h.F(Z), F, rtol=0, atol=1e-13 * max(1.0, np.abs(Fr).max()))
+    if int(h.dims.hess_nnz):
+        mu = np.random.default_rng(order).standard_normal(prob.n_rows)
+        assert_close_h(h.hess(Z, mu), oracle.mu_d2F(prob, Z, mu), "hess")
+    h.close()
 
 
 def test_stress_script_short_run():
