@@ -77,8 +77,7 @@ enum {
 enum { QC_PADE = 0, QC_EXPONENTIAL = 1 };
 
 /* Kernel selection (qc_desc.kernel). AUTO picks the MFMA path for systems with N <= 16 levels (sizes other than 8 / 16
- * levels zero-padded to the tiles) with the Pade order 4 or the exponential integrator (up to 8 levels: any Pade order for
- * F and dF; mu_d2F at orders other than 4 runs on the generic path), and for 17 .. 32 levels (5 qubits) with the Pade order 4; else the generic LDS/VALU path (its scratch in a global workspace when it exceeds the LDS).
+ * levels zero-padded to the tiles) with the Pade order 4 or the exponential integrator (up to 8 levels: any Pade order), and for 17 .. 32 levels (5 qubits) with the Pade order 4; else the generic LDS/VALU path (its scratch in a global workspace when it exceeds the LDS).
  * The Hessian of a 17 .. 32-level MFMA handle allocates 128 MiB of device scratch at its first evaluation.  Forcing a path that cannot serve the descriptor is
  * QC_ERR_UNSUPPORTED. */
 enum { QC_KERNEL_AUTO = 0, QC_KERNEL_LDS = 1, QC_KERNEL_MFMA = 2 };

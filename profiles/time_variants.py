@@ -51,7 +51,7 @@ s3 = qc.multi_qubit_system(3)
 time_dyn("config 3 Pade-4 (mfma16)", qc.config_inputs(3))
 time_dyn("config 3 Pade-4 (lds)", qc.config_inputs(3), kernel="lds")
 for order in (2, 6, 12, 20):
-    time_dyn(f"config 3 Pade-{order} (mfma16 any-order; mu_d2F on lds)", qc.unitary_smooth_pulse_inputs(s3, qc.GATES["TOFFOLI"], 1000, pade_order=order))
+    time_dyn(f"config 3 Pade-{order} (mfma16 any-order)", qc.unitary_smooth_pulse_inputs(s3, qc.GATES["TOFFOLI"], 1000, pade_order=order))
 time_dyn("config 3 Pade-12 (lds)", qc.unitary_smooth_pulse_inputs(s3, qc.GATES["TOFFOLI"], 1000, pade_order=12), kernel="lds", reps=50)
 time_dyn("config 3 exponential (mfma16-exp)", qc.unitary_smooth_pulse_inputs(s3, qc.GATES["TOFFOLI"], 1000, integrator="exponential"))
 time_dyn("config 3 exponential (lds)", qc.unitary_smooth_pulse_inputs(s3, qc.GATES["TOFFOLI"], 1000, integrator="exponential"), reps=30, kernel="lds")

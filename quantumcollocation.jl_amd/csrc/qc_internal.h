@@ -96,6 +96,8 @@ void qc_mfma32_pack_G(const QcParams& P, const double* G_host, double* Gx_host);
 hipError_t qc_launch_mfma32_F_jac(const QcParams& P, const double* dZ, double* dF, double* dJ, hipStream_t st);
 bool qc_mfma16_padeP_supported(const QcParams& P);
 hipError_t qc_launch_mfma16_padeP(const QcParams& P, const double* dZ, double* dF, double* dJ, hipStream_t st);
+bool qc_mfma16_padeP_hess_supported(const QcParams& P);
+hipError_t qc_launch_mfma16_padeP_hess(const QcParams& P, const double* dZ, const double* dMu, double* dH, hipStream_t st);
 bool qc_mfma64_supported(const QcParams& P);
 size_t qc_mfma64_gx_doubles(const QcParams& P);
 void qc_mfma64_pack_G(const QcParams& P, const double* G_host, double* Gx_host);

@@ -243,7 +243,7 @@ __global__ __launch_bounds__(64) void qc_mfma16_pade4_hess_kernel(const QcParams
 }  // namespace
 
 bool qc_mfma_hess_supported(const QcParams& P) {
-    if (qc_mfma32_hess_supported(P) || qc_mfma64_hess_supported(P)) return true;
+    if (qc_mfma32_hess_supported(P) || qc_mfma64_hess_supported(P) || qc_mfma16_padeP_hess_supported(P)) return true;
     return P.integrator == QC_PADE && P.p == 2 && P.n <= 16 && P.nc <= 8 && P.m <= kHMmax;
 }
 
@@ -263,6 +263,7 @@ hipError_t qc_launch_mfma16_hess_batch(const QcParams& P0, const QcParams* dPb, 
 }
 
 hipError_t qc_launch_mfma_hess(const QcParams& P, const double* dZ, const double* dMu, double* dH, hipStream_t st) {
+    if (qc_mfma16_padeP_hess_supported(P)) return qc_launch_mfma16_padeP_hess(P, dZ, dMu, dH, st);
     if (P.n > 32) return qc_launch_mfma64_hess(P, dZ, dMu, dH, st);
     if (P.n > 16) return qc_launch_mfma32_hess(P, dZ, dMu, dH, st);
     const int grid = P.n_int < 4096 ? P.n_int : 4096;
