@@ -77,9 +77,10 @@ enum {
 enum { QC_PADE = 0, QC_EXPONENTIAL = 1 };
 
 /* Kernel selection (qc_desc.kernel). AUTO picks the MFMA path for systems with N <= 16 levels (sizes other than 8 / 16
- * levels zero-padded to the tiles) with the Pade order 4 or the exponential integrator (up to 8 levels: any Pade order), and for 17 .. 32 levels (5 qubits) with the Pade order 4; else the generic LDS/VALU path (its scratch in a global workspace when it exceeds the LDS).
- * The Hessian of a 17 .. 32-level MFMA handle allocates 128 MiB of device scratch at its first evaluation.  Forcing a path that cannot serve the descriptor is
- * QC_ERR_UNSUPPORTED. */
+ * levels zero-padded to the tiles) with the Pade order 4 or the exponential integrator, for up to 8 levels with any Pade
+ * order, and for 17 .. 32 levels (5 qubits) with the Pade order 4; else the generic LDS/VALU path (its scratch in a global
+ * workspace when it exceeds the LDS).  The Hessian of a 17 .. 32-level MFMA handle allocates 128 MiB of device scratch at
+ * its first evaluation.  Forcing a path that cannot serve the descriptor is QC_ERR_UNSUPPORTED. */
 enum { QC_KERNEL_AUTO = 0, QC_KERNEL_LDS = 1, QC_KERNEL_MFMA = 2 };
 
 #define QC_MAX_DERIV 8
