@@ -80,7 +80,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="0 disables the CPU baseline leg")
     ap.add_argument("--hessian", action=argparse.BooleanOptionalAction, default=True,
                     help="also time mu_d2F and F alone and report the ms/Ipopt-iter proxy of the metric (extra fields)")
-    ap.add_argument("--allgather", action="store_true", help="also time the RCCL all-gather of the value blocks")
+    ap.add_argument("--allgather", dest="allgather", action="store_true", default=True,
+                    help="at N > 1 also time the RCCL all-gather of the value blocks (default; reported beside the metric, never part of it)")
+    ap.add_argument("--no-allgather", dest="allgather", action="store_false")
     ap.add_argument("--streams", type=int, default=0, help="also time the same steps issued round-robin on S streams "
                     "(independent evaluations overlapping their launch/drain phases; reported as an extra field, never `value`)")
     ap.add_argument("--host-visible", action=argparse.BooleanOptionalAction, default=True,
@@ -229,17 +231,27 @@ def main():
             dyn.F_dF_into(Zh, Fh, Jh)
         extra["host_visible_ms_per_eval"] = (time.perf_counter() - h0) / 20 * 1e3
     if args.allgather and world > 1:
-        pad = torch.zeros(sd.padded_len(nnz), dtype=torch.float64, device=dev)
-        pad[:Jb[0].numel()].copy_(Jb[0])
-        full = torch.empty(world * pad.numel(), dtype=torch.float64, device=dev)
-        for _ in range(5):
-            sd.all_gather_values(pad, nnz, out=full)
-        torch.cuda.synchronize()
-        a0 = time.perf_counter()
-        for _ in range(20):
-            sd.all_gather_values(pad, nnz, out=full)
-        torch.cuda.synchronize()
-        extra["allgather_ms"] = (time.perf_counter() - a0) / 20 * 1e3
+        # SURVEY 8(e) "report both": the device-resident full Jacobian on every GPU (RCCL all-gather over xGMI), timed
+        # outside the metric's region.  A failure here must not lose the metric line.
+        try:
+            gdev = dev if backend == "nccl" else torch.device("cpu")
+            pad = torch.zeros(sd.padded_len(nnz), dtype=torch.float64, device=gdev)
+            pad[:Jb[0].numel()].copy_(Jb[0])
+            full = torch.empty(world * pad.numel(), dtype=torch.float64, device=gdev)
+            for _ in range(3):
+                sd.all_gather_values(pad, nnz, out=full)
+            torch.cuda.synchronize()
+            barrier()
+            a0 = time.perf_counter()
+            for _ in range(10):
+                sd.all_gather_values(pad, nnz, out=full)
+            torch.cuda.synchronize()
+            ag = torch.tensor([(time.perf_counter() - a0) / 10 * 1e3], dtype=torch.float64, device=gdev)
+            dist.all_reduce(ag, op=dist.ReduceOp.MAX)
+            extra["allgather_ms"] = float(ag.item())
+            extra["allgather_GB_per_gpu_received"] = (world - 1) * pad.numel() * 8 / 1e9
+        except Exception as exc:   # noqa: BLE001
+            extra["allgather_error"] = repr(exc)[:200]
 
     total_intervals = (T_total - 1)
     t1000_equiv = total_intervals / (T_PER_GPU - 1) if args.config in (3, 4) else float(world)
