@@ -176,6 +176,11 @@ void qc_destroy(qc_handle* h);
 const char* qc_last_error(const qc_handle* h);
 
 int qc_dims(const qc_handle* h, qc_dims_t* out);
+/* Names of the device kernels this handle's evaluations run on (diagnostic; static strings, never NULL):
+ * which = 0: F / F + dF ("mfma16-pade4", "mfma16-padeP", "mfma32-pade4", "mfma64-pade4", "mfma16-exp", "mfma32-exp",
+ * "lds", "lds-gws");  which = 1: mu_d2F ("mfma16-pade4-hess", "mfma16-padeP-hess", "mfma32-pade4-hess",
+ * "mfma64-pade4-hess", "lds-hess", "lds-gws-hess", or "none" for the exponential integrator). */
+const char* qc_kernel_name(const qc_handle* h, int32_t which);
 int qc_jac_structure(const qc_handle* h, int64_t* rows, int64_t* cols, int one_based);
 int qc_hess_structure(const qc_handle* h, int64_t* rows, int64_t* cols, int one_based);
 

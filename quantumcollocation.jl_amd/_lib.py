@@ -126,6 +126,7 @@ SYMBOLS = {
     "qc_create": (C.c_int, [_DESC_P, C.POINTER(_H)]),
     "qc_destroy": (None, [_H]),
     "qc_last_error": (C.c_char_p, [_H]),
+    "qc_kernel_name": (C.c_char_p, [_H, C.c_int32]),
     "qc_dims": (C.c_int, [_H, _DIMS_P]),
     "qc_jac_structure": (C.c_int, [_H, _c_int64_p, _c_int64_p, C.c_int]),
     "qc_hess_structure": (C.c_int, [_H, _c_int64_p, _c_int64_p, C.c_int]),

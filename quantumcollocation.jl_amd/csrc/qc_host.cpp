@@ -433,6 +433,24 @@ extern "C" int qc_debug_read_stamps(qc_handle* h, uint64_t* out, int64_t count) 
     return QC_OK;
 }
 
+extern "C" const char* qc_kernel_name(const qc_handle* h, int32_t which) {
+    if (!h) return "none";
+    const QcParams& P = h->prm;
+    const bool mfma = h->kernel == QC_KERNEL_MFMA;
+    if (which == 0) {
+        if (!mfma) return P.use_ws ? "lds-gws" : "lds";
+        if (P.integrator == QC_EXPONENTIAL) return P.n > 16 ? "mfma32-exp" : "mfma16-exp";
+        if (qc_mfma16_padeP_supported(P)) return "mfma16-padeP";
+        return P.n > 32 ? "mfma64-pade4" : (P.n > 16 ? "mfma32-pade4" : "mfma16-pade4");
+    }
+    if (P.integrator != QC_PADE) return "none";
+    if (mfma && qc_mfma_hess_supported(P)) {
+        if (qc_mfma16_padeP_hess_supported(P)) return "mfma16-padeP-hess";
+        return P.n > 32 ? "mfma64-pade4-hess" : (P.n > 16 ? "mfma32-pade4-hess" : "mfma16-pade4-hess");
+    }
+    return P.use_ws ? "lds-gws-hess" : "lds-hess";
+}
+
 extern "C" int qc_dims(const qc_handle* h, qc_dims_t* out) {
     if (!h || !out) return fail(nullptr, QC_ERR_INVALID, "qc_dims: NULL argument");
     *out = h->dims;

@@ -169,6 +169,7 @@ class QuantumDynamics:
         self.dim = int(dims.ddim)          # dynamics rows per interval (= Z.dims.states)
         self.device = device
         self.kernel = {_lib.QC_KERNEL_LDS: "lds", _lib.QC_KERNEL_MFMA: "mfma"}[dims.kernel]
+        self.kernel_names = (_lib.lib.qc_kernel_name(self._h, 0).decode(), _lib.lib.qc_kernel_name(self._h, 1).decode())
         self._structs = None
 
     # -- lifetime --------------------------------------------------------------------------------

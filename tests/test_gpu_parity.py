@@ -967,6 +967,8 @@ def test_mfma64_kernel_matches_oracle(qc, oracle, N, m, T, free_time, layout, nc
         prob.derivs = []          # no drives: no derivative integrators either
     h = RawHandle(qc, prob)
     assert h.dims.kernel == qc._lib.QC_KERNEL_MFMA
+    assert qc._lib.lib.qc_kernel_name(h.h, 0) == b"mfma64-pade4"
+    assert qc._lib.lib.qc_kernel_name(h.h, 1) == (b"mfma64-pade4-hess" if prob.m <= 14 else b"lds-gws-hess")
     F, J = h.F_jac(Z)
     Fr, Jr = oracle.F(prob, Z), oracle.dF(prob, Z)
     np.testing.assert_allclose(F, Fr, rtol=1e-10, atol=1e-12 * max(1.0, np.abs(Fr).max()))
@@ -1038,6 +1040,8 @@ def test_any_order_mfma_kernel_matches_oracle(qc, oracle, order, N, m, ncol, fre
         prob.derivs = []
     h = RawHandle(qc, prob)
     assert h.dims.kernel == qc._lib.QC_KERNEL_MFMA
+    assert qc._lib.lib.qc_kernel_name(h.h, 0) == b"mfma16-padeP"
+    assert qc._lib.lib.qc_kernel_name(h.h, 1) == (b"mfma16-padeP-hess" if prob.m <= 8 else b"lds-hess")
     F, J = h.F_jac(Z)
     Fr, Jr = oracle.F(prob, Z), oracle.dF(prob, Z)
     np.testing.assert_allclose(F, Fr, rtol=1e-10, atol=1e-12 * max(1.0, np.abs(Fr).max()))
@@ -1047,6 +1051,30 @@ def test_any_order_mfma_kernel_matches_oracle(qc, oracle, order, N, m, ncol, fre
         mu = np.random.default_rng(order).standard_normal(prob.n_rows)
         assert_close_h(h.hess(Z, mu), oracle.mu_d2F(prob, Z, mu), "hess")
     h.close()
+
+
+def test_kernel_names_of_the_baseline_configurations(qc):
+    """Which device kernels serve BASELINE.json's configurations (qc_kernel_name): the tuned MFMA kernels, not a generic path."""
+    expect = {1: ("mfma16-pade4", "mfma16-pade4-hess"), 2: ("mfma16-pade4", "mfma16-pade4-hess"),
+              3: ("mfma16-pade4", "mfma16-pade4-hess"), 5: ("mfma32-pade4", "mfma32-pade4-hess")}
+    for cfg, names in expect.items():
+        inp = qc.config_inputs(cfg, T=5)
+        dyn = qc.QuantumDynamics(inp.integrators, inp.traj)
+        assert dyn.kernel_names == names, (cfg, dyn.kernel_names)
+        dyn.close()
+    s3 = qc.multi_qubit_system(3)
+    for kw, names in [(dict(integrator="exponential"), ("mfma16-exp", "none")), (dict(pade_order=12), ("mfma16-padeP", "mfma16-padeP-hess"))]:
+        inp = qc.unitary_smooth_pulse_inputs(s3, qc.GATES["TOFFOLI"], 5, **kw)
+        dyn = qc.QuantumDynamics(inp.integrators, inp.traj)
+        assert dyn.kernel_names == names, (kw, dyn.kernel_names)
+        dyn.close()
+    inp = qc.unitary_smooth_pulse_inputs(qc.multi_qubit_system(5), np.eye(32, dtype=complex), 4)
+    dyn = qc.QuantumDynamics(inp.integrators, inp.traj)
+    assert dyn.kernel_names == ("mfma64-pade4", "mfma64-pade4-hess")
+    dyn.close()
+    dyn = qc.QuantumDynamics(inp.integrators, inp.traj, kernel="lds")
+    assert dyn.kernel_names == ("lds-gws", "lds-gws-hess")
+    dyn.close()
 
 
 def test_stress_script_short_run():
