@@ -1078,8 +1078,8 @@ def test_kernel_names_of_the_baseline_configurations(qc):
 
 
 def test_stress_script_short_run():
-    """tests/stress_gpu.py (random systems up to 24 levels, all integrators and kernels) with 60 trials; the full runs
-    (4 x 400 trials, worst relative error 3.4e-13) are quoted in DESIGN.md."""
+    """tests/stress_gpu.py (random systems up to 32 levels, all integrators and kernels) with 60 trials; the full runs
+    (about 5000 trials, worst relative error 6.3e-13) are quoted in DESIGN.md."""
     import subprocess
     import sys as _sys
     here = os.path.dirname(os.path.abspath(__file__))
