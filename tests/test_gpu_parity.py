@@ -214,6 +214,31 @@ def test_shards_concatenate_to_the_full_evaluation(qc, oracle):
     np.testing.assert_array_equal(np.concatenate(Js), J)
 
 
+@pytest.mark.parametrize("N,m,order", [(8, 5, 6), (8, 3, 12), (20, 3, 4), (32, 2, 4)])
+def test_shards_of_the_newer_kernels_concatenate(qc, oracle, N, m, order):
+    """Knot shards (t_begin > 0) through the any-order kernels (F+dF and mu_d2F) and the 4 x 4-tile kernels: the shards'
+    values concatenate bit-identically to the full evaluation."""
+    prob, Z = random_problem(oracle, N=N, m=m, T=9, order=order, seed=N + order)
+    mu = np.random.default_rng(5).standard_normal(prob.n_rows)
+    full = RawHandle(qc, prob)
+    assert full.dims.kernel == qc._lib.QC_KERNEL_MFMA
+    F, J = full.F_jac(Z)
+    H = full.hess(Z, mu)
+    full.close()
+    Fs, Js, Hs = [], [], []
+    for a, b in ((0, 3), (3, 4), (4, 8)):
+        h = RawHandle(qc, prob, t_range=(a, b))
+        f, j = h.F_jac(Z)
+        Fs.append(f)
+        Js.append(j)
+        # the multiplier vector of a shard call is the FULL vector (rows of interval t_begin first are read at t_begin * ddim)
+        Hs.append(h.hess(Z, mu))
+        h.close()
+    np.testing.assert_array_equal(np.concatenate(Fs), F)
+    np.testing.assert_array_equal(np.concatenate(Js), J)
+    np.testing.assert_array_equal(np.concatenate(Hs), H)
+
+
 def test_device_resident_entry_points(qc, oracle):
     inp = qc.config_inputs(2, T=30)
     Z = inp.traj.datavec
