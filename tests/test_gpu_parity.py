@@ -214,6 +214,28 @@ def test_shards_concatenate_to_the_full_evaluation(qc, oracle):
     np.testing.assert_array_equal(np.concatenate(Js), J)
 
 
+@pytest.mark.parametrize("order", [6, 12])
+def test_sampling_problem_at_other_pade_orders(qc, oracle, order):
+    """UnitarySamplingProblem with `pade_order` != 4: the any-order kernels write into the shared per-interval blocks of a
+    composed problem (rows_per_interval / offsets); F, dF, mu_d2F against the composed oracle."""
+    from oracle_bridge import composed_oracle
+    base = qc.multi_qubit_system(2)
+    systems = [qc.QuantumSystem(base.H_drift * f, base.H_drives) for f in (0.9, 1.0, 1.15)]
+    inp = qc.unitary_sampling_inputs(systems, qc.GATES["CNOT"], 9, pade_order=order)
+    dyn = qc.QuantumDynamics(inp.integrators, inp.traj)
+    assert isinstance(dyn, qc.ComposedQuantumDynamics) and len(dyn._parts) == 3
+    for part in dyn._parts:
+        assert qc._lib.lib.qc_kernel_name(part[2], 0) == b"mfma16-padeP" and qc._lib.lib.qc_kernel_name(part[2], 1) == b"mfma16-padeP-hess"
+    ref = composed_oracle(inp)
+    Z = inp.traj.datavec
+    F, J = dyn.F_dF(Z)
+    assert_close(F, ref.F(Z), "composed F")
+    assert_close(J, ref.dF(Z), "composed dF")
+    mu = np.random.default_rng(order).standard_normal(dyn.dims.n_rows)
+    assert_close_h(dyn.mu_d2F(Z, mu), ref.mu_d2F(Z, mu), "composed hessian")
+    dyn.close()
+
+
 @pytest.mark.parametrize("N,m,order", [(8, 5, 6), (8, 3, 12), (20, 3, 4), (32, 2, 4)])
 def test_shards_of_the_newer_kernels_concatenate(qc, oracle, N, m, order):
     """Knot shards (t_begin > 0) through the any-order kernels (F+dF and mu_d2F) and the 4 x 4-tile kernels: the shards'
