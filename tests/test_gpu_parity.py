@@ -261,6 +261,25 @@ def test_shards_of_the_newer_kernels_concatenate(qc, oracle, N, m, order):
     np.testing.assert_array_equal(np.concatenate(Hs), H)
 
 
+def test_host_results_held_by_the_caller_are_not_overwritten(qc):
+    """The Python mirror recycles its result arrays (QuantumDynamics._out): three evaluations at different points, all
+    results kept, each still equal to a fresh evaluation afterwards."""
+    inp = qc.config_inputs(2, T=12)
+    dyn = qc.QuantumDynamics(inp.integrators, inp.traj)
+    rng = np.random.default_rng(0)
+    Zs = [inp.traj.datavec + 1e-2 * k * rng.standard_normal(inp.traj.datavec.size) for k in range(3)]
+    mu = rng.standard_normal(dyn.dims.n_rows)
+    kept = [(dyn.F_dF(Z), dyn.mu_d2F(Z, mu)) for Z in Zs]
+    for Z, ((F, J), H) in zip(Zs, kept):
+        F2 = dyn.F(Z).copy()
+        J2 = dyn.dF(Z).copy()
+        H2 = dyn.mu_d2F(Z, mu).copy()
+        np.testing.assert_array_equal(F, F2)
+        np.testing.assert_array_equal(J, J2)
+        np.testing.assert_array_equal(H, H2)
+    dyn.close()
+
+
 def test_device_resident_entry_points(qc, oracle):
     inp = qc.config_inputs(2, T=30)
     Z = inp.traj.datavec

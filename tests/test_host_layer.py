@@ -49,3 +49,28 @@ def test_dynamics_requires_unitary_integrator_first(qc):
     inp = qc.config_inputs(1, T=5)
     with pytest.raises(NotImplementedError):
         qc.make_desc(inp.integrators[1:], inp.traj)
+
+
+def test_result_arrays_are_recycled_only_when_the_caller_let_go(qc):
+    """QuantumDynamics._out: results the caller still holds (or holds a view of) are never overwritten; released ones are
+    reused (two per kind, so that `J = dyn.dF(Z)` in a loop alternates between two arrays instead of allocating 40 MB)."""
+    import types
+    obj = types.SimpleNamespace()
+    out = lambda name, n: qc.QuantumDynamics._out(obj, name, n)
+    ids = []
+    J = None
+    for k in range(6):
+        J = out("J", 10)
+        J[:] = k
+        ids.append(id(J))
+    assert len(set(ids)) == 2
+    keep = []
+    for k in range(5):
+        a = out("J", 10)
+        a[:] = k
+        keep.append(a)
+    assert all(keep[k][0] == k for k in range(5)) and len({id(x) for x in keep}) == 5
+    v = out("H", 8)[:2]
+    w = out("H", 8)
+    assert not np.shares_memory(v, w)
+    assert out("J", 12).size == 12
