@@ -12,7 +12,8 @@
 // (A B)[16 R + j][16 C + 4 r + g]): lanes run along rows, so every 8-byte-per-lane store writes four whole 128-byte lines
 // of a column-major output block.  All outputs are produced that way; nothing is transposed after the fact.
 //
-// One 1024-thread workgroup (16 wavefronts, 152 KB of LDS) per interval, one workgroup per CU; the hardware deals the
+// One 1024-thread workgroup (16 wavefronts, 152 KB of LDS) per interval (up to four per interval when there are fewer
+// intervals than CUs: each takes every `parts`-th drive and copy), one workgroup per CU; the hardware deals the
 // waves round-robin over the 4 SIMDs, so every SIMD hosts two compute and two copy waves.
 //   phase 0   all threads: G = G_0 + sum_k a_k G_k (zero-padded global images, L2 hits), [S | D] = [U1 + U0 | U1 - U0].
 //   phase A   compute wave (I, J'): tiles (I, J') of G S and G D (32 MFMAs) -> Q_0 = -c1 h S + c2 h^2 G D,
@@ -78,7 +79,7 @@ __device__ __forceinline__ void settle_fragment(double (&f)[16]) {
 }
 
 template <bool JAC>
-__global__ __launch_bounds__(kThreads64, 1) void qc_mfma64_pade4_kernel(const QcParams P, const double* __restrict__ Z,
+__global__ __launch_bounds__(kThreads64, 1) void qc_mfma64_pade4_kernel(const QcParams P, const int parts, const double* __restrict__ Z,
                                                                        double* __restrict__ F, double* __restrict__ J) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double* __restrict__ Gs = sm + oG;
@@ -95,7 +96,13 @@ __global__ __launch_bounds__(kThreads64, 1) void qc_mfma64_pade4_kernel(const Qc
     const double c1 = P.c[1], c2 = P.c[2];
     const double* __restrict__ Gx = P.Gx;
 
-    const int b = qc_xcd_remap(blockIdx.x, P.n_int);
+    // Few intervals (T <~ 128: fewer workgroups than CUs): `parts` workgroups share an interval -- each repeats phases 0 / A,
+    // then takes the drives k = part, part + parts, ... and the copies q = part, part + parts, ...; part 0 also stores the
+    // residual, d/dh and the derivative-integrator rows.
+    const int part = JAC ? (int)(blockIdx.x % (unsigned)parts) : 0;
+    const int step = JAC ? parts : 1;
+    const int ml = part < m ? (m - part + step - 1) / step : 0;        // drives of this workgroup
+    const int b = qc_xcd_remap(blockIdx.x / (unsigned)step, P.n_int);
     const long long t = P.t_begin + b;
     const double* __restrict__ z0 = Z + t * (long long)P.zdim;
     const double* __restrict__ z1 = z0 + P.zdim;
@@ -130,7 +137,7 @@ __global__ __launch_bounds__(kThreads64, 1) void qc_mfma64_pade4_kernel(const Qc
             Xs[(32 + c) * kLd + r] = u1 - u0;
         }
     }
-    if (w == 15) deriv_rows_generic(P, z0, z1, h, Fb, Jb, lane, false);   // derivative-integrator rows: loads, then a few stores
+    if (w == 15 && part == 0) deriv_rows_generic(P, z0, z1, h, Fb, Jb, lane, false);   // derivative-integrator rows: loads, then a few stores
     __syncthreads();
 
     const bool compute = w < 8;
@@ -171,7 +178,7 @@ __global__ __launch_bounds__(kThreads64, 1) void qc_mfma64_pade4_kernel(const Qc
 #pragma unroll
         for (int q = 0; q < 16; ++q) fG[q] = rowG[q * 4 * kLd];
         double fk[16];                                                 // row fragment I of the current drive's generator
-        if (JAC && m > 0) load_drive_fragment(Gx, 1, I, g, j, fk);
+        if (JAC && ml > 0) load_drive_fragment(Gx, part + 1, I, g, j, fk);
         const double* colQh = Qhs + (16 * Jp + j) * kLd + g;
         v4d res = Dt, dh = {0.0, 0.0, 0.0, 0.0};
         if constexpr (JAC) {
@@ -180,29 +187,30 @@ __global__ __launch_bounds__(kThreads64, 1) void qc_mfma64_pade4_kernel(const Qc
 #pragma unroll                                                         // the residual-only launch returns bit-identical values
             for (int q = 0; q < 16; ++q) res = mfma4(colS[q * 4], fG[q], res);
         }
-        if (JAC && m > 0) settle_fragment(fk);
+        if (JAC && ml > 0) settle_fragment(fk);
         const int row = 16 * I + j;
         const bool rok = row < n;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int col = 16 * Jp + 4 * r + g;
-            if (rok && col < nc) {
+            if (rok && col < nc && part == 0) {
                 if (Fb) qc_st8m<2>(Fb + col * n + row, res[r]);
                 if constexpr (JAC) { if (ft) qc_st8m<2>(Jb + P.jo_h + col * n + row, dh[r]); }
             }
         }
         if constexpr (JAC) {
-            for (int k = 0; k < m; ++k) {
-                double* __restrict__ Vk = Vs + (k & 1) * kHalf;
+            for (int kl = 0; kl < ml; ++kl) {
+                const int k = part + kl * step;
+                double* __restrict__ Vk = Vs + (kl & 1) * kHalf;
                 v4d T1L = {0.0, 0.0, 0.0, 0.0}, T1R = {0.0, 0.0, 0.0, 0.0};
                 mm_a2_reg(colS, colD, 4, fk, T1L, T1R);                // (G_k Q_0)^T, (G_k D')^T
                 double* vT = Vk + (16 * Jp + g) * kLd + 16 * I + j;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) vT[4 * r * kLd] = T1R[r];
-                if (k + 1 < m) load_drive_fragment(Gx, k + 2, I, g, j, fk);
+                if (kl + 1 < ml) load_drive_fragment(Gx, k + step + 1, I, g, j, fk);
                 __syncthreads();                                       // G_k D' complete (the other buffer is free again)
                 const v4d Y = mm_a1_reg(Vk + (16 * Jp + j) * kLd + g, 4, fG, T1L);   // + (G (G_k D'))^T
-                if (k + 1 < m) settle_fragment(fk);
+                if (kl + 1 < ml) settle_fragment(fk);
                 double* pa = Jb + P.jo_a + (size_t)k * P.s;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -246,21 +254,23 @@ __global__ __launch_bounds__(kThreads64, 1) void qc_mfma64_pade4_kernel(const Qc
             const size_t n2 = (size_t)n * n;
             double* __restrict__ pF = Jb + P.jo_F + (size_t)(8 * c) * n + lane;
             double* __restrict__ pB = Jb + P.jo_B + (size_t)(8 * c) * n + lane;
-            const int share = m > 0 ? (nc + m - 1) / m : nc;          // copies between two drive barriers
+            const int ncl = part < nc ? (nc - part + step - 1) / step : 0;   // copies of this workgroup: q = part + ql * step
+            const int share = ml > 0 ? (ncl + ml - 1) / ml : ncl;             // copies between two drive barriers
             int q0 = 0;
-            for (int k = 0; k <= m; ++k) {
-                const int q1 = k < m ? (q0 + share < nc ? q0 + share : nc) : nc;
-                for (int q = q0; q < q1; ++q) {
+            for (int kl = 0; kl <= ml; ++kl) {
+                const int q1 = kl < ml ? (q0 + share < ncl ? q0 + share : ncl) : ncl;
+                for (int ql = q0; ql < q1; ++ql) {
+                    const size_t qo = (size_t)(part + ql * step) * n2;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         if (rok && 8 * c + e < n) {
-                            qc_st8m<2>(pF + q * n2 + (size_t)e * n, fc[e]);
-                            qc_st8m<2>(pB + q * n2 + (size_t)e * n, bc[e]);
+                            qc_st8m<2>(pF + qo + (size_t)e * n, fc[e]);
+                            qc_st8m<2>(pB + qo + (size_t)e * n, bc[e]);
                         }
                     }
                 }
                 q0 = q1;
-                if (k < m) __syncthreads();
+                if (kl < ml) __syncthreads();
             }
         }
     }
@@ -293,7 +303,10 @@ hipError_t qc_launch_mfma64_F_jac(const QcParams& P, const double* dZ, double* d
                       : hipFuncSetAttribute(reinterpret_cast<const void*>(qc_mfma64_pade4_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     if (P.n_int <= 0) return hipSuccess;
-    if (dJ) hipLaunchKernelGGL((qc_mfma64_pade4_kernel<true>), dim3(P.n_int), dim3(kThreads64), lds, st, P, dZ, dF, dJ);
-    else hipLaunchKernelGGL((qc_mfma64_pade4_kernel<false>), dim3(P.n_int), dim3(kThreads64), lds, st, P, dZ, dF, dJ);
+    // fewer intervals than CUs: up to 4 workgroups share an interval (drives and copies dealt round-robin)
+    int parts = 1;
+    if (dJ) { while (parts < 4 && 2 * parts * P.n_int <= 256) parts *= 2; }
+    if (dJ) hipLaunchKernelGGL((qc_mfma64_pade4_kernel<true>), dim3((unsigned)P.n_int * parts), dim3(kThreads64), lds, st, P, parts, dZ, dF, dJ);
+    else hipLaunchKernelGGL((qc_mfma64_pade4_kernel<false>), dim3(P.n_int), dim3(kThreads64), lds, st, P, 1, dZ, dF, dJ);
     return hipGetLastError();
 }
