@@ -79,7 +79,9 @@ __device__ inline void store_T32_masked(double* __restrict__ p, const v4d& x, in
 }
 
 // KET: K < 16 ket states (column-masked loads and stores); false = unitary, every mask folds away at compile time
-template <bool JAC, bool DIAG, bool KET>
+// SINGLE: one interval per workgroup (fewer intervals than CUs: T <~ 256) -- the four compute waves share the interval's drives
+// (k = w, w + 4, ...), the four copy waves its block rows and copies (halves), so a workgroup is done in about half the time
+template <bool JAC, bool DIAG, bool KET, bool SINGLE = false>
 __global__ __launch_bounds__(kThreads32, 2) void qc_mfma32_pade4_kernel(const QcParams P, const double* __restrict__ Z,
                                                                        double* __restrict__ F, double* __restrict__ J) {
     __shared__ __attribute__((aligned(16))) double GaL[2 * 4 * 256];                    // G tiles of the two intervals
@@ -101,10 +103,10 @@ __global__ __launch_bounds__(kThreads32, 2) void qc_mfma32_pade4_kernel(const Qc
     const double c1 = P.c[1], c2 = P.c[2];
     const double* __restrict__ Gx = P.Gx;
     const v4d IdB = identity_B(g, j);
-    const int n_wg = (P.n_int + 1) / 2;
+    const int n_wg = SINGLE ? P.n_int : (P.n_int + 1) / 2;
 
     for (int vb = blockIdx.x; vb < n_wg; vb += gridDim.x) {
-        const int b_raw = 2 * qc_xcd_remap(vb, n_wg) + slot;
+        const int b_raw = SINGLE ? qc_xcd_remap(vb, n_wg) : 2 * qc_xcd_remap(vb, n_wg) + slot;
         const bool active = b_raw < P.n_int;                  // an odd interval count leaves the last slot empty;
         const int b = active ? b_raw : P.n_int - 1;           // its waves still load images and take part in the barriers
         const long long t = P.t_begin + b;
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(kThreads32, 2) void qc_mfma32_pade4_kernel(const Qc
             }
         }
         const bool dfast = P.n_deriv <= kDF32;
-        const bool deriv_wave = copy_role && sub == 0;        // waves 4 and 6
+        const bool deriv_wave = copy_role && sub == 0 && (!SINGLE || slot == 0);   // waves 4 and 6 (SINGLE: wave 4)
         double* __restrict__ derl = DerL + slot * (2 * kDF32 * 64);
         if (deriv_wave) {   // requested now (before any store of the workgroup), parked in LDS, used after the copies
 #pragma unroll
@@ -214,7 +216,7 @@ __global__ __launch_bounds__(kThreads32, 2) void qc_mfma32_pade4_kernel(const Qc
                 // lane (g, j) reg r = B^T[16I+4r+g][16Jt+j] = B[16Jt+j][16I+4r+g]
                 double* pF = Jb + P.jo_F;
                 double* pB = Jb + P.jo_B;
-                for (int q = 0; q < (KET ? nc : 16); ++q) {
+                for (int q = SINGLE ? slot : 0; q < (KET ? nc : 16); q += SINGLE ? 2 : 1) {   // SINGLE: waves 4, 5 even copies, 6, 7 odd
                     if constexpr (KET) {
                         const size_t o = (size_t)q * nr * nr;
                         store_T32_masked(pF + o, Fm[0], 0, 16 * I, nr, g, j);
@@ -262,7 +264,9 @@ __global__ __launch_bounds__(kThreads32, 2) void qc_mfma32_pade4_kernel(const Qc
             v4d GD[2];
 #pragma unroll
             for (int I = 0; I < 2; ++I) GD[I] = mm16x2(Ga[2 * I], D[0], Ga[2 * I + 1], D[1]);
-            if (sub == 0) {
+            const int csub = SINGLE ? (w & 3) : sub;           // this wave's first drive;  SINGLE: four compute waves per interval
+            constexpr int cstep = SINGLE ? 4 : 2;
+            if (csub == 0) {
                 v4d GS[2], G2D[2];
 #pragma unroll
                 for (int I = 0; I < 2; ++I) {
@@ -286,7 +290,7 @@ __global__ __launch_bounds__(kThreads32, 2) void qc_mfma32_pade4_kernel(const Qc
                 v4d Q0[2];                          // Q_1 = h^2 c2 D is applied as a scale on G (G_k D) below
 #pragma unroll
                 for (int I = 0; I < 2; ++I) Q0[I] = (-hc1) * S[I] + hc2 * GD[I];
-                for (int k = sub; k < m; k += 2) {
+                for (int k = csub; k < m; k += cstep) {
                     v4d Gk[4];
 #pragma unroll
                     for (int tI = 0; tI < 4; ++tI)   // LDS image block for the first kMU32 drives, global memory beyond
@@ -360,6 +364,11 @@ hipError_t qc_launch_mfma32_F_jac(const QcParams& P, const double* dZ, double* d
     const int n_wg = (P.n_int + 1) / 2;
     const int grid = n_wg < kMaxGrid32 ? n_wg : kMaxGrid32;
     const bool diag = P.stamps != nullptr || P.dbg_skip != 0;
+    if (dJ && !diag && P.n_int <= 256) {   // fewer intervals than CUs: one interval per workgroup, all eight waves on it
+        if (P.nc != 16 || P.n != 32) hipLaunchKernelGGL((qc_mfma32_pade4_kernel<true, false, true, true>), dim3(P.n_int), dim3(kThreads32), 0, st, P, dZ, dF, dJ);
+        else hipLaunchKernelGGL((qc_mfma32_pade4_kernel<true, false, false, true>), dim3(P.n_int), dim3(kThreads32), 0, st, P, dZ, dF, dJ);
+        return hipGetLastError();
+    }
     if (P.nc != 16 || P.n != 32) {
         if (dJ) hipLaunchKernelGGL((qc_mfma32_pade4_kernel<true, false, true>), dim3(grid), dim3(kThreads32), 0, st, P, dZ, dF, dJ);
         else hipLaunchKernelGGL((qc_mfma32_pade4_kernel<false, false, true>), dim3(grid), dim3(kThreads32), 0, st, P, dZ, dF, dJ);
