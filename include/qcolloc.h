@@ -46,9 +46,14 @@
  *     after a call returns, except that G_drift/G_drives are copied to the device by qc_create.
  *   - Return value 0 = QC_OK, negative = error; text via qc_last_error (thread-local for
  *     handle-less calls).  Nothing throws or exits across this boundary.
- *   - A handle is bound to ONE HIP device and evaluates the interval range [t_begin, t_end) of the
- *     T-1 intervals (one process per GPU shards the knots).  A handle is not
- *     thread-safe.  Non-finite inputs are evaluated, not rejected (Ipopt probes wild points).
+ *   - A handle from qc_create is bound to ONE HIP device and evaluates the interval range [t_begin, t_end) of the
+ *     T-1 intervals; a handle from qc_create_multi spreads that range over several devices inside this
+ *     library (one process, N GPUs: what a Julia/Ipopt consumer needs).  Every entry
+ *     point selects the handle's device itself and restores the caller's current device before returning.
+ *     A handle is not thread-safe and may have ONE evaluation in flight at a time: several kernels keep
+ *     scratch in the handle (lds-gws, mfma64 Hessian, rollout, batched launches), so a second "_dev"
+ *     call on another stream must be ordered after the first by the caller (different handles are
+ *     independent).  Non-finite inputs are evaluated, not rejected (Ipopt probes wild points).
  *   - "_dev" entry points take DEVICE pointers and a hipStream_t (passed as void*) and are
  *     asynchronous on that stream.  The plain entry points take HOST pointers and return after the
  *     results are in the caller's buffers.
@@ -64,7 +69,7 @@ extern "C" {
 #endif
 
 #define QC_VERSION_MAJOR 0
-#define QC_VERSION_MINOR 1
+#define QC_VERSION_MINOR 2
 
 enum {
     QC_OK = 0,
@@ -84,6 +89,7 @@ enum { QC_PADE = 0, QC_EXPONENTIAL = 1 };
 enum { QC_KERNEL_AUTO = 0, QC_KERNEL_LDS = 1, QC_KERNEL_MFMA = 2 };
 
 #define QC_MAX_DERIV 8
+enum { QC_ROWS_STACKED = 0, QC_ROWS_BY_COMPONENT = 1 };
 
 typedef struct qc_handle qc_handle;
 
@@ -116,7 +122,12 @@ typedef struct qc_desc {
                              * K >= 1 = K kets psi~ = [Re psi; Im psi] stored back to back (2N x K, length 2NK), i.e.
                              * K QuantumStatePadeIntegrators over the same system
                              * (quantum_state_smooth_pulse_problem.jl:146-152).  off_U is the first ket's offset. */
-    int32_t reserved0;
+    int32_t hess_align;     /* The Hessian value block of an interval is padded with explicit zeros to a multiple of this many
+                             * doubles, so that every interval's block starts on a cache-line boundary (partial lines written by two
+                             * workgroups cost 1.1 - 1.4x the HBM write traffic).  0 = default (16 doubles = 128 B),
+                             * 1 = no padding.  The padding entries appear in the structure as duplicates of the interval's first
+                             * structure entry with value 0 (COO duplicates are summed: reference test/test_utils.jl:14-20).
+                             * Ignored for composed handles (hess_per_interval > 0): see hess_tail_zeros. */
     /* Composition (all 0 = this handle is the whole dynamics).  A problem whose integrator list holds several
      * unitary integrators (UnitarySamplingProblem: one per system over a merged trajectory,
      * unitary_sampling_problem.jl:134-155) is served by one handle per unitary integrator; each handle's rows and
@@ -127,6 +138,18 @@ typedef struct qc_desc {
     int64_t jac_offset;
     int64_t hess_per_interval;  /* Hessian values of the whole problem per interval */
     int64_t hess_offset;
+    /* Row placement.  QC_ROWS_STACKED (0): this handle's rows are [state integrator (s) | derivative integrators in
+     * order], starting at row_offset.  QC_ROWS_BY_COMPONENT (1): the state integrator's rows start at row_offset and
+     * derivative integrator i's rows at deriv_row_off[i] inside the per-interval block of rows_per_interval rows (which
+     * must then be given): every integrator's rows sit at its state component's position among the trajectory's state
+     * components, and components WITHOUT an integrator leave structurally empty rows, so that
+     * n_rows == Z.dims.states * (T - 1) as the reference's own harness declares
+     * (test/scripts/integrator_test_script.jl:23-44, integrator_test_1qubit.jl:24-44).  Empty rows are never written by
+     * the "_dev" entry points (zero them once); the host-buffer entry points deliver them as 0. */
+    int32_t row_placement;
+    int32_t hess_tail_zeros;    /* composed handles only: explicit zero entries this handle appends after its own Hessian
+                                 * values (the composer pads the shared per-interval block through its last handle) */
+    int32_t deriv_row_off[QC_MAX_DERIV];
 } qc_desc;
 
 typedef struct qc_dims_t {
@@ -136,9 +159,11 @@ typedef struct qc_dims_t {
     int64_t jac_nnz_interval;
     int64_t hess_nnz_interval;
     int64_t n_intervals;     /* t_end - t_begin, intervals this handle owns */
-    int64_t F_len;           /* ddim * n_intervals          (this handle's slice) */
+    int64_t F_len;           /* rows per interval of the F vector this handle writes into (ddim, or rows_per_interval when
+                              * given) * n_intervals */
     int64_t jac_nnz;         /* jac_nnz_interval * n_intervals */
-    int64_t hess_nnz;        /* hess_nnz_interval * n_intervals (0 if no analytic Hessian) */
+    int64_t hess_nnz;        /* hess_nnz_interval * n_intervals (0 if no analytic Hessian); hess_nnz_interval includes the
+                              * alignment padding (qc_desc.hess_align / hess_tail_zeros) */
     int64_t Z_len;           /* zdim*T + global_dim: length of the Z argument (always the full vector) */
     int32_t kernel;          /* QC_KERNEL_LDS or QC_KERNEL_MFMA actually selected */
     int32_t reserved;
@@ -205,6 +230,46 @@ int qc_eval_hess_dev(qc_handle* h, const double* dZ, const double* dmu, double* 
  * kernels differ are evaluated one launch each, with the same result. */
 int qc_eval_F_jac_dev_multi(qc_handle* const* hs, int32_t count, const double* dZ, double* dF, double* dvals, void* stream);
 int qc_eval_hess_dev_multi(qc_handle* const* hs, int32_t count, const double* dZ, const double* dmu, double* dhvals, void* stream);
+
+/* ---- one handle over several GPUs ("n_gpus, device_ids[]"; 8e) ------------------------------------ */
+/* The reference's consumer is ONE process (Julia + Ipopt, unitary_smooth_pulse_problem.jl:181-190, solve! at :219), so
+ * the knot sharding of SURVEY 8(e) lives behind this boundary: qc_create_multi splits the descriptor's interval range
+ * [t_begin, t_end) into n_shards contiguous chunks of ceil(len / n_shards) intervals (trailing shards may be short or
+ * empty), shard i bound to HIP device device_ids[i] (ordinals may repeat: several shards on one device).  The result
+ * is an ordinary qc_handle: qc_dims / qc_*_structure / qc_eval_F / qc_eval_jac / qc_eval_F_jac / qc_eval_hess /
+ * qc_rollout behave exactly as on a single-device handle over the same range and return bit-identical arrays; every
+ * shard has its own host thread, stream and pinned staging, copies only its knots (+ 1 halo knot) to its device and
+ * writes its contiguous slice of the caller's arrays, so the N PCIe links run in parallel.  There is no collective on
+ * this path (a CPU consumer needs none).  The "_dev" entry points take ONE device's pointers: use them on the shard
+ * handles (qc_multi_shard), or qc_multi_eval_F_jac_dev / qc_multi_all_gather_dev below. */
+int qc_create_multi(const qc_desc* d, int32_t n_shards, const int32_t* device_ids, qc_handle** out);
+/* Number of shards of a multi-device handle (0 for a single-device handle). */
+int32_t qc_multi_count(const qc_handle* h);
+/* Borrowed pointer to shard i's single-device handle (owned by h; NULL if out of range).  Its interval range, device and
+ * sizes are in its qc_dims; its device ordinal via qc_multi_shard_info. */
+qc_handle* qc_multi_shard(qc_handle* h, int32_t i);
+int qc_multi_shard_info(const qc_handle* h, int32_t i, int32_t* device, int64_t* t_begin, int64_t* t_end);
+/* Device-resident evaluation of every shard, each on its own device and internal stream, asynchronous; dZ[i] / dF[i] /
+ * dvals[i] are DEVICE pointers on shard i's device: dZ[i] the full Z vector, dF[i] / dvals[i] FULL-LENGTH vectors of
+ * the multi handle's range (shard i writes its slice at its offset; a chunk-padded length, qc_multi_padded_len, is
+ * needed for the all-gather).  dF or dvals may be NULL.  qc_multi_sync waits for all shards. */
+int qc_multi_eval_F_jac_dev(qc_handle* h, const double* const* dZ, double* const* dF, double* const* dvals);
+int qc_multi_eval_hess_dev(qc_handle* h, const double* const* dZ, const double* const* dmu, double* const* dhvals);
+int qc_multi_sync(qc_handle* h);
+/* RCCL all-gather over xGMI of the per-shard slices (north_star / SURVEY 8e: "ncclAllGather on the per-GPU value
+ * blocks when a device-resident full Jacobian is wanted"): in place on the full-length vectors, bufs[i] on shard i's
+ * device holding that shard's slice at offset i * chunk * per_interval; afterwards every device holds all slices.
+ * per_interval = doubles per interval (jac_nnz_interval, ddim or hess_nnz_interval); every buffer must hold
+ * qc_multi_padded_len(h, per_interval) doubles.  Needs distinct devices (one RCCL rank per device; librccl is loaded
+ * on first use, QC_ERR_UNSUPPORTED when it is absent or devices repeat).  Ordered after the shards' evaluations on their
+ * internal streams; qc_multi_sync waits for it. */
+int64_t qc_multi_padded_len(const qc_handle* h, int64_t per_interval);
+int qc_multi_all_gather_dev(qc_handle* h, double* const* bufs, int64_t per_interval);
+
+/* sizeof of the ABI structs as this build sees them: a binding asserts them against its own mirror at load time. */
+int64_t qc_sizeof_desc(void);
+int64_t qc_sizeof_dims(void);
+int64_t qc_sizeof_terms_desc(void);
 
 /* ---- fidelity of the final knot (SURVEY 8f "next" row 1) -------------------------------------------- */
 /* F(U~) = |tr(U_goal' U)| / n over the subspace block (`iso_vec_unitary_fidelity(U_T, U_G, subspace=...)`,

@@ -86,6 +86,14 @@ class Problem:
     global_dim: int = 0
     ncol: int = 0                # columns of the iso state: 0 -> N (unitary); K -> K kets stored back to back
                                  # (QuantumStatePadeIntegrator per ket, reference quantum_state_smooth_pulse_problem.jl:146-152)
+    hess_align: int = 16         # the per-interval Hessian value block is padded with explicit zeros (structure: duplicates
+                                 # of its first entry) to a multiple of this many entries; 1 = none (qc_desc.hess_align)
+    # Row placement (qc_desc.row_placement = QC_ROWS_BY_COMPONENT): rows_per_interval = Z.dims.states, the state
+    # integrator's rows at row_offset, derivative integrator i's rows at deriv_rows[i]; rows of state components without an
+    # integrator stay structurally empty (reference test/scripts/integrator_test_script.jl:23-44).  None = stacked rows.
+    rows_per_interval: int = 0
+    row_offset: int = 0
+    deriv_rows: List[int] | None = None
 
     @property
     def n(self) -> int:
@@ -112,8 +120,25 @@ class Problem:
         return self.zdim * self.T + self.global_dim
 
     @property
+    def row_stride(self) -> int:
+        """Rows of the F / mu vectors per interval (ddim unless rows_per_interval says otherwise)."""
+        return self.rows_per_interval if self.rows_per_interval > 0 else self.ddim
+
+    @property
+    def row_map(self) -> np.ndarray:
+        """Row inside the per-interval block of each of the ddim stacked rows [state integrator | derivative integrators]."""
+        rm = np.empty(self.ddim, dtype=np.int64)
+        rm[:self.s] = self.row_offset + np.arange(self.s)
+        r = self.s
+        for i, d in enumerate(self.derivs):
+            base = self.deriv_rows[i] if self.deriv_rows is not None else self.row_offset + r
+            rm[r:r + d.dim] = base + np.arange(d.dim)
+            r += d.dim
+        return rm
+
+    @property
     def n_rows(self) -> int:
-        return self.ddim * (self.T - 1)
+        return self.row_stride * (self.T - 1)
 
 
 def pade_coeffs(order: int) -> List[float]:
@@ -414,8 +439,15 @@ def jac_nnz_interval(prob: Problem) -> int:
     return len(jac_structure_local(prob))
 
 
+def hess_pad(prob: Problem) -> int:
+    """Explicit zero entries appended to an interval's Hessian values (alignment of the value blocks)."""
+    k = len(hess_structure_local(prob))
+    a = max(1, prob.hess_align)
+    return (-k) % a if k else 0
+
+
 def hess_nnz_interval(prob: Problem) -> int:
-    return len(hess_structure_local(prob))
+    return len(hess_structure_local(prob)) + hess_pad(prob)
 
 
 def jac_structure(prob: Problem, one_based: bool = False, t_begin: int = 0, t_end: int | None = None):
@@ -423,7 +455,7 @@ def jac_structure(prob: Problem, one_based: bool = False, t_begin: int = 0, t_en
     loc = np.array(jac_structure_local(prob), dtype=np.int64).reshape(-1, 2)
     t_end = prob.T - 1 if t_end is None else t_end
     ts = np.arange(t_begin, t_end, dtype=np.int64)
-    rows = (ts[:, None] * prob.ddim + loc[None, :, 0]).reshape(-1)
+    rows = (ts[:, None] * prob.row_stride + prob.row_map[loc[None, :, 0]]).reshape(-1)
     cols = (ts[:, None] * prob.zdim + loc[None, :, 1]).reshape(-1)
     o = 1 if one_based else 0
     return rows + o, cols + o
@@ -431,6 +463,8 @@ def jac_structure(prob: Problem, one_based: bool = False, t_begin: int = 0, t_en
 
 def hess_structure(prob: Problem, one_based: bool = False, t_begin: int = 0, t_end: int | None = None):
     loc = np.array(hess_structure_local(prob), dtype=np.int64).reshape(-1, 2)
+    if hess_pad(prob):
+        loc = np.concatenate([loc, np.repeat(loc[:1], hess_pad(prob), axis=0)])
     t_end = prob.T - 1 if t_end is None else t_end
     ts = np.arange(t_begin, t_end, dtype=np.int64)
     rows = (ts[:, None] * prob.zdim + loc[None, :, 0]).reshape(-1)
@@ -450,11 +484,12 @@ def _knots(prob: Problem, Z: np.ndarray, t: int):
 
 def F(prob: Problem, Z: np.ndarray, t_begin: int = 0, t_end: int | None = None) -> np.ndarray:
     t_end = prob.T - 1 if t_end is None else t_end
-    out = np.empty((t_end - t_begin) * prob.ddim)
+    out = np.zeros((t_end - t_begin, prob.row_stride))
+    rm = prob.row_map
     for k, t in enumerate(range(t_begin, t_end)):
         z0, z1 = _knots(prob, Z, t)
-        out[k * prob.ddim:(k + 1) * prob.ddim] = interval_residual(prob, z0, z1)
-    return out
+        out[k, rm] = interval_residual(prob, z0, z1)
+    return out.reshape(-1)
 
 
 def dF(prob: Problem, Z: np.ndarray, t_begin: int = 0, t_end: int | None = None) -> np.ndarray:
@@ -473,11 +508,13 @@ def mu_d2F(prob: Problem, Z: np.ndarray, mu: np.ndarray, t_begin: int = 0, t_end
     t_end = prob.T - 1 if t_end is None else t_end
     loc = np.array(hess_structure_local(prob), dtype=np.int64).reshape(-1, 2)
     nnz = loc.shape[0]
-    out = np.empty((t_end - t_begin) * nnz)
+    stride = nnz + hess_pad(prob)
+    out = np.zeros((t_end - t_begin) * stride)
+    rs, rm = prob.row_stride, prob.row_map
     for k, t in enumerate(range(t_begin, t_end)):
         z0, z1 = _knots(prob, Z, t)
-        Hd = interval_hessian_dense(prob, z0, z1, mu[t * prob.ddim:(t + 1) * prob.ddim])
-        out[k * nnz:(k + 1) * nnz] = Hd[loc[:, 0], loc[:, 1]]
+        Hd = interval_hessian_dense(prob, z0, z1, mu[t * rs:(t + 1) * rs][rm])
+        out[k * stride:k * stride + nnz] = Hd[loc[:, 0], loc[:, 1]]
     return out
 
 

@@ -57,7 +57,12 @@ class COracle:
         self.p = p
         self.ddim = self.lib.qco_ddim(C.byref(p))
         self.jac_nnz = self.lib.qco_jac_nnz(C.byref(p))
-        self.hess_nnz = self.lib.qco_hess_nnz(C.byref(p))
+        self.hess_nnz = self.lib.qco_hess_nnz(C.byref(p))      # own values per interval (the C code knows no padding)
+        a = max(1, getattr(prob, "hess_align", 1))
+        self.hess_pad = (-self.hess_nnz) % a if self.hess_nnz else 0
+        self.row_stride = getattr(prob, "row_stride", self.ddim)
+        self.row_map = np.asarray(getattr(prob, "row_map", np.arange(self.ddim)))
+        self._plain_rows = self.row_stride == self.ddim and np.array_equal(self.row_map, np.arange(self.ddim))
 
     def F_dF(self, Z, t_begin=0, t_end=None, want_F=True, want_J=True):
         t_end = self.prob.T - 1 if t_end is None else t_end
@@ -68,14 +73,24 @@ class COracle:
         rc = self.lib.qco_eval_F_jac(C.byref(self.p), Z.ctypes.data_as(_dp), F.ctypes.data_as(_dp) if want_F else None,
                                      J.ctypes.data_as(_dp) if want_J else None, t_begin, t_end, self.threads)
         assert rc == 0, rc
+        if want_F and not self._plain_rows:       # rows at their state component's position (Problem.row_map)
+            Fs = np.zeros((k, self.row_stride))
+            Fs[:, self.row_map] = F.reshape(k, self.ddim)
+            F = Fs.reshape(-1)
         return F, J
 
     def mu_d2F(self, Z, mu, t_begin=0, t_end=None):
         t_end = self.prob.T - 1 if t_end is None else t_end
         Z = np.ascontiguousarray(Z, dtype=np.float64)
         mu = np.ascontiguousarray(mu, dtype=np.float64)
+        if not self._plain_rows:
+            mu = np.ascontiguousarray(mu.reshape(-1, self.row_stride)[:, self.row_map]).reshape(-1)
         H = np.empty((t_end - t_begin) * self.hess_nnz)
         rc = self.lib.qco_eval_hess(C.byref(self.p), Z.ctypes.data_as(_dp), mu.ctypes.data_as(_dp), H.ctypes.data_as(_dp),
                                     t_begin, t_end, self.threads)
         assert rc == 0, rc
+        if self.hess_pad:                          # explicit zeros after each interval's values (Problem.hess_align)
+            Hp = np.zeros((t_end - t_begin, self.hess_nnz + self.hess_pad))
+            Hp[:, :self.hess_nnz] = H.reshape(t_end - t_begin, self.hess_nnz)
+            H = Hp.reshape(-1)
         return H

@@ -34,6 +34,8 @@ QC_MAX_DERIV = 8
 QC_FID_UNITARY, QC_FID_KET, QC_FID_DENSITY = 0, 1, 2
 QC_REG_DT_SCALED = 0
 QC_REG_PLAIN = 1
+QC_ROWS_STACKED = 0
+QC_ROWS_BY_COMPONENT = 1
 
 _c_double_p = C.POINTER(C.c_double)
 _c_int64_p = C.POINTER(C.c_int64)
@@ -63,13 +65,16 @@ class qc_desc(C.Structure):
         ("t_begin", C.c_int64),
         ("t_end", C.c_int64),
         ("state_cols", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("hess_align", C.c_int32),
         ("rows_per_interval", C.c_int64),
         ("row_offset", C.c_int64),
         ("jac_per_interval", C.c_int64),
         ("jac_offset", C.c_int64),
         ("hess_per_interval", C.c_int64),
         ("hess_offset", C.c_int64),
+        ("row_placement", C.c_int32),
+        ("hess_tail_zeros", C.c_int32),
+        ("deriv_row_off", C.c_int32 * QC_MAX_DERIV),
     ]
 
 
@@ -138,6 +143,18 @@ SYMBOLS = {
     "qc_eval_hess_dev": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "qc_eval_F_jac_dev_multi": (C.c_int, [C.POINTER(_H), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "qc_eval_hess_dev_multi": (C.c_int, [C.POINTER(_H), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "qc_create_multi": (C.c_int, [_DESC_P, C.c_int32, C.POINTER(C.c_int32), C.POINTER(_H)]),
+    "qc_multi_count": (C.c_int32, [_H]),
+    "qc_multi_shard": (_H, [_H, C.c_int32]),
+    "qc_multi_shard_info": (C.c_int, [_H, C.c_int32, C.POINTER(C.c_int32), _c_int64_p, _c_int64_p]),
+    "qc_multi_padded_len": (C.c_int64, [_H, C.c_int64]),
+    "qc_multi_eval_F_jac_dev": (C.c_int, [_H, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "qc_multi_eval_hess_dev": (C.c_int, [_H, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "qc_multi_sync": (C.c_int, [_H]),
+    "qc_multi_all_gather_dev": (C.c_int, [_H, C.POINTER(C.c_void_p), C.c_int64]),
+    "qc_sizeof_desc": (C.c_int64, []),
+    "qc_sizeof_dims": (C.c_int64, []),
+    "qc_sizeof_terms_desc": (C.c_int64, []),
     "qc_fidelity_create": (C.c_int, [C.c_int32, _c_double_p, C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.POINTER(_H)]),
     "qc_fidelity_create_kind": (C.c_int, [C.c_int32, C.c_int32, _c_double_p, C.c_int32, C.POINTER(_H)]),
     "qc_fidelity_destroy": (None, [_H]),
@@ -178,6 +195,11 @@ def _load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
+    # the struct mirrors above must be the structs this build of the library was compiled with
+    for name, mirror in (("qc_sizeof_desc", qc_desc), ("qc_sizeof_dims", qc_dims_t), ("qc_sizeof_terms_desc", qc_terms_desc)):
+        if getattr(lib, name)() != C.sizeof(mirror):
+            raise ImportError(f"{LIB_PATH}: {name}() = {getattr(lib, name)()} but the Python mirror has {C.sizeof(mirror)} bytes "
+                              "(stale build? run __graft_entry__.build())")
     return lib
 
 

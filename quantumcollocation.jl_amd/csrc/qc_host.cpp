@@ -20,19 +20,12 @@
 
 static thread_local std::string g_err;
 
-static int fail(std::string* err, int code, const std::string& msg) {
+int qc_fail(std::string* err, int code, const std::string& msg) {
     if (err) *err = msg;
     g_err = msg;
     return code;
 }
-
-#define QC_HIP(h, call)                                                                          \
-    do {                                                                                         \
-        hipError_t e_ = (call);                                                                  \
-        if (e_ != hipSuccess) {                                                                  \
-            return fail(&(h)->err, QC_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
-        }                                                                                        \
-    } while (0)
+#define fail qc_fail
 
 extern "C" const char* qc_version(void) { return "qcolloc-hip 0.1 (gfx950, fp64; kernels: lds, mfma16, mfma32, mfma64, mfma16-exp, mfma32-exp)"; }
 
@@ -102,6 +95,7 @@ int qc_build_params(const qc_desc* d, QcParams* P, qc_dims_t* dims, std::string*
     if (d->state_cols < 0 || d->state_cols > 64) return fail(err, QC_ERR_INVALID, "state_cols must be in 0..64");
     P->nc = d->state_cols > 0 ? d->state_cols : d->N;
     P->s = 2 * d->N * P->nc;
+    P->copies = P->nc;
     P->m = d->m;
     P->zdim = d->zdim;
     P->off_U = d->off_U;
@@ -130,6 +124,10 @@ int qc_build_params(const qc_desc* d, QcParams* P, qc_dims_t* dims, std::string*
     if (d->n_deriv < 0 || d->n_deriv > QC_MAX_DERIV) return fail(err, QC_ERR_INVALID, "n_deriv out of range");
     P->n_deriv = d->n_deriv;
     P->ddim = P->s;
+    if (d->row_placement != QC_ROWS_STACKED && d->row_placement != QC_ROWS_BY_COMPONENT)
+        return fail(err, QC_ERR_INVALID, "unknown row_placement");
+    const bool by_comp = d->row_placement == QC_ROWS_BY_COMPONENT;
+    if (by_comp && d->rows_per_interval <= 0) return fail(err, QC_ERR_INVALID, "QC_ROWS_BY_COMPONENT needs rows_per_interval (Z.dims.states)");
     for (int i = 0; i < d->n_deriv; ++i) {
         const int dim = d->deriv_dim[i], xo = d->deriv_x_off[i], dxo = d->deriv_dx_off[i];
         if (dim < 1 || xo < 0 || dxo < 0 || xo + dim > d->zdim || dxo + dim > d->zdim)
@@ -140,6 +138,18 @@ int qc_build_params(const qc_desc* d, QcParams* P, qc_dims_t* dims, std::string*
         P->x_off[i] = xo;
         P->dx_off[i] = dxo;
         P->ddim_i[i] = dim;
+        if (by_comp) {
+            const long long ro = d->deriv_row_off[i];
+            if (ro < 0 || ro + dim > d->rows_per_interval) return fail(err, QC_ERR_INVALID, "deriv_row_off out of the per-interval row block");
+            if (overlaps((int)ro, (int)ro + dim, (int)d->row_offset, (int)d->row_offset + P->s))
+                return fail(err, QC_ERR_INVALID, "derivative integrator rows overlap the state integrator's rows");
+            for (int k = 0; k < i; ++k)
+                if (overlaps((int)ro, (int)ro + dim, d->deriv_row_off[k], d->deriv_row_off[k] + d->deriv_dim[k]))
+                    return fail(err, QC_ERR_INVALID, "derivative integrator rows overlap each other");
+            P->drow[i] = (int)(ro - d->row_offset);
+        } else {
+            P->drow[i] = P->ddim;
+        }
         P->ddim += dim;
     }
     long long tb = d->t_begin, te = d->t_end;
@@ -181,9 +191,19 @@ int qc_build_params(const qc_desc* d, QcParams* P, qc_dims_t* dims, std::string*
     P->F_off = d->row_offset;
     P->J_stride = d->jac_per_interval > 0 ? d->jac_per_interval : P->jac_nnz;
     P->J_off = d->jac_offset;
-    P->H_stride = d->hess_per_interval > 0 ? d->hess_per_interval : P->hess_nnz;
+    // Line alignment of the per-interval Hessian blocks: explicit zeros after the handle's own values.
+    if (d->hess_align < 0 || d->hess_align > 4096) return fail(err, QC_ERR_INVALID, "hess_align must be in 0..4096");
+    if (d->hess_tail_zeros < 0 || d->hess_tail_zeros > 4096) return fail(err, QC_ERR_INVALID, "hess_tail_zeros must be in 0..4096");
+    if (d->hess_per_interval > 0) {
+        P->h_pad = P->hess_nnz ? d->hess_tail_zeros : 0;
+    } else {
+        const int al = d->hess_align == 0 ? 16 : d->hess_align;
+        P->h_pad = P->hess_nnz ? (al - P->hess_nnz % al) % al : 0;
+    }
+    P->H_stride = d->hess_per_interval > 0 ? d->hess_per_interval : P->hess_nnz + P->h_pad;
     P->H_off = d->hess_offset;
-    if (P->F_off + P->ddim > P->F_stride || P->J_off + P->jac_nnz > P->J_stride || (P->hess_nnz && P->H_off + P->hess_nnz > P->H_stride))
+    const long long own_rows_end = by_comp ? P->F_off + P->s : P->F_off + P->ddim;   // (derivative rows were checked above)
+    if (own_rows_end > P->F_stride || P->J_off + P->jac_nnz > P->J_stride || (P->hess_nnz && P->H_off + P->hess_nnz + P->h_pad > P->H_stride))
         return fail(err, QC_ERR_INVALID, "composition offset + own size exceeds the per-interval block");
 
     if (dims) {
@@ -192,11 +212,11 @@ int qc_build_params(const qc_desc* d, QcParams* P, qc_dims_t* dims, std::string*
         dims->n_cols = (int64_t)d->zdim * d->T + d->global_dim;
         dims->ddim = P->ddim;
         dims->jac_nnz_interval = P->jac_nnz;
-        dims->hess_nnz_interval = P->hess_nnz;
+        dims->hess_nnz_interval = P->hess_nnz + P->h_pad;
         dims->n_intervals = P->n_int;
-        dims->F_len = (int64_t)P->ddim * P->n_int;
+        dims->F_len = (int64_t)P->F_stride * P->n_int;
         dims->jac_nnz = (int64_t)P->jac_nnz * P->n_int;
-        dims->hess_nnz = (int64_t)P->hess_nnz * P->n_int;
+        dims->hess_nnz = (int64_t)(P->hess_nnz + P->h_pad) * P->n_int;
         dims->Z_len = dims->n_cols;
         dims->kernel = 0;
     }
@@ -223,14 +243,12 @@ void qc_local_jac_structure(const QcParams& P, std::vector<int32_t>* R, std::vec
         for (int i = 0; i < s; ++i) { R->push_back(i); C->push_back(P.off_a + j); }
     if (ft)
         for (int i = 0; i < s; ++i) { R->push_back(i); C->push_back(P.off_dt); }
-    int r0 = s;
     for (int d = 0; d < P.n_deriv; ++d) {
-        const int dim = P.ddim_i[d];
+        const int dim = P.ddim_i[d], r0 = P.drow[d];   // relative to the handle's row block (F_off is added by the caller)
         for (int i = 0; i < dim; ++i) { R->push_back(r0 + i); C->push_back(P.x_off[d] + i); }
         for (int i = 0; i < dim; ++i) { R->push_back(r0 + i); C->push_back(zd + P.x_off[d] + i); }
         for (int i = 0; i < dim; ++i) { R->push_back(r0 + i); C->push_back(P.dx_off[d] + i); }
         if (ft) for (int i = 0; i < dim; ++i) { R->push_back(r0 + i); C->push_back(P.off_dt); }
-        r0 += dim;
     }
 }
 
@@ -250,6 +268,8 @@ void qc_local_hess_structure(const QcParams& P, std::vector<int32_t>* R, std::ve
         up(P.off_dt, P.off_dt);
         for (int d = 0; d < P.n_deriv; ++d) for (int i = 0; i < P.ddim_i[d]; ++i) up(P.dx_off[d] + i, P.off_dt);
     }
+    // alignment padding: explicit zeros, recorded as duplicates of the first entry (COO duplicates are summed)
+    for (int i = 0; i < P.h_pad; ++i) { R->push_back((*R)[0]); C->push_back((*C)[0]); }
 }
 
 static void expand_structure(const QcParams& P, const std::vector<int32_t>& lr, const std::vector<int32_t>& lc,
@@ -330,7 +350,8 @@ extern "C" int qc_create(const qc_desc* d, qc_handle** out) {
     if (kernel == QC_KERNEL_AUTO) kernel = mfma_ok ? QC_KERNEL_MFMA : QC_KERNEL_LDS;
     if (kernel == QC_KERNEL_MFMA && !mfma_ok) {
         delete h;
-        return fail(nullptr, QC_ERR_UNSUPPORTED, "qc_create: MFMA kernels need the Pade integrator of order 4 and 2N in {16, 32}");
+        return fail(nullptr, QC_ERR_UNSUPPORTED, "qc_create: no MFMA kernel serves this descriptor (order-4 Pade up to 32 levels, other Pade orders up to 8 levels, "
+                                                   "the exponential integrator up to 16 levels; see qc_desc.kernel)");
     }
     if (kernel != QC_KERNEL_MFMA && kernel != QC_KERNEL_LDS) { delete h; return fail(nullptr, QC_ERR_INVALID, "qc_create: unknown kernel id"); }
     static std::atomic<unsigned long long> next_serial{1};
@@ -341,7 +362,8 @@ extern "C" int qc_create(const qc_desc* d, qc_handle** out) {
     auto bail = [&](int code, const std::string& msg) { std::string m2 = msg; qc_destroy(h); return fail(nullptr, code, m2); };
 #define QC_HIP_C(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return bail(QC_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
 
-    QC_HIP_C(hipSetDevice(h->device));
+    qc_device_guard guard(h->device);
+    QC_HIP_C(guard.err);
     const size_t n2 = (size_t)P.n * P.n;
     std::vector<double> G((size_t)(P.m + 1) * n2);
     memcpy(G.data(), d->G_drift, n2 * sizeof(double));
@@ -411,13 +433,21 @@ extern "C" int qc_create(const qc_desc* d, qc_handle** out) {
 
 extern "C" void qc_destroy(qc_handle* h) {
     if (!h) return;
-    (void)hipSetDevice(h->device);
+    if (!h->shards.empty() || h->fan) {   // multi-device handle: no device state of its own
+        if (h->fan) qc_fanout_destroy(h->fan);
+        if (h->rccl) qc_rccl_destroy(h->rccl);
+        for (qc_handle* sh : h->shards) qc_destroy(sh);
+        delete h;
+        return;
+    }
+    qc_device_guard guard(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     double* bufs[] = {h->dG, h->dGx, h->dZ, h->dF, h->dJ, h->dMu, h->dH, (double*)h->dStamps, h->dRE, h->dRQ, h->dRS, h->dRinit, h->dRout, h->dWs, h->dHs};
     if (h->hJc) (void)hipHostFree(h->hJc);
+    if (h->hFc) (void)hipHostFree(h->hFc);
+    if (h->hZ) (void)hipHostFree(h->hZ);
     if (h->dBatch) (void)hipFree(h->dBatch);
     for (hipEvent_t ev : h->chunk_events) if (ev) (void)hipEventDestroy(ev);
-    if (h->pool) qc_host_pool_destroy(h->pool);
     for (double* b : bufs) if (b) (void)hipFree(b);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -425,9 +455,11 @@ extern "C" void qc_destroy(qc_handle* h) {
 
 extern "C" int qc_debug_read_stamps(qc_handle* h, uint64_t* out, int64_t count) {
     if (!h || !out) return fail(nullptr, QC_ERR_INVALID, "qc_debug_read_stamps: NULL argument");
+    if (!h->shards.empty()) return fail(&h->err, QC_ERR_UNSUPPORTED, "qc_debug_read_stamps: use the shard handles of a multi-device handle");
     if (!h->dStamps) return fail(&h->err, QC_ERR_UNSUPPORTED, "handle was not created with QC_STAMPS=1");
     if (count > (int64_t)h->prm.n_int * 16) count = (int64_t)h->prm.n_int * 16;
-    QC_HIP(h, hipSetDevice(h->device));
+    qc_device_guard guard(h->device);
+    QC_HIP(h, guard.err);
     QC_HIP(h, hipDeviceSynchronize());
     QC_HIP(h, hipMemcpy(out, h->dStamps, (size_t)count * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return QC_OK;
@@ -435,6 +467,7 @@ extern "C" int qc_debug_read_stamps(qc_handle* h, uint64_t* out, int64_t count) 
 
 extern "C" const char* qc_kernel_name(const qc_handle* h, int32_t which) {
     if (!h) return "none";
+    if (!h->shards.empty()) return qc_kernel_name(h->shards[0], which);
     const QcParams& P = h->prm;
     const bool mfma = h->kernel == QC_KERNEL_MFMA;
     if (which == 0) {
@@ -475,364 +508,3 @@ extern "C" int qc_hess_structure(const qc_handle* h, int64_t* rows, int64_t* col
     return QC_OK;
 }
 
-// ------------------------------------------------------------------------------------------------
-//  Device-resident evaluation
-// ------------------------------------------------------------------------------------------------
-static int check_align(qc_handle* h, const void* p, size_t a, const char* what) {
-    if (p && ((uintptr_t)p % a) != 0) return fail(&h->err, QC_ERR_INVALID, std::string(what) + " is not sufficiently aligned");
-    return QC_OK;
-}
-
-extern "C" int qc_eval_F_jac_dev(qc_handle* h, const double* dZ, double* dF, double* dvals, void* stream) {
-    if (!h) return fail(nullptr, QC_ERR_INVALID, "qc_eval_F_jac_dev: NULL handle");
-    if (!dZ || (!dF && !dvals)) return fail(&h->err, QC_ERR_INVALID, "qc_eval_F_jac_dev: NULL buffer");
-    int rc;
-    if ((rc = check_align(h, dZ, 8, "dZ"))) return rc;
-    if ((rc = check_align(h, dF, 8, "dF"))) return rc;
-    if ((rc = check_align(h, dvals, 8, "dvals"))) return rc;
-    if (h->prm.n_int == 0) return QC_OK;
-    hipError_t e;
-    if (h->kernel == QC_KERNEL_MFMA) e = qc_launch_mfma_F_jac(h->prm, dZ, dF, dvals, (hipStream_t)stream);
-    else e = qc_launch_lds_F_jac(h->prm, dZ, dF, dvals, h->lds_bytes_jac, (hipStream_t)stream);
-    if (e != hipSuccess) return fail(&h->err, QC_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
-    return QC_OK;
-}
-
-// ------------------------------------------------------------------------------------------------
-//  Several handles in one launch (the systems of a sampling problem)
-// ------------------------------------------------------------------------------------------------
-// Returns 1 when the handles can share a launch (and hs[0]->dBatch holds their parameter blocks), 0 when not, < 0 on error.
-static int prepare_batch(qc_handle* const* hs, int32_t count, bool hessian) {
-    qc_handle* h0 = hs[0];
-    if (count < 2 || count > 65535) return 0;
-    for (int i = 0; i < count; ++i) {
-        const qc_handle* h = hs[i];
-        if (h->kernel != QC_KERNEL_MFMA || h->device != h0->device || !qc_mfma16_batchable(h->prm)) return 0;
-        if (h->prm.m > 8 && hessian) return 0;
-        if (h->prm.n_int != h0->prm.n_int || h->prm.t_begin != h0->prm.t_begin || h->prm.zdim != h0->prm.zdim || h->prm.m != h0->prm.m ||
-            h->prm.n != h0->prm.n || h->prm.nc != h0->prm.nc)
-            return 0;
-    }
-    bool same = h0->dBatch != nullptr && (int)h0->batch_members.size() == count;
-    for (int i = 0; same && i < count; ++i) same = h0->batch_members[i] == hs[i]->serial;
-    if (same) return 1;
-    QC_HIP(h0, hipSetDevice(h0->device));
-    if (h0->dBatch) { (void)hipFree(h0->dBatch); h0->dBatch = nullptr; }
-    std::vector<QcParams> blocks(count);
-    for (int i = 0; i < count; ++i) blocks[i] = hs[i]->prm;
-    QC_HIP(h0, hipMalloc((void**)&h0->dBatch, sizeof(QcParams) * count));
-    QC_HIP(h0, hipMemcpy(h0->dBatch, blocks.data(), sizeof(QcParams) * count, hipMemcpyHostToDevice));
-    h0->batch_members.clear();
-    for (int i = 0; i < count; ++i) h0->batch_members.push_back(hs[i]->serial);
-    return 1;
-}
-
-extern "C" int qc_eval_F_jac_dev_multi(qc_handle* const* hs, int32_t count, const double* dZ, double* dF, double* dvals, void* stream) {
-    if (!hs || count < 1) return fail(nullptr, QC_ERR_INVALID, "qc_eval_F_jac_dev_multi: no handles");
-    for (int i = 0; i < count; ++i) if (!hs[i]) return fail(nullptr, QC_ERR_INVALID, "qc_eval_F_jac_dev_multi: NULL handle");
-    qc_handle* h0 = hs[0];
-    if (!dZ || (!dF && !dvals)) return fail(&h0->err, QC_ERR_INVALID, "qc_eval_F_jac_dev_multi: NULL buffer");
-    int rc;
-    if ((rc = check_align(h0, dZ, 8, "dZ"))) return rc;
-    if ((rc = check_align(h0, dF, 8, "dF"))) return rc;
-    if ((rc = check_align(h0, dvals, 8, "dvals"))) return rc;
-    const int ok = prepare_batch(hs, count, false);
-    if (ok < 0) return ok;
-    if (ok == 0 || h0->prm.n_int == 0) {   // shapes differ or not the batchable kernel: one launch per handle
-        for (int i = 0; i < count; ++i) if ((rc = qc_eval_F_jac_dev(hs[i], dZ, dF, dvals, stream))) return rc;
-        return QC_OK;
-    }
-    hipError_t e = qc_launch_mfma16_F_jac_batch(h0->prm, h0->dBatch, count, dZ, dF, dvals, (hipStream_t)stream);
-    if (e != hipSuccess) return fail(&h0->err, QC_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
-    return QC_OK;
-}
-
-extern "C" int qc_eval_hess_dev_multi(qc_handle* const* hs, int32_t count, const double* dZ, const double* dmu, double* dhvals, void* stream) {
-    if (!hs || count < 1) return fail(nullptr, QC_ERR_INVALID, "qc_eval_hess_dev_multi: no handles");
-    for (int i = 0; i < count; ++i) if (!hs[i]) return fail(nullptr, QC_ERR_INVALID, "qc_eval_hess_dev_multi: NULL handle");
-    qc_handle* h0 = hs[0];
-    if (!dZ || !dmu || !dhvals) return fail(&h0->err, QC_ERR_INVALID, "qc_eval_hess_dev_multi: NULL buffer");
-    int rc;
-    if ((rc = check_align(h0, dZ, 8, "dZ"))) return rc;
-    if ((rc = check_align(h0, dmu, 8, "dmu"))) return rc;
-    if ((rc = check_align(h0, dhvals, 8, "dhvals"))) return rc;
-    const int ok = prepare_batch(hs, count, true);
-    if (ok < 0) return ok;
-    bool hess_ok = ok == 1 && h0->prm.n_int > 0;
-    for (int i = 0; hess_ok && i < count; ++i) hess_ok = hs[i]->prm.hess_nnz > 0 && qc_mfma_hess_supported(hs[i]->prm);
-    if (!hess_ok) {
-        for (int i = 0; i < count; ++i) if ((rc = qc_eval_hess_dev(hs[i], dZ, dmu, dhvals, stream))) return rc;
-        return QC_OK;
-    }
-    hipError_t e = qc_launch_mfma16_hess_batch(h0->prm, h0->dBatch, count, dZ, dmu, dhvals, (hipStream_t)stream);
-    if (e != hipSuccess) return fail(&h0->err, QC_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
-    return QC_OK;
-}
-
-extern "C" int qc_eval_hess_dev(qc_handle* h, const double* dZ, const double* dmu, double* dhvals, void* stream) {
-    if (!h) return fail(nullptr, QC_ERR_INVALID, "qc_eval_hess_dev: NULL handle");
-    if (h->prm.integrator != QC_PADE)
-        return fail(&h->err, QC_ERR_UNSUPPORTED, "no analytic Hessian for the exponential integrator (upstream has none either; use eval_hessian=false)");
-    if (h->prm.hess_nnz == 0) return QC_OK;   // no drives and a fixed timestep: the constraint is linear
-    if (!dZ || !dmu || !dhvals) return fail(&h->err, QC_ERR_INVALID, "qc_eval_hess_dev: NULL buffer");
-    int rc;
-    if ((rc = check_align(h, dZ, 8, "dZ"))) return rc;
-    if ((rc = check_align(h, dmu, 8, "dmu"))) return rc;
-    if ((rc = check_align(h, dhvals, 8, "dhvals"))) return rc;
-    if (h->prm.n_int == 0) return QC_OK;
-    hipError_t e;
-    if (h->kernel == QC_KERNEL_MFMA && qc_mfma64_hess_supported(h->prm) && !h->dHs) {   // 128 MiB of scratch, first Hessian call only
-        QC_HIP(h, hipSetDevice(h->device));
-        QC_HIP(h, hipMalloc((void**)&h->dHs, qc_mfma64_hess_scratch_doubles(h->prm) * sizeof(double)));
-        h->prm.hs = h->dHs;
-    }
-    if (h->kernel == QC_KERNEL_MFMA && qc_mfma_hess_supported(h->prm))
-        e = qc_launch_mfma_hess(h->prm, dZ, dmu, dhvals, (hipStream_t)stream);
-    else
-        e = qc_launch_lds_hess(h->prm, dZ, dmu, dhvals, h->lds_bytes_hess, (hipStream_t)stream);
-    if (e != hipSuccess) return fail(&h->err, QC_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
-    return QC_OK;
-}
-
-// ------------------------------------------------------------------------------------------------
-//  Host-buffer evaluation (H2D -> kernel -> D2H, synchronous)
-// ------------------------------------------------------------------------------------------------
-static int ensure(qc_handle* h, double** p, size_t count) {
-    if (*p || count == 0) return QC_OK;
-    QC_HIP(h, hipMalloc((void**)p, count * sizeof(double)));
-    return QC_OK;
-}
-
-static bool is_composed(const qc_handle* h) {
-    const QcParams& P = h->prm;
-    return P.F_stride != P.ddim || P.J_stride != P.jac_nnz || (P.hess_nnz && P.H_stride != P.hess_nnz) || P.F_off || P.J_off || P.H_off;
-}
-
-// Compact transfer of the Jacobian values to a host buffer.  Of the 5040 values of a config-3 interval 4096 are the
-// N copies of -F and of B (I_N (x) B): only one copy of each crosses PCIe (3.5x fewer bytes), worker threads
-// replicate it into the caller's array while the next chunk is in flight.  The device-resident entry points are not
-// affected (they always produce the full value vector).  Config 3 on the MI355X host: 0.52 ms per qc_eval_F_jac instead
-// of 0.83 ms (PCIe part 0.22 ms; the rest is the host-side replication of 41.5 MB).  Diagnostics: QC_HOST_COMPACT=0
-// (plain full copy), QC_HOST_THREADS, QC_HOST_CHUNKS.
-struct CompactPlan {
-    bool useful;
-    int n2, head2, tail_src, tail_len, comp_len, copies, second_copies;
-};
-
-static CompactPlan compact_plan(const QcParams& P) {
-    CompactPlan c{};
-    c.n2 = P.n * P.n;
-    c.copies = P.nc;
-    const bool pade = P.integrator == QC_PADE;
-    c.second_copies = pade ? P.nc : 0;            // the exponential integrator's d/dU_{t+1} block is an identity (s entries, no copies)
-    c.head2 = pade ? 2 * c.n2 : c.n2;
-    c.tail_src = pade ? P.jo_a : P.jo_B;
-    c.tail_len = P.jac_nnz - c.tail_src;
-    c.comp_len = c.head2 + c.tail_len;
-    c.useful = P.nc > 1 && P.jo_F == 0 && P.jo_B == P.nc * c.n2 && (!pade || P.jo_a == 2 * P.nc * c.n2);
-    return c;
-}
-
-static inline void copy_block(double* dst, const double* src, size_t n) { memcpy(dst, src, n * sizeof(double)); }   // (non-temporal
-                                                                     // stores were tried here: no gain, and the consumer reads the values next)
-
-static void expand_intervals(const QcParams& P, const CompactPlan& cp, const double* comp, double* vals, int b0, int b1) {
-    for (int b = b0; b < b1; ++b) {
-        const double* src = comp + (size_t)b * cp.comp_len;
-        double* dst = vals + (size_t)b * P.jac_nnz;
-        for (int c = 0; c < cp.copies; ++c) copy_block(dst + P.jo_F + (size_t)c * cp.n2, src, cp.n2);
-        for (int c = 0; c < cp.second_copies; ++c) copy_block(dst + P.jo_B + (size_t)c * cp.n2, src + cp.n2, cp.n2);
-        copy_block(dst + cp.tail_src, src + cp.head2, (size_t)cp.tail_len);
-    }
-}
-
-// Worker pool of a handle: blocked on a condition variable between calls (a thread spinning in hipEventSynchronize
-// per chunk was tried first: on a CPU-quota-limited host the spinning threads starve the copying ones).
-struct qc_host_pool {
-    std::vector<std::thread> th;
-    std::mutex mu;
-    std::condition_variable cv, cv_done;
-    std::vector<std::pair<int, int>> jobs;   // interval ranges ready to expand
-    size_t taken = 0;
-    int outstanding = 0;
-    bool stop = false;
-    const QcParams* P = nullptr;
-    CompactPlan cp{};
-    const double* comp = nullptr;
-    double* vals = nullptr;
-
-    void run() {
-        std::unique_lock<std::mutex> lk(mu);
-        for (;;) {
-            cv.wait(lk, [&] { return stop || taken < jobs.size(); });
-            if (stop) return;
-            const std::pair<int, int> j = jobs[taken++];
-            lk.unlock();
-            expand_intervals(*P, cp, comp, vals, j.first, j.second);
-            lk.lock();
-            if (--outstanding == 0) cv_done.notify_all();
-        }
-    }
-    void start(int n) {
-        for (int i = 0; i < n; ++i) th.emplace_back([this] { run(); });
-    }
-    void push(int b0, int b1) {
-        { std::lock_guard<std::mutex> lk(mu); jobs.emplace_back(b0, b1); ++outstanding; }
-        cv.notify_one();
-    }
-    void wait_all() {
-        std::unique_lock<std::mutex> lk(mu);
-        cv_done.wait(lk, [&] { return outstanding == 0; });
-        jobs.clear();
-        taken = 0;
-    }
-    ~qc_host_pool() {
-        { std::lock_guard<std::mutex> lk(mu); stop = true; }
-        cv.notify_all();
-        for (auto& t : th) t.join();
-    }
-};
-
-void qc_host_pool_destroy(qc_host_pool* p) { delete p; }
-
-static int finish_compact(qc_handle* h, const CompactPlan& cp, double* vals) {
-    const QcParams& P = h->prm;
-    const size_t total = (size_t)P.n_int * cp.comp_len;
-    if (!h->hJc) QC_HIP(h, hipHostMalloc((void**)&h->hJc, total * sizeof(double), hipHostMallocDefault));
-    if (!h->pool) {
-        unsigned hw = std::thread::hardware_concurrency();
-        int workers = (int)std::min<unsigned>(hw ? hw : 4, 8);   // measured best on the MI355X host (16-CPU quota): 8 workers, 16 chunks
-        if (const char* ev = getenv("QC_HOST_THREADS")) workers = std::max(1, std::min(64, atoi(ev)));
-        h->pool = new qc_host_pool();
-        h->pool->start(workers);
-    }
-    qc_host_pool& pool = *h->pool;
-    // The gather kernel writes straight into the pinned host buffer (device-visible), one launch per chunk: a shader
-    // copy moves ~50 GB/s over PCIe here, hipMemcpyAsync into pinned memory (SDMA engine) only 27 GB/s.
-    const int workers = (int)pool.th.size();
-    const int min_chunk = 16;
-    int n_chunks = std::max(1, std::min(2 * workers, (P.n_int + min_chunk - 1) / min_chunk));
-    if (const char* ev = getenv("QC_HOST_CHUNKS")) n_chunks = std::max(1, std::min(P.n_int, atoi(ev)));
-    const int per = (P.n_int + n_chunks - 1) / n_chunks;
-    n_chunks = (P.n_int + per - 1) / per;
-    if ((int)h->chunk_events.size() < n_chunks) {
-        const size_t old = h->chunk_events.size();
-        h->chunk_events.resize(n_chunks, nullptr);
-        for (size_t k = old; k < h->chunk_events.size(); ++k) QC_HIP(h, hipEventCreateWithFlags(&h->chunk_events[k], hipEventDisableTiming));
-    }
-    for (int k = 0; k < n_chunks; ++k) {
-        const int b0 = k * per, b1 = std::min(P.n_int, b0 + per);
-        hipError_t e = qc_launch_pack_jac(h->dJ + (size_t)b0 * P.jac_nnz, h->hJc + (size_t)b0 * cp.comp_len, b1 - b0, P.jac_nnz, cp.comp_len,
-                                          cp.n2, P.jo_F, P.jo_B, cp.head2, cp.tail_src, h->stream);
-        if (e != hipSuccess) return fail(&h->err, QC_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
-        QC_HIP(h, hipEventRecord(h->chunk_events[k], h->stream));
-    }
-    pool.P = &P;
-    pool.cp = cp;
-    pool.comp = h->hJc;
-    pool.vals = vals;
-    int rc_wait = QC_OK;
-    for (int k = 0; k < n_chunks; ++k) {
-        if (hipEventSynchronize(h->chunk_events[k]) != hipSuccess) { rc_wait = QC_ERR_HIP; break; }
-        pool.push(k * per, std::min(P.n_int, (k + 1) * per));
-    }
-    pool.wait_all();
-    QC_HIP(h, hipStreamSynchronize(h->stream));
-    if (rc_wait) return fail(&h->err, QC_ERR_HIP, "hipEventSynchronize failed in the compact transfer");
-    return QC_OK;
-}
-
-static int eval_host(qc_handle* h, const double* Z, double* F, double* vals) {
-    if (!h) return fail(nullptr, QC_ERR_INVALID, "qc_eval: NULL handle");
-    if (is_composed(h)) return fail(&h->err, QC_ERR_UNSUPPORTED, "composed handles write into shared vectors: use the _dev entry points");
-    if (!Z || (!F && !vals)) return fail(&h->err, QC_ERR_INVALID, "qc_eval: NULL buffer");
-    QC_HIP(h, hipSetDevice(h->device));
-    int rc;
-    if ((rc = ensure(h, &h->dZ, (size_t)h->dims.Z_len))) return rc;
-    if (F && (rc = ensure(h, &h->dF, (size_t)h->dims.F_len))) return rc;
-    if (vals && (rc = ensure(h, &h->dJ, (size_t)h->dims.jac_nnz))) return rc;
-    // Only the knots this handle touches need to cross PCIe: [t_begin, t_end] inclusive.
-    const size_t z0 = (size_t)h->prm.t_begin * h->prm.zdim;
-    const size_t zn = (size_t)(h->prm.n_int + 1) * h->prm.zdim;
-    if (h->prm.n_int > 0)
-        QC_HIP(h, hipMemcpyAsync(h->dZ + z0, Z + z0, zn * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    if ((rc = qc_eval_F_jac_dev(h, h->dZ, F ? h->dF : nullptr, vals ? h->dJ : nullptr, h->stream))) return rc;
-    if (F && h->dims.F_len) QC_HIP(h, hipMemcpyAsync(F, h->dF, (size_t)h->dims.F_len * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    if (vals && h->dims.jac_nnz) {
-        const CompactPlan cp = compact_plan(h->prm);
-        if (h->host_compact && cp.useful && h->prm.n_int > 0) return finish_compact(h, cp, vals);
-        QC_HIP(h, hipMemcpyAsync(vals, h->dJ, (size_t)h->dims.jac_nnz * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    }
-    QC_HIP(h, hipStreamSynchronize(h->stream));
-    return QC_OK;
-}
-
-extern "C" int qc_eval_F(qc_handle* h, const double* Z, double* F) { return eval_host(h, Z, F, nullptr); }
-extern "C" int qc_eval_jac(qc_handle* h, const double* Z, double* vals) { return eval_host(h, Z, nullptr, vals); }
-extern "C" int qc_eval_F_jac(qc_handle* h, const double* Z, double* F, double* vals) {
-    if (h && (!F || !vals)) return fail(&h->err, QC_ERR_INVALID, "qc_eval_F_jac: NULL buffer");
-    return eval_host(h, Z, F, vals);
-}
-
-extern "C" int qc_eval_hess(qc_handle* h, const double* Z, const double* mu, double* hvals) {
-    if (!h) return fail(nullptr, QC_ERR_INVALID, "qc_eval_hess: NULL handle");
-    if (h->prm.integrator != QC_PADE)
-        return fail(&h->err, QC_ERR_UNSUPPORTED, "no analytic Hessian for the exponential integrator (upstream has none either; use eval_hessian=false)");
-    if (h->prm.hess_nnz == 0) return QC_OK;   // no drives and a fixed timestep: the constraint is linear
-    if (!Z || !mu || !hvals) return fail(&h->err, QC_ERR_INVALID, "qc_eval_hess: NULL buffer");
-    if (is_composed(h)) return fail(&h->err, QC_ERR_UNSUPPORTED, "composed handles write into shared vectors: use the _dev entry points");
-    QC_HIP(h, hipSetDevice(h->device));
-    int rc;
-    if ((rc = ensure(h, &h->dZ, (size_t)h->dims.Z_len))) return rc;
-    if ((rc = ensure(h, &h->dMu, (size_t)h->dims.n_rows))) return rc;
-    if ((rc = ensure(h, &h->dH, (size_t)h->dims.hess_nnz))) return rc;
-    const size_t z0 = (size_t)h->prm.t_begin * h->prm.zdim;
-    const size_t zn = (size_t)(h->prm.n_int + 1) * h->prm.zdim;
-    const size_t m0 = (size_t)h->prm.t_begin * h->prm.ddim;
-    const size_t mn = (size_t)h->prm.n_int * h->prm.ddim;
-    if (h->prm.n_int > 0) {
-        QC_HIP(h, hipMemcpyAsync(h->dZ + z0, Z + z0, zn * sizeof(double), hipMemcpyHostToDevice, h->stream));
-        QC_HIP(h, hipMemcpyAsync(h->dMu + m0, mu + m0, mn * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    }
-    if ((rc = qc_eval_hess_dev(h, h->dZ, h->dMu, h->dH, h->stream))) return rc;
-    if (h->dims.hess_nnz) QC_HIP(h, hipMemcpyAsync(hvals, h->dH, (size_t)h->dims.hess_nnz * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    QC_HIP(h, hipStreamSynchronize(h->stream));
-    return QC_OK;
-}
-
-// ------------------------------------------------------------------------------------------------
-//  Rollouts
-// ------------------------------------------------------------------------------------------------
-extern "C" int qc_rollout_dev(qc_handle* h, const double* dZ, const double* dinit, double* dout, void* stream) {
-    if (!h) return fail(nullptr, QC_ERR_INVALID, "qc_rollout_dev: NULL handle");
-    if (!dZ || !dinit || !dout) return fail(&h->err, QC_ERR_INVALID, "qc_rollout_dev: NULL buffer");
-    if (!qc_rollout_supported(h->prm)) return fail(&h->err, QC_ERR_UNSUPPORTED, "qc_rollout: state dimension 2N > 64");
-    QC_HIP(h, hipSetDevice(h->device));
-    size_t nE, nQ, nS;
-    int chunk, n_chunks;
-    qc_rollout_scratch(h->prm, h->desc.T, &nE, &nQ, &nS, &chunk, &n_chunks);
-    int rc;
-    if ((rc = ensure(h, &h->dRE, nE))) return rc;
-    if ((rc = ensure(h, &h->dRQ, nQ))) return rc;
-    if ((rc = ensure(h, &h->dRS, nS))) return rc;
-    hipError_t e = qc_launch_rollout(h->prm, h->desc.T, dZ, dinit, dout, h->dRE, h->dRQ, h->dRS, (hipStream_t)stream);
-    if (e != hipSuccess) return fail(&h->err, QC_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
-    return QC_OK;
-}
-
-extern "C" int qc_rollout(qc_handle* h, const double* Z, const double* init, double* out) {
-    if (!h) return fail(nullptr, QC_ERR_INVALID, "qc_rollout: NULL handle");
-    if (!Z || !init || !out) return fail(&h->err, QC_ERR_INVALID, "qc_rollout: NULL buffer");
-    QC_HIP(h, hipSetDevice(h->device));
-    const size_t ns = (size_t)h->prm.n * h->prm.nc, T = (size_t)h->desc.T;
-    int rc;
-    if ((rc = ensure(h, &h->dZ, (size_t)h->dims.Z_len))) return rc;
-    if ((rc = ensure(h, &h->dRinit, ns))) return rc;
-    if ((rc = ensure(h, &h->dRout, ns * T))) return rc;
-    QC_HIP(h, hipMemcpyAsync(h->dZ, Z, (size_t)h->dims.Z_len * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    QC_HIP(h, hipMemcpyAsync(h->dRinit, init, ns * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    if ((rc = qc_rollout_dev(h, h->dZ, h->dRinit, h->dRout, h->stream))) return rc;
-    QC_HIP(h, hipMemcpyAsync(out, h->dRout, ns * T * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    QC_HIP(h, hipStreamSynchronize(h->stream));
-    return QC_OK;
-}

@@ -1,0 +1,791 @@
+// Host side of libqcolloc_hip.so, part 2: the evaluation entry points -- device-resident launches, the host-buffer
+// path (H2D of the knots, kernels, compact D2H with host-side replication), rollouts, and the multi-device handle
+// (one process, N GPUs: per-shard threads / streams / pinned staging, optional in-library RCCL all-gather).
+// Descriptor validation, structures and handle lifetime are in qc_host.cpp.  No CPU evaluation path anywhere.
+#include <dlfcn.h>
+#include <sched.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <utility>
+#include <vector>
+
+#include "qc_internal.h"
+
+#define fail qc_fail
+
+static int check_align(qc_handle* h, const void* p, size_t a, const char* what) {
+    if (p && ((uintptr_t)p % a) != 0) return fail(&h->err, QC_ERR_INVALID, std::string(what) + " is not sufficiently aligned");
+    return QC_OK;
+}
+
+static bool is_multi(const qc_handle* h) { return !h->shards.empty(); }
+
+#define QC_NOT_MULTI(h, name)                                                                                        \
+    do {                                                                                                             \
+        if (is_multi(h))                                                                                             \
+            return fail(&(h)->err, QC_ERR_INVALID, std::string(name) + ": a multi-device handle has no single device; " \
+                        "use its shard handles (qc_multi_shard) or the qc_multi_* entry points");                     \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+//  Device-resident evaluation
+// ------------------------------------------------------------------------------------------------
+extern "C" int qc_eval_F_jac_dev(qc_handle* h, const double* dZ, double* dF, double* dvals, void* stream) {
+    if (!h) return fail(nullptr, QC_ERR_INVALID, "qc_eval_F_jac_dev: NULL handle");
+    QC_NOT_MULTI(h, "qc_eval_F_jac_dev");
+    if (!dZ || (!dF && !dvals)) return fail(&h->err, QC_ERR_INVALID, "qc_eval_F_jac_dev: NULL buffer");
+    int rc;
+    if ((rc = check_align(h, dZ, 8, "dZ"))) return rc;
+    if ((rc = check_align(h, dF, 8, "dF"))) return rc;
+    if ((rc = check_align(h, dvals, 8, "dvals"))) return rc;
+    if (h->prm.n_int == 0) return QC_OK;
+    qc_device_guard guard(h->device);
+    QC_HIP(h, guard.err);
+    hipError_t e;
+    if (h->kernel == QC_KERNEL_MFMA) e = qc_launch_mfma_F_jac(h->prm, dZ, dF, dvals, (hipStream_t)stream);
+    else e = qc_launch_lds_F_jac(h->prm, dZ, dF, dvals, h->lds_bytes_jac, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(&h->err, QC_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    return QC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+//  Several handles in one launch (the systems of a sampling problem)
+// ------------------------------------------------------------------------------------------------
+// Returns 1 when the handles can share a launch (and hs[0]->dBatch holds their parameter blocks), 0 when not, < 0 on error.
+static int prepare_batch(qc_handle* const* hs, int32_t count, bool hessian) {
+    qc_handle* h0 = hs[0];
+    for (int i = 0; i < count; ++i) {
+        if (is_multi(hs[i])) return fail(&h0->err, QC_ERR_INVALID, "batched launch: multi-device handles are not accepted");
+        if (hs[i]->device != h0->device) return fail(&h0->err, QC_ERR_INVALID, "batched launch: the handles are bound to different devices");
+    }
+    if (count < 2 || count > 65535) return 0;
+    for (int i = 0; i < count; ++i) {
+        const qc_handle* h = hs[i];
+        if (h->kernel != QC_KERNEL_MFMA || !qc_mfma16_batchable(h->prm)) return 0;
+        if (h->prm.m > 8 && hessian) return 0;
+        if (h->prm.n_int != h0->prm.n_int || h->prm.t_begin != h0->prm.t_begin || h->prm.zdim != h0->prm.zdim || h->prm.m != h0->prm.m ||
+            h->prm.n != h0->prm.n || h->prm.nc != h0->prm.nc)
+            return 0;
+    }
+    bool same = h0->dBatch != nullptr && (int)h0->batch_members.size() == count;
+    for (int i = 0; same && i < count; ++i) same = h0->batch_members[i] == hs[i]->serial;
+    if (same) return 1;
+    qc_device_guard guard(h0->device);
+    QC_HIP(h0, guard.err);
+    if (h0->dBatch) { (void)hipFree(h0->dBatch); h0->dBatch = nullptr; }
+    std::vector<QcParams> blocks(count);
+    for (int i = 0; i < count; ++i) blocks[i] = hs[i]->prm;
+    QC_HIP(h0, hipMalloc((void**)&h0->dBatch, sizeof(QcParams) * count));
+    QC_HIP(h0, hipMemcpy(h0->dBatch, blocks.data(), sizeof(QcParams) * count, hipMemcpyHostToDevice));
+    h0->batch_members.clear();
+    for (int i = 0; i < count; ++i) h0->batch_members.push_back(hs[i]->serial);
+    return 1;
+}
+
+extern "C" int qc_eval_F_jac_dev_multi(qc_handle* const* hs, int32_t count, const double* dZ, double* dF, double* dvals, void* stream) {
+    if (!hs || count < 1) return fail(nullptr, QC_ERR_INVALID, "qc_eval_F_jac_dev_multi: no handles");
+    for (int i = 0; i < count; ++i) if (!hs[i]) return fail(nullptr, QC_ERR_INVALID, "qc_eval_F_jac_dev_multi: NULL handle");
+    qc_handle* h0 = hs[0];
+    if (!dZ || (!dF && !dvals)) return fail(&h0->err, QC_ERR_INVALID, "qc_eval_F_jac_dev_multi: NULL buffer");
+    int rc;
+    if ((rc = check_align(h0, dZ, 8, "dZ"))) return rc;
+    if ((rc = check_align(h0, dF, 8, "dF"))) return rc;
+    if ((rc = check_align(h0, dvals, 8, "dvals"))) return rc;
+    const int ok = prepare_batch(hs, count, false);
+    if (ok < 0) return ok;
+    if (ok == 0 || h0->prm.n_int == 0) {   // shapes differ or not the batchable kernel: one launch per handle
+        for (int i = 0; i < count; ++i) if ((rc = qc_eval_F_jac_dev(hs[i], dZ, dF, dvals, stream))) return rc;
+        return QC_OK;
+    }
+    qc_device_guard guard(h0->device);
+    QC_HIP(h0, guard.err);
+    hipError_t e = qc_launch_mfma16_F_jac_batch(h0->prm, h0->dBatch, count, dZ, dF, dvals, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(&h0->err, QC_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    return QC_OK;
+}
+
+extern "C" int qc_eval_hess_dev_multi(qc_handle* const* hs, int32_t count, const double* dZ, const double* dmu, double* dhvals, void* stream) {
+    if (!hs || count < 1) return fail(nullptr, QC_ERR_INVALID, "qc_eval_hess_dev_multi: no handles");
+    for (int i = 0; i < count; ++i) if (!hs[i]) return fail(nullptr, QC_ERR_INVALID, "qc_eval_hess_dev_multi: NULL handle");
+    qc_handle* h0 = hs[0];
+    if (!dZ || !dmu || !dhvals) return fail(&h0->err, QC_ERR_INVALID, "qc_eval_hess_dev_multi: NULL buffer");
+    int rc;
+    if ((rc = check_align(h0, dZ, 8, "dZ"))) return rc;
+    if ((rc = check_align(h0, dmu, 8, "dmu"))) return rc;
+    if ((rc = check_align(h0, dhvals, 8, "dhvals"))) return rc;
+    const int ok = prepare_batch(hs, count, true);
+    if (ok < 0) return ok;
+    bool hess_ok = ok == 1 && h0->prm.n_int > 0;
+    for (int i = 0; hess_ok && i < count; ++i) hess_ok = hs[i]->prm.hess_nnz > 0 && qc_mfma_hess_supported(hs[i]->prm);
+    if (!hess_ok) {
+        for (int i = 0; i < count; ++i) if ((rc = qc_eval_hess_dev(hs[i], dZ, dmu, dhvals, stream))) return rc;
+        return QC_OK;
+    }
+    qc_device_guard guard(h0->device);
+    QC_HIP(h0, guard.err);
+    hipError_t e = qc_launch_mfma16_hess_batch(h0->prm, h0->dBatch, count, dZ, dmu, dhvals, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(&h0->err, QC_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    return QC_OK;
+}
+
+extern "C" int qc_eval_hess_dev(qc_handle* h, const double* dZ, const double* dmu, double* dhvals, void* stream) {
+    if (!h) return fail(nullptr, QC_ERR_INVALID, "qc_eval_hess_dev: NULL handle");
+    QC_NOT_MULTI(h, "qc_eval_hess_dev");
+    if (h->prm.integrator != QC_PADE)
+        return fail(&h->err, QC_ERR_UNSUPPORTED, "no analytic Hessian for the exponential integrator (upstream has none either; use eval_hessian=false)");
+    if (h->prm.hess_nnz == 0) return QC_OK;   // no drives and a fixed timestep: the constraint is linear
+    if (!dZ || !dmu || !dhvals) return fail(&h->err, QC_ERR_INVALID, "qc_eval_hess_dev: NULL buffer");
+    int rc;
+    if ((rc = check_align(h, dZ, 8, "dZ"))) return rc;
+    if ((rc = check_align(h, dmu, 8, "dmu"))) return rc;
+    if ((rc = check_align(h, dhvals, 8, "dhvals"))) return rc;
+    if (h->prm.n_int == 0) return QC_OK;
+    qc_device_guard guard(h->device);
+    QC_HIP(h, guard.err);
+    hipError_t e;
+    if (h->kernel == QC_KERNEL_MFMA && qc_mfma64_hess_supported(h->prm) && !h->dHs) {   // 128 MiB of scratch, first Hessian call only
+        QC_HIP(h, hipMalloc((void**)&h->dHs, qc_mfma64_hess_scratch_doubles(h->prm) * sizeof(double)));
+        h->prm.hs = h->dHs;
+    }
+    if (h->kernel == QC_KERNEL_MFMA && qc_mfma_hess_supported(h->prm))
+        e = qc_launch_mfma_hess(h->prm, dZ, dmu, dhvals, (hipStream_t)stream);
+    else
+        e = qc_launch_lds_hess(h->prm, dZ, dmu, dhvals, h->lds_bytes_hess, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(&h->err, QC_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    return QC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+//  Host-buffer evaluation (H2D -> kernel -> D2H, synchronous)
+// ------------------------------------------------------------------------------------------------
+static int ensure(qc_handle* h, double** p, size_t count) {
+    if (*p || count == 0) return QC_OK;
+    QC_HIP(h, hipMalloc((void**)p, count * sizeof(double)));
+    return QC_OK;
+}
+static int ensure_zeroed(qc_handle* h, double** p, size_t count) {   // rows no kernel writes (QC_ROWS_BY_COMPONENT) stay 0
+    if (*p || count == 0) return QC_OK;
+    QC_HIP(h, hipMalloc((void**)p, count * sizeof(double)));
+    QC_HIP(h, hipMemset(*p, 0, count * sizeof(double)));
+    return QC_OK;
+}
+static int ensure_pinned(qc_handle* h, double** p, size_t count, bool zero) {
+    if (*p || count == 0) return QC_OK;
+    QC_HIP(h, hipHostMalloc((void**)p, count * sizeof(double), hipHostMallocDefault));
+    if (zero) memset(*p, 0, count * sizeof(double));
+    return QC_OK;
+}
+
+// A handle whose VALUE vectors are shared with other handles (the integrator groups of a sampling problem) cannot use the
+// host-buffer entry points; a handle that only places its rows inside a wider row block (QC_ROWS_BY_COMPONENT) can.
+static bool shares_values(const qc_handle* h) {
+    const QcParams& P = h->prm;
+    return P.J_stride != P.jac_nnz || (P.hess_nnz && P.H_stride != P.hess_nnz + P.h_pad) || P.J_off || P.H_off ||
+           (h->desc.row_placement == QC_ROWS_STACKED && (P.F_stride != P.ddim || P.F_off));
+}
+
+// Compact transfer of the Jacobian values to a host buffer.  Of the 5040 values of a config-3 interval 4096 are the
+// N copies of -F and of B (I_N (x) B): only one copy of each crosses PCIe (3.5x fewer bytes), worker threads
+// replicate it into the caller's array while the next chunk is in flight.  The device-resident entry points are not
+// affected (they always produce the full value vector).  Two forms:
+//   direct  the order-4 MFMA kernels (2N = 16 and 32: BASELINE configs 1-5) write the compact form -- and the residuals --
+//           STRAIGHT into pinned host memory, one launch per chunk of intervals (QcParams.copies = 1): no full-size value
+//           vector in HBM, no gather kernels;
+//   packed  every other kernel writes the full vector to HBM and qc_pack_jac_kernel gathers the compact form chunk by chunk.
+// Diagnostics: QC_HOST_COMPACT=0 (plain full copy), =2 (packed form even where direct is available), QC_HOST_THREADS,
+// QC_HOST_CHUNKS.
+struct CompactPlan {
+    bool useful;
+    int n2, head2, tail_src, tail_len, comp_len, copies, second_copies;
+};
+
+static CompactPlan compact_plan(const QcParams& P) {
+    CompactPlan c{};
+    c.n2 = P.n * P.n;
+    c.copies = P.nc;
+    const bool pade = P.integrator == QC_PADE;
+    c.second_copies = pade ? P.nc : 0;            // the exponential integrator's d/dU_{t+1} block is an identity (s entries, no copies)
+    c.head2 = pade ? 2 * c.n2 : c.n2;
+    c.tail_src = pade ? P.jo_a : P.jo_B;
+    c.tail_len = P.jac_nnz - c.tail_src;
+    c.comp_len = c.head2 + c.tail_len;
+    c.useful = P.nc > 1 && P.jo_F == 0 && P.jo_B == P.nc * c.n2 && (!pade || P.jo_a == 2 * P.nc * c.n2);
+    return c;
+}
+
+static void expand_intervals(const QcParams& P, const CompactPlan& cp, const double* comp, double* vals, int b0, int b1) {
+    for (int b = b0; b < b1; ++b) {
+        const double* src = comp + (size_t)b * cp.comp_len;
+        double* dst = vals + (size_t)b * P.jac_nnz;
+        for (int c = 0; c < cp.copies; ++c) memcpy(dst + P.jo_F + (size_t)c * cp.n2, src, (size_t)cp.n2 * sizeof(double));
+        for (int c = 0; c < cp.second_copies; ++c) memcpy(dst + P.jo_B + (size_t)c * cp.n2, src + cp.n2, (size_t)cp.n2 * sizeof(double));
+        memcpy(dst + cp.tail_src, src + cp.head2, (size_t)cp.tail_len * sizeof(double));
+    }
+}
+
+static int usable_cores() {
+    int n = (int)std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {   // cgroup v2 CPU quota ("max" or "<quota> <period>")
+        long long q = 0, per = 0;
+        if (fscanf(f, "%lld %lld", &q, &per) == 2 && q > 0 && per > 0) n = std::min<long long>(n, std::max<long long>(1, q / per));
+        fclose(f);
+    }
+    return std::max(1, n);
+}
+
+// Process-wide pool of replication workers, shared by every handle (the shards of a multi-device handle push into it
+// concurrently).  Workers block on a condition variable between jobs (threads spinning in hipEventSynchronize per chunk
+// were tried first: on a CPU-quota-limited host they starve the copying ones).
+namespace {
+struct HostGroup {   // completion of one call's jobs
+    std::mutex mu;
+    std::condition_variable cv;
+    int outstanding = 0;
+    void add() { std::lock_guard<std::mutex> lk(mu); ++outstanding; }
+    void done() { std::lock_guard<std::mutex> lk(mu); if (--outstanding == 0) cv.notify_all(); }
+    void wait() { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return outstanding == 0; }); }
+};
+struct HostPool {
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::pair<std::function<void()>, HostGroup*>> q;
+    bool stop = false;
+    void run() {
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv.wait(lk, [&] { return stop || !q.empty(); });
+            if (stop) return;
+            auto job = std::move(q.front());
+            q.pop_front();
+            lk.unlock();
+            job.first();
+            job.second->done();
+            lk.lock();
+        }
+    }
+    void ensure(int n) {
+        std::lock_guard<std::mutex> lk(mu);
+        while ((int)th.size() < n) th.emplace_back([this] { run(); });
+    }
+    void push(std::function<void()> fn, HostGroup* g) {
+        g->add();
+        { std::lock_guard<std::mutex> lk(mu); q.emplace_back(std::move(fn), g); }
+        cv.notify_one();
+    }
+    ~HostPool() {
+        { std::lock_guard<std::mutex> lk(mu); stop = true; }
+        cv.notify_all();
+        for (auto& t : th) t.join();
+    }
+};
+HostPool& host_pool() {
+    static HostPool* p = new HostPool();   // intentionally leaked: worker threads must not be joined from a static destructor
+    return *p;
+}
+int pool_workers(int shards) {
+    static const int cores = usable_cores();
+    int w = std::min(cores, shards > 1 ? 16 : 8);   // measured best on the MI355X host (16-CPU quota): 8 workers, 16 chunks per handle
+    if (const char* ev = getenv("QC_HOST_THREADS")) w = std::max(1, std::min(64, atoi(ev)));
+    return std::max(1, w);
+}
+}  // namespace
+
+static int chunk_count(const qc_handle* h, int n_int, int workers) {
+    const int min_chunk = 16;
+    int n_chunks = std::max(1, std::min(2 * workers, (n_int + min_chunk - 1) / min_chunk));
+    if (const char* ev = getenv("QC_HOST_CHUNKS")) n_chunks = std::max(1, std::min(n_int, atoi(ev)));
+    (void)h;
+    return n_chunks;
+}
+
+static int ensure_events(qc_handle* h, int n) {
+    if ((int)h->chunk_events.size() < n) {
+        const size_t old = h->chunk_events.size();
+        h->chunk_events.resize(n, nullptr);
+        for (size_t k = old; k < h->chunk_events.size(); ++k) QC_HIP(h, hipEventCreateWithFlags(&h->chunk_events[k], hipEventDisableTiming));
+    }
+    return QC_OK;
+}
+
+// Parameters of the compact value layout [ -F (n2) | B (n2) | drive columns ... ] with ONE copy of the replicated blocks,
+// for the kernels that can write it themselves (QcParams.copies).
+static QcParams compact_params(const QcParams& P, const CompactPlan& cp) {
+    QcParams C = P;
+    const int shift = cp.head2 - cp.tail_src;   // every block behind the replicated ones moves up
+    C.copies = 1;
+    C.jo_F = 0;
+    C.jo_B = cp.n2;
+    C.jo_a = P.jo_a + shift;
+    C.jo_h = P.jo_h + shift;
+    C.jo_d = P.jo_d + shift;
+    C.jac_nnz = cp.comp_len;
+    C.J_stride = cp.comp_len;
+    C.J_off = 0;
+    return C;
+}
+
+// Chunked tail of a host evaluation: `produce(k, b0, b1)` enqueues the work that makes chunk k's compact values (and
+// residuals) appear in the pinned buffers; the worker pool expands each chunk into the caller's arrays as it lands.
+static int run_chunks(qc_handle* h, const CompactPlan& cp, double* F, double* vals, int shards,
+                      const std::function<int(int, int, int)>& produce) {
+    const QcParams& P = h->prm;
+    HostPool& pool = host_pool();
+    const int workers = pool_workers(shards);
+    pool.ensure(workers);
+    int n_chunks = chunk_count(h, P.n_int, workers);
+    const int per = (P.n_int + n_chunks - 1) / n_chunks;
+    n_chunks = (P.n_int + per - 1) / per;
+    int rc;
+    if ((rc = ensure_events(h, n_chunks))) return rc;
+    for (int k = 0; k < n_chunks; ++k) {
+        const int b0 = k * per, b1 = std::min(P.n_int, b0 + per);
+        if ((rc = produce(k, b0, b1))) return rc;
+        QC_HIP(h, hipEventRecord(h->chunk_events[k], h->stream));
+    }
+    HostGroup grp;
+    int rc_wait = QC_OK;
+    const double* comp = h->hJc;
+    const double* hF = F ? h->hFc : nullptr;
+    const QcParams* Pp = &P;
+    for (int k = 0; k < n_chunks; ++k) {
+        if (hipEventSynchronize(h->chunk_events[k]) != hipSuccess) { rc_wait = QC_ERR_HIP; break; }
+        const int b0 = k * per, b1 = std::min(P.n_int, b0 + per);
+        pool.push([=] {
+            if (vals) expand_intervals(*Pp, cp, comp, vals, b0, b1);
+            if (hF) memcpy(F + (size_t)b0 * Pp->F_stride, hF + (size_t)b0 * Pp->F_stride, (size_t)(b1 - b0) * Pp->F_stride * sizeof(double));
+        }, &grp);
+    }
+    grp.wait();
+    QC_HIP(h, hipStreamSynchronize(h->stream));
+    if (rc_wait) return fail(&h->err, QC_ERR_HIP, "hipEventSynchronize failed in the compact transfer");
+    return QC_OK;
+}
+
+static int eval_host(qc_handle* h, const double* Z, double* F, double* vals, int shards) {
+    if (shares_values(h)) return fail(&h->err, QC_ERR_UNSUPPORTED, "composed handles write into shared vectors: use the _dev entry points");
+    if (!Z || (!F && !vals)) return fail(&h->err, QC_ERR_INVALID, "qc_eval: NULL buffer");
+    const QcParams& P = h->prm;
+    if (P.n_int == 0) return QC_OK;
+    qc_device_guard guard(h->device);
+    QC_HIP(h, guard.err);
+    int rc;
+    if ((rc = ensure(h, &h->dZ, (size_t)h->dims.Z_len))) return rc;
+    // Only the knots this handle touches cross PCIe: [t_begin, t_end] inclusive, through a pinned staging buffer (an
+    // asynchronous copy from pageable memory is staged by the runtime in small pieces and blocks the calling thread).
+    const size_t z0 = (size_t)P.t_begin * P.zdim;
+    const size_t zn = (size_t)(P.n_int + 1) * P.zdim;
+    if ((rc = ensure_pinned(h, &h->hZ, zn, false))) return rc;
+    memcpy(h->hZ, Z + z0, zn * sizeof(double));
+    QC_HIP(h, hipMemcpyAsync(h->dZ + z0, h->hZ, zn * sizeof(double), hipMemcpyHostToDevice, h->stream));
+
+    const CompactPlan cp = compact_plan(P);
+    const bool compact = vals && h->host_compact && cp.useful;
+    const bool direct = compact && h->host_compact != 2 && h->kernel == QC_KERNEL_MFMA && qc_mfma_compact_supported(P);
+    if (direct) {
+        // the kernel writes residuals and compact values straight into pinned host memory, one launch per chunk
+        if ((rc = ensure_pinned(h, &h->hJc, (size_t)P.n_int * cp.comp_len, false))) return rc;
+        if (F && (rc = ensure_pinned(h, &h->hFc, (size_t)h->dims.F_len, true))) return rc;
+        const QcParams C = compact_params(P, cp);
+        return run_chunks(h, cp, F, vals, shards, [&](int, int b0, int b1) -> int {
+            QcParams Ck = C;
+            Ck.t_begin = C.t_begin + b0;
+            Ck.n_int = b1 - b0;
+            hipError_t e = qc_launch_mfma_F_jac(Ck, h->dZ, F ? h->hFc + (size_t)b0 * C.F_stride : nullptr, h->hJc + (size_t)b0 * cp.comp_len, h->stream);
+            if (e != hipSuccess) return fail(&h->err, QC_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+            return QC_OK;
+        });
+    }
+    if (F && (rc = ensure_zeroed(h, &h->dF, (size_t)h->dims.F_len))) return rc;
+    if (vals && (rc = ensure(h, &h->dJ, (size_t)h->dims.jac_nnz))) return rc;
+    if ((rc = qc_eval_F_jac_dev(h, h->dZ, F ? h->dF : nullptr, vals ? h->dJ : nullptr, h->stream))) return rc;
+    if (F && h->dims.F_len) QC_HIP(h, hipMemcpyAsync(F, h->dF, (size_t)h->dims.F_len * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (compact) {
+        // gather kernels write the compact form into the pinned host buffer (device-visible), one launch per chunk: a shader
+        // copy moves ~50 GB/s over PCIe here, hipMemcpyAsync into pinned memory (SDMA engine) only 27 GB/s
+        if ((rc = ensure_pinned(h, &h->hJc, (size_t)P.n_int * cp.comp_len, false))) return rc;
+        return run_chunks(h, cp, nullptr, vals, shards, [&](int, int b0, int b1) -> int {
+            hipError_t e = qc_launch_pack_jac(h->dJ + (size_t)b0 * P.jac_nnz, h->hJc + (size_t)b0 * cp.comp_len, b1 - b0, P.jac_nnz, cp.comp_len,
+                                              cp.n2, P.jo_F, P.jo_B, cp.head2, cp.tail_src, h->stream);
+            if (e != hipSuccess) return fail(&h->err, QC_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+            return QC_OK;
+        });
+    }
+    if (vals && h->dims.jac_nnz)
+        QC_HIP(h, hipMemcpyAsync(vals, h->dJ, (size_t)h->dims.jac_nnz * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    QC_HIP(h, hipStreamSynchronize(h->stream));
+    return QC_OK;
+}
+
+static int hess_host(qc_handle* h, const double* Z, const double* mu, double* hvals) {
+    if (h->prm.integrator != QC_PADE)
+        return fail(&h->err, QC_ERR_UNSUPPORTED, "no analytic Hessian for the exponential integrator (upstream has none either; use eval_hessian=false)");
+    if (h->prm.hess_nnz == 0) return QC_OK;   // no drives and a fixed timestep: the constraint is linear
+    if (!Z || !mu || !hvals) return fail(&h->err, QC_ERR_INVALID, "qc_eval_hess: NULL buffer");
+    if (shares_values(h)) return fail(&h->err, QC_ERR_UNSUPPORTED, "composed handles write into shared vectors: use the _dev entry points");
+    const QcParams& P = h->prm;
+    if (P.n_int == 0) return QC_OK;
+    qc_device_guard guard(h->device);
+    QC_HIP(h, guard.err);
+    int rc;
+    if ((rc = ensure(h, &h->dZ, (size_t)h->dims.Z_len))) return rc;
+    if ((rc = ensure(h, &h->dMu, (size_t)h->dims.n_rows))) return rc;
+    if ((rc = ensure(h, &h->dH, (size_t)h->dims.hess_nnz))) return rc;
+    const size_t z0 = (size_t)P.t_begin * P.zdim;
+    const size_t zn = (size_t)(P.n_int + 1) * P.zdim;
+    const size_t m0 = (size_t)P.t_begin * P.F_stride;
+    const size_t mn = (size_t)P.n_int * P.F_stride;
+    QC_HIP(h, hipMemcpyAsync(h->dZ + z0, Z + z0, zn * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    QC_HIP(h, hipMemcpyAsync(h->dMu + m0, mu + m0, mn * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if ((rc = qc_eval_hess_dev(h, h->dZ, h->dMu, h->dH, h->stream))) return rc;
+    QC_HIP(h, hipMemcpyAsync(hvals, h->dH, (size_t)h->dims.hess_nnz * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    QC_HIP(h, hipStreamSynchronize(h->stream));
+    return QC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+//  Multi-device handle: one worker thread per shard, each driving its own device / stream / pinned staging
+// ------------------------------------------------------------------------------------------------
+struct qc_fanout {
+    struct Worker {
+        std::thread th;
+        std::mutex mu;
+        std::condition_variable cv;
+        std::function<int()> task;
+        bool has = false, done = true, stop = false;
+        int rc = 0;
+        void loop() {
+            std::unique_lock<std::mutex> lk(mu);
+            for (;;) {
+                cv.wait(lk, [&] { return stop || has; });
+                if (stop) return;
+                has = false;
+                lk.unlock();
+                const int r = task();
+                lk.lock();
+                rc = r;
+                done = true;
+                cv.notify_all();
+            }
+        }
+    };
+    std::vector<std::unique_ptr<Worker>> w;
+    explicit qc_fanout(int n) {
+        for (int i = 0; i < n; ++i) {
+            w.emplace_back(new Worker());
+            Worker* p = w.back().get();
+            p->th = std::thread([p] { p->loop(); });
+        }
+    }
+    // runs task(i) for every shard concurrently; returns the first non-zero status (by shard order)
+    int run(const std::function<int(int)>& task) {
+        for (size_t i = 0; i < w.size(); ++i) {
+            Worker* p = w[i].get();
+            std::lock_guard<std::mutex> lk(p->mu);
+            p->task = [&task, i] { return task((int)i); };
+            p->has = true;
+            p->done = false;
+            p->cv.notify_all();
+        }
+        int rc = 0;
+        for (auto& up : w) {
+            Worker* p = up.get();
+            std::unique_lock<std::mutex> lk(p->mu);
+            p->cv.wait(lk, [&] { return p->done; });
+            if (!rc && p->rc) rc = p->rc;
+        }
+        return rc;
+    }
+    ~qc_fanout() {
+        for (auto& up : w) {
+            { std::lock_guard<std::mutex> lk(up->mu); up->stop = true; }
+            up->cv.notify_all();
+            up->th.join();
+        }
+    }
+};
+void qc_fanout_destroy(qc_fanout* f) { delete f; }
+
+static int multi_run(qc_handle* h, const std::function<int(int)>& task) {
+    const int n = (int)h->shards.size();
+    int rc;
+    if (n == 1) rc = task(0);
+    else rc = h->fan->run(task);
+    if (rc) {
+        for (qc_handle* sh : h->shards)
+            if (!sh->err.empty()) { h->err = sh->err; break; }
+        return fail(&h->err, rc, h->err.empty() ? std::string("a shard reported an error") : h->err);
+    }
+    return QC_OK;
+}
+
+extern "C" int qc_create_multi(const qc_desc* d, int32_t n_shards, const int32_t* device_ids, qc_handle** out) {
+    if (!out) return fail(nullptr, QC_ERR_INVALID, "qc_create_multi: out is NULL");
+    *out = nullptr;
+    if (n_shards < 1 || n_shards > 1024 || !device_ids) return fail(nullptr, QC_ERR_INVALID, "qc_create_multi: n_shards must be in 1..1024 with a device list");
+    QcParams P; qc_dims_t dims; std::string err;
+    int rc = qc_build_params(d, &P, &dims, &err);
+    if (rc) return rc;
+    if (d->hess_per_interval > 0 || d->jac_per_interval > 0 || d->jac_offset || d->hess_offset || (d->row_placement == QC_ROWS_STACKED && (d->rows_per_interval > 0 || d->row_offset)))
+        return fail(nullptr, QC_ERR_UNSUPPORTED, "qc_create_multi: composed descriptors (shared value vectors) are served by one handle per device and integrator");
+    qc_handle* h = new qc_handle();
+    h->desc = *d;
+    h->desc.G_drift = nullptr;
+    h->desc.G_drives = nullptr;
+    h->device = device_ids[0];
+    h->prm = P;
+    h->dims = dims;
+    const long long len = P.n_int, tb = P.t_begin;
+    const long long chunk = (len + n_shards - 1) / n_shards;
+    h->shard_chunk = chunk;
+    for (int i = 0; i < n_shards; ++i) {
+        qc_desc di = *d;
+        di.device = device_ids[i];
+        long long b0 = std::min(len, (long long)i * chunk), b1 = std::min(len, (long long)(i + 1) * chunk);
+        di.t_begin = tb + b0;
+        di.t_end = tb + b1;
+        if (di.t_begin == 0 && di.t_end == 0) { di.t_begin = di.t_end = 1; }   // an empty first shard of a 1-interval problem cannot happen (chunk >= 1), kept for safety
+        qc_handle* sh = nullptr;
+        rc = qc_create(&di, &sh);
+        if (rc) {
+            const std::string msg = std::string("qc_create_multi: shard ") + std::to_string(i) + ": " + qc_last_error(nullptr);
+            qc_destroy(h);
+            return fail(nullptr, rc, msg);
+        }
+        h->shards.push_back(sh);
+        h->shard_F_off.push_back(b0 * P.F_stride);
+        h->shard_J_off.push_back(b0 * P.J_stride);
+        h->shard_H_off.push_back(b0 * P.H_stride);
+    }
+    h->kernel = h->shards[0]->kernel;
+    h->dims.kernel = h->kernel;
+    if (n_shards > 1) h->fan = new qc_fanout(n_shards);
+    *out = h;
+    return QC_OK;
+}
+
+extern "C" int32_t qc_multi_count(const qc_handle* h) { return h ? (int32_t)h->shards.size() : 0; }
+
+extern "C" qc_handle* qc_multi_shard(qc_handle* h, int32_t i) {
+    if (!h || i < 0 || i >= (int32_t)h->shards.size()) return nullptr;
+    return h->shards[i];
+}
+
+extern "C" int qc_multi_shard_info(const qc_handle* h, int32_t i, int32_t* device, int64_t* t_begin, int64_t* t_end) {
+    if (!h || i < 0 || i >= (int32_t)h->shards.size()) return fail(nullptr, QC_ERR_INVALID, "qc_multi_shard_info: not a multi-device handle or shard out of range");
+    const qc_handle* sh = h->shards[i];
+    if (device) *device = sh->device;
+    if (t_begin) *t_begin = sh->prm.t_begin;
+    if (t_end) *t_end = sh->prm.t_begin + sh->prm.n_int;
+    return QC_OK;
+}
+
+extern "C" int64_t qc_multi_padded_len(const qc_handle* h, int64_t per_interval) {
+    if (!h || h->shards.empty() || per_interval < 0) return 0;
+    return (int64_t)h->shard_chunk * (int64_t)h->shards.size() * per_interval;
+}
+
+extern "C" int qc_multi_eval_F_jac_dev(qc_handle* h, const double* const* dZ, double* const* dF, double* const* dvals) {
+    if (!h || h->shards.empty()) return fail(h ? &h->err : nullptr, QC_ERR_INVALID, "qc_multi_eval_F_jac_dev: not a multi-device handle");
+    if (!dZ || (!dF && !dvals)) return fail(&h->err, QC_ERR_INVALID, "qc_multi_eval_F_jac_dev: NULL pointer list");
+    for (size_t i = 0; i < h->shards.size(); ++i) {   // launches are asynchronous: no threads needed
+        qc_handle* sh = h->shards[i];
+        const int rc = qc_eval_F_jac_dev(sh, dZ[i], dF && dF[i] ? dF[i] + h->shard_F_off[i] : nullptr,
+                                         dvals && dvals[i] ? dvals[i] + h->shard_J_off[i] : nullptr, sh->stream);
+        if (rc) return fail(&h->err, rc, sh->err);
+    }
+    return QC_OK;
+}
+
+extern "C" int qc_multi_eval_hess_dev(qc_handle* h, const double* const* dZ, const double* const* dmu, double* const* dhvals) {
+    if (!h || h->shards.empty()) return fail(h ? &h->err : nullptr, QC_ERR_INVALID, "qc_multi_eval_hess_dev: not a multi-device handle");
+    if (!dZ || !dmu || !dhvals) return fail(&h->err, QC_ERR_INVALID, "qc_multi_eval_hess_dev: NULL pointer list");
+    for (size_t i = 0; i < h->shards.size(); ++i) {
+        qc_handle* sh = h->shards[i];
+        const int rc = qc_eval_hess_dev(sh, dZ[i], dmu[i], dhvals[i] ? dhvals[i] + h->shard_H_off[i] : nullptr, sh->stream);
+        if (rc) return fail(&h->err, rc, sh->err);
+    }
+    return QC_OK;
+}
+
+extern "C" int qc_multi_sync(qc_handle* h) {
+    if (!h || h->shards.empty()) return fail(h ? &h->err : nullptr, QC_ERR_INVALID, "qc_multi_sync: not a multi-device handle");
+    for (qc_handle* sh : h->shards) {
+        qc_device_guard guard(sh->device);
+        QC_HIP(h, guard.err);
+        QC_HIP(h, hipStreamSynchronize(sh->stream));
+    }
+    return QC_OK;
+}
+
+// ---- RCCL all-gather of the shard slices (loaded on first use; the library itself links only libamdhip64) ----------
+namespace {
+typedef struct ncclComm* ncclComm_t;
+struct RcclApi {
+    void* lib = nullptr;
+    int (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    int (*CommDestroy)(ncclComm_t) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    bool ok = false;
+};
+RcclApi& rccl_api() {
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        // prefer a copy that is already in the process (torch bundles its own librccl): two RCCL runtimes must not mix
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* n : names) if (!api.lib) api.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+        for (const char* n : names) if (!api.lib) api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (!api.lib) return;
+        api.CommInitAll = (decltype(api.CommInitAll))dlsym(api.lib, "ncclCommInitAll");
+        api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.lib, "ncclCommDestroy");
+        api.AllGather = (decltype(api.AllGather))dlsym(api.lib, "ncclAllGather");
+        api.GroupStart = (decltype(api.GroupStart))dlsym(api.lib, "ncclGroupStart");
+        api.GroupEnd = (decltype(api.GroupEnd))dlsym(api.lib, "ncclGroupEnd");
+        api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.lib, "ncclGetErrorString");
+        api.ok = api.CommInitAll && api.CommDestroy && api.AllGather && api.GroupStart && api.GroupEnd && api.GetErrorString;
+    });
+    return api;
+}
+constexpr int kNcclFloat64 = 8;   // ncclDataType_t ncclFloat64 (rccl.h)
+}  // namespace
+
+struct qc_rccl_state {
+    std::vector<ncclComm_t> comms;
+};
+void qc_rccl_destroy(qc_rccl_state* r) {
+    if (!r) return;
+    RcclApi& api = rccl_api();
+    if (api.ok) for (ncclComm_t c : r->comms) if (c) (void)api.CommDestroy(c);
+    delete r;
+}
+
+extern "C" int qc_multi_all_gather_dev(qc_handle* h, double* const* bufs, int64_t per_interval) {
+    if (!h || h->shards.empty()) return fail(h ? &h->err : nullptr, QC_ERR_INVALID, "qc_multi_all_gather_dev: not a multi-device handle");
+    if (!bufs || per_interval <= 0) return fail(&h->err, QC_ERR_INVALID, "qc_multi_all_gather_dev: bad argument");
+    const int n = (int)h->shards.size();
+    std::vector<int> devs(n);
+    for (int i = 0; i < n; ++i) {
+        devs[i] = h->shards[i]->device;
+        if (!bufs[i]) return fail(&h->err, QC_ERR_INVALID, "qc_multi_all_gather_dev: NULL buffer");
+        for (int k = 0; k < i; ++k)
+            if (devs[k] == devs[i]) return fail(&h->err, QC_ERR_UNSUPPORTED, "qc_multi_all_gather_dev: one RCCL rank per device: the shards must be on distinct devices");
+    }
+    RcclApi& api = rccl_api();
+    if (!api.ok) return fail(&h->err, QC_ERR_UNSUPPORTED, "qc_multi_all_gather_dev: librccl could not be loaded");
+    if (!h->rccl) {
+        std::unique_ptr<qc_rccl_state> st(new qc_rccl_state());
+        st->comms.assign(n, nullptr);
+        const int r = api.CommInitAll(st->comms.data(), n, devs.data());
+        if (r != 0) return fail(&h->err, QC_ERR_HIP, std::string("ncclCommInitAll: ") + api.GetErrorString(r));
+        h->rccl = st.release();
+    }
+    const size_t count = (size_t)h->shard_chunk * (size_t)per_interval;
+    int r = api.GroupStart();
+    for (int i = 0; r == 0 && i < n; ++i) {
+        qc_device_guard guard(devs[i]);
+        // in place: rank i's contribution already sits at offset i * count of its own full-length vector
+        r = api.AllGather(bufs[i] + (size_t)i * count, bufs[i], count, kNcclFloat64, h->rccl->comms[i], h->shards[i]->stream);
+    }
+    const int r2 = api.GroupEnd();
+    if (r != 0 || r2 != 0) return fail(&h->err, QC_ERR_HIP, std::string("ncclAllGather: ") + api.GetErrorString(r != 0 ? r : r2));
+    return QC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+//  Host-buffer entry points (single- and multi-device handles)
+// ------------------------------------------------------------------------------------------------
+static int eval_host_any(qc_handle* h, const double* Z, double* F, double* vals) {
+    if (!h) return fail(nullptr, QC_ERR_INVALID, "qc_eval: NULL handle");
+    if (!is_multi(h)) return eval_host(h, Z, F, vals, 1);
+    if (!Z || (!F && !vals)) return fail(&h->err, QC_ERR_INVALID, "qc_eval: NULL buffer");
+    const int n = (int)h->shards.size();
+    return multi_run(h, [&](int i) {
+        return eval_host(h->shards[i], Z, F ? F + h->shard_F_off[i] : nullptr, vals ? vals + h->shard_J_off[i] : nullptr, n);
+    });
+}
+
+extern "C" int qc_eval_F(qc_handle* h, const double* Z, double* F) { return eval_host_any(h, Z, F, nullptr); }
+extern "C" int qc_eval_jac(qc_handle* h, const double* Z, double* vals) { return eval_host_any(h, Z, nullptr, vals); }
+extern "C" int qc_eval_F_jac(qc_handle* h, const double* Z, double* F, double* vals) {
+    if (h && (!F || !vals)) return fail(&h->err, QC_ERR_INVALID, "qc_eval_F_jac: NULL buffer");
+    return eval_host_any(h, Z, F, vals);
+}
+
+extern "C" int qc_eval_hess(qc_handle* h, const double* Z, const double* mu, double* hvals) {
+    if (!h) return fail(nullptr, QC_ERR_INVALID, "qc_eval_hess: NULL handle");
+    if (!is_multi(h)) return hess_host(h, Z, mu, hvals);
+    if (h->prm.integrator != QC_PADE)
+        return fail(&h->err, QC_ERR_UNSUPPORTED, "no analytic Hessian for the exponential integrator (upstream has none either; use eval_hessian=false)");
+    if (h->prm.hess_nnz == 0) return QC_OK;
+    if (!Z || !mu || !hvals) return fail(&h->err, QC_ERR_INVALID, "qc_eval_hess: NULL buffer");
+    return multi_run(h, [&](int i) { return hess_host(h->shards[i], Z, mu, hvals + h->shard_H_off[i]); });
+}
+
+// ------------------------------------------------------------------------------------------------
+//  Rollouts
+// ------------------------------------------------------------------------------------------------
+extern "C" int qc_rollout_dev(qc_handle* h, const double* dZ, const double* dinit, double* dout, void* stream) {
+    if (!h) return fail(nullptr, QC_ERR_INVALID, "qc_rollout_dev: NULL handle");
+    QC_NOT_MULTI(h, "qc_rollout_dev");
+    if (!dZ || !dinit || !dout) return fail(&h->err, QC_ERR_INVALID, "qc_rollout_dev: NULL buffer");
+    if (!qc_rollout_supported(h->prm)) return fail(&h->err, QC_ERR_UNSUPPORTED, "qc_rollout: state dimension 2N > 64");
+    qc_device_guard guard(h->device);
+    QC_HIP(h, guard.err);
+    size_t nE, nQ, nS;
+    int chunk, n_chunks;
+    qc_rollout_scratch(h->prm, h->desc.T, &nE, &nQ, &nS, &chunk, &n_chunks);
+    int rc;
+    if ((rc = ensure(h, &h->dRE, nE))) return rc;
+    if ((rc = ensure(h, &h->dRQ, nQ))) return rc;
+    if ((rc = ensure(h, &h->dRS, nS))) return rc;
+    hipError_t e = qc_launch_rollout(h->prm, h->desc.T, dZ, dinit, dout, h->dRE, h->dRQ, h->dRS, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(&h->err, QC_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    return QC_OK;
+}
+
+extern "C" int qc_rollout(qc_handle* h, const double* Z, const double* init, double* out) {
+    if (!h) return fail(nullptr, QC_ERR_INVALID, "qc_rollout: NULL handle");
+    if (is_multi(h)) {   // a rollout is a sequential scan over the whole trajectory: shard 0's device serves it
+        const int rc = qc_rollout(h->shards[0], Z, init, out);
+        if (rc) h->err = h->shards[0]->err;
+        return rc;
+    }
+    if (!Z || !init || !out) return fail(&h->err, QC_ERR_INVALID, "qc_rollout: NULL buffer");
+    qc_device_guard guard(h->device);
+    QC_HIP(h, guard.err);
+    const size_t ns = (size_t)h->prm.n * h->prm.nc, T = (size_t)h->desc.T;
+    int rc;
+    if ((rc = ensure(h, &h->dZ, (size_t)h->dims.Z_len))) return rc;
+    if ((rc = ensure(h, &h->dRinit, ns))) return rc;
+    if ((rc = ensure(h, &h->dRout, ns * T))) return rc;
+    QC_HIP(h, hipMemcpyAsync(h->dZ, Z, (size_t)h->dims.Z_len * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    QC_HIP(h, hipMemcpyAsync(h->dRinit, init, ns * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if ((rc = qc_rollout_dev(h, h->dZ, h->dRinit, h->dRout, h->stream))) return rc;
+    QC_HIP(h, hipMemcpyAsync(out, h->dRout, ns * T * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    QC_HIP(h, hipStreamSynchronize(h->stream));
+    return QC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+//  ABI struct sizes (bindings assert them at load time)
+// ------------------------------------------------------------------------------------------------
+extern "C" int64_t qc_sizeof_desc(void) { return (int64_t)sizeof(qc_desc); }
+extern "C" int64_t qc_sizeof_dims(void) { return (int64_t)sizeof(qc_dims_t); }
+extern "C" int64_t qc_sizeof_terms_desc(void) { return (int64_t)sizeof(qc_terms_desc); }

@@ -26,9 +26,13 @@ struct QcParams {
     double c[QC_MAX_P + 1];  // Pade coefficients c_0..c_p
     int n_deriv;
     int dx_off[QC_MAX_DERIV], x_off[QC_MAX_DERIV], ddim_i[QC_MAX_DERIV];
+    int drow[QC_MAX_DERIV];  // first row of derivative integrator i relative to this handle's row block (stacked: s + sum of the
+                             // earlier dims; QC_ROWS_BY_COMPONENT: deriv_row_off[i] - row_offset, possibly negative)
     long long t_begin;       // first interval of this handle
     int n_int;               // number of intervals of this handle
-    int jac_nnz, hess_nnz;   // per interval
+    int jac_nnz, hess_nnz;   // per interval (own values; hess_nnz excludes the padding)
+    int copies;              // copies of the -F / B blocks the MFMA order-4 kernels write (nc; 1 = compact form of the host path)
+    int h_pad;               // explicit zeros this handle writes after its hess_nnz values (line alignment of the interval blocks)
     // placement of this handle's rows / values inside the problem's vectors (composed problems: several integrator
     // groups share one row block and one value block per interval; default = own sizes, offset 0)
     long long F_stride, F_off, J_stride, J_off, H_stride, H_off;
@@ -46,8 +50,26 @@ struct QcParams {
     unsigned long long* stamps;  // diagnostic: 16 s_memrealtime slots per interval, or nullptr (normal)
 };
 
-struct qc_host_pool;
-void qc_host_pool_destroy(qc_host_pool* p);
+struct qc_fanout;
+void qc_fanout_destroy(qc_fanout* f);
+struct qc_rccl_state;
+void qc_rccl_destroy(qc_rccl_state* r);
+
+// Selects a HIP device for the lifetime of the object and restores the caller's current device afterwards (every entry
+// point uses one: the library never leaves the calling thread on another device than it found).
+struct qc_device_guard {
+    int prev = -1, dev = -1;
+    hipError_t err = hipSuccess;
+    explicit qc_device_guard(int device) : dev(device) {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != dev) err = hipSetDevice(dev);
+    }
+    ~qc_device_guard() {
+        if (prev >= 0 && prev != dev) (void)hipSetDevice(prev);
+    }
+    qc_device_guard(const qc_device_guard&) = delete;
+    qc_device_guard& operator=(const qc_device_guard&) = delete;
+};
 
 struct qc_handle {
     qc_desc desc;  // G pointers nulled after create
@@ -62,10 +84,17 @@ struct qc_handle {
     double *dZ = nullptr, *dF = nullptr, *dJ = nullptr, *dMu = nullptr, *dH = nullptr;
     unsigned long long* dStamps = nullptr;
     double* hJc = nullptr;     // compact Jacobian values (one copy of the replicated blocks): pinned host staging, device-visible
+    double* hFc = nullptr;     // residuals of the direct-to-host path: pinned host staging, device-visible
+    double* hZ = nullptr;      // pinned staging of this handle's knots for the host-to-device copy
     QcParams* dBatch = nullptr;                // device copy of the parameter blocks of a batched launch led by this handle
     std::vector<unsigned long long> batch_members;   // serial numbers of the handles the cached blocks belong to
     unsigned long long serial = 0;             // unique per created handle (a recycled address is not the same handle)
-    struct qc_host_pool* pool = nullptr;       // worker threads of the compact transfer (created on first use)
+    // multi-device handle (qc_create_multi): no device state of its own, `shards` own the devices
+    std::vector<qc_handle*> shards;
+    std::vector<long long> shard_F_off, shard_J_off, shard_H_off;   // offsets (doubles) of each shard's slice in the full vectors
+    long long shard_chunk = 0;                 // intervals per shard (ceil), the all-gather's chunk
+    struct qc_fanout* fan = nullptr;           // one worker thread per shard
+    struct qc_rccl_state* rccl = nullptr;      // communicators of qc_multi_all_gather_dev (first use)
     std::vector<hipEvent_t> chunk_events;
     int host_compact = 1;      // QC_HOST_COMPACT=0 disables the compact D2H path of the host-buffer entry points
     double* dWs = nullptr;     // global workspace of the LDS kernels for systems beyond the LDS budget
@@ -74,6 +103,15 @@ struct qc_handle {
     hipStream_t stream = nullptr;
     std::string err;
 };
+
+int qc_fail(std::string* err, int code, const std::string& msg);   // records the message (handle and thread-local), returns code
+#define QC_HIP(h, call)                                                                             \
+    do {                                                                                            \
+        hipError_t e_ = (call);                                                                     \
+        if (e_ != hipSuccess) {                                                                     \
+            return qc_fail(&(h)->err, QC_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+        }                                                                                           \
+    } while (0)
 
 // Fills prm/dims from a descriptor (host only). Returns QC_OK or error with message in `err`.
 int qc_build_params(const qc_desc* d, QcParams* prm, qc_dims_t* dims, std::string* err);
@@ -88,6 +126,7 @@ hipError_t qc_launch_lds_hess(const QcParams& P, const double* dZ, const double*
                               hipStream_t st);
 bool qc_mfma_supported(const QcParams& P);
 bool qc_mfma_hess_supported(const QcParams& P);
+bool qc_mfma_compact_supported(const QcParams& P);   // the F + dF kernel honours QcParams.copies (order-4 kernels, 2N <= 32)
 size_t qc_mfma_gx_doubles(const QcParams& P);
 void qc_mfma_pack_G(const QcParams& P, const double* G_host, double* Gx_host);
 hipError_t qc_launch_mfma_F_jac(const QcParams& P, const double* dZ, double* dF, double* dJ, hipStream_t st);
@@ -172,6 +211,19 @@ __device__ inline void qc_st8(double* p, double v, int mode) {
     if (mode == 1) qc_st8m<1>(p, v);
     else if (mode == 2) qc_st8m<2>(p, v);
     else qc_st8m<0>(p, v);
+}
+
+// Tail of an interval's Hessian block: the derivative integrators' entries d2/d(dx_i) dh = -mu_i (free timestep only) and the
+// alignment padding (explicit zeros; qc_desc.hess_align).  `mu`, `Hb` point at this handle's rows / values of the interval.
+__device__ inline void qc_hess_tail(const QcParams& P, const double* __restrict__ mu, double* __restrict__ Hb, int tid, int nthreads) {
+    if (P.off_dt >= 0) {
+        int o = P.ho_d;
+        for (int d = 0; d < P.n_deriv; ++d) {
+            for (int i = tid; i < P.ddim_i[d]; i += nthreads) Hb[o + i] = -mu[P.drow[d] + i];
+            o += P.ddim_i[d];
+        }
+    }
+    for (int i = tid; i < P.h_pad; i += nthreads) Hb[P.hess_nnz + i] = 0.0;
 }
 
 // XCD-aware block -> local interval map: blocks b and b+8 share an XCD (round-robin dispatch,

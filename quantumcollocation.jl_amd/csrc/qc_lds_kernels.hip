@@ -127,9 +127,9 @@ __global__ __launch_bounds__(GWS ? kThreadsGws : kThreadsLds) void qc_lds_pade_k
     }
     // derivative integrators
     {
-        int r0 = s, jo = P.jo_d;
+        int jo = P.jo_d;
         for (int d = 0; d < P.n_deriv; ++d) {
-            const int dim = P.ddim_i[d];
+            const int dim = P.ddim_i[d], r0 = P.drow[d];
             for (int i = tid; i < dim; i += kThreads) {
                 const double dx = z0[P.dx_off[d] + i];
                 if (Fb) Fb[r0 + i] = z1[P.x_off[d] + i] - z0[P.x_off[d] + i] - h * dx;
@@ -140,7 +140,6 @@ __global__ __launch_bounds__(GWS ? kThreadsGws : kThreadsLds) void qc_lds_pade_k
                     if (ft) Jb[jo + 3 * dim + i] = -dx;
                 }
             }
-            r0 += dim;
             jo += (ft ? 4 : 3) * dim;
         }
     }
@@ -352,15 +351,7 @@ __global__ __launch_bounds__(GWS ? kThreadsGws : kThreadsLds) void qc_lds_pade_h
             Qp[r * nN + idx] = qp;
         }
     }
-    // derivative integrators: -mu
-    if (ft) {
-        int r0 = s, o = P.ho_d;
-        for (int d = 0; d < P.n_deriv; ++d) {
-            for (int i = tid; i < P.ddim_i[d]; i += kThreads) Hb[o + i] = -mu[r0 + i];
-            r0 += P.ddim_i[d];
-            o += P.ddim_i[d];
-        }
-    }
+    qc_hess_tail(P, mu, Hb, tid, kThreads);   // derivative integrators: -mu; alignment padding
     __syncthreads();
     if (ft) {
         // (h,h): one wave reduces
@@ -690,9 +681,9 @@ __global__ __launch_bounds__(GWS ? kThreadsGws : kThreadsLds) void qc_lds_exp_ke
         if (JAC) Jb[P.jo_B + idx] = 1.0;
     }
     {
-        int r0 = s, jo = P.jo_d;
+        int jo = P.jo_d;
         for (int d = 0; d < P.n_deriv; ++d) {
-            const int dim = P.ddim_i[d];
+            const int dim = P.ddim_i[d], r0 = P.drow[d];
             for (int i = tid; i < dim; i += kThreads) {
                 const double dx = z0[P.dx_off[d] + i];
                 if (Fb) Fb[r0 + i] = z1[P.x_off[d] + i] - z0[P.x_off[d] + i] - h * dx;
@@ -703,7 +694,6 @@ __global__ __launch_bounds__(GWS ? kThreadsGws : kThreadsLds) void qc_lds_exp_ke
                     if (ft) Jb[jo + 3 * dim + i] = -dx;
                 }
             }
-            r0 += dim;
             jo += (ft ? 4 : 3) * dim;
         }
     }

@@ -183,9 +183,9 @@ __global__ __launch_bounds__(kHThreads32, 1) void qc_mfma32_pade4_hess_kernel(co
                     put_tile(DL, I, lane, u1 - u0);
                 }
             }
-            if (ft && w == 5) {   // derivative integrators: d2/d(dx_i) dh = -mu_i, a plain copy (done here: a load issued after
-                                  // the stores of phase 2 would wait for all of them)
-                for (int i = lane; i < P.ddim - P.s; i += 64) Hb[P.ho_d + i] = -mu[P.s + i];
+            if (w == 5) {   // derivative integrators: d2/d(dx_i) dh = -mu_i, a plain copy (done here: a load issued after
+                            // the stores of phase 2 would wait for all of them), and the alignment padding
+                qc_hess_tail(P, mu, Hb, lane, 64);
             }
             v2d Gh = img[0];
 #pragma unroll

@@ -216,7 +216,8 @@ __global__ __launch_bounds__(kThreads32, 2) void qc_mfma32_pade4_kernel(const Qc
                 // lane (g, j) reg r = B^T[16I+4r+g][16Jt+j] = B[16Jt+j][16I+4r+g]
                 double* pF = Jb + P.jo_F;
                 double* pB = Jb + P.jo_B;
-                for (int q = SINGLE ? slot : 0; q < (KET ? nc : 16); q += SINGLE ? 2 : 1) {   // SINGLE: waves 4, 5 even copies, 6, 7 odd
+                const int ncop = P.copies;   // N copies of each block; 1 when the host path asks for the compact form
+                for (int q = SINGLE ? slot : 0; q < ncop; q += SINGLE ? 2 : 1) {   // SINGLE: waves 4, 5 even copies, 6, 7 odd
                     if constexpr (KET) {
                         const size_t o = (size_t)q * nr * nr;
                         store_T32_masked(pF + o, Fm[0], 0, 16 * I, nr, g, j);
@@ -231,12 +232,12 @@ __global__ __launch_bounds__(kThreads32, 2) void qc_mfma32_pade4_kernel(const Qc
                     store_T32(pB + q * 1024, Bm[1], 16, 16 * I, g, j);
                 }
                 if (deriv_wave) {   // derivative integrator rows
-                    int r0 = P.s, jo = P.jo_d;
+                    int jo = P.jo_d;
                     bool all_fast = dfast;
 #pragma unroll
                     for (int d = 0; d < kDF32; ++d) {
                         if (d < P.n_deriv) {
-                            const int dim = P.ddim_i[d];
+                            const int dim = P.ddim_i[d], r0 = P.drow[d];
                             if (dfast && dim <= 64) {
                                 if (lane < dim) {
                                     const double dx = derl[(2 * d) * 64 + lane], df = derl[(2 * d + 1) * 64 + lane];
@@ -249,7 +250,6 @@ __global__ __launch_bounds__(kThreads32, 2) void qc_mfma32_pade4_kernel(const Qc
                             } else {
                                 all_fast = false;
                             }
-                            r0 += dim;
                             jo += (ft ? 4 : 3) * dim;
                         }
                     }

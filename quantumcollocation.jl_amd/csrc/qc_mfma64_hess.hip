@@ -161,9 +161,7 @@ __global__ __launch_bounds__(kHT64, 1) void qc_mfma64_pade4_hess_kernel(const Qc
                 Ds[c * kLd + r] = u1 - u0;
             }
         }
-        if (ft && w == 15) {                               // derivative integrators: d2/d(dx_i) dh = -mu_i
-            for (int i = lane; i < P.ddim - P.s; i += 64) Hb[P.ho_d + i] = -mu[P.s + i];
-        }
+        if (w == 15) qc_hess_tail(P, mu, Hb, lane, 64);    // derivative integrators: d2/d(dx_i) dh = -mu_i; alignment padding
         __syncthreads();
         QC_TS(1);
 

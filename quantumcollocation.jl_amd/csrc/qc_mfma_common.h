@@ -91,9 +91,9 @@ __device__ inline v4d identity_B(int g, int j) {
 __device__ inline void deriv_rows_generic(const QcParams& P, const double* __restrict__ z0, const double* __restrict__ z1,
                                           double h, double* __restrict__ Fb, double* __restrict__ Jb, int lane, bool skip_small) {
     const bool ft = P.off_dt >= 0;
-    int r0 = P.s, jo = P.jo_d;
+    int jo = P.jo_d;
     for (int d = 0; d < P.n_deriv; ++d) {
-        const int dim = P.ddim_i[d];
+        const int dim = P.ddim_i[d], r0 = P.drow[d];
         if (!(skip_small && dim <= 64)) {
             for (int i = lane; i < dim; i += 64) {
                 const double dx = z0[P.dx_off[d] + i];
@@ -106,7 +106,6 @@ __device__ inline void deriv_rows_generic(const QcParams& P, const double* __res
                 }
             }
         }
-        r0 += dim;
         jo += (ft ? 4 : 3) * dim;
     }
 }

@@ -228,14 +228,7 @@ __global__ __launch_bounds__(64) void qc_mfma16_pade4_hess_kernel(const QcParams
                 Hb[o] = sum;
             }
         }
-        if (ft) {   // derivative integrators: d2/d(dx_i) dh = -mu_i
-            int r0 = P.s, o = P.ho_d;
-            for (int d = 0; d < P.n_deriv; ++d) {
-                for (int i = lane; i < P.ddim_i[d]; i += 64) Hb[o + i] = -mu[r0 + i];
-                r0 += P.ddim_i[d];
-                o += P.ddim_i[d];
-            }
-        }
+        qc_hess_tail(P, mu, Hb, lane, 64);   // derivative integrators: d2/d(dx_i) dh = -mu_i; alignment padding
         __builtin_amdgcn_wave_barrier();   // the scratch rows are rewritten by the next interval
     }
 }

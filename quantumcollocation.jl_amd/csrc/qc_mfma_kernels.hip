@@ -216,12 +216,13 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
                 double* pF = Jb + P.jo_F;
                 double* pB = Jb + P.jo_B;
                 // 8 bytes per lane, 512 contiguous bytes per instruction.  (Pairing lanes for 16-byte stores measured 8 % slower.)
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
+                // P.copies = N copies of each block (I_N (x) B); 1 when the host path asks for the compact form
+                const int ncop = P.copies;
+                for (int q = 0; q < ncop; ++q) {
                     if constexpr (!KET) {
                         store_tile_T<MODE>(pF + q * 256, Fm, g, j);
                         store_tile_T<MODE>(pB + q * 256, Bm, g, j);
-                    } else if (q < nc) {
+                    } else {
                         store_tile_T_masked<MODE>(pF + q * nr * nr, Fm, nr, g, j);
                         store_tile_T_masked<MODE>(pB + q * nr * nr, Bm, nr, g, j);
                     }
@@ -229,12 +230,12 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
                 __builtin_amdgcn_s_setprio(0);
                 QC_STAMP(P, b, lane, 2);
                 {   // derivative integrator rows: residual x_{t+1} - x_t - h dx_t and the 4 (3) diagonal blocks
-                    int r0 = P.s, jo = P.jo_d;
+                    int jo = P.jo_d;
                     bool all_fast = dfast;
 #pragma unroll
                     for (int d = 0; d < kDF; ++d) {
                         if (d < P.n_deriv) {
-                            const int dim = P.ddim_i[d];
+                            const int dim = P.ddim_i[d], r0 = P.drow[d];
                             if (dfast && dim <= 64) {
                                 if (lane < dim) {
                                     if (Fb) Fb[r0 + lane] = dfv[d] - h * dxv[d];
@@ -246,7 +247,6 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
                             } else {
                                 all_fast = false;
                             }
-                            r0 += dim;
                             jo += (ft ? 4 : 3) * dim;
                         }
                     }
@@ -424,6 +424,10 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
 }
 
 }  // namespace
+
+bool qc_mfma_compact_supported(const QcParams& P) {
+    return P.integrator == QC_PADE && P.p == 2 && !qc_mfma16_padeP_supported(P) && ((P.n <= 16 && P.nc <= 8) || (P.n <= 32 && P.nc <= 16)) && P.m <= 32;
+}
 
 bool qc_mfma_supported(const QcParams& P) {
     if (qc_mfma_exp_supported(P) || qc_mfma32_exp_supported(P) || qc_mfma64_supported(P) || qc_mfma16_padeP_supported(P)) return true;

@@ -125,9 +125,7 @@ __global__ __launch_bounds__(kPHThreads, 4) void qc_mfma16_padeP_hess_kernel(con
             t1[r] = ok ? a1 : 0.0;
         }
     }
-    if (ft && w == 7) {                // derivative integrators: d2/d(dx_i) dh = -mu_i
-        for (int i = lane; i < P.ddim - P.s; i += 64) Hb[P.ho_d + i] = -mu[P.s + i];
-    }
+    if (w == 7) qc_hess_tail(P, mu, Hb, lane, 64);   // derivative integrators: d2/d(dx_i) dh = -mu_i; alignment padding
     {
         v4d part = w == 0 ? load_GA(Gx, 0, lane) : zero;
         for (int k = w; k < m; k += 8) part += z0[P.off_a + k] * load_GA(Gx, k + 1, lane);

@@ -54,9 +54,31 @@ def split_groups(integrators: Sequence):
     return groups
 
 
+def state_row_offset(traj: NamedTrajectory, name: str) -> int:
+    """First row of state component `name` among the trajectory's STATE components in trajectory order (controls, the free
+    timestep included, carry no dynamics rows): the row convention under which `Z.dims.states` rows per interval hold every
+    integrator at its component's position (reference test/scripts/integrator_test_script.jl:23-44)."""
+    if name in traj.controls:
+        raise ValueError(f"{name} is a control component: it has no dynamics rows")
+    r = 0
+    for other in traj.names:
+        if other == name:
+            return r
+        if other not in traj.controls:
+            r += len(traj.components[other])
+    raise KeyError(name)
+
+
 def make_desc(integrators: Sequence, traj: NamedTrajectory, *, device: int = 0, kernel: str = "auto",
-              t_range: Optional[Tuple[int, int]] = None, placement: Optional[dict] = None):
-    """Translate (integrators, traj) into a qc_desc.  Returns (desc, keepalive)."""
+              t_range: Optional[Tuple[int, int]] = None, placement: Optional[dict] = None, rows: str = "stacked",
+              hess_align: int = 0):
+    """Translate (integrators, traj) into a qc_desc.  Returns (desc, keepalive).
+
+    rows = "stacked": rows of an interval are the integrators' rows in integrator order (default; what every problem
+    template produces, since it lists one integrator per state component in component order).  rows = "by_component":
+    every integrator's rows sit at its state component's position inside Z.dims.states rows per interval; state components
+    without an integrator leave structurally empty rows (qc_desc.row_placement = QC_ROWS_BY_COMPONENT).
+    hess_align: qc_desc.hess_align (0 = library default, 16 doubles; 1 = no padding)."""
     if not integrators or not isinstance(integrators[0], (_UnitaryIntegrator, _KetIntegrator, DensityOperatorExponentialIntegrator)):
         raise NotImplementedError("the first integrator must be the unitary (or the first ket) integrator "
                                   "(row order of reference unitary_smooth_pulse_problem.jl:175-179)")
@@ -118,6 +140,17 @@ def make_desc(integrators: Sequence, traj: NamedTrajectory, *, device: int = 0, 
     d.G_drives = _lib.dptr(Gd)
     d.device = device
     d.kernel = _KERNELS[kernel]
+    d.hess_align = int(hess_align)
+    if rows == "by_component":
+        if placement:
+            raise NotImplementedError("rows='by_component' with several unitary integrators")
+        d.row_placement = _lib.QC_ROWS_BY_COMPONENT
+        d.rows_per_interval = int(traj.dims.states)
+        d.row_offset = state_row_offset(traj, P.state_name)
+        for i, D in enumerate(derivs):
+            d.deriv_row_off[i] = state_row_offset(traj, D.x)
+    elif rows != "stacked":
+        raise ValueError("rows must be 'stacked' or 'by_component'")
     if placement:
         for k, v in placement.items():
             setattr(d, k, int(v))
@@ -156,13 +189,26 @@ class QuantumDynamics:
         return super().__new__(cls)
 
     def __init__(self, integrators: Sequence, traj: NamedTrajectory, *, device: int = 0, kernel: str = "auto",
-                 t_range: Optional[Tuple[int, int]] = None, eval_hessian: bool = True):
+                 t_range: Optional[Tuple[int, int]] = None, eval_hessian: bool = True, devices: Optional[Sequence[int]] = None,
+                 rows: str = "stacked", hess_align: int = 0):
+        """devices = [d0, d1, ...]: ONE evaluator over several GPUs (qc_create_multi): the interval range is split into
+        len(devices) contiguous shards, shard i on HIP device devices[i] (ordinals may repeat); F / dF / mu_d2F behave
+        exactly as on one device and return the same arrays."""
         self.integrators = list(integrators)
         self.traj = traj
         self.eval_hessian = eval_hessian
-        self._desc, self._keep = make_desc(integrators, traj, device=device, kernel=kernel, t_range=t_range)
+        self.devices = None if devices is None else [int(x) for x in devices]
+        if self.devices is not None:
+            if not self.devices:
+                raise ValueError("devices must name at least one device")
+            device = self.devices[0]
+        self._desc, self._keep = make_desc(integrators, traj, device=device, kernel=kernel, t_range=t_range, rows=rows, hess_align=hess_align)
         self._h = C.c_void_p()
-        _lib.check(_lib.lib.qc_create(C.byref(self._desc), C.byref(self._h)))
+        if self.devices is None:
+            _lib.check(_lib.lib.qc_create(C.byref(self._desc), C.byref(self._h)))
+        else:
+            ids = (C.c_int32 * len(self.devices))(*self.devices)
+            _lib.check(_lib.lib.qc_create_multi(C.byref(self._desc), len(self.devices), ids, C.byref(self._h)))
         dims = _lib.qc_dims_t()
         _lib.check(_lib.lib.qc_dims(self._h, C.byref(dims)), self._h)
         self.dims = dims
@@ -245,54 +291,61 @@ class QuantumDynamics:
             raise ValueError(f"Z has length {Z.size}, expected {self.dims.Z_len}")
         return Z
 
-    def _out(self, name: str, n: int) -> np.ndarray:
-        """Result array of `n` doubles.  Earlier results of the same kind are recycled once the caller no longer holds them
-        (or any view of them): a fresh 40 MB array per call costs ~2.7 ms of page faults at config 3, five times the
-        evaluation itself (glibc hands allocations above 32 MB straight back to the kernel).  Two arrays per kind, because in
-        `F, J = dyn.F_dF(Z)` the previous result is still bound while the next call runs."""
-        import sys
-        ring = self.__dict__.setdefault("_out_pool", {}).setdefault(name, [])
-        for i in range(len(ring)):
-            if ring[i].size == n and sys.getrefcount(ring[i]) == 2:   # the ring's reference + getrefcount's argument
-                return ring[i]
-        arr = np.empty(n)
-        if len(ring) >= 2:
-            ring.pop(0)
-        ring.append(arr)
-        return arr
+    def _out(self, name: str, n: int, out: Optional[np.ndarray] = None) -> np.ndarray:
+        """Result array of `n` doubles: the caller's `out` (hot loops: a fresh 40 MB array per call costs ~2.7 ms of page
+        faults at config 3, five times the evaluation itself), else a fresh array.  Nothing is recycled behind the caller's
+        back, so results of earlier calls are never overwritten."""
+        if out is None:
+            return np.empty(n)
+        if not (isinstance(out, np.ndarray) and out.dtype == np.float64 and out.flags.c_contiguous and out.size == n):
+            raise ValueError(f"out for {name} must be a contiguous float64 array of {n} elements")
+        return out
 
-    def F(self, Z) -> np.ndarray:
+    def F(self, Z, out: Optional[np.ndarray] = None) -> np.ndarray:
         Z = self._Z(Z)
-        out = self._out("F", int(self.dims.F_len))
+        out = self._out("F", int(self.dims.F_len), out)
         _lib.check(_lib.lib.qc_eval_F(self._h, _lib.dptr(Z), _lib.dptr(out)), self._h)
         return out
 
-    def dF(self, Z) -> np.ndarray:
+    def dF(self, Z, out: Optional[np.ndarray] = None) -> np.ndarray:
         Z = self._Z(Z)
-        out = self._out("J", int(self.dims.jac_nnz))
+        out = self._out("J", int(self.dims.jac_nnz), out)
         _lib.check(_lib.lib.qc_eval_jac(self._h, _lib.dptr(Z), _lib.dptr(out)), self._h)
         return out
 
-    def F_dF(self, Z):
+    def F_dF(self, Z, out: Optional[Tuple[np.ndarray, np.ndarray]] = None):
         Z = self._Z(Z)
-        F = self._out("F", int(self.dims.F_len))
-        J = self._out("J", int(self.dims.jac_nnz))
+        F = self._out("F", int(self.dims.F_len), None if out is None else out[0])
+        J = self._out("J", int(self.dims.jac_nnz), None if out is None else out[1])
         _lib.check(_lib.lib.qc_eval_F_jac(self._h, _lib.dptr(Z), _lib.dptr(F), _lib.dptr(J)), self._h)
         return F, J
 
-    def mu_d2F(self, Z, mu) -> np.ndarray:
+    def mu_d2F(self, Z, mu, out: Optional[np.ndarray] = None) -> np.ndarray:
         Z = self._Z(Z)
         mu = np.ascontiguousarray(mu, dtype=np.float64)
         if mu.size != self.dims.n_rows:
             raise ValueError(f"mu has length {mu.size}, expected {self.dims.n_rows}")
-        out = self._out("H", int(self.dims.hess_nnz))
+        out = self._out("H", int(self.dims.hess_nnz), out)
         _lib.check(_lib.lib.qc_eval_hess(self._h, _lib.dptr(Z), _lib.dptr(mu), _lib.dptr(out)), self._h)
         return out
+
+    # -- multi-device handles ---------------------------------------------------------------------
+    @property
+    def n_shards(self) -> int:
+        return int(_lib.lib.qc_multi_count(self._h))
+
+    def shard_info(self, i: int) -> Tuple[int, int, int]:
+        """(device, t_begin, t_end) of shard i of a multi-device evaluator."""
+        dev, t0, t1 = C.c_int32(), C.c_int64(), C.c_int64()
+        _lib.check(_lib.lib.qc_multi_shard_info(self._h, i, C.byref(dev), C.byref(t0), C.byref(t1)), self._h)
+        return dev.value, t0.value, t1.value
 
     # -- device-resident evaluation (torch tensors are only the memory/stream plumbing) -----------
     def _dev_ptr(self, t: Optional[torch.Tensor], length: int, name: str):
         if t is None:
             return None
+        if getattr(self, "devices", None) is not None:
+            raise ValueError("device-resident calls on a multi-device evaluator go through qc_multi_eval_*_dev (one pointer per shard)")
         if t.dtype != torch.float64 or not t.is_cuda or not t.is_contiguous():
             raise ValueError(f"{name} must be a contiguous float64 tensor on the GPU")
         if t.device.index != self.device:
@@ -333,24 +386,32 @@ class ComposedQuantumDynamics(QuantumDynamics):
     out in the reference's order: interval-major, integrator-major inside an interval."""
 
     def __init__(self, integrators: Sequence, traj: NamedTrajectory, *, device: int = 0, kernel: str = "auto",
-                 t_range: Optional[Tuple[int, int]] = None, eval_hessian: bool = True):
+                 t_range: Optional[Tuple[int, int]] = None, eval_hessian: bool = True, devices: Optional[Sequence[int]] = None,
+                 rows: str = "stacked", hess_align: int = 0):
+        if devices is not None or rows != "stacked":
+            raise NotImplementedError("several unitary integrators: one device, stacked rows")
         self.integrators = list(integrators)
         self.traj = traj
         self.eval_hessian = eval_hessian
         self.device = device
+        self.devices = None
         groups = split_groups(integrators)
         own = []
         for g in groups:
-            d0, keep = make_desc(g, traj, device=device, kernel=kernel, t_range=t_range)
+            d0, keep = make_desc(g, traj, device=device, kernel=kernel, t_range=t_range, hess_align=1)
             own.append(desc_dims(d0))
         rows = sum(int(x.ddim) for x in own)
         jac = sum(int(x.jac_nnz_interval) for x in own)
-        hess = sum(int(x.hess_nnz_interval) for x in own) if all(x.hess_nnz_interval for x in own) else 0
+        hess_own = sum(int(x.hess_nnz_interval) for x in own) if all(x.hess_nnz_interval for x in own) else 0
+        # the shared per-interval Hessian block is padded to whole 128-byte lines through its LAST handle (qc_desc.hess_tail_zeros)
+        al = 16 if hess_align == 0 else max(1, int(hess_align))
+        hess = -(-hess_own // al) * al if hess_own else 0
         self._parts = []
         ro = jo = ho = 0
-        for g, x in zip(groups, own):
+        for gi, (g, x) in enumerate(zip(groups, own)):
             place = dict(rows_per_interval=rows, row_offset=ro, jac_per_interval=jac, jac_offset=jo,
-                         hess_per_interval=hess if hess else 0, hess_offset=ho if hess else 0)
+                         hess_per_interval=hess if hess else 0, hess_offset=ho if hess else 0,
+                         hess_tail_zeros=(hess - hess_own) if (hess and gi == len(groups) - 1) else 0)
             desc, keep = make_desc(g, traj, device=device, kernel=kernel, t_range=t_range, placement=place)
             h = C.c_void_p()
             _lib.check(_lib.lib.qc_create(C.byref(desc), C.byref(h)))
@@ -424,7 +485,13 @@ class ComposedQuantumDynamics(QuantumDynamics):
     def bind_F_dF_device(self, Z, F, J, stream=None):
         return lambda: (self.F_dF_device(Z, F, J, stream), 0)[1]
 
-    def F_dF(self, Z):
+    def rollout(self, Z, init):
+        raise NotImplementedError("rollouts of a sampling problem are per system: build a QuantumDynamics per unitary integrator")
+
+    def F_dF_into(self, Z, F, J):
+        F[:], J[:] = self.F_dF(Z)
+
+    def F_dF(self, Z, out=None):
         Zh = self._Z(Z)
         dZ = self._buf("Z", Zh.size)
         dZ[:Zh.size].copy_(torch.from_numpy(Zh))
@@ -433,7 +500,7 @@ class ComposedQuantumDynamics(QuantumDynamics):
         torch.cuda.synchronize(self._dev)
         return dF[:self.dims.F_len].cpu().numpy(), dJ[:self.dims.jac_nnz].cpu().numpy()
 
-    def F(self, Z):
+    def F(self, Z, out=None):
         Zh = self._Z(Z)
         dZ = self._buf("Z", Zh.size)
         dZ[:Zh.size].copy_(torch.from_numpy(Zh))
@@ -442,10 +509,10 @@ class ComposedQuantumDynamics(QuantumDynamics):
         torch.cuda.synchronize(self._dev)
         return dF[:self.dims.F_len].cpu().numpy()
 
-    def dF(self, Z):
+    def dF(self, Z, out=None):
         return self.F_dF(Z)[1]
 
-    def mu_d2F(self, Z, mu):
+    def mu_d2F(self, Z, mu, out=None):
         Zh = self._Z(Z)
         mu = np.ascontiguousarray(mu, dtype=np.float64)
         if mu.size != self.dims.n_rows:

@@ -1,4 +1,5 @@
-"""Knot sharding across GPUs: one process per GPU, each owning a contiguous range of the T-1
+"""Knot sharding across GPUs, process-per-GPU flavour (bench.py under torchrun; a consumer that lives in ONE process --
+Julia + Ipopt -- uses the in-library form instead: `QuantumDynamics(..., devices=[...])` = qc_create_multi).  One process per GPU, each owning a contiguous range of the T-1
 intervals (plus the halo knot z_{t_end}, read-only).  Intervals are independent given Z (the
 constraint couples only z_t and z_{t+1}: reference unitary_smooth_pulse_problem.jl:14-16), so there
 is NO collective on the data path.  `all_gather_values` (RCCL all-gather over xGMI when the backend
@@ -45,9 +46,10 @@ class ShardedDynamics:
 
             def make_local(t0, t1):
                 return QuantumDynamics(integrators, traj, device=device, kernel=kernel, t_range=(t0, t1))
-        # an empty tail shard still needs valid dims: give it the last interval's descriptor, evaluate nothing
+        # an empty tail shard (more ranks than intervals) gets a zero-interval evaluator: t_begin = t_end = T-1 > 0 is a valid
+        # range, its dims are all zero-length and its launches are no-ops, so every rank runs the same code path
         self.empty = self.t1 == self.t0
-        self.local = None if self.empty else make_local(self.t0, self.t1)
+        self.local = make_local(self.t0, self.t1)
 
     @property
     def n_local(self) -> int:

@@ -143,9 +143,14 @@ def test_product_code_never_imports_the_oracle():
         for fn in files:
             if fn.endswith((".py", ".cpp", ".hip", ".h")):
                 txt = open(os.path.join(dirpath, fn)).read()
-                for pat in (r"import\s+oracle", r"from\s+oracle", r"qc_oracle", r"libqc_oracle", r"oracle/", r"load_oracle",
-                            r"dlopen", r"qco_"):
+                for pat in (r"import\s+oracle", r"from\s+oracle", r"qc_oracle", r"libqc_oracle", r"oracle/", r"load_oracle", r"qco_"):
                     assert not re.search(pat, txt), f"{fn} references the oracle ({pat})"
+                if re.search(r"dlopen|CDLL", txt):
+                    # run-time loading exists in two places only: the ctypes binding loads libqcolloc_hip.so, and the library
+                    # loads RCCL on first use of the in-library all-gather; every shared-object name in such a file must be one of those
+                    assert fn in ("_lib.py", "qc_host_eval.cpp"), f"{fn} loads shared objects at run time"
+                    for so in re.findall(r'"([^"\s]*\.so[.\d]*)"', txt):
+                        assert "rccl" in so or "libqcolloc_hip" in so, f"{fn} may load {so}"
 
 
 def test_ket_integrators_build_a_descriptor(qc, oracle):
@@ -218,7 +223,9 @@ def test_random_descriptors_structure_properties(qc, oracle):
         d.integrator, d.pade_order, d.n_deriv, d.state_cols = prob.integrator, prob.order, len(prob.derivs), ncol
         for i, dv in enumerate(prob.derivs):
             d.deriv_x_off[i], d.deriv_dx_off[i], d.deriv_dim[i] = dv.x_off, dv.dx_off, dv.dim
-        tag = f"trial {trial}: N={N} m={m} T={T} order={order} ft={free_time} integ={integ} ncol={ncol}"
+        d.hess_align = int(rng.choice([0, 1, 8, 16, 24]))          # 0 = the library default (16 doubles)
+        prob.hess_align = d.hess_align or 16
+        tag = f"trial {trial}: N={N} m={m} T={T} order={order} ft={free_time} integ={integ} ncol={ncol} align={d.hess_align}"
         dims = qc.desc_dims(d)
         assert dims.n_rows == prob.n_rows and dims.n_cols == prob.n_vars, tag
         jr, jc, hr, hc = qc.desc_structures(d)
@@ -232,7 +239,10 @@ def test_random_descriptors_structure_properties(qc, oracle):
             np.testing.assert_array_equal(hr, ohr, err_msg=tag)
             np.testing.assert_array_equal(hc, ohc, err_msg=tag)
             if hr.size:
-                assert np.all(hr <= hc) and len(set(zip(hr.tolist(), hc.tolist()))) == hr.size and hc.max() < dims.n_cols, tag
+                # the alignment padding repeats an interval's first entry (explicit zeros); everything else is duplicate-free
+                pad = oracle.hess_pad(prob) * (prob.T - 1)
+                assert dims.hess_nnz_interval % prob.hess_align == 0 and dims.hess_nnz_interval - oracle.hess_pad(prob) == len(oracle.hess_structure_local(prob)), tag
+                assert np.all(hr <= hc) and len(set(zip(hr.tolist(), hc.tolist()))) == hr.size - pad and hc.max() < dims.n_cols, tag
         else:
             assert hr.size == 0, tag
         jr1, jc1, hr1, hc1 = qc.desc_structures(d, one_based=True)
@@ -264,7 +274,7 @@ def test_c_example_compiles_as_c99_and_fails_loudly_without_a_device(qc, tmp_pat
     and stops at qc_create with QC_ERR_NO_DEVICE (no CPU path)."""
     exe = _build_c_example(tmp_path)
     r = subprocess.run([str(exe)], capture_output=True, text=True)
-    assert r.returncode == 1 and "rows 60 cols 90 jac_nnz 520 hess_nnz 290" in r.stdout
+    assert r.returncode == 1 and "rows 60 cols 90 jac_nnz 520 hess_nnz 320" in r.stdout   # 58 values per interval, padded to 64 (hess_align)
     assert "no HIP device" in r.stderr
 
 

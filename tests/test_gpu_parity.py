@@ -413,11 +413,21 @@ def test_hessian_fixture_golden_and_exponential_unsupported(qc, oracle):
     sys_ = qc.QuantumSystem(0.1 * qc.PAULIS["Z"], [qc.PAULIS["X"], qc.PAULIS["Y"]])
     integ = [qc.UnitaryPadeIntegrator("Ũ⃗", "a", sys_, traj, order=4), qc.DerivativeIntegrator("a", "da", traj),
              qc.DerivativeIntegrator("da", "dda", traj)]
-    dyn = qc.QuantumDynamics(integ, traj)
+    dyn = qc.QuantumDynamics(integ, traj, hess_align=1)   # the golden vectors are the unpadded layout
     assert_close_h(dyn.mu_d2F(traj.datavec, np.ones(dyn.dims.n_rows)), gold["mu_d2F"])
     hr, hc = dyn.mu_d2F_structure
     np.testing.assert_array_equal(hr, gold["mu_d2F_rows"])
     np.testing.assert_array_equal(hc, gold["mu_d2F_cols"])
+    dyn.close()
+    # default layout: every interval's 58 values padded to 64 with explicit zeros that duplicate the interval's first entry
+    dyn = qc.QuantumDynamics(integ, traj)
+    own = gold["mu_d2F"].size // (traj.T - 1)
+    Hp = dyn.mu_d2F(traj.datavec, np.ones(dyn.dims.n_rows)).reshape(traj.T - 1, -1)
+    assert Hp.shape[1] == 64 and own == 58 and not Hp[:, own:].any()
+    assert_close_h(Hp[:, :own].reshape(-1), gold["mu_d2F"])
+    hr, hc = (x.reshape(traj.T - 1, -1) for x in dyn.mu_d2F_structure)
+    np.testing.assert_array_equal(hr[:, :own].reshape(-1), gold["mu_d2F_rows"])
+    np.testing.assert_array_equal(hc[:, own:], np.repeat(hc[:, :1], 64 - own, axis=1))
     dyn.close()
 
 

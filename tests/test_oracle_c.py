@@ -24,7 +24,7 @@ def test_c_oracle_matches_numpy_oracle(oracle, coracle, N, m, order, free_time):
     F, J = co.F_dF(Z)
     np.testing.assert_allclose(F, oracle.F(prob, Z), rtol=1e-12, atol=1e-13)
     np.testing.assert_allclose(J, oracle.dF(prob, Z), rtol=1e-12, atol=1e-13)
-    assert co.jac_nnz == oracle.jac_nnz_interval(prob) and co.hess_nnz == oracle.hess_nnz_interval(prob)
+    assert co.jac_nnz == oracle.jac_nnz_interval(prob) and co.hess_nnz + co.hess_pad == oracle.hess_nnz_interval(prob)
     mu = np.random.default_rng(1).standard_normal(prob.n_rows)
     np.testing.assert_allclose(co.mu_d2F(Z, mu), oracle.mu_d2F(prob, Z, mu), rtol=1e-11, atol=1e-12)
 
@@ -57,6 +57,15 @@ def test_oracles_reproduce_the_golden_vectors(oracle, coracle):
     mu = np.ones(prob.n_rows)
     np.testing.assert_allclose(oracle.F(prob, Zv), gold["F"], rtol=1e-14, atol=1e-16)
     np.testing.assert_allclose(oracle.dF(prob, Zv), gold["dF"], rtol=1e-14, atol=1e-16)
+    # the golden Hessian vector is the unpadded one (hess_align = 1); the default layout pads every interval's 58 values to 64
+    Hp = oracle.mu_d2F(prob, Zv, mu).reshape(prob.T - 1, -1)
+    own = len(oracle.hess_structure_local(prob))
+    assert Hp.shape[1] == 64 and own == 58 and not Hp[:, own:].any()
+    np.testing.assert_allclose(Hp[:, :own].reshape(-1), gold["mu_d2F"], rtol=1e-13, atol=1e-16)
+    hr, hc = oracle.hess_structure(prob)
+    np.testing.assert_array_equal(hr.reshape(prob.T - 1, -1)[:, :own].reshape(-1), gold["mu_d2F_rows"])
+    np.testing.assert_array_equal(hr.reshape(prob.T - 1, -1)[:, own:], np.repeat(hr.reshape(prob.T - 1, -1)[:, :1], 6, axis=1))
+    prob.hess_align = 1
     np.testing.assert_allclose(oracle.mu_d2F(prob, Zv, mu), gold["mu_d2F"], rtol=1e-13, atol=1e-16)
     r, c = oracle.jac_structure(prob)
     np.testing.assert_array_equal(r, gold["dF_rows"])

@@ -164,7 +164,10 @@ def test_nnz_formulas_match_survey_table(oracle):
                               derivs=[oracle.DerivSpec(s, s + m, m), oracle.DerivSpec(s + m, s + 2 * m, m)])
         assert prob.zdim == s + 3 * m + 1 and prob.ddim == ddim
         assert oracle.jac_nnz_interval(prob) == jn == 2 * N * n * n + s * m + s + 8 * m
-        assert oracle.hess_nnz_interval(prob) == hn == m * (m + 1) // 2 + 2 * s * m + m + 2 * s + 1 + 2 * m
+        assert len(oracle.hess_structure_local(prob)) == hn == m * (m + 1) // 2 + 2 * s * m + m + 2 * s + 1 + 2 * m
+        assert oracle.hess_nnz_interval(prob) == -(-hn // 16) * 16       # default layout: padded to whole 128-byte lines
+        prob.hess_align = 1
+        assert oracle.hess_nnz_interval(prob) == hn
 
 
 @pytest.mark.parametrize("integrator", ["pade", "exp"])
@@ -185,8 +188,9 @@ def test_coo_assembly_equals_dense(oracle, integrator):
         hv = oracle.mu_d2F(prob, Z, mu)
         hr, hc = oracle.hess_structure(prob)
         assert (hr <= hc).all()
-        assert len(set(zip(hr.tolist(), hc.tolist()))) == hr.size
-        Hd = oracle.dense_from_coo(hv, hr, hc, (prob.n_vars, prob.n_vars), symmetric=True)
+        # duplicate-free except for the alignment padding (explicit zeros repeating an interval's first entry)
+        assert len(set(zip(hr.tolist(), hc.tolist()))) == hr.size - oracle.hess_pad(prob) * (prob.T - 1)
+        Hd =oracle.dense_from_coo(hv, hr, hc, (prob.n_vars, prob.n_vars), symmetric=True)
         refH = np.zeros_like(Hd)
         for t in range(prob.T - 1):
             refH[t * zd:(t + 2) * zd, t * zd:(t + 2) * zd] += oracle.interval_hessian_dense(
