@@ -309,17 +309,19 @@ int qc_rollout(qc_handle* h, const double* Z, const double* init, double* out);
 int qc_rollout_dev(qc_handle* h, const double* dZ, const double* dinit, double* dout, void* stream);
 
 /* ---- trajectory cost terms (SURVEY 8f "next" row 3) ----------------------------------------------- */
-/* J(Z) = sum_t 1/2 sum_k R_k (sc_t (v_tk - b_tk))^2 + D sum_{t < min_time_knots} dt_t,   sc_t = dt_t or 1:
+/* J(Z) = sum_t 1/2 sum_k R_k (sc_t (v_tk - b_tk))^2 + D sum_{t < min_time_knots} dt_t,   sc_t = 1 (default) or dt_t:
  * the `QuadraticRegularizer(name, traj, R; baseline, timestep_name)` terms on a / da / dda (reference call sites
  * unitary_smooth_pulse_problem.jl:151-153) flattened into one list of regularised scalar entries of a knot, plus
  * `MinimumTimeObjective(traj; D)` (unitary_minimum_time_problem.jl:67-69; the last knot's timestep drives no
- * interval, hence min_time_knots = T-1 there).  The dt-scaling inside the square is how QuantumCollocationCore 0.3
- * is recalled to define the regulariser (not vendored); QC_REG_PLAIN removes it.
+ * interval, hence min_time_knots = T-1 there).  The default weighting QC_REG_PLAIN is the only definition the reference
+ * repository states (docstring unitary_smooth_pulse_problem.jl:13: "1/2 sum_t R_a a_t^2 + ..."); QC_REG_DT_SCALED puts the
+ * timestep inside the square, which is how QuantumCollocationCore 0.3 is recalled to define the regulariser (not
+ * vendored; INTEGRATION.md lists the one-liner that settles it).
  * Gradient: dense, Z_len entries (zeros included).  Hessian: upper triangle, per knot
  * [ (v_k,v_k) k=0..n_reg-1 | (v_k,dt) k=0..n_reg-1 | (dt,dt) ]; the last two groups exist only for QC_REG_DT_SCALED
  * with a free timestep. */
-#define QC_REG_DT_SCALED 0
-#define QC_REG_PLAIN 1
+#define QC_REG_PLAIN 0
+#define QC_REG_DT_SCALED 1
 typedef struct qc_terms_desc {
     int64_t T;
     int32_t zdim;

@@ -6,7 +6,7 @@ of include/qcolloc.h.  The directory name carries a dot, so load it through
 """
 from . import _lib
 from ._lib import QCollocError
-from .dynamics import ComposedQuantumDynamics, QuantumDynamics, desc_dims, desc_structures, make_desc, split_groups
+from .dynamics import ComposedQuantumDynamics, QuantumDynamics, desc_dims, desc_structures, make_desc, split_groups, state_row_offset
 from .gates import GATES, PAULIS, operator_from_string
 from .integrators import (DensityOperatorExponentialIntegrator, DerivativeIntegrator, QuantumStateExponentialIntegrator, QuantumStatePadeIntegrator,
                           UnitaryExponentialIntegrator, UnitaryPadeIntegrator)
@@ -31,5 +31,5 @@ __all__ = [
     "unitary_geodesic", "iso_vec_unitary_fidelity", "UnitaryInfidelityObjective", "FinalUnitaryFidelityConstraint", "QuantumStateObjective", "FinalQuantumStateFidelityConstraint", "DensityOperatorPureStateInfidelityObjective", "iso_fidelity",
     "QuadraticRegularizer", "MinimumTimeObjective", "TrajectoryObjective", "TimeStepsAllEqualConstraint",
     "OpenQuantumSystem", "DensityOperatorExponentialIntegrator", "density_operator_smooth_pulse_inputs",
-    "density_to_iso_vec", "iso_vec_to_density", "iso_operator", "unitary_rollout", "rollout", "open_rollout", "unitary_rollout_fidelity", "make_desc", "desc_dims", "desc_structures", "QCollocError",
+    "density_to_iso_vec", "iso_vec_to_density", "iso_operator", "unitary_rollout", "rollout", "open_rollout", "unitary_rollout_fidelity", "make_desc", "desc_dims", "desc_structures", "state_row_offset", "QCollocError",
 ]

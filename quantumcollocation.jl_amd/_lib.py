@@ -32,8 +32,8 @@ QC_KERNEL_LDS = 1
 QC_KERNEL_MFMA = 2
 QC_MAX_DERIV = 8
 QC_FID_UNITARY, QC_FID_KET, QC_FID_DENSITY = 0, 1, 2
-QC_REG_DT_SCALED = 0
-QC_REG_PLAIN = 1
+QC_REG_PLAIN = 0
+QC_REG_DT_SCALED = 1
 QC_ROWS_STACKED = 0
 QC_ROWS_BY_COMPONENT = 1
 

@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <functional>
@@ -177,7 +178,8 @@ static int ensure(qc_handle* h, double** p, size_t count) {
 static int ensure_zeroed(qc_handle* h, double** p, size_t count) {   // rows no kernel writes (QC_ROWS_BY_COMPONENT) stay 0
     if (*p || count == 0) return QC_OK;
     QC_HIP(h, hipMalloc((void**)p, count * sizeof(double)));
-    QC_HIP(h, hipMemset(*p, 0, count * sizeof(double)));
+    // on the handle's stream: it is a non-blocking stream, a memset on the null stream would race with the kernel behind it
+    QC_HIP(h, hipMemsetAsync(*p, 0, count * sizeof(double), h->stream));
     return QC_OK;
 }
 static int ensure_pinned(qc_handle* h, double** p, size_t count, bool zero) {
@@ -224,14 +226,30 @@ static CompactPlan compact_plan(const QcParams& P) {
     return c;
 }
 
+// qc_host_copy.cpp: streaming copy (non-temporal stores where the CPU has them; QC_HOST_NT=0 -> memcpy, 2 -> 32-byte form)
+typedef void (*qc_copy_fn)(double*, const double*, size_t);
+void qc_host_copy_select(int mode, qc_copy_fn* fn);
+void qc_host_copy_fence();
+static qc_copy_fn host_copy() {
+    static qc_copy_fn fn = [] {
+        qc_copy_fn f = nullptr;
+        const char* ev = getenv("QC_HOST_NT");
+        qc_host_copy_select(ev ? atoi(ev) : 1, &f);
+        return f;
+    }();
+    return fn;
+}
+
 static void expand_intervals(const QcParams& P, const CompactPlan& cp, const double* comp, double* vals, int b0, int b1) {
+    const qc_copy_fn cpy = host_copy();
     for (int b = b0; b < b1; ++b) {
         const double* src = comp + (size_t)b * cp.comp_len;
         double* dst = vals + (size_t)b * P.jac_nnz;
-        for (int c = 0; c < cp.copies; ++c) memcpy(dst + P.jo_F + (size_t)c * cp.n2, src, (size_t)cp.n2 * sizeof(double));
-        for (int c = 0; c < cp.second_copies; ++c) memcpy(dst + P.jo_B + (size_t)c * cp.n2, src + cp.n2, (size_t)cp.n2 * sizeof(double));
-        memcpy(dst + cp.tail_src, src + cp.head2, (size_t)cp.tail_len * sizeof(double));
+        for (int c = 0; c < cp.copies; ++c) cpy(dst + P.jo_F + (size_t)c * cp.n2, src, (size_t)cp.n2);
+        for (int c = 0; c < cp.second_copies; ++c) cpy(dst + P.jo_B + (size_t)c * cp.n2, src + cp.n2, (size_t)cp.n2);
+        cpy(dst + cp.tail_src, src + cp.head2, (size_t)cp.tail_len);
     }
+    qc_host_copy_fence();
 }
 
 static int usable_cores() {
@@ -340,9 +358,15 @@ static QcParams compact_params(const QcParams& P, const CompactPlan& cp) {
 
 // Chunked tail of a host evaluation: `produce(k, b0, b1)` enqueues the work that makes chunk k's compact values (and
 // residuals) appear in the pinned buffers; the worker pool expands each chunk into the caller's arrays as it lands.
+static double now_us() {
+    return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+static bool host_trace() { static const bool on = getenv("QC_HOST_TRACE") && atoi(getenv("QC_HOST_TRACE")); return on; }
+
 static int run_chunks(qc_handle* h, const CompactPlan& cp, double* F, double* vals, int shards,
                       const std::function<int(int, int, int)>& produce) {
     const QcParams& P = h->prm;
+    const double t_begin = now_us();
     HostPool& pool = host_pool();
     const int workers = pool_workers(shards);
     pool.ensure(workers);
@@ -358,11 +382,15 @@ static int run_chunks(qc_handle* h, const CompactPlan& cp, double* F, double* va
     }
     HostGroup grp;
     int rc_wait = QC_OK;
+    const double t_launched = now_us();
+    double t_first = 0, t_last = 0;
     const double* comp = h->hJc;
     const double* hF = F ? h->hFc : nullptr;
     const QcParams* Pp = &P;
     for (int k = 0; k < n_chunks; ++k) {
         if (hipEventSynchronize(h->chunk_events[k]) != hipSuccess) { rc_wait = QC_ERR_HIP; break; }
+        if (k == 0) t_first = now_us();
+        if (k == n_chunks - 1) t_last = now_us();
         const int b0 = k * per, b1 = std::min(P.n_int, b0 + per);
         pool.push([=] {
             if (vals) expand_intervals(*Pp, cp, comp, vals, b0, b1);
@@ -370,7 +398,11 @@ static int run_chunks(qc_handle* h, const CompactPlan& cp, double* F, double* va
         }, &grp);
     }
     grp.wait();
+    const double t_done = now_us();
     QC_HIP(h, hipStreamSynchronize(h->stream));
+    if (host_trace())
+        fprintf(stderr, "qcolloc host trace: %d chunks, %d workers: launches issued +%.0f us, first chunk landed +%.0f, last chunk landed +%.0f, "
+                "replication done +%.0f us\n", n_chunks, workers, t_launched - t_begin, t_first - t_begin, t_last - t_begin, t_done - t_begin);
     if (rc_wait) return fail(&h->err, QC_ERR_HIP, "hipEventSynchronize failed in the compact transfer");
     return QC_OK;
 }

@@ -243,7 +243,7 @@ class TrajectoryObjective:
     `"∂²L_structure"` resolve to the same members."""
     _ALIASES = {"∇L": "grad_L", "∂²L": "hess_L", "∂²L_structure": "hess_structure"}
 
-    def __init__(self, terms, traj: NamedTrajectory, dt_scaled: bool = True, device: int = 0):
+    def __init__(self, terms, traj: NamedTrajectory, dt_scaled: bool = False, device: int = 0):
         if isinstance(terms, TrajectoryObjectiveSpec):
             terms = terms.terms
         elif isinstance(terms, (QuadraticRegularizer, MinimumTimeObjective)):

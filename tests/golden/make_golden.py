@@ -23,6 +23,7 @@ prob = o.Problem(N=2, m=2, T=5, zdim=15, off_U=0, off_a=8, off_dt=14, G_drift=o.
 Zv = data.reshape(-1, order="F")
 mu = np.ones(prob.n_rows)            # reference script uses mu = ones (integrator_test_1qubit.jl:50)
 rows, cols = o.jac_structure(prob)
+prob.hess_align = 1            # the committed Hessian vectors are the unpadded layout
 hr, hc = o.hess_structure(prob)
 np.savez(os.path.join(HERE, "fixture_outputs.npz"), F=o.F(prob, Zv), dF=o.dF(prob, Zv), dF_rows=rows, dF_cols=cols,
          mu_d2F=o.mu_d2F(prob, Zv, mu), mu_d2F_rows=hr, mu_d2F_cols=hc)
@@ -37,7 +38,7 @@ init = np.array(fx["initial_U"], dtype=float)      # the fixture's own initial /
 goal = np.array(fx["goal_U"], dtype=float)
 roll = o.rollout(pe, Zv, init)
 fid, gfid, hfid = o.fidelity_value_grad_hess(roll[:, -1], goal)
-tm = o.Terms(T=5, zdim=15, off_dt=14, reg_index=np.arange(8, 12), reg_R=np.array([1e-2, 1e-2, 2e-2, 3e-2]), D=1.5, n_mt=4)
+tm = o.Terms(T=5, zdim=15, off_dt=14, reg_index=np.arange(8, 12), reg_R=np.array([1e-2, 1e-2, 2e-2, 3e-2]), D=1.5, n_mt=4, dt_scaled=True)
 thr, thc = o.terms_hess_structure(tm)
 np.savez(os.path.join(HERE, "fixture_outputs_8f.npz"), exp_F=o.F(pe, Zv), exp_dF=o.dF(pe, Zv), rollout=roll, init=init, goal=goal,
          fidelity=fid, fidelity_grad=gfid, fidelity_hess=hfid, terms_J=o.terms_value(tm, Zv), terms_grad=o.terms_grad(tm, Zv),

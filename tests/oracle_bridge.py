@@ -77,7 +77,11 @@ def composed_oracle(inp):
     qc = g.load_package()
     groups = qc.split_groups(inp.integrators)
     probs = [problem_from_inputs(SimpleNamespace(integrators=grp, traj=inp.traj)) for grp in groups]
+    for p in probs:
+        p.hess_align = 1          # the groups share one per-interval block: it is padded as a whole (below), not per group
     T = inp.traj.T
+    hess_total = sum(len(o.hess_structure_local(p)) for p in probs)
+    hess_padn = (-hess_total) % 16 if all(len(o.hess_structure_local(p)) for p in probs) else 0
 
     def interleave(parts):
         return np.concatenate([p.reshape(T - 1, -1) for p in parts], axis=1).reshape(-1)
@@ -106,6 +110,8 @@ def composed_oracle(inp):
         for p in probs:
             out.append(o.mu_d2F(p, Z, np.ascontiguousarray(mus[:, ro:ro + p.ddim]).reshape(-1)))
             ro += p.ddim
+        if hess_padn:
+            out.append(np.zeros((T - 1) * hess_padn))
         return interleave(out)
 
     def hess_structure():
@@ -114,6 +120,9 @@ def composed_oracle(inp):
             r, c = o.hess_structure(p)
             rs.append(r.reshape(T - 1, -1))
             cs.append(c.reshape(T - 1, -1))
+        if hess_padn:   # the last handle repeats ITS first entry for the padding
+            rs.append(np.repeat(rs[-1][:, :1], hess_padn, axis=1))
+            cs.append(np.repeat(cs[-1][:, :1], hess_padn, axis=1))
         return np.concatenate(rs, axis=1).reshape(-1), np.concatenate(cs, axis=1).reshape(-1)
 
     return SimpleNamespace(F=F, dF=dF, structure=structure, mu_d2F=mu_d2F, hess_structure=hess_structure, rows=rows, probs=probs)

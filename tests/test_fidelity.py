@@ -91,10 +91,10 @@ def test_objective_and_constraint_mirror(qc, oracle):
     Hd = np.zeros((Z.size, Z.size))
     Hd[r, c] = getattr(obj, "∂²L")(Z)
     first = obj.first
-    np.testing.assert_allclose(Hd[first:first + 32, first:first + 32], np.triu(100.0 * Hl), rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(Hd[first:first + 32, first:first + 32], np.triu(100.0 * Hl), rtol=1e-10, atol=1e-11)
     np.testing.assert_allclose(con.g(Z), [Fr - 0.99], atol=1e-13)
     np.testing.assert_allclose(con.dg(Z), gF, rtol=1e-10, atol=1e-12)
-    np.testing.assert_allclose(con.mu_d2g(Z, [2.5]), 2.5 * HF[np.triu_indices(32)][np.lexsort((np.triu_indices(32)[0], np.triu_indices(32)[1]))], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(con.mu_d2g(Z, [2.5]), 2.5 * HF[np.triu_indices(32)][np.lexsort((np.triu_indices(32)[0], np.triu_indices(32)[1]))], rtol=1e-10, atol=1e-11)
     obj.close()
     con.close()
 

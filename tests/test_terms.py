@@ -96,11 +96,11 @@ def test_terms_structure_host_entry_points(qc, oracle):
     # invalid descriptors
     for mut in (lambda: setattr(d, "weighting", 5), lambda: setattr(d, "off_dt", tm.zdim), lambda: setattr(d, "n_reg", tm.zdim + 1),
                 lambda: setattr(d, "min_time_knots", tm.T + 1), lambda: setattr(d, "T", 0)):
-        d.weighting, d.off_dt, d.n_reg, d.min_time_knots, d.T = 0, tm.off_dt, idx.size, tm.T - 1, tm.T
+        d.weighting, d.off_dt, d.n_reg, d.min_time_knots, d.T = qc._lib.QC_REG_DT_SCALED, tm.off_dt, idx.size, tm.T - 1, tm.T
         mut()
         assert qc._lib.lib.qc_terms_desc_hess_nnz(C.byref(d), C.byref(nnz)) == qc._lib.QC_ERR_INVALID
         assert qc._lib.lib.qc_terms_last_error(None)
-    d.weighting, d.off_dt, d.n_reg, d.min_time_knots, d.T = 0, tm.off_dt, idx.size, tm.T - 1, tm.T
+    d.weighting, d.off_dt, d.n_reg, d.min_time_knots, d.T = qc._lib.QC_REG_DT_SCALED, tm.off_dt, idx.size, tm.T - 1, tm.T
     bad = idx.copy()
     bad[1] = bad[0]
     d.reg_index = bad.ctypes.data_as(C.POINTER(C.c_int32))
