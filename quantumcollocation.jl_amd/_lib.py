@@ -19,6 +19,9 @@ import torch  # noqa: F401  (device memory, streams, torch.distributed: plumbing
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libqcolloc_hip.so")
+# kernel experiments (profiles/build_variant.sh): QCOLLOC_HIP_VARIANT=name loads csrc/libqcolloc_hip.<name>.so (always in-tree)
+if os.environ.get("QCOLLOC_HIP_VARIANT"):
+    LIB_PATH = LIB_PATH[:-2] + os.path.basename(os.environ["QCOLLOC_HIP_VARIANT"]) + LIB_PATH[-3:]   # libqcolloc_hip.<name>.so
 
 QC_OK = 0
 QC_ERR_INVALID = -1

@@ -426,6 +426,8 @@ extern "C" int qc_create(const qc_desc* d, qc_handle** out) {
         }
     }
     QC_HIP_C(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    QC_HIP_C(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+    QC_HIP_C(hipEventCreateWithFlags(&h->ev_staged, hipEventDisableTiming));
 #undef QC_HIP_C
     *out = h;
     return QC_OK;
@@ -449,6 +451,8 @@ extern "C" void qc_destroy(qc_handle* h) {
     if (h->dBatch) (void)hipFree(h->dBatch);
     for (hipEvent_t ev : h->chunk_events) if (ev) (void)hipEventDestroy(ev);
     for (double* b : bufs) if (b) (void)hipFree(b);
+    if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
+    if (h->ev_staged) (void)hipEventDestroy(h->ev_staged);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }

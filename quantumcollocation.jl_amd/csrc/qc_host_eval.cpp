@@ -282,6 +282,8 @@ struct HostPool {
     std::condition_variable cv;
     std::deque<std::pair<std::function<void()>, HostGroup*>> q;
     bool stop = false;
+    // (Workers that poll for ~100 us before blocking were measured on the 16-CPU-quota host: 0.55 instead of 0.48 ms per
+    // config-3 evaluation -- the polling threads eat the quota the launching thread needs.)
     void run() {
         std::unique_lock<std::mutex> lk(mu);
         for (;;) {
@@ -362,15 +364,20 @@ static double now_us() {
     return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 static bool host_trace() { static const bool on = getenv("QC_HOST_TRACE") && atoi(getenv("QC_HOST_TRACE")); return on; }
+static thread_local double g_call_begin = 0.0;   // entry of the host-buffer call being traced (QC_HOST_TRACE)
 
+// (One launch over all intervals in order, with per-chunk completion counters added to by the kernel in pinned host memory and
+// polled here, was built and measured: every interval then has to drain its PCIe writes (s_waitcnt vmcnt(0)) before it can be
+// counted, 137 us per round of 128 intervals -- 1.2 ms per evaluation instead of 0.5.  Rejected.)
+// `two_streams`: odd chunks are produced on h->stream2 (produce() picks the stream by the chunk's parity).
 static int run_chunks(qc_handle* h, const CompactPlan& cp, double* F, double* vals, int shards,
-                      const std::function<int(int, int, int)>& produce) {
+                      const std::function<int(int, int, int)>& produce, bool two_streams = false) {
     const QcParams& P = h->prm;
     const double t_begin = now_us();
     HostPool& pool = host_pool();
     const int workers = pool_workers(shards);
     pool.ensure(workers);
-    int n_chunks = chunk_count(h, P.n_int, workers);
+    int n_chunks = vals ? chunk_count(h, P.n_int, workers) : 1;   // residuals only: ~1 MB, one launch
     const int per = (P.n_int + n_chunks - 1) / n_chunks;
     n_chunks = (P.n_int + per - 1) / per;
     int rc;
@@ -378,7 +385,7 @@ static int run_chunks(qc_handle* h, const CompactPlan& cp, double* F, double* va
     for (int k = 0; k < n_chunks; ++k) {
         const int b0 = k * per, b1 = std::min(P.n_int, b0 + per);
         if ((rc = produce(k, b0, b1))) return rc;
-        QC_HIP(h, hipEventRecord(h->chunk_events[k], h->stream));
+        QC_HIP(h, hipEventRecord(h->chunk_events[k], (two_streams && (k & 1)) ? h->stream2 : h->stream));
     }
     HostGroup grp;
     int rc_wait = QC_OK;
@@ -392,19 +399,44 @@ static int run_chunks(qc_handle* h, const CompactPlan& cp, double* F, double* va
         if (k == 0) t_first = now_us();
         if (k == n_chunks - 1) t_last = now_us();
         const int b0 = k * per, b1 = std::min(P.n_int, b0 + per);
-        pool.push([=] {
-            if (vals) expand_intervals(*Pp, cp, comp, vals, b0, b1);
-            if (hF) memcpy(F + (size_t)b0 * Pp->F_stride, hF + (size_t)b0 * Pp->F_stride, (size_t)(b1 - b0) * Pp->F_stride * sizeof(double));
-        }, &grp);
+        // several jobs per chunk, so that the LAST chunk's replication (the un-overlapped tail) is shared by the workers
+        static const int max_pieces = getenv("QC_HOST_PIECES") ? std::max(1, atoi(getenv("QC_HOST_PIECES"))) : 4;
+        const int pieces = std::max(1, std::min(std::min(workers, max_pieces), (b1 - b0) / 4));
+        const int step = (b1 - b0 + pieces - 1) / pieces;
+        for (int c0 = b0; c0 < b1; c0 += step) {
+            const int c1 = std::min(b1, c0 + step);
+            pool.push([=] {
+                if (vals) expand_intervals(*Pp, cp, comp, vals, c0, c1);
+                if (hF) memcpy(F + (size_t)c0 * Pp->F_stride, hF + (size_t)c0 * Pp->F_stride, (size_t)(c1 - c0) * Pp->F_stride * sizeof(double));
+            }, &grp);
+        }
     }
     grp.wait();
     const double t_done = now_us();
     QC_HIP(h, hipStreamSynchronize(h->stream));
+    if (two_streams) QC_HIP(h, hipStreamSynchronize(h->stream2));
     if (host_trace())
-        fprintf(stderr, "qcolloc host trace: %d chunks, %d workers: launches issued +%.0f us, first chunk landed +%.0f, last chunk landed +%.0f, "
-                "replication done +%.0f us\n", n_chunks, workers, t_launched - t_begin, t_first - t_begin, t_last - t_begin, t_done - t_begin);
+        fprintf(stderr, "qcolloc host trace: %d chunks, %d workers: chunk loop entered +%.0f us after the call, launches issued +%.0f, first chunk "
+                "landed +%.0f, last chunk landed +%.0f, replication done +%.0f, stream idle +%.0f us\n", n_chunks, workers, t_begin - g_call_begin,
+                t_launched - g_call_begin, t_first - g_call_begin, t_last - g_call_begin, t_done - g_call_begin, now_us() - g_call_begin);
     if (rc_wait) return fail(&h->err, QC_ERR_HIP, "hipEventSynchronize failed in the compact transfer");
     return QC_OK;
+}
+
+// memcpy shared by the pool's workers (staging of the trajectory vector into pinned memory: 1.2 MB at config 3, 9.4 MB at config 4)
+static void pool_memcpy(double* dst, const double* src, size_t n, int workers) {
+    const size_t min_piece = 16384;   // doubles
+    const int pieces = (int)std::max<size_t>(1, std::min<size_t>((size_t)workers, n / min_piece));
+    if (pieces == 1) { memcpy(dst, src, n * sizeof(double)); return; }
+    HostPool& pool = host_pool();
+    HostGroup grp;
+    const size_t step = (n + pieces - 1) / pieces;
+    for (size_t o = step; o < n; o += step) {
+        const size_t len = std::min(step, n - o);
+        pool.push([=] { memcpy(dst + o, src + o, len * sizeof(double)); }, &grp);
+    }
+    memcpy(dst, src, std::min(step, n) * sizeof(double));   // the caller takes the first piece
+    grp.wait();
 }
 
 static int eval_host(qc_handle* h, const double* Z, double* F, double* vals, int shards) {
@@ -412,35 +444,60 @@ static int eval_host(qc_handle* h, const double* Z, double* F, double* vals, int
     if (!Z || (!F && !vals)) return fail(&h->err, QC_ERR_INVALID, "qc_eval: NULL buffer");
     const QcParams& P = h->prm;
     if (P.n_int == 0) return QC_OK;
+    if (host_trace()) g_call_begin = now_us();
     qc_device_guard guard(h->device);
     QC_HIP(h, guard.err);
     int rc;
-    if ((rc = ensure(h, &h->dZ, (size_t)h->dims.Z_len))) return rc;
     // Only the knots this handle touches cross PCIe: [t_begin, t_end] inclusive, through a pinned staging buffer (an
     // asynchronous copy from pageable memory is staged by the runtime in small pieces and blocks the calling thread).
     const size_t z0 = (size_t)P.t_begin * P.zdim;
-    const size_t zn = (size_t)(P.n_int + 1) * P.zdim;
-    if ((rc = ensure_pinned(h, &h->hZ, zn, false))) return rc;
-    memcpy(h->hZ, Z + z0, zn * sizeof(double));
-    QC_HIP(h, hipMemcpyAsync(h->dZ + z0, h->hZ, zn * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if ((rc = ensure_pinned(h, &h->hZ, (size_t)h->dims.Z_len, false))) return rc;
+    if ((rc = ensure(h, &h->dZ, (size_t)h->dims.Z_len))) return rc;
+    HostPool& pool = host_pool();
+    const int workers = pool_workers(shards);
+    pool.ensure(workers);
+    // knots [k0, k1) of this handle's range: pageable -> pinned (worker threads) -> device (asynchronous on the handle's stream)
+    auto stage_knots = [&](size_t k0, size_t k1) -> int {
+        const size_t o = z0 + k0 * P.zdim, n = (k1 - k0) * P.zdim;
+        pool_memcpy(h->hZ + o, Z + o, n, workers);
+        QC_HIP(h, hipMemcpyAsync(h->dZ + o, h->hZ + o, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        return QC_OK;
+    };
 
     const CompactPlan cp = compact_plan(P);
     const bool compact = vals && h->host_compact && cp.useful;
-    const bool direct = compact && h->host_compact != 2 && h->kernel == QC_KERNEL_MFMA && qc_mfma_compact_supported(P);
+    const bool direct = (compact || !vals) && h->host_compact == 1 && h->kernel == QC_KERNEL_MFMA && qc_mfma_compact_supported(P);
     if (direct) {
-        // the kernel writes residuals and compact values straight into pinned host memory, one launch per chunk
-        if ((rc = ensure_pinned(h, &h->hJc, (size_t)P.n_int * cp.comp_len, false))) return rc;
+        // Direct form: the kernel writes residuals and compact values straight into pinned host memory, one launch per chunk of
+        // intervals; the first chunk's knots are staged and copied ahead of the rest, so that the first launch (and with it the
+        // PCIe write stream) starts after ~75 KB instead of the whole trajectory vector.  (Reading the knots from the pinned
+        // buffer inside the kernel -- no H2D copy at all -- was measured slower: every chunk launch then begins with a PCIe
+        // round trip, 23 instead of 16 us per chunk at config 3.)
+        if (vals && (rc = ensure_pinned(h, &h->hJc, (size_t)P.n_int * cp.comp_len, false))) return rc;
         if (F && (rc = ensure_pinned(h, &h->hFc, (size_t)h->dims.F_len, true))) return rc;
-        const QcParams C = compact_params(P, cp);
-        return run_chunks(h, cp, F, vals, shards, [&](int, int b0, int b1) -> int {
+        const QcParams C = vals ? compact_params(P, cp) : P;
+        static const bool two = !(getenv("QC_HOST_STREAMS") && atoi(getenv("QC_HOST_STREAMS")) == 1);
+        return run_chunks(h, cp, F, vals, shards, [&](int k, int b0, int b1) -> int {
+            int rs = QC_OK;
+            if (k == 0) rs = stage_knots(0, (size_t)b1 + 1);                                   // chunk 0 and its halo knot
+            else if (k == 1) {
+                rs = stage_knots((size_t)b0 + 1, (size_t)P.n_int + 1);                         // everything else
+                if (!rs && two) {   // the second stream starts behind the copies
+                    QC_HIP(h, hipEventRecord(h->ev_staged, h->stream));
+                    QC_HIP(h, hipStreamWaitEvent(h->stream2, h->ev_staged, 0));
+                }
+            }
+            if (rs) return rs;
             QcParams Ck = C;
             Ck.t_begin = C.t_begin + b0;
             Ck.n_int = b1 - b0;
-            hipError_t e = qc_launch_mfma_F_jac(Ck, h->dZ, F ? h->hFc + (size_t)b0 * C.F_stride : nullptr, h->hJc + (size_t)b0 * cp.comp_len, h->stream);
+            hipError_t e = qc_launch_mfma_F_jac(Ck, h->dZ, F ? h->hFc + (size_t)b0 * C.F_stride : nullptr,
+                                                vals ? h->hJc + (size_t)b0 * cp.comp_len : nullptr, (two && (k & 1)) ? h->stream2 : h->stream);
             if (e != hipSuccess) return fail(&h->err, QC_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
             return QC_OK;
-        });
+        }, two);
     }
+    if ((rc = stage_knots(0, (size_t)P.n_int + 1))) return rc;
     if (F && (rc = ensure_zeroed(h, &h->dF, (size_t)h->dims.F_len))) return rc;
     if (vals && (rc = ensure(h, &h->dJ, (size_t)h->dims.jac_nnz))) return rc;
     if ((rc = qc_eval_F_jac_dev(h, h->dZ, F ? h->dF : nullptr, vals ? h->dJ : nullptr, h->stream))) return rc;

@@ -101,6 +101,8 @@ struct qc_handle {
     double* dHs = nullptr;     // scratch of the 4 x 4-tile Hessian kernel (first Hessian call)
     double *dRE = nullptr, *dRQ = nullptr, *dRS = nullptr, *dRinit = nullptr, *dRout = nullptr;   // rollout scratch / staging
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;   // odd chunks of the direct-to-host path (kernel boundaries of one stream overlap the other's stores)
+    hipEvent_t ev_staged = nullptr;  // the knots are on the device (recorded on `stream`, waited for by `stream2`)
     std::string err;
 };
 
@@ -211,6 +213,22 @@ __device__ inline void qc_st8(double* p, double v, int mode) {
     if (mode == 1) qc_st8m<1>(p, v);
     else if (mode == 2) qc_st8m<2>(p, v);
     else qc_st8m<0>(p, v);
+}
+
+// Kernel-argument warm-up.  QcParams travels by value in the kernarg segment (~0.6 KB = 10 cache lines); the compiler reads
+// its fields with scalar loads in several DEPENDENT batches (load, wait, branch, load more ...), and every batch that touches a
+// new line is a scalar-cache miss served from L2 / HBM (the command processor has just written the segment): four to five
+// serial round trips of 0.3 - 0.5 us in front of the first global load of every wave (with the segment in host memory,
+// HIP_FORCE_DEV_KERNARG=0, the config-3 launch takes 16.3 instead of 11.3 us).  One dword of EVERY line is requested here in a
+// single batch, so the later batches hit the scalar cache.  BYTES = size of the kernel's argument block.
+template <int BYTES>
+__device__ __forceinline__ void qc_kernarg_touch() {
+    typedef __attribute__((address_space(4))) const int kint;
+    kint* k = (kint*)__builtin_amdgcn_kernarg_segment_ptr();
+    int w = 0;
+#pragma unroll
+    for (int o = 0; o < BYTES; o += 64) w += k[o / 4];
+    asm volatile("" ::"s"(w));   // keeps the loads; nothing depends on the sum
 }
 
 // Tail of an interval's Hessian block: the derivative integrators' entries d2/d(dx_i) dh = -mu_i (free timestep only) and the

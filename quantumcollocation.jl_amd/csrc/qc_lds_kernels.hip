@@ -63,6 +63,7 @@ __device__ inline double wave_sum(double v) {
 template <bool JAC, bool GWS>
 __global__ __launch_bounds__(GWS ? kThreadsGws : kThreadsLds) void qc_lds_pade_kernel(const QcParams P, const double* __restrict__ Z,
                                                                double* __restrict__ F, double* __restrict__ J) {
+    qc_kernarg_touch<sizeof(QcParams) + 64>();   // one batch of scalar-cache misses instead of one per use (qc_internal.h)
     constexpr int kThreads = GWS ? kThreadsGws : kThreadsLds;
     extern __shared__ __attribute__((aligned(16))) double lds_sm[];
     double* sm;
@@ -267,6 +268,7 @@ template <bool GWS>
 __global__ __launch_bounds__(GWS ? kThreadsGws : kThreadsLds) void qc_lds_pade_hess_kernel(const QcParams P, const double* __restrict__ Z,
                                                                     const double* __restrict__ Mu, double* __restrict__ H,
                                                                     int cj) {
+    qc_kernarg_touch<sizeof(QcParams) + 64>();   // one batch of scalar-cache misses instead of one per use (qc_internal.h)
     constexpr int kThreads = GWS ? kThreadsGws : kThreadsLds;
     extern __shared__ __attribute__((aligned(16))) double lds_sm[];
     double* sm;
@@ -532,6 +534,7 @@ __host__ __device__ inline LdsExpLayout exp_layout(const QcParams& P, int cj) {
 template <bool JAC, bool GWS>
 __global__ __launch_bounds__(GWS ? kThreadsGws : kThreadsLds) void qc_lds_exp_kernel(const QcParams P, const double* __restrict__ Z,
                                                               double* __restrict__ F, double* __restrict__ J, int cj) {
+    qc_kernarg_touch<sizeof(QcParams) + 64>();   // one batch of scalar-cache misses instead of one per use (qc_internal.h)
     constexpr int kThreads = GWS ? kThreadsGws : kThreadsLds;
     extern __shared__ __attribute__((aligned(16))) double lds_sm[];
     double* sm;

@@ -97,6 +97,7 @@ __device__ inline void e32_store_T(double* __restrict__ p, const v4d& x, int ld,
 template <bool JAC>
 __global__ __launch_bounds__(kE32Threads, 1) void qc_mfma32_exp_kernel(const QcParams P, const double* __restrict__ Z,
                                                                        double* __restrict__ F, double* __restrict__ J) {
+    qc_kernarg_touch<sizeof(QcParams) + 64>();   // one batch of scalar-cache misses instead of one per use (qc_internal.h)
     __shared__ __attribute__((aligned(16))) double GL[4 * 256];          // G (unscaled), A-layout tiles 2I+K
     __shared__ __attribute__((aligned(16))) double RL[2][4 * 256];       // the shared chain R / E, D-layout tiles 2K+J, double-buffered
     __shared__ double TS[8 * 16 * 17];                                   // per-wave transpose scratch

@@ -101,6 +101,7 @@ __device__ inline void store_T(double* __restrict__ p, const v4d& x, int J, int 
 template <bool DIAG>
 __global__ __launch_bounds__(kHThreads32, 1) void qc_mfma32_pade4_hess_kernel(const QcParams P, const int per_wg, const double* __restrict__ Z,
                                                                               const double* __restrict__ Mu, double* __restrict__ H) {
+    qc_kernarg_touch<sizeof(QcParams) + 64>();   // one batch of scalar-cache misses instead of one per use (qc_internal.h)
     __shared__ __attribute__((aligned(16))) double GL[8 * 256];                 // G: tiles 0-3 A-layout (2I+K), 4-7 B-layout (4+2K+J)
     __shared__ __attribute__((aligned(16))) double ML[2 * 256];                 // M tiles
     __shared__ __attribute__((aligned(16))) double DL[2 * 256];                 // D = U_t+1 - U_t tiles
@@ -144,8 +145,7 @@ __global__ __launch_bounds__(kHThreads32, 1) void qc_mfma32_pade4_hess_kernel(co
         const double* __restrict__ z1 = z0 + P.zdim;
         const double* __restrict__ mu = Mu + t * P.F_stride + P.F_off;
         double* __restrict__ Hb = H + (size_t)b * P.H_stride + P.H_off;
-        const double h = ft ? z0[P.off_dt] : P.dt_fixed;
-        const double hc1 = h * c1, hc2 = h * h * c2, c2h2 = 2.0 * c2 * h;
+        const double h = ft ? z0[P.off_dt] : P.dt_fixed;   // requested with the other loads; first used behind the barrier
         QC_STAMP_DECL;
         QC_STAMP(P, b, lane, 0);
 
@@ -194,6 +194,7 @@ __global__ __launch_bounds__(kHThreads32, 1) void qc_mfma32_pade4_hess_kernel(co
         }
         QC_STAMP(P, b, lane, 1);      // loads arrived, G half tile published
         __syncthreads();
+        const double hc1 = h * c1, hc2 = h * h * c2, c2h2 = 2.0 * c2 * h;
         QC_STAMP(P, b, lane, 2);
 
         // ---- phase 1 ---------------------------------------------------------------------------------------------

@@ -84,6 +84,7 @@ __device__ inline void store_T32_masked(double* __restrict__ p, const v4d& x, in
 template <bool JAC, bool DIAG, bool KET, bool SINGLE = false>
 __global__ __launch_bounds__(kThreads32, 2) void qc_mfma32_pade4_kernel(const QcParams P, const double* __restrict__ Z,
                                                                        double* __restrict__ F, double* __restrict__ J) {
+    qc_kernarg_touch<sizeof(QcParams) + 64>();   // one batch of scalar-cache misses instead of one per use (qc_internal.h)
     __shared__ __attribute__((aligned(16))) double GaL[2 * 4 * 256];                    // G tiles of the two intervals
     __shared__ __attribute__((aligned(16))) double ImgL[(kMU32 + 1) * 4 * 256];        // image tile t of matrix k at (k * 4 + t) * 256
     __shared__ double DerL[2 * 2 * kDF32 * 64];                                          // derivative-integrator data parked until the end
@@ -114,8 +115,7 @@ __global__ __launch_bounds__(kThreads32, 2) void qc_mfma32_pade4_kernel(const Qc
         const double* __restrict__ z1 = z0 + P.zdim;
         double* __restrict__ Jb = JAC ? J + (size_t)b * P.J_stride + P.J_off : nullptr;
         double* __restrict__ Fb = F ? F + (size_t)b * P.F_stride + P.F_off : nullptr;
-        const double h = ft ? z0[P.off_dt] : P.dt_fixed;
-        const double hc1 = h * c1, hc2 = h * h * c2;
+        const double h = ft ? z0[P.off_dt] : P.dt_fixed;   // requested with the other loads; first used behind the barriers
         QC_STAMP_DECL;
         QC_STAMP(P, b, lane, 0);
 
@@ -190,6 +190,7 @@ __global__ __launch_bounds__(kThreads32, 2) void qc_mfma32_pade4_kernel(const Qc
         }
         __syncthreads();
         QC_STAMP(P, b, lane, 2);
+        const double hc1 = h * c1, hc2 = h * h * c2;
         const double* __restrict__ GaS = GaL + slot * 1024;
 
         if (copy_role) {

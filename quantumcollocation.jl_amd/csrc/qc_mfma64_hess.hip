@@ -96,6 +96,7 @@ __device__ __forceinline__ void block_put(double* __restrict__ p, int n, int nc,
 __global__ __launch_bounds__(kHT64, 1) void qc_mfma64_pade4_hess_kernel(const QcParams P, const double* __restrict__ Z,
                                                                        const double* __restrict__ Mu, double* __restrict__ H,
                                                                        double* __restrict__ scratch) {
+    qc_kernarg_touch<sizeof(QcParams) + 64>();   // one batch of scalar-cache misses instead of one per use (qc_internal.h)
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double* __restrict__ Gs = sm + oG;
     double* __restrict__ Ms = sm + oM;

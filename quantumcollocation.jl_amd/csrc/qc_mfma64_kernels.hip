@@ -81,6 +81,7 @@ __device__ __forceinline__ void settle_fragment(double (&f)[16]) {
 template <bool JAC>
 __global__ __launch_bounds__(kThreads64, 1) void qc_mfma64_pade4_kernel(const QcParams P, const int parts, const double* __restrict__ Z,
                                                                        double* __restrict__ F, double* __restrict__ J) {
+    qc_kernarg_touch<sizeof(QcParams) + 64>();   // one batch of scalar-cache misses instead of one per use (qc_internal.h)
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double* __restrict__ Gs = sm + oG;
     double* __restrict__ Xs = sm + oX;

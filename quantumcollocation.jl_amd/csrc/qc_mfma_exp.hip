@@ -105,6 +105,7 @@ __device__ __forceinline__ void square_step(const v4d& Et, const v4d (&Kt)[M], v
 template <bool JAC, int kMU, int kW>
 __global__ __launch_bounds__(64 * kW, kW) void qc_mfma16_exp_kernel(const QcParams P, const double* __restrict__ Z, double* __restrict__ F,
                                                                     double* __restrict__ J) {
+    qc_kernarg_touch<sizeof(QcParams) + 64>();   // one batch of scalar-cache misses instead of one per use (qc_internal.h)
     __shared__ double scr_all[kW * (kMU + 1) * 16 * 17];      // per-wave transpose scratch: E and the kMU L_j tiles in one LDS round trip
     const int lane = threadIdx.x & 63;
     const int wv = kW > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;

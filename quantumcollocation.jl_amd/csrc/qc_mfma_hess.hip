@@ -36,6 +36,7 @@ template <int kHM, bool KET, bool BATCH>
 __global__ __launch_bounds__(64) void qc_mfma16_pade4_hess_kernel(const QcParams Pk, const double* __restrict__ Z,
                                                                   const double* __restrict__ Mu, double* __restrict__ H,
                                                                   const QcParams* __restrict__ Pb) {
+    qc_kernarg_touch<sizeof(QcParams) + 64>();   // one batch of scalar-cache misses instead of one per use (qc_internal.h)
     const QcParams& P = BATCH ? Pb[blockIdx.y] : Pk;      // BATCH: one launch for several handles (qc_mfma_kernels.hip)
     __shared__ double red[kHVals * kHStride];
     __shared__ double tscr[(kHM + 1) * 16 * 17];

@@ -50,6 +50,17 @@ constexpr int kIntervalsPerWG = QC_IPW;    // interval pairs per workgroup: wave
                                            // Measured on MI355X (bench.py, config 3): IPW 1 -> 11.55 us, 2 -> 11.60 us,
                                            // 4 -> 12.0 us per evaluation (the wider barrier couples four intervals).
 constexpr int kThreads = 128 * kIntervalsPerWG;
+#ifndef QC_HANDOFF_FLAGS
+#define QC_HANDOFF_FLAGS 0
+#endif
+// Hand-off of G / U_t / U_t+1 / the G_j images from a copy wave to its compute wave: 0 = workgroup barriers (two per interval),
+// 1 = one LDS flag per wave pair (the pairs of a workgroup are then independent of each other; one barrier at kernel entry).
+constexpr bool kFlags = QC_HANDOFF_FLAGS != 0;
+
+__device__ inline void flag_set(int* f, int v) { __hip_atomic_store(f, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ inline void flag_wait(int* f, int v) {
+    while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != v) __builtin_amdgcn_s_sleep(1);
+}
 constexpr int kMaxGrid = 1024;             // persistent beyond this many workgroups
 
 // A-layout image of generator `mat` (0 = drift): [matrix][pair(2)][lane(64)][2] doubles
@@ -136,6 +147,12 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
     const QcParams& P = BATCH ? Pb[blockIdx.y] : Pk;
     constexpr int kLdsBlock = kLdsGk + kMU * 256;
     __shared__ __attribute__((aligned(16))) double sm_all[JAC ? kIntervalsPerWG * kLdsBlock : 2];
+    __shared__ int hflag[2 * kIntervalsPerWG];   // per wave pair: [0] block published (sequence number), [1] block consumed
+    unsigned long long t_entry = 0;
+    if constexpr (DIAG) t_entry = __builtin_amdgcn_s_memrealtime();
+#ifndef QC_NO_KERNARG_TOUCH
+    qc_kernarg_touch<sizeof(QcParams) + 64>();
+#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = JAC ? __builtin_amdgcn_readfirstlane(tid >> 6) : 0;
@@ -157,8 +174,15 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
     const double c1 = P.c[1], c2 = P.c[2];
     const double* __restrict__ Gx = P.Gx;
     const v4d IdB = identity_B(g, j);
+    int* const fl = hflag + 2 * slot;
+    int seq = 0;
+    if constexpr (JAC && kFlags) {
+        if (tid < 2 * kIntervalsPerWG) hflag[tid] = 0;
+        __syncthreads();
+    }
 
     for (int vb = blockIdx.x; vb < n_wg; vb += gridDim.x) {
+        ++seq;
         const int b_raw = qc_xcd_remap(vb, n_wg) * ipw + slot;   // local interval of this wave pair
         const bool active = b_raw < P.n_int;                      // the last workgroup may be partly empty;
         const int b = active ? b_raw : P.n_int - 1;               // its idle waves still take part in the barriers
@@ -167,16 +191,17 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
         const double* __restrict__ z1 = z0 + P.zdim;
         double* __restrict__ Jb = JAC ? J + (size_t)b * P.J_stride + P.J_off : nullptr;
         double* __restrict__ Fb = F ? F + (size_t)b * P.F_stride + P.F_off : nullptr;
-        const double h = ft ? z0[P.off_dt] : P.dt_fixed;
-        const double hc1 = h * c1, hc2 = h * h * c2;
         QC_STAMP_DECL;
 
         if (JAC && role == 1) {
             // ================= copy wave =====================================================================
-            if (!active) { __syncthreads(); __syncthreads(); continue; }
+            if (!active) { if constexpr (!kFlags) { __syncthreads(); __syncthreads(); } continue; }
             __builtin_amdgcn_s_setprio(3);   // critical path: nothing reaches HBM before this wave's first store
+            if constexpr (DIAG) qc_ts_[9] = t_entry;
             QC_STAMP(P, b, lane, 0);
-            // every global load of the interval, in one batch
+            // every global load of the interval, in one batch -- the timestep INCLUDED: loaded (and multiplied) in front of
+            // the role branch it cost one full HBM round trip before any other load of the wave was even issued
+            const double h = ft ? z0[P.off_dt] : P.dt_fixed;
             const v4d u0 = load_state_tile<KET>(z0 + P.off_U, jc, nr, g);
             const v4d u1 = load_state_tile<KET>(z1 + P.off_U, jc, nr, g);
             double dxv[kDF], dfv[kDF];       // derivative integrators, register fast path (<= kDF of <= 64 rows)
@@ -190,16 +215,25 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
             }
             v4d gk[kMU];
             double ak[kMU];
+            if constexpr (DIAG) {   // when do the scalar loads (amplitudes, h) and when do the vector loads arrive?
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                QC_STAMP(P, b, lane, 10);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                QC_STAMP(P, b, lane, 11);
+            }
             const v4d Ga = assemble_G(P, Gx, z0, lane, gk, ak);
+            const double hc1 = h * c1, hc2 = h * h * c2;
             QC_STAMP(P, b, lane, 1);
             // hand-off to the compute wave
+            if constexpr (kFlags) { if (seq > 1) flag_wait(fl + 1, seq - 1); }   // persistent grid: the previous block has been consumed
             lds_put(sm + kLdsGa, lane, Ga);
             lds_put(sm + kLdsU0, lane, u0);
             lds_put(sm + kLdsU1, lane, u1);
 #pragma unroll
             for (int u = 0; u < kMU; ++u)
                 if (u < m) lds_put(sm + kLdsGk + u * 256, lane, gk[u]);
-            __syncthreads();
+            if constexpr (kFlags) { if (lane == 0) flag_set(fl, seq); }
+            else __syncthreads();
             bool skip = false;
             if constexpr (DIAG) skip = (P.dbg_skip & 1) != 0;
             if (!skip) {
@@ -257,20 +291,23 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
                     QC_STAMP(P, b, lane, 3);
                 }
                 QC_STAMP_FLUSH(P, b, lane, 0, 3);
+                QC_STAMP_FLUSH(P, b, lane, 9, 11);
             }
-            __syncthreads();   // the hand-off block is rewritten by the next interval of a persistent grid
+            if constexpr (!kFlags) __syncthreads();   // the hand-off block is rewritten by the next interval of a persistent grid
             continue;
         }
 
         // ===================== compute wave ===========================================================
-        if (!active) { if constexpr (JAC) { __syncthreads(); __syncthreads(); } continue; }
+        if (!active) { if constexpr (JAC && !kFlags) { __syncthreads(); __syncthreads(); } continue; }
         __builtin_amdgcn_s_setprio(1);
         QC_STAMP(P, b, lane, 4);
         QC_STAMP_CYCLES(13);
+        const double h = ft ? z0[P.off_dt] : P.dt_fixed;   // requested now, back long before the hand-off arrives
         v4d u0, u1, Ga;
         v4d gk[kMU];
         if constexpr (JAC) {
-            __syncthreads();                      // wait for the copy wave's hand-off
+            if constexpr (kFlags) flag_wait(fl, seq);
+            else __syncthreads();                 // wait for the copy wave's hand-off
             Ga = lds_get(sm + kLdsGa, lane);
             u0 = lds_get(sm + kLdsU0, lane);
             u1 = lds_get(sm + kLdsU1, lane);
@@ -280,6 +317,7 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
             double ak[kMU];
             Ga = assemble_G(P, Gx, z0, lane, gk, ak);
         }
+        const double hc1 = h * c1, hc2 = h * h * c2;
         QC_STAMP(P, b, lane, 5);
         bool skipc = false;
         if constexpr (DIAG) skipc = (P.dbg_skip & 2) != 0;
@@ -312,6 +350,9 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
                     }
                 }
                 mm16_multi<NB>(aB, bB, sB);
+            }
+            if constexpr (JAC && kFlags) {            // every tile of the hand-off block is in registers (or consumed): release it
+                if (gridDim.x < (unsigned)n_wg && lane == 0) flag_set(fl + 1, seq);
             }
             const v4d P2 = sB[0];                     // [G^2 D | G^2 S]
             QC_STAMP(P, b, lane, 6);
@@ -419,7 +460,7 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
             }
             QC_STAMP_FLUSH(P, b, lane, 4, 14);
         }
-        if constexpr (JAC) __syncthreads();   // pairs with the copy wave's end-of-interval barrier
+        if constexpr (JAC && !kFlags) __syncthreads();   // pairs with the copy wave's end-of-interval barrier
     }
 }
 

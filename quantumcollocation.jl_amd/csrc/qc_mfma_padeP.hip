@@ -55,6 +55,7 @@ __host__ __device__ inline int lds_doubles_padeP(int p) { return 1024 + 16 + 256
 template <bool JAC>
 __global__ __launch_bounds__(kPThreads) void qc_mfma16_padeP_kernel(const QcParams P, const double* __restrict__ Z,
                                                                    double* __restrict__ F, double* __restrict__ J) {
+    qc_kernarg_touch<sizeof(QcParams) + 64>();   // one batch of scalar-cache misses instead of one per use (qc_internal.h)
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int p = P.p, m = P.m;
     double* __restrict__ PartL = sm;

@@ -79,6 +79,7 @@ __host__ __device__ inline PHLayout ph_layout(int p, int m) {
 
 __global__ __launch_bounds__(kPHThreads, 4) void qc_mfma16_padeP_hess_kernel(const QcParams P, const double* __restrict__ Z,
                                                                         const double* __restrict__ Mu, double* __restrict__ H) {
+    qc_kernarg_touch<sizeof(QcParams) + 64>();   // one batch of scalar-cache misses instead of one per use (qc_internal.h)
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int p = P.p, m = P.m;
     const PHLayout L = ph_layout(p, m);

@@ -11,6 +11,7 @@
 //   hipcc -O3 --offload-arch=gfx950 tests/hip/store_floor.hip -o tests/hip/store_floor && tests/hip/store_floor
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <algorithm>
 #include <vector>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
@@ -21,10 +22,13 @@ constexpr int kJac = 5040, kF = 140, kZ = 147, kImg = 7 * 256;   // doubles
 
 template <int WAVES, int PROLOGUE, int MFMA>
 __global__ __launch_bounds__(WAVES * 64 < 128 ? 128 : WAVES * 64) void floor_kernel(const double* __restrict__ Z, const double* __restrict__ Gx,
-                                                                                  double* __restrict__ F, double* __restrict__ J, int n_int) {
+                                                                                  double* __restrict__ F, double* __restrict__ J, int n_int,
+                                                                                  unsigned long long* __restrict__ stamps) {
     __shared__ double hand[64];
     const int b = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (b >= n_int) return;
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0;
+    if (stamps) ts0 = __builtin_amdgcn_s_memrealtime();
     double v = (double)b;
     if (PROLOGUE) {
         if (PROLOGUE == 1 ? (w < WAVES) : (w == 0)) {
@@ -51,6 +55,7 @@ __global__ __launch_bounds__(WAVES * 64 < 128 ? 128 : WAVES * 64) void floor_ker
         }
     }
     if (w >= WAVES) return;
+    if (stamps) { __builtin_amdgcn_sched_barrier(0); asm volatile("" :: "v"(v)); ts1 = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); }
     double* Jb = J + (size_t)b * kJac;
     // 5040 doubles = 78.75 wave stores of 64 doubles: store s of the interval goes to wave s % WAVES
     for (int s = w; s < 79; s += WAVES) {
@@ -59,6 +64,13 @@ __global__ __launch_bounds__(WAVES * 64 < 128 ? 128 : WAVES * 64) void floor_ker
     }
     if (w == WAVES - 1)
         for (int i = lane; i < kF; i += 64) __builtin_nontemporal_store(v, F + (size_t)b * kF + i);
+    if (stamps) {
+        __builtin_amdgcn_sched_barrier(0);
+        ts2 = __builtin_amdgcn_s_memrealtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ts3 = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0 && w == 0) { stamps[b * 4] = ts0; stamps[b * 4 + 1] = ts1; stamps[b * 4 + 2] = ts2; stamps[b * 4 + 3] = ts3; }
+    }
 }
 
 template <int WAVES, int PROLOGUE, int MFMA>
@@ -66,18 +78,35 @@ static int run(const char* name, const double* dZ, const double* dG, std::vector
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const int reps = 600, nbuf = (int)Jb.size();
     const int threads = WAVES * 64 < 128 ? 128 : WAVES * 64;
-    for (int i = 0; i < 40; ++i) floor_kernel<WAVES, PROLOGUE, MFMA><<<n_int, threads>>>(dZ, dG, Fb[i % nbuf], Jb[i % nbuf], n_int);
+    for (int i = 0; i < 40; ++i) floor_kernel<WAVES, PROLOGUE, MFMA><<<n_int, threads>>>(dZ, dG, Fb[i % nbuf], Jb[i % nbuf], n_int, nullptr);
     CK(hipDeviceSynchronize());
     float best = 1e9f;
     for (int rep = 0; rep < 3; ++rep) {
         CK(hipEventRecord(e0));
-        for (int i = 0; i < reps; ++i) floor_kernel<WAVES, PROLOGUE, MFMA><<<n_int, threads>>>(dZ, dG, Fb[i % nbuf], Jb[i % nbuf], n_int);
+        for (int i = 0; i < reps; ++i) floor_kernel<WAVES, PROLOGUE, MFMA><<<n_int, threads>>>(dZ, dG, Fb[i % nbuf], Jb[i % nbuf], n_int, nullptr);
         CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         if (ms < best) best = ms;
     }
     const double us = best * 1e3 / reps, bytes = (double)n_int * (kJac + kF + kZ) * 8;
     printf("%-44s %6.2f us/launch  %5.2f TB/s  (frac of 8 TB/s %.3f)\n", name, us, bytes / us / 1e6, bytes / us / 1e6 / 8.0);
+    {   // in-kernel phases (s_memrealtime, 100 MHz) of wave 0 of every workgroup, in the middle of a run of launches
+        unsigned long long* dst; CK(hipMalloc(&dst, (size_t)n_int * 4 * 8));
+        for (int i = 0; i < 30; ++i) floor_kernel<WAVES, PROLOGUE, MFMA><<<n_int, threads>>>(dZ, dG, Fb[i % nbuf], Jb[i % nbuf], n_int, i == 29 ? dst : nullptr);
+        CK(hipDeviceSynchronize());
+        std::vector<unsigned long long> st((size_t)n_int * 4);
+        CK(hipMemcpy(st.data(), dst, st.size() * 8, hipMemcpyDeviceToHost));
+        CK(hipFree(dst));
+        unsigned long long t0 = ~0ull;
+        for (int b = 0; b < n_int; ++b) if (st[b * 4] < t0) t0 = st[b * 4];
+        const char* what[4] = {"start", "loads done", "stores issued", "drained"};
+        for (int k = 0; k < 4; ++k) {
+            std::vector<double> v(n_int);
+            for (int b = 0; b < n_int; ++b) v[b] = (double)(st[b * 4 + k] - t0) * 0.01;
+            std::sort(v.begin(), v.end());
+            printf("      %-14s min %5.2f  median %5.2f  max %5.2f us\n", what[k], v[0], v[n_int / 2], v[n_int - 1]);
+        }
+    }
     return 0;
 }
 

@@ -111,7 +111,7 @@ def test_oracle_reproduces_the_8f_golden_vectors(oracle):
     f, g, H = oracle.fidelity_value_grad_hess(roll[:, -1], gold["goal"])
     assert abs(f - float(gold["fidelity"])) < 1e-14
     np.testing.assert_allclose(g, gold["fidelity_grad"], rtol=1e-12, atol=1e-14)
-    tm = oracle.Terms(T=5, zdim=15, off_dt=14, reg_index=gold["terms_index"], reg_R=gold["terms_R"], D=1.5, n_mt=4)
+    tm = oracle.Terms(T=5, zdim=15, off_dt=14, reg_index=gold["terms_index"], reg_R=gold["terms_R"], D=1.5, n_mt=4, dt_scaled=True)   # the golden vectors were made with the dt-scaled weighting
     assert abs(oracle.terms_value(tm, Zv) - float(gold["terms_J"])) < 1e-15
     np.testing.assert_allclose(oracle.terms_grad(tm, Zv), gold["terms_grad"], rtol=1e-14, atol=1e-16)
     np.testing.assert_allclose(oracle.terms_hess(tm, Zv), gold["terms_hess"], rtol=1e-14, atol=1e-16)
