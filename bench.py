@@ -69,6 +69,97 @@ def cpu_baseline(qc, inp, seconds: float):
             "sample": f"{n} full F+dF evaluations of the same T={prob.T} workload in {el:.1f} s (oracle/qc_oracle.c, OpenMP)"}
 
 
+PCIE_PEAK_GBS = 63.0    # MI355X_MICROARCH.md: PCIe Gen5 x16 host link
+
+
+def host_visible_times(dyn, Zh, reps=30):
+    """PCIe-inclusive times of the host-buffer entry points (what the reference's consumer, a CPU Ipopt process, sees):
+    qc_eval_F_jac, qc_eval_hess, qc_eval_F with caller-owned numpy arrays, milliseconds per call."""
+    dims = dyn.dims
+    Fh, Jh = np.empty(int(dims.F_len)), np.empty(int(dims.jac_nnz))
+    Hh, mu = np.empty(int(dims.hess_nnz)), np.ones(int(dims.n_rows))
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    out = {"F_dF_ms": timed(lambda: dyn.F_dF(Zh, out=(Fh, Jh))), "F_ms": timed(lambda: dyn.F(Zh, out=Fh))}
+    if dims.hess_nnz:
+        out["hess_ms"] = timed(lambda: dyn.mu_d2F(Zh, mu, out=Hh))
+    return out
+
+
+def host_visible_record(qc, inp, dyn, Zh, cpu_value):
+    """The `host_visible` object of the bench line (never `value`: the metric is device-resident)."""
+    dims = dyn.dims
+    t = host_visible_times(dyn, Zh)
+    # bytes that cross PCIe per F + dF call: the knots in, the residuals and the COMPACT Jacobian form out (one copy of the
+    # N replicated -F / B blocks; the host replicates them into the caller's array)
+    n = 2 * inp.system.levels
+    nc = inp.system.levels
+    compact = int(dims.jac_nnz_interval) - 2 * (nc - 1) * n * n
+    pcie_bytes = 8 * (inp.traj.dim * (int(dims.n_intervals) + 1) + (int(dims.ddim) + compact) * int(dims.n_intervals))
+    rec = dict(t)
+    rec["evals_per_s"] = 1e3 / t["F_dF_ms"]
+    rec["speedup_vs_cpu_baseline"] = (1e3 / t["F_dF_ms"]) / cpu_value if cpu_value else None
+    rec["pcie_bytes_per_eval"] = pcie_bytes
+    rec["pcie_GBps_achieved"] = pcie_bytes / (t["F_dF_ms"] * 1e-3) / 1e9
+    rec["pcie_GBps_peak"] = PCIE_PEAK_GBS
+    if "hess_ms" in t:
+        rec["ms_per_ipopt_iter"] = t["F_dF_ms"] + t["hess_ms"] + t["F_ms"]   # F + dF, mu_d2F, one line-search F
+    return rec
+
+
+def config5_record(qc, dev_index, steps=300):
+    """BASELINE config 5 (4-qubit QFT, T = 500, the 2N = 32 MFMA path) on the device: north_star asks for the MFMA
+    utilisation of the large-n case.  FLOP counts are the kernels' own MFMA counts (624 / 544
+    v_mfma_f64_16x16x4_f64 per interval, 2048 FLOP each; the counter run is profiles/r02_mfma_util_c5.json)."""
+    inp = qc.config_inputs(5)
+    dyn = qc.QuantumDynamics(inp.integrators, inp.traj, device=dev_index)
+    dev = torch.device("cuda", dev_index)
+    dims = dyn.dims
+    n_int = int(dims.n_intervals)
+    rng = np.random.default_rng(5)
+    Z = torch.from_numpy(inp.traj.datavec).to(dev)
+    mu = torch.from_numpy(rng.standard_normal(int(dims.n_rows))).to(dev)
+    nb = 6     # 6 x 153 MB of values > the 256 MiB Infinity Cache
+    Fb = [torch.empty(int(dims.F_len), dtype=torch.float64, device=dev) for _ in range(nb)]
+    Jb = [torch.empty(int(dims.jac_nnz), dtype=torch.float64, device=dev) for _ in range(nb)]
+    Hb = [torch.empty(int(dims.hess_nnz), dtype=torch.float64, device=dev) for _ in range(nb)]
+    st = torch.cuda.current_stream(dev)
+
+    def timed(fn):
+        for i in range(20):
+            fn(i)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        for i in range(steps):
+            fn(i)
+        e1.record(st)
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / steps
+
+    jac_us = timed(lambda i: dyn.F_dF_device(Z, Fb[i % nb], Jb[i % nb], st))
+    hess_us = timed(lambda i: dyn.mu_d2F_device(Z, mu, Hb[i % nb], st))
+    zdim, ddim = inp.traj.dim, int(dims.ddim)
+    jac_bytes = 8 * (zdim * (n_int + 1) + (ddim + int(dims.jac_nnz_interval)) * n_int)
+    hess_bytes = 8 * (zdim * (n_int + 1) + (ddim + int(dims.hess_nnz_interval)) * n_int)
+    peak_tf = 78.6       # f64 MFMA: 256 CUs x 4 SIMDs x 2048 FLOP / 64 cycles x 2.4 GHz
+    rec = {"workload": qc.CONFIGS[5].description + f"; T={inp.traj.T}", "kernels": list(dyn.kernel_names),
+           "F_dF_us": jac_us, "F_dF_hbm_frac": jac_bytes / (jac_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+           "F_dF_mfma_frac": 624 * n_int * 2048 / (jac_us * 1e-6) / 1e12 / peak_tf,
+           "hess_us": hess_us, "hess_hbm_frac": hess_bytes / (hess_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+           "hess_mfma_frac": 544 * n_int * 2048 / (hess_us * 1e-6) / 1e12 / peak_tf,
+           "mfma_peak_TFLOPs": peak_tf}
+    dyn.close()
+    return rec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -86,7 +177,9 @@ def main():
     ap.add_argument("--streams", type=int, default=0, help="also time the same steps issued round-robin on S streams "
                     "(independent evaluations overlapping their launch/drain phases; reported as an extra field, never `value`)")
     ap.add_argument("--host-visible", action=argparse.BooleanOptionalAction, default=True,
-                    help="also time qc_eval_F_jac with host buffers (PCIe-inclusive; an extra field, never `value`)")
+                    help="also time the host-buffer entry points (PCIe-inclusive; the `host_visible` object, never `value`)")
+    ap.add_argument("--config5", action=argparse.BooleanOptionalAction, default=True,
+                    help="at N = 1 also run BASELINE config 5 on the device and report its HBM / MFMA fractions (`config5` object)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -220,16 +313,12 @@ def main():
         torch.cuda.synchronize()
         extra["pipelined_streams"] = args.streams
         extra["pipelined_ms_per_step"] = (time.perf_counter() - p0) / args.steps * 1e3
-    if args.host_visible and world == 1:
-        # PCIe-inclusive rate of the host-buffer entry point (what a CPU Ipopt consumer sees); reported beside, never as, `value`.
-        # (Page-locking the caller's arrays with hipHostRegister was tried: 0.80 vs 0.82 ms, not worth an API.)
-        Fh, Jh = np.empty(int(dims.F_len)), np.empty(int(dims.jac_nnz))
-        for _ in range(3):
-            dyn.F_dF_into(Zh, Fh, Jh)
-        h0 = time.perf_counter()
-        for _ in range(20):
-            dyn.F_dF_into(Zh, Fh, Jh)
-        extra["host_visible_ms_per_eval"] = (time.perf_counter() - h0) / 20 * 1e3
+    rccl_ranks = None
+    if world > 1:
+        # self-verification of the N > 1 run: the number of ranks as the collective library itself counts them
+        ones = torch.ones(1, dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        rccl_ranks = int(round(float(ones.item())))
     if args.allgather and world > 1:
         # SURVEY 8(e) "report both": the device-resident full Jacobian on every GPU (RCCL all-gather over xGMI), timed
         # outside the metric's region.  A failure here must not lose the metric line.
@@ -252,6 +341,37 @@ def main():
             extra["allgather_GB_per_gpu_received"] = (world - 1) * pad.numel() * 8 / 1e9
         except Exception as exc:   # noqa: BLE001
             extra["allgather_error"] = repr(exc)[:200]
+
+    cpu_rec = None
+    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+        cpu_rec = cpu_baseline(qc, inp, args.cpu_seconds)
+    host_rec = None
+    if args.host_visible:
+        try:
+            if world == 1:
+                host_rec = host_visible_record(qc, inp, dyn, Zh, cpu_rec["value"] if cpu_rec else None)
+                host_rec["devices"] = [dev_index]
+            else:
+                # The reference's consumer is ONE process: rank 0 builds the in-library multi-device handle
+                # (qc_create_multi over all N GPUs) and times the same host-buffer calls on the whole T = 1000 N
+                # trajectory while the other ranks wait at the barrier; N PCIe links work in parallel.
+                barrier()
+                if rank == 0:
+                    devs = list(range(world)) if backend == "nccl" else [r % torch.cuda.device_count() for r in range(world)]
+                    md = qc.QuantumDynamics(inp.integrators, inp.traj, devices=devs, kernel=args.kernel)
+                    host_rec = host_visible_record(qc, inp, md, Zh, None)
+                    host_rec["devices"] = devs
+                    host_rec["evals_per_s_T1000_equivalent"] = host_rec["evals_per_s"] * (T_total - 1) / (T_PER_GPU - 1)
+                    md.close()
+                barrier()
+        except Exception as exc:   # noqa: BLE001  (must not lose the metric line)
+            host_rec = {"error": repr(exc)[:300]}
+    c5 = None
+    if args.config5 and world == 1 and rank == 0 and args.config in (3, 4):
+        try:
+            c5 = config5_record(qc, dev_index)
+        except Exception as exc:   # noqa: BLE001
+            c5 = {"error": repr(exc)[:300]}
 
     total_intervals = (T_total - 1)
     t1000_equiv = total_intervals / (T_PER_GPU - 1) if args.config in (3, 4) else float(world)
@@ -293,8 +413,16 @@ def main():
                          "kernel_us_event_pairs": kernel_us_pairs, "step_us_stream_events": kernel_us_stream},
         }
         line.update(extra)
-        if world == 1 and args.cpu_seconds > 0:
-            line["cpu_baseline"] = cpu_baseline(qc, inp, args.cpu_seconds)
+        line["value_device_resident_evals_per_s"] = value
+        if rccl_ranks is not None:
+            line["rccl_ranks"] = rccl_ranks
+            line["collective_backend"] = backend
+        if host_rec is not None:
+            line["host_visible"] = host_rec
+        if c5 is not None:
+            line["config5"] = c5
+        if cpu_rec is not None:
+            line["cpu_baseline"] = cpu_rec
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -368,6 +368,17 @@ extern "C" int qc_create(const qc_desc* d, qc_handle** out) {
     std::vector<double> G((size_t)(P.m + 1) * n2);
     memcpy(G.data(), d->G_drift, n2 * sizeof(double));
     if (P.m) memcpy(G.data() + n2, d->G_drives, (size_t)P.m * n2 * sizeof(double));
+    {   // exact antisymmetry of every generator (G = iso(-iH) of a Hermitian H): lets the Hessian kernels skip the transposed images
+        bool anti = true;
+        for (int mat = 0; anti && mat <= P.m; ++mat) {
+            const double* A = G.data() + (size_t)mat * n2;
+            for (int c = 0; anti && c < P.n; ++c)
+                for (int r = 0; r <= c; ++r)
+                    if (A[(size_t)c * P.n + r] != -A[(size_t)r * P.n + c]) { anti = false; break; }
+        }
+        h->prm.antisym = anti ? 1 : 0;
+        if (const char* e = getenv("QC_NO_ANTISYM")) if (atoi(e)) h->prm.antisym = 0;   // diagnostic: force the general path
+    }
     QC_HIP_C(hipMalloc((void**)&h->dG, G.size() * sizeof(double)));
     QC_HIP_C(hipMemcpy(h->dG, G.data(), G.size() * sizeof(double), hipMemcpyHostToDevice));
     h->prm.G = h->dG;

@@ -31,6 +31,8 @@ struct QcParams {
     long long t_begin;       // first interval of this handle
     int n_int;               // number of intervals of this handle
     int jac_nnz, hess_nnz;   // per interval (own values; hess_nnz excludes the padding)
+    int antisym;             // every generator is exactly antisymmetric (Hermitian Hamiltonians): G_k^T = -G_k bit for bit, so the
+                             // transposed (B-layout) generator images need not be loaded (Hessian kernels)
     int copies;              // copies of the -F / B blocks the MFMA order-4 kernels write (nc; 1 = compact form of the host path)
     int h_pad;               // explicit zeros this handle writes after its hess_nnz values (line alignment of the interval blocks)
     // placement of this handle's rows / values inside the problem's vectors (composed problems: several integrator

@@ -32,7 +32,9 @@ __device__ inline v4d sel(bool c, const v4d& a, const v4d& b) {
     return v4d{c ? a[0] : b[0], c ? a[1] : b[1], c ? a[2] : b[2], c ? a[3] : b[3]};
 }
 
-template <int kHM, bool KET, bool BATCH>
+// ANTI: every generator is exactly antisymmetric (QcParams.antisym): B-layout(G_k) = A-layout(G_k^T) = -A-layout(G_k), so the
+// transposed images are not loaded at all (half the L2 -> CU traffic of the interval's prologue, 48 registers fewer)
+template <int kHM, bool KET, bool BATCH, bool ANTI>
 __global__ __launch_bounds__(64) void qc_mfma16_pade4_hess_kernel(const QcParams Pk, const double* __restrict__ Z,
                                                                   const double* __restrict__ Mu, double* __restrict__ H,
                                                                   const QcParams* __restrict__ Pb) {
@@ -86,18 +88,24 @@ __global__ __launch_bounds__(64) void qc_mfma16_pade4_hess_kernel(const QcParams
         v4d gA[kHM], gB[kHM];
         double ak[kHM];
         v4d Ga = load_img(GxA, 0, lane);
-        v4d Gb = load_img(GxB, 0, lane);                    // B-layout of G = A-layout of G^T, assembled like Ga (no identity product)
+        v4d Gb;                                             // B-layout of G = A-layout of G^T, assembled like Ga (no identity product)
+        if constexpr (!ANTI) Gb = load_img(GxB, 0, lane);
 #pragma unroll
         for (int u = 0; u < kHM; ++u) {
             const int k = u < m ? u : (m > 0 ? m - 1 : 0);
             gA[u] = load_img(GxA, m > 0 ? k + 1 : 0, lane);
-            gB[u] = load_img(GxB, m > 0 ? k + 1 : 0, lane);
+            if constexpr (!ANTI) gB[u] = load_img(GxB, m > 0 ? k + 1 : 0, lane);
             ak[u] = (u < m) ? z0[P.off_a + k] : 0.0;
         }
 #pragma unroll
         for (int u = 0; u < kHM; ++u) {
             Ga += ak[u] * gA[u];
-            Gb += ak[u] * gB[u];
+            if constexpr (!ANTI) Gb += ak[u] * gB[u];
+        }
+        if constexpr (ANTI) {
+            Gb = -Ga;
+#pragma unroll
+            for (int u = 0; u < kHM; ++u) gB[u] = -gA[u];
         }
         const double hc1 = h * c1, hc2 = h * h * c2, c2h2 = 2.0 * c2 * h;
 
@@ -244,16 +252,23 @@ bool qc_mfma_hess_supported(const QcParams& P) {
 hipError_t qc_launch_mfma16_hess_batch(const QcParams& P0, const QcParams* dPb, int count, const double* dZ, const double* dMu, double* dH,
                                        hipStream_t st) {
     const int grid = P0.n_int < 4096 ? P0.n_int : 4096;
+    // (the batched launch reads each handle's parameters from device memory; it keeps the general form)
 #define QC_B(HM_)                                                                                                                      \
     do {                                                                                                                            \
         if (P0.nc != 8 || P0.n != 16)                                                                                               \
-            hipLaunchKernelGGL((qc_mfma16_pade4_hess_kernel<HM_, true, true>), dim3(grid, count), dim3(64), 0, st, P0, dZ, dMu, dH, dPb); \
+            hipLaunchKernelGGL((qc_mfma16_pade4_hess_kernel<HM_, true, true, false>), dim3(grid, count), dim3(64), 0, st, P0, dZ, dMu, dH, dPb); \
         else                                                                                                                        \
-            hipLaunchKernelGGL((qc_mfma16_pade4_hess_kernel<HM_, false, true>), dim3(grid, count), dim3(64), 0, st, P0, dZ, dMu, dH, dPb); \
+            hipLaunchKernelGGL((qc_mfma16_pade4_hess_kernel<HM_, false, true, false>), dim3(grid, count), dim3(64), 0, st, P0, dZ, dMu, dH, dPb); \
     } while (0)
     if (P0.m <= 2) QC_B(2); else if (P0.m <= 4) QC_B(4); else if (P0.m <= 6) QC_B(6); else QC_B(8);
 #undef QC_B
     return hipGetLastError();
+}
+
+template <int HM, bool KET>
+static void launch_hess16(const QcParams& P, const double* dZ, const double* dMu, double* dH, hipStream_t st, int grid) {
+    if (P.antisym) hipLaunchKernelGGL((qc_mfma16_pade4_hess_kernel<HM, KET, false, true>), dim3(grid), dim3(64), 0, st, P, dZ, dMu, dH, nullptr);
+    else hipLaunchKernelGGL((qc_mfma16_pade4_hess_kernel<HM, KET, false, false>), dim3(grid), dim3(64), 0, st, P, dZ, dMu, dH, nullptr);
 }
 
 hipError_t qc_launch_mfma_hess(const QcParams& P, const double* dZ, const double* dMu, double* dH, hipStream_t st) {
@@ -262,15 +277,15 @@ hipError_t qc_launch_mfma_hess(const QcParams& P, const double* dZ, const double
     if (P.n > 16) return qc_launch_mfma32_hess(P, dZ, dMu, dH, st);
     const int grid = P.n_int < 4096 ? P.n_int : 4096;
     if (P.nc != 8 || P.n != 16) {
-        if (P.m <= 2) hipLaunchKernelGGL((qc_mfma16_pade4_hess_kernel<2, true, false>), dim3(grid), dim3(64), 0, st, P, dZ, dMu, dH, nullptr);
-        else if (P.m <= 4) hipLaunchKernelGGL((qc_mfma16_pade4_hess_kernel<4, true, false>), dim3(grid), dim3(64), 0, st, P, dZ, dMu, dH, nullptr);
-        else if (P.m <= 6) hipLaunchKernelGGL((qc_mfma16_pade4_hess_kernel<6, true, false>), dim3(grid), dim3(64), 0, st, P, dZ, dMu, dH, nullptr);
-        else hipLaunchKernelGGL((qc_mfma16_pade4_hess_kernel<8, true, false>), dim3(grid), dim3(64), 0, st, P, dZ, dMu, dH, nullptr);
+        if (P.m <= 2) launch_hess16<2, true>(P, dZ, dMu, dH, st, grid);
+        else if (P.m <= 4) launch_hess16<4, true>(P, dZ, dMu, dH, st, grid);
+        else if (P.m <= 6) launch_hess16<6, true>(P, dZ, dMu, dH, st, grid);
+        else launch_hess16<8, true>(P, dZ, dMu, dH, st, grid);
         return hipGetLastError();
     }
-    if (P.m <= 2) hipLaunchKernelGGL((qc_mfma16_pade4_hess_kernel<2, false, false>), dim3(grid), dim3(64), 0, st, P, dZ, dMu, dH, nullptr);
-    else if (P.m <= 4) hipLaunchKernelGGL((qc_mfma16_pade4_hess_kernel<4, false, false>), dim3(grid), dim3(64), 0, st, P, dZ, dMu, dH, nullptr);
-    else if (P.m <= 6) hipLaunchKernelGGL((qc_mfma16_pade4_hess_kernel<6, false, false>), dim3(grid), dim3(64), 0, st, P, dZ, dMu, dH, nullptr);
-    else hipLaunchKernelGGL((qc_mfma16_pade4_hess_kernel<8, false, false>), dim3(grid), dim3(64), 0, st, P, dZ, dMu, dH, nullptr);
+    if (P.m <= 2) launch_hess16<2, false>(P, dZ, dMu, dH, st, grid);
+    else if (P.m <= 4) launch_hess16<4, false>(P, dZ, dMu, dH, st, grid);
+    else if (P.m <= 6) launch_hess16<6, false>(P, dZ, dMu, dH, st, grid);
+    else launch_hess16<8, false>(P, dZ, dMu, dH, st, grid);
     return hipGetLastError();
 }

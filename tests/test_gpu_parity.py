@@ -431,6 +431,21 @@ def test_hessian_fixture_golden_and_exponential_unsupported(qc, oracle):
     dyn.close()
 
 
+def test_antisymmetric_generator_shortcut_is_bit_identical(qc, monkeypatch):
+    """Hermitian Hamiltonians give exactly antisymmetric generators; the Hessian kernel then derives the transposed generator
+    images by negation instead of loading them (QcParams.antisym).  Same bits as the general path (QC_NO_ANTISYM=1)."""
+    inp = qc.config_inputs(3, T=40)
+    Z = inp.traj.datavec
+    out = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("QC_NO_ANTISYM", flag)
+        dyn = qc.QuantumDynamics(inp.integrators, inp.traj)
+        mu = np.random.default_rng(9).standard_normal(dyn.dims.n_rows)
+        out.append(dyn.mu_d2F(Z, mu))
+        dyn.close()
+    np.testing.assert_array_equal(out[0], out[1])
+
+
 @pytest.mark.parametrize("cfg,T", [(3, 1000), (5, 500)])
 def test_full_size_hessian_properties(qc, oracle, cfg, T):
     """Configs 3 (T=1000) and 5 (T=500) at full size: linearity in mu, directional second derivative against the Jacobian,
