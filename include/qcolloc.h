@@ -180,6 +180,10 @@ int qc_iso_vec_to_operator(int32_t N, const double* iso_vec, double* U_re, doubl
  * (2N x 2N, column-major), i.e. QuantumSystem's G_drift / G_drives entries. */
 int qc_generator_from_hamiltonian(int32_t N, const double* H_re, const double* H_im, double* G);
 
+/* Eigen-decomposition A = V diag(w) V' of a complex Hermitian d x d matrix (column-major, re / im planes), d <= 64: the
+ * host-side set-up step of the free-phase fidelity (phase operators, qc_fidelity_desc), exposed so that it can be checked. */
+int qc_hermitian_eig(int32_t d, const double* A_re, const double* A_im, double* w, double* V_re, double* V_im);
+
 /* Pade coefficients c_0..c_p (p = order/2) of the diagonal approximant. out has p+1 entries. */
 int qc_pade_coefficients(int32_t order, double* out);
 
@@ -291,6 +295,33 @@ int qc_fidelity_create(int32_t N, const double* goal_iso, const int32_t* subspac
 #define QC_FID_KET 1
 #define QC_FID_DENSITY 2
 int qc_fidelity_create_kind(int32_t kind, int32_t N, const double* goal_ket_iso, int32_t device, qc_fidelity** out);
+/* Descriptor form: everything above plus the two choices that PiccoloQuantumObjects 0.3 (not vendored) makes and this
+ * repository cannot inspect, and the free-phase fidelity of the minimum-time / smooth-pulse templates:
+ *   form      QC_FID_FORM_ABS   F = |tr(U_goal' U)| / n      (the reference's docstring, unitary_smooth_pulse_problem.jl:23-28; default)
+ *             QC_FID_FORM_ABS2  F = |tr(U_goal' U)|^2 / n^2
+ *   n_phases  K > 0: `iso_vec_unitary_free_phase_fidelity(U, U_goal, phases, phase_operators; subspace)` and
+ *             `FinalUnitaryFreePhaseFidelityConstraint` (unitary_minimum_time_problem.jl:86-100, phases = global
+ *             variables `traj.global_data[phase_name]`, trajectory_initialization.jl:370-380):
+ *                 F(U, phi) = |tr(U_goal' R(phi) U)| / n,   R(phi) = (x)_k exp(i phi_k Op_k)   (Julia's reduce(kron, ...)),
+ *             Op_k Hermitian d_k x d_k with prod d_k = subspace size (Paulis Z for virtual-Z corrections,
+ *             unitary_smooth_pulse_problem.jl:345-346).  The evaluation input is then [U~ (2N^2) ; phi (K)], gradient and
+ *             Hessian cover all 2N^2 + K variables (qc_fidelity_input_len). */
+#define QC_FID_FORM_ABS 0
+#define QC_FID_FORM_ABS2 1
+typedef struct qc_fidelity_desc {
+    int32_t kind;               /* QC_FID_UNITARY | QC_FID_KET | QC_FID_DENSITY (subspace / form / phases: unitary only) */
+    int32_t N;
+    const double* goal_iso;     /* unitary: iso-vec of U_goal (2N^2); ket / density: [Re psi_goal; Im psi_goal] */
+    const int32_t* subspace;    /* 0-based level indices, or NULL = all levels */
+    int32_t n_sub;
+    int32_t form;               /* QC_FID_FORM_* */
+    int32_t n_phases;           /* K, 0..16 */
+    int32_t device;
+    const int32_t* phase_dims;  /* K dimensions d_k */
+    const double* phase_ops;    /* operator k after operator k-1: d_k x d_k real plane, then d_k x d_k imaginary plane, column-major */
+} qc_fidelity_desc;
+int qc_fidelity_create_desc(const qc_fidelity_desc* d, qc_fidelity** out);
+int32_t qc_fidelity_input_len(const qc_fidelity* h);   /* 2N^2 + K (state length for kets / density operators) */
 void qc_fidelity_destroy(qc_fidelity* h);
 const char* qc_fidelity_last_error(const qc_fidelity* h);
 /* host buffers; any of fidelity / infidelity / grad / hess may be NULL */

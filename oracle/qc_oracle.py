@@ -698,3 +698,82 @@ def density_fidelity_value_grad(rho_iso: np.ndarray, goal_ket_iso: np.ndarray):
     P = np.outer(g, g.conj())
     gr = np.concatenate([P.real.reshape(-1, order="F"), P.imag.reshape(-1, order="F")])
     return float(gr @ rho_iso), gr
+
+
+# --------------------------------------------------------------------------------------------
+#  Free-phase fidelity (reference unitary_minimum_time_problem.jl:86-100: `iso_vec_unitary_free_phase_fidelity(U_T, U_G,
+#  phases, phase_operators; subspace)`, `FinalUnitaryFreePhaseFidelityConstraint`; phases are global variables of the
+#  trajectory, trajectory_initialization.jl:370-380).  [RECALL] PiccoloQuantumObjects 0.3:
+#      R(phi) = reduce(kron, [exp(i phi_k Op_k)]),   F = fidelity(R(phi) U, U_goal)   (phase gates applied AFTER the pulse)
+#  Dense restatement over x = [u ; phi]: t = tr(G' R U) on the subspace, dt/dphi_k = i tr(G' O_k R U),
+#  d2t/dphi_k dphi_l = -tr(G' O_k O_l R U), O_k = I (x) .. Op_k .. (x) I.  `form`: "abs" |t| / n (docstring), "abs2" |t|^2 / n^2.
+# --------------------------------------------------------------------------------------------
+def free_phase_operator(phases, phase_ops) -> np.ndarray:
+    R = np.ones((1, 1), dtype=complex)
+    for ph, Op in zip(phases, phase_ops):
+        R = np.kron(R, expm_taylor(1j * ph * np.asarray(Op, dtype=complex)))
+    return R
+
+
+def _embedded_phase_ops(phase_ops):
+    dims = [np.asarray(Op).shape[0] for Op in phase_ops]
+    out = []
+    for k, Op in enumerate(phase_ops):
+        M = np.ones((1, 1), dtype=complex)
+        for j, d in enumerate(dims):
+            M = np.kron(M, np.asarray(Op, dtype=complex) if j == k else np.eye(d, dtype=complex))
+        out.append(M)
+    return out
+
+
+def free_phase_fidelity_value_grad_hess(x: np.ndarray, goal_iso: np.ndarray, phase_ops, subspace=None, form: str = "abs"):
+    """F, dF/dx, d2F/dx2 (dense) over x = [u (2N^2) ; phi (K)]."""
+    N = int(round(math.sqrt(goal_iso.size / 2)))
+    s, K = 2 * N * N, len(phase_ops)
+    sub = list(range(N)) if subspace is None else list(subspace)
+    n = len(sub)
+    u, phi = np.asarray(x[:s], dtype=float), np.asarray(x[s:], dtype=float)
+    G = iso_vec_to_operator(goal_iso)[np.ix_(sub, sub)]
+    R = free_phase_operator(phi, phase_ops) if K else np.eye(n, dtype=complex)
+    Ok = _embedded_phase_ops(phase_ops)
+    assert R.shape == (n, n), "the phase operators' dimensions must multiply to the subspace size"
+
+    def coeff_vectors(A):
+        """t = tr(A' U_sub) = a . u + i b . u  ->  (a, b) over the iso-vec u."""
+        a, b = np.zeros(s), np.zeros(s)
+        for jb, j in enumerate(sub):
+            for ia, i in enumerate(sub):
+                c = np.conj(A[ia, jb])                 # coefficient of U_ij
+                re, im = j * 2 * N + i, j * 2 * N + N + i
+                a[re], b[re] = c.real, c.imag          # Re U_ij
+                a[im], b[im] = -c.imag, c.real         # Im U_ij enters as i c
+        return a, b
+
+    P = s + K
+    a1, b1 = np.zeros(P), np.zeros(P)
+    a2, b2 = np.zeros((P, P)), np.zeros((P, P))
+    a1[:s], b1[:s] = coeff_vectors(R.conj().T @ G)
+    t = a1[:s] @ u + 1j * (b1[:s] @ u)
+    for k in range(K):
+        ak, bk = coeff_vectors((1j * Ok[k] @ R).conj().T @ G)
+        a1[s + k], b1[s + k] = ak @ u, bk @ u
+        a2[:s, s + k] = a2[s + k, :s] = ak
+        b2[:s, s + k] = b2[s + k, :s] = bk
+        for l in range(K):
+            akl, bkl = coeff_vectors((-(Ok[k] @ Ok[l]) @ R).conj().T @ G)
+            a2[s + k, s + l], b2[s + k, s + l] = akl @ u, bkl @ u
+    tr, ti = t.real, t.imag
+    S = tr * tr + ti * ti
+    q = np.outer(a1, a1) + np.outer(b1, b1) + tr * a2 + ti * b2
+    if form == "abs2":
+        return S / n ** 2, 2.0 * (tr * a1 + ti * b1) / n ** 2, 2.0 * q / n ** 2
+    Fv = math.sqrt(S) / n
+    grad = (tr * a1 + ti * b1) / (n * n * Fv)
+    return Fv, grad, q / (n * n * Fv) - np.outer(grad, grad) / Fv
+
+
+def unitary_free_phase_fidelity(U: np.ndarray, U_goal: np.ndarray, phases, phase_ops, subspace=None, form: str = "abs") -> float:
+    """Direct statement on operators (no derivatives): |tr(U_goal' R(phi) U)| / n on the subspace."""
+    sub = list(range(U.shape[0])) if subspace is None else list(subspace)
+    t = np.trace(U_goal[np.ix_(sub, sub)].conj().T @ free_phase_operator(phases, phase_ops) @ U[np.ix_(sub, sub)])
+    return abs(t) ** 2 / len(sub) ** 2 if form == "abs2" else abs(t) / len(sub)

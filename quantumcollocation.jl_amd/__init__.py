@@ -15,7 +15,8 @@ from .isomorphisms import (density_to_iso_vec, iso_generator, iso_operator, iso_
 from .named_trajectory import NamedTrajectory
 from .objectives import (DensityOperatorPureStateInfidelityObjective, FinalQuantumStateFidelityConstraint, FinalUnitaryFidelityConstraint,
                          QuantumStateObjective, iso_fidelity, MinimumTimeObjective, QuadraticRegularizer, TimeStepsAllEqualConstraint,
-                         TrajectoryObjective, UnitaryInfidelityObjective, iso_vec_unitary_fidelity)
+                         TrajectoryObjective, UnitaryInfidelityObjective, iso_vec_unitary_fidelity, iso_vec_unitary_free_phase_fidelity,
+                         UnitaryFreePhaseInfidelityObjective, FinalUnitaryFreePhaseFidelityConstraint)
 from .problems import (CONFIGS, config_inputs, density_operator_smooth_pulse_inputs, multi_qubit_system, quantum_state_sampling_inputs, quantum_state_smooth_pulse_inputs,
                        unitary_sampling_inputs, unitary_smooth_pulse_inputs)
 from .quantum_systems import OpenQuantumSystem, QuantumSystem
@@ -28,7 +29,8 @@ __all__ = [
     "QuantumStateExponentialIntegrator", "quantum_state_smooth_pulse_inputs", "quantum_state_sampling_inputs", "unitary_sampling_inputs", "ComposedQuantumDynamics", "split_groups", "operator_to_iso_vec", "iso_vec_to_operator",
     "iso_generator", "pade_coefficients", "GATES", "PAULIS", "operator_from_string", "config_inputs",
     "unitary_smooth_pulse_inputs", "multi_qubit_system", "CONFIGS", "initialize_trajectory",
-    "unitary_geodesic", "iso_vec_unitary_fidelity", "UnitaryInfidelityObjective", "FinalUnitaryFidelityConstraint", "QuantumStateObjective", "FinalQuantumStateFidelityConstraint", "DensityOperatorPureStateInfidelityObjective", "iso_fidelity",
+    "unitary_geodesic", "iso_vec_unitary_fidelity", "iso_vec_unitary_free_phase_fidelity", "UnitaryFreePhaseInfidelityObjective",
+    "FinalUnitaryFreePhaseFidelityConstraint", "UnitaryInfidelityObjective", "FinalUnitaryFidelityConstraint", "QuantumStateObjective", "FinalQuantumStateFidelityConstraint", "DensityOperatorPureStateInfidelityObjective", "iso_fidelity",
     "QuadraticRegularizer", "MinimumTimeObjective", "TrajectoryObjective", "TimeStepsAllEqualConstraint",
     "OpenQuantumSystem", "DensityOperatorExponentialIntegrator", "density_operator_smooth_pulse_inputs",
     "density_to_iso_vec", "iso_vec_to_density", "iso_operator", "unitary_rollout", "rollout", "open_rollout", "unitary_rollout_fidelity", "make_desc", "desc_dims", "desc_structures", "state_row_offset", "QCollocError",

@@ -37,6 +37,7 @@ QC_MAX_DERIV = 8
 QC_FID_UNITARY, QC_FID_KET, QC_FID_DENSITY = 0, 1, 2
 QC_REG_PLAIN = 0
 QC_REG_DT_SCALED = 1
+QC_FID_FORM_ABS, QC_FID_FORM_ABS2 = 0, 1
 QC_ROWS_STACKED = 0
 QC_ROWS_BY_COMPONENT = 1
 
@@ -95,6 +96,21 @@ class qc_dims_t(C.Structure):
         ("Z_len", C.c_int64),
         ("kernel", C.c_int32),
         ("reserved", C.c_int32),
+    ]
+
+
+class qc_fidelity_desc(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32),
+        ("N", C.c_int32),
+        ("goal_iso", _c_double_p),
+        ("subspace", C.POINTER(C.c_int32)),
+        ("n_sub", C.c_int32),
+        ("form", C.c_int32),
+        ("n_phases", C.c_int32),
+        ("device", C.c_int32),
+        ("phase_dims", C.POINTER(C.c_int32)),
+        ("phase_ops", _c_double_p),
     ]
 
 
@@ -159,6 +175,9 @@ SYMBOLS = {
     "qc_sizeof_dims": (C.c_int64, []),
     "qc_sizeof_terms_desc": (C.c_int64, []),
     "qc_fidelity_create": (C.c_int, [C.c_int32, _c_double_p, C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.POINTER(_H)]),
+    "qc_fidelity_create_desc": (C.c_int, [C.POINTER(qc_fidelity_desc), C.POINTER(_H)]),
+    "qc_fidelity_input_len": (C.c_int32, [_H]),
+    "qc_hermitian_eig": (C.c_int, [C.c_int32, _c_double_p, _c_double_p, _c_double_p, _c_double_p, _c_double_p]),
     "qc_fidelity_create_kind": (C.c_int, [C.c_int32, C.c_int32, _c_double_p, C.c_int32, C.POINTER(_H)]),
     "qc_fidelity_destroy": (None, [_H]),
     "qc_fidelity_last_error": (C.c_char_p, [_H]),

@@ -25,20 +25,38 @@ from .named_trajectory import NamedTrajectory
 
 
 class _Fidelity:
-    def __init__(self, goal_iso: np.ndarray, subspace: Optional[Sequence[int]] = None, device: int = 0, kind: str = "unitary"):
+    def __init__(self, goal_iso: np.ndarray, subspace: Optional[Sequence[int]] = None, device: int = 0, kind: str = "unitary",
+                 form: str = "abs", phase_operators: Optional[Sequence[np.ndarray]] = None):
         goal_iso = np.ascontiguousarray(goal_iso, dtype=np.float64)
         self._h = C.c_void_p()
+        self.K = 0
         if kind == "unitary":
             self.N = int(round((goal_iso.size / 2) ** 0.5))
             self.s = 2 * self.N * self.N
             if goal_iso.size != self.s:
                 raise ValueError("goal must be an iso-vec of length 2 N^2")
             sub = None if subspace is None else np.ascontiguousarray(subspace, dtype=np.int32)
-            rc = _lib.lib.qc_fidelity_create(self.N, _lib.dptr(goal_iso), None if sub is None else sub.ctypes.data_as(C.POINTER(C.c_int32)),
-                                             0 if sub is None else sub.size, device, C.byref(self._h))
+            d = _lib.qc_fidelity_desc()
+            d.kind, d.N, d.goal_iso = _lib.QC_FID_UNITARY, self.N, _lib.dptr(goal_iso)
+            d.subspace = None if sub is None else sub.ctypes.data_as(C.POINTER(C.c_int32))
+            d.n_sub = 0 if sub is None else sub.size
+            d.form = {"abs": _lib.QC_FID_FORM_ABS, "abs2": _lib.QC_FID_FORM_ABS2}[form]
+            d.device = device
+            keep = []
+            if phase_operators is not None and len(phase_operators):
+                ops = [np.asarray(Op, dtype=complex) for Op in phase_operators]
+                dims = np.ascontiguousarray([Op.shape[0] for Op in ops], dtype=np.int32)
+                planes = np.ascontiguousarray(np.concatenate([np.concatenate([Op.real.reshape(-1, order="F"), Op.imag.reshape(-1, order="F")])
+                                                              for Op in ops]))
+                d.n_phases = self.K = len(ops)
+                d.phase_dims = dims.ctypes.data_as(C.POINTER(C.c_int32))
+                d.phase_ops = _lib.dptr(planes)
+                keep = [dims, planes]
+            rc = _lib.lib.qc_fidelity_create_desc(C.byref(d), C.byref(self._h))
+            del keep
         else:   # "ket": state psi~ (2N);  "density": state rho~ (2N^2) against the pure goal |psi_goal><psi_goal|
-            if subspace is not None:
-                raise ValueError("subspace applies to unitary fidelities only")
+            if subspace is not None or phase_operators is not None or form != "abs":
+                raise ValueError("subspace, form and free phases apply to unitary fidelities only")
             if goal_iso.size % 2:
                 raise ValueError("the goal ket must be an iso-vec [Re psi; Im psi]")
             self.N = goal_iso.size // 2
@@ -47,14 +65,15 @@ class _Fidelity:
                                                   device, C.byref(self._h))
         if rc != _lib.QC_OK:
             raise _lib.QCollocError(rc, _lib.lib.qc_fidelity_last_error(None).decode())
+        self.P = self.s + self.K          # input length: [state ; free phases]
 
     def eval(self, u: np.ndarray, grad: bool = True, hess: bool = True):
         u = np.ascontiguousarray(u, dtype=np.float64)
-        if u.size != self.s:
-            raise ValueError(f"state has length {u.size}, expected {self.s}")
+        if u.size != self.P:
+            raise ValueError(f"input has length {u.size}, expected {self.P} (state{' + phases' if self.K else ''})")
         F, L = C.c_double(), C.c_double()
-        g = np.empty(self.s) if grad else None
-        H = np.empty(self.s * (self.s + 1) // 2) if hess else None
+        g = np.empty(self.P) if grad else None
+        H = np.empty(self.P * (self.P + 1) // 2) if hess else None
         rc = _lib.lib.qc_fidelity_eval(self._h, _lib.dptr(u), C.byref(F), C.byref(L), _lib.dptr(g) if grad else None,
                                        _lib.dptr(H) if hess else None)
         if rc != _lib.QC_OK:
@@ -73,10 +92,23 @@ class _Fidelity:
             pass
 
 
-def iso_vec_unitary_fidelity(U_T: np.ndarray, U_G: np.ndarray, subspace: Optional[Sequence[int]] = None, device: int = 0) -> float:
-    f = _Fidelity(U_G, subspace, device)
+def iso_vec_unitary_fidelity(U_T: np.ndarray, U_G: np.ndarray, subspace: Optional[Sequence[int]] = None, device: int = 0,
+                             form: str = "abs") -> float:
+    """`form`: "abs" = |tr(U_G' U_T)| / n (the reference's docstring), "abs2" = |tr|^2 / n^2 (INTEGRATION.md, table of choices)."""
+    f = _Fidelity(U_G, subspace, device, form=form)
     try:
         return f.eval(U_T, grad=False, hess=False)[0]
+    finally:
+        f.close()
+
+
+def iso_vec_unitary_free_phase_fidelity(U_T: np.ndarray, U_G: np.ndarray, phases, phase_operators, subspace=None, device: int = 0,
+                                        form: str = "abs") -> float:
+    """|tr(U_G' R(phi) U_T)| / n with R(phi) = kron_k exp(i phi_k Op_k) (reference unitary_minimum_time_problem.jl:86-90)."""
+    f = _Fidelity(U_G, subspace, device, form=form, phase_operators=phase_operators)
+    try:
+        return f.eval(np.concatenate([np.asarray(U_T, dtype=np.float64), np.asarray(phases, dtype=np.float64).ravel()]),
+                      grad=False, hess=False)[0]
     finally:
         f.close()
 
@@ -85,25 +117,41 @@ class _FinalKnotTerm:
     _ALIASES = {}
     _KIND = "unitary"
 
-    def __init__(self, state_name: str, traj: NamedTrajectory, subspace, device, goal=None):
+    def __init__(self, state_name: str, traj: NamedTrajectory, subspace, device, goal=None, form: str = "abs",
+                 phase_name: Optional[str] = None, phase_operators=None):
         self.traj = traj
         self.s = len(traj.components[state_name])
         self.first = (traj.T - 1) * traj.dim + traj.offset(state_name)     # 0-based global index of the final state
         goal = traj.goal.get(state_name) if goal is None else goal
         if goal is None:
             raise ValueError(f"trajectory has no goal for {state_name}")
-        self._f = _Fidelity(np.asarray(goal, dtype=np.float64), subspace, device, kind=type(self)._KIND)
+        self._f = _Fidelity(np.asarray(goal, dtype=np.float64), subspace, device, kind=type(self)._KIND, form=form,
+                            phase_operators=phase_operators)
         if self._f.s != self.s:
             raise ValueError(f"component {state_name} has length {self.s}, the goal implies {self._f.s}")
-        self.state_indices = np.arange(self.first, self.first + self.s)
-        r, c = np.triu_indices(self.s)
+        idx = np.arange(self.first, self.first + self.s)
+        if self._f.K:
+            # the free phases are global variables behind the knots: Z = [vec(data) ; global_data...]  (trajectory_initialization.jl:370-380)
+            off = traj.T * traj.dim
+            for name, v in traj.global_data.items():
+                if name == phase_name:
+                    break
+                off += v.size
+            else:
+                raise ValueError(f"trajectory has no global component {phase_name}")
+            if traj.global_data[phase_name].size != self._f.K:
+                raise ValueError("one phase per phase operator")
+            idx = np.concatenate([idx, np.arange(off, off + self._f.K)])
+        self.state_indices = idx           # variables of the term: the final state (and the free phases)
+        P = idx.size
+        r, c = np.triu_indices(P)
         # column-major upper triangle: entry (i <= j) at j(j+1)/2 + i
         order = np.lexsort((r, c))
-        self.hess_structure = (self.first + r[order], self.first + c[order])
+        self.hess_structure = (idx[r[order]], idx[c[order]])
 
     def _u(self, Z):
         Z = np.asarray(Z, dtype=np.float64)
-        return Z[self.first:self.first + self.s]
+        return Z[self.state_indices]
 
     def __getattr__(self, name):
         al = type(self)._ALIASES
@@ -120,8 +168,8 @@ class UnitaryInfidelityObjective(_FinalKnotTerm):
     `getattr(obj, "∇L")` / `"∂²L"` resolve to the same members."""
     _ALIASES = {"∇L": "grad_L", "∂²L": "hess_L", "∂²L_structure": "hess_structure"}
 
-    def __init__(self, state_name: str, traj: NamedTrajectory, Q: float = 100.0, subspace=None, device: int = 0):
-        super().__init__(state_name, traj, subspace, device)
+    def __init__(self, state_name: str, traj: NamedTrajectory, Q: float = 100.0, subspace=None, device: int = 0, form: str = "abs"):
+        super().__init__(state_name, traj, subspace, device, form=form)
         self.Q = float(Q)
 
     def L(self, Z) -> float:
@@ -140,8 +188,8 @@ class FinalUnitaryFidelityConstraint(_FinalKnotTerm):
     """g(Z) = F(U~_T) - value >= 0 (one row).  `g`, `dg` (values on `state_indices`), `mu_d2g(Z, mu)`."""
     _ALIASES = {"∂g": "dg", "μ∂²g": "mu_d2g", "μ∂²g_structure": "hess_structure"}
 
-    def __init__(self, state_name: str, value: float, traj: NamedTrajectory, subspace=None, device: int = 0):
-        super().__init__(state_name, traj, subspace, device)
+    def __init__(self, state_name: str, value: float, traj: NamedTrajectory, subspace=None, device: int = 0, form: str = "abs"):
+        super().__init__(state_name, traj, subspace, device, form=form)
         self.value = float(value)
         self.dim = 1
 
@@ -153,6 +201,26 @@ class FinalUnitaryFidelityConstraint(_FinalKnotTerm):
 
     def mu_d2g(self, Z, mu) -> np.ndarray:
         return float(np.asarray(mu).ravel()[0]) * self._f.eval(self._u(Z), grad=False, hess=True)[3]
+
+
+class UnitaryFreePhaseInfidelityObjective(UnitaryInfidelityObjective):
+    """Q * |1 - F(U~_T, phi)| with free phases (reference unitary_smooth_pulse_problem.jl:138-143): variables = the final state
+    and the K global phases `traj.global_data[phase_name]`."""
+
+    def __init__(self, state_name: str, phase_name: str, phase_operators, traj: NamedTrajectory, Q: float = 100.0, subspace=None,
+                 device: int = 0, form: str = "abs"):
+        _FinalKnotTerm.__init__(self, state_name, traj, subspace, device, form=form, phase_name=phase_name, phase_operators=phase_operators)
+        self.Q = float(Q)
+
+
+class FinalUnitaryFreePhaseFidelityConstraint(FinalUnitaryFidelityConstraint):
+    """g(Z) = F(U~_T, phi) - value >= 0 (reference unitary_minimum_time_problem.jl:95-100)."""
+
+    def __init__(self, state_name: str, phase_name: str, phase_operators, value: float, traj: NamedTrajectory, subspace=None,
+                 device: int = 0, form: str = "abs"):
+        _FinalKnotTerm.__init__(self, state_name, traj, subspace, device, form=form, phase_name=phase_name, phase_operators=phase_operators)
+        self.value = float(value)
+        self.dim = 1
 
 
 def iso_fidelity(psi_iso: np.ndarray, psi_goal_iso: np.ndarray, device: int = 0) -> float:

@@ -185,3 +185,117 @@ def test_ket_and_density_objectives_through_the_host_mirror(qc, oracle):
     np.testing.assert_allclose(dobj.grad_L(Zd), -np.sign(1 - Fd) * 10.0 * gd, rtol=1e-12, atol=1e-13)
     for o in (obj, con, dobj):
         o.close()
+
+
+# ------------------------------------------------------------------------------------------------
+#  Free-phase fidelity (unitary_minimum_time_problem.jl:86-100) and the |tr|^2 / n^2 form
+# ------------------------------------------------------------------------------------------------
+ZP = np.array([[1, 0], [0, -1]], dtype=complex)
+XP = np.array([[0, 1], [1, 0]], dtype=complex)
+FREE_PHASE_CASES = [(2, None, [ZP]), (4, None, [ZP, ZP]), (4, None, [ZP, 0.3 * XP + 0.5 * ZP]), (9, [0, 1, 3, 4], [ZP, ZP]),
+                    (16, None, [ZP, ZP, ZP, ZP]), (8, None, [np.diag([0.0, 1.0, 2.0, 3.0]).astype(complex), ZP])]
+
+
+def test_hermitian_eig_helper(qc):
+    """qc_hermitian_eig (host-side set-up of the phase operators): A = V diag(w) V', V unitary."""
+    L = qc._lib
+    rng = np.random.default_rng(0)
+    for d in (1, 2, 3, 4, 7, 16):
+        A = rng.standard_normal((d, d)) + 1j * rng.standard_normal((d, d))
+        A = (A + A.conj().T) / 2
+        for M in (A, np.diag(rng.standard_normal(d)).astype(complex)):
+            Ar, Ai = np.asfortranarray(M.real), np.asfortranarray(M.imag)
+            w, Vr, Vi = np.empty(d), np.empty((d, d), order="F"), np.empty((d, d), order="F")
+            assert L.lib.qc_hermitian_eig(d, L.dptr(Ar), L.dptr(Ai), L.dptr(w), L.dptr(Vr), L.dptr(Vi)) == 0
+            V = Vr + 1j * Vi
+            assert np.abs(V @ np.diag(w) @ V.conj().T - M).max() < 1e-13 and np.abs(V.conj().T @ V - np.eye(d)).max() < 1e-13
+            np.testing.assert_allclose(np.sort(w), np.linalg.eigvalsh(M), atol=1e-13)
+
+
+@pytest.mark.parametrize("case", range(4))
+@pytest.mark.parametrize("form", ["abs", "abs2"])
+def test_free_phase_fidelity_oracle(oracle, case, form):
+    """Oracle: value against the operator-level statement, derivatives against central differences, known answers:
+    a Y gate is an X gate followed by a virtual Z rotation (the reference's own test, unitary_smooth_pulse_problem.jl:342-374)."""
+    N, sub, ops = FREE_PHASE_CASES[case]
+    rng = np.random.default_rng(case)
+    Q = rand_unitary(N, rng)
+    U = Q @ (np.eye(N) + 0.1 * (rng.standard_normal((N, N)) + 1j * rng.standard_normal((N, N))))
+    goal, u = oracle.operator_to_iso_vec(Q), oracle.operator_to_iso_vec(U)
+    phi = rng.standard_normal(len(ops))
+    x = np.concatenate([u, phi])
+    F, g, H = oracle.free_phase_fidelity_value_grad_hess(x, goal, ops, sub, form)
+    assert abs(F - oracle.unitary_free_phase_fidelity(U, Q, phi, ops, sub, form)) < 1e-14
+    eps = 1e-6
+    f = lambda y: oracle.free_phase_fidelity_value_grad_hess(y, goal, ops, sub, form)
+    gfd = np.array([(f(x + eps * e)[0] - f(x - eps * e)[0]) / (2 * eps) for e in np.eye(x.size)])
+    Hfd = np.array([(f(x + eps * e)[1] - f(x - eps * e)[1]) / (2 * eps) for e in np.eye(x.size)])
+    np.testing.assert_allclose(g, gfd, rtol=1e-7, atol=2e-9)
+    np.testing.assert_allclose(H, Hfd, rtol=1e-6, atol=2e-8)
+    np.testing.assert_allclose(H, H.T, atol=1e-15)
+    if case == 0:
+        Y = np.array([[0, -1j], [1j, 0]])
+        fy = lambda ph: oracle.unitary_free_phase_fidelity(XP, Y, [ph], [ZP])
+        assert fy(0.0) < 1e-15 and abs(fy(np.pi / 2) - 1.0) < 1e-14
+        # no phase operators: the plain fidelity
+        F0, g0, H0 = oracle.free_phase_fidelity_value_grad_hess(u, goal, [], sub, "abs")
+        Fp, gp, Hp = oracle.fidelity_value_grad_hess(u, goal, sub)
+        assert abs(F0 - Fp) < 1e-15
+        np.testing.assert_allclose(g0, gp, atol=1e-15)
+        np.testing.assert_allclose(H0, Hp, atol=1e-14)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", range(len(FREE_PHASE_CASES)))
+@pytest.mark.parametrize("form", ["abs", "abs2"])
+def test_free_phase_fidelity_kernel(qc, oracle, case, form):
+    """qc_fidelity_create_desc with free phases (eigenbasis form on the device) against the oracle's dense Kronecker /
+    matrix-exponential form: value, gradient and Hessian over [U~ ; phi]."""
+    from qcolloc_amd.objectives import _Fidelity
+    N, sub, ops = FREE_PHASE_CASES[case]
+    rng = np.random.default_rng(30 + case)
+    Q = rand_unitary(N, rng)
+    goal = oracle.operator_to_iso_vec(Q)
+    u = oracle.operator_to_iso_vec(rand_unitary(N, rng)) + 0.05 * rng.standard_normal(2 * N * N)
+    x = np.concatenate([u, rng.standard_normal(len(ops))])
+    f = _Fidelity(goal, sub, form=form, phase_operators=ops)
+    assert f.P == x.size == qc._lib.lib.qc_fidelity_input_len(f._h)
+    F, L, grad, H = f.eval(x)
+    Fr, gr, Hr = oracle.free_phase_fidelity_value_grad_hess(x, goal, ops, sub, form)
+    assert abs(F - Fr) < 1e-12 * max(1, abs(Fr)) and abs(L - abs(1 - Fr)) < 1e-12
+    np.testing.assert_allclose(grad, gr, rtol=1e-10, atol=1e-12)
+    r, c = np.triu_indices(x.size)
+    order = np.lexsort((r, c))
+    np.testing.assert_allclose(H, Hr[r[order], c[order]], rtol=1e-10, atol=1e-11 * max(1.0, np.abs(Hr).max()))
+    assert abs(qc.iso_vec_unitary_free_phase_fidelity(u, goal, x[u.size:], ops, subspace=sub, form=form) - Fr) < 1e-12
+    f.close()
+    # the squared form without phases, and the plain form through the descriptor entry point
+    fp = _Fidelity(goal, sub, form=form)
+    F, L, grad, H = fp.eval(u)
+    Fr, gr, Hr = oracle.free_phase_fidelity_value_grad_hess(u, goal, [], sub, form)
+    assert abs(F - Fr) < 1e-13
+    np.testing.assert_allclose(grad, gr, rtol=1e-11, atol=1e-13)
+    r, c = np.triu_indices(u.size)
+    order = np.lexsort((r, c))
+    np.testing.assert_allclose(H, Hr[r[order], c[order]], rtol=1e-10, atol=1e-12 * max(1.0, np.abs(Hr).max()))
+    fp.close()
+
+
+@pytest.mark.gpu
+def test_free_phase_descriptor_errors(qc, oracle):
+    L = qc._lib
+    import ctypes as C
+    goal = oracle.operator_to_iso_vec(np.eye(4, dtype=complex))
+    d = L.qc_fidelity_desc()
+    d.kind, d.N, d.goal_iso, d.n_phases = L.QC_FID_UNITARY, 4, L.dptr(goal), 1
+    dims = np.array([2], dtype=np.int32)                     # 2 != subspace size 4
+    ops = np.concatenate([ZP.real.reshape(-1), ZP.imag.reshape(-1)])
+    d.phase_dims, d.phase_ops = dims.ctypes.data_as(C.POINTER(C.c_int32)), L.dptr(ops)
+    h = C.c_void_p()
+    assert L.lib.qc_fidelity_create_desc(C.byref(d), C.byref(h)) == L.QC_ERR_INVALID
+    dims[0] = 4
+    bad = np.arange(32, dtype=np.float64)                    # not Hermitian
+    d.phase_ops = L.dptr(bad)
+    assert L.lib.qc_fidelity_create_desc(C.byref(d), C.byref(h)) == L.QC_ERR_INVALID
+    d.n_phases, d.form = 0, 7
+    assert L.lib.qc_fidelity_create_desc(C.byref(d), C.byref(h)) == L.QC_ERR_INVALID

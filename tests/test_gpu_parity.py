@@ -1291,3 +1291,81 @@ def test_shard_of_a_layout_with_odd_block_sizes(qc, oracle):
         np.testing.assert_allclose(dF.cpu().numpy()[dd:4 * dd], Fr[dd:4 * dd], rtol=1e-10, atol=1e-12)
         assert not dJ.cpu().numpy()[:nnz].any() and not dJ.cpu().numpy()[4 * nnz:].any()
         h.close()
+
+
+def test_config5_callback_set_on_one_stream(qc, oracle):
+    """BASELINE config 5 as the reference's evaluator sees it (UnitaryMinimumTimeProblem, unitary_minimum_time_problem.jl:67-111):
+    dynamics F / dF / mu_d2F, FinalUnitaryFreePhaseFidelityConstraint (value, gradient, Hessian), MinimumTimeObjective and
+    the regularisers -- every device-side callback of one Ipopt iteration enqueued on ONE stream at the full T = 500, then
+    compared with the oracles (C restatement for the full-size dynamics, numpy for a window and for the terms)."""
+    import ctypes as C
+    import oracle.qc_oracle_c as oc
+    L = qc._lib
+    inp = qc.config_inputs(5)
+    T, N = inp.traj.T, 16
+    rng = np.random.default_rng(55)
+    phase_ops = [np.diag([1.0, -1.0]).astype(complex)] * 4
+    phases = rng.standard_normal(4)
+    comps = {name: inp.traj[name] for name in inp.traj.names}
+    traj = qc.NamedTrajectory(comps, controls=inp.traj.controls, timestep=inp.traj.timestep, goal=inp.traj.goal,
+                              global_data={"ϕ": phases})
+    integ = [qc.UnitaryPadeIntegrator("Ũ⃗", "a", inp.system, traj, order=4), qc.DerivativeIntegrator("a", "da", traj),
+             qc.DerivativeIntegrator("da", "dda", traj)]
+    dyn = qc.QuantumDynamics(integ, traj)
+    assert dyn.kernel_names == ("mfma32-pade4", "mfma32-pade4-hess") and dyn.dims.n_cols == traj.dim * T + 4
+    con = qc.FinalUnitaryFreePhaseFidelityConstraint("Ũ⃗", "ϕ", phase_ops, 0.99, traj)
+    terms = qc.TrajectoryObjective(qc.QuadraticRegularizer("a", traj, 1e-2) + qc.QuadraticRegularizer("da", traj, 1e-2)
+                                   + qc.QuadraticRegularizer("dda", traj, 1e-2) + qc.MinimumTimeObjective(traj, 1.0), traj)
+    Zh = traj.datavec
+    mu_h = rng.standard_normal(int(dyn.dims.n_rows))
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        Z = torch.from_numpy(Zh).cuda()
+        mu = torch.from_numpy(mu_h).cuda()
+        dF = torch.empty(int(dyn.dims.F_len), dtype=torch.float64, device="cuda")
+        dJ = torch.empty(int(dyn.dims.jac_nnz), dtype=torch.float64, device="cuda")
+        dH = torch.empty(int(dyn.dims.hess_nnz), dtype=torch.float64, device="cuda")
+        P = con._f.P
+        x = torch.cat([Z[torch.from_numpy(con.state_indices).cuda()]])          # final state and the phases, gathered on the device
+        fval = torch.empty(2, dtype=torch.float64, device="cuda")
+        fgrad = torch.empty(P, dtype=torch.float64, device="cuda")
+        fhess = torch.empty(P * (P + 1) // 2, dtype=torch.float64, device="cuda")
+        tJ = torch.empty(1, dtype=torch.float64, device="cuda")
+        tg = torch.empty(Zh.size, dtype=torch.float64, device="cuda")
+        nnz_t = C.c_int64()
+        L.check(L.lib.qc_terms_hess_nnz(terms._h, C.byref(nnz_t)))
+        tH = torch.empty(nnz_t.value, dtype=torch.float64, device="cuda")
+        sp = C.c_void_p(st.cuda_stream)
+        dyn.F_dF_device(Z, dF, dJ, st)
+        dyn.mu_d2F_device(Z, mu, dH, st)
+        L.check(L.lib.qc_fidelity_eval_dev(con._f._h, C.c_void_p(x.data_ptr()), C.c_void_p(fval.data_ptr()), C.c_void_p(fgrad.data_ptr()),
+                                           C.c_void_p(fhess.data_ptr()), sp))
+        L.check(L.lib.qc_terms_eval_dev(terms._h, C.c_void_p(Z.data_ptr()), C.c_void_p(tJ.data_ptr()), C.c_void_p(tg.data_ptr()),
+                                        C.c_void_p(tH.data_ptr()), sp))
+    st.synchronize()
+    # dynamics against the C restatement at full size, and against the numpy oracle on a window
+    prob = problem_from_inputs(type("I", (), {"integrators": integ, "traj": traj})())
+    co = oc.COracle(prob)
+    Fr, Jr = co.F_dF(Zh)
+    assert_close(dF.cpu().numpy(), Fr, "config 5 F")
+    assert_close(dJ.cpu().numpy(), Jr, "config 5 dF")
+    assert_close_h(dH.cpu().numpy(), co.mu_d2F(Zh, mu_h), "config 5 mu_d2F")
+    nnz = int(dyn.dims.jac_nnz_interval)
+    assert_close(dJ.cpu().numpy()[250 * nnz:251 * nnz], oracle.dF(prob, Zh, 250, 251), "config 5 dF window")
+    # fidelity constraint with free phases
+    Fv, gv, Hv = oracle.free_phase_fidelity_value_grad_hess(Zh[con.state_indices], traj.goal["Ũ⃗"], phase_ops)
+    assert abs(float(fval[0]) - Fv) < 1e-12
+    np.testing.assert_allclose(fgrad.cpu().numpy(), gv, rtol=1e-10, atol=1e-12)
+    r, c = np.triu_indices(P)
+    order = np.lexsort((r, c))
+    np.testing.assert_allclose(fhess.cpu().numpy(), Hv[r[order], c[order]], rtol=1e-10, atol=1e-11)
+    assert abs(con.g(Zh)[0] - (Fv - 0.99)) < 1e-12
+    # objective terms
+    idx = np.concatenate([np.asarray(traj.components[n]) for n in ("a", "da", "dda")])
+    tm = oracle.Terms(T=T, zdim=traj.dim, off_dt=traj.offset("Δt"), reg_index=np.sort(idx), reg_R=np.full(idx.size, 1e-2), D=1.0, n_mt=T - 1,
+                      global_dim=4)
+    assert abs(float(tJ[0]) - oracle.terms_value(tm, Zh)) < 1e-10 * max(1.0, abs(oracle.terms_value(tm, Zh)))
+    np.testing.assert_allclose(tg.cpu().numpy(), oracle.terms_grad(tm, Zh), rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(tH.cpu().numpy(), oracle.terms_hess(tm, Zh), rtol=1e-12, atol=1e-14)
+    for o_ in (dyn, con, terms):
+        o_.close()
