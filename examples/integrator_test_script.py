@@ -50,13 +50,13 @@ def harness(name, H_drift, H_drives, U_goal, T, dt):
         controls=("da",), timestep="Δt", goal={"Ũ⃗": qc.operator_to_iso_vec(U_goal)})
     P = qc.UnitaryPadeIntegrator("Ũ⃗", "a", system, Z)
     D = qc.DerivativeIntegrator("a", "da", Z)
-    dynamics = qc.QuantumDynamics([P, D], Z)
+    # the script's `g` component is a state WITHOUT an integrator: rows = "by_component" puts every integrator's rows at its state
+    # component's position and leaves g's rows structurally empty, so the shapes are exactly the script's
+    dynamics = qc.QuantumDynamics([P, D], Z, rows="by_component")
     shape = (Z.dims.states * (Z.T - 1), Z.dim * Z.T + Z.global_dim)
-    # the script's `g` component is a state without an integrator: the library stacks the rows of the integrators that exist
-    # (8 + 2 per interval), which fits inside the script's dense() shape (Z.dims.states = 12 rows per interval)
-    assert int(dynamics.dims.n_rows) <= shape[0] and int(dynamics.dims.n_cols) == shape[1]
+    assert (int(dynamics.dims.n_rows), int(dynamics.dims.n_cols)) == shape
     z = Z.datavec
-    mu = np.ones(int(dynamics.dims.n_rows))        # the script's ones(Z.dims.states * (Z.T - 1)) is longer than the rows that exist
+    mu = np.ones(Z.dims.states * (Z.T - 1))         # the script's own multiplier vector
     tF = btime(lambda: dynamics.F(z))
     tJ = btime(lambda: (getattr(dynamics, "∂F")(z), getattr(dynamics, "∂F_structure")))
     tH = btime(lambda: (getattr(dynamics, "μ∂²F")(z, mu), getattr(dynamics, "μ∂²F_structure")))

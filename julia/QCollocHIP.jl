@@ -15,7 +15,8 @@ using Libdl
 const LIB = Ref{String}(get(ENV, "QCOLLOC_HIP_LIB", "libqcolloc_hip.so"))
 const QC_MAX_DERIV = 8
 
-# mirror of `qc_desc` (include/qcolloc.h); field order and types must match the header
+# mirror of `qc_desc` (include/qcolloc.h); field order and types must match the header -- `__init__` checks the sizes against
+# the library's own `sizeof` (qc_sizeof_desc / qc_sizeof_dims / qc_sizeof_terms_desc) when the module is loaded
 struct QCDesc
     N::Int32; m::Int32; T::Int64; zdim::Int32; global_dim::Int64
     off_U::Int32; off_a::Int32; off_dt::Int32; dt_fixed::Float64
@@ -23,14 +24,39 @@ struct QCDesc
     deriv_x_off::NTuple{QC_MAX_DERIV,Int32}; deriv_dx_off::NTuple{QC_MAX_DERIV,Int32}; deriv_dim::NTuple{QC_MAX_DERIV,Int32}
     G_drift::Ptr{Float64}; G_drives::Ptr{Float64}
     device::Int32; kernel::Int32; t_begin::Int64; t_end::Int64
-    state_cols::Int32; reserved0::Int32     # 0 = unitary iso-vec; K = K ket integrators stored back to back
+    state_cols::Int32                       # 0 = unitary iso-vec; K = K ket integrators stored back to back
+    hess_align::Int32                       # 0 = default (interval blocks of the Hessian values padded to 16 doubles), 1 = none
     rows_per_interval::Int64; row_offset::Int64; jac_per_interval::Int64; jac_offset::Int64   # composition (all 0 =
     hess_per_interval::Int64; hess_offset::Int64                                               # this handle is the whole dynamics)
+    row_placement::Int32                    # 0 = rows stacked in integrator order, 1 = rows at the state components' positions
+    hess_tail_zeros::Int32
+    deriv_row_off::NTuple{QC_MAX_DERIV,Int32}
 end
 
 struct QCDims
     n_rows::Int64; n_cols::Int64; ddim::Int64; jac_nnz_interval::Int64; hess_nnz_interval::Int64
     n_intervals::Int64; F_len::Int64; jac_nnz::Int64; hess_nnz::Int64; Z_len::Int64; kernel::Int32; reserved::Int32
+end
+
+# mirror of `qc_terms_desc`
+struct QCTermsDesc
+    T::Int64; zdim::Int32; off_dt::Int32; global_dim::Int64; dt_fixed::Float64
+    n_reg::Int32; weighting::Int32; reg_index::Ptr{Int32}; reg_R::Ptr{Float64}; reg_baseline::Ptr{Float64}
+    min_time_D::Float64; min_time_knots::Int64; device::Int32; reserved0::Int32
+end
+
+# mirror of `qc_fidelity_desc`
+struct QCFidelityDesc
+    kind::Int32; N::Int32; goal_iso::Ptr{Float64}; subspace::Ptr{Int32}; n_sub::Int32; form::Int32; n_phases::Int32; device::Int32
+    phase_dims::Ptr{Int32}; phase_ops::Ptr{Float64}
+end
+
+function __init__()
+    # a stale mirror would corrupt memory silently: compare with the structs the library was compiled with
+    for (sym, T) in ((:qc_sizeof_desc, QCDesc), (:qc_sizeof_dims, QCDims), (:qc_sizeof_terms_desc, QCTermsDesc))
+        lib = ccall(dlsym(dlopen(LIB[]), sym), Int64, ())
+        lib == sizeof(T) || error("QCollocHIP: $(T) has $(sizeof(T)) bytes, $(LIB[]) expects $lib (header / binding version mismatch)")
+    end
 end
 
 function check(rc::Cint, h::Ptr{Cvoid}=C_NULL)
@@ -42,7 +68,9 @@ end
 pad8(v) = ntuple(i -> i <= length(v) ? Int32(v[i]) : Int32(0), QC_MAX_DERIV)
 
 """
-Field-compatible stand-in for `QuantumDynamics` (QuantumCollocationCore.Dynamics).
+Field-compatible stand-in for `QuantumDynamics` (QuantumCollocationCore.Dynamics).  `F`, `∂F`, `μ∂²F` return a FRESH vector
+per call (two results of the same closure never alias); `F!`, `∂F!`, `μ∂²F!` write into a caller-owned vector (what an MOI
+callback does with Ipopt's buffers: no allocation, no copy).
 """
 mutable struct HIPDynamics
     handle::Ptr{Cvoid}
@@ -53,18 +81,35 @@ mutable struct HIPDynamics
     μ∂²F::Union{Function,Nothing}
     μ∂²F_structure::Union{Vector{Tuple{Int,Int}},Nothing}
     dim::Int
+    F!::Function
+    ∂F!::Function
+    μ∂²F!::Union{Function,Nothing}
+end
+
+# first row of state component `name` among the trajectory's state components (controls carry no dynamics rows)
+function state_row_offset(traj, name)
+    r = 0
+    for other in traj.names
+        other == name && return r
+        other in traj.control_names || (r += length(traj.components[other]))
+    end
+    error("no state component $name")
 end
 
 """
-    dynamics(integrators, traj, system; device=0, eval_hessian=true)
+    dynamics(integrators, traj, system; device=0, devices=nothing, eval_hessian=true, rows=:stacked)
 
 `integrators[1]` must be the `UnitaryPadeIntegrator` / `UnitaryExponentialIntegrator`, followed by
 `DerivativeIntegrator`s (the order of unitary_smooth_pulse_problem.jl:175-179).  `component_offset(traj, name)`
 is `first(traj.components[name]) - 1`.
+
+`devices = 0:7` builds ONE evaluator over several GPUs (`qc_create_multi`): the knots are sharded inside the library, each
+GPU copies its own contiguous slice of `∂F` into the caller's vector over its own PCIe link; everything else is unchanged.
+`rows = :by_component` places every integrator's rows at its state component's position (`Z.dims.states` rows per interval).
 """
-function dynamics(integrators, traj, system; device::Int=0, eval_hessian::Bool=true,
+function dynamics(integrators, traj, system; device::Int=0, devices=nothing, eval_hessian::Bool=true,
                   state_name=:Ũ⃗, control_name=:a, pade_order::Int=4, exponential::Bool=false,
-                  derivative_pairs=[(:a, :da), (:da, :dda)], n_kets::Int=0)
+                  derivative_pairs=[(:a, :da), (:da, :dda)], n_kets::Int=0, rows::Symbol=:stacked, hess_align::Int=0)
     off(name) = first(traj.components[name]) - 1
     n = 2 * system.levels
     G0 = Matrix{Float64}(system.G_drift)                       # column-major n x n
@@ -72,43 +117,58 @@ function dynamics(integrators, traj, system; device::Int=0, eval_hessian::Bool=t
     free_time = traj.timestep isa Symbol
     xs = [off(p[1]) for p in derivative_pairs]; dxs = [off(p[2]) for p in derivative_pairs]
     dms = [length(traj.components[p[1]]) for p in derivative_pairs]
+    bycomp = rows == :by_component
     h = Ref{Ptr{Cvoid}}(C_NULL)
     dims = Ref{QCDims}()
-    GC.@preserve G0 Gd begin
+    devs = isnothing(devices) ? Int32[] : Int32.(collect(devices))
+    GC.@preserve G0 Gd devs begin
         desc = Ref(QCDesc(system.levels, length(system.G_drives), traj.T, traj.dim, traj.global_dim,
                           off(state_name), off(control_name), free_time ? off(traj.timestep) : -1,
                           free_time ? 0.0 : Float64(traj.timestep),
                           exponential ? 1 : 0, exponential ? 0 : pade_order, length(derivative_pairs),
-                          pad8(xs), pad8(dxs), pad8(dms), pointer(G0), pointer(Gd), device, 0, 0, 0, n_kets, 0, 0, 0, 0, 0, 0, 0))
-        check(ccall((:qc_create, LIB[]), Cint, (Ref{QCDesc}, Ref{Ptr{Cvoid}}), desc, h))
+                          pad8(xs), pad8(dxs), pad8(dms), pointer(G0), pointer(Gd),
+                          isempty(devs) ? device : devs[1], 0, 0, 0, n_kets, hess_align,
+                          bycomp ? traj.dims.states : 0, bycomp ? state_row_offset(traj, state_name) : 0, 0, 0, 0, 0,
+                          bycomp ? 1 : 0, 0, bycomp ? pad8([state_row_offset(traj, p[1]) for p in derivative_pairs]) : pad8(Int[])))
+        if isempty(devs)
+            check(ccall((:qc_create, LIB[]), Cint, (Ref{QCDesc}, Ref{Ptr{Cvoid}}), desc, h))
+        else
+            check(ccall((:qc_create_multi, LIB[]), Cint, (Ref{QCDesc}, Int32, Ptr{Int32}, Ref{Ptr{Cvoid}}), desc, length(devs), devs, h))
+        end
     end
     check(ccall((:qc_dims, LIB[]), Cint, (Ptr{Cvoid}, Ref{QCDims}), h[], dims), h[])
     d = dims[]
-    rows = Vector{Int64}(undef, d.jac_nnz); cols = similar(rows)
-    check(ccall((:qc_jac_structure, LIB[]), Cint, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}, Cint), h[], rows, cols, 1), h[])
-    ∂F_structure = collect(zip(Int.(rows), Int.(cols)))          # 1-based (row, col) tuples, value order
-    Fbuf = Vector{Float64}(undef, d.F_len); Jbuf = Vector{Float64}(undef, d.jac_nnz)
-    F = function (Z⃗::AbstractVector{Float64})
-        GC.@preserve Z⃗ Fbuf check(ccall((:qc_eval_F, LIB[]), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), h[], Z⃗, Fbuf), h[])
-        return Fbuf
+    rows_ = Vector{Int64}(undef, d.jac_nnz); cols = similar(rows_)
+    check(ccall((:qc_jac_structure, LIB[]), Cint, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}, Cint), h[], rows_, cols, 1), h[])
+    ∂F_structure = collect(zip(Int.(rows_), Int.(cols)))          # 1-based (row, col) tuples, value order
+    F! = function (out::AbstractVector{Float64}, Z⃗::AbstractVector{Float64})
+        length(out) == d.F_len || error("F!: output has length $(length(out)), expected $(d.F_len)")
+        GC.@preserve Z⃗ out check(ccall((:qc_eval_F, LIB[]), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), h[], Z⃗, out), h[])
+        return out
     end
-    ∂F = function (Z⃗::AbstractVector{Float64})
-        GC.@preserve Z⃗ Jbuf check(ccall((:qc_eval_jac, LIB[]), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), h[], Z⃗, Jbuf), h[])
-        return Jbuf
+    ∂F! = function (out::AbstractVector{Float64}, Z⃗::AbstractVector{Float64})
+        length(out) == d.jac_nnz || error("∂F!: output has length $(length(out)), expected $(d.jac_nnz)")
+        GC.@preserve Z⃗ out check(ccall((:qc_eval_jac, LIB[]), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), h[], Z⃗, out), h[])
+        return out
     end
-    μ∂²F = nothing; μ∂²F_structure = nothing
+    F = Z⃗ -> F!(Vector{Float64}(undef, d.F_len), Z⃗)
+    ∂F = Z⃗ -> ∂F!(Vector{Float64}(undef, d.jac_nnz), Z⃗)
+    μ∂²F = nothing; μ∂²F! = nothing; μ∂²F_structure = nothing
     if eval_hessian && d.hess_nnz > 0
         hr = Vector{Int64}(undef, d.hess_nnz); hc = similar(hr)
         check(ccall((:qc_hess_structure, LIB[]), Cint, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}, Cint), h[], hr, hc, 1), h[])
-        μ∂²F_structure = collect(zip(Int.(hr), Int.(hc)))       # upper triangle, as test/test_utils.jl:14-27 expects
-        Hbuf = Vector{Float64}(undef, d.hess_nnz)
-        μ∂²F = function (Z⃗::AbstractVector{Float64}, μ⃗::AbstractVector{Float64})
-            GC.@preserve Z⃗ μ⃗ Hbuf check(ccall((:qc_eval_hess, LIB[]), Cint,
-                (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), h[], Z⃗, μ⃗, Hbuf), h[])
-            return Hbuf
+        μ∂²F_structure = collect(zip(Int.(hr), Int.(hc)))       # upper triangle, as test/test_utils.jl:14-27 expects; the
+                                                                # alignment padding repeats an entry with value 0 (duplicates are summed)
+        μ∂²F! = function (out::AbstractVector{Float64}, Z⃗::AbstractVector{Float64}, μ⃗::AbstractVector{Float64})
+            length(out) == d.hess_nnz || error("μ∂²F!: output has length $(length(out)), expected $(d.hess_nnz)")
+            length(μ⃗) == d.n_rows || error("μ∂²F!: μ has length $(length(μ⃗)), expected $(d.n_rows)")
+            GC.@preserve Z⃗ μ⃗ out check(ccall((:qc_eval_hess, LIB[]), Cint,
+                (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), h[], Z⃗, μ⃗, out), h[])
+            return out
         end
+        μ∂²F = (Z⃗, μ⃗) -> μ∂²F!(Vector{Float64}(undef, d.hess_nnz), Z⃗, μ⃗)
     end
-    dyn = HIPDynamics(h[], d, F, ∂F, ∂F_structure, μ∂²F, μ∂²F_structure, Int(d.ddim))
+    dyn = HIPDynamics(h[], d, F, ∂F, ∂F_structure, μ∂²F, μ∂²F_structure, Int(bycomp ? traj.dims.states : d.ddim), F!, ∂F!, μ∂²F!)
     finalizer(x -> ccall((:qc_destroy, LIB[]), Cvoid, (Ptr{Cvoid},), x.handle), dyn)
     return dyn
 end
@@ -117,21 +177,15 @@ end
 #  Objective terms and rollouts (SURVEY.md 8f): the same `ccall` pattern over qc_terms_* / qc_fidelity_* / qc_rollout
 # ---------------------------------------------------------------------------------------------------------------
 
-# mirror of `qc_terms_desc`
-struct QCTermsDesc
-    T::Int64; zdim::Int32; off_dt::Int32; global_dim::Int64; dt_fixed::Float64
-    n_reg::Int32; weighting::Int32; reg_index::Ptr{Int32}; reg_R::Ptr{Float64}; reg_baseline::Ptr{Float64}
-    min_time_D::Float64; min_time_knots::Int64; device::Int32; reserved0::Int32
-end
 
 """
-    regularizers(traj, names_and_R; D=0.0, device=0, dt_scaled=true)
+    regularizers(traj, names_and_R; D=0.0, device=0, dt_scaled=false)
 
 `names_and_R = [(:a, R_a), (:da, R_da), (:dda, R_dda)]` (scalars or vectors, unitary_smooth_pulse_problem.jl:151-153);
 `D` adds `MinimumTimeObjective(traj; D)` (unitary_minimum_time_problem.jl:67-69).  Returns `(L, ∇L, ∂²L, ∂²L_structure)`
 closures over one device handle.
 """
-function regularizers(traj, names_and_R; D::Float64=0.0, device::Int=0, dt_scaled::Bool=true)
+function regularizers(traj, names_and_R; D::Float64=0.0, device::Int=0, dt_scaled::Bool=false)
     idx = Int32[]; R = Float64[]
     for (name, r) in names_and_R
         comps = collect(traj.components[name]) .- 1
@@ -142,7 +196,7 @@ function regularizers(traj, names_and_R; D::Float64=0.0, device::Int=0, dt_scale
     h = Ref{Ptr{Cvoid}}(C_NULL)
     GC.@preserve idx R begin
         desc = Ref(QCTermsDesc(traj.T, traj.dim, free_time ? first(traj.components[traj.timestep]) - 1 : -1, traj.global_dim,
-                               free_time ? 0.0 : Float64(traj.timestep), length(idx), dt_scaled ? 0 : 1,
+                               free_time ? 0.0 : Float64(traj.timestep), length(idx), dt_scaled ? 1 : 0,   # QC_REG_PLAIN = 0 (docstring form), QC_REG_DT_SCALED = 1
                                pointer(idx), pointer(R), C_NULL, D, D == 0.0 ? 0 : traj.T - 1, device, 0))
         rc = ccall((:qc_terms_create, LIB[]), Cint, (Ref{QCTermsDesc}, Ref{Ptr{Cvoid}}), desc, h)
         rc == 0 || error("qc_terms_create: " * unsafe_string(ccall((:qc_terms_last_error, LIB[]), Cstring, (Ptr{Cvoid},), C_NULL)))
@@ -152,11 +206,10 @@ function regularizers(traj, names_and_R; D::Float64=0.0, device::Int=0, dt_scale
     hr = Vector{Int64}(undef, nnz[]); hc = similar(hr)
     ccall((:qc_terms_hess_structure, LIB[]), Cint, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}, Cint), h[], hr, hc, 1)
     Zlen = traj.dim * traj.T + traj.global_dim
-    gbuf = Vector{Float64}(undef, Zlen); Hbuf = Vector{Float64}(undef, nnz[])
     ev(Z⃗, J, g, H) = ccall((:qc_terms_eval, LIB[]), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), h[], Z⃗, J, g, H)
     L(Z⃗) = (J = Ref(0.0); GC.@preserve Z⃗ ev(Z⃗, J, C_NULL, C_NULL); J[])
-    ∇L(Z⃗) = (GC.@preserve Z⃗ gbuf ev(Z⃗, C_NULL, gbuf, C_NULL); gbuf)
-    ∂²L(Z⃗) = (GC.@preserve Z⃗ Hbuf ev(Z⃗, C_NULL, C_NULL, Hbuf); Hbuf)
+    ∇L(Z⃗) = (g = Vector{Float64}(undef, Zlen); GC.@preserve Z⃗ g ev(Z⃗, C_NULL, g, C_NULL); g)          # fresh vectors: results never alias
+    ∂²L(Z⃗) = (H = Vector{Float64}(undef, nnz[]); GC.@preserve Z⃗ H ev(Z⃗, C_NULL, C_NULL, H); H)
     return L, ∇L, ∂²L, collect(zip(Int.(hr), Int.(hc)))
 end
 
@@ -173,22 +226,33 @@ function unitary_rollout(dyn::HIPDynamics, Z⃗::AbstractVector{Float64}, init::
 end
 
 """
-    iso_vec_unitary_fidelity(Ũ⃗, Ũ⃗_goal; subspace=nothing, device=0)   (unitary_minimum_time_problem.jl:77)
+    iso_vec_unitary_fidelity(Ũ⃗, Ũ⃗_goal; subspace=nothing, device=0, squared=false)          (unitary_minimum_time_problem.jl:77)
+    iso_vec_unitary_free_phase_fidelity(Ũ⃗, Ũ⃗_goal, phases, phase_operators; subspace=nothing)  (unitary_minimum_time_problem.jl:86-90)
+
+`squared = true` selects |tr|²/n² instead of the docstring's |tr|/n (INTEGRATION.md, table of unverifiable choices).
 """
-function iso_vec_unitary_fidelity(Ũ⃗::AbstractVector{Float64}, Ũ⃗_goal::AbstractVector{Float64}; subspace=nothing, device::Int=0)
+function iso_vec_unitary_free_phase_fidelity(Ũ⃗::AbstractVector{Float64}, Ũ⃗_goal::AbstractVector{Float64}, phases, phase_operators;
+                                             subspace=nothing, device::Int=0, squared::Bool=false)
     N = isqrt(length(Ũ⃗_goal) ÷ 2)
     sub = isnothing(subspace) ? Int32[] : Int32.(collect(subspace) .- 1)
+    dims = Int32[size(Op, 1) for Op in phase_operators]
+    planes = isempty(dims) ? Float64[] : reduce(vcat, [vcat(vec(Float64.(real.(Op))), vec(Float64.(imag.(Op)))) for Op in phase_operators])
+    x = vcat(Ũ⃗, Float64.(collect(phases)))
     h = Ref{Ptr{Cvoid}}(C_NULL)
-    GC.@preserve Ũ⃗_goal sub begin
-        rc = ccall((:qc_fidelity_create, LIB[]), Cint, (Int32, Ptr{Float64}, Ptr{Int32}, Int32, Int32, Ref{Ptr{Cvoid}}),
-                   N, Ũ⃗_goal, isempty(sub) ? C_NULL : pointer(sub), length(sub), device, h)
-        rc == 0 || error("qc_fidelity_create failed")
+    GC.@preserve Ũ⃗_goal sub dims planes begin
+        desc = Ref(QCFidelityDesc(0, N, pointer(Ũ⃗_goal), isempty(sub) ? C_NULL : pointer(sub), length(sub), squared ? 1 : 0,
+                                  length(dims), device, isempty(dims) ? C_NULL : pointer(dims), isempty(planes) ? C_NULL : pointer(planes)))
+        rc = ccall((:qc_fidelity_create_desc, LIB[]), Cint, (Ref{QCFidelityDesc}, Ref{Ptr{Cvoid}}), desc, h)
+        rc == 0 || error("qc_fidelity_create_desc: " * unsafe_string(ccall((:qc_fidelity_last_error, LIB[]), Cstring, (Ptr{Cvoid},), C_NULL)))
     end
     F = Ref(0.0)
-    GC.@preserve Ũ⃗ ccall((:qc_fidelity_eval, LIB[]), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ref{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
-                          h[], Ũ⃗, F, C_NULL, C_NULL, C_NULL)
+    GC.@preserve x ccall((:qc_fidelity_eval, LIB[]), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ref{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+                         h[], x, F, C_NULL, C_NULL, C_NULL)
     ccall((:qc_fidelity_destroy, LIB[]), Cvoid, (Ptr{Cvoid},), h[])
     return F[]
 end
+
+iso_vec_unitary_fidelity(Ũ⃗::AbstractVector{Float64}, Ũ⃗_goal::AbstractVector{Float64}; kw...) =
+    iso_vec_unitary_free_phase_fidelity(Ũ⃗, Ũ⃗_goal, Float64[], Matrix{ComplexF64}[]; kw...)
 
 end # module

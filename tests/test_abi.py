@@ -375,3 +375,40 @@ def test_descriptor_fuzz_never_crashes(qc):
         if dims.hess_nnz:
             assert hr[:dims.hess_nnz].min() >= 0 and hc[:dims.hess_nnz].max() < dims.n_cols and np.all(hr[:dims.hess_nnz] <= hc[:dims.hess_nnz])
     assert ok > 20      # the generator does produce valid descriptors too
+
+
+def test_julia_struct_mirrors_match_the_ctypes_mirrors(qc):
+    """julia/QCollocHIP.jl cannot be run here (no Julia in the image): at least its struct mirrors are checked field by field --
+    name, order and type -- against the ctypes mirrors, whose sizes the library itself confirms at import (qc_sizeof_*)."""
+    import ctypes as C
+    txt = open(os.path.join(ROOT, "julia", "QCollocHIP.jl"), encoding="utf-8").read()
+    L = qc._lib
+    tmap = {"Int32": C.c_int32, "Int64": C.c_int64, "Float64": C.c_double}
+
+    def julia_fields(name):
+        body = re.search(r"^struct " + name + r"\n(.*?)^end", txt, flags=re.S | re.M).group(1)
+        body = re.sub(r"#[^\n]*", "", body)
+        out = []
+        for decl in re.split(r"[;\n]", body):
+            decl = decl.strip()
+            if not decl:
+                continue
+            fname, ftype = [x.strip() for x in decl.split("::")]
+            if ftype.startswith("Ptr{"):
+                ct = "ptr"
+            elif ftype.startswith("NTuple{QC_MAX_DERIV,"):
+                ct = tmap[ftype[len("NTuple{QC_MAX_DERIV,"):-1]] * L.QC_MAX_DERIV
+            else:
+                ct = tmap[ftype]
+            out.append((fname, ct))
+        return out
+
+    for jname, mirror in (("QCDesc", L.qc_desc), ("QCDims", L.qc_dims_t), ("QCTermsDesc", L.qc_terms_desc), ("QCFidelityDesc", L.qc_fidelity_desc)):
+        jf = julia_fields(jname)
+        assert [f for f, _ in jf] == [f for f, _ in mirror._fields_], jname
+        for (fname, jt), (_, ct) in zip(jf, mirror._fields_):
+            if jt == "ptr":
+                assert issubclass(ct, C._Pointer), (jname, fname)
+            else:
+                assert C.sizeof(jt) == C.sizeof(ct) and (jt is ct or jt._type_ == getattr(ct, "_type_", None)), (jname, fname)
+    assert "qc_sizeof_desc" in txt and "qc_create_multi" in txt and "F!" in txt
