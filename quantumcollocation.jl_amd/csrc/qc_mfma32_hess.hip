@@ -98,7 +98,9 @@ __device__ inline void store_T(double* __restrict__ p, const v4d& x, int J, int 
     for (int r = 0; r < 4; ++r) if (4 * r + g < nc && 16 * J + j < nr) qc_st8m<2>(p + (4 * r + g) * nr + 16 * J + j, x[r]);
 }
 
-template <bool DIAG>
+// ANTI: every generator is exactly antisymmetric (QcParams.antisym): the B-layout image tile (K, J) is minus the A-layout
+// tile (J, K), so only the A-layout images are fetched (half of the workgroup's one-time 128 KB image load)
+template <bool DIAG, bool ANTI>
 __global__ __launch_bounds__(kHThreads32, 1) void qc_mfma32_pade4_hess_kernel(const QcParams P, const int per_wg, const double* __restrict__ Z,
                                                                               const double* __restrict__ Mu, double* __restrict__ H) {
     qc_kernarg_touch<sizeof(QcParams) + 64>();   // one batch of scalar-cache misses instead of one per use (qc_internal.h)
@@ -131,7 +133,10 @@ __global__ __launch_bounds__(kHThreads32, 1) void qc_mfma32_pade4_hess_kernel(co
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             GkA[q] = g_tile(GxA + (size_t)kmat * 1024, q, lane);
-            GkB[q] = g_tile(GxB + (size_t)kmat * 1024, q, lane);
+            if constexpr (!ANTI) GkB[q] = g_tile(GxB + (size_t)kmat * 1024, q, lane);
+        }
+        if constexpr (ANTI) {   // B tile 2K+J = -(A tile 2J+K)
+            GkB[0] = -GkA[0]; GkB[1] = -GkA[2]; GkB[2] = -GkA[1]; GkB[3] = -GkA[3];
         }
     }
     const int n_wg = (P.n_int + per_wg - 1) / per_wg;
@@ -326,7 +331,8 @@ hipError_t qc_launch_mfma32_hess(const QcParams& P, const double* dZ, const doub
     // one workgroup per CU (239 VGPRs, 121 KB LDS); each takes a contiguous run of intervals and keeps its drive images
     const int per_wg = (P.n_int + kHCUs - 1) / kHCUs;
     const int grid = (P.n_int + per_wg - 1) / per_wg;
-    if (P.stamps != nullptr) hipLaunchKernelGGL(qc_mfma32_pade4_hess_kernel<true>, dim3(grid), dim3(kHThreads32), 0, st, P, per_wg, dZ, dMu, dH);
-    else hipLaunchKernelGGL(qc_mfma32_pade4_hess_kernel<false>, dim3(grid), dim3(kHThreads32), 0, st, P, per_wg, dZ, dMu, dH);
+    if (P.stamps != nullptr) hipLaunchKernelGGL((qc_mfma32_pade4_hess_kernel<true, false>), dim3(grid), dim3(kHThreads32), 0, st, P, per_wg, dZ, dMu, dH);
+    else if (P.antisym) hipLaunchKernelGGL((qc_mfma32_pade4_hess_kernel<false, true>), dim3(grid), dim3(kHThreads32), 0, st, P, per_wg, dZ, dMu, dH);
+    else hipLaunchKernelGGL((qc_mfma32_pade4_hess_kernel<false, false>), dim3(grid), dim3(kHThreads32), 0, st, P, per_wg, dZ, dMu, dH);
     return hipGetLastError();
 }

@@ -431,10 +431,11 @@ def test_hessian_fixture_golden_and_exponential_unsupported(qc, oracle):
     dyn.close()
 
 
-def test_antisymmetric_generator_shortcut_is_bit_identical(qc, monkeypatch):
-    """Hermitian Hamiltonians give exactly antisymmetric generators; the Hessian kernel then derives the transposed generator
+@pytest.mark.parametrize("cfg,T", [(3, 40), (5, 9), (2, 30)])
+def test_antisymmetric_generator_shortcut_is_bit_identical(qc, monkeypatch, cfg, T):
+    """Hermitian Hamiltonians give exactly antisymmetric generators; the Hessian kernels then derive the transposed generator
     images by negation instead of loading them (QcParams.antisym).  Same bits as the general path (QC_NO_ANTISYM=1)."""
-    inp = qc.config_inputs(3, T=40)
+    inp = qc.config_inputs(cfg, T=T)
     Z = inp.traj.datavec
     out = []
     for flag in ("0", "1"):
