@@ -29,7 +29,7 @@ st = out.reshape(n, 16).astype(np.int64)
 t0 = st[:, 0].min()
 rel = (st - t0) * 10.0 / 1e3   # microseconds (100 MHz)
 names = ["copy: start", "copy: loads done, G assembled", "copy: stores issued", "copy: drained", "comp: start", "comp: hand-off received",
-         "comp: P1,P2", "comp: E^T ready", "comp: pair0 ready", "copy: kernel entry", "copy: scalar loads back", "copy: vector loads back", "comp: drained"]
+         "comp: P1,P2", "comp: E^T ready", "comp: pair0 ready", "copy: kernel entry", "copy: kernel arguments read (QC_DEBUG_SKIP=4: scalar loads back)", "copy: vector loads back", "comp: drained"]
 t0 = st[:, :13][st[:, :13] > 0].min()
 rel = (st - t0) * 10.0 / 1e3
 print(f"T={T}: {n} intervals; kernel span (first start -> last drain) = {max(rel[:, 3].max(), rel[:, 12].max()):.2f} us")

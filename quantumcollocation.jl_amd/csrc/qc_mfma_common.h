@@ -81,6 +81,26 @@ __device__ __forceinline__ void lds_transpose16_multi(double* __restrict__ scr, 
     __builtin_amdgcn_wave_barrier();
 }
 
+// Drive amplitudes of a knot.  Written as `a_k = z0[off_a + k]` per drive, the compiler emits one SCALAR load per amplitude,
+// each behind its own `s_waitcnt lgkmcnt(0)` (the offset is re-read from the kernel arguments under a branch on k < m): the
+// m loads then return one after the other -- m dependent HBM round trips in front of the first product of every wave.  Here
+// the whole control vector is fetched by ONE vector load (lane l holds a_min(l, m-1)) and amplitude k is broadcast from lane k.
+__device__ inline double load_amp_lanes(const double* __restrict__ z0, int off_a, int m, int lane) {
+    const int k = lane < m ? lane : (m > 0 ? m - 1 : 0);
+    return m > 0 ? z0[off_a + k] : 0.0;
+}
+__device__ inline double bcast_lane(double v, int src_lane) {   // src_lane wave-uniform
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src_lane), __builtin_amdgcn_readlane(__double2loint(v), src_lane));
+}
+// A wave-uniform double (the timestep) through the VECTOR memory path as well: every lane loads the same address and keeps
+// its own copy in a VGPR.  (A scalar load would share lgkmcnt with the LDS traffic and the kernel-argument loads; a broadcast
+// by v_readlane right behind the load makes the compiler wait for it before it issues the next load.)
+__device__ inline double load_uniform(const double* __restrict__ p) {
+    int zero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(zero));       // opaque: keeps the address in a VGPR
+    return p[zero];
+}
+
 // Identity in B/D layout: lane (g, j) reg r = (4r + g == j)
 __device__ inline v4d identity_B(int g, int j) {
     return v4d{(g == j) ? 1.0 : 0.0, (4 + g == j) ? 1.0 : 0.0, (8 + g == j) ? 1.0 : 0.0, (12 + g == j) ? 1.0 : 0.0};

@@ -79,16 +79,19 @@ template <int kMU>
 __device__ inline v4d assemble_G(const QcParams& P, const double* __restrict__ Gx, const double* __restrict__ z0,
                                  int lane, v4d (&gk)[kMU], double (&ak)[kMU]) {
     const int m = P.m;
+    const double av = load_amp_lanes(z0, P.off_a, m, lane);   // every amplitude in one vector load (qc_mfma_common.h)
     v4d Ga = load_GA(Gx, 0, lane);
 #pragma unroll
     for (int u = 0; u < kMU; ++u) {
         const int k = u < m ? u : (m > 0 ? m - 1 : 0);     // clamped: the load is unconditional
         gk[u] = load_GA(Gx, m > 0 ? k + 1 : 0, lane);
-        ak[u] = (u < m) ? z0[P.off_a + k] : 0.0;
     }
 #pragma unroll
-    for (int u = 0; u < kMU; ++u) Ga += ak[u] * gk[u];
-    for (int k = kMU; k < m; ++k) Ga += z0[P.off_a + k] * load_GA(Gx, k + 1, lane);
+    for (int u = 0; u < kMU; ++u) {
+        ak[u] = (u < m) ? bcast_lane(av, u) : 0.0;
+        Ga += ak[u] * gk[u];
+    }
+    for (int k = kMU; k < m; ++k) Ga += bcast_lane(av, k) * load_GA(Gx, k + 1, lane);
     return Ga;
 }
 
@@ -140,7 +143,11 @@ __device__ inline v4d lds_get(const double* __restrict__ base, int lane) {
 // BATCH: blockIdx.y selects one of several handles' parameter blocks in device memory (the systems of a sampling
 // problem: same shapes, different generators and output slots) so that they share ONE launch; the parameters are then
 // read with scalar loads from global memory instead of the kernarg segment, everything else is identical.
-template <bool JAC, int MODE, bool DIAG, int kMU, bool KET, bool BATCH>
+// ONCE: one interval per workgroup (grid = number of workgroups needed, no persistent loop).  With the loop, the compiler hoists
+// every loop-invariant mask, address and predicate (~350 instructions, SGPRs spilled to VGPR lanes) in front of it, i.e. in
+// front of the FIRST GLOBAL LOAD of the copy wave: 1.6 us between a wave's first instruction and its first load request
+// (profiles/r02_stamps_d.txt).  Without the loop the loads are scheduled first and the set-up runs under their latency.
+template <bool JAC, int MODE, bool DIAG, int kMU, bool KET, bool BATCH, bool ONCE = false>
 __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel(const QcParams Pk, const double* __restrict__ Z,
                                                                       double* __restrict__ F, double* __restrict__ J,
                                                                       const QcParams* __restrict__ Pb) {
@@ -148,8 +155,14 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
     constexpr int kLdsBlock = kLdsGk + kMU * 256;
     __shared__ __attribute__((aligned(16))) double sm_all[JAC ? kIntervalsPerWG * kLdsBlock : 2];
     __shared__ int hflag[2 * kIntervalsPerWG];   // per wave pair: [0] block published (sequence number), [1] block consumed
-    unsigned long long t_entry = 0;
-    if constexpr (DIAG) t_entry = __builtin_amdgcn_s_memrealtime();
+    unsigned long long t_entry = 0, t_kernarg = 0;
+    if constexpr (DIAG) {
+        t_entry = __builtin_amdgcn_s_memrealtime();
+        // a stamp that cannot issue before one field of (nearly) every line of the argument block has arrived
+        const long long dep = (long long)Pk.N + Pk.n_deriv + Pk.drow[7] + Pk.jac_nnz + Pk.jo_d + Pk.ho_d + (long long)Pk.G + (long long)Pk.stamps +
+                              (long long)Z + (long long)Pb + (long long)(Pk.c[2] != 0.0) + (long long)(Pk.dt_fixed != 0.0);
+        asm volatile("s_memrealtime %0" : "=s"(t_kernarg) : "s"(dep));
+    }
 #ifndef QC_NO_KERNARG_TOUCH
     qc_kernarg_touch<sizeof(QcParams) + 64>();
 #endif
@@ -184,7 +197,9 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
         __syncthreads();
     }
 
-    for (int vb = blockIdx.x; vb < n_wg; vb += gridDim.x) {
+    int vb = blockIdx.x;
+    if (vb >= n_wg) return;   // (never: the grid has at most n_wg workgroups)
+    do {
         ++seq;
         const int b_raw = qc_xcd_remap(vb, n_wg) * ipw + slot;   // local interval of this wave pair
         const bool active = b_raw < P.n_int;                      // the last workgroup may be partly empty;
@@ -198,13 +213,13 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
 
         if (JAC && role == 1) {
             // ================= copy wave =====================================================================
-            if (!active) { if constexpr (!kFlags) { __syncthreads(); __syncthreads(); } continue; }
+            if (!active) { if constexpr (!kFlags) { __syncthreads(); if constexpr (!ONCE) __syncthreads(); } continue; }
             __builtin_amdgcn_s_setprio(3);   // critical path: nothing reaches HBM before this wave's first store
-            if constexpr (DIAG) qc_ts_[9] = t_entry;
+            if constexpr (DIAG) { qc_ts_[9] = t_entry; if (!(P.dbg_skip & 4)) qc_ts_[10] = t_kernarg; }
             QC_STAMP(P, b, lane, 0);
             // every global load of the interval, in one batch -- the timestep INCLUDED: loaded (and multiplied) in front of
             // the role branch it cost one full HBM round trip before any other load of the wave was even issued
-            const double h = ft ? z0[P.off_dt] : P.dt_fixed;
+            const double h = ft ? load_uniform(z0 + P.off_dt) : P.dt_fixed;
             const v4d u0 = load_state_tile<KET>(z0 + P.off_U, jc, nr, g);
             const v4d u1 = load_state_tile<KET>(z1 + P.off_U, jc, nr, g);
             double dxv[kDF], dfv[kDF];       // derivative integrators, register fast path (<= kDF of <= 64 rows)
@@ -218,7 +233,7 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
             }
             v4d gk[kMU];
             double ak[kMU];
-            if constexpr (DIAG) {   // when do the scalar loads (amplitudes, h) and when do the vector loads arrive?
+            if (DIAG && (P.dbg_skip & 4)) {   // QC_DEBUG_SKIP=4: when do the scalar loads (amplitudes, h) and when do the vector loads arrive?
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 QC_STAMP(P, b, lane, 10);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -296,16 +311,16 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
                 QC_STAMP_FLUSH(P, b, lane, 0, 3);
                 QC_STAMP_FLUSH(P, b, lane, 9, 11);
             }
-            if constexpr (!kFlags) __syncthreads();   // the hand-off block is rewritten by the next interval of a persistent grid
+            if constexpr (!kFlags && !ONCE) __syncthreads();   // the hand-off block is rewritten by the next interval of a persistent grid
             continue;
         }
 
         // ===================== compute wave ===========================================================
-        if (!active) { if constexpr (JAC && !kFlags) { __syncthreads(); __syncthreads(); } continue; }
+        if (!active) { if constexpr (JAC && !kFlags) { __syncthreads(); if constexpr (!ONCE) __syncthreads(); } continue; }
         __builtin_amdgcn_s_setprio(1);
         QC_STAMP(P, b, lane, 4);
         QC_STAMP_CYCLES(13);
-        const double h = ft ? z0[P.off_dt] : P.dt_fixed;   // requested now, back long before the hand-off arrives
+        const double h = ft ? load_uniform(z0 + P.off_dt) : P.dt_fixed;   // requested now, back long before the hand-off arrives
         v4d u0, u1, Ga;
         v4d gk[kMU];
         if constexpr (JAC) {
@@ -463,8 +478,8 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
             }
             QC_STAMP_FLUSH(P, b, lane, 4, 14);
         }
-        if constexpr (JAC && !kFlags) __syncthreads();   // pairs with the copy wave's end-of-interval barrier
-    }
+        if constexpr (JAC && !kFlags && !ONCE) __syncthreads();   // pairs with the copy wave's end-of-interval barrier
+    } while (!ONCE && (vb += gridDim.x) < n_wg);
 }
 
 }  // namespace
@@ -506,13 +521,21 @@ void qc_mfma_pack_G(const QcParams& P, const double* G, double* Gx) {
 template <bool JAC, bool DIAG, int MU>
 static void launch16m(const QcParams& P, const double* dZ, double* dF, double* dJ, hipStream_t st, int grid, int threads) {
     if (P.nc != 8 || P.n != 16) {   // K < 8 kets and / or N < 8 levels: the masked instantiation (non-temporal stores, no diagnostics)
-        hipLaunchKernelGGL((qc_mfma16_pade4_kernel<JAC, 2, false, MU, true, false>), dim3(grid), dim3(threads), 0, st, P, dZ, dF, dJ, nullptr);
+        const int n_wg_k = JAC ? (P.n_int + kIntervalsPerWG - 1) / kIntervalsPerWG : P.n_int;
+        if (grid == n_wg_k) hipLaunchKernelGGL((qc_mfma16_pade4_kernel<JAC, 2, false, MU, true, false, true>), dim3(grid), dim3(threads), 0, st, P, dZ, dF, dJ, nullptr);
+        else hipLaunchKernelGGL((qc_mfma16_pade4_kernel<JAC, 2, false, MU, true, false>), dim3(grid), dim3(threads), 0, st, P, dZ, dF, dJ, nullptr);
         return;
     }
+    const int n_wg = JAC ? (P.n_int + kIntervalsPerWG - 1) / kIntervalsPerWG : P.n_int;
     switch (P.store_mode) {
         case 0: hipLaunchKernelGGL((qc_mfma16_pade4_kernel<JAC, 0, DIAG, MU, false, false>), dim3(grid), dim3(threads), 0, st, P, dZ, dF, dJ, nullptr); break;
         case 1: hipLaunchKernelGGL((qc_mfma16_pade4_kernel<JAC, 1, DIAG, MU, false, false>), dim3(grid), dim3(threads), 0, st, P, dZ, dF, dJ, nullptr); break;
-        default: hipLaunchKernelGGL((qc_mfma16_pade4_kernel<JAC, 2, DIAG, MU, false, false>), dim3(grid), dim3(threads), 0, st, P, dZ, dF, dJ, nullptr); break;
+        default:
+            if (!DIAG && grid == n_wg)   // one interval per workgroup: the loop-free instantiation
+                hipLaunchKernelGGL((qc_mfma16_pade4_kernel<JAC, 2, false, MU, false, false, true>), dim3(grid), dim3(threads), 0, st, P, dZ, dF, dJ, nullptr);
+            else
+                hipLaunchKernelGGL((qc_mfma16_pade4_kernel<JAC, 2, DIAG, MU, false, false>), dim3(grid), dim3(threads), 0, st, P, dZ, dF, dJ, nullptr);
+            break;
     }
 }
 
