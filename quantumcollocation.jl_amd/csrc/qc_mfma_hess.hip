@@ -34,7 +34,9 @@ __device__ inline v4d sel(bool c, const v4d& a, const v4d& b) {
 
 // ANTI: every generator is exactly antisymmetric (QcParams.antisym): B-layout(G_k) = A-layout(G_k^T) = -A-layout(G_k), so the
 // transposed images are not loaded at all (half the L2 -> CU traffic of the interval's prologue, 48 registers fewer)
-template <int kHM, bool KET, bool BATCH, bool ANTI>
+// ONCE: one interval per workgroup, no persistent loop (whose invariants the compiler hoists in front of the first load; see
+// qc_mfma16_pade4_kernel)
+template <int kHM, bool KET, bool BATCH, bool ANTI, bool ONCE = false>
 __global__ __launch_bounds__(64) void qc_mfma16_pade4_hess_kernel(const QcParams Pk, const double* __restrict__ Z,
                                                                   const double* __restrict__ Mu, double* __restrict__ H,
                                                                   const QcParams* __restrict__ Pb) {
@@ -52,7 +54,9 @@ __global__ __launch_bounds__(64) void qc_mfma16_pade4_hess_kernel(const QcParams
     const double* __restrict__ GxB = P.Gx + (size_t)(m + 1) * 256;  // B-layout images (= A-layout of the transposes)
     const v4d zero = {0.0, 0.0, 0.0, 0.0};
 
-    for (int vb = blockIdx.x; vb < P.n_int; vb += gridDim.x) {
+    int vb = blockIdx.x;
+    if (vb >= P.n_int) return;
+    do {
         const int b = qc_xcd_remap(vb, P.n_int);
         const long long t = P.t_begin + b;
         const double* __restrict__ z0 = Z + t * (long long)P.zdim;
@@ -84,7 +88,7 @@ __global__ __launch_bounds__(64) void qc_mfma16_pade4_hess_kernel(const QcParams
             }
         }
         const v4d mv = (!KET || jj < nc) ? mraw : v4d{0.0, 0.0, 0.0, 0.0};
-        const double h = ft ? z0[P.off_dt] : P.dt_fixed;
+        const double h = ft ? load_uniform(z0 + P.off_dt) : P.dt_fixed;
         v4d gA[kHM], gB[kHM];
         double ak[kHM];
         v4d Ga = load_img(GxA, 0, lane);
@@ -239,7 +243,7 @@ __global__ __launch_bounds__(64) void qc_mfma16_pade4_hess_kernel(const QcParams
         }
         qc_hess_tail(P, mu, Hb, lane, 64);   // derivative integrators: d2/d(dx_i) dh = -mu_i; alignment padding
         __builtin_amdgcn_wave_barrier();   // the scratch rows are rewritten by the next interval
-    }
+    } while (!ONCE && (vb += gridDim.x) < P.n_int);
 }
 
 }  // namespace
@@ -267,6 +271,11 @@ hipError_t qc_launch_mfma16_hess_batch(const QcParams& P0, const QcParams* dPb, 
 
 template <int HM, bool KET>
 static void launch_hess16(const QcParams& P, const double* dZ, const double* dMu, double* dH, hipStream_t st, int grid) {
+    if (grid == P.n_int) {   // one interval per workgroup: the loop-free instantiations
+        if (P.antisym) hipLaunchKernelGGL((qc_mfma16_pade4_hess_kernel<HM, KET, false, true, true>), dim3(grid), dim3(64), 0, st, P, dZ, dMu, dH, nullptr);
+        else hipLaunchKernelGGL((qc_mfma16_pade4_hess_kernel<HM, KET, false, false, true>), dim3(grid), dim3(64), 0, st, P, dZ, dMu, dH, nullptr);
+        return;
+    }
     if (P.antisym) hipLaunchKernelGGL((qc_mfma16_pade4_hess_kernel<HM, KET, false, true>), dim3(grid), dim3(64), 0, st, P, dZ, dMu, dH, nullptr);
     else hipLaunchKernelGGL((qc_mfma16_pade4_hess_kernel<HM, KET, false, false>), dim3(grid), dim3(64), 0, st, P, dZ, dMu, dH, nullptr);
 }
