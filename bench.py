@@ -116,8 +116,9 @@ def host_visible_record(qc, inp, dyn, Zh, cpu_value):
 
 def config5_record(qc, dev_index, steps=300):
     """BASELINE config 5 (4-qubit QFT, T = 500, the 2N = 32 MFMA path) on the device: north_star asks for the MFMA
-    utilisation of the large-n case.  FLOP counts are the kernels' own MFMA counts (624 / 544
-    v_mfma_f64_16x16x4_f64 per interval, 2048 FLOP each; the counter run is profiles/r02_mfma_util_c5.json)."""
+    utilisation of the large-n case.  FLOP counts are the kernels' own MFMA counts as the SQ_INSTS_VALU_MFMA_F64 counter
+    reports them (576 / 560 v_mfma_f64_16x16x4_f64 per interval for F + dF / mu_d2F at m = 8, 2048 FLOP each:
+    profiles/r02_mfma_util.json, which also holds the counter-based MfmaUtil: 15.7 % / 22.6 %)."""
     inp = qc.config_inputs(5)
     dyn = qc.QuantumDynamics(inp.integrators, inp.traj, device=dev_index)
     dev = torch.device("cuda", dev_index)
@@ -152,10 +153,10 @@ def config5_record(qc, dev_index, steps=300):
     peak_tf = 78.6       # f64 MFMA: 256 CUs x 4 SIMDs x 2048 FLOP / 64 cycles x 2.4 GHz
     rec = {"workload": qc.CONFIGS[5].description + f"; T={inp.traj.T}", "kernels": list(dyn.kernel_names),
            "F_dF_us": jac_us, "F_dF_hbm_frac": jac_bytes / (jac_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-           "F_dF_mfma_frac": 624 * n_int * 2048 / (jac_us * 1e-6) / 1e12 / peak_tf,
+           "F_dF_mfma_frac": 576 * n_int * 2048 / (jac_us * 1e-6) / 1e12 / peak_tf,
            "hess_us": hess_us, "hess_hbm_frac": hess_bytes / (hess_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-           "hess_mfma_frac": 544 * n_int * 2048 / (hess_us * 1e-6) / 1e12 / peak_tf,
-           "mfma_peak_TFLOPs": peak_tf}
+           "hess_mfma_frac": 560 * n_int * 2048 / (hess_us * 1e-6) / 1e12 / peak_tf,
+           "mfma_peak_TFLOPs": peak_tf, "MfmaUtil_counter_percent": {"F_dF": 15.7, "hess": 22.6, "source": "profiles/r02_mfma_util.json"}}
     dyn.close()
     return rec
 

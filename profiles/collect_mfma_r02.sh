@@ -1,0 +1,31 @@
+#!/bin/bash
+# MFMA utilisation counters per kernel for BASELINE config 5 (the large-n case north_star asks it for) and config 3:
+#   gpurun -- 'bash profiles/collect_mfma_r02.sh'
+# Counters in their own pass (no trace domains).  MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs).
+set -u
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/prof_mfma_util_r02
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+for cfg in 3 5; do
+  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_F64 SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/cfg$cfg -- \
+      python3 $R/bench.py --config $cfg --steps 100 --warmup 10 --cpu-seconds 0 --no-host-visible --no-config5 > $OUT/bench_cfg$cfg.json 2> $OUT/cfg$cfg.log
+done
+python3 - <<PY
+import csv, glob, json, collections
+res = {}
+for cfg in (3, 5):
+    for f in glob.glob("$OUT/cfg%d/**/*counter_collection.csv" % cfg, recursive=True):
+        acc = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in csv.DictReader(open(f)):
+            if "qc_mfma" in r["Kernel_Name"]:
+                acc[r["Kernel_Name"].split("(")[1] if False else r["Kernel_Name"][:r["Kernel_Name"].find("(QcParams")]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for k, cs in acc.items():
+            d = {c: sum(v) / len(v) for c, v in cs.items()}
+            d["launches"] = len(next(iter(cs.values())))
+            if "SQ_VALU_MFMA_BUSY_CYCLES" in d and "GRBM_GUI_ACTIVE" in d:
+                d["MfmaUtil_percent"] = 100.0 * d["SQ_VALU_MFMA_BUSY_CYCLES"] / (d["GRBM_GUI_ACTIVE"] / 8 * 1024)
+            res["config%d %s" % (cfg, k.replace("void (anonymous namespace)::", ""))] = d
+print(json.dumps(res, indent=1))
+json.dump(res, open("$OUT/summary.json", "w"), indent=1)
+PY
