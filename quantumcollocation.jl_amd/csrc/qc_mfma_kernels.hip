@@ -73,19 +73,26 @@ __device__ inline v4d load_GA(const double* __restrict__ Gx, int mat, int lane) 
 constexpr int kDF = 4;   // derivative integrators handled from registers in the copy wave
 
 
-// G = G_0 + sum_k a_k G_k (A-layout).  The first kMU drive images and their amplitudes are requested
-// in one batch (no load waits on another) and returned in gk/ak for reuse by the drive-column loop.
+// G = G_0 + sum_k a_k G_k (A-layout).  The first kMU drive images and the amplitudes are requested in one batch (no load
+// waits on another) and returned in gk/ak for reuse by the drive-column loop.  Two halves, so that a caller can put other
+// load requests between them: assemble_G_request issues the loads, assemble_G_combine waits for them and forms G.
 template <int kMU>
-__device__ inline v4d assemble_G(const QcParams& P, const double* __restrict__ Gx, const double* __restrict__ z0,
-                                 int lane, v4d (&gk)[kMU], double (&ak)[kMU]) {
+__device__ inline void assemble_G_request(const QcParams& P, const double* __restrict__ Gx, const double* __restrict__ z0, int lane,
+                                          v4d& g0, v4d (&gk)[kMU], double& av) {
     const int m = P.m;
-    const double av = load_amp_lanes(z0, P.off_a, m, lane);   // every amplitude in one vector load (qc_mfma_common.h)
-    v4d Ga = load_GA(Gx, 0, lane);
+    av = load_amp_lanes(z0, P.off_a, m, lane);   // every amplitude in one vector load (qc_mfma_common.h)
+    g0 = load_GA(Gx, 0, lane);
 #pragma unroll
     for (int u = 0; u < kMU; ++u) {
         const int k = u < m ? u : (m > 0 ? m - 1 : 0);     // clamped: the load is unconditional
         gk[u] = load_GA(Gx, m > 0 ? k + 1 : 0, lane);
     }
+}
+template <int kMU>
+__device__ inline v4d assemble_G_combine(const QcParams& P, const double* __restrict__ Gx, int lane, const v4d& g0, const v4d (&gk)[kMU],
+                                         double av, double (&ak)[kMU]) {
+    const int m = P.m;
+    v4d Ga = g0;
 #pragma unroll
     for (int u = 0; u < kMU; ++u) {
         ak[u] = (u < m) ? bcast_lane(av, u) : 0.0;
@@ -93,6 +100,14 @@ __device__ inline v4d assemble_G(const QcParams& P, const double* __restrict__ G
     }
     for (int k = kMU; k < m; ++k) Ga += bcast_lane(av, k) * load_GA(Gx, k + 1, lane);
     return Ga;
+}
+template <int kMU>
+__device__ inline v4d assemble_G(const QcParams& P, const double* __restrict__ Gx, const double* __restrict__ z0,
+                                 int lane, v4d (&gk)[kMU], double (&ak)[kMU]) {
+    v4d g0;
+    double av;
+    assemble_G_request(P, Gx, z0, lane, g0, gk, av);
+    return assemble_G_combine(P, Gx, lane, g0, gk, av, ak);
 }
 
 // Store a transposed tile: lane (g, j) reg r holds X[j][4r+g] of a 16 x 16 column-major block at p.
@@ -217,9 +232,14 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
             __builtin_amdgcn_s_setprio(3);   // critical path: nothing reaches HBM before this wave's first store
             if constexpr (DIAG) { qc_ts_[9] = t_entry; if (!(P.dbg_skip & 4)) qc_ts_[10] = t_kernarg; }
             QC_STAMP(P, b, lane, 0);
-            // every global load of the interval, in one batch -- the timestep INCLUDED: loaded (and multiplied) in front of
-            // the role branch it cost one full HBM round trip before any other load of the wave was even issued
+            // Every global load of the interval in one batch, in the order the wave needs them: first what G depends on (the
+            // timestep, the amplitudes, the generator images), then the state tiles and the derivative-integrator data that are only
+            // passed on.  G, its two products and B^T / F^T are formed as soon as the first group is back (the compiler's counted
+            // vmcnt leaves the second group in flight); the hand-off to the compute wave follows, then the stores.
             const double h = ft ? load_uniform(z0 + P.off_dt) : P.dt_fixed;
+            v4d g0, gk[kMU];
+            double av, ak[kMU];
+            assemble_G_request(P, Gx, z0, lane, g0, gk, av);
             const v4d u0 = load_state_tile<KET>(z0 + P.off_U, jc, nr, g);
             const v4d u1 = load_state_tile<KET>(z1 + P.off_U, jc, nr, g);
             double dxv[kDF], dfv[kDF];       // derivative integrators, register fast path (<= kDF of <= 64 rows)
@@ -231,17 +251,27 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
                 dxv[d] = z0[P.dx_off[d] + i];
                 dfv[d] = z1[P.x_off[d] + i] - z0[P.x_off[d] + i];
             }
-            v4d gk[kMU];
-            double ak[kMU];
             if (DIAG && (P.dbg_skip & 4)) {   // QC_DEBUG_SKIP=4: when do the scalar loads (amplitudes, h) and when do the vector loads arrive?
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 QC_STAMP(P, b, lane, 10);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 QC_STAMP(P, b, lane, 11);
             }
-            const v4d Ga = assemble_G(P, Gx, z0, lane, gk, ak);
+            const v4d Ga = assemble_G_combine(P, Gx, lane, g0, gk, av, ak);
             const double hc1 = h * c1, hc2 = h * h * c2;
             QC_STAMP(P, b, lane, 1);
+            bool skip = false;
+            if constexpr (DIAG) skip = (P.dbg_skip & 1) != 0;
+            // A-layout(G^T) = B-layout(G) = Gb;  B-layout(G^T) = D-layout(G^T) = A-layout(G) = Ga.
+            const v4d Gb = mm16(Ga, IdB);
+            const v4d G2T = mm16(Gb, Ga);
+            v4d Fm, Bm;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double ev = IdB[r] + hc2 * G2T[r];
+                Fm[r] = -(ev + hc1 * Ga[r]);       // -F^T
+                Bm[r] = ev - hc1 * Ga[r];          //  B^T
+            }
             // hand-off to the compute wave
             if constexpr (kFlags) { if (seq > 1) flag_wait(fl + 1, seq - 1); }   // persistent grid: the previous block has been consumed
             lds_put(sm + kLdsGa, lane, Ga);
@@ -252,19 +282,7 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
                 if (u < m) lds_put(sm + kLdsGk + u * 256, lane, gk[u]);
             if constexpr (kFlags) { if (lane == 0) flag_set(fl, seq); }
             else __syncthreads();
-            bool skip = false;
-            if constexpr (DIAG) skip = (P.dbg_skip & 1) != 0;
             if (!skip) {
-                // A-layout(G^T) = B-layout(G) = Gb;  B-layout(G^T) = D-layout(G^T) = A-layout(G) = Ga.
-                const v4d Gb = mm16(Ga, IdB);
-                const v4d G2T = mm16(Gb, Ga);
-                v4d Fm, Bm;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const double ev = IdB[r] + hc2 * G2T[r];
-                    Fm[r] = -(ev + hc1 * Ga[r]);       // -F^T
-                    Bm[r] = ev - hc1 * Ga[r];          //  B^T
-                }
                 double* pF = Jb + P.jo_F;
                 double* pB = Jb + P.jo_B;
                 // 8 bytes per lane, 512 contiguous bytes per instruction.  (Pairing lanes for 16-byte stores measured 8 % slower.)
@@ -531,8 +549,8 @@ static void launch16m(const QcParams& P, const double* dZ, double* dF, double* d
         case 0: hipLaunchKernelGGL((qc_mfma16_pade4_kernel<JAC, 0, DIAG, MU, false, false>), dim3(grid), dim3(threads), 0, st, P, dZ, dF, dJ, nullptr); break;
         case 1: hipLaunchKernelGGL((qc_mfma16_pade4_kernel<JAC, 1, DIAG, MU, false, false>), dim3(grid), dim3(threads), 0, st, P, dZ, dF, dJ, nullptr); break;
         default:
-            if (!DIAG && grid == n_wg)   // one interval per workgroup: the loop-free instantiation
-                hipLaunchKernelGGL((qc_mfma16_pade4_kernel<JAC, 2, false, MU, false, false, true>), dim3(grid), dim3(threads), 0, st, P, dZ, dF, dJ, nullptr);
+            if (grid == n_wg)   // one interval per workgroup: the loop-free instantiation (also for the stamped diagnostic build)
+                hipLaunchKernelGGL((qc_mfma16_pade4_kernel<JAC, 2, DIAG, MU, false, false, true>), dim3(grid), dim3(threads), 0, st, P, dZ, dF, dJ, nullptr);
             else
                 hipLaunchKernelGGL((qc_mfma16_pade4_kernel<JAC, 2, DIAG, MU, false, false>), dim3(grid), dim3(threads), 0, st, P, dZ, dF, dJ, nullptr);
             break;
