@@ -77,16 +77,20 @@ constexpr int kDF = 4;   // derivative integrators handled from registers in the
 // waits on another) and returned in gk/ak for reuse by the drive-column loop.  Two halves, so that a caller can put other
 // load requests between them: assemble_G_request issues the loads, assemble_G_combine waits for them and forms G.
 template <int kMU>
-__device__ inline void assemble_G_request(const QcParams& P, const double* __restrict__ Gx, const double* __restrict__ z0, int lane,
-                                          v4d& g0, v4d (&gk)[kMU], double& av) {
+__device__ inline void request_images(const QcParams& P, const double* __restrict__ Gx, int lane, v4d& g0, v4d (&gk)[kMU]) {
     const int m = P.m;
-    av = load_amp_lanes(z0, P.off_a, m, lane);   // every amplitude in one vector load (qc_mfma_common.h)
     g0 = load_GA(Gx, 0, lane);
 #pragma unroll
     for (int u = 0; u < kMU; ++u) {
         const int k = u < m ? u : (m > 0 ? m - 1 : 0);     // clamped: the load is unconditional
         gk[u] = load_GA(Gx, m > 0 ? k + 1 : 0, lane);
     }
+}
+template <int kMU>
+__device__ inline void assemble_G_request(const QcParams& P, const double* __restrict__ Gx, const double* __restrict__ z0, int lane,
+                                          v4d& g0, v4d (&gk)[kMU], double& av) {
+    av = load_amp_lanes(z0, P.off_a, P.m, lane);   // every amplitude in one vector load (qc_mfma_common.h)
+    request_images(P, Gx, lane, g0, gk);
 }
 template <int kMU>
 __device__ inline v4d assemble_G_combine(const QcParams& P, const double* __restrict__ Gx, int lane, const v4d& g0, const v4d (&gk)[kMU],
@@ -181,6 +185,7 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
 #ifndef QC_NO_KERNARG_TOUCH
     qc_kernarg_touch<sizeof(QcParams) + 64>();
 #endif
+    // (Demanding every argument of the prologue at one point -- one batch of scalar loads -- was measured: 10.0 vs 9.6 us.)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = JAC ? __builtin_amdgcn_readfirstlane(tid >> 6) : 0;
@@ -212,6 +217,10 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
         __syncthreads();
     }
 
+    // The copy wave's generator images depend on nothing but the kernel arguments: they are requested before any address of the
+    // interval is computed (and once for all intervals of a persistent grid).
+    v4d g0_img, gk_img[kMU];
+    if (JAC && role == 1) request_images(P, Gx, lane, g0_img, gk_img);
     int vb = blockIdx.x;
     if (vb >= n_wg) return;   // (never: the grid has at most n_wg workgroups)
     do {
@@ -237,9 +246,10 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
             // passed on.  G, its two products and B^T / F^T are formed as soon as the first group is back (the compiler's counted
             // vmcnt leaves the second group in flight); the hand-off to the compute wave follows, then the stores.
             const double h = ft ? load_uniform(z0 + P.off_dt) : P.dt_fixed;
-            v4d g0, gk[kMU];
-            double av, ak[kMU];
-            assemble_G_request(P, Gx, z0, lane, g0, gk, av);
+            double ak[kMU];
+            const double av = load_amp_lanes(z0, P.off_a, m, lane);   // every amplitude in one vector load (qc_mfma_common.h)
+            const v4d& g0 = g0_img;
+            const v4d (&gk)[kMU] = gk_img;
             const v4d u0 = load_state_tile<KET>(z0 + P.off_U, jc, nr, g);
             const v4d u1 = load_state_tile<KET>(z1 + P.off_U, jc, nr, g);
             double dxv[kDF], dfv[kDF];       // derivative integrators, register fast path (<= kDF of <= 64 rows)
