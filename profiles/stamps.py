@@ -30,10 +30,13 @@ t0 = st[:, 0].min()
 rel = (st - t0) * 10.0 / 1e3   # microseconds (100 MHz)
 names = ["copy: start", "copy: loads done, G assembled", "copy: stores issued", "copy: drained", "comp: start", "comp: hand-off received",
          "comp: P1,P2", "comp: E^T ready", "comp: pair0 ready", "copy: kernel entry", "copy: kernel arguments read (QC_DEBUG_SKIP=4: scalar loads back)", "copy: vector loads back", "comp: drained"]
-t0 = st[:, :13][st[:, :13] > 0].min()
+tcols = [c for c in range(13) if c != 11]      # slot 11 (and 15) hold HW_REG_HW_ID, not a time
+t0 = st[:, tcols][st[:, tcols] > 0].min()
 rel = (st - t0) * 10.0 / 1e3
 print(f"T={T}: {n} intervals; kernel span (first start -> last drain) = {max(rel[:, 3].max(), rel[:, 12].max()):.2f} us")
 for k, nm in enumerate(names):
+    if k == 11 and not (int(os.environ.get("QC_DEBUG_SKIP", "0")) & 4):
+        continue
     col = rel[:, k]
     col = col[st[:, k] > 0]
     if col.size:

@@ -231,6 +231,10 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
         const long long t = P.t_begin + b;
         const double* __restrict__ z0 = Z + t * (long long)P.zdim;
         const double* __restrict__ z1 = z0 + P.zdim;
+        // what G depends on besides the images -- the amplitudes and the timestep -- is requested as soon as the knot's address
+        // exists, before the output addresses are computed (both waves: the compute wave needs the timestep too)
+        const double av_pre = (JAC && role == 1) ? load_amp_lanes(z0, P.off_a, m, lane) : 0.0;
+        const double h_pre = ft ? load_uniform(z0 + P.off_dt) : P.dt_fixed;
         double* __restrict__ Jb = JAC ? J + (size_t)b * P.J_stride + P.J_off : nullptr;
         double* __restrict__ Fb = F ? F + (size_t)b * P.F_stride + P.F_off : nullptr;
         QC_STAMP_DECL;
@@ -239,17 +243,22 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
             // ================= copy wave =====================================================================
             if (!active) { if constexpr (!kFlags) { __syncthreads(); if constexpr (!ONCE) __syncthreads(); } continue; }
             __builtin_amdgcn_s_setprio(3);   // critical path: nothing reaches HBM before this wave's first store
-            if constexpr (DIAG) { qc_ts_[9] = t_entry; if (!(P.dbg_skip & 4)) qc_ts_[10] = t_kernarg; }
+            if constexpr (DIAG) {
+                qc_ts_[9] = t_entry;
+                if (!(P.dbg_skip & 4)) { qc_ts_[10] = t_kernarg; qc_ts_[11] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | (1ull << 40); }   // HW_REG_HW_ID: where the wave runs
+            }
             QC_STAMP(P, b, lane, 0);
             // Every global load of the interval in one batch, in the order the wave needs them: first what G depends on (the
             // timestep, the amplitudes, the generator images), then the state tiles and the derivative-integrator data that are only
             // passed on.  G, its two products and B^T / F^T are formed as soon as the first group is back (the compiler's counted
             // vmcnt leaves the second group in flight); the hand-off to the compute wave follows, then the stores.
-            const double h = ft ? load_uniform(z0 + P.off_dt) : P.dt_fixed;
+            const double h = h_pre;
             double ak[kMU];
-            const double av = load_amp_lanes(z0, P.off_a, m, lane);   // every amplitude in one vector load (qc_mfma_common.h)
+            const double av = av_pre;   // every amplitude in one vector load (qc_mfma_common.h)
             const v4d& g0 = g0_img;
             const v4d (&gk)[kMU] = gk_img;
+            // (Dropping these twenty loads altogether -- wrong results, timing only -- gains 0.23 us: the vector-memory pipeline of
+            // the CU is not what the first store waits for; it waits for the round trip of the amplitudes and the images.)
             const v4d u0 = load_state_tile<KET>(z0 + P.off_U, jc, nr, g);
             const v4d u1 = load_state_tile<KET>(z1 + P.off_U, jc, nr, g);
             double dxv[kDF], dfv[kDF];       // derivative integrators, register fast path (<= kDF of <= 64 rows)
@@ -348,7 +357,7 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
         __builtin_amdgcn_s_setprio(1);
         QC_STAMP(P, b, lane, 4);
         QC_STAMP_CYCLES(13);
-        const double h = ft ? load_uniform(z0 + P.off_dt) : P.dt_fixed;   // requested now, back long before the hand-off arrives
+        const double h = h_pre;   // requested at the top, back long before the hand-off arrives
         v4d u0, u1, Ga;
         v4d gk[kMU];
         if constexpr (JAC) {
@@ -415,8 +424,11 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
 #pragma unroll
                 for (int r = 0; r < 4; ++r) E[r] = left ? dl[r] : dhs[r];
             }
+            // JAC: the transposes for the line-wide stores (E^T and the drive-pair tiles) go through the hand-off block in LDS,
+            // which nobody reads any more after stage B, instead of through identity products: 4 + 2 kMU MFMAs (a quarter of the
+            // wave's matrix-pipe time) off the dependent chain, one LDS round trip for all tiles (lds_transpose16_multi).
             constexpr int NC = JAC ? kMU / 2 + 1 : 1;
-            v4d sC[NC];                               // stage C results: E^T, T_p = G [R_2p(right) | R_2p+1(right)]
+            v4d sC[NC];                               // stage C results: (E^T,) T_p = G [R_2p(right) | R_2p+1(right)]
             v4d Y[NC];                                // Y[p+1] = [R_2p(left) | R_2p+1(left)]
             {
                 v4d aC[NC], bC[NC];
@@ -435,9 +447,33 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
                         }
                     }
                 }
-                mm16_multi<NC>(aC, bC, sC);
+                if constexpr (JAC) {                  // T_p only; E is transposed through LDS below
+                    if constexpr (kMU / 2 > 0) {
+                        v4d aT[kMU / 2], bT[kMU / 2], dT[kMU / 2];
+#pragma unroll
+                        for (int p2 = 0; p2 < kMU / 2; ++p2) { aT[p2] = aC[p2 + 1]; bT[p2] = bC[p2 + 1]; }
+                        mm16_multi<kMU / 2>(aT, bT, dT);
+#pragma unroll
+                        for (int p2 = 0; p2 < kMU / 2; ++p2) sC[p2 + 1] = dT[p2];
+                    }
+                } else {
+                    mm16_multi<NC>(aC, bC, sC);
+                }
             }
-            const v4d ET = sC[0];                     // lane (g, j) reg r = E[j][4r+g]
+            v4d ET;                                   // lane (g, j) reg r = E[j][4r+g]
+            v4d YT[kMU / 2 > 0 ? kMU / 2 : 1];        // transposes of [d/da_k | d/da_k+1]
+            if constexpr (JAC) {
+                v4d tin[kMU / 2 + 1], tout[kMU / 2 + 1];
+                tin[0] = E;
+#pragma unroll
+                for (int p2 = 0; p2 < kMU / 2; ++p2) tin[p2 + 1] = Y[p2 + 1] + sC[p2 + 1];
+                lds_transpose16_multi<kMU / 2 + 1>(sm, tin, tout, g, j);
+                ET = tout[0];
+#pragma unroll
+                for (int p2 = 0; p2 < kMU / 2; ++p2) YT[p2] = tout[p2 + 1];
+            } else {
+                ET = sC[0];
+            }
             // The compute wave's few stores are issued AFTER its MFMA chain: a store issued while the copy
             // waves flood the CU's store queue stalls this wave for microseconds.
             auto store_ET = [&]() {
@@ -469,16 +505,6 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
                         else if (two && (!KET || (c - 8 < nc && j < nr))) qc_st8m<MODE>(p + sk + (c - 8) * nr + j, YTk[r]);
                     }
                 };
-                v4d YT[kMU / 2];                      // stage D: transposes of [d/da_k | d/da_k+1]
-                {
-                    v4d aD[kMU / 2], bD[kMU / 2];
-#pragma unroll
-                    for (int p2 = 0; p2 < kMU / 2; ++p2) {
-                        aD[p2] = Y[p2 + 1] + sC[p2 + 1];
-                        bD[p2] = IdB;
-                    }
-                    mm16_multi<kMU / 2>(aD, bD, YT);
-                }
                 QC_STAMP(P, b, lane, 8);
                 store_ET();
 #pragma unroll
@@ -504,7 +530,8 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
                 QC_STAMP(P, b, lane, 12);
                 QC_STAMP_CYCLES(14);
             }
-            QC_STAMP_FLUSH(P, b, lane, 4, 14);
+            if constexpr (DIAG) qc_ts_[15] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | (1ull << 40);   // HW_REG_HW_ID
+            QC_STAMP_FLUSH(P, b, lane, 4, 15);
         }
         if constexpr (JAC && !kFlags && !ONCE) __syncthreads();   // pairs with the copy wave's end-of-interval barrier
     } while (!ONCE && (vb += gridDim.x) < n_wg);
