@@ -303,8 +303,12 @@ def main():
     if args.streams > 1:
         # Independent evaluations (e.g. the systems of a sampling problem, or several line-search points) may overlap the
         # ~4 us of dispatch + write-back of one launch with the store phase of the next.  A serial Ipopt loop cannot.
+        # qcolloc.h: a handle has ONE evaluation in flight unless its kernel keeps no scratch in the handle.
+        if not (dyn.kernel_names[0].startswith(("mfma16", "mfma32")) or dyn.kernel_names[0] == "lds"):
+            raise SystemExit(f"--streams: the F+dF kernel of this handle ({dyn.kernel_names[0]}) keeps scratch in the handle; "
+                             "launches of one handle on several streams would race")
         sts = [torch.cuda.Stream(device=dev) for _ in range(args.streams)]
-        ln = [dyn.bind_F_dF_device(Zs[i & 3], Fb[i % nbuf], Jb[i % nbuf], sts[i % args.streams]) for i in range(period * args.streams)]
+        ln =[dyn.bind_F_dF_device(Zs[i & 3], Fb[i % nbuf], Jb[i % nbuf], sts[i % args.streams]) for i in range(period * args.streams)]
         for i in range(args.warmup):
             ln[i % len(ln)]()
         torch.cuda.synchronize()
