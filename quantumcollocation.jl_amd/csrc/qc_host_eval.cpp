@@ -77,6 +77,7 @@ static int prepare_batch(qc_handle* const* hs, int32_t count, bool hessian) {
         const qc_handle* h = hs[i];
         if (h->kernel != QC_KERNEL_MFMA || !qc_mfma16_batchable(h->prm)) return 0;
         if (h->prm.m > 8 && hessian) return 0;
+        if (hessian && h->prm.antisym != h0->prm.antisym) return 0;   // (the antisymmetric generators' Hessian kernel is a different one)
         if (h->prm.n_int != h0->prm.n_int || h->prm.t_begin != h0->prm.t_begin || h->prm.zdim != h0->prm.zdim || h->prm.m != h0->prm.m ||
             h->prm.n != h0->prm.n || h->prm.nc != h0->prm.nc)
             return 0;

@@ -432,9 +432,9 @@ def test_hessian_fixture_golden_and_exponential_unsupported(qc, oracle):
 
 
 @pytest.mark.parametrize("cfg,T", [(3, 40), (5, 9), (2, 30)])
-def test_antisymmetric_generator_shortcut_is_bit_identical(qc, monkeypatch, cfg, T):
-    """Hermitian Hamiltonians give exactly antisymmetric generators; the Hessian kernels then derive the transposed generator
-    images by negation instead of loading them (QcParams.antisym).  Same bits as the general path (QC_NO_ANTISYM=1)."""
+def test_antisymmetric_generator_path_matches_general_path(qc, monkeypatch, cfg, T):
+    """Hermitian Hamiltonians give exactly antisymmetric generators; the Hessian kernels then never load the transposed
+    generator images (QcParams.antisym).  Against the general path (QC_NO_ANTISYM=1)."""
     inp = qc.config_inputs(cfg, T=T)
     Z = inp.traj.datavec
     out = []
@@ -444,7 +444,12 @@ def test_antisymmetric_generator_shortcut_is_bit_identical(qc, monkeypatch, cfg,
         mu = np.random.default_rng(9).standard_normal(dyn.dims.n_rows)
         out.append(dyn.mu_d2F(Z, mu))
         dyn.close()
-    np.testing.assert_array_equal(out[0], out[1])
+    if cfg == 5:
+        np.testing.assert_array_equal(out[0], out[1])      # 2N = 32: the same kernel, images by negation
+    else:
+        # 2N = 16: a kernel of its own for antisymmetric generators (sign-free formulation, two product stages)
+        scale = np.abs(out[1]).max()
+        np.testing.assert_allclose(out[0], out[1], rtol=1e-11, atol=1e-12 * scale)
 
 
 @pytest.mark.parametrize("cfg,T", [(3, 1000), (5, 500)])
