@@ -119,7 +119,7 @@ __global__ __launch_bounds__(kE32Threads, 1) void qc_mfma32_exp_kernel(const QcP
     const double* __restrict__ z1 = z0 + P.zdim;
     double* __restrict__ Jb = JAC ? J + (size_t)b * P.J_stride + P.J_off : nullptr;
     double* __restrict__ Fb = F ? F + (size_t)b * P.F_stride + P.F_off : nullptr;
-    const double h = ft ? z0[P.off_dt] : P.dt_fixed;
+    const double h = ft ? z0[P.off_dt] : opaque_scalar(P.dt_fixed);
 
     // ---- loads: this wave's half tile of the generator images (assembly), its drive's images, U_t ---------------------
     v4d Gj[4];

@@ -114,16 +114,14 @@ __global__ __launch_bounds__(kHThreads32, 1) void qc_mfma32_pade4_hess_kernel(co
     __shared__ __attribute__((aligned(16))) double NVL[kHMax32 * 4 * 256];      // per drive: N_k[0], N_k[1], V_k[0], V_k[1]
     __shared__ double TS[8 * 16 * 17];                                          // per-wave transpose scratch
     const int tid = threadIdx.x;
-    const int lane = tid & 63;
+    const int lane0 = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = P.m;
-    const int g = lane >> 4, j = lane & 15;
     const bool ft = P.off_dt >= 0;
     const bool drive = w < m;
     const double c1 = P.c[1], c2 = P.c[2];
     const double* __restrict__ GxA = P.Gx;                              // A-layout images [mat][2I+K]
     const double* __restrict__ GxB = P.Gx + (size_t)(m + 1) * 1024;     // B-layout images [mat][2K+J]
-    double* __restrict__ scr = TS + w * (16 * 17);
 
     // The drive's images stay in registers for every interval of this workgroup: they are the bulk of the L2 traffic
     // (16 KB per wave), and with one interval per workgroup the kernel was L2-bandwidth-bound in its load phase.
@@ -132,8 +130,8 @@ __global__ __launch_bounds__(kHThreads32, 1) void qc_mfma32_pade4_hess_kernel(co
         const int kmat = drive ? w + 1 : 0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            GkA[q] = g_tile(GxA + (size_t)kmat * 1024, q, lane);
-            if constexpr (!ANTI) GkB[q] = g_tile(GxB + (size_t)kmat * 1024, q, lane);
+            GkA[q] = g_tile(GxA + (size_t)kmat * 1024, q, lane0);
+            if constexpr (!ANTI) GkB[q] = g_tile(GxB + (size_t)kmat * 1024, q, lane0);
         }
         if constexpr (ANTI) {   // B tile 2K+J = -(A tile 2J+K)
             GkB[0] = -GkA[0]; GkB[1] = -GkA[2]; GkB[2] = -GkA[1]; GkB[3] = -GkA[3];
@@ -145,19 +143,32 @@ __global__ __launch_bounds__(kHThreads32, 1) void qc_mfma32_pade4_hess_kernel(co
     for (int it = 0; it < per_wg; ++it) {
         const int b = b0 + it;
         if (b >= P.n_int) break;
+        // An opaque copy of the lane index per interval: what derives from it (LDS and store offsets) is recomputed instead of
+        // being hoisted out of the interval loop and held through the products (251 -> 238 registers).
+        int lane = lane0;
+        asm volatile("" : "+v"(lane));
+        const int g = lane >> 4, j = lane & 15;
+        double* __restrict__ scr = TS + w * (16 * 17);
         const long long t = P.t_begin + b;
         const double* __restrict__ z0 = Z + t * (long long)P.zdim;
         const double* __restrict__ z1 = z0 + P.zdim;
         const double* __restrict__ mu = Mu + t * P.F_stride + P.F_off;
         double* __restrict__ Hb = H + (size_t)b * P.H_stride + P.H_off;
-        const double h = ft ? z0[P.off_dt] : P.dt_fixed;   // requested with the other loads; first used behind the barrier
+        // (the fixed timestep as an opaque value: qc_mfma_common.h -- as a second load the compiler merges the two arms into one
+        //  FLAT load, fenced by vmcnt(0))
+        const double h = ft ? z0[P.off_dt] : opaque_scalar(P.dt_fixed);   // requested with the other loads; first used behind the barrier
         QC_STAMP_DECL;
         QC_STAMP(P, b, lane, 0);
 
         // ---- phase 0: wave w assembles half (w & 1) of A-layout tile (w >> 1) of G; waves 4-7 fetch M, U_t, U_t+1 ----
         // (every load unconditional and issued before the first use: a load behind a branch on m is not hoisted.
-        //  Requesting these inputs one interval ahead was tried: the registers it holds across the products spill, and a
-        //  spill reload queued behind the interval's stores costs more than the 1.2 us of load latency it hides.)
+        //  Requesting these inputs one interval ahead was tried twice.  Round 1: the registers it holds across the products spill,
+        //  and a spill reload queued behind the interval's stores costs more than the 1.2 us of load latency it hides.  Round 2,
+        //  with room in the register file: double-buffered LDS blocks, the next interval's loads requested at the start of
+        //  phase 1 and written to LDS at its end.  The second interval of a workgroup got 1.6 us shorter (no phase 0), the
+        //  first 0.9 us longer (eight waves' staging loads in the compute unit's vector-memory issue path next to the products)
+        //  plus the staging of the first interval in front of the loop: 23.6 - 24.8 us against 23.25 us at two intervals per
+        //  workgroup.  It would pay from about four intervals per workgroup (T > 1000 at 4 qubits).)
         {
             const v2d* __restrict__ ab = reinterpret_cast<const v2d*>(GxA) + (w >> 1) * 128 + (w & 1) * 64 + lane;
             v2d img[kHMax32 + 1];

@@ -115,7 +115,7 @@ __global__ __launch_bounds__(kThreads32, 2) void qc_mfma32_pade4_kernel(const Qc
         const double* __restrict__ z1 = z0 + P.zdim;
         double* __restrict__ Jb = JAC ? J + (size_t)b * P.J_stride + P.J_off : nullptr;
         double* __restrict__ Fb = F ? F + (size_t)b * P.F_stride + P.F_off : nullptr;
-        const double h = ft ? z0[P.off_dt] : P.dt_fixed;   // requested with the other loads; first used behind the barriers
+        const double h = ft ? z0[P.off_dt] : opaque_scalar(P.dt_fixed);   // requested with the other loads; first used behind the barriers
         QC_STAMP_DECL;
         QC_STAMP(P, b, lane, 0);
 

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(kHT64, 1) void qc_mfma64_pade4_hess_kernel(const Qc
         const double* __restrict__ z1 = z0 + P.zdim;
         const double* __restrict__ mu = Mu + t * P.F_stride + P.F_off;
         double* __restrict__ Hb = H + (size_t)b * P.H_stride + P.H_off;
-        const double h = ft ? z0[P.off_dt] : P.dt_fixed;
+        const double h = ft ? z0[P.off_dt] : opaque_scalar(P.dt_fixed);
         const double hc1 = h * c1, hc2 = h * h * c2, c2h2 = 2.0 * c2 * h;
         // The thread coordinates are re-derived from an opaque copy of the thread id in every interval: everything computed
         // from them (a few dozen LDS / scratch / image / output offsets) is otherwise hoisted out of the interval loop and spilled.

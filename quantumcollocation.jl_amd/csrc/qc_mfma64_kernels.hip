@@ -109,7 +109,7 @@ __global__ __launch_bounds__(kThreads64, 1) void qc_mfma64_pade4_kernel(const Qc
     const double* __restrict__ z1 = z0 + P.zdim;
     double* __restrict__ Jb = JAC ? J + (size_t)b * P.J_stride + P.J_off : nullptr;
     double* __restrict__ Fb = F ? F + (size_t)b * P.F_stride + P.F_off : nullptr;
-    const double h = ft ? z0[P.off_dt] : P.dt_fixed;
+    const double h = ft ? z0[P.off_dt] : opaque_scalar(P.dt_fixed);
     const double hc1 = h * c1, hc2 = h * h * c2;
 
     // ---------------- phase 0: G and [S | D] into LDS ---------------------------------------------------------

@@ -101,6 +101,26 @@ __device__ inline double load_uniform(const double* __restrict__ p) {
     return p[zero];
 }
 
+// The fixed timestep as a VALUE.  Written `ft ? z0[off_dt] : P.dt_fixed`, both arms are loads (global memory / kernel-argument
+// segment) and the compiler merges them into ONE load through a selected pointer: a FLAT load, in front of which it waits
+// for every outstanding memory operation of the wave -- vmcnt(0), which on gfx9 includes the stores of the previous interval
+// of a persistent loop.  An opaque copy of the kernel argument keeps the arms apart.
+__device__ inline double opaque_scalar(double x) {
+    asm volatile("" : "+s"(x));
+    return x;
+}
+
+// A generator image tile: [pair(2)][lane(64)][2] doubles at `tile`, always device (hipMalloc) memory.  The pointer comes out of
+// the parameter block; in the batched launches that block itself lives in global memory, a pointer loaded from memory has no
+// known address space, and every access through it would be a FLAT load (which the compiler fences with vmcnt(0) /
+// lgkmcnt(0)).  The integer round trip states the address space.
+__device__ inline v4d load_image_tile(const double* tile, int lane) {
+    typedef const __attribute__((address_space(1))) v2d* gptr;
+    const gptr p = (gptr)(unsigned long long)tile + lane;
+    const v2d lo = p[0], hi = p[64];
+    return v4d{lo[0], lo[1], hi[0], hi[1]};
+}
+
 // Identity in B/D layout: lane (g, j) reg r = (4r + g == j)
 __device__ inline v4d identity_B(int g, int j) {
     return v4d{(g == j) ? 1.0 : 0.0, (4 + g == j) ? 1.0 : 0.0, (8 + g == j) ? 1.0 : 0.0, (12 + g == j) ? 1.0 : 0.0};

@@ -126,7 +126,7 @@ __global__ __launch_bounds__(64 * kW, kW) void qc_mfma16_exp_kernel(const QcPara
         const double* __restrict__ z1 = z0 + P.zdim;
         double* __restrict__ Jb = JAC ? J + (size_t)b * P.J_stride + P.J_off : nullptr;
         double* __restrict__ Fb = F ? F + (size_t)b * P.F_stride + P.F_off : nullptr;
-        const double h = ft ? z0[P.off_dt] : P.dt_fixed;
+        const double h = ft ? z0[P.off_dt] : opaque_scalar(P.dt_fixed);
 
         // ---- loads (one batch): knots, generator images --------------------------------------------------------
         // K kets: columns >= nc re-read column 0 and are never stored; N < 8 levels: nr = 2N < 16 rows, zero-padded to the tile

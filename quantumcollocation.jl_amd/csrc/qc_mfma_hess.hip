@@ -22,11 +22,7 @@ constexpr int kHMmax = 8;                     // at most this many drives (held 
 constexpr int kHVals = kHMmax * (kHMmax + 1) / 2 + kHMmax + 1;
 constexpr int kHStride = 65;                  // LDS row stride (doubles) of the reduction scratch
 
-__device__ inline v4d load_img(const double* __restrict__ Gx, int mat, int lane) {
-    const v2d* p = reinterpret_cast<const v2d*>(Gx) + mat * 128 + lane;
-    const v2d lo = p[0], hi = p[64];
-    return v4d{lo[0], lo[1], hi[0], hi[1]};
-}
+__device__ inline v4d load_img(const double* __restrict__ Gx, int mat, int lane) { return load_image_tile(Gx + mat * 256, lane); }
 __device__ inline double dot4(const v4d& a, const v4d& b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3]; }
 __device__ inline v4d sel(bool c, const v4d& a, const v4d& b) {
     return v4d{c ? a[0] : b[0], c ? a[1] : b[1], c ? a[2] : b[2], c ? a[3] : b[3]};
@@ -75,7 +71,7 @@ __global__ __launch_bounds__(64) void qc_mfma16_pade4_hess_kernel(const QcParams
         const int nc = KET ? P.nc : 8, jc = (!KET || jj < nc) ? jj : 0;     // KET = false: the masks fold away at compile time
         const int nr = KET ? P.n : 16;                                      // rows per column (N < 8 levels: zero-padded tile)
         const double av = load_amp_lanes(z0, P.off_a, m, lane);
-        const double h = ft ? load_uniform(z0 + P.off_dt) : P.dt_fixed;
+        const double h = ft ? load_uniform(z0 + P.off_dt) : opaque_scalar(P.dt_fixed);
         v4d gA[kHM], gB[kHM];
         v4d Gb = load_img(GxB, 0, lane);                    // B-layout of G = A-layout of G^T, assembled like Ga (no identity product)
 #pragma unroll
@@ -296,6 +292,10 @@ __global__ __launch_bounds__(64) void qc_mfma16_pade4_hess_kernel(const QcParams
 //   (a_u, a_v) = - sum over ALL lanes of T_u . swap8(T_v)     (left lanes: -N_u . c2 h^2 V_v,  right lanes: c2 h^2 V_u . -N_v)
 //   (a_k, h)   = <Q_p, D> + c1 <[-N_k | -N_k+1], S>  by halves of the lanes;      (h, h) = 2 c2 <M2, D>  (left lanes)
 // Unused drive slots (u >= m) repeat the last drive; nothing derived from them is stored, so nothing is zeroed.
+// (Tried and removed: four intervals per workgroup with the generator images fetched once and shared through LDS -- the images
+// are 14 of the 21 KB a wave requests and the load phase is bound by the compute unit's 64 B / clock vector-memory path.  In the
+// timeline the loads were back 0.25 us earlier, the launch took 10.15 instead of 9.76 us: the 256-thread, 124 KB-LDS workgroups
+// cost more to dispatch and to retire than the loads saved.)
 // The scalar blocks: one row of per-lane partial sums per value in LDS; lanes l and l + 32 sum the left / right lanes' columns of
 // row l, so a row can carry two values (the pair rows) without a lane mask.
 template <int kHM>
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(64) void qc_mfma16_pade4_hess_anti_kernel(const QcP
         const int nc = KET ? P.nc : 8, jc = (!KET || jj < nc) ? jj : 0;
         const int nr = KET ? P.n : 16;
         const double av = load_amp_lanes(z0, P.off_a, m, lane);
-        const double h = ft ? load_uniform(z0 + P.off_dt) : P.dt_fixed;
+        const double h = ft ? load_uniform(z0 + P.off_dt) : opaque_scalar(P.dt_fixed);
         QC_STAMP(P, b, lane, 11);                 // first two loads requested
         v4d gA[kHM];
         v4d Ga = load_img(GxA, 0, lane);

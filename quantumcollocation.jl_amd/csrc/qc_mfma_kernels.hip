@@ -64,11 +64,7 @@ __device__ inline void flag_wait(int* f, int v) {
 constexpr int kMaxGrid = 1024;             // persistent beyond this many workgroups
 
 // A-layout image of generator `mat` (0 = drift): [matrix][pair(2)][lane(64)][2] doubles
-__device__ inline v4d load_GA(const double* __restrict__ Gx, int mat, int lane) {
-    const v2d* p = reinterpret_cast<const v2d*>(Gx) + mat * 128 + lane;
-    const v2d lo = p[0], hi = p[64];
-    return v4d{lo[0], lo[1], hi[0], hi[1]};
-}
+__device__ inline v4d load_GA(const double* __restrict__ Gx, int mat, int lane) { return load_image_tile(Gx + mat * 256, lane); }
 
 constexpr int kDF = 4;   // derivative integrators handled from registers in the copy wave
 
@@ -234,7 +230,7 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
         // what G depends on besides the images -- the amplitudes and the timestep -- is requested as soon as the knot's address
         // exists, before the output addresses are computed (both waves: the compute wave needs the timestep too)
         const double av_pre = (JAC && role == 1) ? load_amp_lanes(z0, P.off_a, m, lane) : 0.0;
-        const double h_pre = ft ? load_uniform(z0 + P.off_dt) : P.dt_fixed;
+        const double h_pre = ft ? load_uniform(z0 + P.off_dt) : opaque_scalar(P.dt_fixed);
         double* __restrict__ Jb = JAC ? J + (size_t)b * P.J_stride + P.J_off : nullptr;
         double* __restrict__ Fb = F ? F + (size_t)b * P.F_stride + P.F_off : nullptr;
         QC_STAMP_DECL;

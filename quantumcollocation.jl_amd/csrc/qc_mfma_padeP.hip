@@ -80,7 +80,7 @@ __global__ __launch_bounds__(kPThreads) void qc_mfma16_padeP_kernel(const QcPara
     const double* __restrict__ z1 = z0 + P.zdim;
     double* __restrict__ Jb = JAC ? J + (size_t)b * P.J_stride + P.J_off : nullptr;
     double* __restrict__ Fb = F ? F + (size_t)b * P.F_stride + P.F_off : nullptr;
-    const double h = ft ? z0[P.off_dt] : P.dt_fixed;
+    const double h = ft ? z0[P.off_dt] : opaque_scalar(P.dt_fixed);
 
     // ---- all waves: partial sums of G = G_0 + sum_k a_k G_k (wave w takes k = w, w+4, ...), two images per round trip ----
     v4d u0 = zero, u1 = zero;

@@ -109,7 +109,7 @@ __global__ __launch_bounds__(kPHThreads, 4) void qc_mfma16_padeP_hess_kernel(con
     const double* __restrict__ z1 = z0 + P.zdim;
     const double* __restrict__ mu = Mu + t * P.F_stride + P.F_off;
     double* __restrict__ Hb = H + (size_t)b * P.H_stride + P.H_off;
-    const double h = ft ? z0[P.off_dt] : P.dt_fixed;
+    const double h = ft ? z0[P.off_dt] : opaque_scalar(P.dt_fixed);
 
     // ---- loads: multipliers (wave 0), states (wave 1), generator images (all), this wave's drive images -------------------
     v4d t0 = zero, t1 = zero, tm = zero;   // waves 0, 1: U_t, U_t+1 tiles [U | U];  wave 0 also [M | M]
