@@ -73,6 +73,23 @@ __device__ inline double wave_sum(double x) {
     return (readlane_f64(x, 0) + readlane_f64(x, 16)) + (readlane_f64(x, 32) + readlane_f64(x, 48));
 }
 
+// N sums at once: every stage of the reduction for all N values before the next stage, so that no instruction waits for its
+// predecessor (one at a time, each of the 4 DPP stages and the read-lane tail is a chain of dependent instructions).  Same
+// order of additions per value as wave_sum: bit-identical results.
+template <int N>
+__device__ __forceinline__ void wave_sum_multi(double (&x)[N]) {
+#pragma unroll
+    for (int q = 0; q < N; ++q) x[q] += dpp_f64<0x128>(x[q]);
+#pragma unroll
+    for (int q = 0; q < N; ++q) x[q] += dpp_f64<0x124>(x[q]);
+#pragma unroll
+    for (int q = 0; q < N; ++q) x[q] += dpp_f64<0x122>(x[q]);
+#pragma unroll
+    for (int q = 0; q < N; ++q) x[q] += dpp_f64<0x121>(x[q]);
+#pragma unroll
+    for (int q = 0; q < N; ++q) x[q] = (readlane_f64(x[q], 0) + readlane_f64(x[q], 16)) + (readlane_f64(x[q], 32) + readlane_f64(x[q], 48));
+}
+
 // NQ independent outputs d[q] = a0[q] * b0[q] + a1[q] * b1[q], MFMAs interleaved round-robin over the outputs
 template <int NQ>
 __device__ __forceinline__ void mm16x2_multi(const v4d (&a0)[NQ], const v4d (&b0)[NQ], const v4d (&a1)[NQ], const v4d (&b1)[NQ],
@@ -93,16 +110,25 @@ __device__ __forceinline__ void mm16x2_multi(const v4d (&a0)[NQ], const v4d (&b0
 }
 
 // lane (g, j) reg r = X[16 J + j][4 r + g] of a column-major 32-row block at p  (a transposed-land tile)
+// FULL: 16 levels and 16 columns exactly (a 4-qubit unitary): no masks -- each mask is an exec-mask save / restore pair around its
+// store, 85 of them per interval, and the scalar registers they occupy are spilled to vector-register lanes
+template <bool FULL>
 __device__ inline void store_T(double* __restrict__ p, const v4d& x, int J, int g, int j, int nc, int nr) {
+    if constexpr (FULL) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) qc_st8m<2>(p + (4 * r + g) * 32 + 16 * J + j, x[r]);
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) if (4 * r + g < nc && 16 * J + j < nr) qc_st8m<2>(p + (4 * r + g) * nr + 16 * J + j, x[r]);
 }
 
 // ANTI: every generator is exactly antisymmetric (QcParams.antisym): the B-layout image tile (K, J) is minus the A-layout
 // tile (J, K), so only the A-layout images are fetched (half of the workgroup's one-time 128 KB image load)
-template <bool DIAG, bool ANTI>
-__global__ __launch_bounds__(kHThreads32, 1) void qc_mfma32_pade4_hess_kernel(const QcParams P, const int per_wg, const double* __restrict__ Z,
+template <bool DIAG, bool ANTI, bool FULL = false>
+__global__ __launch_bounds__(kHThreads32, 1) void qc_mfma32_pade4_hess_kernel(const QcParams Pk, const int per_wg, const double* __restrict__ Z,
                                                                               const double* __restrict__ Mu, double* __restrict__ H) {
+    const QcParams& P = Pk;
     qc_kernarg_touch<sizeof(QcParams) + 64>();   // one batch of scalar-cache misses instead of one per use (qc_internal.h)
     __shared__ __attribute__((aligned(16))) double GL[8 * 256];                 // G: tiles 0-3 A-layout (2I+K), 4-7 B-layout (4+2K+J)
     __shared__ __attribute__((aligned(16))) double ML[2 * 256];                 // M tiles
@@ -115,19 +141,18 @@ __global__ __launch_bounds__(kHThreads32, 1) void qc_mfma32_pade4_hess_kernel(co
     __shared__ double TS[8 * 16 * 17];                                          // per-wave transpose scratch
     const int tid = threadIdx.x;
     const int lane0 = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int m = P.m;
+    const int w0 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = P.m;
     const bool ft = P.off_dt >= 0;
-    const bool drive = w < m;
-    const double c1 = P.c[1], c2 = P.c[2];
+    const bool drive0 = w0 < m0;
     const double* __restrict__ GxA = P.Gx;                              // A-layout images [mat][2I+K]
-    const double* __restrict__ GxB = P.Gx + (size_t)(m + 1) * 1024;     // B-layout images [mat][2K+J]
+    const double* __restrict__ GxB = P.Gx + (size_t)(m0 + 1) * 1024;    // B-layout images [mat][2K+J]
 
     // The drive's images stay in registers for every interval of this workgroup: they are the bulk of the L2 traffic
     // (16 KB per wave), and with one interval per workgroup the kernel was L2-bandwidth-bound in its load phase.
     v4d GkA[4], GkB[4];
     {
-        const int kmat = drive ? w + 1 : 0;
+        const int kmat = drive0 ? w0 + 1 : 0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             GkA[q] = g_tile(GxA + (size_t)kmat * 1024, q, lane0);
@@ -147,8 +172,20 @@ __global__ __launch_bounds__(kHThreads32, 1) void qc_mfma32_pade4_hess_kernel(co
         // being hoisted out of the interval loop and held through the products (251 -> 238 registers).
         int lane = lane0;
         asm volatile("" : "+v"(lane));
+        int w = w0;                                   // (and of the wave index: what derives from it lives in scalar registers)
+        asm volatile("" : "+s"(w));
         const int g = lane >> 4, j = lane & 15;
         double* __restrict__ scr = TS + w * (16 * 17);
+        // The same for the parameter block: its fields are scalar loads from the kernel-argument segment; hoisted out of the loop
+        // they outnumber the scalar registers and are spilled to vector-register lanes (282 v_readlane / 163 v_writelane per
+        // interval, vector instructions all).  Read through an opaque pointer they are re-read where used (scalar-cache hits).
+        typedef const __attribute__((address_space(4))) QcParams* kparams_t;
+        kparams_t Pq = (kparams_t)__builtin_amdgcn_kernarg_segment_ptr();     // (the parameter block is the first argument)
+        asm volatile("" : "+s"(Pq));
+        const auto& P = *Pq;
+        const int m = P.m;                            // (with it the drive-count conditions: sixteen 64-bit masks when hoisted)
+        const bool drive = w < m;
+        const double c1 = P.c[1], c2 = P.c[2];
         const long long t = P.t_begin + b;
         const double* __restrict__ z0 = Z + t * (long long)P.zdim;
         const double* __restrict__ z1 = z0 + P.zdim;
@@ -182,16 +219,16 @@ __global__ __launch_bounds__(kHThreads32, 1) void qc_mfma32_pade4_hess_kernel(co
                 // whole tiles) and nothing of them is stored.  The kernel is MFMA-bound: run-time masks cost nothing here.
                 // Systems with 9 .. 15 levels: nr = 2N < 32 rows per column, zero-padded to the 2 x 2 tiles.
                 const int I = w & 1;
-                const int nr = P.n, cb = (j < P.nc ? j : 0) * nr;
+                const int nr = FULL ? 32 : P.n, cb = ((FULL || j < P.nc) ? j : 0) * nr;
                 auto ld4 = [&](const double* base) {
                     v4d v;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { const int row = 16 * I + 4 * r + g; v[r] = row < nr ? base[cb + row] : 0.0; }
+                    for (int r = 0; r < 4; ++r) { const int row = 16 * I + 4 * r + g; v[r] = (FULL || row < nr) ? base[cb + row] : 0.0; }
                     return v;
                 };
                 if (w < 6) {
                     const v4d mraw = ld4(mu);
-                    put_tile(ML, I, lane, j < P.nc ? mraw : v4d{0.0, 0.0, 0.0, 0.0});
+                    put_tile(ML, I, lane, (FULL || j < P.nc) ? mraw : v4d{0.0, 0.0, 0.0, 0.0});
                 } else {
                     const v4d u0 = ld4(z0 + P.off_U);
                     const v4d u1 = ld4(z1 + P.off_U);
@@ -201,7 +238,7 @@ __global__ __launch_bounds__(kHThreads32, 1) void qc_mfma32_pade4_hess_kernel(co
             }
             if (w == 5) {   // derivative integrators: d2/d(dx_i) dh = -mu_i, a plain copy (done here: a load issued after
                             // the stores of phase 2 would wait for all of them), and the alignment padding
-                qc_hess_tail(P, mu, Hb, lane, 64);
+                qc_hess_tail(Pk, mu, Hb, lane, 64);
             }
             v2d Gh = img[0];
 #pragma unroll
@@ -262,18 +299,51 @@ __global__ __launch_bounds__(kHThreads32, 1) void qc_mfma32_pade4_hess_kernel(co
                 v4d a2[2] = {Nk[0], Nk[0]}, b2[2] = {g_tile(GL, 4, lane), g_tile(GL, 5, lane)}, a3[2] = {Nk[1], Nk[1]},
                     b3[2] = {g_tile(GL, 6, lane), g_tile(GL, 7, lane)}, x1[2];
                 mm16x2_multi<2>(a2, b2, a3, b3, x1);
-                double* pUa = Hb + P.ho_Ua + (size_t)w * P.s;
-                double* paU = Hb + P.ho_aU + (size_t)w * P.s;
+                double* pUa = Hb + P.ho_Ua + (size_t)w * (FULL ? 512 : P.s);
+                double* paU = Hb + P.ho_aU + (size_t)w * (FULL ? 512 : P.s);
 #pragma unroll
                 for (int J = 0; J < 2; ++J) {
                     const v4d lin = (-hc1) * NkT[J], q = hc2 * (x0[J] + x1[J]);
-                    store_T(pUa, lin - q, J, g, j, P.nc, P.n);
-                    store_T(paU, lin + q, J, g, j, P.nc, P.n);
+                    store_T<FULL>(pUa, lin - q, J, g, j, P.nc, P.n);
+                    store_T<FULL>(paU, lin + q, J, g, j, P.nc, P.n);
                 }
             };
             // scalar blocks of this drive from registers + the partner's tiles in LDS: (a_k,h), (a_k,a_k), and the pairs
             // {k, (k+d) mod m}: d = 1 .. (m-1)/2 for every k, d = m/2 (m even) for k < m/2  ->  each unordered pair once
             auto scalar_blocks = [&]() {
+                constexpr int kPairs = kHMax32 / 2;
+                double pv[2 + kPairs];                        // per-lane partial sums: (a_k,h), (a_k,a_k), the pairs at distance 1 .. 4
+                pv[0] = ft ? (dot4(Nk[0], g_tile(WLL, 0, lane)) + dot4(Nk[1], g_tile(WLL, 1, lane))) +
+                                 c2h2 * (dot4(M1a, Vk[0]) + dot4(M1b, Vk[1]))
+                           : 0.0;
+                pv[1] = 2.0 * hc2 * (dot4(Nk[0], Vk[0]) + dot4(Nk[1], Vk[1]));
+#pragma unroll
+                for (int dd = 1; dd <= kPairs; ++dd) {
+                    pv[1 + dd] = 0.0;
+                    if (2 * dd < m || (2 * dd == m && w < dd)) {
+                        const int k = w + dd < m ? w + dd : w + dd - m;
+                        const double* nk = NVL + k * 1024;
+                        const v4d n0 = g_tile(nk, 0, lane), n1 = g_tile(nk, 1, lane), v0 = g_tile(nk, 2, lane), v1 = g_tile(nk, 3, lane);
+                        pv[1 + dd] = hc2 * ((dot4(Nk[0], v0) + dot4(Nk[1], v1)) + (dot4(n0, Vk[0]) + dot4(n1, Vk[1])));
+                    }
+                }
+                // ONE reduction for the six values (one at a time each is a chain of dependent DPP / read-lane instructions
+                // behind its own LDS wait); the same order of additions per value: bit-identical
+                wave_sum_multi<2 + kPairs>(pv);
+                if (lane == 0) {
+                    if (ft) Hb[P.ho_ah + w] = pv[0];
+                    Hb[P.ho_aa + w * (w + 1) / 2 + w] = pv[1];
+#pragma unroll
+                    for (int dd = 1; dd <= kPairs; ++dd) {
+                        if (2 * dd < m || (2 * dd == m && w < dd)) {
+                            const int k = w + dd < m ? w + dd : w + dd - m;
+                            const int lo = k < w ? k : w, hi = k < w ? w : k;
+                            Hb[P.ho_aa + hi * (hi + 1) / 2 + lo] = pv[1 + dd];
+                        }
+                    }
+                }
+            };
+            auto scalar_blocks_serial = [&]() {
                 if (ft) {
                     const double v = wave_sum((dot4(Nk[0], g_tile(WLL, 0, lane)) + dot4(Nk[1], g_tile(WLL, 1, lane))) +
                                               c2h2 * (dot4(M1a, Vk[0]) + dot4(M1b, Vk[1])));
@@ -296,27 +366,30 @@ __global__ __launch_bounds__(kHThreads32, 1) void qc_mfma32_pade4_hess_kernel(co
                 }
             };
             // waves w and w + 4 share a SIMD: one runs its MFMA chain while the other does LDS/VALU work
+            // (the scalar blocks with ONE batched reduction behind the matrix blocks: 1.4 instead of 2.3 us; in front of them,
+            //  next to the other wave's MFMAs: 3.0 instead of 2.5 us -- measured both ways in one run)
             if (w < 4) {
                 matrix_blocks();
                 QC_STAMP(P, b, lane, 5);
                 scalar_blocks();
             } else {
-                scalar_blocks();
+                scalar_blocks_serial();
                 QC_STAMP(P, b, lane, 5);
                 matrix_blocks();
             }
         }
         QC_STAMP(P, b, lane, 6);      // drive blocks and scalars done
         if (ft) {
-            if (w == 4 || w == 5) {   // (U_t,h)^T and (h,U_t+1)^T, column block J
-                const int J = w - 4;
+            // (waves 0 - 2: with the batched reduction they are through their drive blocks 0.9 us before waves 4 - 7)
+            if (w == 0 || w == 1) {   // (U_t,h)^T and (h,U_t+1)^T, column block J
+                const int J = w;
                 const v4d gb0 = g_tile(GL, 4 + J, lane), gb1 = g_tile(GL, 4 + 2 + J, lane);
                 v4d a0[1] = {M1a}, b0[1] = {gb0}, a1[1] = {M1b}, b1[1] = {gb1}, d[1];
                 mm16x2_multi<1>(a0, b0, a1, b1, d);      // M2^T[J] = sum_K M1[K]^T G[K][J]
                 const v4d m1t = lds_transpose16(scr, J == 0 ? M1a : M1b, g, j);   // M1^T[J] = (M1[J])^T
-                store_T(Hb + P.ho_Uh, -(c1 * m1t + c2h2 * d[0]), J, g, j, P.nc, P.n);
-                store_T(Hb + P.ho_hU, (-c1) * m1t + c2h2 * d[0], J, g, j, P.nc, P.n);
-            } else if (w == 6) {      // (h, h)
+                store_T<FULL>(Hb + P.ho_Uh, -(c1 * m1t + c2h2 * d[0]), J, g, j, P.nc, P.n);
+                store_T<FULL>(Hb + P.ho_hU, (-c1) * m1t + c2h2 * d[0], J, g, j, P.nc, P.n);
+            } else if (w == 2) {      // (h, h)
                 const double sum = wave_sum(dot4(M1a, g_tile(GDL, 0, lane)) + dot4(M1b, g_tile(GDL, 1, lane)));
                 if (lane == 0) Hb[P.ho_hh] = 2.0 * c2 * sum;
             }
@@ -339,10 +412,12 @@ bool qc_mfma32_hess_supported(const QcParams& P) {
 }
 
 hipError_t qc_launch_mfma32_hess(const QcParams& P, const double* dZ, const double* dMu, double* dH, hipStream_t st) {
-    // one workgroup per CU (239 VGPRs, 121 KB LDS); each takes a contiguous run of intervals and keeps its drive images
+    // one workgroup per CU (200 VGPRs, 121 KB LDS); each takes a contiguous run of intervals and keeps its drive images
     const int per_wg = (P.n_int + kHCUs - 1) / kHCUs;
     const int grid = (P.n_int + per_wg - 1) / per_wg;
-    if (P.stamps != nullptr) hipLaunchKernelGGL((qc_mfma32_pade4_hess_kernel<true, false>), dim3(grid), dim3(kHThreads32), 0, st, P, per_wg, dZ, dMu, dH);
+    if (P.stamps != nullptr && P.antisym && P.n == 32 && P.nc == 16) hipLaunchKernelGGL((qc_mfma32_pade4_hess_kernel<true, true, true>), dim3(grid), dim3(kHThreads32), 0, st, P, per_wg, dZ, dMu, dH);
+    else if (P.stamps != nullptr) hipLaunchKernelGGL((qc_mfma32_pade4_hess_kernel<true, false>), dim3(grid), dim3(kHThreads32), 0, st, P, per_wg, dZ, dMu, dH);
+    else if (P.antisym && P.n == 32 && P.nc == 16) hipLaunchKernelGGL((qc_mfma32_pade4_hess_kernel<false, true, true>), dim3(grid), dim3(kHThreads32), 0, st, P, per_wg, dZ, dMu, dH);
     else if (P.antisym) hipLaunchKernelGGL((qc_mfma32_pade4_hess_kernel<false, true>), dim3(grid), dim3(kHThreads32), 0, st, P, per_wg, dZ, dMu, dH);
     else hipLaunchKernelGGL((qc_mfma32_pade4_hess_kernel<false, false>), dim3(grid), dim3(kHThreads32), 0, st, P, per_wg, dZ, dMu, dH);
     return hipGetLastError();

@@ -444,12 +444,11 @@ def test_antisymmetric_generator_path_matches_general_path(qc, monkeypatch, cfg,
         mu = np.random.default_rng(9).standard_normal(dyn.dims.n_rows)
         out.append(dyn.mu_d2F(Z, mu))
         dyn.close()
-    if cfg == 5:
-        np.testing.assert_array_equal(out[0], out[1])      # 2N = 32: the same kernel, images by negation
-    else:
-        # 2N = 16: a kernel of its own for antisymmetric generators (sign-free formulation, two product stages)
-        scale = np.abs(out[1]).max()
-        np.testing.assert_allclose(out[0], out[1], rtol=1e-11, atol=1e-12 * scale)
+    # 2N = 16: a kernel of its own for antisymmetric generators (sign-free formulation, two product stages); 2N = 32: the same
+    # kernel, images by negation, but an instantiation of its own (no masks at 16 levels x 16 columns): the compiler contracts
+    # multiply-adds differently, the last bit may differ
+    scale = np.abs(out[1]).max()
+    np.testing.assert_allclose(out[0], out[1], rtol=1e-11, atol=1e-12 * scale)
 
 
 @pytest.mark.parametrize("cfg,T", [(3, 1000), (5, 500)])
