@@ -333,6 +333,15 @@ __global__ __launch_bounds__(64) void qc_mfma16_pade4_hess_anti_kernel(const QcP
     const double* __restrict__ GxA = P.Gx;
     const v4d zero = {0.0, 0.0, 0.0, 0.0};
 
+    // The generator images depend on nothing but the kernel arguments: requested before any address of the interval is computed
+    // (and once for all intervals of a persistent grid)
+    v4d gA[kHM];
+    const v4d G0 = load_img(GxA, 0, lane);
+#pragma unroll
+    for (int u = 0; u < kHM; ++u) {
+        const int k = u < m ? u : (m > 0 ? m - 1 : 0);
+        gA[u] = load_img(GxA, m > 0 ? k + 1 : 0, lane);
+    }
     int vb = blockIdx.x;
     if (vb >= P.n_int) return;
     do {
@@ -349,13 +358,7 @@ __global__ __launch_bounds__(64) void qc_mfma16_pade4_hess_anti_kernel(const QcP
         const double av = load_amp_lanes(z0, P.off_a, m, lane);
         const double h = ft ? load_uniform(z0 + P.off_dt) : opaque_scalar(P.dt_fixed);
         QC_STAMP(P, b, lane, 11);                 // first two loads requested
-        v4d gA[kHM];
-        v4d Ga = load_img(GxA, 0, lane);
-#pragma unroll
-        for (int u = 0; u < kHM; ++u) {
-            const int k = u < m ? u : (m > 0 ? m - 1 : 0);
-            gA[u] = load_img(GxA, m > 0 ? k + 1 : 0, lane);
-        }
+        v4d Ga = G0;
         v4d u0, u1, mraw;
         if constexpr (!KET) {
             const double* u0p = z0 + P.off_U + jc * 16 + g;
