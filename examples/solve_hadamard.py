@@ -16,7 +16,6 @@ import os
 import sys
 
 import numpy as np
-import scipy.sparse as sp
 from scipy.optimize import Bounds, NonlinearConstraint, minimize
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -44,10 +43,9 @@ def solve(max_iter: int = 60, T: int = 50, verbose: bool = True, method: str = "
     R = 1e-2   # R_a = R_da = R_dda (reference unitary_smooth_pulse_problem.jl:151-153), evaluated by qc_terms_*
     reg = qc.TrajectoryObjective(qc.QuadraticRegularizer("a", traj, R) + qc.QuadraticRegularizer("da", traj, R)
                                  + qc.QuadraticRegularizer("dda", traj, R), traj)
-    rhr, rhc = reg.hess_structure
-    jr, jc = dyn.dF_structure
-    hr, hc = dyn.mu_d2F_structure
-    ohr, ohc = obj.hess_structure
+    # the NLP evaluator Ipopt's interface would drive (quantumcollocation.jl_amd/evaluator.py): objective terms, dynamics rows,
+    # Lagrangian Hessian over one fixed structure
+    ev = qc.QuantumControlEvaluator(dyn, [obj, reg])
 
     # pinned variables (initial state, initial/final controls) are eliminated: the solver sees only the free ones
     z_full = traj.datavec.copy()
@@ -69,31 +67,26 @@ def solve(max_iter: int = 60, T: int = 50, verbose: bool = True, method: str = "
         return z
 
     def fun(x):
-        z = full(x)
-        return obj.L(z) + reg.L(z)
+        return ev.eval_objective(full(x))
 
     def grad(x):
-        z = full(x)
-        gvec = reg.grad_L(z).copy()
-        gvec[obj.state_indices] += obj.grad_L(z)
+        gvec = np.empty(nv)
+        ev.eval_objective_gradient(gvec, full(x))
         return gvec[free]
 
     def hess_obj(x):
-        z = full(x)
-        Hu = sp.coo_matrix((obj.hess_L(z), (ohr, ohc)), shape=(nv, nv)).tocsr()
-        Hu = Hu + sp.coo_matrix((reg.hess_L(z), (rhr, rhc)), shape=(nv, nv)).tocsr()
-        Hm = Hu + sp.triu(Hu, 1).T
-        return Hm[free][:, free]
+        return ev.hessian_lagrangian_matrix(full(x), 1.0, np.zeros(ev.n_constraints))[free][:, free]
 
     def cons(x):
-        return dyn.F(full(x))
+        c = np.empty(ev.n_constraints)
+        ev.eval_constraint(c, full(x))
+        return c
 
     def cons_jac(x):
-        return sp.coo_matrix((dyn.dF(full(x)), (jr, jc)), shape=(int(dyn.dims.n_rows), nv)).tocsc()[:, free]
+        return ev.jacobian_matrix(full(x)).tocsc()[:, free]
 
     def cons_hess(x, v):
-        Hu = sp.coo_matrix((dyn.mu_d2F(full(x), v), (hr, hc)), shape=(nv, nv)).tocsr()
-        return (Hu + sp.triu(Hu, 1).T)[free][:, free]
+        return ev.hessian_lagrangian_matrix(full(x), 0.0, v)[free][:, free]
 
     # bounds: |a| <= 1, |dda| <= 1, dt in [0.1, 0.3]
     lb, ub = np.full(nv, -np.inf), np.full(nv, np.inf)

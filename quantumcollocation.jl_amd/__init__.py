@@ -6,6 +6,7 @@ of include/qcolloc.h.  The directory name carries a dot, so load it through
 """
 from . import _lib
 from ._lib import QCollocError
+from .evaluator import QuantumControlEvaluator
 from .dynamics import ComposedQuantumDynamics, QuantumDynamics, desc_dims, desc_structures, make_desc, split_groups, state_row_offset
 from .gates import GATES, PAULIS, operator_from_string
 from .integrators import (DensityOperatorExponentialIntegrator, DerivativeIntegrator, QuantumStateExponentialIntegrator, QuantumStatePadeIntegrator,
@@ -24,6 +25,7 @@ from .rollouts import open_rollout, rollout, unitary_rollout, unitary_rollout_fi
 from .trajectory_initialization import initialize_trajectory, unitary_geodesic
 
 __all__ = [
+    "QuantumControlEvaluator",
     "QuantumDynamics", "QuantumSystem", "NamedTrajectory", "UnitaryPadeIntegrator",
     "UnitaryExponentialIntegrator", "DerivativeIntegrator", "QuantumStatePadeIntegrator",
     "QuantumStateExponentialIntegrator", "quantum_state_smooth_pulse_inputs", "quantum_state_sampling_inputs", "unitary_sampling_inputs", "ComposedQuantumDynamics", "split_groups", "operator_to_iso_vec", "iso_vec_to_operator",
