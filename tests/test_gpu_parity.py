@@ -1374,3 +1374,47 @@ def test_config5_callback_set_on_one_stream(qc, oracle):
     np.testing.assert_allclose(tH.cpu().numpy(), oracle.terms_hess(tm, Zh), rtol=1e-12, atol=1e-14)
     for o_ in (dyn, con, terms):
         o_.close()
+
+
+@pytest.mark.parametrize("N,m", [(8, 6), (4, 3), (16, 2)])
+@pytest.mark.parametrize("dims", [(), (None,), (None, None, None), (None, None, None, 5), (None, 70), (3, None, 65, None, 1)])
+def test_derivative_integrator_counts_and_sizes(qc, oracle, N, m, dims):
+    """0, 1, 3, 4 and 5 derivative integrators, dimensions up to 70: the kernels serve up to two (Hessian) / four (F + dF)
+    integrators of at most 64 components from registers requested with the interval's other loads, anything else through the
+    generic tail -- both must give the oracle's rows, Jacobian entries and d2/d(dx_i) dh = -mu_i Hessian entries."""
+    rng = np.random.default_rng(41 + N + len(dims))
+    n, s = 2 * N, 2 * N * N
+    dims = [m if d is None else d for d in dims]
+    A = lambda: (lambda X: (X + X.conj().T) / 2)(rng.standard_normal((N, N)) + 1j * rng.standard_normal((N, N)))   # noqa: E731
+    G0 = oracle.generator(A())
+    Gd = np.array([oracle.generator(A()) for _ in range(m)]).reshape(m, n, n)
+    # knot: [U (s), a (m), then per derivative integrator a pair (x, dx) chained where the dimension allows, dt]
+    off, derivs = s + m, []
+    prev_off, prev_dim = s, m                       # the first chain starts at the amplitudes
+    for d in dims:
+        if d == prev_dim:                           # chained: x = the previous dx (a -> da -> dda ...)
+            x_off = prev_off
+        else:                                       # an independent pair
+            x_off = off
+            off += d
+        derivs.append(oracle.DerivSpec(x_off, off, d))
+        prev_off, prev_dim = off, d
+        off += d
+    zdim = off + 1
+    T = 4
+    prob = oracle.Problem(N=N, m=m, T=T, zdim=zdim, off_U=0, off_a=s, off_dt=zdim - 1, G_drift=G0, G_drives=Gd, dt_fixed=0.17,
+                          integrator=oracle.PADE, order=4, derivs=derivs, ncol=0)
+    Z = rng.standard_normal(zdim * T) * 0.5
+    Z[zdim - 1::zdim] = rng.uniform(0.1, 0.3, size=T)
+    mu = rng.standard_normal(prob.n_rows)
+    F_ref, J_ref, H_ref = oracle.F(prob, Z), oracle.dF(prob, Z), oracle.mu_d2F(prob, Z, mu)
+    for kernel in kernels_for(qc, prob):
+        h = RawHandle(qc, prob, kernel=kernel)
+        F, J = h.F_jac(Z)
+        assert_close(F, F_ref, f"F {kernel} {dims}")
+        assert_close(J, J_ref, f"dF {kernel} {dims}")
+        assert_close_h(h.hess(Z, mu), H_ref, f"hess {kernel} {dims}")
+        jr, jc = h.structure()
+        rr, rc = oracle.jac_structure(prob)
+        assert np.array_equal(jr, rr) and np.array_equal(jc, rc)
+        h.close()
