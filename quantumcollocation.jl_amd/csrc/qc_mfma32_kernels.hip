@@ -66,6 +66,37 @@ __device__ inline void store_T32(double* __restrict__ p, const v4d& x, int rowba
 #pragma unroll
     for (int r = 0; r < 4; ++r) qc_st8m<2>(p + (colbase + 4 * r + g) * 32 + rowbase + j, x[r]);   // non-temporal, compile-time
 }
+// Two transposed tiles of the SAME columns, rows 0-15 (x0) and 16-31 (x1), as full 256-byte columns: v_permlane16_swap (gfx950)
+// exchanges the odd 16-lane rows of one register with the even rows of the other, after which lanes 0-31 of a register hold
+// one whole column and lanes 32-63 another -- two contiguous 256-byte pieces per store instruction instead of four 128-byte
+// halves whose partners are written by another instruction at another time (DRAM row locality: config 5's F + dF streams
+// 154 MB per launch).
+__device__ inline void swap16_f64(double a, double b, double& x, double& y) {
+    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    x = __hiloint2double((int)hi[0], (int)lo[0]);     // 16-lane rows: [a.0, b.0, a.2, b.2]
+    y = __hiloint2double((int)hi[1], (int)lo[1]);     //               [a.1, b.1, a.3, b.3]
+}
+struct ColumnPair { v4d e, o; };                      // registers r: columns 4r + (g & 2) and 4r + (g & 2) + 1, rows 16 (g & 1) + j
+__device__ inline ColumnPair merge_rows32(const v4d& x0, const v4d& x1) {
+    ColumnPair c;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        double x, y;
+        swap16_f64(x0[r], x1[r], x, y);
+        c.e[r] = x;
+        c.o[r] = y;
+    }
+    return c;
+}
+__device__ inline void store_T32_columns(double* __restrict__ p, const ColumnPair& c, int colbase, int g, int j) {
+    double* __restrict__ q = p + (colbase + (g & 2)) * 32 + 16 * (g & 1) + j;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        qc_st8m<2>(q + (4 * r) * 32, c.e[r]);
+        qc_st8m<2>(q + (4 * r + 1) * 32, c.o[r]);
+    }
+}
 // the masked forms (KET instantiation): the state block has nr <= 32 rows per column and nc <= 16 columns; the operator
 // blocks are nr x nr (systems with 9 .. 15 levels are zero-padded to the 2 x 2 tiles)
 __device__ inline void store_T32_cols(double* __restrict__ p, const v4d& x, int rowbase, int nc, int nr, int g, int j) {
@@ -89,24 +120,30 @@ __global__ __launch_bounds__(kThreads32, 2) void qc_mfma32_pade4_kernel(const Qc
     __shared__ __attribute__((aligned(16))) double ImgL[(kMU32 + 1) * 4 * 256];        // image tile t of matrix k at (k * 4 + t) * 256
     __shared__ double DerL[2 * 2 * kDF32 * 64];                                          // derivative-integrator data parked until the end
     const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool copy_role = w >= 4;
-    const int slot = (w & 3) >> 1;      // which interval of the pair
-    const int sub = w & 1;              // compute: drive parity; copy: block row I
+    const int lane0 = tid & 63;
+    const int w0 = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = P.m;
     const int mL = m < kMU32 ? m : kMU32;
-    const int g = lane >> 4, j = lane & 15;
-    const int nc = KET ? P.nc : 16;
-    const int nr = KET ? P.n : 32;
-    const int jc = (!KET || j < nc) ? j : 0;
     const bool ft = P.off_dt >= 0;
     const double c1 = P.c[1], c2 = P.c[2];
     const double* __restrict__ Gx = P.Gx;
-    const v4d IdB = identity_B(g, j);
     const int n_wg = SINGLE ? P.n_int : (P.n_int + 1) / 2;
 
     for (int vb = blockIdx.x; vb < n_wg; vb += gridDim.x) {
+        // Opaque per-pass copies of the lane and wave indices: what derives from them (LDS and store offsets, role flags) is
+        // computed where it is used instead of being hoisted out of the persistent loop and held -- at the kernel's 256-register
+        // budget: spilled -- through the products (qc_mfma32_hess.hip).
+        int lane = lane0, w = w0;
+        asm volatile("" : "+v"(lane));
+        asm volatile("" : "+s"(w));
+        const bool copy_role = w >= 4;
+        const int slot = (w & 3) >> 1;      // which interval of the pair
+        const int sub = w & 1;              // compute: drive parity; copy: block row I
+        const int g = lane >> 4, j = lane & 15;
+        const int nc = KET ? P.nc : 16;
+        const int nr = KET ? P.n : 32;
+        const int jc = (!KET || j < nc) ? j : 0;
+        const v4d IdB = identity_B(g, j);
         const int b_raw = SINGLE ? qc_xcd_remap(vb, n_wg) : 2 * qc_xcd_remap(vb, n_wg) + slot;
         const bool active = b_raw < P.n_int;                  // an odd interval count leaves the last slot empty;
         const int b = active ? b_raw : P.n_int - 1;           // its waves still load images and take part in the barriers
@@ -218,6 +255,11 @@ __global__ __launch_bounds__(kThreads32, 2) void qc_mfma32_pade4_kernel(const Qc
                 double* pF = Jb + P.jo_F;
                 double* pB = Jb + P.jo_B;
                 const int ncop = P.copies;   // N copies of each block; 1 when the host path asks for the compact form
+                ColumnPair Fc, Bc;
+                if constexpr (!KET) {
+                    Fc = merge_rows32(Fm[0], Fm[1]);
+                    Bc = merge_rows32(Bm[0], Bm[1]);
+                }
                 for (int q = SINGLE ? slot : 0; q < ncop; q += SINGLE ? 2 : 1) {   // SINGLE: waves 4, 5 even copies, 6, 7 odd
                     if constexpr (KET) {
                         const size_t o = (size_t)q * nr * nr;
@@ -227,10 +269,8 @@ __global__ __launch_bounds__(kThreads32, 2) void qc_mfma32_pade4_kernel(const Qc
                         store_T32_masked(pB + o, Bm[1], 16, 16 * I, nr, g, j);
                         continue;
                     }
-                    store_T32(pF + q * 1024, Fm[0], 0, 16 * I, g, j);
-                    store_T32(pF + q * 1024, Fm[1], 16, 16 * I, g, j);
-                    store_T32(pB + q * 1024, Bm[0], 0, 16 * I, g, j);
-                    store_T32(pB + q * 1024, Bm[1], 16, 16 * I, g, j);
+                    store_T32_columns(pF + q * 1024, Fc, 16 * I, g, j);
+                    store_T32_columns(pB + q * 1024, Bc, 16 * I, g, j);
                 }
                 if (deriv_wave) {   // derivative integrator rows
                     int jo = P.jo_d;
@@ -300,12 +340,15 @@ __global__ __launch_bounds__(kThreads32, 2) void qc_mfma32_pade4_kernel(const Qc
 #pragma unroll
                     for (int I = 0; I < 2; ++I) R1[I] = mm16x2(Gk[2 * I], D[0], Gk[2 * I + 1], D[1]);
                     double* pa = Jb + P.jo_a + (size_t)k * (KET ? P.s : 512);
+                    v4d YT[2];
 #pragma unroll
                     for (int I = 0; I < 2; ++I) {
                         const v4d R0 = mm16x2(Gk[2 * I], Q0[0], Gk[2 * I + 1], Q0[1]);          // G_k Q_0
                         const v4d Y = R0 + hc2 * mm16x2(Ga[2 * I], R1[0], Ga[2 * I + 1], R1[1]);   // + h^2 c2 G (G_k D)
-                        if constexpr (KET) store_T32_cols(pa, mm16(Y, IdB), 16 * I, nc, nr, g, j); else store_T32(pa, mm16(Y, IdB), 16 * I, 0, g, j);
+                        YT[I] = mm16(Y, IdB);
+                        if constexpr (KET) store_T32_cols(pa, YT[I], 16 * I, nc, nr, g, j);
                     }
+                    if constexpr (!KET) store_T32_columns(pa, merge_rows32(YT[0], YT[1]), 0, g, j);
                 }
             }
         }

@@ -183,7 +183,7 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
 #endif
     // (Demanding every argument of the prologue at one point -- one batch of scalar loads -- was measured: 10.0 vs 9.6 us.)
     const int tid = threadIdx.x;
-    const int lane = tid & 63;
+    const int lane0 = tid & 63;
     const int wave = JAC ? __builtin_amdgcn_readfirstlane(tid >> 6) : 0;
     // 0 compute wave, 1 copy wave (the first wave of the workgroup computes).  Swapping the roles in every other workgroup, so
     // that the compute waves of a CU's workgroups do not share SIMDs, was measured (blockIdx bits 0, 3, 8, 9): 10.4 - 11.3 us
@@ -194,18 +194,14 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
     const int ipw = JAC ? kIntervalsPerWG : 1;
     const int n_wg = (P.n_int + ipw - 1) / ipw;
     const int m = P.m;
-    const int g = lane >> 4, j = lane & 15, jj = j & 7;
     // KET = false: a unitary on N = 8 levels, every mask below folds away at compile time (as run-time tests they cost the
     // headline kernel 0.8 us per launch).  KET = true: the masked instantiation -- K <= 8 state columns (kets) and / or
     // N < 8 levels (2N = nr < 16 rows, zero-padded to the tile).
     const int nc = KET ? P.nc : 8;
     const int nr = KET ? P.n : 16;
-    const int jc = (!KET || jj < nc) ? jj : 0;
-    const bool left = j < 8;
     const bool ft = P.off_dt >= 0;
     const double c1 = P.c[1], c2 = P.c[2];
     const double* __restrict__ Gx = P.Gx;
-    const v4d IdB = identity_B(g, j);
     int* const fl = hflag + 2 * slot;
     int seq = 0;
     if constexpr (JAC && kFlags) {
@@ -216,11 +212,20 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
     // The copy wave's generator images depend on nothing but the kernel arguments: they are requested before any address of the
     // interval is computed (and once for all intervals of a persistent grid).
     v4d g0_img, gk_img[kMU];
-    if (JAC && role == 1) request_images(P, Gx, lane, g0_img, gk_img);
+    if (JAC && role == 1) request_images(P, Gx, lane0, g0_img, gk_img);
     int vb = blockIdx.x;
     if (vb >= n_wg) return;   // (never: the grid has at most n_wg workgroups)
     do {
         ++seq;
+        // Persistent grids: an opaque copy of the lane index per pass -- what derives from it (tile masks, LDS and store offsets,
+        // the identity tile) is computed where it is used instead of being hoisted out of the loop and held, at this kernel's
+        // 256-register budget spilled, through the products (22 of the 96 instantiations kept 20 - 260 bytes of scratch).
+        int lane = lane0;
+        if constexpr (!ONCE) asm volatile("" : "+v"(lane));
+        const int g = lane >> 4, j = lane & 15, jj = j & 7;
+        const int jc = (!KET || jj < nc) ? jj : 0;
+        const bool left = j < 8;
+        const v4d IdB = identity_B(g, j);
         const int b_raw = qc_xcd_remap(vb, n_wg) * ipw + slot;   // local interval of this wave pair
         const bool active = b_raw < P.n_int;                      // the last workgroup may be partly empty;
         const int b = active ? b_raw : P.n_int - 1;               // its idle waves still take part in the barriers
