@@ -43,24 +43,12 @@ namespace {
 
 using namespace qc_mfma;
 
-#ifndef QC_IPW
-#define QC_IPW 1
-#endif
-constexpr int kIntervalsPerWG = QC_IPW;    // interval pairs per workgroup: waves [0, IPW) compute, [IPW, 2 IPW) copy.
+constexpr int kIntervalsPerWG = 1;         // interval pairs per workgroup: waves [0, IPW) compute, [IPW, 2 IPW) copy.
                                            // Measured on MI355X (bench.py, config 3): IPW 1 -> 11.55 us, 2 -> 11.60 us,
-                                           // 4 -> 12.0 us per evaluation (the wider barrier couples four intervals).
+                                           // 4 -> 12.0 us per evaluation (the wider barrier couples four intervals); with the
+                                           // hand-off through one LDS flag per wave pair instead of the workgroup barriers
+                                           // (pairs independent of each other) 11.34 / 11.75 / 12.04 us against 11.17 us.
 constexpr int kThreads = 128 * kIntervalsPerWG;
-#ifndef QC_HANDOFF_FLAGS
-#define QC_HANDOFF_FLAGS 0
-#endif
-// Hand-off of G / U_t / U_t+1 / the G_j images from a copy wave to its compute wave: 0 = workgroup barriers (two per interval),
-// 1 = one LDS flag per wave pair (the pairs of a workgroup are then independent of each other; one barrier at kernel entry).
-constexpr bool kFlags = QC_HANDOFF_FLAGS != 0;
-
-__device__ inline void flag_set(int* f, int v) { __hip_atomic_store(f, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__device__ inline void flag_wait(int* f, int v) {
-    while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != v) __builtin_amdgcn_s_sleep(1);
-}
 constexpr int kMaxGrid = 1024;             // persistent beyond this many workgroups
 
 // A-layout image of generator `mat` (0 = drift): [matrix][pair(2)][lane(64)][2] doubles
@@ -169,7 +157,6 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
     const QcParams& P = BATCH ? Pb[blockIdx.y] : Pk;
     constexpr int kLdsBlock = kLdsGk + kMU * 256;
     __shared__ __attribute__((aligned(16))) double sm_all[JAC ? kIntervalsPerWG * kLdsBlock : 2];
-    __shared__ int hflag[2 * kIntervalsPerWG];   // per wave pair: [0] block published (sequence number), [1] block consumed
     unsigned long long t_entry = 0, t_kernarg = 0;
     if constexpr (DIAG) {
         t_entry = __builtin_amdgcn_s_memrealtime();
@@ -202,12 +189,6 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
     const bool ft = P.off_dt >= 0;
     const double c1 = P.c[1], c2 = P.c[2];
     const double* __restrict__ Gx = P.Gx;
-    int* const fl = hflag + 2 * slot;
-    int seq = 0;
-    if constexpr (JAC && kFlags) {
-        if (tid < 2 * kIntervalsPerWG) hflag[tid] = 0;
-        __syncthreads();
-    }
 
     // The copy wave's generator images depend on nothing but the kernel arguments: they are requested before any address of the
     // interval is computed (and once for all intervals of a persistent grid).
@@ -216,7 +197,6 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
     int vb = blockIdx.x;
     if (vb >= n_wg) return;   // (never: the grid has at most n_wg workgroups)
     do {
-        ++seq;
         // Persistent grids: an opaque copy of the lane index per pass -- what derives from it (tile masks, LDS and store offsets,
         // the identity tile) is computed where it is used instead of being hoisted out of the loop and held, at this kernel's
         // 256-register budget spilled, through the products (22 of the 96 instantiations kept 20 - 260 bytes of scratch).
@@ -242,7 +222,7 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
 
         if (JAC && role == 1) {
             // ================= copy wave =====================================================================
-            if (!active) { if constexpr (!kFlags) { __syncthreads(); if constexpr (!ONCE) __syncthreads(); } continue; }
+            if (!active) { __syncthreads(); if constexpr (!ONCE) __syncthreads(); continue; }
             __builtin_amdgcn_s_setprio(3);   // critical path: nothing reaches HBM before this wave's first store
             if constexpr (DIAG) {
                 qc_ts_[9] = t_entry;
@@ -293,15 +273,13 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
                 Bm[r] = ev - hc1 * Ga[r];          //  B^T
             }
             // hand-off to the compute wave
-            if constexpr (kFlags) { if (seq > 1) flag_wait(fl + 1, seq - 1); }   // persistent grid: the previous block has been consumed
             lds_put(sm + kLdsGa, lane, Ga);
             lds_put(sm + kLdsU0, lane, u0);
             lds_put(sm + kLdsU1, lane, u1);
 #pragma unroll
             for (int u = 0; u < kMU; ++u)
                 if (u < m) lds_put(sm + kLdsGk + u * 256, lane, gk[u]);
-            if constexpr (kFlags) { if (lane == 0) flag_set(fl, seq); }
-            else __syncthreads();
+            __syncthreads();
             if (!skip) {
                 double* pF = Jb + P.jo_F;
                 double* pB = Jb + P.jo_B;
@@ -349,12 +327,12 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
                 QC_STAMP_FLUSH(P, b, lane, 0, 3);
                 QC_STAMP_FLUSH(P, b, lane, 9, 11);
             }
-            if constexpr (!kFlags && !ONCE) __syncthreads();   // the hand-off block is rewritten by the next interval of a persistent grid
+            if constexpr (!ONCE) __syncthreads();   // the hand-off block is rewritten by the next interval of a persistent grid
             continue;
         }
 
         // ===================== compute wave ===========================================================
-        if (!active) { if constexpr (JAC && !kFlags) { __syncthreads(); if constexpr (!ONCE) __syncthreads(); } continue; }
+        if (!active) { if constexpr (JAC) { __syncthreads(); if constexpr (!ONCE) __syncthreads(); } continue; }
         __builtin_amdgcn_s_setprio(1);
         QC_STAMP(P, b, lane, 4);
         QC_STAMP_CYCLES(13);
@@ -362,8 +340,7 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
         v4d u0, u1, Ga;
         v4d gk[kMU];
         if constexpr (JAC) {
-            if constexpr (kFlags) flag_wait(fl, seq);
-            else __syncthreads();                 // wait for the copy wave's hand-off
+            __syncthreads();                      // wait for the copy wave's hand-off
             Ga = lds_get(sm + kLdsGa, lane);
             u0 = lds_get(sm + kLdsU0, lane);
             u1 = lds_get(sm + kLdsU1, lane);
@@ -406,9 +383,6 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
                     }
                 }
                 mm16_multi<NB>(aB, bB, sB);
-            }
-            if constexpr (JAC && kFlags) {            // every tile of the hand-off block is in registers (or consumed): release it
-                if (gridDim.x < (unsigned)n_wg && lane == 0) flag_set(fl + 1, seq);
             }
             const v4d P2 = sB[0];                     // [G^2 D | G^2 S]
             QC_STAMP(P, b, lane, 6);
@@ -534,7 +508,7 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
             if constexpr (DIAG) qc_ts_[15] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | (1ull << 40);   // HW_REG_HW_ID
             QC_STAMP_FLUSH(P, b, lane, 4, 15);
         }
-        if constexpr (JAC && !kFlags && !ONCE) __syncthreads();   // pairs with the copy wave's end-of-interval barrier
+        if constexpr (JAC && !ONCE) __syncthreads();   // pairs with the copy wave's end-of-interval barrier
     } while (!ONCE && (vb += gridDim.x) < n_wg);
 }
 
