@@ -327,9 +327,14 @@ int pool_workers(int shards) {
 }
 }  // namespace
 
-static int chunk_count(const qc_handle* h, int n_int, int workers) {
+// Chunks of the compact transfer: at most two per worker, at least 16 intervals and ~256 KB of compact values each -- a chunk is
+// a kernel launch (~5 us of latency each, serialised on two streams), so the small problems (config 1: 40 KB, config 2: 0.5 MB
+// in all) go out in one or two.
+static int chunk_count(const qc_handle* h, int n_int, int workers, size_t bytes_per_interval) {
     const int min_chunk = 16;
-    int n_chunks = std::max(1, std::min(2 * workers, (n_int + min_chunk - 1) / min_chunk));
+    const size_t min_bytes = 256 << 10;
+    const size_t by_bytes = std::max<size_t>(1, (size_t)n_int * bytes_per_interval / min_bytes);
+    int n_chunks = std::max(1, std::min<int>(std::min<size_t>(2 * workers, by_bytes), (n_int + min_chunk - 1) / min_chunk));
     if (const char* ev = getenv("QC_HOST_CHUNKS")) n_chunks = std::max(1, std::min(n_int, atoi(ev)));
     (void)h;
     return n_chunks;
@@ -380,7 +385,7 @@ static int run_chunks(qc_handle* h, const CompactPlan& cp, double* F, double* va
     HostPool& pool = host_pool();
     const int workers = pool_workers(shards);
     pool.ensure(workers);
-    int n_chunks = vals ? chunk_count(h, P.n_int, workers) : 1;   // residuals only: ~1 MB, one launch
+    int n_chunks = vals ? chunk_count(h, P.n_int, workers, (size_t)cp.comp_len * sizeof(double)) : 1;   // residuals only: ~1 MB, one launch
     const int per = (P.n_int + n_chunks - 1) / n_chunks;
     n_chunks = (P.n_int + per - 1) / per;
     int rc;
