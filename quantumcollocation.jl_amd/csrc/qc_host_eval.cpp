@@ -411,6 +411,14 @@ static int run_chunks(qc_handle* h, const CompactPlan& cp, double* F, double* va
         static const int max_pieces = getenv("QC_HOST_PIECES") ? std::max(1, atoi(getenv("QC_HOST_PIECES"))) : 4;
         const int pieces = std::max(1, std::min(std::min(workers, max_pieces), (b1 - b0) / 4));
         const int step = (b1 - b0 + pieces - 1) / pieces;
+        // (small outputs -- configs 1 and 2, short trajectories -- are expanded by the calling thread: waking a worker costs
+        //  20 - 40 us, more than copying 100 KB)
+        const size_t out_bytes = (size_t)(b1 - b0) * ((vals ? (size_t)Pp->jac_nnz : 0) + (hF ? (size_t)Pp->F_stride : 0)) * sizeof(double);
+        if (out_bytes <= (128u << 10)) {
+            if (vals) expand_intervals(*Pp, cp, comp, vals, b0, b1);
+            if (hF) memcpy(F + (size_t)b0 * Pp->F_stride, hF + (size_t)b0 * Pp->F_stride, (size_t)(b1 - b0) * Pp->F_stride * sizeof(double));
+            continue;
+        }
         for (int c0 = b0; c0 < b1; c0 += step) {
             const int c1 = std::min(b1, c0 + step);
             pool.push([=] {
