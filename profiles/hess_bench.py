@@ -28,7 +28,9 @@ for spec in cfgs:
     mu = torch.from_numpy(np.random.default_rng(0).standard_normal(int(dims.n_rows))).cuda()
     nb = max(4, int((640 << 20) // (8 * int(dims.jac_nnz))) + 1)
     nb = min(nb, 24)
-    Hs = [torch.empty(int(dims.hess_nnz), dtype=torch.float64, device="cuda") for _ in range(nb)]
+    nh = max(2, int((640 << 20) // (8 * max(1, int(dims.hess_nnz)))) + 1) if int(dims.hess_nnz) else 1   # its own ring: > 2 x the Infinity Cache
+    nh = min(nh, 64)
+    Hs = [torch.empty(int(dims.hess_nnz), dtype=torch.float64, device="cuda") for _ in range(nh)]
     Fs = [torch.empty(int(dims.F_len), dtype=torch.float64, device="cuda") for _ in range(nb)]
     Js = [torch.empty(int(dims.jac_nnz), dtype=torch.float64, device="cuda") for _ in range(nb)]
     st = torch.cuda.current_stream()
@@ -48,7 +50,7 @@ for spec in cfgs:
             best.append(e0.elapsed_time(e1) * 1e3 / steps)
         return min(best), float(np.median(best))
 
-    h = timed(lambda i: dyn.mu_d2F_device(Z, mu, Hs[i % nb], st)) if int(dims.hess_nnz) else (float("nan"), float("nan"))
+    h = timed(lambda i: dyn.mu_d2F_device(Z, mu, Hs[i % nh], st)) if int(dims.hess_nnz) else (float("nan"), float("nan"))
     j = timed(lambda i: dyn.F_dF_device(Z, Fs[i % nb], Js[i % nb], st))
     print(f"variant {os.environ.get('QCOLLOC_HIP_VARIANT', 'product')} config {c} {kw} T={inp.traj.T} kernels {dyn.kernel_names}: "
           f"mu_d2F {h[0]:.2f} us (median of 3: {h[1]:.2f}), F+dF {j[0]:.2f} us (median {j[1]:.2f})", flush=True)
