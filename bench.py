@@ -366,12 +366,15 @@ def main():
                 # trajectory while the other ranks wait at the barrier; N PCIe links work in parallel.
                 barrier()
                 if rank == 0:
-                    devs = list(range(world)) if backend == "nccl" else [r % torch.cuda.device_count() for r in range(world)]
-                    md = qc.QuantumDynamics(inp.integrators, inp.traj, devices=devs, kernel=args.kernel)
-                    host_rec = host_visible_record(qc, inp, md, Zh, None)
-                    host_rec["devices"] = devs
-                    host_rec["evals_per_s_T1000_equivalent"] = host_rec["evals_per_s"] * (T_total - 1) / (T_PER_GPU - 1)
-                    md.close()
+                    try:   # (whatever happens here, rank 0 reaches the barrier the other ranks are waiting at)
+                        devs = list(range(world)) if backend == "nccl" else [r % torch.cuda.device_count() for r in range(world)]
+                        md = qc.QuantumDynamics(inp.integrators, inp.traj, devices=devs, kernel=args.kernel)
+                        host_rec = host_visible_record(qc, inp, md, Zh, None)
+                        host_rec["devices"] = devs
+                        host_rec["evals_per_s_T1000_equivalent"] = host_rec["evals_per_s"] * (T_total - 1) / (T_PER_GPU - 1)
+                        md.close()
+                    except Exception as exc:   # noqa: BLE001
+                        host_rec = {"error": repr(exc)[:300]}
                 barrier()
         except Exception as exc:   # noqa: BLE001  (must not lose the metric line)
             host_rec = {"error": repr(exc)[:300]}
