@@ -14,16 +14,17 @@ out = sys.argv[1]
 res = {}
 for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), recursive=True):
     rows = [r for r in csv.DictReader(open(f)) if r["Kernel_Name"].find("qc_") >= 0]
-    byk = {}
+    byk, first = {}, {}
     for r in rows:
         byk.setdefault(r["Kernel_Name"], []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        first.setdefault(r["Kernel_Name"], r)
     for k, d in byk.items():
         res.setdefault(k, {})["calls"] = len(d)
         res[k]["avg_us"] = sum(d) / len(d) / 1e3
         res[k]["median_us"] = statistics.median(d) / 1e3
         res[k]["min_us"] = min(d) / 1e3
-        res[k]["vgpr"] = rows[0].get("VGPR_Count")
-        res[k]["lds"] = rows[0].get("LDS_Block_Size")
+        res[k]["vgpr"] = first[k].get("VGPR_Count")       # (of this kernel's own first dispatch)
+        res[k]["lds"] = first[k].get("LDS_Block_Size")
 for name in ("fetch", "write"):
     for f in glob.glob(os.path.join(out, name, "**", "*counter_collection.csv"), recursive=True):
         acc = {}
