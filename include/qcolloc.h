@@ -388,7 +388,7 @@ int qc_terms_eval_dev(qc_terms* h, const double* dZ, double* dJ, double* dgrad, 
  * QC_ERR_UNSUPPORTED. */
 int qc_debug_read_stamps(qc_handle* h, uint64_t* out, int64_t count);
 
-/* Library/build identification: "qcolloc-hip 0.1 gfx950 ..." */
+/* Library/build identification: "qcolloc-hip <major>.<minor> (gfx950, ...)" */
 const char* qc_version(void);
 
 #ifdef __cplusplus

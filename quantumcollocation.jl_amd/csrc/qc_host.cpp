@@ -27,7 +27,12 @@ int qc_fail(std::string* err, int code, const std::string& msg) {
 }
 #define fail qc_fail
 
-extern "C" const char* qc_version(void) { return "qcolloc-hip 0.1 (gfx950, fp64; kernels: lds, mfma16, mfma32, mfma64, mfma16-exp, mfma32-exp)"; }
+#define QC_STR2(x) #x
+#define QC_STR(x) QC_STR2(x)
+extern "C" const char* qc_version(void) {
+    return "qcolloc-hip " QC_STR(QC_VERSION_MAJOR) "." QC_STR(QC_VERSION_MINOR)
+           " (gfx950, fp64; kernels: lds, mfma16, mfma32, mfma64, mfma16-exp, mfma32-exp)";
+}
 
 extern "C" const char* qc_last_error(const qc_handle* h) { return h ? h->err.c_str() : g_err.c_str(); }
 
