@@ -245,3 +245,54 @@ def test_evaluator_drives_an_ipopt_ordered_iteration_on_the_library(qc):
     assert np.isfinite(H).all() and np.isfinite(g).all()
     dyn.close()
     obj.close()
+
+
+@pytest.mark.gpu
+def test_evaluator_with_linear_and_free_phase_constraints(qc):
+    """Config 1 with a `TimeStepsAllEqualConstraint` (T - 1 constant rows given by a local structure) behind the dynamics rows and a
+    fidelity row behind those: rows, Jacobian entries and the Lagrangian Hessian land where the structures say."""
+    inp = qc.config_inputs(1, T=6)
+    traj = inp.traj
+    dyn = qc.QuantumDynamics(inp.integrators, traj)
+    obj = qc.UnitaryInfidelityObjective("Ũ⃗", traj, Q=10.0, form="abs2")
+    teq = qc.TimeStepsAllEqualConstraint("Δt", traj)
+    fid = qc.FinalUnitaryFidelityConstraint("Ũ⃗", 0.9, traj, form="abs2")
+    ev = qc.QuantumControlEvaluator(dyn, [obj], [teq, fid])
+    n_dyn = int(dyn.dims.n_rows)
+    assert ev.n_constraints == n_dyn + (traj.T - 1) + 1
+    rng = np.random.default_rng(8)
+    x = traj.datavec + 1e-2 * rng.standard_normal(traj.datavec.size)
+    c = np.empty(ev.n_constraints)
+    ev.eval_constraint(c, x)
+    np.testing.assert_array_equal(c[n_dyn:n_dyn + traj.T - 1], teq.g(x))
+    assert c[-1] == fid.g(x)[0]
+    J = ev.jacobian_matrix(x).toarray()
+    rows, cols = teq.jac_structure
+    Jt = np.zeros((traj.T - 1, x.size))
+    Jt[rows, cols] = teq.dg(x)
+    np.testing.assert_array_equal(J[n_dyn:n_dyn + traj.T - 1], Jt)
+    np.testing.assert_array_equal(J[-1, fid.state_indices], fid.dg(x))
+    assert not np.delete(J[-1], fid.state_indices).any()
+    # central differences of every constraint row against the assembled Jacobian, a few random directions
+    eps = 1e-6
+    for _ in range(4):
+        v = rng.standard_normal(x.size)
+        cp, cm = np.empty_like(c), np.empty_like(c)
+        ev.eval_constraint(cp, x + eps * v)
+        ev.eval_constraint(cm, x - eps * v)
+        np.testing.assert_allclose(J @ v, (cp - cm) / (2 * eps), rtol=1e-6, atol=1e-7)
+    mu = rng.standard_normal(ev.n_constraints)
+    H = ev.hessian_lagrangian_matrix(x, 0.5, mu)
+    lag_grad = lambda z: 0.5 * _grad(ev, z) + ev.jacobian_matrix(z).T @ mu     # noqa: E731
+    for _ in range(4):
+        v = rng.standard_normal(x.size)
+        fd = (lag_grad(x + eps * v) - lag_grad(x - eps * v)) / (2 * eps)
+        np.testing.assert_allclose(H @ v, fd, rtol=2e-6, atol=2e-6 * max(1.0, np.abs(fd).max()))
+    for o in (dyn, obj, fid):
+        o.close()
+
+
+def _grad(ev, z):
+    g = np.empty(ev.n_variables)
+    ev.eval_objective_gradient(g, z)
+    return g
