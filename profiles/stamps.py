@@ -49,3 +49,14 @@ ok = (dt_real > 0) & (dt_cyc > 0)
 if ok.any():
     print(f"shader clock over the compute waves: median {np.median(dt_cyc[ok] / dt_real[ok]) / 1e9:.3f} GHz "
           f"(min {np.min(dt_cyc[ok] / dt_real[ok]) / 1e9:.3f}, max {np.max(dt_cyc[ok] / dt_real[ok]) / 1e9:.3f})")
+
+# drain time of the copy waves by XCD (workgroup vb -> XCD vb % 8; interval = qc_xcd_remap(vb): invert it)
+q8, r8 = divmod(n, 8)
+def xcd_of_interval(b):
+    for x in range(8):
+        lo = x * (q8 + 1) if x < r8 else r8 * (q8 + 1) + (x - r8) * q8
+        if lo <= b < lo + (q8 + 1 if x < r8 else q8):
+            return x
+    return -1
+xcd = np.array([xcd_of_interval(b) for b in range(n)])
+print("copy waves drained, by XCD (median / max us):", "  ".join(f"{x}: {np.median(rel[xcd == x, 3]):.2f}/{rel[xcd == x, 3].max():.2f}" for x in range(8)))

@@ -42,3 +42,18 @@ for wi, wn in enumerate(["compute wave 0", "compute wave 1", "copy wave 0", "cop
         col = rel[:, wi, k][st[:, wi, k] > 0]
         if col.size:
             print(f"  {wn:15s} {nm:26s} min {col.min():6.2f}  median {np.median(col):6.2f}  max {col.max():6.2f} us")
+
+# finish time of the copy waves by XCD (workgroup vb runs on XCD vb % 8; interval pair 2 * remap(vb) -> invert the remap)
+n_wg = (n + 1) // 2
+q, r = divmod(n_wg, 8)
+def xcd_of_pair(p):          # inverse of qc_xcd_remap: pair index -> blockIdx % 8
+    for x in range(8):
+        lo = x * (q + 1) if x < r else r * (q + 1) + (x - r) * q
+        hi = lo + (q + 1 if x < r else q)
+        if lo <= p < hi:
+            return x
+    return -1
+fin = np.maximum(rel[:, 2, 3], rel[:, 3, 3])
+xcd = np.array([xcd_of_pair(b // 2) for b in range(n)])
+print("copy waves' last acknowledged store by XCD (median / max us):",
+      "  ".join(f"{x}: {np.median(fin[xcd == x]):.1f}/{fin[xcd == x].max():.1f}" for x in range(8)))
