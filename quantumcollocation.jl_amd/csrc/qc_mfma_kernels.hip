@@ -240,6 +240,7 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
             const v4d (&gk)[kMU] = gk_img;
             // (Dropping these twenty loads altogether -- wrong results, timing only -- gains 0.23 us: the vector-memory pipeline of
             // the CU is not what the first store waits for; it waits for the round trip of the amplitudes and the images.)
+            // (The compute wave fetching the state tiles itself, so that the hand-off need not wait for them: 9.78 vs 9.17 us.)
             const v4d u0 = load_state_tile<KET>(z0 + P.off_U, jc, nr, g);
             const v4d u1 = load_state_tile<KET>(z1 + P.off_U, jc, nr, g);
             double dxv[kDF], dfv[kDF];       // derivative integrators, register fast path (<= kDF of <= 64 rows)
@@ -272,6 +273,22 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
                 Fm[r] = -(ev + hc1 * Ga[r]);       // -F^T
                 Bm[r] = ev - hc1 * Ga[r];          //  B^T
             }
+            // The first kEarly copies of -F^T / B^T leave BEFORE the hand-off: the hand-off waits for the state tiles (the last loads of
+            // the batch) and for the barrier, and nothing reaches HBM before this wave's first store.  Measured, copies stored
+            // first -> step: 0 -> 9.42-9.66 us, 1 -> 9.36, 3 -> 9.18-9.34, 4 -> 8.95-9.37, 5 -> 9.57-9.69, 6 -> 10.0, 8 -> 10.6
+            // (beyond half of them the compute wave starts too late).
+            constexpr int kEarly = (!KET && ONCE) ? 4 : 0;
+            if constexpr (kEarly > 0) {
+                if (!skip) {
+#pragma unroll
+                    for (int q = 0; q < kEarly; ++q) {
+                        if (q < P.copies) {
+                            store_tile_T<MODE>(Jb + P.jo_F + q * 256, Fm, g, j);
+                            store_tile_T<MODE>(Jb + P.jo_B + q * 256, Bm, g, j);
+                        }
+                    }
+                }
+            }
             // hand-off to the compute wave
             lds_put(sm + kLdsGa, lane, Ga);
             lds_put(sm + kLdsU0, lane, u0);
@@ -286,7 +303,7 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
                 // 8 bytes per lane, 512 contiguous bytes per instruction.  (Pairing lanes for 16-byte stores measured 8 % slower.)
                 // P.copies = N copies of each block (I_N (x) B); 1 when the host path asks for the compact form
                 const int ncop = P.copies;
-                for (int q = 0; q < ncop; ++q) {
+                for (int q = kEarly; q < ncop; ++q) {
                     if constexpr (!KET) {
                         store_tile_T<MODE>(pF + q * 256, Fm, g, j);
                         store_tile_T<MODE>(pB + q * 256, Bm, g, j);
