@@ -277,7 +277,9 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
             // the batch) and for the barrier, and nothing reaches HBM before this wave's first store.  Measured, copies stored
             // first -> step: 0 -> 9.42-9.66 us, 1 -> 9.36, 3 -> 9.18-9.34, 4 -> 8.95-9.37, 5 -> 9.57-9.69, 6 -> 10.0, 8 -> 10.6
             // (beyond half of them the compute wave starts too late).  Only in the loop-free unitary instantiation: in the persistent
-            // and the masked ones it measured slower (T = 2000: 17.7 vs 17.15 us, config 2: 5.8 vs 5.2-5.5 us).
+            // and the masked ones it measured slower (T = 2000: 17.7 vs 17.15 us, config 2: 5.8 vs 5.2-5.5 us).  With the early copies
+            // this wave drains a microsecond before the compute wave; giving it the residual / d/dh block (12 MFMAs) in return made
+            // the launch slower (9.45 vs 9.05 us): its MFMAs share a SIMD with another workgroup's compute wave.
             constexpr int kEarly = (!KET && ONCE) ? 4 : 0;
             if constexpr (kEarly > 0) {
                 if (!skip) {
