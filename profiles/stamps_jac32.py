@@ -38,7 +38,10 @@ t0 = st[st > 0].min()
 rel = (st - t0) * 10.0 / 1e3
 print(f"T={T}: {n} intervals; kernels {dyn.kernel_names}; span = {rel.max():.2f} us")
 for wi, wn in enumerate(["compute wave 0", "compute wave 1", "copy wave 0", "copy wave 1"]):
-    for k, nm in enumerate(["loads requested", "G assembled (barrier 2)", "every store issued", "every store acknowledged"]):
+    labels = ["loads landed (barrier 1)", "G assembled (barrier 2)", "every store issued", "every store acknowledged"]
+    if wi == 1:      # this wave records the prologue instead (first pass of a persistent workgroup: kernel entry)
+        labels = ["kernel entry", "arguments read, addresses known", "loads landed (barrier 1)", "every store acknowledged"]
+    for k, nm in enumerate(labels):
         col = rel[:, wi, k][st[:, wi, k] > 0]
         if col.size:
             print(f"  {wn:15s} {nm:26s} min {col.min():6.2f}  median {np.median(col):6.2f}  max {col.max():6.2f} us")

@@ -7,10 +7,11 @@
 // hosts exactly one MFMA-heavy wave and one store-heavy wave (two 4-wave workgroups per CU put two compute
 // waves on one SIMD about half the time: their MFMA chains then ran 1.7x longer and became the tail).
 //   phase 1     the 8 waves share the (m+1) x 4 tiles of the generator images (72 KB for m = 8): each tile is
-//               requested ONCE per workgroup and parked in LDS; the compute waves also request their knot data,
-//               wave 4 / 6 the derivative-integrator data of their interval.  Barrier.
+//               requested ONCE per workgroup and parked in LDS; timestep and amplitudes by scalar loads.  Barrier.
+//               NOTHING else is requested here: the images alone keep the CU's vector-memory pipeline busy for ~1.2 us.
 //   phase 2     wave w assembles tile w&3 of G = G_0 + sum_k a_k G_k for interval w>>2 from the LDS images.  Barrier.
-//               After it no wave issues a global load (a load issued during the store burst waits microseconds).
+//               The copy waves issue no global load at all; the compute waves request their knot data (and waves 1 / 3
+//               the derivative-integrator data) behind barrier 2 -- they have the slack (done at half the launch time).
 //   waves 4-7   "copy waves": wave 4 + 2 s + I owns block row I of B^T and F^T of interval s (two tiles):
 //               G_B tiles by identity products, (G^2)^T[I][J] = sum_K G_B[K][I] * G_A[J][K]  (24 MFMAs),
 //               then the 2N = 32 tile stores x 2 tiles x 2 matrices of the I_N (x) B / -I_N (x) F copies.
@@ -115,6 +116,8 @@ __device__ inline void store_T32_masked(double* __restrict__ p, const v4d& x, in
 template <bool JAC, bool DIAG, bool KET, bool SINGLE = false>
 __global__ __launch_bounds__(kThreads32, 2) void qc_mfma32_pade4_kernel(const QcParams P, const double* __restrict__ Z,
                                                                        double* __restrict__ F, double* __restrict__ J) {
+    unsigned long long t_entry = 0;
+    if constexpr (DIAG) t_entry = __builtin_amdgcn_s_memrealtime();
     qc_kernarg_touch<sizeof(QcParams) + 64>();   // one batch of scalar-cache misses instead of one per use (qc_internal.h)
     __shared__ __attribute__((aligned(16))) double GaL[2 * 4 * 256];                    // G tiles of the two intervals
     __shared__ __attribute__((aligned(16))) double ImgL[(kMU32 + 1) * 4 * 256];        // image tile t of matrix k at (k * 4 + t) * 256
@@ -152,61 +155,43 @@ __global__ __launch_bounds__(kThreads32, 2) void qc_mfma32_pade4_kernel(const Qc
         const double* __restrict__ z1 = z0 + P.zdim;
         double* __restrict__ Jb = JAC ? J + (size_t)b * P.J_stride + P.J_off : nullptr;
         double* __restrict__ Fb = F ? F + (size_t)b * P.F_stride + P.F_off : nullptr;
-        const double h = ft ? z0[P.off_dt] : opaque_scalar(P.dt_fixed);   // requested with the other loads; first used behind the barriers
         QC_STAMP_DECL;
         QC_STAMP(P, b, lane, 0);
 
-        // ---- phase 1: every global load of the pair of intervals -------------------------------------------------
-        {   // image tiles: matrix parity by wave half, tile by w & 3  ->  each of the (mL+1) x 4 tiles exactly once
-            constexpr int kPer = (kMU32 + 2) / 2;             // matrices per wave (5 for kMU32 = 8)
-            v4d img[kPer];
+        // ---- phase 1: the generator images, the timestep and the amplitudes ----------------------------------------------
+        constexpr int kPer = (kMU32 + 2) / 2;             // image tiles: matrix parity by wave half, tile by w & 3 -> each of
+        v4d img[kPer];                                    // the (mL+1) x 4 tiles exactly once; 5 matrices per wave for kMU32 = 8
 #pragma unroll
-            for (int u = 0; u < kPer; ++u) {
-                const int mat = 2 * u + (w >> 2);
-                img[u] = load_GA32(Gx, mat <= mL ? mat : mL, w & 3, lane);
-            }
-#pragma unroll
-            for (int u = 0; u < kPer; ++u) {
-                const int mat = 2 * u + (w >> 2);
-                if (mat <= mL) lds_put_tile(ImgL, mat * 4 + (w & 3), lane, img[u]);
-            }
+        for (int u = 0; u < kPer; ++u) {
+            const int mat = 2 * u + (w >> 2);
+            img[u] = load_GA32(Gx, mat <= mL ? mat : mL, w & 3, lane);
         }
-        v4d S[2], D[2];
-        if (!copy_role) {
-#pragma unroll
-            for (int I = 0; I < 2; ++I) {
-                v4d u0, u1;
-                if constexpr (!KET) {
-                    const double* u0p = z0 + P.off_U + jc * 32 + 16 * I + g;
-                    const double* u1p = z1 + P.off_U + jc * 32 + 16 * I + g;
-                    u0 = v4d{u0p[0], u0p[4], u0p[8], u0p[12]};
-                    u1 = v4d{u1p[0], u1p[4], u1p[8], u1p[12]};
-                } else {   // columns >= nc re-read column 0 (never stored); rows >= nr are the zero padding
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = 16 * I + 4 * r + g;
-                        u0[r] = row < nr ? z0[P.off_U + jc * nr + row] : 0.0;
-                        u1[r] = row < nr ? z1[P.off_U + jc * nr + row] : 0.0;
-                    }
-                }
-                S[I] = u1 + u0;
-                D[I] = u1 - u0;
-            }
-        }
-        const bool dfast = P.n_deriv <= kDF32;
-        const bool deriv_wave = copy_role && sub == 0 && (!SINGLE || slot == 0);   // waves 4 and 6 (SINGLE: wave 4)
-        double* __restrict__ derl = DerL + slot * (2 * kDF32 * 64);
-        if (deriv_wave) {   // requested now (before any store of the workgroup), parked in LDS, used after the copies
-#pragma unroll
-            for (int d = 0; d < kDF32; ++d) {   // unused slots have zero offsets/dims: the loads stay in bounds
-                const int i = lane < P.ddim_i[d] ? lane : 0;
-                derl[(2 * d) * 64 + lane] = z0[P.dx_off[d] + i];
-                derl[(2 * d + 1) * 64 + lane] = z1[P.x_off[d] + i] - z0[P.x_off[d] + i];
-            }
-        }
-        double ak[kMU32];                                     // amplitudes of this wave's interval (scalar loads)
+        // The timestep and the amplitudes are SCALAR loads from the trajectory (one address per wave): whatever scalar wait
+        // follows one of them -- a kernel argument read a little later, say -- waits for its round trip through L2 as well (the
+        // counter is shared and scalar loads return out of order), and a chain of such waits stood between "addresses known" and
+        // the last vector load request: 1.0 us on the compute waves, 2.0 - 2.4 us on the copy waves (profiles/stamps_jac32_prologue.py).
+        // They are requested LAST, behind every vector load; the first scalar wait after them is the barrier's.
+        asm volatile("" ::: "memory");
+        const double h = ft ? z0[P.off_dt] : opaque_scalar(P.dt_fixed);   // first used behind the barriers
+        double ak[kMU32];                                     // amplitudes of this wave's interval
 #pragma unroll
         for (int u = 0; u < kMU32; ++u) ak[u] = (u < m) ? z0[P.off_a + (u < m ? u : 0)] : 0.0;
+        asm volatile("" ::: "memory");   // no load sinks below this line, no LDS store rises above it
+#ifdef QC_STAMP_PROLOGUE
+        QC_STAMP(P, b, lane, 5);         // every load requested
+#if QC_STAMP_PROLOGUE != 2
+        if constexpr (DIAG) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+        QC_STAMP(P, b, lane, 6);         // this wave's loads are back
+#endif
+#pragma unroll
+        for (int u = 0; u < kPer; ++u) {
+            const int mat = 2 * u + (w >> 2);
+            if (mat <= mL) lds_put_tile(ImgL, mat * 4 + (w & 3), lane, img[u]);
+        }
+#ifdef QC_STAMP_PROLOGUE
+        QC_STAMP(P, b, lane, 7);         // LDS written, at the barrier
+#endif
         __syncthreads();
         QC_STAMP(P, b, lane, 1);
 
@@ -225,6 +210,12 @@ __global__ __launch_bounds__(kThreads32, 2) void qc_mfma32_pade4_kernel(const Qc
             for (int k = kMU32; k < m; ++k) Gt += z0[P.off_a + k] * load_GA32(Gx, k + 1, tile, lane);
             lds_put_tile(GaL + slot * 1024, tile, lane, Gt);
         }
+#ifdef QC_STAMP_PROLOGUE
+        QC_STAMP(P, b, lane, 8);
+#endif
+#ifdef QC_STAMP_PROLOGUE
+        QC_STAMP(P, b, lane, 9);
+#endif
         __syncthreads();
         QC_STAMP(P, b, lane, 2);
         const double hc1 = h * c1, hc2 = h * h * c2;
@@ -272,41 +263,60 @@ __global__ __launch_bounds__(kThreads32, 2) void qc_mfma32_pade4_kernel(const Qc
                     store_T32_columns(pF + q * 1024, Fc, 16 * I, g, j);
                     store_T32_columns(pB + q * 1024, Bc, 16 * I, g, j);
                 }
-                if (deriv_wave) {   // derivative integrator rows
-                    int jo = P.jo_d;
-                    bool all_fast = dfast;
-#pragma unroll
-                    for (int d = 0; d < kDF32; ++d) {
-                        if (d < P.n_deriv) {
-                            const int dim = P.ddim_i[d], r0 = P.drow[d];
-                            if (dfast && dim <= 64) {
-                                if (lane < dim) {
-                                    const double dx = derl[(2 * d) * 64 + lane], df = derl[(2 * d + 1) * 64 + lane];
-                                    if (Fb) Fb[r0 + lane] = df - h * dx;
-                                    Jb[jo + lane] = -1.0;
-                                    Jb[jo + dim + lane] = 1.0;
-                                    Jb[jo + 2 * dim + lane] = -h;
-                                    if (ft) Jb[jo + 3 * dim + lane] = -dx;
-                                }
-                            } else {
-                                all_fast = false;
-                            }
-                            jo += (ft ? 4 : 3) * dim;
-                        }
-                    }
-                    if (!all_fast) deriv_rows_generic(P, z0, z1, h, Fb, Jb, lane, dfast);
-                }
             }
         } else if (active) {
             // ===================== compute waves ===========================================================
+            // The knots' state tiles and the derivative-integrator data are requested HERE, behind barrier 2, by the waves that
+            // use them.  Requested with the images they delayed barrier 1 by 2 us (the CU's vector-memory pipeline needs ~1.2 us
+            // for the 80 requests of 1 KB that bring the 72 KB of images; a strided state request costs it ~200 cycles, sixteen of
+            // them per wave 1.6 us), requested between the barriers they delayed barrier 2 by as much -- and either way the copy
+            // waves' first store, which is what the launch time follows.  The compute waves have the slack: they are done after
+            // 15 us of the launch's 36 (profiles/stamps_jac32.py, stamps_jac32_prologue.py).
+            const int csub = SINGLE ? (w & 3) : sub;           // this wave's first drive;  SINGLE: four compute waves per interval
+            constexpr int cstep = SINGLE ? 4 : 2;
+            v4d U0[2], U1[2];
+#pragma unroll
+            for (int I = 0; I < 2; ++I) {
+                if constexpr (!KET) {
+                    const double* u0p = z0 + P.off_U + jc * 32 + 16 * I + g;
+                    const double* u1p = z1 + P.off_U + jc * 32 + 16 * I + g;
+                    U0[I] = v4d{u0p[0], u0p[4], u0p[8], u0p[12]};
+                    U1[I] = v4d{u1p[0], u1p[4], u1p[8], u1p[12]};
+                } else {   // columns >= nc re-read column 0 (never stored); rows >= nr are the zero padding
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 16 * I + 4 * r + g;
+                        U0[I][r] = row < nr ? z0[P.off_U + jc * nr + row] : 0.0;
+                        U1[I][r] = row < nr ? z1[P.off_U + jc * nr + row] : 0.0;
+                    }
+                }
+            }
+            const bool dfast = P.n_deriv <= kDF32;
+            const bool deriv_wave = JAC && csub == 1;          // waves 1 and 3 (SINGLE: wave 1) also write the derivative rows
+            double* __restrict__ derl = DerL + slot * (2 * kDF32 * 64);
+            if (deriv_wave) {   // requested before this wave's first store, parked in LDS, used after the drives
+                double dvx[kDF32], dva[kDF32], dvb[kDF32];
+#pragma unroll
+                for (int d = 0; d < kDF32; ++d) {   // unused slots have zero offsets/dims: the loads stay in bounds
+                    const int i = lane < P.ddim_i[d] ? lane : 0;
+                    dvx[d] = z0[P.dx_off[d] + i];
+                    dva[d] = z0[P.x_off[d] + i];
+                    dvb[d] = z1[P.x_off[d] + i];
+                }
+#pragma unroll
+                for (int d = 0; d < kDF32; ++d) {
+                    derl[(2 * d) * 64 + lane] = dvx[d];
+                    derl[(2 * d + 1) * 64 + lane] = dvb[d] - dva[d];
+                }
+            }
             v4d Ga[4];
 #pragma unroll
             for (int tI = 0; tI < 4; ++tI) Ga[tI] = lds_tile(GaS, tI, lane);
+            const v4d S[2] = {U1[0] + U0[0], U1[1] + U0[1]};
+            const v4d D[2] = {U1[0] - U0[0], U1[1] - U0[1]};
             v4d GD[2];
 #pragma unroll
             for (int I = 0; I < 2; ++I) GD[I] = mm16x2(Ga[2 * I], D[0], Ga[2 * I + 1], D[1]);
-            const int csub = SINGLE ? (w & 3) : sub;           // this wave's first drive;  SINGLE: four compute waves per interval
-            constexpr int cstep = SINGLE ? 4 : 2;
             if (csub == 0) {
                 v4d GS[2], G2D[2];
 #pragma unroll
@@ -351,6 +361,30 @@ __global__ __launch_bounds__(kThreads32, 2) void qc_mfma32_pade4_kernel(const Qc
                     if constexpr (!KET) store_T32_columns(pa, merge_rows32(YT[0], YT[1]), 0, g, j);
                 }
             }
+            if (deriv_wave) {   // derivative integrator rows
+                int jo = P.jo_d;
+                bool all_fast = dfast;
+#pragma unroll
+                for (int d = 0; d < kDF32; ++d) {
+                    if (d < P.n_deriv) {
+                        const int dim = P.ddim_i[d], r0 = P.drow[d];
+                        if (dfast && dim <= 64) {
+                            if (lane < dim) {
+                                const double dx = derl[(2 * d) * 64 + lane], df = derl[(2 * d + 1) * 64 + lane];
+                                if (Fb) Fb[r0 + lane] = df - h * dx;
+                                Jb[jo + lane] = -1.0;
+                                Jb[jo + dim + lane] = 1.0;
+                                Jb[jo + 2 * dim + lane] = -h;
+                                if (ft) Jb[jo + 3 * dim + lane] = -dx;
+                            }
+                        } else {
+                            all_fast = false;
+                        }
+                        jo += (ft ? 4 : 3) * dim;
+                    }
+                }
+                if (!all_fast) deriv_rows_generic(P, z0, z1, h, Fb, Jb, lane, dfast);
+            }
         }
         if constexpr (DIAG) {
             QC_STAMP(P, b, lane, 3);                       // everything issued
@@ -360,6 +394,26 @@ __global__ __launch_bounds__(kThreads32, 2) void qc_mfma32_pade4_kernel(const Qc
                 const int wi = (copy_role ? 2 : 0) + sub;
 #pragma unroll
                 for (int k_ = 0; k_ < 4; ++k_) P.stamps[(size_t)b * 16 + wi * 4 + k_] = qc_ts_[k_ == 3 ? 4 : (k_ == 0 ? 1 : k_ + 1)];
+#ifdef QC_STAMP_PROLOGUE
+#if QC_STAMP_PROLOGUE == 2
+                P.stamps[(size_t)b * 16 + wi * 4 + 0] = qc_ts_[1];     // behind barrier 1
+                P.stamps[(size_t)b * 16 + wi * 4 + 1] = qc_ts_[8];     // G tile assembled and written
+                P.stamps[(size_t)b * 16 + wi * 4 + 2] = qc_ts_[9];     // knot loads requested, at barrier 2
+                P.stamps[(size_t)b * 16 + wi * 4 + 3] = qc_ts_[2];     // behind barrier 2
+#else
+                P.stamps[(size_t)b * 16 + wi * 4 + 0] = qc_ts_[0];
+                P.stamps[(size_t)b * 16 + wi * 4 + 1] = qc_ts_[5];
+                P.stamps[(size_t)b * 16 + wi * 4 + 2] = qc_ts_[6];
+                P.stamps[(size_t)b * 16 + wi * 4 + 3] = qc_ts_[7];
+                if (wi == 1) P.stamps[(size_t)b * 16 + wi * 4 + 0] = qc_ts_[1];
+#endif
+                if (false)
+#endif
+                if (wi == 1) {   // compute wave 1 records the prologue instead: kernel entry, addresses known (arguments read), loads landed
+                    P.stamps[(size_t)b * 16 + 4] = t_entry;
+                    P.stamps[(size_t)b * 16 + 5] = qc_ts_[0];
+                    P.stamps[(size_t)b * 16 + 6] = qc_ts_[1];
+                }
             }
         }
         __syncthreads();   // the LDS blocks are rewritten by the next pair of a persistent grid
