@@ -48,6 +48,11 @@ __device__ inline void lds_put_tile(double* __restrict__ base, int tile, int lan
     p[64] = v2d{x[2], x[3]};
 }
 
+// the value lane `src` holds, as a wave-uniform scalar
+__device__ inline double lane_value(double v, int src) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
+}
+
 // A0*B0 + A1*B1 (two 16x16x16 products summed): two accumulator chains of four MFMAs
 __device__ inline v4d mm16x2(const v4d& a0, const v4d& b0, const v4d& a1, const v4d& b1) {
     const v4d z = {0.0, 0.0, 0.0, 0.0};
@@ -113,7 +118,9 @@ __device__ inline void store_T32_masked(double* __restrict__ p, const v4d& x, in
 // KET: K < 16 ket states (column-masked loads and stores); false = unitary, every mask folds away at compile time
 // SINGLE: one interval per workgroup (fewer intervals than CUs: T <~ 256) -- the four compute waves share the interval's drives
 // (k = w, w + 4, ...), the four copy waves its block rows and copies (halves), so a workgroup is done in about half the time
-template <bool JAC, bool DIAG, bool KET, bool SINGLE = false>
+// ONCE: the grid covers every pair (always, below 2 x kMaxGrid32 intervals): no persistent loop, so nothing is hoisted in front
+// of the first load request (with the loop: ~280 scalar instructions and six dependent batches of argument reads, 1.45 us).
+template <bool JAC, bool DIAG, bool KET, bool SINGLE = false, bool ONCE = false>
 __global__ __launch_bounds__(kThreads32, 2) void qc_mfma32_pade4_kernel(const QcParams P, const double* __restrict__ Z,
                                                                        double* __restrict__ F, double* __restrict__ J) {
     unsigned long long t_entry = 0;
@@ -166,16 +173,12 @@ __global__ __launch_bounds__(kThreads32, 2) void qc_mfma32_pade4_kernel(const Qc
             const int mat = 2 * u + (w >> 2);
             img[u] = load_GA32(Gx, mat <= mL ? mat : mL, w & 3, lane);
         }
-        // The timestep and the amplitudes are SCALAR loads from the trajectory (one address per wave): whatever scalar wait
-        // follows one of them -- a kernel argument read a little later, say -- waits for its round trip through L2 as well (the
-        // counter is shared and scalar loads return out of order), and a chain of such waits stood between "addresses known" and
-        // the last vector load request: 1.0 us on the compute waves, 2.0 - 2.4 us on the copy waves (profiles/stamps_jac32_prologue.py).
-        // They are requested LAST, behind every vector load; the first scalar wait after them is the barrier's.
-        asm volatile("" ::: "memory");
-        const double h = ft ? z0[P.off_dt] : opaque_scalar(P.dt_fixed);   // first used behind the barriers
-        double ak[kMU32];                                     // amplitudes of this wave's interval
-#pragma unroll
-        for (int u = 0; u < kMU32; ++u) ak[u] = (u < m) ? z0[P.off_a + (u < m ? u : 0)] : 0.0;
+        // The timestep and the first kMU32 amplitudes: ONE vector load (lane u < m: a_u, the other lanes: the timestep), read
+        // out lane by lane behind barrier 1.  As scalar loads they were a trap twice over: every scalar wait that follows one
+        // -- a kernel argument read a little later -- waits for its round trip through L2 as well (shared counter, out-of-order
+        // return), and without the persistent loop the compiler put a wait behind EACH of the nine.
+        const int ia = lane < mL ? P.off_a + lane : (ft ? P.off_dt : P.off_a);
+        const double av = z0[ia];
         asm volatile("" ::: "memory");   // no load sinks below this line, no LDS store rises above it
 #ifdef QC_STAMP_PROLOGUE
         QC_STAMP(P, b, lane, 5);         // every load requested
@@ -194,6 +197,7 @@ __global__ __launch_bounds__(kThreads32, 2) void qc_mfma32_pade4_kernel(const Qc
 #endif
         __syncthreads();
         QC_STAMP(P, b, lane, 1);
+        const double h = ft ? lane_value(av, 63) : opaque_scalar(P.dt_fixed);
 
         // ---- phase 2: tile w & 3 of G for interval (w >> 2) ... the copy half assembles for slot of (w-4)>>1 --------
         {
@@ -204,7 +208,7 @@ __global__ __launch_bounds__(kThreads32, 2) void qc_mfma32_pade4_kernel(const Qc
             v4d Gt = lds_tile(ImgL, tile, lane);
 #pragma unroll
             for (int u = 0; u < kMU32; ++u) {
-                if (u < m) Gt += ak[u] * lds_tile(ImgL, (u + 1) * 4 + tile, lane);
+                if (u < m) Gt += lane_value(av, u) * lds_tile(ImgL, (u + 1) * 4 + tile, lane);
                 if ((u & 1) == 1) __builtin_amdgcn_sched_barrier(0);   // two tiles in flight, not all eight (register pressure)
             }
             for (int k = kMU32; k < m; ++k) Gt += z0[P.off_a + k] * load_GA32(Gx, k + 1, tile, lane);
@@ -416,6 +420,7 @@ __global__ __launch_bounds__(kThreads32, 2) void qc_mfma32_pade4_kernel(const Qc
                 }
             }
         }
+        if constexpr (ONCE) break;
         __syncthreads();   // the LDS blocks are rewritten by the next pair of a persistent grid
     }
 }
@@ -461,19 +466,29 @@ void qc_mfma32_pack_G(const QcParams& P, const double* G, double* Gx) {
 hipError_t qc_launch_mfma32_F_jac(const QcParams& P, const double* dZ, double* dF, double* dJ, hipStream_t st) {
     const int n_wg = (P.n_int + 1) / 2;
     const int grid = n_wg < kMaxGrid32 ? n_wg : kMaxGrid32;
+    const bool once = n_wg <= kMaxGrid32;
     const bool diag = P.stamps != nullptr || P.dbg_skip != 0;
+    const bool ket = P.nc != 16 || P.n != 32;
+#define QC_LAUNCH32(JAC_, DIAG_, KET_, SINGLE_, ONCE_, GRID_) \
+    hipLaunchKernelGGL((qc_mfma32_pade4_kernel<JAC_, DIAG_, KET_, SINGLE_, ONCE_>), dim3(GRID_), dim3(kThreads32), 0, st, P, dZ, dF, dJ)
     if (dJ && !diag && P.n_int <= 256) {   // fewer intervals than CUs: one interval per workgroup, all eight waves on it
-        if (P.nc != 16 || P.n != 32) hipLaunchKernelGGL((qc_mfma32_pade4_kernel<true, false, true, true>), dim3(P.n_int), dim3(kThreads32), 0, st, P, dZ, dF, dJ);
-        else hipLaunchKernelGGL((qc_mfma32_pade4_kernel<true, false, false, true>), dim3(P.n_int), dim3(kThreads32), 0, st, P, dZ, dF, dJ);
+        if (ket) QC_LAUNCH32(true, false, true, true, true, P.n_int);
+        else QC_LAUNCH32(true, false, false, true, true, P.n_int);
         return hipGetLastError();
     }
-    if (P.nc != 16 || P.n != 32) {
-        if (dJ) hipLaunchKernelGGL((qc_mfma32_pade4_kernel<true, false, true>), dim3(grid), dim3(kThreads32), 0, st, P, dZ, dF, dJ);
-        else hipLaunchKernelGGL((qc_mfma32_pade4_kernel<false, false, true>), dim3(grid), dim3(kThreads32), 0, st, P, dZ, dF, dJ);
+    if (ket) {
+        if (dJ && once) QC_LAUNCH32(true, false, true, false, true, grid);
+        else if (dJ) QC_LAUNCH32(true, false, true, false, false, grid);
+        else if (once) QC_LAUNCH32(false, false, true, false, true, grid);
+        else QC_LAUNCH32(false, false, true, false, false, grid);
         return hipGetLastError();
     }
-    if (dJ && diag) hipLaunchKernelGGL((qc_mfma32_pade4_kernel<true, true, false>), dim3(grid), dim3(kThreads32), 0, st, P, dZ, dF, dJ);
-    else if (dJ) hipLaunchKernelGGL((qc_mfma32_pade4_kernel<true, false, false>), dim3(grid), dim3(kThreads32), 0, st, P, dZ, dF, dJ);
-    else hipLaunchKernelGGL((qc_mfma32_pade4_kernel<false, false, false>), dim3(grid), dim3(kThreads32), 0, st, P, dZ, dF, dJ);
+    if (dJ && diag && once) QC_LAUNCH32(true, true, false, false, true, grid);
+    else if (dJ && diag) QC_LAUNCH32(true, true, false, false, false, grid);
+    else if (dJ && once) QC_LAUNCH32(true, false, false, false, true, grid);
+    else if (dJ) QC_LAUNCH32(true, false, false, false, false, grid);
+    else if (once) QC_LAUNCH32(false, false, false, false, true, grid);
+    else QC_LAUNCH32(false, false, false, false, false, grid);
+#undef QC_LAUNCH32
     return hipGetLastError();
 }
