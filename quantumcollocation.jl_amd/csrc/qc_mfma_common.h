@@ -92,6 +92,36 @@ __device__ inline double load_amp_lanes(const double* __restrict__ z0, int off_a
 __device__ inline double bcast_lane(double v, int src_lane) {   // src_lane wave-uniform
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src_lane), __builtin_amdgcn_readlane(__double2loint(v), src_lane));
 }
+// A 16-row column piece in the B-operand / C-D lane map -- lane (g, j) reg r = col[4 r + g], `col` the lane's column -- fetched as
+// 32 CONTIGUOUS bytes per lane (rows 4g .. 4g+3: two 16-byte requests) instead of four 8-byte requests of stride 4, then
+// transposed between the lane groups g and the registers r: v_permlane32_swap exchanges (g bit 1, r bit 1),
+// v_permlane16_swap (g bit 0, r bit 0) (gfx950).  The compute unit has ONE vector-memory pipeline; with four waves per CU each
+// requesting images and state tiles at kernel start, the load phase is bound by the number of requests, not by latency.
+__device__ inline void swap32_f64(double& a, double& b) {   // a: [a.0 a.1 b.0 b.1], b: [a.2 a.3 b.2 b.3]  (16-lane rows)
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    a = __hiloint2double((int)hi[0], (int)lo[0]);
+    b = __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ inline void swap16_rows_f64(double& a, double& b) {   // a: [a.0 b.0 a.2 b.2], b: [a.1 b.1 a.3 b.3]
+    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    a = __hiloint2double((int)hi[0], (int)lo[0]);
+    b = __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ inline v4d load_col16_T(const double* __restrict__ col, int g) {
+    typedef double v2d_ __attribute__((ext_vector_type(2)));
+    typedef v2d_ __attribute__((aligned(8))) v2d_u;                      // the trajectory vector is 8-byte aligned only
+    const v2d_u* q = reinterpret_cast<const v2d_u*>(col + 4 * g);
+    const v2d_ q0 = q[0], q1 = q[1];
+    double x0 = q0[0], x1 = q0[1], x2 = q1[0], x3 = q1[1];                // x_r' = col[4 g + r']
+    swap32_f64(x0, x2);
+    swap32_f64(x1, x3);
+    swap16_rows_f64(x0, x1);
+    swap16_rows_f64(x2, x3);
+    return v4d{x0, x1, x2, x3};                                           // x_r = col[4 r + g]
+}
+
 // A wave-uniform double (the timestep) through the VECTOR memory path as well: every lane loads the same address and keeps
 // its own copy in a VGPR.  (A scalar load would share lgkmcnt with the LDS traffic and the kernel-argument loads; a broadcast
 // by v_readlane right behind the load makes the compiler wait for it before it issues the next load.)

@@ -82,12 +82,9 @@ __global__ __launch_bounds__(64) void qc_mfma16_pade4_hess_kernel(const QcParams
         }
         v4d u0, u1, mraw;
         if constexpr (!KET) {
-            const double* u0p = z0 + P.off_U + jc * 16 + g;
-            const double* u1p = z1 + P.off_U + jc * 16 + g;
-            const double* mp = mu + jc * 16 + g;
-            u0 = v4d{u0p[0], u0p[4], u0p[8], u0p[12]};
-            u1 = v4d{u1p[0], u1p[4], u1p[8], u1p[12]};
-            mraw = v4d{mp[0], mp[4], mp[8], mp[12]};
+            u0 = load_col16_T(z0 + P.off_U + jc * 16, g);     // 2 requests of 16 bytes per lane instead of 4 of 8 (qc_mfma_common.h)
+            u1 = load_col16_T(z1 + P.off_U + jc * 16, g);
+            mraw = load_col16_T(mu + jc * 16, g);
         } else {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -361,12 +358,9 @@ __global__ __launch_bounds__(64) void qc_mfma16_pade4_hess_anti_kernel(const QcP
         v4d Ga = G0;
         v4d u0, u1, mraw;
         if constexpr (!KET) {
-            const double* u0p = z0 + P.off_U + jc * 16 + g;
-            const double* u1p = z1 + P.off_U + jc * 16 + g;
-            const double* mp = mu + jc * 16 + g;
-            u0 = v4d{u0p[0], u0p[4], u0p[8], u0p[12]};
-            u1 = v4d{u1p[0], u1p[4], u1p[8], u1p[12]};
-            mraw = v4d{mp[0], mp[4], mp[8], mp[12]};
+            u0 = load_col16_T(z0 + P.off_U + jc * 16, g);     // 2 requests of 16 bytes per lane instead of 4 of 8 (qc_mfma_common.h)
+            u1 = load_col16_T(z1 + P.off_U + jc * 16, g);
+            mraw = load_col16_T(mu + jc * 16, g);
         } else {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
