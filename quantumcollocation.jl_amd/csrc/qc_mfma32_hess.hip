@@ -221,6 +221,7 @@ __global__ __launch_bounds__(kHThreads32, 1) void qc_mfma32_pade4_hess_kernel(co
                 const int I = w & 1;
                 const int nr = FULL ? 32 : P.n, cb = ((FULL || j < P.nc) ? j : 0) * nr;
                 auto ld4 = [&](const double* base) {
+                    if constexpr (FULL) return load_col16_T(base + cb + 16 * I, g);   // 2 x 16 bytes per lane, transposed in registers (qc_mfma_common.h)
                     v4d v;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { const int row = 16 * I + 4 * r + g; v[r] = (FULL || row < nr) ? base[cb + row] : 0.0; }
