@@ -282,10 +282,8 @@ __global__ __launch_bounds__(kThreads32, 2) void qc_mfma32_pade4_kernel(const Qc
 #pragma unroll
             for (int I = 0; I < 2; ++I) {
                 if constexpr (!KET) {
-                    const double* u0p = z0 + P.off_U + jc * 32 + 16 * I + g;
-                    const double* u1p = z1 + P.off_U + jc * 32 + 16 * I + g;
-                    U0[I] = v4d{u0p[0], u0p[4], u0p[8], u0p[12]};
-                    U1[I] = v4d{u1p[0], u1p[4], u1p[8], u1p[12]};
+                    U0[I] = load_col16_T(z0 + P.off_U + jc * 32 + 16 * I, g);   // 2 x 16 bytes per lane, transposed in registers
+                    U1[I] = load_col16_T(z1 + P.off_U + jc * 32 + 16 * I, g);
                 } else {   // columns >= nc re-read column 0 (never stored); rows >= nr are the zero padding
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
