@@ -194,6 +194,9 @@ __global__ __launch_bounds__(kHThreads32, 1) void qc_mfma32_pade4_hess_kernel(co
         // (the fixed timestep as an opaque value: qc_mfma_common.h -- as a second load the compiler merges the two arms into one
         //  FLAT load, fenced by vmcnt(0))
         const double h = ft ? z0[P.off_dt] : opaque_scalar(P.dt_fixed);   // requested with the other loads; first used behind the barrier
+        // (Timestep and amplitudes by one vector load read out with v_readlane, as in qc_mfma32_kernels.hip, where the scalar
+        //  loads each cost a round trip in front of the next batch of requests: 21.76 against 21.43 us here, same run.  The eight
+        //  waves of a workgroup read the same words: one scalar-cache miss, seven hits.)
         QC_STAMP_DECL;
         QC_STAMP(P, b, lane, 0);
 

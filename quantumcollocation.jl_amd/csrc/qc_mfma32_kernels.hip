@@ -177,7 +177,7 @@ __global__ __launch_bounds__(kThreads32, 2) void qc_mfma32_pade4_kernel(const Qc
         // out lane by lane behind barrier 1.  As scalar loads they were a trap twice over: every scalar wait that follows one
         // -- a kernel argument read a little later -- waits for its round trip through L2 as well (shared counter, out-of-order
         // return), and without the persistent loop the compiler put a wait behind EACH of the nine.
-        const int ia = lane < mL ? P.off_a + lane : (ft ? P.off_dt : P.off_a);
+        const int ia = lane < mL ? P.off_a + lane : (ft ? P.off_dt : 0);
         const double av = z0[ia];
         asm volatile("" ::: "memory");   // no load sinks below this line, no LDS store rises above it
 #ifdef QC_STAMP_PROLOGUE
