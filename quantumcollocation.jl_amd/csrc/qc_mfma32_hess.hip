@@ -209,6 +209,8 @@ __global__ __launch_bounds__(kHThreads32, 1) void qc_mfma32_pade4_hess_kernel(co
         //  first 0.9 us longer (eight waves' staging loads in the compute unit's vector-memory issue path next to the products)
         //  plus the staging of the first interval in front of the loop: 23.6 - 24.8 us against 23.25 us at two intervals per
         //  workgroup.  It would pay from about four intervals per workgroup (T > 1000 at 4 qubits).)
+        const bool dfast = ft && P.n_deriv <= 2 && P.ddim_i[0] <= 64 && P.ddim_i[1] <= 64;
+        double mud[2] = {0.0, 0.0};
         {
             const v2d* __restrict__ ab = reinterpret_cast<const v2d*>(GxA) + (w >> 1) * 128 + (w & 1) * 64 + lane;
             v2d img[kHMax32 + 1];
@@ -240,9 +242,12 @@ __global__ __launch_bounds__(kHThreads32, 1) void qc_mfma32_pade4_hess_kernel(co
                     put_tile(DL, I, lane, u1 - u0);
                 }
             }
-            if (w == 5) {   // derivative integrators: d2/d(dx_i) dh = -mu_i, a plain copy (done here: a load issued after
-                            // the stores of phase 2 would wait for all of them), and the alignment padding
-                qc_hess_tail(Pk, mu, Hb, lane, 64);
+            if (w == 5 && dfast) {   // derivative integrators: d2/d(dx_i) dh = -mu_i, a plain copy.  Only REQUESTED here (a load issued
+                                     // after the stores of phase 2 would wait for all of them); written behind the barrier.  (The
+                                     // general form, qc_hess_tail, is a loop of load -> store round trips: run here it held wave 5
+                                     // -- and with it barrier 1 -- for two of them.)
+#pragma unroll
+                for (int d = 0; d < 2; ++d) mud[d] = mu[P.drow[d] + (lane < P.ddim_i[d] ? lane : 0)];   // unused slots: zero dims, in bounds
             }
             v2d Gh = img[0];
 #pragma unroll
@@ -255,6 +260,19 @@ __global__ __launch_bounds__(kHThreads32, 1) void qc_mfma32_pade4_hess_kernel(co
         QC_STAMP(P, b, lane, 2);
 
         // ---- phase 1 ---------------------------------------------------------------------------------------------
+        if (w == 5) {   // the tail of the interval's block: derivative-integrator entries and the alignment padding
+            if (dfast) {
+                int o = P.ho_d;
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    if (lane < P.ddim_i[d]) Hb[o + lane] = -mud[d];
+                    o += P.ddim_i[d];
+                }
+                for (int i = lane; i < P.h_pad; i += 64) Hb[P.hess_nnz + i] = 0.0;
+            } else {
+                qc_hess_tail(Pk, mu, Hb, lane, 64);
+            }
+        }
         const v4d Mt[2] = {g_tile(ML, 0, lane), g_tile(ML, 1, lane)};
         const v4d D[2] = {g_tile(DL, 0, lane), g_tile(DL, 1, lane)};
         if (w < 2) {          // B-layout tiles (K, I) of G by identity products, then M1[I] = sum_K (G[K][I])^T M[K]
