@@ -656,7 +656,7 @@ def test_randomised_descriptor_sweep(qc, oracle):
         h.close()
 
 
-@pytest.mark.parametrize("N,m", [(8, 0), (8, 1), (8, 7), (8, 8), (8, 9), (16, 1), (16, 9)])
+@pytest.mark.parametrize("N,m", [(8, 0), (8, 1), (8, 7), (8, 8), (8, 9), (16, 0), (16, 1), (16, 9)])
 def test_mfma_drive_count_edges(qc, oracle, N, m):
     """MFMA kernels at the edges of their register/LDS drive blocks (0, odd, exactly 8, beyond 8)."""
     prob, Z = random_problem(oracle, N=N, m=max(m, 1), T=3, order=4, seed=300 + N + m)
@@ -673,6 +673,24 @@ def test_mfma_drive_count_edges(qc, oracle, N, m):
         mu = np.random.default_rng(1).standard_normal(prob.n_rows)
         assert_close_h(h.hess(Z, mu), oracle.mu_d2F(prob, Z, mu), f"{kernel} hess")
         h.close()
+
+
+@pytest.mark.parametrize("T", [2, 7])
+def test_mfma32_fixed_time_without_drives(qc, oracle, T):
+    """2N = 32 with neither a timestep nor an amplitude in the knots: the kernels' one vector load of (amplitudes | timestep)
+    has nothing to fetch and must stay in bounds (first knot of the vector included)."""
+    prob, Z = random_problem(oracle, N=16, m=1, T=T, order=4, free_time=False, seed=911 + T)
+    prob.m = 0
+    prob.G_drives = prob.G_drives[:0]
+    prob.derivs = []
+    Fr, Jr = oracle.F(prob, Z), oracle.dF(prob, Z)
+    h = RawHandle(qc, prob, kernel="mfma")
+    F, J = h.F_jac(Z)
+    assert_close(F, Fr, "mfma32 F, m = 0, fixed dt")
+    assert_close(J, Jr, "mfma32 dF, m = 0, fixed dt")
+    mu = np.random.default_rng(T).standard_normal(prob.n_rows)
+    assert_close_h(h.hess(Z, mu), oracle.mu_d2F(prob, Z, mu), "mfma32 hess, m = 0, fixed dt")
+    h.close()
 
 
 @pytest.mark.parametrize("m,free_time,layout,hermitian", [(8, True, "standard", True), (5, False, "shuffled", False), (2, True, "shuffled", False),
