@@ -385,13 +385,32 @@ static int run_chunks(qc_handle* h, const CompactPlan& cp, double* F, double* va
     HostPool& pool = host_pool();
     const int workers = pool_workers(shards);
     pool.ensure(workers);
-    int n_chunks = vals ? chunk_count(h, P.n_int, workers, (size_t)cp.comp_len * sizeof(double)) : 1;   // residuals only: ~1 MB, one launch
-    const int per = (P.n_int + n_chunks - 1) / n_chunks;
-    n_chunks = (P.n_int + per - 1) / per;
+    // (residuals only: ~1 MB in all; QC_HOST_F_CHUNKS, default 1)
+    static const int f_chunks = getenv("QC_HOST_F_CHUNKS") ? std::max(1, atoi(getenv("QC_HOST_F_CHUNKS"))) : 1;
+    int n_chunks = vals ? chunk_count(h, P.n_int, workers, (size_t)cp.comp_len * sizeof(double)) : std::max(1, std::min(f_chunks, P.n_int / 64));
+    // Chunk boundaries.  QC_HOST_TAPER=t (default 0: equal chunks): sizes fall linearly from the first chunk to the last by the
+    // factor t -- large chunks keep the link busy, and only the LAST chunk's replication is not overlapped with a transfer.
+    static const double taper = getenv("QC_HOST_TAPER") ? std::max(1.0, atof(getenv("QC_HOST_TAPER"))) : 1.0;
+    std::vector<int> bound(1, 0);
+    if (taper <= 1.0 || n_chunks < 3) {
+        const int per = (P.n_int + n_chunks - 1) / n_chunks;
+        for (int b = per; b < P.n_int; b += per) bound.push_back(b);
+    } else {
+        double wsum = 0.0;
+        for (int k = 0; k < n_chunks; ++k) wsum += taper - (taper - 1.0) * k / (n_chunks - 1);
+        double acc = 0.0;
+        for (int k = 0; k + 1 < n_chunks; ++k) {
+            acc += taper - (taper - 1.0) * k / (n_chunks - 1);
+            const int b = (int)(P.n_int * acc / wsum + 0.5);
+            if (b > bound.back() && b < P.n_int) bound.push_back(b);
+        }
+    }
+    bound.push_back(P.n_int);
+    n_chunks = (int)bound.size() - 1;
     int rc;
     if ((rc = ensure_events(h, n_chunks))) return rc;
     for (int k = 0; k < n_chunks; ++k) {
-        const int b0 = k * per, b1 = std::min(P.n_int, b0 + per);
+        const int b0 = bound[k], b1 = bound[k + 1];
         if ((rc = produce(k, b0, b1))) return rc;
         QC_HIP(h, hipEventRecord(h->chunk_events[k], (two_streams && (k & 1)) ? h->stream2 : h->stream));
     }
@@ -403,10 +422,16 @@ static int run_chunks(qc_handle* h, const CompactPlan& cp, double* F, double* va
     const double* hF = F ? h->hFc : nullptr;
     const QcParams* Pp = &P;
     for (int k = 0; k < n_chunks; ++k) {
-        if (hipEventSynchronize(h->chunk_events[k]) != hipSuccess) { rc_wait = QC_ERR_HIP; break; }
+        // (hipEventQuery in a loop: the calling thread has nothing else to do, and a blocking wait reacts 20 - 50 us late;
+        //  QC_HOST_WAIT=1 restores hipEventSynchronize)
+        static const bool blocking_wait = getenv("QC_HOST_WAIT") && atoi(getenv("QC_HOST_WAIT")) == 1;
+        hipError_t ew = hipSuccess;
+        if (blocking_wait) ew = hipEventSynchronize(h->chunk_events[k]);
+        else while ((ew = hipEventQuery(h->chunk_events[k])) == hipErrorNotReady) __builtin_ia32_pause();
+        if (ew != hipSuccess) { rc_wait = QC_ERR_HIP; break; }
         if (k == 0) t_first = now_us();
         if (k == n_chunks - 1) t_last = now_us();
-        const int b0 = k * per, b1 = std::min(P.n_int, b0 + per);
+        const int b0 = bound[k], b1 = bound[k + 1];
         // several jobs per chunk, so that the LAST chunk's replication (the un-overlapped tail) is shared by the workers
         static const int max_pieces = getenv("QC_HOST_PIECES") ? std::max(1, atoi(getenv("QC_HOST_PIECES"))) : 4;
         const int pieces = std::max(1, std::min(std::min(workers, max_pieces), (b1 - b0) / 4));
@@ -419,18 +444,27 @@ static int run_chunks(qc_handle* h, const CompactPlan& cp, double* F, double* va
             if (hF) memcpy(F + (size_t)b0 * Pp->F_stride, hF + (size_t)b0 * Pp->F_stride, (size_t)(b1 - b0) * Pp->F_stride * sizeof(double));
             continue;
         }
-        for (int c0 = b0; c0 < b1; c0 += step) {
+        // (the LAST chunk's first piece is expanded by this thread, which has nothing left to wait for: a worker's wake-up
+        //  alone costs 20 - 40 us)
+        const bool last = k == n_chunks - 1;
+        auto piece = [=](int c0, int c1) {
+            if (vals) expand_intervals(*Pp, cp, comp, vals, c0, c1);
+            if (hF) memcpy(F + (size_t)c0 * Pp->F_stride, hF + (size_t)c0 * Pp->F_stride, (size_t)(c1 - c0) * Pp->F_stride * sizeof(double));
+        };
+        for (int c0 = b0 + (last ? step : 0); c0 < b1; c0 += step) {
             const int c1 = std::min(b1, c0 + step);
-            pool.push([=] {
-                if (vals) expand_intervals(*Pp, cp, comp, vals, c0, c1);
-                if (hF) memcpy(F + (size_t)c0 * Pp->F_stride, hF + (size_t)c0 * Pp->F_stride, (size_t)(c1 - c0) * Pp->F_stride * sizeof(double));
-            }, &grp);
+            pool.push([=] { piece(c0, c1); }, &grp);
         }
+        if (last) piece(b0, std::min(b1, b0 + step));
     }
     grp.wait();
     const double t_done = now_us();
-    QC_HIP(h, hipStreamSynchronize(h->stream));
-    if (two_streams) QC_HIP(h, hipStreamSynchronize(h->stream2));
+    // Every chunk's event has completed, and the last two were the last operations of the two streams: both are idle.  (An explicit
+    // hipStreamSynchronize on each cost 38 us per call for nothing.)  After a failed wait the streams are drained the slow way.
+    if (rc_wait) {
+        (void)hipStreamSynchronize(h->stream);
+        if (two_streams) (void)hipStreamSynchronize(h->stream2);
+    }
     if (host_trace())
         fprintf(stderr, "qcolloc host trace: %d chunks, %d workers: chunk loop entered +%.0f us after the call, launches issued +%.0f, first chunk "
                 "landed +%.0f, last chunk landed +%.0f, replication done +%.0f, stream idle +%.0f us\n", n_chunks, workers, t_begin - g_call_begin,
