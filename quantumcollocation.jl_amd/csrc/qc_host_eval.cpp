@@ -422,9 +422,11 @@ static int run_chunks(qc_handle* h, const CompactPlan& cp, double* F, double* va
     const double* hF = F ? h->hFc : nullptr;
     const QcParams* Pp = &P;
     for (int k = 0; k < n_chunks; ++k) {
-        // (hipEventQuery in a loop: the calling thread has nothing else to do, and a blocking wait reacts 20 - 50 us late;
-        //  QC_HOST_WAIT=1 restores hipEventSynchronize)
-        static const bool blocking_wait = getenv("QC_HOST_WAIT") && atoi(getenv("QC_HOST_WAIT")) == 1;
+        // (hipEventQuery in a loop: the calling thread has nothing else to do, and a blocking wait reacts 20 - 50 us late.  Not for
+        //  the shards of a multi-device handle: N spinning shard threads next to the replication workers exceed a 16-CPU quota.
+        //  QC_HOST_WAIT=1 restores hipEventSynchronize everywhere)
+        static const bool blocking_env = getenv("QC_HOST_WAIT") && atoi(getenv("QC_HOST_WAIT")) == 1;
+        const bool blocking_wait = blocking_env || shards > 1;
         hipError_t ew = hipSuccess;
         if (blocking_wait) ew = hipEventSynchronize(h->chunk_events[k]);
         else while ((ew = hipEventQuery(h->chunk_events[k])) == hipErrorNotReady) __builtin_ia32_pause();
