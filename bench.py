@@ -264,14 +264,21 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     ev0.record(stream)
+    ta = time.perf_counter()
     for i in range(args.steps):
         step(i)
+    tb = time.perf_counter()
     ev1.record(stream)
     while not ev1.query():  # the launching thread polls for the last step's end; a blocking synchronize wakes up 10 - 30 us late,
         pass                # which at K = 20 steps of 9 us is a tenth of the measurement
+    tc = time.perf_counter()
     torch.cuda.synchronize()
+    td = time.perf_counter()
     barrier()
     elapsed = time.perf_counter() - t0
+    if os.environ.get("QC_BENCH_TRACE"):
+        print(f"timed region: first record +{(ta - t0) * 1e6:.1f} us, launches issued +{(tb - t0) * 1e6:.1f}, last step seen done "
+              f"+{(tc - t0) * 1e6:.1f}, synchronize returned +{(td - t0) * 1e6:.1f}, end +{elapsed * 1e6:.1f}", file=sys.stderr)
     assert status[0] == 0, "qc_eval_F_jac_dev reported an error during the timed loop"
     stream_ms = ev0.elapsed_time(ev1)
     if world > 1:
