@@ -72,6 +72,59 @@ def cpu_baseline(qc, inp, seconds: float):
 PCIE_PEAK_GBS = 63.0    # MI355X_MICROARCH.md: PCIe Gen5 x16 host link
 
 
+class NodeBarrier:
+    """Barrier between the ranks of ONE node through a page in /dev/shm: one cache line per rank, each written by its owner only
+    (a generation count), every rank spins until all lines carry the current generation.  The contract brackets the timed region
+    with a barrier on both sides; the ranks exchange no data (the path shards without a collective), so the
+    barrier is measurement scaffolding, and `dist.barrier()` on the RCCL backend -- an all-reduce kernel plus a stream
+    synchronisation, 40 - 100 us -- would be a fifth to a half of a K = 20 measurement of 9-us steps at N > 1 and none of it at
+    N = 1.  Falls back to `dist.barrier()` when the ranks are not all on this node or the page cannot be set up."""
+
+    def __init__(self, rank, world):
+        import mmap
+        self.rank, self.world, self.gen, self.slots = rank, world, 0, None
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+        ok = local_world == world and os.path.isdir("/dev/shm") and os.environ.get("QC_BENCH_BARRIER", "shm") != "dist"
+        self.path = f"/dev/shm/qcolloc_bench_{os.getuid()}_{os.environ.get('MASTER_PORT', '0')}"
+        try:
+            if ok and rank == 0:
+                with open(self.path, "wb") as f:
+                    f.write(bytes(64 * world))
+            dist.barrier()                                   # the page exists (or rank 0 failed: the open below fails everywhere)
+            if ok:
+                self._f = open(self.path, "r+b")
+                self._mm = mmap.mmap(self._f.fileno(), 64 * world)
+                self.slots = np.frombuffer(self._mm, dtype=np.int64).reshape(world, 8)
+        except OSError:
+            self.slots = None
+        flag = torch.tensor([1 if self.slots is not None else 0], dtype=torch.int32,
+                            device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)          # every rank or none
+        if int(flag.item()) == 0:
+            self.slots = None
+        self.kind = "shared-memory page (/dev/shm)" if self.slots is not None else "dist.barrier"
+
+    def wait(self):
+        if self.slots is None:
+            dist.barrier()
+            return
+        self.gen += 1
+        self.slots[self.rank, 0] = self.gen
+        col = self.slots[:, 0]
+        while int(col.min()) < self.gen:
+            pass
+
+    def close(self):
+        if self.slots is not None:
+            dist.barrier()                                   # nobody is still spinning on the page
+            self.slots = None
+            if self.rank == 0:
+                try:
+                    os.unlink(self.path)
+                except OSError:
+                    pass
+
+
 def host_visible_times(dyn, Zh, reps=30):
     """PCIe-inclusive times of the host-buffer entry points (what the reference's consumer, a CPU Ipopt process, sees):
     qc_eval_F_jac, qc_eval_hess, qc_eval_F with caller-owned numpy arrays, milliseconds per call."""
@@ -240,9 +293,11 @@ def main():
     def step(i):
         status[0] |= launch[i % period]()
 
+    node_barrier = NodeBarrier(rank, world) if world > 1 else None
+
     def barrier():
         if world > 1:
-            dist.barrier()
+            node_barrier.wait()
 
     # Untimed pre-warm, IN ADDITION to the W warm-up steps: every slot of the output ring is written at least once (a first write
     # to fresh device memory pays for its page-table entries: with W = 5 and K = 20 twelve of the timed steps would be first
@@ -466,6 +521,7 @@ def main():
         if rccl_ranks is not None:
             line["rccl_ranks"] = rccl_ranks
             line["collective_backend"] = backend
+            line["timing_barrier"] = node_barrier.kind
         if host_rec is not None:
             line["host_visible"] = host_rec
         if c5 is not None:
@@ -474,6 +530,7 @@ def main():
             line["cpu_baseline"] = cpu_rec
         print(json.dumps(line), flush=True)
     if world > 1:
+        node_barrier.close()
         dist.barrier()
         dist.destroy_process_group()
     dyn.close()
