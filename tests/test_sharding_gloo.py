@@ -86,3 +86,49 @@ def test_knot_shards_partition():
             assert all(a[1] == b[0] for a, b in zip(sh, sh[1:]))
             c = -(-(T - 1) // w)
             assert all(t0 == min(r * c, T - 1) for r, (t0, _) in enumerate(sh))
+
+
+def _barrier_worker(rank, world, port, mode, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_WORLD_SIZE=str(world), QC_BENCH_BARRIER=mode)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import time
+        import bench
+        nb = bench.NodeBarrier(rank, world)
+        path = nb.path
+        order = []
+        for it in range(200):                  # ranks take turns being late: nobody may leave a barrier before the late rank arrives
+            if it % world == rank:
+                time.sleep(0.0005)
+            t_arrive = time.perf_counter()
+            nb.wait()
+            order.append((t_arrive, time.perf_counter()))
+        arr = torch.tensor(order, dtype=torch.float64)
+        allr = [torch.zeros_like(arr) for _ in range(world)]
+        dist.all_gather(allr, arr)
+        allr = torch.stack(allr).numpy()       # [rank, iteration, (arrive, leave)]  -- one clock: the processes share the host
+        ok = bool((allr[:, :, 1].min(axis=0) >= allr[:, :, 0].max(axis=0) - 1e-6).all())
+        kind = nb.kind
+        nb.close()
+        q.put((rank, ok, kind, os.path.exists(path)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode,world", [("shm", 2), ("shm", 3), ("dist", 2)])
+def test_bench_node_barrier(mode, world):
+    """bench.py's timing barrier at N > 1 (a page in /dev/shm; `dist.barrier()` as the fallback): no rank leaves before the last
+    one arrives, and the page is gone afterwards."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_barrier_worker, args=(r, world, port, mode, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] for r in res), res
+    assert all(r[2] == ("shared-memory page (/dev/shm)" if mode == "shm" else "dist.barrier") for r in res), res
+    assert not any(r[3] for r in sorted(res)[:1]), res     # rank 0 removed the page (checked after close() on rank 0)
