@@ -233,6 +233,24 @@ __device__ __forceinline__ void qc_kernarg_touch() {
     asm volatile("" ::"s"(w));   // keeps the loads; nothing depends on the sum
 }
 
+// The same in two halves: the requests at one point, the (only) wait for them at another -- for kernels whose first vector
+// load requests depend on preloaded arguments only and must not stand behind a scalar wait (qc_mfma_kernels.hip).
+template <int BYTES>
+struct QcKernargTouch {
+    static constexpr int kN = (BYTES + 63) / 64;
+    int v[kN];
+    __device__ __forceinline__ void request() {
+        typedef __attribute__((address_space(4))) const int kint;
+        kint* k = (kint*)__builtin_amdgcn_kernarg_segment_ptr();
+#pragma unroll
+        for (int i = 0; i < kN; ++i) v[i] = k[i * 16];
+    }
+    __device__ __forceinline__ void consume() {
+#pragma unroll
+        for (int i = 0; i < kN; ++i) asm volatile("" ::"s"(v[i]));
+    }
+};
+
 // Tail of an interval's Hessian block: the derivative integrators' entries d2/d(dx_i) dh = -mu_i (free timestep only) and the
 // alignment padding (explicit zeros; qc_desc.hess_align).  `mu`, `Hb` point at this handle's rows / values of the interval.
 __device__ inline void qc_hess_tail(const QcParams& P, const double* __restrict__ mu, double* __restrict__ Hb, int tid, int nthreads) {

@@ -61,8 +61,7 @@ constexpr int kDF = 4;   // derivative integrators handled from registers in the
 // waits on another) and returned in gk/ak for reuse by the drive-column loop.  Two halves, so that a caller can put other
 // load requests between them: assemble_G_request issues the loads, assemble_G_combine waits for them and forms G.
 template <int kMU>
-__device__ inline void request_images(const QcParams& P, const double* __restrict__ Gx, int lane, v4d& g0, v4d (&gk)[kMU]) {
-    const int m = P.m;
+__device__ inline void request_images(int m, const double* __restrict__ Gx, int lane, v4d& g0, v4d (&gk)[kMU]) {
     g0 = load_GA(Gx, 0, lane);
 #pragma unroll
     for (int u = 0; u < kMU; ++u) {
@@ -74,7 +73,7 @@ template <int kMU>
 __device__ inline void assemble_G_request(const QcParams& P, const double* __restrict__ Gx, const double* __restrict__ z0, int lane,
                                           v4d& g0, v4d (&gk)[kMU], double& av) {
     av = load_amp_lanes(z0, P.off_a, P.m, lane);   // every amplitude in one vector load (qc_mfma_common.h)
-    request_images(P, Gx, lane, g0, gk);
+    request_images(P.m, Gx, lane, g0, gk);
 }
 template <int kMU>
 __device__ inline v4d assemble_G_combine(const QcParams& P, const double* __restrict__ Gx, int lane, const v4d& g0, const v4d (&gk)[kMU],
@@ -152,11 +151,22 @@ __device__ inline v4d lds_get(const double* __restrict__ base, int lane) {
 // every loop-invariant mask, address and predicate (~350 instructions, SGPRs spilled to VGPR lanes) in front of it, i.e. in
 // front of the FIRST GLOBAL LOAD of the copy wave: 1.6 us between a wave's first instruction and its first load request
 // (profiles/r02_stamps_d.txt).  Without the loop the loads are scheduled first and the set-up runs under their latency.
+// QcHot: what the first load requests of a wave depend on, as the FIRST kernel arguments -- this file is compiled with
+// -amdgpu-kernarg-preload-count, which has the hardware place the leading argument dwords in scalar registers while the wave is
+// launched, so the image and amplitude requests do not wait for a scalar load from the argument block (the by-value parameter
+// block, 0.55 KB, follows; it is read under the latency of those requests).
+// (Scalars and pointers only: a by-value struct is passed by reference and is not preloaded.)
+#define QC_HOT_ARGS(P) (P).Gx, dZ, (P).t_begin, (P).n_int, (P).zdim, (P).off_a, (P).off_dt, (P).m
+
 template <bool JAC, int MODE, bool DIAG, int kMU, bool KET, bool BATCH, bool ONCE = false>
-__global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel(const QcParams Pk, const double* __restrict__ Z,
+__global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel(const double* __restrict__ hot_Gx, const double* __restrict__ Z, long long hot_t_begin, int hot_n_int,
+                                                                      int hot_zdim, int hot_off_a, int hot_off_dt, int hot_m, const QcParams Pk,
                                                                       double* __restrict__ F, double* __restrict__ J,
                                                                       const QcParams* __restrict__ Pb) {
     const QcParams& P = BATCH ? Pb[blockIdx.y] : Pk;
+    const int h_n_int = BATCH ? P.n_int : hot_n_int, h_zdim = BATCH ? P.zdim : hot_zdim, h_off_a = BATCH ? P.off_a : hot_off_a;
+    const int h_off_dt = BATCH ? P.off_dt : hot_off_dt;
+    const long long h_t_begin = BATCH ? P.t_begin : hot_t_begin;
     constexpr int kLdsBlock = kLdsGk + kMU * 256;
     __shared__ __attribute__((aligned(16))) double sm_all[JAC ? kIntervalsPerWG * kLdsBlock : 2];
     unsigned long long t_entry = 0, t_kernarg = 0;
@@ -167,8 +177,11 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
                               (long long)Z + (long long)Pb + (long long)(Pk.c[2] != 0.0) + (long long)(Pk.dt_fixed != 0.0);
         asm volatile("s_memrealtime %0" : "=s"(t_kernarg) : "s"(dep));
     }
+    // One dword of every line of the argument block is REQUESTED here (one batch of scalar-cache misses instead of one per use,
+    // qc_internal.h) and waited for behind the image requests, which depend on preloaded arguments only.
 #ifndef QC_NO_KERNARG_TOUCH
-    qc_kernarg_touch<sizeof(QcParams) + 64>();
+    QcKernargTouch<sizeof(QcParams) + 96> touch;
+    touch.request();
 #endif
     // (Demanding every argument of the prologue at one point -- one batch of scalar loads -- was measured: 10.0 vs 9.6 us.)
     const int tid = threadIdx.x;
@@ -181,21 +194,24 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
     const int slot = wave % kIntervalsPerWG;      // which of the workgroup's intervals
     double* __restrict__ sm = sm_all + (JAC ? slot * kLdsBlock : 0);
     const int ipw = JAC ? kIntervalsPerWG : 1;
-    const int n_wg = (P.n_int + ipw - 1) / ipw;
-    const int m = P.m;
+    const int n_wg = (h_n_int + ipw - 1) / ipw;
+    const int m = BATCH ? P.m : hot_m;
     // KET = false: a unitary on N = 8 levels, every mask below folds away at compile time (as run-time tests they cost the
     // headline kernel 0.8 us per launch).  KET = true: the masked instantiation -- K <= 8 state columns (kets) and / or
     // N < 8 levels (2N = nr < 16 rows, zero-padded to the tile).
     const int nc = KET ? P.nc : 8;
     const int nr = KET ? P.n : 16;
-    const bool ft = P.off_dt >= 0;
+    const bool ft = h_off_dt >= 0;
     const double c1 = P.c[1], c2 = P.c[2];
-    const double* __restrict__ Gx = P.Gx;
+    const double* __restrict__ Gx = BATCH ? P.Gx : hot_Gx;
 
     // The copy wave's generator images depend on nothing but the kernel arguments: they are requested before any address of the
     // interval is computed (and once for all intervals of a persistent grid).
     v4d g0_img, gk_img[kMU];
-    if (JAC && role == 1) request_images(P, Gx, lane0, g0_img, gk_img);
+    if (JAC && role == 1) request_images(m, Gx, lane0, g0_img, gk_img);
+#ifndef QC_NO_KERNARG_TOUCH
+    touch.consume();
+#endif
     int vb = blockIdx.x;
     if (vb >= n_wg) return;   // (never: the grid has at most n_wg workgroups)
     do {
@@ -209,15 +225,15 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
         const bool left = j < 8;
         const v4d IdB = identity_B(g, j);
         const int b_raw = qc_xcd_remap(vb, n_wg) * ipw + slot;   // local interval of this wave pair
-        const bool active = b_raw < P.n_int;                      // the last workgroup may be partly empty;
-        const int b = active ? b_raw : P.n_int - 1;               // its idle waves still take part in the barriers
-        const long long t = P.t_begin + b;
-        const double* __restrict__ z0 = Z + t * (long long)P.zdim;
-        const double* __restrict__ z1 = z0 + P.zdim;
+        const bool active = b_raw < h_n_int;                      // the last workgroup may be partly empty;
+        const int b = active ? b_raw : h_n_int - 1;               // its idle waves still take part in the barriers
+        const long long t = h_t_begin + b;
+        const double* __restrict__ z0 = Z + t * (long long)h_zdim;
+        const double* __restrict__ z1 = z0 + h_zdim;
         // what G depends on besides the images -- the amplitudes and the timestep -- is requested as soon as the knot's address
         // exists, before the output addresses are computed (both waves: the compute wave needs the timestep too)
-        const double av_pre = (JAC && role == 1) ? load_amp_lanes(z0, P.off_a, m, lane) : 0.0;
-        const double h_pre = ft ? load_uniform(z0 + P.off_dt) : opaque_scalar(P.dt_fixed);
+        const double av_pre = (JAC && role == 1) ? load_amp_lanes(z0, h_off_a, m, lane) : 0.0;
+        const double h_pre = ft ? load_uniform(z0 + h_off_dt) : opaque_scalar(P.dt_fixed);
         double* __restrict__ Jb = JAC ? J + (size_t)b * P.J_stride + P.J_off : nullptr;
         double* __restrict__ Fb = F ? F + (size_t)b * P.F_stride + P.F_off : nullptr;
         QC_STAMP_DECL;
@@ -574,19 +590,19 @@ template <bool JAC, bool DIAG, int MU>
 static void launch16m(const QcParams& P, const double* dZ, double* dF, double* dJ, hipStream_t st, int grid, int threads) {
     if (P.nc != 8 || P.n != 16) {   // K < 8 kets and / or N < 8 levels: the masked instantiation (non-temporal stores, no diagnostics)
         const int n_wg_k = JAC ? (P.n_int + kIntervalsPerWG - 1) / kIntervalsPerWG : P.n_int;
-        if (grid == n_wg_k) hipLaunchKernelGGL((qc_mfma16_pade4_kernel<JAC, 2, false, MU, true, false, true>), dim3(grid), dim3(threads), 0, st, P, dZ, dF, dJ, nullptr);
-        else hipLaunchKernelGGL((qc_mfma16_pade4_kernel<JAC, 2, false, MU, true, false>), dim3(grid), dim3(threads), 0, st, P, dZ, dF, dJ, nullptr);
+        if (grid == n_wg_k) hipLaunchKernelGGL((qc_mfma16_pade4_kernel<JAC, 2, false, MU, true, false, true>), dim3(grid), dim3(threads), 0, st, QC_HOT_ARGS(P), P, dF, dJ, nullptr);
+        else hipLaunchKernelGGL((qc_mfma16_pade4_kernel<JAC, 2, false, MU, true, false>), dim3(grid), dim3(threads), 0, st, QC_HOT_ARGS(P), P, dF, dJ, nullptr);
         return;
     }
     const int n_wg = JAC ? (P.n_int + kIntervalsPerWG - 1) / kIntervalsPerWG : P.n_int;
     switch (P.store_mode) {
-        case 0: hipLaunchKernelGGL((qc_mfma16_pade4_kernel<JAC, 0, DIAG, MU, false, false>), dim3(grid), dim3(threads), 0, st, P, dZ, dF, dJ, nullptr); break;
-        case 1: hipLaunchKernelGGL((qc_mfma16_pade4_kernel<JAC, 1, DIAG, MU, false, false>), dim3(grid), dim3(threads), 0, st, P, dZ, dF, dJ, nullptr); break;
+        case 0: hipLaunchKernelGGL((qc_mfma16_pade4_kernel<JAC, 0, DIAG, MU, false, false>), dim3(grid), dim3(threads), 0, st, QC_HOT_ARGS(P), P, dF, dJ, nullptr); break;
+        case 1: hipLaunchKernelGGL((qc_mfma16_pade4_kernel<JAC, 1, DIAG, MU, false, false>), dim3(grid), dim3(threads), 0, st, QC_HOT_ARGS(P), P, dF, dJ, nullptr); break;
         default:
             if (grid == n_wg)   // one interval per workgroup: the loop-free instantiation (also for the stamped diagnostic build)
-                hipLaunchKernelGGL((qc_mfma16_pade4_kernel<JAC, 2, DIAG, MU, false, false, true>), dim3(grid), dim3(threads), 0, st, P, dZ, dF, dJ, nullptr);
+                hipLaunchKernelGGL((qc_mfma16_pade4_kernel<JAC, 2, DIAG, MU, false, false, true>), dim3(grid), dim3(threads), 0, st, QC_HOT_ARGS(P), P, dF, dJ, nullptr);
             else
-                hipLaunchKernelGGL((qc_mfma16_pade4_kernel<JAC, 2, DIAG, MU, false, false>), dim3(grid), dim3(threads), 0, st, P, dZ, dF, dJ, nullptr);
+                hipLaunchKernelGGL((qc_mfma16_pade4_kernel<JAC, 2, DIAG, MU, false, false>), dim3(grid), dim3(threads), 0, st, QC_HOT_ARGS(P), P, dF, dJ, nullptr);
             break;
     }
 }
@@ -611,9 +627,9 @@ template <bool JAC, int MU>
 static void launch16_batch(const QcParams& P0, const QcParams* dPb, int count, const double* dZ, double* dF, double* dJ, hipStream_t st, int grid,
                            int threads) {
     if (P0.nc != 8 || P0.n != 16)   // kets / padded systems: the masked instantiation
-        hipLaunchKernelGGL((qc_mfma16_pade4_kernel<JAC, 2, false, MU, true, true>), dim3(grid, count), dim3(threads), 0, st, P0, dZ, dF, dJ, dPb);
+        hipLaunchKernelGGL((qc_mfma16_pade4_kernel<JAC, 2, false, MU, true, true>), dim3(grid, count), dim3(threads), 0, st, QC_HOT_ARGS(P0), P0, dF, dJ, dPb);
     else
-        hipLaunchKernelGGL((qc_mfma16_pade4_kernel<JAC, 2, false, MU, false, true>), dim3(grid, count), dim3(threads), 0, st, P0, dZ, dF, dJ, dPb);
+        hipLaunchKernelGGL((qc_mfma16_pade4_kernel<JAC, 2, false, MU, false, true>), dim3(grid, count), dim3(threads), 0, st, QC_HOT_ARGS(P0), P0, dF, dJ, dPb);
 }
 
 hipError_t qc_launch_mfma16_F_jac_batch(const QcParams& P0, const QcParams* dPb, int count, const double* dZ, double* dF, double* dJ,
