@@ -305,14 +305,25 @@ __device__ __forceinline__ void st_off(double* __restrict__ ubase, unsigned byte
     qc_st8m<MODE>(reinterpret_cast<double*>(reinterpret_cast<char*>(ubase) + byteoff), v);
 }
 
+// The leading scalar / pointer arguments are PRELOADED into scalar registers while the wave is launched (this file is compiled
+// with -amdgpu-kernarg-preload-count): they are what the first load requests depend on (qc_mfma_kernels.hip).  mu0 = the
+// multipliers of this handle's first interval; f_stride = rows per interval.
+#define QC_HESS_HOT_ARGS(P) (P).Gx, dZ + (P).t_begin * (long long)(P).zdim, dMu + (P).t_begin * (P).F_stride + (P).F_off, (P).n_int, (P).zdim, (P).off_a, \
+                            (P).off_dt, (P).m, (P).off_U, (int)(P).F_stride
 template <int kHM, bool KET, bool BATCH, bool ONCE, bool DIAG = false>
-__global__ __launch_bounds__(64) void qc_mfma16_pade4_hess_anti_kernel(const QcParams Pk, const double* __restrict__ Z,
+__global__ __launch_bounds__(64) void qc_mfma16_pade4_hess_anti_kernel(const double* __restrict__ hot_Gx, const double* __restrict__ hot_Zt,
+                                                                       const double* __restrict__ hot_mu0, int hot_n_int,
+                                                                       int hot_zdim, int hot_off_a, int hot_off_dt, int hot_m, int hot_off_U,
+                                                                       int hot_f_stride, const QcParams Pk, const double* __restrict__ Z,
                                                                        const double* __restrict__ Mu, double* __restrict__ H,
                                                                        const QcParams* __restrict__ Pb) {
     QC_STAMP_DECL;
     QC_STAMP(Pk, 0, 0, 0);                        // kernel entry
-    qc_kernarg_touch<sizeof(QcParams) + 64>();
+    QcKernargTouch<sizeof(QcParams) + 128> touch; // requested here, waited for behind the first load requests (qc_internal.h)
+    touch.request();
     const QcParams& P = BATCH ? Pb[blockIdx.y] : Pk;      // BATCH: one launch for several handles (qc_mfma_kernels.hip)
+    const int h_n_int = BATCH ? P.n_int : hot_n_int, h_zdim = BATCH ? P.zdim : hot_zdim, h_off_a = BATCH ? P.off_a : hot_off_a;
+    const int h_off_dt = BATCH ? P.off_dt : hot_off_dt, h_off_U = BATCH ? P.off_U : hot_off_U;
     if constexpr (DIAG) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         QC_STAMP(Pk, 0, 0, 10);                   // kernel arguments in the scalar cache
@@ -322,12 +333,12 @@ __global__ __launch_bounds__(64) void qc_mfma16_pade4_hess_anti_kernel(const QcP
     __shared__ double tscr[(kHM + 1) * 16 * 17];
     __shared__ double tsave[kHM * 256];           // the stage-A tiles T_k, parked for the (a, a) sums (registers: see below)
     const int lane = threadIdx.x;
-    const int m = P.m;
+    const int m = BATCH ? P.m : hot_m;
     const int g = lane >> 4, j = lane & 15, jj = j & 7;
     const bool left = j < 8;
-    const bool ft = P.off_dt >= 0;
+    const bool ft = h_off_dt >= 0;
     const double c1 = P.c[1], c2 = P.c[2];
-    const double* __restrict__ GxA = P.Gx;
+    const double* __restrict__ GxA = BATCH ? P.Gx : hot_Gx;
     const v4d zero = {0.0, 0.0, 0.0, 0.0};
 
     // The generator images depend on nothing but the kernel arguments: requested before any address of the interval is computed
@@ -340,26 +351,25 @@ __global__ __launch_bounds__(64) void qc_mfma16_pade4_hess_anti_kernel(const QcP
         gA[u] = load_img(GxA, m > 0 ? k + 1 : 0, lane);
     }
     int vb = blockIdx.x;
-    if (vb >= P.n_int) return;
+    if (vb >= h_n_int) return;
     do {
-        const int b = qc_xcd_remap(vb, P.n_int);
-        const long long t = P.t_begin + b;
-        const double* __restrict__ z0 = Z + t * (long long)P.zdim;
-        const double* __restrict__ z1 = z0 + P.zdim;
-        const double* __restrict__ mu = Mu + t * P.F_stride + P.F_off;
+        const int b = qc_xcd_remap(vb, h_n_int);
+        const double* __restrict__ z0 = BATCH ? Z + (P.t_begin + b) * (long long)h_zdim : hot_Zt + (long long)b * h_zdim;
+        const double* __restrict__ z1 = z0 + h_zdim;
+        const double* __restrict__ mu = BATCH ? Mu + (P.t_begin + b) * P.F_stride + P.F_off : hot_mu0 + (long long)b * hot_f_stride;
         double* __restrict__ Hb = H + (size_t)b * P.H_stride + P.H_off;
 
         // ---- loads: one batch, amplitudes and images (-> G) first (see the general kernel) -------------------------------
         const int nc = KET ? P.nc : 8, jc = (!KET || jj < nc) ? jj : 0;
         const int nr = KET ? P.n : 16;
-        const double av = load_amp_lanes(z0, P.off_a, m, lane);
-        const double h = ft ? load_uniform(z0 + P.off_dt) : opaque_scalar(P.dt_fixed);
+        const double av = load_amp_lanes(z0, h_off_a, m, lane);
+        const double h = ft ? load_uniform(z0 + h_off_dt) : opaque_scalar(P.dt_fixed);
         QC_STAMP(P, b, lane, 11);                 // first two loads requested
         v4d Ga = G0;
         v4d u0, u1, mraw;
         if constexpr (!KET) {
-            u0 = load_col16_T(z0 + P.off_U + jc * 16, g);     // 2 requests of 16 bytes per lane instead of 4 of 8 (qc_mfma_common.h)
-            u1 = load_col16_T(z1 + P.off_U + jc * 16, g);
+            u0 = load_col16_T(z0 + h_off_U + jc * 16, g);     // 2 requests of 16 bytes per lane instead of 4 of 8 (qc_mfma_common.h)
+            u1 = load_col16_T(z1 + h_off_U + jc * 16, g);
             mraw = load_col16_T(mu + jc * 16, g);
         } else {
 #pragma unroll
@@ -378,6 +388,7 @@ __global__ __launch_bounds__(64) void qc_mfma16_pade4_hess_anti_kernel(const QcP
             for (int d = 0; d < 2; ++d) mud[d] = mu[P.drow[d] + (lane < P.ddim_i[d] ? lane : 0)];
         }
         QC_STAMP(P, b, lane, 1);                  // every load of the interval requested
+        touch.consume();                          // (the argument block's lines: the one scalar wait, behind every request)
         if constexpr (DIAG) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             QC_STAMP(P, b, lane, 2);              // ... and back
@@ -606,7 +617,7 @@ __global__ __launch_bounds__(64) void qc_mfma16_pade4_hess_anti_kernel(const QcP
             QC_STAMP_FLUSH(P, b, lane, 0, 11);
         }
         __builtin_amdgcn_wave_barrier();   // the scratch rows are rewritten by the next interval
-    } while (!ONCE && (vb += gridDim.x) < P.n_int);
+    } while (!ONCE && (vb += gridDim.x) < h_n_int);
 }
 
 }  // namespace
@@ -623,9 +634,9 @@ hipError_t qc_launch_mfma16_hess_batch(const QcParams& P0, const QcParams* dPb, 
 #define QC_B(HM_)                                                                                                                      \
     do {                                                                                                                            \
         if (P0.antisym && (P0.nc != 8 || P0.n != 16))                                                                               \
-            hipLaunchKernelGGL((qc_mfma16_pade4_hess_anti_kernel<HM_, true, true, false>), dim3(grid, count), dim3(64), 0, st, P0, dZ, dMu, dH, dPb); \
+            hipLaunchKernelGGL((qc_mfma16_pade4_hess_anti_kernel<HM_, true, true, false>), dim3(grid, count), dim3(64), 0, st, QC_HESS_HOT_ARGS(P0), P0, dZ, dMu, dH, dPb); \
         else if (P0.antisym)                                                                                                        \
-            hipLaunchKernelGGL((qc_mfma16_pade4_hess_anti_kernel<HM_, false, true, false>), dim3(grid, count), dim3(64), 0, st, P0, dZ, dMu, dH, dPb); \
+            hipLaunchKernelGGL((qc_mfma16_pade4_hess_anti_kernel<HM_, false, true, false>), dim3(grid, count), dim3(64), 0, st, QC_HESS_HOT_ARGS(P0), P0, dZ, dMu, dH, dPb); \
         else if (P0.nc != 8 || P0.n != 16)                                                                                               \
             hipLaunchKernelGGL((qc_mfma16_pade4_hess_kernel<HM_, true, true>), dim3(grid, count), dim3(64), 0, st, P0, dZ, dMu, dH, dPb); \
         else                                                                                                                        \
@@ -642,12 +653,12 @@ static void launch_hess16(const QcParams& P, const double* dZ, const double* dMu
     if (P.antisym) {
         if constexpr (HM == 6 && !KET) {
             if (once && P.stamps != nullptr) {   // diagnostic timeline (QC_STAMPS=1)
-                hipLaunchKernelGGL((qc_mfma16_pade4_hess_anti_kernel<HM, KET, false, true, true>), dim3(grid), dim3(64), 0, st, P, dZ, dMu, dH, nullptr);
+                hipLaunchKernelGGL((qc_mfma16_pade4_hess_anti_kernel<HM, KET, false, true, true>), dim3(grid), dim3(64), 0, st, QC_HESS_HOT_ARGS(P), P, dZ, dMu, dH, nullptr);
                 return;
             }
         }
-        if (once) hipLaunchKernelGGL((qc_mfma16_pade4_hess_anti_kernel<HM, KET, false, true>), dim3(grid), dim3(64), 0, st, P, dZ, dMu, dH, nullptr);
-        else hipLaunchKernelGGL((qc_mfma16_pade4_hess_anti_kernel<HM, KET, false, false>), dim3(grid), dim3(64), 0, st, P, dZ, dMu, dH, nullptr);
+        if (once) hipLaunchKernelGGL((qc_mfma16_pade4_hess_anti_kernel<HM, KET, false, true>), dim3(grid), dim3(64), 0, st, QC_HESS_HOT_ARGS(P), P, dZ, dMu, dH, nullptr);
+        else hipLaunchKernelGGL((qc_mfma16_pade4_hess_anti_kernel<HM, KET, false, false>), dim3(grid), dim3(64), 0, st, QC_HESS_HOT_ARGS(P), P, dZ, dMu, dH, nullptr);
         return;
     }
     if (once) hipLaunchKernelGGL((qc_mfma16_pade4_hess_kernel<HM, KET, false, true>), dim3(grid), dim3(64), 0, st, P, dZ, dMu, dH, nullptr);
