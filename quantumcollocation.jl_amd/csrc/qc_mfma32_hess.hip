@@ -126,10 +126,16 @@ __device__ inline void store_T(double* __restrict__ p, const v4d& x, int J, int 
 // ANTI: every generator is exactly antisymmetric (QcParams.antisym): the B-layout image tile (K, J) is minus the A-layout
 // tile (J, K), so only the A-layout images are fetched (half of the workgroup's one-time 128 KB image load)
 template <bool DIAG, bool ANTI, bool FULL = false>
-__global__ __launch_bounds__(kHThreads32, 1) void qc_mfma32_pade4_hess_kernel(const QcParams Pk, const int per_wg, const double* __restrict__ Z,
-                                                                              const double* __restrict__ Mu, double* __restrict__ H) {
+__global__ __launch_bounds__(kHThreads32, 1) void qc_mfma32_pade4_hess_kernel(const double* __restrict__ hot_Gx, const double* __restrict__ hot_Zt,
+                                                                              const double* __restrict__ hot_mu0, const int hot_n_int, const int per_wg,
+                                                                              const int hot_zdim, const int hot_m, const int hot_off_a, const int hot_off_dt,
+                                                                              const int hot_off_U, const int hot_f_stride, const QcParams Pk,
+                                                                              double* __restrict__ H) {
+    // (the leading arguments are preloaded into scalar registers at wave launch -- -amdgpu-kernarg-preload-count --: every load
+    //  request of phase 0 depends on them only; hot_Zt / hot_mu0 = the handle's first knot / first interval's multipliers)
     const QcParams& P = Pk;
-    qc_kernarg_touch<sizeof(QcParams) + 64>();   // one batch of scalar-cache misses instead of one per use (qc_internal.h)
+    QcKernargTouch<sizeof(QcParams) + 96> touch;   // one batch of scalar-cache misses instead of one per use (qc_internal.h):
+    touch.request();                               // requested here, waited for behind the drive images' requests
     __shared__ __attribute__((aligned(16))) double GL[8 * 256];                 // G: tiles 0-3 A-layout (2I+K), 4-7 B-layout (4+2K+J)
     __shared__ __attribute__((aligned(16))) double ML[2 * 256];                 // M tiles
     __shared__ __attribute__((aligned(16))) double DL[2 * 256];                 // D = U_t+1 - U_t tiles
@@ -142,11 +148,11 @@ __global__ __launch_bounds__(kHThreads32, 1) void qc_mfma32_pade4_hess_kernel(co
     const int tid = threadIdx.x;
     const int lane0 = tid & 63;
     const int w0 = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int m0 = P.m;
-    const bool ft = P.off_dt >= 0;
+    const int m0 = hot_m;
+    const bool ft = hot_off_dt >= 0;
     const bool drive0 = w0 < m0;
-    const double* __restrict__ GxA = P.Gx;                              // A-layout images [mat][2I+K]
-    const double* __restrict__ GxB = P.Gx + (size_t)(m0 + 1) * 1024;    // B-layout images [mat][2K+J]
+    const double* __restrict__ GxA = hot_Gx;                              // A-layout images [mat][2I+K]
+    const double* __restrict__ GxB = hot_Gx + (size_t)(m0 + 1) * 1024;    // B-layout images [mat][2K+J]
 
     // The drive's images stay in registers for every interval of this workgroup: they are the bulk of the L2 traffic
     // (16 KB per wave), and with one interval per workgroup the kernel was L2-bandwidth-bound in its load phase.
@@ -162,12 +168,13 @@ __global__ __launch_bounds__(kHThreads32, 1) void qc_mfma32_pade4_hess_kernel(co
             GkB[0] = -GkA[0]; GkB[1] = -GkA[2]; GkB[2] = -GkA[1]; GkB[3] = -GkA[3];
         }
     }
-    const int n_wg = (P.n_int + per_wg - 1) / per_wg;
+    touch.consume();
+    const int n_wg = (hot_n_int + per_wg - 1) / per_wg;
     const int b0 = qc_xcd_remap((int)blockIdx.x, n_wg) * per_wg;
 
     for (int it = 0; it < per_wg; ++it) {
         const int b = b0 + it;
-        if (b >= P.n_int) break;
+        if (b >= hot_n_int) break;
         // An opaque copy of the lane index per interval: what derives from it (LDS and store offsets) is recomputed instead of
         // being hoisted out of the interval loop and held through the products (251 -> 238 registers).
         int lane = lane0;
@@ -180,20 +187,23 @@ __global__ __launch_bounds__(kHThreads32, 1) void qc_mfma32_pade4_hess_kernel(co
         // they outnumber the scalar registers and are spilled to vector-register lanes (282 v_readlane / 163 v_writelane per
         // interval, vector instructions all).  Read through an opaque pointer they are re-read where used (scalar-cache hits).
         typedef const __attribute__((address_space(4))) QcParams* kparams_t;
-        kparams_t Pq = (kparams_t)__builtin_amdgcn_kernarg_segment_ptr();     // (the parameter block is the first argument)
+        // (the parameter block follows the preloaded arguments: 3 pointers + 8 ints = 56 bytes, 8-byte aligned)
+        constexpr int kParamsOffset = 3 * 8 + 8 * 4;
+        static_assert(kParamsOffset % 8 == 0, "QcParams is 8-byte aligned in the kernel-argument segment");
+        kparams_t Pq = (kparams_t)((const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() + kParamsOffset);
         asm volatile("" : "+s"(Pq));
         const auto& P = *Pq;
-        const int m = P.m;                            // (with it the drive-count conditions: sixteen 64-bit masks when hoisted)
+        int m = hot_m;                                // (an opaque copy: with it the drive-count conditions -- sixteen 64-bit masks when hoisted)
+        asm volatile("" : "+s"(m));
         const bool drive = w < m;
         const double c1 = P.c[1], c2 = P.c[2];
-        const long long t = P.t_begin + b;
-        const double* __restrict__ z0 = Z + t * (long long)P.zdim;
-        const double* __restrict__ z1 = z0 + P.zdim;
-        const double* __restrict__ mu = Mu + t * P.F_stride + P.F_off;
+        const double* __restrict__ z0 = hot_Zt + (long long)b * hot_zdim;
+        const double* __restrict__ z1 = z0 + hot_zdim;
+        const double* __restrict__ mu = hot_mu0 + (long long)b * hot_f_stride;
         double* __restrict__ Hb = H + (size_t)b * P.H_stride + P.H_off;
         // (the fixed timestep as an opaque value: qc_mfma_common.h -- as a second load the compiler merges the two arms into one
         //  FLAT load, fenced by vmcnt(0))
-        const double h = ft ? z0[P.off_dt] : opaque_scalar(P.dt_fixed);   // requested with the other loads; first used behind the barrier
+        const double h = ft ? z0[hot_off_dt] : opaque_scalar(P.dt_fixed);   // requested with the other loads; first used behind the barrier
         // (Timestep and amplitudes by one vector load read out with v_readlane, as in qc_mfma32_kernels.hip, where the scalar
         //  loads each cost a round trip in front of the next batch of requests: 21.76 against 21.43 us here, same run.  The eight
         //  waves of a workgroup read the same words: one scalar-cache miss, seven hits.)
@@ -218,7 +228,7 @@ __global__ __launch_bounds__(kHThreads32, 1) void qc_mfma32_pade4_hess_kernel(co
 #pragma unroll
             for (int u = 0; u <= kHMax32; ++u) img[u] = ab[(size_t)(u <= m ? u : 0) * 512];
 #pragma unroll
-            for (int u = 0; u < kHMax32; ++u) ak[u] = z0[P.off_a + (u < m ? u : 0)];
+            for (int u = 0; u < kHMax32; ++u) ak[u] = z0[hot_off_a + (u < m ? u : 0)];
             if (w >= 4) {
                 // K < 16 kets: tile columns >= nc re-read column 0; the multipliers there are zeroed (the scalar blocks sum over
                 // whole tiles) and nothing of them is stored.  The kernel is MFMA-bound: run-time masks cost nothing here.
@@ -236,8 +246,8 @@ __global__ __launch_bounds__(kHThreads32, 1) void qc_mfma32_pade4_hess_kernel(co
                     const v4d mraw = ld4(mu);
                     put_tile(ML, I, lane, (FULL || j < P.nc) ? mraw : v4d{0.0, 0.0, 0.0, 0.0});
                 } else {
-                    const v4d u0 = ld4(z0 + P.off_U);
-                    const v4d u1 = ld4(z1 + P.off_U);
+                    const v4d u0 = ld4(z0 + hot_off_U);
+                    const v4d u1 = ld4(z1 + hot_off_U);
                     put_tile(SL, I, lane, u1 + u0);
                     put_tile(DL, I, lane, u1 - u0);
                 }
@@ -437,10 +447,10 @@ hipError_t qc_launch_mfma32_hess(const QcParams& P, const double* dZ, const doub
     // one workgroup per CU (200 VGPRs, 121 KB LDS); each takes a contiguous run of intervals and keeps its drive images
     const int per_wg = (P.n_int + kHCUs - 1) / kHCUs;
     const int grid = (P.n_int + per_wg - 1) / per_wg;
-    if (P.stamps != nullptr && P.antisym && P.n == 32 && P.nc == 16) hipLaunchKernelGGL((qc_mfma32_pade4_hess_kernel<true, true, true>), dim3(grid), dim3(kHThreads32), 0, st, P, per_wg, dZ, dMu, dH);
-    else if (P.stamps != nullptr) hipLaunchKernelGGL((qc_mfma32_pade4_hess_kernel<true, false>), dim3(grid), dim3(kHThreads32), 0, st, P, per_wg, dZ, dMu, dH);
-    else if (P.antisym && P.n == 32 && P.nc == 16) hipLaunchKernelGGL((qc_mfma32_pade4_hess_kernel<false, true, true>), dim3(grid), dim3(kHThreads32), 0, st, P, per_wg, dZ, dMu, dH);
-    else if (P.antisym) hipLaunchKernelGGL((qc_mfma32_pade4_hess_kernel<false, true>), dim3(grid), dim3(kHThreads32), 0, st, P, per_wg, dZ, dMu, dH);
-    else hipLaunchKernelGGL((qc_mfma32_pade4_hess_kernel<false, false>), dim3(grid), dim3(kHThreads32), 0, st, P, per_wg, dZ, dMu, dH);
+    if (P.stamps != nullptr && P.antisym && P.n == 32 && P.nc == 16) hipLaunchKernelGGL((qc_mfma32_pade4_hess_kernel<true, true, true>), dim3(grid), dim3(kHThreads32), 0, st, P.Gx, dZ + P.t_begin * (long long)P.zdim, dMu + P.t_begin * P.F_stride + P.F_off, P.n_int, per_wg, P.zdim, P.m, P.off_a, P.off_dt, P.off_U, (int)P.F_stride, P, dH);
+    else if (P.stamps != nullptr) hipLaunchKernelGGL((qc_mfma32_pade4_hess_kernel<true, false>), dim3(grid), dim3(kHThreads32), 0, st, P.Gx, dZ + P.t_begin * (long long)P.zdim, dMu + P.t_begin * P.F_stride + P.F_off, P.n_int, per_wg, P.zdim, P.m, P.off_a, P.off_dt, P.off_U, (int)P.F_stride, P, dH);
+    else if (P.antisym && P.n == 32 && P.nc == 16) hipLaunchKernelGGL((qc_mfma32_pade4_hess_kernel<false, true, true>), dim3(grid), dim3(kHThreads32), 0, st, P.Gx, dZ + P.t_begin * (long long)P.zdim, dMu + P.t_begin * P.F_stride + P.F_off, P.n_int, per_wg, P.zdim, P.m, P.off_a, P.off_dt, P.off_U, (int)P.F_stride, P, dH);
+    else if (P.antisym) hipLaunchKernelGGL((qc_mfma32_pade4_hess_kernel<false, true>), dim3(grid), dim3(kHThreads32), 0, st, P.Gx, dZ + P.t_begin * (long long)P.zdim, dMu + P.t_begin * P.F_stride + P.F_off, P.n_int, per_wg, P.zdim, P.m, P.off_a, P.off_dt, P.off_U, (int)P.F_stride, P, dH);
+    else hipLaunchKernelGGL((qc_mfma32_pade4_hess_kernel<false, false>), dim3(grid), dim3(kHThreads32), 0, st, P.Gx, dZ + P.t_begin * (long long)P.zdim, dMu + P.t_begin * P.F_stride + P.F_off, P.n_int, per_wg, P.zdim, P.m, P.off_a, P.off_dt, P.off_U, (int)P.F_stride, P, dH);
     return hipGetLastError();
 }

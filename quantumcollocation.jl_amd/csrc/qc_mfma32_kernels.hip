@@ -121,23 +121,27 @@ __device__ inline void store_T32_masked(double* __restrict__ p, const v4d& x, in
 // ONCE: the grid covers every pair (always, below 2 x kMaxGrid32 intervals): no persistent loop, so nothing is hoisted in front
 // of the first load request (with the loop: ~280 scalar instructions and six dependent batches of argument reads, 1.45 us).
 template <bool JAC, bool DIAG, bool KET, bool SINGLE = false, bool ONCE = false>
-__global__ __launch_bounds__(kThreads32, 2) void qc_mfma32_pade4_kernel(const QcParams P, const double* __restrict__ Z,
-                                                                       double* __restrict__ F, double* __restrict__ J) {
+__global__ __launch_bounds__(kThreads32, 2) void qc_mfma32_pade4_kernel(const double* __restrict__ hot_Gx, const double* __restrict__ hot_Zt,
+                                                                       int hot_n_int, int hot_zdim, int hot_off_a, int hot_off_dt, int hot_m,
+                                                                       const QcParams P, double* __restrict__ F, double* __restrict__ J) {
+    // (the leading arguments are preloaded into scalar registers at wave launch -- this file is compiled with
+    //  -amdgpu-kernarg-preload-count --: the image and amplitude requests depend on nothing else; hot_Zt = the handle's first knot)
     unsigned long long t_entry = 0;
     if constexpr (DIAG) t_entry = __builtin_amdgcn_s_memrealtime();
-    qc_kernarg_touch<sizeof(QcParams) + 64>();   // one batch of scalar-cache misses instead of one per use (qc_internal.h)
+    QcKernargTouch<sizeof(QcParams) + 96> touch;   // one batch of scalar-cache misses instead of one per use (qc_internal.h):
+    touch.request();                               // requested here, waited for behind the image requests
     __shared__ __attribute__((aligned(16))) double GaL[2 * 4 * 256];                    // G tiles of the two intervals
     __shared__ __attribute__((aligned(16))) double ImgL[(kMU32 + 1) * 4 * 256];        // image tile t of matrix k at (k * 4 + t) * 256
     __shared__ double DerL[2 * 2 * kDF32 * 64];                                          // derivative-integrator data parked until the end
     const int tid = threadIdx.x;
     const int lane0 = tid & 63;
     const int w0 = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int m = P.m;
+    const int m = hot_m;
     const int mL = m < kMU32 ? m : kMU32;
-    const bool ft = P.off_dt >= 0;
+    const bool ft = hot_off_dt >= 0;
     const double c1 = P.c[1], c2 = P.c[2];
-    const double* __restrict__ Gx = P.Gx;
-    const int n_wg = SINGLE ? P.n_int : (P.n_int + 1) / 2;
+    const double* __restrict__ Gx = hot_Gx;
+    const int n_wg = SINGLE ? hot_n_int : (hot_n_int + 1) / 2;
 
     for (int vb = blockIdx.x; vb < n_wg; vb += gridDim.x) {
         // Opaque per-pass copies of the lane and wave indices: what derives from them (LDS and store offsets, role flags) is
@@ -155,13 +159,10 @@ __global__ __launch_bounds__(kThreads32, 2) void qc_mfma32_pade4_kernel(const Qc
         const int jc = (!KET || j < nc) ? j : 0;
         const v4d IdB = identity_B(g, j);
         const int b_raw = SINGLE ? qc_xcd_remap(vb, n_wg) : 2 * qc_xcd_remap(vb, n_wg) + slot;
-        const bool active = b_raw < P.n_int;                  // an odd interval count leaves the last slot empty;
-        const int b = active ? b_raw : P.n_int - 1;           // its waves still load images and take part in the barriers
-        const long long t = P.t_begin + b;
-        const double* __restrict__ z0 = Z + t * (long long)P.zdim;
-        const double* __restrict__ z1 = z0 + P.zdim;
-        double* __restrict__ Jb = JAC ? J + (size_t)b * P.J_stride + P.J_off : nullptr;
-        double* __restrict__ Fb = F ? F + (size_t)b * P.F_stride + P.F_off : nullptr;
+        const bool active = b_raw < hot_n_int;                // an odd interval count leaves the last slot empty;
+        const int b = active ? b_raw : hot_n_int - 1;         // its waves still load images and take part in the barriers
+        const double* __restrict__ z0 = hot_Zt + (long long)b * hot_zdim;
+        const double* __restrict__ z1 = z0 + hot_zdim;
         QC_STAMP_DECL;
         QC_STAMP(P, b, lane, 0);
 
@@ -177,9 +178,13 @@ __global__ __launch_bounds__(kThreads32, 2) void qc_mfma32_pade4_kernel(const Qc
         // out lane by lane behind barrier 1.  As scalar loads they were a trap twice over: every scalar wait that follows one
         // -- a kernel argument read a little later -- waits for its round trip through L2 as well (shared counter, out-of-order
         // return), and without the persistent loop the compiler put a wait behind EACH of the nine.
-        const int ia = lane < mL ? P.off_a + lane : (ft ? P.off_dt : 0);
+        const int ia = lane < mL ? hot_off_a + lane : (ft ? hot_off_dt : 0);
         const double av = z0[ia];
         asm volatile("" ::: "memory");   // no load sinks below this line, no LDS store rises above it
+        touch.consume();                 // (the argument block's lines: the scalar wait, behind every request of the phase)
+        // (output addresses: they depend on fields of the argument block, i.e. on a scalar wait -- behind the requests as well)
+        double* __restrict__ Jb = JAC ? J + (size_t)b * P.J_stride + P.J_off : nullptr;
+        double* __restrict__ Fb = F ? F + (size_t)b * P.F_stride + P.F_off : nullptr;
 #ifdef QC_STAMP_PROLOGUE
         QC_STAMP(P, b, lane, 5);         // every load requested
 #if QC_STAMP_PROLOGUE != 2
@@ -468,7 +473,8 @@ hipError_t qc_launch_mfma32_F_jac(const QcParams& P, const double* dZ, double* d
     const bool diag = P.stamps != nullptr || P.dbg_skip != 0;
     const bool ket = P.nc != 16 || P.n != 32;
 #define QC_LAUNCH32(JAC_, DIAG_, KET_, SINGLE_, ONCE_, GRID_) \
-    hipLaunchKernelGGL((qc_mfma32_pade4_kernel<JAC_, DIAG_, KET_, SINGLE_, ONCE_>), dim3(GRID_), dim3(kThreads32), 0, st, P, dZ, dF, dJ)
+    hipLaunchKernelGGL((qc_mfma32_pade4_kernel<JAC_, DIAG_, KET_, SINGLE_, ONCE_>), dim3(GRID_), dim3(kThreads32), 0, st, P.Gx,                 \
+                       dZ + P.t_begin * (long long)P.zdim, P.n_int, P.zdim, P.off_a, P.off_dt, P.m, P, dF, dJ)
     if (dJ && !diag && P.n_int <= 256) {   // fewer intervals than CUs: one interval per workgroup, all eight waves on it
         if (ket) QC_LAUNCH32(true, false, true, true, true, P.n_int);
         else QC_LAUNCH32(true, false, false, true, true, P.n_int);
