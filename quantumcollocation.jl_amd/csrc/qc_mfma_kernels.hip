@@ -298,7 +298,10 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
             // and the masked ones it measured slower (T = 2000: 17.7 vs 17.15 us, config 2: 5.8 vs 5.2-5.5 us).  With the early copies
             // this wave drains a microsecond before the compute wave; giving it the residual / d/dh block (12 MFMAs) in return made
             // the launch slower (9.45 vs 9.05 us): its MFMAs share a SIMD with another workgroup's compute wave.
-            constexpr int kEarly = (!KET && ONCE) ? 4 : 0;
+#ifndef QC_EARLY_COPIES
+#define QC_EARLY_COPIES 4
+#endif
+            constexpr int kEarly = (!KET && ONCE) ? QC_EARLY_COPIES : 0;
             if constexpr (kEarly > 0) {
                 if (!skip) {
 #pragma unroll
