@@ -86,17 +86,20 @@ class NodeBarrier:
         local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
         ok = local_world == world and os.path.isdir("/dev/shm") and os.environ.get("QC_BENCH_BARRIER", "shm") != "dist"
         self.path = f"/dev/shm/qcolloc_bench_{os.getuid()}_{os.environ.get('MASTER_PORT', '0')}"
-        try:
-            if ok and rank == 0:
+        if ok and rank == 0:
+            try:
                 with open(self.path, "wb") as f:
                     f.write(bytes(64 * world))
-            dist.barrier()                                   # the page exists (or rank 0 failed: the open below fails everywhere)
-            if ok:
+            except OSError:
+                ok = False
+        dist.barrier()                                       # (every rank, whatever happened above) the page exists, or does not
+        if ok:
+            try:
                 self._f = open(self.path, "r+b")
                 self._mm = mmap.mmap(self._f.fileno(), 64 * world)
                 self.slots = np.frombuffer(self._mm, dtype=np.int64).reshape(world, 8)
-        except OSError:
-            self.slots = None
+            except (OSError, ValueError):
+                self.slots = None
         flag = torch.tensor([1 if self.slots is not None else 0], dtype=torch.int32,
                             device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)          # every rank or none
