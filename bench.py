@@ -458,7 +458,7 @@ def main():
                 # The reference's consumer is ONE process: rank 0 builds the in-library multi-device handle
                 # (qc_create_multi over all N GPUs) and times the same host-buffer calls on the whole T = 1000 N
                 # trajectory while the other ranks wait at the barrier; N PCIe links work in parallel.
-                barrier()
+                dist.barrier()     # (the collective, not the spinning page of the timed region: the other ranks wait here for seconds)
                 if rank == 0:
                     try:   # (whatever happens here, rank 0 reaches the barrier the other ranks are waiting at)
                         devs = list(range(world)) if backend == "nccl" else [r % torch.cuda.device_count() for r in range(world)]
@@ -469,7 +469,7 @@ def main():
                         md.close()
                     except Exception as exc:   # noqa: BLE001
                         host_rec = {"error": repr(exc)[:300]}
-                barrier()
+                dist.barrier()
         except Exception as exc:   # noqa: BLE001  (must not lose the metric line)
             host_rec = {"error": repr(exc)[:300]}
     c5 = None
