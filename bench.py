@@ -114,8 +114,13 @@ class NodeBarrier:
         self.gen += 1
         self.slots[self.rank, 0] = self.gen
         col = self.slots[:, 0]
+        spins, t_start = 0, None
         while int(col.min()) < self.gen:
-            pass
+            spins += 1
+            if (spins & 0xFFFF) == 0:                        # a rank that died must not leave the others spinning for ever
+                t_start = t_start or time.perf_counter()
+                if time.perf_counter() - t_start > 300.0:
+                    raise RuntimeError(f"bench.py: rank {self.rank} waited 300 s at the timing barrier (generation {self.gen}): {col.tolist()}")
 
     def close(self):
         if self.slots is not None:
