@@ -133,7 +133,6 @@ __global__ __launch_bounds__(kHThreads32, 1) void qc_mfma32_pade4_hess_kernel(co
                                                                               double* __restrict__ H) {
     // (the leading arguments are preloaded into scalar registers at wave launch -- -amdgpu-kernarg-preload-count --: every load
     //  request of phase 0 depends on them only; hot_Zt / hot_mu0 = the handle's first knot / first interval's multipliers)
-    const QcParams& P = Pk;
     QcKernargTouch<sizeof(QcParams) + 96> touch;   // one batch of scalar-cache misses instead of one per use (qc_internal.h):
     touch.request();                               // requested here, waited for behind the drive images' requests
     __shared__ __attribute__((aligned(16))) double GL[8 * 256];                 // G: tiles 0-3 A-layout (2I+K), 4-7 B-layout (4+2K+J)
