@@ -182,7 +182,7 @@ def config5_record(qc, dev_index, steps=300):
     """BASELINE config 5 (4-qubit QFT, T = 500, the 2N = 32 MFMA path) on the device: north_star asks for the MFMA
     utilisation of the large-n case.  FLOP counts are the kernels' own MFMA counts as the SQ_INSTS_VALU_MFMA_F64 counter
     reports them (576 / 560 v_mfma_f64_16x16x4_f64 per interval for F + dF / mu_d2F at m = 8, 2048 FLOP each:
-    profiles/r02_mfma_util.json, which also holds the counter-based MfmaUtil: 16.5 % / 23.5 %)."""
+    profiles/r02_mfma_util.json, which also holds the counter-based MfmaUtil: 19.1 % / 24.9 %)."""
     inp = qc.config_inputs(5)
     dyn = qc.QuantumDynamics(inp.integrators, inp.traj, device=dev_index)
     dev = torch.device("cuda", dev_index)
@@ -221,7 +221,7 @@ def config5_record(qc, dev_index, steps=300):
            "F_dF_mfma_frac": 576 * n_int * 2048 / (jac_us * 1e-6) / 1e12 / peak_tf,
            "hess_us": hess_us, "hess_hbm_frac": hess_bytes / (hess_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
            "hess_mfma_frac": 560 * n_int * 2048 / (hess_us * 1e-6) / 1e12 / peak_tf,
-           "mfma_peak_TFLOPs": peak_tf, "MfmaUtil_counter_percent": {"F_dF": 16.5, "hess": 23.5, "source": "profiles/r02_mfma_util.json"}}
+           "mfma_peak_TFLOPs": peak_tf, "MfmaUtil_counter_percent": {"F_dF": 19.1, "hess": 24.9, "source": "profiles/r02_mfma_util.json"}}
     dyn.close()
     return rec
 

@@ -9,7 +9,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for cfg in 3 5; do
   rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_F64 SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/cfg$cfg -- \
-      python3 $R/bench.py --config $cfg --steps 100 --warmup 10 --cpu-seconds 0 --no-host-visible --no-config5 > $OUT/bench_cfg$cfg.json 2> $OUT/cfg$cfg.log
+      python3 $R/bench.py --config $cfg --steps 100 --warmup 10 --cpu-seconds 0 --prewarm-seconds 0 --no-host-visible --no-config5 > $OUT/bench_cfg$cfg.json 2> $OUT/cfg$cfg.log
 done
 python3 - <<PY
 import csv, glob, json, collections
@@ -19,7 +19,7 @@ for cfg in (3, 5):
         acc = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
             if "qc_mfma" in r["Kernel_Name"]:
-                acc[r["Kernel_Name"].split("(")[1] if False else r["Kernel_Name"][:r["Kernel_Name"].find("(QcParams")]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                acc[r["Kernel_Name"][:r["Kernel_Name"].rfind(">(") + 1]][r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, cs in acc.items():
             d = {c: sum(v) / len(v) for c, v in cs.items()}
             d["launches"] = len(next(iter(cs.values())))
