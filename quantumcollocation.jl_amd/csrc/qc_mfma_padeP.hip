@@ -53,11 +53,15 @@ __device__ inline void wave_lds_sync() {
 __host__ __device__ inline int lds_doubles_padeP(int p) { return 1024 + 16 + 256 * p + 256 * ((p + 1) / 2); }
 
 template <bool JAC>
-__global__ __launch_bounds__(kPThreads) void qc_mfma16_padeP_kernel(const QcParams P, const double* __restrict__ Z,
-                                                                   double* __restrict__ F, double* __restrict__ J) {
-    qc_kernarg_touch<sizeof(QcParams) + 64>();   // one batch of scalar-cache misses instead of one per use (qc_internal.h)
+__global__ __launch_bounds__(kPThreads) void qc_mfma16_padeP_kernel(const double* __restrict__ hot_Gx, const double* __restrict__ hot_Zt,
+                                                                   int hot_n_int, int hot_zdim, int hot_off_a, int hot_off_dt, int hot_m, int hot_p, int hot_off_U,
+                                                                   const QcParams P, double* __restrict__ F, double* __restrict__ J) {
+    // (the leading arguments are preloaded into scalar registers at wave launch -- -amdgpu-kernarg-preload-count, qc_mfma_kernels.hip --:
+    //  the first load requests depend on them only; hot_Zt = the handle's first knot)
+    QcKernargTouch<sizeof(QcParams) + 96> touch;   // one batch of scalar-cache misses instead of one per use (qc_internal.h)
+    touch.request();
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    const int p = P.p, m = P.m;
+    const int p = hot_p, m = hot_m;
     double* __restrict__ PartL = sm;
     double* __restrict__ ChL = sm + 1024;
     int* FlagL = reinterpret_cast<int*>(sm + 1039);                     // hand-off flag (last slot of the coefficient block)
@@ -69,25 +73,22 @@ __global__ __launch_bounds__(kPThreads) void qc_mfma16_padeP_kernel(const QcPara
     const int g = lane >> 4, j = lane & 15, jj = j & 7;
     const bool left = j < 8;
     const int nc = P.nc, nr = P.n;
-    const bool ft = P.off_dt >= 0;
-    const double* __restrict__ Gx = P.Gx;
+    const bool ft = hot_off_dt >= 0;
+    const double* __restrict__ Gx = hot_Gx;
     const v4d IdB = identity_B(g, j);
     const v4d zero = {0.0, 0.0, 0.0, 0.0};
 
-    const int b = qc_xcd_remap(blockIdx.x, P.n_int);
-    const long long t = P.t_begin + b;
-    const double* __restrict__ z0 = Z + t * (long long)P.zdim;
-    const double* __restrict__ z1 = z0 + P.zdim;
-    double* __restrict__ Jb = JAC ? J + (size_t)b * P.J_stride + P.J_off : nullptr;
-    double* __restrict__ Fb = F ? F + (size_t)b * P.F_stride + P.F_off : nullptr;
-    const double h = ft ? z0[P.off_dt] : opaque_scalar(P.dt_fixed);
+    const int b = qc_xcd_remap(blockIdx.x, hot_n_int);
+    const double* __restrict__ z0 = hot_Zt + (long long)b * hot_zdim;
+    const double* __restrict__ z1 = z0 + hot_zdim;
+    const double h = ft ? z0[hot_off_dt] : opaque_scalar(P.dt_fixed);
 
     // ---- all waves: partial sums of G = G_0 + sum_k a_k G_k (wave w takes k = w, w+4, ...), two images per round trip ----
     v4d u0 = zero, u1 = zero;
     if (w == 1) {   // state tiles [U | U]: lane (g, j) reg r = U[4r+g][j & 7]; columns >= nc and rows >= nr are zero
         const bool cok = jj < nc;
-        const double* p0 = z0 + P.off_U + (cok ? jj : 0) * nr;
-        const double* p1 = z1 + P.off_U + (cok ? jj : 0) * nr;
+        const double* p0 = z0 + hot_off_U + (cok ? jj : 0) * nr;
+        const double* p1 = z1 + hot_off_U + (cok ? jj : 0) * nr;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const bool ok = cok && 4 * r + g < nr;
@@ -95,22 +96,25 @@ __global__ __launch_bounds__(kPThreads) void qc_mfma16_padeP_kernel(const QcPara
             u1[r] = ok ? p1[4 * r + g] : 0.0;
         }
     }
-    if (w == 3) deriv_rows_generic(P, z0, z1, h, Fb, Jb, lane, false);   // derivative-integrator rows (a few loads and stores, first thing)
     {
         v4d part = w == 0 ? load_GA(Gx, 0, lane) : zero;
         for (int k = w; k < m; k += 8) {
             const int k2 = k + 4 < m ? k + 4 : k;
             const v4d ga = load_GA(Gx, k + 1, lane), gb = load_GA(Gx, k2 + 1, lane);
-            const double aa = z0[P.off_a + k], ab = k + 4 < m ? z0[P.off_a + k2] : 0.0;
+            const double aa = z0[hot_off_a + k], ab = k + 4 < m ? z0[hot_off_a + k2] : 0.0;
             part += aa * ga;
             part += ab * gb;
         }
         lds_put(PartL + 256 * w, lane, part);
+        touch.consume();   // the argument block's lines: the scalar wait, behind the first requests
         if (w == 0) {                                                   // Pade coefficients -> LDS (read with per-lane indices later)
             for (int k = 0; k <= p; ++k) if (lane == 0) ChL[k] = P.c[k];
             if (lane == 0) *FlagL = 0;
         }
     }
+    double* __restrict__ Jb = JAC ? J + (size_t)b * P.J_stride + P.J_off : nullptr;
+    double* __restrict__ Fb = F ? F + (size_t)b * P.F_stride + P.F_off : nullptr;
+    if (w == 3) deriv_rows_generic(P, z0, z1, h, Fb, Jb, lane, false);   // derivative-integrator rows (a few loads and stores, before the wave's other stores)
     // images of this wave's first pair of drives, requested before anything waits
     const int n_pairs = (m + 1) / 2;
     const int my_first = w == 2 ? 0 : (w == 3 ? 1 : (w == 1 ? 2 : n_pairs));   // pairs 0, 1, 2 -> waves 2, 3, 1, then round-robin
@@ -287,7 +291,8 @@ bool qc_mfma16_padeP_supported(const QcParams& P) {
 hipError_t qc_launch_mfma16_padeP(const QcParams& P, const double* dZ, double* dF, double* dJ, hipStream_t st) {
     if (P.n_int <= 0) return hipSuccess;
     const size_t lds = (size_t)lds_doubles_padeP(P.p) * sizeof(double);
-    if (dJ) hipLaunchKernelGGL((qc_mfma16_padeP_kernel<true>), dim3(P.n_int), dim3(kPThreads), lds, st, P, dZ, dF, dJ);
-    else hipLaunchKernelGGL((qc_mfma16_padeP_kernel<false>), dim3(P.n_int), dim3(kPThreads), lds, st, P, dZ, dF, dJ);
+    const double* dZt = dZ + P.t_begin * (long long)P.zdim;
+    if (dJ) hipLaunchKernelGGL((qc_mfma16_padeP_kernel<true>), dim3(P.n_int), dim3(kPThreads), lds, st, P.Gx, dZt, P.n_int, P.zdim, P.off_a, P.off_dt, P.m, P.p, P.off_U, P, dF, dJ);
+    else hipLaunchKernelGGL((qc_mfma16_padeP_kernel<false>), dim3(P.n_int), dim3(kPThreads), lds, st, P.Gx, dZt, P.n_int, P.zdim, P.off_a, P.off_dt, P.m, P.p, P.off_U, P, dF, dJ);
     return hipGetLastError();
 }
