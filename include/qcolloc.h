@@ -69,7 +69,7 @@ extern "C" {
 #endif
 
 #define QC_VERSION_MAJOR 0
-#define QC_VERSION_MINOR 2
+#define QC_VERSION_MINOR 3
 
 enum {
     QC_OK = 0,
@@ -221,6 +221,13 @@ int qc_eval_jac(qc_handle* h, const double* Z, double* vals);
 int qc_eval_F_jac(qc_handle* h, const double* Z, double* F, double* vals);
 int qc_eval_hess(qc_handle* h, const double* Z, const double* mu, double* hvals);
 
+/* Ipopt's `new_x` flag (the C interface hands it to every callback; MOI evaluators track it themselves): new_x = 0 declares
+ * that the trajectory vector of the following host-buffer calls is the one the handle's previous host-buffer call received --
+ * the accepted trial point, at which Ipopt asks for the Jacobian and the Hessian after the residuals -- so the knots already
+ * on the device are used and Z is not read at all.  Stays in force until qc_set_new_x(h, 1) (the default: every call copies
+ * its Z).  A handle that has not seen a Z yet copies regardless.  Multi-device handles pass the flag on to their shards. */
+int qc_set_new_x(qc_handle* h, int new_x);
+
 /* ---- evaluation, device-resident (asynchronous on `stream`, a hipStream_t) --------------------- */
 /* dZ: device pointer to the full Z vector (8-byte aligned).  dF may be NULL (skip residual store);
  * dvals may be NULL (residual only).  dF/dvals/dhvals point at THIS HANDLE'S slice
@@ -344,15 +351,19 @@ int qc_rollout_dev(qc_handle* h, const double* dZ, const double* dinit, double* 
  * the `QuadraticRegularizer(name, traj, R; baseline, timestep_name)` terms on a / da / dda (reference call sites
  * unitary_smooth_pulse_problem.jl:151-153) flattened into one list of regularised scalar entries of a knot, plus
  * `MinimumTimeObjective(traj; D)` (unitary_minimum_time_problem.jl:67-69; the last knot's timestep drives no
- * interval, hence min_time_knots = T-1 there).  The default weighting QC_REG_PLAIN is the only definition the reference
- * repository states (docstring unitary_smooth_pulse_problem.jl:13: "1/2 sum_t R_a a_t^2 + ..."); QC_REG_DT_SCALED puts the
- * timestep inside the square, which is how QuantumCollocationCore 0.3 is recalled to define the regulariser (not
- * vendored; INTEGRATION.md lists the one-liner that settles it).
+ * interval, hence min_time_knots = T-1 there).  QC_REG_DT_SCALED (0, the default of every binding) puts the timestep
+ * inside the square: every problem template hands the regulariser the timestep's name
+ * (`QuadraticRegularizer(name, traj, R; timestep_name=timestep_name)`, unitary_smooth_pulse_problem.jl:151-153,
+ * unitary_sampling_problem.jl:116-118, quantum_state_sampling_problem.jl:82-84), which only a definition that reads dt_t
+ * needs, and that is how QuantumCollocationCore 0.3 is recalled to define it (not vendored, SURVEY 8c;
+ * julia/reconcile.jl settles it).  QC_REG_PLAIN (1) is the docstring's "1/2 sum_t R_a a_t^2 + ..."
+ * (unitary_smooth_pulse_problem.jl:13).  The numeric values are those of ABI 0.1; ABI 0.2 had them swapped, which is
+ * why bindings must compare qc_abi_version() with the version they were written for at load time.
  * Gradient: dense, Z_len entries (zeros included).  Hessian: upper triangle, per knot
  * [ (v_k,v_k) k=0..n_reg-1 | (v_k,dt) k=0..n_reg-1 | (dt,dt) ]; the last two groups exist only for QC_REG_DT_SCALED
  * with a free timestep. */
-#define QC_REG_PLAIN 0
-#define QC_REG_DT_SCALED 1
+#define QC_REG_DT_SCALED 0
+#define QC_REG_PLAIN 1
 typedef struct qc_terms_desc {
     int64_t T;
     int32_t zdim;
@@ -390,6 +401,9 @@ int qc_debug_read_stamps(qc_handle* h, uint64_t* out, int64_t count);
 
 /* Library/build identification: "qcolloc-hip <major>.<minor> (gfx950, ...)" */
 const char* qc_version(void);
+/* QC_VERSION_MAJOR * 1000 + QC_VERSION_MINOR of the build.  A binding compares it with the header version it mirrors when
+ * it loads the library (struct sizes alone do not reveal a renumbered constant). */
+int32_t qc_abi_version(void);
 
 #ifdef __cplusplus
 }

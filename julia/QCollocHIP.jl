@@ -14,6 +14,7 @@ using Libdl
 
 const LIB = Ref{String}(get(ENV, "QCOLLOC_HIP_LIB", "libqcolloc_hip.so"))
 const QC_MAX_DERIV = 8
+const QC_ABI_VERSION = 3      # QC_VERSION_MAJOR * 1000 + QC_VERSION_MINOR of the include/qcolloc.h these mirrors were written against
 
 # mirror of `qc_desc` (include/qcolloc.h); field order and types must match the header -- `__init__` checks the sizes against
 # the library's own `sizeof` (qc_sizeof_desc / qc_sizeof_dims / qc_sizeof_terms_desc) when the module is loaded
@@ -52,6 +53,9 @@ struct QCFidelityDesc
 end
 
 function __init__()
+    # constants were renumbered between ABI 0.1 / 0.2 / 0.3 (QC_REG_*): the struct sizes do not show that, the version does
+    abi = ccall(dlsym(dlopen(LIB[]), :qc_abi_version), Int32, ())
+    abi == QC_ABI_VERSION || error("QCollocHIP: $(LIB[]) has ABI version $abi, this binding mirrors $QC_ABI_VERSION")
     # a stale mirror would corrupt memory silently: compare with the structs the library was compiled with
     for (sym, T) in ((:qc_sizeof_desc, QCDesc), (:qc_sizeof_dims, QCDims), (:qc_sizeof_terms_desc, QCTermsDesc))
         lib = ccall(dlsym(dlopen(LIB[]), sym), Int64, ())
@@ -179,13 +183,13 @@ end
 
 
 """
-    regularizers(traj, names_and_R; D=0.0, device=0, dt_scaled=false)
+    regularizers(traj, names_and_R; D=0.0, device=0, dt_scaled=true)
 
 `names_and_R = [(:a, R_a), (:da, R_da), (:dda, R_dda)]` (scalars or vectors, unitary_smooth_pulse_problem.jl:151-153);
 `D` adds `MinimumTimeObjective(traj; D)` (unitary_minimum_time_problem.jl:67-69).  Returns `(L, ∇L, ∂²L, ∂²L_structure)`
 closures over one device handle.
 """
-function regularizers(traj, names_and_R; D::Float64=0.0, device::Int=0, dt_scaled::Bool=false)
+function regularizers(traj, names_and_R; D::Float64=0.0, device::Int=0, dt_scaled::Bool=true)
     idx = Int32[]; R = Float64[]
     for (name, r) in names_and_R
         comps = collect(traj.components[name]) .- 1
@@ -196,7 +200,7 @@ function regularizers(traj, names_and_R; D::Float64=0.0, device::Int=0, dt_scale
     h = Ref{Ptr{Cvoid}}(C_NULL)
     GC.@preserve idx R begin
         desc = Ref(QCTermsDesc(traj.T, traj.dim, free_time ? first(traj.components[traj.timestep]) - 1 : -1, traj.global_dim,
-                               free_time ? 0.0 : Float64(traj.timestep), length(idx), dt_scaled ? 1 : 0,   # QC_REG_PLAIN = 0 (docstring form), QC_REG_DT_SCALED = 1
+                               free_time ? 0.0 : Float64(traj.timestep), length(idx), dt_scaled ? 0 : 1,   # QC_REG_DT_SCALED = 0 (templates pass timestep_name=), QC_REG_PLAIN = 1 (docstring form)
                                pointer(idx), pointer(R), C_NULL, D, D == 0.0 ? 0 : traj.T - 1, device, 0))
         rc = ccall((:qc_terms_create, LIB[]), Cint, (Ref{QCTermsDesc}, Ref{Ptr{Cvoid}}), desc, h)
         rc == 0 || error("qc_terms_create: " * unsafe_string(ccall((:qc_terms_last_error, LIB[]), Cstring, (Ptr{Cvoid},), C_NULL)))

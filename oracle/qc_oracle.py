@@ -587,7 +587,7 @@ class Terms:
     reg_index: np.ndarray             # offsets inside a knot
     reg_R: np.ndarray
     baseline: np.ndarray | None = None   # (T, n_reg)
-    dt_scaled: bool = False      # default: the docstring form 1/2 sum R x^2 (unitary_smooth_pulse_problem.jl:13)
+    dt_scaled: bool = True       # default: dt inside the square (the templates pass timestep_name=, unitary_smooth_pulse_problem.jl:151-153); False: the docstring form 1/2 sum R x^2 (:13)
     dt_fixed: float = 0.0
     D: float = 0.0
     n_mt: int = 0

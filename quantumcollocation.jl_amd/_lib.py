@@ -35,8 +35,9 @@ QC_KERNEL_LDS = 1
 QC_KERNEL_MFMA = 2
 QC_MAX_DERIV = 8
 QC_FID_UNITARY, QC_FID_KET, QC_FID_DENSITY = 0, 1, 2
-QC_REG_PLAIN = 0
-QC_REG_DT_SCALED = 1
+QC_REG_DT_SCALED = 0
+QC_REG_PLAIN = 1
+QC_ABI_VERSION = 3          # QC_VERSION_MAJOR * 1000 + QC_VERSION_MINOR of the include/qcolloc.h this file mirrors
 QC_FID_FORM_ABS, QC_FID_FORM_ABS2 = 0, 1
 QC_ROWS_STACKED = 0
 QC_ROWS_BY_COMPONENT = 1
@@ -158,6 +159,7 @@ SYMBOLS = {
     "qc_eval_jac": (C.c_int, [_H, _c_double_p, _c_double_p]),
     "qc_eval_F_jac": (C.c_int, [_H, _c_double_p, _c_double_p, _c_double_p]),
     "qc_eval_hess": (C.c_int, [_H, _c_double_p, _c_double_p, _c_double_p]),
+    "qc_set_new_x": (C.c_int, [_H, C.c_int]),
     "qc_eval_F_jac_dev": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "qc_eval_hess_dev": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "qc_eval_F_jac_dev_multi": (C.c_int, [C.POINTER(_H), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -196,6 +198,7 @@ SYMBOLS = {
     "qc_terms_eval_dev": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "qc_debug_read_stamps": (C.c_int, [_H, C.POINTER(C.c_uint64), C.c_int64]),
     "qc_version": (C.c_char_p, []),
+    "qc_abi_version": (C.c_int32, []),
 }
 
 
@@ -217,6 +220,9 @@ def _load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
+    if lib.qc_abi_version() != QC_ABI_VERSION:
+        raise ImportError(f"{LIB_PATH}: ABI version {lib.qc_abi_version()} but this binding mirrors {QC_ABI_VERSION} "
+                          "(constants were renumbered between minor versions; stale build? run __graft_entry__.build())")
     # the struct mirrors above must be the structs this build of the library was compiled with
     for name, mirror in (("qc_sizeof_desc", qc_desc), ("qc_sizeof_dims", qc_dims_t), ("qc_sizeof_terms_desc", qc_terms_desc)):
         if getattr(lib, name)() != C.sizeof(mirror):

@@ -34,6 +34,8 @@ extern "C" const char* qc_version(void) {
            " (gfx950, fp64; kernels: lds, mfma16, mfma32, mfma64, mfma16-exp, mfma32-exp)";
 }
 
+extern "C" int32_t qc_abi_version(void) { return QC_VERSION_MAJOR * 1000 + QC_VERSION_MINOR; }
+
 extern "C" const char* qc_last_error(const qc_handle* h) { return h ? h->err.c_str() : g_err.c_str(); }
 
 // ------------------------------------------------------------------------------------------------
@@ -434,6 +436,7 @@ extern "C" int qc_create(const qc_desc* d, qc_handle** out) {
         }
     }
     if (const char* e = getenv("QC_HOST_COMPACT")) h->host_compact = atoi(e);
+    if (const char* e = getenv("QC_HOST_LANDING")) h->host_landing = atoi(e);
     if (const char* e = getenv("QC_STAMPS")) {
         if (atoi(e) && P.n_int > 0) {
             QC_HIP_C(hipMalloc((void**)&h->dStamps, (size_t)P.n_int * 16 * sizeof(unsigned long long)));
@@ -444,6 +447,7 @@ extern "C" int qc_create(const qc_desc* d, qc_handle** out) {
     QC_HIP_C(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     QC_HIP_C(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
     QC_HIP_C(hipEventCreateWithFlags(&h->ev_staged, hipEventDisableTiming));
+    QC_HIP_C(hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming));
 #undef QC_HIP_C
     *out = h;
     return QC_OK;
@@ -459,11 +463,16 @@ extern "C" void qc_destroy(qc_handle* h) {
         return;
     }
     qc_device_guard guard(h->device);
+    // both streams idle before any pinned or device block is freed (a failed call may have left chunk kernels in flight on either)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->stream2) (void)hipStreamSynchronize(h->stream2);
     double* bufs[] = {h->dG, h->dGx, h->dZ, h->dF, h->dJ, h->dMu, h->dH, (double*)h->dStamps, h->dRE, h->dRQ, h->dRS, h->dRinit, h->dRout, h->dWs, h->dHs};
     if (h->hJc) (void)hipHostFree(h->hJc);
     if (h->hFc) (void)hipHostFree(h->hFc);
     if (h->hZ) (void)hipHostFree(h->hZ);
+    if (h->hC) (void)hipHostFree(h->hC);
+    if (h->dC) (void)hipFree(h->dC);
+    if (h->ev_done) (void)hipEventDestroy(h->ev_done);
     if (h->dBatch) (void)hipFree(h->dBatch);
     for (hipEvent_t ev : h->chunk_events) if (ev) (void)hipEventDestroy(ev);
     for (double* b : bufs) if (b) (void)hipFree(b);

@@ -40,3 +40,57 @@ copy_fn pick(int mode) {
 // mode: 0 memcpy, 1 widest non-temporal form the CPU has, 2 32-byte non-temporal stores
 void qc_host_copy_select(int mode, void (**fn)(double*, const double*, size_t)) { *fn = pick(mode); }
 void qc_host_copy_fence() { _mm_sfence(); }
+
+// ---- landing watch (qc_host_eval.cpp): the pinned staging buffers are pre-filled with a sentinel word and the kernels' stores
+// ---- are watched as they land; these are the two primitives, with the same run-time dispatch as the copies above.
+namespace {
+
+__attribute__((target("avx512f"))) size_t scan512(const double* p, size_t n, unsigned long long s) {
+    const __m512i sv = _mm512_set1_epi64((long long)s);
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        const __mmask8 k = _mm512_cmpeq_epi64_mask(_mm512_loadu_si512((const void*)(p + i)), sv);
+        if (k) return i + (size_t)__builtin_ctz((unsigned)k);
+    }
+    for (; i < n; ++i) if (*(const volatile unsigned long long*)(p + i) == s) return i;
+    return n;
+}
+
+__attribute__((target("avx2"))) size_t scan256(const double* p, size_t n, unsigned long long s) {
+    const __m256i sv = _mm256_set1_epi64x((long long)s);
+    size_t i = 0;
+    for (; i + 4 <= n; i += 4) {
+        const int k = _mm256_movemask_pd(_mm256_castsi256_pd(_mm256_cmpeq_epi64(_mm256_loadu_si256((const __m256i*)(p + i)), sv)));
+        if (k) return i + (size_t)__builtin_ctz((unsigned)k);
+    }
+    for (; i < n; ++i) if (*(const volatile unsigned long long*)(p + i) == s) return i;
+    return n;
+}
+
+size_t scan_plain(const double* p, size_t n, unsigned long long s) {
+    const volatile unsigned long long* u = (const volatile unsigned long long*)p;
+    for (size_t i = 0; i < n; ++i) if (u[i] == s) return i;
+    return n;
+}
+
+typedef size_t (*scan_fn)(const double*, size_t, unsigned long long);
+scan_fn pick_scan() {
+    __builtin_cpu_init();
+    if (__builtin_cpu_supports("avx512f")) return scan512;
+    if (__builtin_cpu_supports("avx2")) return scan256;
+    return scan_plain;
+}
+
+}  // namespace
+
+// index of the first word of p[0 .. n) that still holds the sentinel bit pattern, n when there is none
+size_t qc_host_scan(const double* p, size_t n, unsigned long long sentinel) {
+    static const scan_fn fn = pick_scan();
+    return fn(p, n, sentinel);
+}
+
+// p[0 .. n) = sentinel (ordinary stores: the lines were just read by the same thread)
+void qc_host_fill(double* p, size_t n, unsigned long long sentinel) {
+    unsigned long long* u = (unsigned long long*)p;
+    for (size_t i = 0; i < n; ++i) u[i] = sentinel;
+}

@@ -309,6 +309,13 @@ struct HostPool {
         { std::lock_guard<std::mutex> lk(mu); q.emplace_back(std::move(fn), g); }
         cv.notify_one();
     }
+    // `count` team members running the same function: one wake-up call for all of them (a notify per job is a futex call each)
+    void push_many(const std::function<void()>& fn, int count, HostGroup* g) {
+        if (count <= 0) return;
+        for (int i = 0; i < count; ++i) g->add();
+        { std::lock_guard<std::mutex> lk(mu); for (int i = 0; i < count; ++i) q.emplace_back(fn, g); }
+        cv.notify_all();
+    }
     ~HostPool() {
         { std::lock_guard<std::mutex> lk(mu); stop = true; }
         cv.notify_all();
@@ -411,8 +418,13 @@ static int run_chunks(qc_handle* h, const CompactPlan& cp, double* F, double* va
     if ((rc = ensure_events(h, n_chunks))) return rc;
     for (int k = 0; k < n_chunks; ++k) {
         const int b0 = bound[k], b1 = bound[k + 1];
-        if ((rc = produce(k, b0, b1))) return rc;
-        QC_HIP(h, hipEventRecord(h->chunk_events[k], (two_streams && (k & 1)) ? h->stream2 : h->stream));
+        hipError_t er = hipSuccess;
+        if (!(rc = produce(k, b0, b1))) er = hipEventRecord(h->chunk_events[k], (two_streams && (k & 1)) ? h->stream2 : h->stream);
+        if (rc || er != hipSuccess) {   // earlier chunks' kernels are still writing into the pinned blocks: let them finish before anyone reuses or frees those
+            (void)hipStreamSynchronize(h->stream);
+            if (two_streams) (void)hipStreamSynchronize(h->stream2);
+            return rc ? rc : fail(&h->err, QC_ERR_HIP, std::string("hipEventRecord: ") + hipGetErrorString(er));
+        }
     }
     HostGroup grp;
     int rc_wait = QC_OK;
@@ -491,11 +503,265 @@ static void pool_memcpy(double* dst, const double* src, size_t n, int workers) {
     grp.wait();
 }
 
+extern "C" int qc_set_new_x(qc_handle* h, int new_x) {
+    if (!h) return fail(nullptr, QC_ERR_INVALID, "qc_set_new_x: NULL handle");
+    h->new_x = new_x ? 1 : 0;
+    for (qc_handle* sh : h->shards) sh->new_x = h->new_x;
+    return QC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+//  One launch and one copy per host-buffer call, watched as it lands ("landing watch")
+// ------------------------------------------------------------------------------------------------
+// The host-buffer calls are bound by the PCIe link (config 3: 12.7 MB of residuals and compact Jacobian values, 14.7 MB of
+// Hessian values per call).  What tests/hip/landing_probe.hip measured on the MI355X host (profiles/r03_landing_probe.txt):
+//   * the copy engine moves 12.8 MB device -> host in 234 us (54.5 GB/s), into pinned AND into pageable memory (the runtime pins
+//     the caller's pages in place; the call then blocks for the duration); 1.2 MB host -> device take 30 us either way;
+//   * kernel stores into pinned host memory reach 44 - 47 GB/s whatever the grid, and they land in NO usable order: the L2
+//     acknowledges a store long before it crosses the link and writes back in its own order -- of one launch over 999 intervals
+//     the first complete interval is seen after 220 us of 440 (QC_HOST_LANDING=2 keeps that variant for comparison);
+//   * round 2's sixteen chunk launches with an event each: 36 - 47 GB/s and 16 launch latencies.
+// So: ONE kernel writes the call's compact output into HBM (3 - 9 us), ONE asynchronous copy brings it to a pinned block in
+// address order at the link's rate, and the data is its own completion flag -- the pinned block holds a sentinel word (a
+// signalling NaN that no arithmetic produces) wherever the copy has not arrived yet; a team of host threads (the calling thread
+// and pool workers) claims pieces of the interval range as their first block is seen to have landed, waits block by block until
+// no word of a block is the sentinel, replicates the block into the caller's array and re-arms it.  No events between
+// chunks, no chunk launches.  Correctness does not rest on the sentinel being unique: the calling thread polls the copy's
+// completion event, and once that has been seen every remaining word is taken as it is (a result that happens to equal the
+// sentinel -- possible only if the caller's input carries that NaN payload -- costs the overlap, not the answer).
+// Residual-only and Hessian calls need no host-side replication: their output goes device -> caller's array in one copy.
+size_t qc_host_scan(const double* p, size_t n, unsigned long long sentinel);   // qc_host_copy.cpp
+void qc_host_fill(double* p, size_t n, unsigned long long sentinel);
+namespace {
+constexpr unsigned long long kLandSentinel = 0x7FF4C0DEC0DE5A5Aull;
+
+struct LandJob {
+    const QcParams* P = nullptr;
+    CompactPlan cp{};
+    // the watched pinned block: one sub-block of `blk` doubles per interval = [ residual rows (f_len) | compact Jacobian values ]
+    double* src = nullptr;
+    size_t blk = 0, f_len = 0;
+    double* vals = nullptr;                             // caller's Jacobian values (replication target)
+    double* F = nullptr;                                // caller's residuals, or nullptr
+    int n_int = 0;
+    std::vector<int> bound;                             // piece k = intervals [bound[k], bound[k + 1])
+    std::unique_ptr<std::atomic<int>[]> claimed;
+    std::atomic<int> remaining{0};
+    std::atomic<int> done{0};                           // 1: the copy's completion event has been seen, 2: it reported an error
+    std::atomic<double> t_first_piece{0.0}, t_last_piece{0.0};   // trace (QC_HOST_TRACE)
+};
+
+inline void cpu_pause() { __builtin_ia32_pause(); }
+
+inline void land_poll(LandJob& J, hipEvent_t ev) {   // calling thread only
+    const hipError_t e = hipEventQuery(ev);
+    if (e == hipSuccess) J.done.store(1, std::memory_order_release);
+    else if (e != hipErrorNotReady) J.done.store(2, std::memory_order_release);
+}
+
+// spins until no word of p[0 .. n) holds the sentinel, or the copy is known to be complete (`poll`: this is the calling thread,
+// the only one that asks the runtime -- it must keep asking while it waits for a block)
+inline void land_wait(LandJob& J, const double* p, size_t n, hipEvent_t ev, bool poll) {
+    size_t off = 0;
+    unsigned spins = 0;
+    while (off < n) {
+        off += qc_host_scan(p + off, n - off, kLandSentinel);
+        if (off >= n) return;
+        if (J.done.load(std::memory_order_acquire)) return;
+        if (poll && (++spins & 15) == 0) land_poll(J, ev);
+        cpu_pause();
+    }
+}
+
+inline bool land_started(const LandJob& J, int b) {   // has interval b's block arrived?  (cheap: its first and last word)
+    const volatile unsigned long long* u = (const volatile unsigned long long*)(J.src + (size_t)b * J.blk);
+    return u[0] != kLandSentinel && u[J.blk - 1] != kLandSentinel;
+}
+
+void land_piece(LandJob& J, int k, hipEvent_t ev, bool poll) {
+    const QcParams& P = *J.P;
+    const qc_copy_fn cpy = host_copy();
+    for (int b = J.bound[k]; b < J.bound[k + 1]; ++b) {
+        double* blk = J.src + (size_t)b * J.blk;
+        land_wait(J, blk, J.blk, ev, poll);
+        if (J.F) memcpy(J.F + (size_t)b * J.f_len, blk, J.f_len * sizeof(double));
+        const double* src = blk + J.f_len;
+        double* dst = J.vals + (size_t)b * P.jac_nnz;
+        for (int c = 0; c < J.cp.copies; ++c) cpy(dst + P.jo_F + (size_t)c * J.cp.n2, src, (size_t)J.cp.n2);
+        for (int c = 0; c < J.cp.second_copies; ++c) cpy(dst + P.jo_B + (size_t)c * J.cp.n2, src + J.cp.n2, (size_t)J.cp.n2);
+        cpy(dst + J.cp.tail_src, src + J.cp.head2, (size_t)J.cp.tail_len);
+        qc_host_fill(blk, J.blk, kLandSentinel);
+    }
+    qc_host_copy_fence();
+}
+
+// Team member: claims pieces whose first block has landed (the copy engine writes in address order, so that is the lowest
+// unclaimed piece; any order would work), until none is left.  `poll`: the calling thread also polls the completion event.
+void land_consume(LandJob& J, hipEvent_t ev, bool poll) {
+    const int np = (int)J.bound.size() - 1;
+    int lo = 0;
+    while (J.remaining.load(std::memory_order_acquire) > 0) {
+        bool got = false;
+        const bool all = J.done.load(std::memory_order_acquire) != 0;
+        while (lo < np && J.claimed[lo].load(std::memory_order_relaxed)) ++lo;
+        // (only a few pieces beyond the frontier are looked at: reads of lines the copy engine is about to write cost it a snoop each)
+        for (int k = lo; k < np && (all || k < lo + 4); ++k) {
+            if (J.claimed[k].load(std::memory_order_relaxed)) continue;
+            if (!all && !land_started(J, J.bound[k])) continue;
+            int expect = 0;
+            if (!J.claimed[k].compare_exchange_strong(expect, 1, std::memory_order_acq_rel)) continue;
+            land_piece(J, k, ev, poll);
+            if (host_trace()) {
+                const double t = now_us();
+                double z = 0.0;
+                J.t_first_piece.compare_exchange_strong(z, t);
+                J.t_last_piece.store(t);
+            }
+            J.remaining.fetch_sub(1, std::memory_order_acq_rel);
+            got = true;
+            break;
+        }
+        if (poll && !all) land_poll(J, ev);
+        if (!got) cpu_pause();
+    }
+}
+
+int land_piece_intervals(size_t block_bytes) {   // ~128 KB of pinned block per piece, at least 2 intervals (QC_HOST_PIECE_KB)
+    static const size_t kb = getenv("QC_HOST_PIECE_KB") ? (size_t)std::max(1, atoi(getenv("QC_HOST_PIECE_KB"))) : 128;
+    return (int)std::max<size_t>(2, (kb << 10) / std::max<size_t>(1, block_bytes));
+}
+}  // namespace
+
+// Brings this handle's knots [t_begin, t_end] to the device unless qc_set_new_x(h, 0) says they are there already.  From where
+// they lie: the runtime pins the caller's pages in place (30 us for config 3's 1.2 MB, the same as from pinned memory).
+static int upload_knots(qc_handle* h, const double* Z) {
+    if (h->new_x == 0 && h->z_valid) return QC_OK;
+    const QcParams& P = h->prm;
+    int rc;
+    if ((rc = ensure(h, &h->dZ, (size_t)h->dims.Z_len))) return rc;
+    const size_t o = (size_t)P.t_begin * P.zdim, n = (size_t)(P.n_int + 1) * P.zdim;
+    QC_HIP(h, hipMemcpyAsync(h->dZ + o, Z + o, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    h->z_valid = true;
+    return QC_OK;
+}
+
+// waits for the handle's completion event without a blocking runtime call (those react 20 - 50 us late); the shards of a
+// multi-device handle yield between polls (N spinning shard threads next to the team would exceed a small CPU quota)
+static int wait_done(qc_handle* h, int shards) {
+    hipError_t e;
+    while ((e = hipEventQuery(h->ev_done)) == hipErrorNotReady) { if (shards > 1) sched_yield(); else cpu_pause(); }
+    if (e != hipSuccess) {
+        (void)hipStreamSynchronize(h->stream);
+        return fail(&h->err, QC_ERR_HIP, std::string("the evaluation failed on the device: ") + hipGetErrorString(e));
+    }
+    return QC_OK;
+}
+
+// Watches the copy into J.src land (recorded as h->ev_done on h->stream by the caller) and replicates it into the caller's arrays.
+static int land_run(qc_handle* h, LandJob& J, int shards, double t_begin, double t_issued) {
+    HostPool& pool = host_pool();
+    const int workers = pool_workers(shards);
+    pool.ensure(workers);
+    J.bound.assign(1, 0);
+    const int per = land_piece_intervals(J.blk * sizeof(double));
+    for (int b = per; b < J.n_int; b += per) J.bound.push_back(b);
+    J.bound.push_back(J.n_int);
+    const int np = (int)J.bound.size() - 1;
+    J.claimed.reset(new std::atomic<int>[np]);
+    for (int k = 0; k < np; ++k) J.claimed[k].store(0, std::memory_order_relaxed);
+    J.remaining.store(np, std::memory_order_release);
+    // helpers: enough to keep up with the link (the replication of config 3 writes 41.5 MB per call), never more than pieces;
+    // small outputs are replicated by the calling thread alone (a worker's wake-up costs 20 - 40 us)
+    const size_t out_bytes = (size_t)J.n_int * ((size_t)J.P->jac_nnz + (J.F ? J.f_len : 0)) * sizeof(double);
+    int helpers = std::max(0, workers / std::max(1, shards) - (shards > 1 ? 1 : 0));
+    if (out_bytes <= (256u << 10)) helpers = 0;
+    helpers = std::max(0, std::min(helpers, np - 1));
+    HostGroup grp;
+    LandJob* Jp = &J;
+    const hipEvent_t ev = h->ev_done;
+    pool.push_many([Jp, ev] { land_consume(*Jp, ev, false); }, helpers, &grp);
+    land_consume(J, ev, true);
+    grp.wait();
+    const double t_consumed = now_us();
+    int rc = QC_OK;
+    if (J.done.load() != 1) rc = wait_done(h, shards);
+    if (host_trace())
+        fprintf(stderr, "qcolloc host trace (%d pieces, %d helpers): inputs, launch and copy issued +%.0f us, first piece done +%.0f, last piece done +%.0f, "
+                "team done +%.0f, event seen +%.0f us\n", np, helpers, t_issued - t_begin, J.t_first_piece.load() ? J.t_first_piece.load() - t_begin : 0.0,
+                J.t_last_piece.load() ? J.t_last_piece.load() - t_begin : 0.0, t_consumed - t_begin, now_us() - t_begin);
+    if (rc || J.done.load() == 2) {
+        h->hC_armed = false;
+        if (!rc) { (void)hipStreamSynchronize(h->stream); rc = fail(&h->err, QC_ERR_HIP, "the evaluation failed on the device"); }
+    }
+    return rc;
+}
+
+static int eval_host_chunked(qc_handle* h, const double* Z, double* F, double* vals, int shards);
+
 static int eval_host(qc_handle* h, const double* Z, double* F, double* vals, int shards) {
     if (shares_values(h)) return fail(&h->err, QC_ERR_UNSUPPORTED, "composed handles write into shared vectors: use the _dev entry points");
     if (!Z || (!F && !vals)) return fail(&h->err, QC_ERR_INVALID, "qc_eval: NULL buffer");
     const QcParams& P = h->prm;
     if (P.n_int == 0) return QC_OK;
+    const CompactPlan cp = compact_plan(P);
+    const bool compact = vals && h->host_compact && cp.useful;
+    const bool direct = (compact || !vals) && h->host_compact == 1 && h->kernel == QC_KERNEL_MFMA && qc_mfma_compact_supported(P);
+    if (vals && (!direct || h->host_landing != 1)) return eval_host_chunked(h, Z, F, vals, shards);
+    const double t_begin = now_us();
+    qc_device_guard guard(h->device);
+    QC_HIP(h, guard.err);
+    int rc;
+    if ((rc = upload_knots(h, Z))) return rc;
+    if (!vals) {
+        // residuals only (a line-search trial): kernel -> HBM -> one copy into the caller's array.  (Rows no kernel writes --
+        // QC_ROWS_BY_COMPONENT -- stay zero in the device vector.)
+        if ((rc = ensure_zeroed(h, &h->dF, (size_t)h->dims.F_len))) return rc;
+        if ((rc = qc_eval_F_jac_dev(h, h->dZ, h->dF, nullptr, h->stream))) return rc;
+        QC_HIP(h, hipMemcpyAsync(F, h->dF, (size_t)h->dims.F_len * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        QC_HIP(h, hipEventRecord(h->ev_done, h->stream));
+        rc = wait_done(h, shards);
+        if (host_trace()) fprintf(stderr, "qcolloc host trace (residuals only): done +%.0f us\n", now_us() - t_begin);
+        return rc;
+    }
+    // residuals + compact Jacobian values, interleaved per interval in ONE device block, so that one copy brings both and a
+    // team member finds everything an interval needs in one place
+    LandJob J;
+    J.P = &h->prm;
+    J.cp = cp;
+    J.n_int = P.n_int;
+    // (a layout with rows no kernel writes keeps its residual rows in the block even when only the values are asked for: the block
+    //  layout of such a handle must not change between calls, or stale values would show through the never-written rows)
+    const bool every_row_written = P.F_stride == P.ddim && P.F_off == 0;
+    const bool with_F = F != nullptr || !every_row_written;
+    J.f_len = with_F ? (size_t)P.F_stride : 0;
+    J.blk = J.f_len + (size_t)cp.comp_len;
+    J.vals = vals;
+    J.F = F;
+    const size_t cap = (size_t)P.n_int * ((size_t)P.F_stride + (size_t)cp.comp_len);
+    if ((rc = ensure_zeroed(h, &h->dC, cap))) return rc;      // (zeroed once: residual rows no kernel writes are delivered as 0)
+    if ((rc = ensure_pinned(h, &h->hC, cap, false))) return rc;
+    if (!h->hC_armed) { qc_host_fill(h->hC, cap, kLandSentinel); h->hC_armed = true; }
+    J.src = h->hC;
+    QcParams C = compact_params(P, cp);
+    C.J_stride = (long long)J.blk;
+    C.J_off = (long long)J.f_len;
+    C.F_stride = (long long)J.blk;
+    const hipError_t e = qc_launch_mfma_F_jac(C, h->dZ, with_F ? h->dC : nullptr, h->dC, h->stream);
+    if (e != hipSuccess) return fail(&h->err, QC_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    hipError_t ec = hipMemcpyAsync(h->hC, h->dC, (size_t)P.n_int * J.blk * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+    if (ec == hipSuccess) ec = hipEventRecord(h->ev_done, h->stream);
+    if (ec != hipSuccess) {
+        (void)hipStreamSynchronize(h->stream);
+        h->hC_armed = false;
+        return fail(&h->err, QC_ERR_HIP, std::string("copy of the compact values: ") + hipGetErrorString(ec));
+    }
+    return land_run(h, J, shards, t_begin, now_us());
+}
+
+// The chunked host path of round 2 (one launch per chunk of intervals, events between them) -- what kernels that cannot write
+// the compact form themselves still use, and the A/B reference of the one-launch path (QC_HOST_LANDING=0).
+static int eval_host_chunked(qc_handle* h, const double* Z, double* F, double* vals, int shards) {
+    const QcParams& P = h->prm;
     if (host_trace()) g_call_begin = now_us();
     qc_device_guard guard(h->device);
     QC_HIP(h, guard.err);
@@ -503,6 +769,7 @@ static int eval_host(qc_handle* h, const double* Z, double* F, double* vals, int
     // Only the knots this handle touches cross PCIe: [t_begin, t_end] inclusive, through a pinned staging buffer (an
     // asynchronous copy from pageable memory is staged by the runtime in small pieces and blocks the calling thread).
     const size_t z0 = (size_t)P.t_begin * P.zdim;
+    const bool z_skip = h->new_x == 0 && h->z_valid;
     if ((rc = ensure_pinned(h, &h->hZ, (size_t)h->dims.Z_len, false))) return rc;
     if ((rc = ensure(h, &h->dZ, (size_t)h->dims.Z_len))) return rc;
     HostPool& pool = host_pool();
@@ -510,6 +777,7 @@ static int eval_host(qc_handle* h, const double* Z, double* F, double* vals, int
     pool.ensure(workers);
     // knots [k0, k1) of this handle's range: pageable -> pinned (worker threads) -> device (asynchronous on the handle's stream)
     auto stage_knots = [&](size_t k0, size_t k1) -> int {
+        if (z_skip) return QC_OK;
         const size_t o = z0 + k0 * P.zdim, n = (k1 - k0) * P.zdim;
         pool_memcpy(h->hZ + o, Z + o, n, workers);
         QC_HIP(h, hipMemcpyAsync(h->dZ + o, h->hZ + o, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -529,7 +797,7 @@ static int eval_host(qc_handle* h, const double* Z, double* F, double* vals, int
         if (F && (rc = ensure_pinned(h, &h->hFc, (size_t)h->dims.F_len, true))) return rc;
         const QcParams C = vals ? compact_params(P, cp) : P;
         static const bool two = !(getenv("QC_HOST_STREAMS") && atoi(getenv("QC_HOST_STREAMS")) == 1);
-        return run_chunks(h, cp, F, vals, shards, [&](int k, int b0, int b1) -> int {
+        rc = run_chunks(h, cp, F, vals, shards, [&](int k, int b0, int b1) -> int {
             int rs = QC_OK;
             if (k == 0) rs = stage_knots(0, (size_t)b1 + 1);                                   // chunk 0 and its halo knot
             else if (k == 1) {
@@ -548,8 +816,11 @@ static int eval_host(qc_handle* h, const double* Z, double* F, double* vals, int
             if (e != hipSuccess) return fail(&h->err, QC_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
             return QC_OK;
         }, two);
+        if (!rc && !z_skip) h->z_valid = true;
+        return rc;
     }
     if ((rc = stage_knots(0, (size_t)P.n_int + 1))) return rc;
+    if (!z_skip) h->z_valid = true;
     if (F && (rc = ensure_zeroed(h, &h->dF, (size_t)h->dims.F_len))) return rc;
     if (vals && (rc = ensure(h, &h->dJ, (size_t)h->dims.jac_nnz))) return rc;
     if ((rc = qc_eval_F_jac_dev(h, h->dZ, F ? h->dF : nullptr, vals ? h->dJ : nullptr, h->stream))) return rc;
@@ -571,7 +842,7 @@ static int eval_host(qc_handle* h, const double* Z, double* F, double* vals, int
     return QC_OK;
 }
 
-static int hess_host(qc_handle* h, const double* Z, const double* mu, double* hvals) {
+static int hess_host(qc_handle* h, const double* Z, const double* mu, double* hvals, int shards) {
     if (h->prm.integrator != QC_PADE)
         return fail(&h->err, QC_ERR_UNSUPPORTED, "no analytic Hessian for the exponential integrator (upstream has none either; use eval_hessian=false)");
     if (h->prm.hess_nnz == 0) return QC_OK;   // no drives and a fixed timestep: the constraint is linear
@@ -579,22 +850,64 @@ static int hess_host(qc_handle* h, const double* Z, const double* mu, double* hv
     if (shares_values(h)) return fail(&h->err, QC_ERR_UNSUPPORTED, "composed handles write into shared vectors: use the _dev entry points");
     const QcParams& P = h->prm;
     if (P.n_int == 0) return QC_OK;
+    const double t_begin = now_us();
     qc_device_guard guard(h->device);
     QC_HIP(h, guard.err);
     int rc;
-    if ((rc = ensure(h, &h->dZ, (size_t)h->dims.Z_len))) return rc;
     if ((rc = ensure(h, &h->dMu, (size_t)h->dims.n_rows))) return rc;
     if ((rc = ensure(h, &h->dH, (size_t)h->dims.hess_nnz))) return rc;
-    const size_t z0 = (size_t)P.t_begin * P.zdim;
-    const size_t zn = (size_t)(P.n_int + 1) * P.zdim;
-    const size_t m0 = (size_t)P.t_begin * P.F_stride;
-    const size_t mn = (size_t)P.n_int * P.F_stride;
-    QC_HIP(h, hipMemcpyAsync(h->dZ + z0, Z + z0, zn * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    QC_HIP(h, hipMemcpyAsync(h->dMu + m0, mu + m0, mn * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    if ((rc = qc_eval_hess_dev(h, h->dZ, h->dMu, h->dH, h->stream))) return rc;
-    QC_HIP(h, hipMemcpyAsync(hvals, h->dH, (size_t)h->dims.hess_nnz * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    QC_HIP(h, hipStreamSynchronize(h->stream));
-    return QC_OK;
+    if ((rc = upload_knots(h, Z))) return rc;
+    const size_t m0 = (size_t)P.t_begin * P.F_stride, mn = (size_t)P.n_int * P.F_stride;
+    // The values have no replicated blocks: kernel -> HBM, then the copy engine straight into the caller's array (14.7 MB at
+    // config 3: 0.27 ms at the link's 54.5 GB/s; the runtime pins the caller's pages in place).  The multipliers go up and the
+    // values come down in QC_HOST_HESS_CHUNKS pieces (default 4) on two streams, so that all but the first piece of the upload
+    // and all but the first kernel run under the download of the piece before.
+    static const int want = getenv("QC_HOST_HESS_CHUNKS") ? std::max(1, atoi(getenv("QC_HOST_HESS_CHUNKS"))) : 4;
+    const bool chunkable = h->kernel == QC_KERNEL_MFMA && qc_mfma_hess_supported(P) && !qc_mfma64_hess_supported(P) && !qc_mfma16_padeP_hess_supported(P) &&
+                           h->host_compact != 0;
+    const int n_chunks = chunkable ? std::max(1, std::min(want, P.n_int / 64)) : 1;
+    if (n_chunks == 1) {
+        QC_HIP(h, hipMemcpyAsync(h->dMu + m0, mu + m0, mn * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        if ((rc = qc_eval_hess_dev(h, h->dZ, h->dMu, h->dH, h->stream))) return rc;
+        QC_HIP(h, hipMemcpyAsync(hvals, h->dH, (size_t)h->dims.hess_nnz * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        QC_HIP(h, hipEventRecord(h->ev_done, h->stream));
+        rc = wait_done(h, shards);
+    } else {
+        if ((rc = ensure_events(h, n_chunks))) return rc;
+        // stream2: the multipliers, piece by piece; stream: kernel and download of piece k behind piece k's upload
+        QC_HIP(h, hipEventRecord(h->ev_staged, h->stream));              // (the knots, and whatever the stream did before)
+        QC_HIP(h, hipStreamWaitEvent(h->stream2, h->ev_staged, 0));
+        const int per = (P.n_int + n_chunks - 1) / n_chunks;
+        for (int k = 0; k < n_chunks; ++k) {
+            const int b0 = k * per, b1 = std::min(P.n_int, b0 + per);
+            if (b0 >= b1) break;
+            const size_t mo = m0 + (size_t)b0 * P.F_stride, ml = (size_t)(b1 - b0) * P.F_stride;
+            QC_HIP(h, hipMemcpyAsync(h->dMu + mo, mu + mo, ml * sizeof(double), hipMemcpyHostToDevice, h->stream2));
+            QC_HIP(h, hipEventRecord(h->chunk_events[k], h->stream2));
+        }
+        hipError_t e = hipSuccess;
+        for (int k = 0; k < n_chunks && e == hipSuccess; ++k) {
+            const int b0 = k * per, b1 = std::min(P.n_int, b0 + per);
+            if (b0 >= b1) break;
+            QcParams Ck = P;
+            Ck.t_begin = P.t_begin + b0;
+            Ck.n_int = b1 - b0;
+            e = hipStreamWaitEvent(h->stream, h->chunk_events[k], 0);
+            if (e == hipSuccess) e = qc_launch_mfma_hess(Ck, h->dZ, h->dMu, h->dH + (size_t)b0 * P.H_stride, h->stream);
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(hvals + (size_t)b0 * P.H_stride, h->dH + (size_t)b0 * P.H_stride, (size_t)(b1 - b0) * P.H_stride * sizeof(double),
+                                   hipMemcpyDeviceToHost, h->stream);
+        }
+        if (e == hipSuccess) e = hipEventRecord(h->ev_done, h->stream);
+        if (e != hipSuccess) {
+            (void)hipStreamSynchronize(h->stream2);
+            (void)hipStreamSynchronize(h->stream);
+            return fail(&h->err, QC_ERR_HIP, std::string("qc_eval_hess: ") + hipGetErrorString(e));
+        }
+        rc = wait_done(h, shards);
+    }
+    if (host_trace()) fprintf(stderr, "qcolloc host trace (Hessian values, %d piece(s)): done +%.0f us\n", n_chunks, now_us() - t_begin);
+    return rc;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -871,12 +1184,13 @@ extern "C" int qc_eval_F_jac(qc_handle* h, const double* Z, double* F, double* v
 
 extern "C" int qc_eval_hess(qc_handle* h, const double* Z, const double* mu, double* hvals) {
     if (!h) return fail(nullptr, QC_ERR_INVALID, "qc_eval_hess: NULL handle");
-    if (!is_multi(h)) return hess_host(h, Z, mu, hvals);
+    if (!is_multi(h)) return hess_host(h, Z, mu, hvals, 1);
     if (h->prm.integrator != QC_PADE)
         return fail(&h->err, QC_ERR_UNSUPPORTED, "no analytic Hessian for the exponential integrator (upstream has none either; use eval_hessian=false)");
     if (h->prm.hess_nnz == 0) return QC_OK;
     if (!Z || !mu || !hvals) return fail(&h->err, QC_ERR_INVALID, "qc_eval_hess: NULL buffer");
-    return multi_run(h, [&](int i) { return hess_host(h->shards[i], Z, mu, hvals + h->shard_H_off[i]); });
+    const int n = (int)h->shards.size();
+    return multi_run(h, [&](int i) { return hess_host(h->shards[i], Z, mu, hvals + h->shard_H_off[i], n); });
 }
 
 // ------------------------------------------------------------------------------------------------

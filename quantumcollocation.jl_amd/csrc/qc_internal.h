@@ -88,6 +88,15 @@ struct qc_handle {
     double* hJc = nullptr;     // compact Jacobian values (one copy of the replicated blocks): pinned host staging, device-visible
     double* hFc = nullptr;     // residuals of the direct-to-host path: pinned host staging, device-visible
     double* hZ = nullptr;      // pinned staging of this handle's knots for the host-to-device copy
+    // One-launch host path ("landing watch", qc_host_eval.cpp): per interval [ residual rows | compact Jacobian values ], written by
+    // the kernel into dC, copied into hC by the copy engine; hC holds a sentinel word wherever the copy has not arrived yet
+    double* dC = nullptr;
+    double* hC = nullptr;
+    bool hC_armed = false;     // hC is completely sentinel-filled (cleared when a call fails midway)
+    int new_x = 1;             // qc_set_new_x: 0 = the knots on the device are current, Z is not read
+    bool z_valid = false;      // dZ holds this handle's knots of SOME host-buffer call
+    hipEvent_t ev_done = nullptr;    // end of the one launch of a host-buffer call
+    int host_landing = 1;      // QC_HOST_LANDING=0: the chunked launches of round 2 instead of one watched copy (A/B diagnostics)
     QcParams* dBatch = nullptr;                // device copy of the parameter blocks of a batched launch led by this handle
     std::vector<unsigned long long> batch_members;   // serial numbers of the handles the cached blocks belong to
     unsigned long long serial = 0;             // unique per created handle (a recycled address is not the same handle)
@@ -133,7 +142,9 @@ bool qc_mfma_hess_supported(const QcParams& P);
 bool qc_mfma_compact_supported(const QcParams& P);   // the F + dF kernel honours QcParams.copies (order-4 kernels, 2N <= 32)
 size_t qc_mfma_gx_doubles(const QcParams& P);
 void qc_mfma_pack_G(const QcParams& P, const double* G_host, double* Gx_host);
-hipError_t qc_launch_mfma_F_jac(const QcParams& P, const double* dZ, double* dF, double* dJ, hipStream_t st);
+// grid_limit > 0 (2N = 16 order-4 kernels only): at most that many workgroups, each walking its intervals in order -- the host
+// path's one launch, whose stores should reach the PCIe link roughly in interval order
+hipError_t qc_launch_mfma_F_jac(const QcParams& P, const double* dZ, double* dF, double* dJ, hipStream_t st, int grid_limit = 0);
 size_t qc_mfma32_gx_doubles(const QcParams& P);
 void qc_mfma32_pack_G(const QcParams& P, const double* G_host, double* Gx_host);
 hipError_t qc_launch_mfma32_F_jac(const QcParams& P, const double* dZ, double* dF, double* dJ, hipStream_t st);
@@ -159,7 +170,7 @@ bool qc_mfma32_exp_supported(const QcParams& P);
 hipError_t qc_launch_mfma32_exp(const QcParams& P, const double* dZ, double* dF, double* dJ, hipStream_t st);
 bool qc_mfma32_hess_supported(const QcParams& P);
 hipError_t qc_launch_mfma32_hess(const QcParams& P, const double* dZ, const double* dMu, double* dH, hipStream_t st);
-hipError_t qc_launch_mfma_hess(const QcParams& P, const double* dZ, const double* dMu, double* dH, hipStream_t st);
+hipError_t qc_launch_mfma_hess(const QcParams& P, const double* dZ, const double* dMu, double* dH, hipStream_t st, int grid_limit = 0);
 
 hipError_t qc_launch_pack_jac(const double* dJ, double* dJc, int n_int, int jac_nnz, int comp_len, int n2, int jo_F, int jo_B, int head2,
                               int tail_src, hipStream_t st);

@@ -329,6 +329,12 @@ class QuantumDynamics:
         _lib.check(_lib.lib.qc_eval_hess(self._h, _lib.dptr(Z), _lib.dptr(mu), _lib.dptr(out)), self._h)
         return out
 
+    def set_new_x(self, new_x: bool) -> None:
+        """Ipopt's `new_x`: False declares that the following host-buffer calls receive the x of the previous one (the accepted
+        trial point: residuals, then Jacobian and Hessian at the same x), so the knots already on the device are used and Z
+        is not read; stays in force until set_new_x(True) (qc_set_new_x)."""
+        _lib.check(_lib.lib.qc_set_new_x(self._h, int(bool(new_x))), self._h)
+
     # -- multi-device handles ---------------------------------------------------------------------
     @property
     def n_shards(self) -> int:
@@ -489,39 +495,55 @@ class ComposedQuantumDynamics(QuantumDynamics):
         raise NotImplementedError("rollouts of a sampling problem are per system: build a QuantumDynamics per unitary integrator")
 
     def F_dF_into(self, Z, F, J):
-        F[:], J[:] = self.F_dF(Z)
+        self.F_dF(Z, out=(F, J))
 
-    def F_dF(self, Z, out=None):
+    def _upload(self, Z):
         Zh = self._Z(Z)
         dZ = self._buf("Z", Zh.size)
         dZ[:Zh.size].copy_(torch.from_numpy(Zh))
+        return dZ
+
+    def _download(self, name: str, t: torch.Tensor, n: int, out: Optional[np.ndarray]) -> np.ndarray:
+        """Device vector -> the caller's `out` (validated like the single-handle class: the evaluator hands Ipopt's own
+        buffers in and reads the result from them) or a fresh array."""
+        out = self._out(name, n, out)
+        if n:
+            torch.from_numpy(out).copy_(t[:n])
+        return out
+
+    def F_dF(self, Z, out=None):
+        dZ = self._upload(Z)
         dF, dJ = self._buf("F", self.dims.F_len), self._buf("J", self.dims.jac_nnz)
         self.F_dF_device(dZ, dF, dJ)
         torch.cuda.synchronize(self._dev)
-        return dF[:self.dims.F_len].cpu().numpy(), dJ[:self.dims.jac_nnz].cpu().numpy()
+        return (self._download("F", dF, int(self.dims.F_len), None if out is None else out[0]),
+                self._download("J", dJ, int(self.dims.jac_nnz), None if out is None else out[1]))
 
     def F(self, Z, out=None):
-        Zh = self._Z(Z)
-        dZ = self._buf("Z", Zh.size)
-        dZ[:Zh.size].copy_(torch.from_numpy(Zh))
+        dZ = self._upload(Z)
         dF = self._buf("F", self.dims.F_len)
         self.F_dF_device(dZ, dF, None)
         torch.cuda.synchronize(self._dev)
-        return dF[:self.dims.F_len].cpu().numpy()
+        return self._download("F", dF, int(self.dims.F_len), out)
 
     def dF(self, Z, out=None):
-        return self.F_dF(Z)[1]
+        dZ = self._upload(Z)
+        dJ = self._buf("J", self.dims.jac_nnz)
+        self.F_dF_device(dZ, None, dJ)
+        torch.cuda.synchronize(self._dev)
+        return self._download("J", dJ, int(self.dims.jac_nnz), out)
 
     def mu_d2F(self, Z, mu, out=None):
-        Zh = self._Z(Z)
         mu = np.ascontiguousarray(mu, dtype=np.float64)
         if mu.size != self.dims.n_rows:
             raise ValueError(f"mu has length {mu.size}, expected {self.dims.n_rows}")
-        dZ = self._buf("Z", Zh.size)
-        dZ[:Zh.size].copy_(torch.from_numpy(Zh))
+        dZ = self._upload(Z)
         dmu = self._buf("mu", mu.size)
         dmu[:mu.size].copy_(torch.from_numpy(mu))
         dH = self._buf("H", self.dims.hess_nnz)
         self.mu_d2F_device(dZ, dmu, dH)
         torch.cuda.synchronize(self._dev)
-        return dH[:self.dims.hess_nnz].cpu().numpy()
+        return self._download("H", dH, int(self.dims.hess_nnz), out)
+
+    def set_new_x(self, new_x: bool) -> None:
+        """Accepted for interface parity with QuantumDynamics.set_new_x; the composed evaluator uploads Z on every call."""

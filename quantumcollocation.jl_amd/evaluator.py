@@ -16,7 +16,9 @@ the order and with the buffer ownership Ipopt uses:
 * Ipopt's call pattern: every trial point of the line search asks for `eval_objective` and `eval_constraint` only; the
   accepted point then asks for the gradient, the Jacobian and the Hessian AT THE SAME x.  `eval_constraint` therefore runs the
   residual-only launch, `eval_constraint_jacobian` the fused `qc_eval_F_jac` (refreshing the cached residuals for free), and
-  nothing is recomputed when a callback repeats the x of the previous one.
+  nothing is recomputed when a callback repeats the x of the previous one.  When the Jacobian or the Hessian is asked for at
+  the x whose residuals were the last thing evaluated, the trajectory vector is not sent again (`dynamics.set_new_x(False)`,
+  the library's counterpart of the `new_x` flag of Ipopt's C callbacks): the knots are on the device already.
 
 Everything numeric happens in the library (dynamics, fidelity and trajectory-term kernels); this file only routes buffers.
 """
@@ -48,8 +50,9 @@ class QuantumControlEvaluator:
         self.n_dynamics_rows = int(d.n_rows)
         self.n_constraints = self.n_dynamics_rows + sum(int(c.dim) for c in self.constraints)
         self._F = np.empty(self.n_dynamics_rows)
-        self._x_F: Optional[np.ndarray] = None          # the x the cached residuals belong to
-        self.stats = {"F": 0, "F_dF": 0, "mu_d2F": 0, "reused_F": 0}
+        self._x_F: Optional[np.ndarray] = None          # the x the cached residuals belong to == the x whose knots are on the device
+        self.stats = {"F": 0, "F_dF": 0, "dF": 0, "mu_d2F": 0, "reused_F": 0, "uploads_elided": 0}
+        self._can_elide = hasattr(dynamics, "set_new_x")
         # ---- Jacobian structure -------------------------------------------------------------------
         jr, jc = dynamics.dF_structure
         rows, cols = [np.asarray(jr, dtype=np.int64)], [np.asarray(jc, dtype=np.int64)]
@@ -139,6 +142,8 @@ class QuantumControlEvaluator:
         if self._same_x(x):
             self.stats["reused_F"] += 1
         else:
+            if self._can_elide:
+                self.dynamics.set_new_x(True)
             self.dynamics.F(x, out=self._F)            # residual-only launch: what a line-search trial costs
             self._x_F = x.copy()
             self.stats["F"] += 1
@@ -148,12 +153,28 @@ class QuantumControlEvaluator:
             c[off:off + cobj.dim] = cobj.g(x)
             off += cobj.dim
 
+    def _at_device_x(self, x: np.ndarray) -> bool:
+        """True (and the library told so) when x is the vector the dynamics evaluated last: its knots are on the device."""
+        same = self._can_elide and self._same_x(x)
+        if self._can_elide:
+            self.dynamics.set_new_x(not same)
+        if same:
+            self.stats["uploads_elided"] += 1
+        return same
+
     def eval_constraint_jacobian(self, J: np.ndarray, x) -> None:
         x = self._x(x)
-        # fused: the residuals come with the Jacobian at no extra cost and refresh the cache
-        self.dynamics.F_dF(x, out=(self._F, J[:self._jac_dyn]))
-        self._x_F = x.copy()
-        self.stats["F_dF"] += 1
+        if self._at_device_x(x):
+            # Ipopt's accepted point: the residuals are cached and the knots are on the device -- Jacobian values only, no upload
+            self.dynamics.dF(x, out=J[:self._jac_dyn])
+            self.stats["dF"] += 1
+        else:
+            # fused: the residuals come with the Jacobian at no extra cost and refresh the cache
+            self.dynamics.F_dF(x, out=(self._F, J[:self._jac_dyn]))
+            self._x_F = x.copy()
+            self.stats["F_dF"] += 1
+        if self._can_elide:
+            self.dynamics.set_new_x(True)
         for cobj, (off, cnt) in zip(self.constraints, self._con_jac):
             J[off:off + cnt] = cobj.dg(x)
 
@@ -168,7 +189,12 @@ class QuantumControlEvaluator:
             H[off:off + cnt] = sigma * np.asarray(o.hess_L(x))
         off, cnt = self._hess_dyn
         if cnt:
+            at_x = self._at_device_x(x)
             self.dynamics.mu_d2F(x, mu[:self.n_dynamics_rows], out=H[off:off + cnt])
+            if self._can_elide:
+                self.dynamics.set_new_x(True)
+                if not at_x:            # the Hessian call just put x's knots on the device, but the cached residuals are another x's
+                    self._x_F = None
             self.stats["mu_d2F"] += 1
         r0 = self.n_dynamics_rows
         for cobj, slot in zip(self.constraints, self._con_hess):

@@ -311,7 +311,9 @@ class TrajectoryObjective:
     `"∂²L_structure"` resolve to the same members."""
     _ALIASES = {"∇L": "grad_L", "∂²L": "hess_L", "∂²L_structure": "hess_structure"}
 
-    def __init__(self, terms, traj: NamedTrajectory, dt_scaled: bool = False, device: int = 0):
+    def __init__(self, terms, traj: NamedTrajectory, dt_scaled: bool = True, device: int = 0):
+        """dt_scaled=True (default): 1/2 sum_t R (dt_t x_t)^2, the weighting the templates' `timestep_name=` argument implies
+        (unitary_smooth_pulse_problem.jl:151-153); False: the docstring's 1/2 sum_t R x_t^2 (QC_REG_PLAIN)."""
         if isinstance(terms, TrajectoryObjectiveSpec):
             terms = terms.terms
         elif isinstance(terms, (QuadraticRegularizer, MinimumTimeObjective)):

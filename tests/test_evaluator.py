@@ -165,7 +165,7 @@ def test_evaluator_call_pattern_with_stand_in_terms():
     ev.eval_hessian_lagrangian(H, x, 1.0, np.ones(ev.n_constraints))
     ev.eval_constraint(c, x)           # after the fused call the residuals are still those of x
     assert dyn.calls == ["F", "F", "F", "F_dF", "mu_d2F"]
-    assert ev.stats == {"F": 3, "F_dF": 1, "mu_d2F": 1, "reused_F": 2}
+    assert ev.stats == {"F": 3, "F_dF": 1, "dF": 0, "mu_d2F": 1, "reused_F": 2, "uploads_elided": 0}   # (a dynamics without set_new_x: nothing elided)
     np.testing.assert_allclose(c, x[:-1] * x[1:] - 1.0)
     with pytest.raises(ValueError):
         ev.eval_constraint(c, np.zeros(n + 1))
@@ -237,7 +237,8 @@ def test_evaluator_drives_an_ipopt_ordered_iteration_on_the_library(qc):
     ev.eval_constraint_jacobian(J, xa)
     ev.eval_hessian_lagrangian(H, xa, 1.0, lam)
     ev.eval_constraint(c, xa)
-    assert ev.stats == {"F": 3, "F_dF": 1, "mu_d2F": 1, "reused_F": 1}
+    # the accepted point's residuals were the last thing evaluated: Jacobian and Hessian run on the knots already on the device
+    assert ev.stats == {"F": 3, "F_dF": 0, "dF": 1, "mu_d2F": 1, "reused_F": 1, "uploads_elided": 2}
     np.testing.assert_array_equal(c, dyn.F(xa))
     np.testing.assert_array_equal(J, dyn.dF(xa))
     off, cnt = ev._hess_dyn
@@ -296,3 +297,31 @@ def _grad(ev, z):
     g = np.empty(ev.n_variables)
     ev.eval_objective_gradient(g, z)
     return g
+
+
+@pytest.mark.gpu
+def test_evaluator_over_a_sampling_problem_fills_the_callers_buffers(qc):
+    """Several unitary integrators (ComposedQuantumDynamics): the evaluator hands its own arrays in as `out=` and reads the results
+    from them -- the composed methods must fill those arrays, not return fresh ones."""
+    systems = [qc.multi_qubit_system(2, zz=z) for z in (0.08, 0.1, 0.12)]
+    inp = qc.unitary_sampling_inputs(systems, qc.GATES["CX"], 12)
+    dyn = qc.QuantumDynamics(inp.integrators, inp.traj)
+    assert isinstance(dyn, qc.ComposedQuantumDynamics)
+    ev = qc.QuantumControlEvaluator(dyn, [])
+    rng = np.random.default_rng(11)
+    x = inp.traj.datavec + 1e-2 * rng.standard_normal(inp.traj.datavec.size)
+    mu = rng.standard_normal(ev.n_constraints)
+    c = np.full(ev.n_constraints, np.nan)
+    J = np.full(ev.jac_nnz, np.nan)
+    H = np.full(ev.hess_nnz, np.nan)
+    ev.eval_constraint(c, x)
+    ev.eval_constraint_jacobian(J, x)
+    ev.eval_hessian_lagrangian(H, x, 1.0, mu)
+    F_ref, J_ref = dyn.F_dF(x)
+    np.testing.assert_array_equal(c, F_ref)
+    np.testing.assert_array_equal(J, J_ref)
+    np.testing.assert_array_equal(H, dyn.mu_d2F(x, mu))
+    np.testing.assert_array_equal(J, dyn.dF(x))
+    with pytest.raises(ValueError):
+        dyn.F(x, out=np.empty(3))
+    dyn.close()
