@@ -48,7 +48,9 @@ def usable_cores() -> int:
 
 
 def cpu_baseline(qc, inp, seconds: float):
-    """The C restatement (oracle/qc_oracle.c, OpenMP over intervals) on the host cores, same workload."""
+    """The C restatement (oracle/qc_oracle.c, OpenMP over intervals) on the host cores, same workload: F + dF (the metric), then
+    mu_d2F and F alone -- the three calls the reference's own harness times (test/scripts/integrator_test_1qubit.jl:45,46,52) --
+    so that `ms/Ipopt-iter` has a CPU figure beside it.  `seconds` is the whole budget: 60 % F + dF, 25 % mu_d2F, 15 % F."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_bridge import problem_from_inputs
     import oracle.qc_oracle_c as oc
@@ -57,19 +59,34 @@ def cpu_baseline(qc, inp, seconds: float):
     threads = usable_cores()
     co = oc.COracle(prob, threads=threads)
     Z = inp.traj.datavec
-    co.F_dF(Z)  # warm-up (thread pool, page faults)
-    n, t0 = 0, time.perf_counter()
-    while True:
-        co.F_dF(Z)
-        n += 1
-        el = time.perf_counter() - t0
-        if el >= seconds and n >= 3:
-            break
-    return {"value": n / el, "unit": "evals/s", "cores": threads, "kind": "port",
-            "sample": f"{n} full F+dF evaluations of the same T={prob.T} workload in {el:.1f} s (oracle/qc_oracle.c, OpenMP)"}
+    mu = np.random.default_rng(1).standard_normal(int(prob.n_rows))
+
+    def loop(fn, budget, min_calls=3):
+        fn()  # warm-up (thread pool, page faults)
+        n, t0 = 0, time.perf_counter()
+        while True:
+            fn()
+            n += 1
+            el = time.perf_counter() - t0
+            if el >= budget and n >= min_calls:
+                return n, el
+
+    n, el = loop(lambda: co.F_dF(Z), 0.60 * seconds)
+    rec = {"value": n / el, "unit": "evals/s", "cores": threads, "kind": "port",
+           "sample": f"{n} full F+dF evaluations of the same T={prob.T} workload in {el:.1f} s (oracle/qc_oracle.c, OpenMP)",
+           "F_dF_ms": el / n * 1e3}
+    if prob.integrator == 0:
+        nh, elh = loop(lambda: co.mu_d2F(Z, mu), 0.25 * seconds)
+        nf, elf = loop(lambda: co.F_dF(Z, want_J=False), 0.15 * seconds)
+        rec["hess_ms"] = elh / nh * 1e3
+        rec["F_ms"] = elf / nf * 1e3
+        rec["ms_per_ipopt_iter"] = rec["F_dF_ms"] + rec["hess_ms"] + rec["F_ms"]      # F + dF, mu_d2F, one line-search F
+        rec["sample"] += f"; {nh} mu_d2F in {elh:.1f} s; {nf} F in {elf:.1f} s"
+    return rec
 
 
 PCIE_PEAK_GBS = 63.0    # MI355X_MICROARCH.md: PCIe Gen5 x16 host link
+XGMI_LINK_GBS = 153.0   # MI355X_MICROARCH.md / SURVEY 8(e): one xGMI link, 7 per GPU in a full mesh
 
 
 class NodeBarrier:
@@ -133,56 +150,121 @@ class NodeBarrier:
                     pass
 
 
-def host_visible_times(dyn, Zh, reps=30):
-    """PCIe-inclusive times of the host-buffer entry points (what the reference's consumer, a CPU Ipopt process, sees):
-    qc_eval_F_jac, qc_eval_hess, qc_eval_F with caller-owned numpy arrays, milliseconds per call."""
+PCIE_COPY_GBS = 54.5    # what the copy engine moves device -> host on this host (tests/hip/landing_probe.hip, profiles/r03_landing_probe.txt)
+
+
+def host_visible_times(dyn, Zs, reps=30):
+    """PCIe-inclusive times of the host-buffer entry points (what the reference's consumer, a CPU Ipopt process, sees), caller-owned
+    numpy arrays, milliseconds per call (median of `reps`).  `*_ms`: every call receives a NEW trajectory vector (Z goes up each
+    time); `*_same_x_ms`: after qc_set_new_x(h, 0), the way Ipopt asks for the Jacobian and the Hessian at its accepted point;
+    `ipopt_sequence_ms`: one F at a new x, then dF and mu_d2F at that x."""
     dims = dyn.dims
     Fh, Jh = np.empty(int(dims.F_len)), np.empty(int(dims.jac_nnz))
     Hh, mu = np.empty(int(dims.hess_nnz)), np.ones(int(dims.n_rows))
+    nz = len(Zs)
 
     def timed(fn):      # median of `reps` calls (the host is shared: one preempted call in thirty moves a mean by a tenth)
-        for _ in range(3):
-            fn()
+        for i in range(3):
+            fn(i)
         ts = []
-        for _ in range(reps):
+        for i in range(reps):
             t0 = time.perf_counter()
-            fn()
+            fn(i)
             ts.append(time.perf_counter() - t0)
         return float(np.median(ts)) * 1e3
 
-    out = {"F_dF_ms": timed(lambda: dyn.F_dF(Zh, out=(Fh, Jh))), "F_ms": timed(lambda: dyn.F(Zh, out=Fh))}
-    if dims.hess_nnz:
-        out["hess_ms"] = timed(lambda: dyn.mu_d2F(Zh, mu, out=Hh))
+    has_h = bool(dims.hess_nnz)
+    dyn.set_new_x(True)
+    out = {"F_dF_ms": timed(lambda i: dyn.F_dF(Zs[i % nz], out=(Fh, Jh))), "F_ms": timed(lambda i: dyn.F(Zs[i % nz], out=Fh))}
+    if has_h:
+        out["hess_ms"] = timed(lambda i: dyn.mu_d2F(Zs[i % nz], mu, out=Hh))
+    dyn.F(Zs[0], out=Fh)
+    dyn.set_new_x(False)
+    out["jac_same_x_ms"] = timed(lambda i: dyn.dF(Zs[0], out=Jh))
+    if has_h:
+        out["hess_same_x_ms"] = timed(lambda i: dyn.mu_d2F(Zs[0], mu, out=Hh))
+
+    def sequence(i):
+        dyn.set_new_x(True)
+        dyn.F(Zs[i % nz], out=Fh)
+        dyn.set_new_x(False)
+        dyn.dF(Zs[i % nz], out=Jh)
+        if has_h:
+            dyn.mu_d2F(Zs[i % nz], mu, out=Hh)
+
+    out["ipopt_sequence_ms"] = timed(sequence)
+    dyn.set_new_x(True)
     return out
 
 
-def host_visible_record(qc, inp, dyn, Zh, cpu_value):
-    """The `host_visible` object of the bench line (never `value`: the metric is device-resident)."""
+def host_visible_record(qc, inp, dyn, Zs, cpu_rec, t1000_equiv=1.0):
+    """The `host_visible` object of the bench line (never `value`: the metric is device-resident).  Every time carries the bound
+    it is measured against: the larger of the PCIe floor (bytes that must cross the link at the copy engine's measured rate) and,
+    for the Jacobian, the host-replication floor (the value array written at the rate this host's worker team reaches)."""
     dims = dyn.dims
-    t = host_visible_times(dyn, Zh)
-    # bytes that cross PCIe per F + dF call: the knots in, the residuals and the COMPACT Jacobian form out (one copy of the
-    # N replicated -F / B blocks; the host replicates them into the caller's array)
+    t = host_visible_times(dyn, Zs)
+    n_int = int(dims.n_intervals)
     n = 2 * inp.system.levels
     nc = inp.system.levels
-    compact = int(dims.jac_nnz_interval) - 2 * (nc - 1) * n * n
-    pcie_bytes = 8 * (inp.traj.dim * (int(dims.n_intervals) + 1) + (int(dims.ddim) + compact) * int(dims.n_intervals))
+    compact = int(dims.jac_nnz_interval) - 2 * (nc - 1) * n * n     # one copy of the N replicated -F / B blocks
+    z_bytes = 8 * inp.traj.dim * (n_int + 1)
+    f_bytes = 8 * int(dims.ddim) * n_int
+    jc_bytes = 8 * compact * n_int
+    h_bytes = 8 * int(dims.hess_nnz)
     rec = dict(t)
     rec["statistic"] = "median of 30 calls"
+    try:
+        expand = dyn.host_expand_rate(5)
+    except Exception:   # noqa: BLE001  (no replicated blocks in this handle's Jacobian)
+        expand = None
+    rec["host_expand_GBps"] = expand
+    rec["pcie_copy_GBps"] = PCIE_COPY_GBS
+    link = PCIE_COPY_GBS * 1e9 * max(1, len(set(getattr(dyn, "devices", None) or [0])))   # one link per distinct device
+    expand_ms = 8 * int(dims.jac_nnz) / (expand * 1e9) * 1e3 if expand else 0.0
+
+    def bound(up, down, host_ms=0.0):     # upload and download are serial (the kernel needs the whole upload)
+        return max((up + down) / link * 1e3, host_ms)
+
+    bounds = {"F_dF_ms": bound(z_bytes, f_bytes + jc_bytes, expand_ms), "F_ms": bound(z_bytes, f_bytes),
+              "jac_same_x_ms": bound(0, jc_bytes, expand_ms)}
+    if "hess_ms" in t:
+        bounds["hess_ms"] = bound(z_bytes + f_bytes, h_bytes)       # (mu has the length of F)
+        bounds["hess_same_x_ms"] = bound(f_bytes, h_bytes)
+        bounds["ipopt_sequence_ms"] = bounds["F_ms"] + bounds["jac_same_x_ms"] + bounds["hess_same_x_ms"]
+    rec["bound_ms"] = bounds
+    rec["frac_of_bound"] = {k: bounds[k] / t[k] for k in bounds if k in t}
     rec["evals_per_s"] = 1e3 / t["F_dF_ms"]
-    rec["speedup_vs_cpu_baseline"] = (1e3 / t["F_dF_ms"]) / cpu_value if cpu_value else None
-    rec["pcie_bytes_per_eval"] = pcie_bytes
-    rec["pcie_GBps_achieved"] = pcie_bytes / (t["F_dF_ms"] * 1e-3) / 1e9
+    rec["evals_per_s_T1000_equivalent"] = rec["evals_per_s"] * t1000_equiv
+    rec["pcie_bytes_per_eval"] = z_bytes + f_bytes + jc_bytes
+    rec["pcie_GBps_achieved"] = rec["pcie_bytes_per_eval"] / (t["F_dF_ms"] * 1e-3) / 1e9
     rec["pcie_GBps_peak"] = PCIE_PEAK_GBS
     if "hess_ms" in t:
-        rec["ms_per_ipopt_iter"] = t["F_dF_ms"] + t["hess_ms"] + t["F_ms"]   # F + dF, mu_d2F, one line-search F
+        rec["ms_per_ipopt_iter"] = t["F_dF_ms"] + t["hess_ms"] + t["F_ms"]   # F + dF, mu_d2F, one line-search F: every call with a new x
+    if cpu_rec:
+        rec["speedup_vs_cpu_baseline"] = rec["evals_per_s_T1000_equivalent"] / cpu_rec["value"]
+        if "ms_per_ipopt_iter" in rec and "ms_per_ipopt_iter" in cpu_rec:
+            rec["ipopt_iter_speedup_vs_cpu_baseline"] = cpu_rec["ms_per_ipopt_iter"] * t1000_equiv / rec["ms_per_ipopt_iter"]
+            rec["ipopt_sequence_speedup_vs_cpu_baseline"] = cpu_rec["ms_per_ipopt_iter"] * t1000_equiv / t["ipopt_sequence_ms"]
     return rec
+
+
+def _mfma_counters():
+    """Counter-based MFMA figures of the newest profiles/r*_mfma_util.json (rocprofv3 --pmc runs, external to this process)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_mfma_util.json")))
+    if not files:
+        return None, None
+    try:
+        return json.load(open(files[-1])), os.path.relpath(files[-1], ROOT)
+    except Exception:   # noqa: BLE001
+        return None, None
 
 
 def config5_record(qc, dev_index, steps=300):
     """BASELINE config 5 (4-qubit QFT, T = 500, the 2N = 32 MFMA path) on the device: north_star asks for the MFMA
-    utilisation of the large-n case.  FLOP counts are the kernels' own MFMA counts as the SQ_INSTS_VALU_MFMA_F64 counter
-    reports them (576 / 560 v_mfma_f64_16x16x4_f64 per interval for F + dF / mu_d2F at m = 8, 2048 FLOP each:
-    profiles/r02_mfma_util.json, which also holds the counter-based MfmaUtil: 19.1 % / 24.9 %)."""
+    utilisation of the large-n case.  The times are measured here; the MFMA instruction counts (SQ_INSTS_VALU_MFMA_F64 per
+    launch, 2048 FLOP per v_mfma_f64_16x16x4_f64) and the counter-based MfmaUtil come from the newest
+    profiles/r*_mfma_util.json and are labelled as external; they are omitted when that file does not hold these kernels."""
     inp = qc.config_inputs(5)
     dyn = qc.QuantumDynamics(inp.integrators, inp.traj, device=dev_index)
     dev = torch.device("cuda", dev_index)
@@ -218,10 +300,20 @@ def config5_record(qc, dev_index, steps=300):
     peak_tf = 78.6       # f64 MFMA: 256 CUs x 4 SIMDs x 2048 FLOP / 64 cycles x 2.4 GHz
     rec = {"workload": qc.CONFIGS[5].description + f"; T={inp.traj.T}", "kernels": list(dyn.kernel_names),
            "F_dF_us": jac_us, "F_dF_hbm_frac": jac_bytes / (jac_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-           "F_dF_mfma_frac": 576 * n_int * 2048 / (jac_us * 1e-6) / 1e12 / peak_tf,
            "hess_us": hess_us, "hess_hbm_frac": hess_bytes / (hess_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-           "hess_mfma_frac": 560 * n_int * 2048 / (hess_us * 1e-6) / 1e12 / peak_tf,
-           "mfma_peak_TFLOPs": peak_tf, "MfmaUtil_counter_percent": {"F_dF": 19.1, "hess": 24.9, "source": "profiles/r02_mfma_util.json"}}
+           "mfma_peak_TFLOPs": peak_tf}
+    counters, src = _mfma_counters()
+    if counters and inp.traj.T == 500:
+        pick = {"F_dF": [v for k, v in counters.items() if k.startswith("config5 qc_mfma32_pade4_kernel<true")],
+                "hess": [v for k, v in counters.items() if k.startswith("config5 qc_mfma32_pade4_hess_kernel<")]}
+        if dyn.kernel_names == ("mfma32-pade4", "mfma32-pade4-hess") and all(len(v) == 1 for v in pick.values()):
+            ext = {"source": src, "note": "external: rocprofv3 --pmc passes recorded in that file, not measured by this run"}
+            for name, us in (("F_dF", jac_us), ("hess", hess_us)):
+                c = pick[name][0]
+                ext[name + "_mfma_instructions_per_launch"] = c["SQ_INSTS_VALU_MFMA_F64"]
+                ext[name + "_MfmaUtil_percent"] = c["MfmaUtil_percent"]
+                rec[name + "_mfma_frac"] = c["SQ_INSTS_VALU_MFMA_F64"] * 2048 / (us * 1e-6) / 1e12 / peak_tf
+            rec["mfma_counters"] = ext
     dyn.close()
     return rec
 
@@ -265,6 +357,14 @@ def main():
     dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    qc = g.load_package()
+    # The CPU baseline is a property of the T = 1000 workload and of this host, not of N: rank 0 times it at every N, BEFORE the
+    # ranks meet (the others wait in the rendezvous below, asleep), so that the N > 1 lines carry the same reference as N = 1.
+    cpu_rec = None
+    if rank == 0 and args.cpu_seconds > 0 and args.config in (3, 4):
+        cpu_rec = cpu_baseline(qc, qc.config_inputs(3, T=T_PER_GPU), args.cpu_seconds)
+    elif rank == 0 and args.cpu_seconds > 0 and world == 1:
+        cpu_rec = cpu_baseline(qc, qc.config_inputs(args.config, T=args.T or None), args.cpu_seconds)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -272,7 +372,6 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    qc = g.load_package()
     from qcolloc_amd.sharding import ShardedDynamics
 
     spec = qc.CONFIGS[args.config]
@@ -347,10 +446,11 @@ def main():
               f"+{(tc - t0) * 1e6:.1f}, synchronize returned +{(td - t0) * 1e6:.1f}, end +{elapsed * 1e6:.1f}", file=sys.stderr)
     assert status[0] == 0, "qc_eval_F_jac_dev reported an error during the timed loop"
     stream_ms = ev0.elapsed_time(ev1)
+    stream_ms_max = stream_ms
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        tt = torch.tensor([elapsed, stream_ms], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        elapsed, stream_ms_max = float(tt[0].item()), float(tt[1].item())
 
     # kernel duration: HIP event pair around each launch, on the launch stream, same steps
     kn = min(args.steps, 400)
@@ -450,17 +550,21 @@ def main():
             dist.all_reduce(ag, op=dist.ReduceOp.MAX)
             extra["allgather_ms"] = float(ag.item())
             extra["allgather_GB_per_gpu_received"] = (world - 1) * pad.numel() * 8 / 1e9
+            # against SURVEY 8(e)'s figure: a full xGMI mesh, every GPU receiving from its N - 1 peers on separate ~153 GB/s links
+            extra["allgather_GBps_per_gpu"] = extra["allgather_GB_per_gpu_received"] / (extra["allgather_ms"] * 1e-3)
+            extra["xgmi_GBps_per_gpu_peak"] = XGMI_LINK_GBS * min(world - 1, 7)
+            extra["allgather_frac_of_xgmi"] = extra["allgather_GBps_per_gpu"] / extra["xgmi_GBps_per_gpu_peak"] if backend == "nccl" else None
         except Exception as exc:   # noqa: BLE001
             extra["allgather_error"] = repr(exc)[:200]
 
-    cpu_rec = None
-    if rank == 0 and world == 1 and args.cpu_seconds > 0:
-        cpu_rec = cpu_baseline(qc, inp, args.cpu_seconds)
+    total_intervals = (T_total - 1)
+    t1000_equiv = total_intervals / (T_PER_GPU - 1) if args.config in (3, 4) else float(world)
     host_rec = None
+    Zhs = [Zh + (1e-3 * k) * rng.standard_normal(Zh.size) for k in range(3)]     # the host-buffer calls get a different vector each time
     if args.host_visible:
         try:
             if world == 1:
-                host_rec = host_visible_record(qc, inp, dyn, Zh, cpu_rec["value"] if cpu_rec else None)
+                host_rec = host_visible_record(qc, inp, dyn, Zhs, cpu_rec, t1000_equiv)
                 host_rec["devices"] = [dev_index]
             else:
                 # The reference's consumer is ONE process: rank 0 builds the in-library multi-device handle
@@ -471,9 +575,8 @@ def main():
                     try:   # (whatever happens here, rank 0 reaches the barrier the other ranks are waiting at)
                         devs = list(range(world)) if backend == "nccl" else [r % torch.cuda.device_count() for r in range(world)]
                         md = qc.QuantumDynamics(inp.integrators, inp.traj, devices=devs, kernel=args.kernel)
-                        host_rec = host_visible_record(qc, inp, md, Zh, None)
+                        host_rec = host_visible_record(qc, inp, md, Zhs, cpu_rec, t1000_equiv)
                         host_rec["devices"] = devs
-                        host_rec["evals_per_s_T1000_equivalent"] = host_rec["evals_per_s"] * (T_total - 1) / (T_PER_GPU - 1)
                         md.close()
                     except Exception as exc:   # noqa: BLE001
                         host_rec = {"error": repr(exc)[:300]}
@@ -487,8 +590,6 @@ def main():
         except Exception as exc:   # noqa: BLE001
             c5 = {"error": repr(exc)[:300]}
 
-    total_intervals = (T_total - 1)
-    t1000_equiv = total_intervals / (T_PER_GPU - 1) if args.config in (3, 4) else float(world)
     value = args.steps * t1000_equiv / elapsed
     if rank == 0:
         traffic = None
@@ -524,9 +625,18 @@ def main():
             "knot_evals_per_s": args.steps * total_intervals / elapsed,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc passes recorded there, not measured by this run)" if traffic else None,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "kernel_us_event_pairs": kernel_us_pairs, "step_us_stream_events": kernel_us_stream},
         }
+        if world > 1:
+            # whole job against N devices' HBM: every rank's launch moves the same algorithmic bytes (equal shards); the slowest
+            # rank's stream-event step time is the job's
+            agg = world * bytes_per_launch / (stream_ms_max * 1e3 / args.steps * 1e-6) / 1e9
+            line["roofline"].update({"scope": "rank 0's shard (achieved / frac); aggregate_*: all ranks against N x peak",
+                                     "aggregate_achieved": agg, "aggregate_peak": world * HBM_PEAK_GBS,
+                                     "aggregate_frac": agg / (world * HBM_PEAK_GBS),
+                                     "step_us_stream_events_max_over_ranks": stream_ms_max * 1e3 / args.steps})
         line.update(extra)
         line["value_device_resident_evals_per_s"] = value
         if rccl_ranks is not None:
@@ -539,6 +649,10 @@ def main():
             line["config5"] = c5
         if cpu_rec is not None:
             line["cpu_baseline"] = cpu_rec
+            if "ms_per_ipopt_iter" in cpu_rec and "ms_per_ipopt_iter_proxy_device" in line:
+                # both halves of BASELINE's metric beside their CPU figure (T = 1000-equivalents at N > 1)
+                line["ipopt_iter_speedup_device_vs_cpu_baseline"] = cpu_rec["ms_per_ipopt_iter"] * t1000_equiv / line["ms_per_ipopt_iter_proxy_device"]
+            line["speedup_vs_cpu_baseline"] = value / cpu_rec["value"]
         print(json.dumps(line), flush=True)
     if world > 1:
         node_barrier.close()

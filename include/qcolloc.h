@@ -399,6 +399,11 @@ int qc_terms_eval_dev(qc_terms* h, const double* dZ, double* dJ, double* dgrad, 
  * QC_ERR_UNSUPPORTED. */
 int qc_debug_read_stamps(qc_handle* h, uint64_t* out, int64_t count);
 
+/* Diagnostic only: the rate (GB/s of values written) at which this host replicates the compact Jacobian form of handle h into a
+ * full value array with the library's own worker team -- no GPU work, no transfer; the host-side bound of qc_eval_jac that
+ * bench.py reports next to the PCIe bound.  QC_ERR_UNSUPPORTED when the handle's Jacobian has no replicated blocks. */
+int qc_debug_host_expand_rate(qc_handle* h, int32_t reps, double* GBps);
+
 /* Library/build identification: "qcolloc-hip <major>.<minor> (gfx950, ...)" */
 const char* qc_version(void);
 /* QC_VERSION_MAJOR * 1000 + QC_VERSION_MINOR of the build.  A binding compares it with the header version it mirrors when

@@ -101,7 +101,7 @@ function state_row_offset(traj, name)
 end
 
 """
-    dynamics(integrators, traj, system; device=0, devices=nothing, eval_hessian=true, rows=:stacked)
+    dynamics(integrators, traj, system; device=0, devices=nothing, eval_hessian=true, rows=:stacked, exact_structure=false)
 
 `integrators[1]` must be the `UnitaryPadeIntegrator` / `UnitaryExponentialIntegrator`, followed by
 `DerivativeIntegrator`s (the order of unitary_smooth_pulse_problem.jl:175-179).  `component_offset(traj, name)`
@@ -110,10 +110,16 @@ is `first(traj.components[name]) - 1`.
 `devices = 0:7` builds ONE evaluator over several GPUs (`qc_create_multi`): the knots are sharded inside the library, each
 GPU copies its own contiguous slice of `∂F` into the caller's vector over its own PCIe link; everything else is unchanged.
 `rows = :by_component` places every integrator's rows at its state component's position (`Z.dims.states` rows per interval).
+`exact_structure = true` (= `hess_align = 1`): `μ∂²F_structure` holds exactly the structural entries, no alignment padding --
+what a `==` / `length` comparison with QuantumCollocationCore's own structure needs (julia/reconcile.jl); the default pads every
+interval's value block to whole cache lines with explicit zero duplicates, which MOI sums away.
+`set_new_x!(dyn, false)` is Ipopt's `new_x = false`: the following calls reuse the knots already on the device.
 """
 function dynamics(integrators, traj, system; device::Int=0, devices=nothing, eval_hessian::Bool=true,
                   state_name=:Ũ⃗, control_name=:a, pade_order::Int=4, exponential::Bool=false,
-                  derivative_pairs=[(:a, :da), (:da, :dda)], n_kets::Int=0, rows::Symbol=:stacked, hess_align::Int=0)
+                  derivative_pairs=[(:a, :da), (:da, :dda)], n_kets::Int=0, rows::Symbol=:stacked, hess_align::Int=0,
+                  exact_structure::Bool=false)
+    exact_structure && (hess_align = 1)
     off(name) = first(traj.components[name]) - 1
     n = 2 * system.levels
     G0 = Matrix{Float64}(system.G_drift)                       # column-major n x n
@@ -176,6 +182,9 @@ function dynamics(integrators, traj, system; device::Int=0, devices=nothing, eva
     finalizer(x -> ccall((:qc_destroy, LIB[]), Cvoid, (Ptr{Cvoid},), x.handle), dyn)
     return dyn
 end
+
+"Ipopt's `new_x`: `false` declares that the next host-buffer calls receive the x of the previous one (`qc_set_new_x`)."
+set_new_x!(dyn::HIPDynamics, new_x::Bool) = check(ccall((:qc_set_new_x, LIB[]), Cint, (Ptr{Cvoid}, Cint), dyn.handle, new_x ? 1 : 0), dyn.handle)
 
 # ---------------------------------------------------------------------------------------------------------------
 #  Objective terms and rollouts (SURVEY.md 8f): the same `ccall` pattern over qc_terms_* / qc_fidelity_* / qc_rollout

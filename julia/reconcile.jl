@@ -1,0 +1,114 @@
+# reconcile.jl -- turns "parity unpinned" into one command for anyone who has Julia and the reference's packages:
+#
+#     julia --project=<QuantumCollocation.jl checkout> julia/reconcile.jl [out_dir = tests/golden]
+#
+# It evaluates QuantumCollocationCore 0.3's OWN `QuantumDynamics` (the object the reference's harness times,
+# test/scripts/integrator_test_1qubit.jl:22-52, built as unitary_smooth_pulse_problem.jl:163-179 builds it) on
+#   fixture : the reference's data fixture (test/test_utils.jl:54-70, free time) with the system of test_utils.jl:123
+#   config1 : 1-qubit Hadamard, T = 50, dt = 0.2, X / Y drives        (BASELINE config 1)
+#   config2 : 2-qubit CNOT, T = 200, order-4 Pade                      (BASELINE config 2)
+# and writes tests/golden/ref_<case>.json: Z, mu, F, dF / mu_d2F values AND structures, plus the scalar definitions this
+# repository could only recall (INTEGRATION.md "Choices this repository cannot verify").  tests/test_reference_golden.py
+# picks the files up (COO comparison as sets of (row, col) -> summed value, hess_align = 1, rtol 1e-10) and the verdict of
+# every row of that table is printed below.  Nothing here runs in the build container (no Julia): keep it in step with the
+# harness script when Core's constructors change.
+using QuantumCollocation, NamedTrajectories, LinearAlgebra, Random
+
+out_dir = length(ARGS) >= 1 ? ARGS[1] : joinpath(@__DIR__, "..", "tests", "golden")
+include(joinpath(pkgdir(QuantumCollocation), "test", "test_utils.jl"))      # named_trajectory_type_1 (test_utils.jl:54-118)
+
+json(x::AbstractFloat) = isfinite(x) ? repr(Float64(x)) : "null"
+json(x::Integer) = string(x)
+json(x::Bool) = x ? "true" : "false"
+json(x::AbstractString) = repr(String(x))
+json(x::Symbol) = repr(String(x))
+json(x::Tuple) = "[" * join(json.(x), ",") * "]"
+json(x::AbstractArray) = "[" * join(json.(vec(collect(x))), ",") * "]"
+json(x::AbstractDict) = "{" * join(("$(repr(String(k))):$(json(v))" for (k, v) in x), ",") * "}"
+json(::Nothing) = "null"
+
+"The harness of integrator_test_1qubit.jl:41-52 on (system, traj): Core's own closures, nothing of this repository."
+function reference_record(system, traj; order=4, seed=1)
+    P = UnitaryPadeIntegrator(:Ũ⃗, :a, system, traj; order=order)                       # unitary_smooth_pulse_problem.jl:165-167
+    integrators = [P, DerivativeIntegrator(:a, :da, traj), DerivativeIntegrator(:da, :dda, traj)]   # :175-179
+    dynamics = QuantumDynamics(integrators, traj)
+    Z⃗ = traj.datavec
+    F = dynamics.F(Z⃗)
+    μ = randn(MersenneTwister(seed), length(F))
+    ∂F = dynamics.∂F(Z⃗)
+    rec = Dict{String,Any}(
+        "T" => traj.T, "dim" => traj.dim, "global_dim" => traj.global_dim, "names" => collect(traj.names),
+        "components" => Dict(String(k) => collect(v) for (k, v) in pairs(traj.components)),
+        "timestep" => traj.timestep isa Symbol ? String(traj.timestep) : Float64(traj.timestep), "pade_order" => order,
+        "H_drift_re" => real.(system.H_drift), "H_drift_im" => imag.(system.H_drift),                  # column-major, as `vec` gives them
+        "H_drives_re" => [real.(H) for H in system.H_drives], "H_drives_im" => [imag.(H) for H in system.H_drives],
+        "levels" => size(system.H_drift, 1), "Z" => Z⃗, "mu" => μ, "F" => F,
+        "dF" => ∂F, "dF_rows" => first.(dynamics.∂F_structure), "dF_cols" => last.(dynamics.∂F_structure),   # 1-based, Core's order
+        "rows_declared" => traj.dims.states * (traj.T - 1))
+    if dynamics.μ∂²F !== nothing
+        rec["mu_d2F"] = dynamics.μ∂²F(Z⃗, μ)
+        rec["mu_d2F_rows"] = first.(dynamics.μ∂²F_structure)
+        rec["mu_d2F_cols"] = last.(dynamics.μ∂²F_structure)
+    end
+    return rec, dynamics
+end
+
+function smooth_pulse_traj(system, U_goal, T, Δt)
+    prob = UnitarySmoothPulseProblem(system, U_goal, T, Δt; ipopt_options=IpoptOptions(print_level=1),
+                                     piccolo_options=PiccoloOptions(verbose=false))
+    return prob.trajectory
+end
+
+verdicts = Pair{String,Any}[]
+mkpath(out_dir)
+
+# ---- fixture --------------------------------------------------------------------------------------------------
+sys1 = QuantumSystem(0.1 * PAULIS[:Z], [PAULIS[:X], PAULIS[:Y]])                          # test_utils.jl:123
+traj = named_trajectory_type_1(free_time=true)
+rec, dyn = reference_record(sys1, traj)
+push!(verdicts, "rows of an interval: length(F) == Z.dims.states * (T - 1)" => (length(rec["F"]) == rec["rows_declared"]))
+push!(verdicts, "COO order inside an interval: first 6 (row, col) of dF_structure" => collect(zip(rec["dF_rows"][1:6], rec["dF_cols"][1:6])))
+push!(verdicts, "Hessian structure is upper-triangular" => all(r <= c for (r, c) in zip(rec["mu_d2F_rows"], rec["mu_d2F_cols"])))
+# scalar definitions (INTEGRATION.md table)
+a = traj.a; Δt = vec(traj.Δt)
+L = QuadraticRegularizer(:a, traj, 1.0; timestep_name=:Δt).L(traj.datavec, traj)
+rec["regularizer_a_R1"] = L
+rec["regularizer_plain"] = 0.5 * sum(abs2, a)
+rec["regularizer_dt_scaled"] = 0.5 * sum(abs2, a .* Δt')
+push!(verdicts, "quadratic regulariser" => (isapprox(L, rec["regularizer_dt_scaled"]; rtol=1e-12) ? "QC_REG_DT_SCALED (dt inside the square)" :
+                                            isapprox(L, rec["regularizer_plain"]; rtol=1e-12) ? "QC_REG_PLAIN" : "NEITHER: $L"))
+Ũ⃗ = traj.Ũ⃗[:, 3]; Ũ⃗g = traj.goal.Ũ⃗
+U = iso_vec_to_operator(Ũ⃗); Ug = iso_vec_to_operator(Ũ⃗g); n = size(U, 1)
+fid = iso_vec_unitary_fidelity(Ũ⃗, Ũ⃗g)
+rec["fidelity_state"] = Ũ⃗; rec["fidelity_goal"] = Ũ⃗g; rec["fidelity"] = fid
+push!(verdicts, "unitary fidelity" => (isapprox(fid, abs(tr(Ug' * U)) / n; rtol=1e-12) ? "QC_FID_FORM_ABS  |tr|/n" :
+                                       isapprox(fid, abs2(tr(Ug' * U)) / n^2; rtol=1e-12) ? "QC_FID_FORM_ABS2  |tr|^2/n^2" : "NEITHER: $fid"))
+ψ = ComplexF64[0.6, 0.8im]; ψg = ComplexF64[1, 1] / sqrt(2)
+kf = iso_fidelity(ket_to_iso(ψ), ket_to_iso(ψg))
+rec["ket_fidelity"] = kf
+push!(verdicts, "ket fidelity" => (isapprox(kf, abs2(ψg' * ψ); rtol=1e-12) ? "|<goal|psi>|^2" : isapprox(kf, abs(ψg' * ψ); rtol=1e-12) ? "|<goal|psi>|" : "NEITHER: $kf"))
+open(io -> write(io, json(rec)), joinpath(out_dir, "ref_fixture.json"), "w")
+
+# ---- exponential integrator: has Core a Hessian for it? -----------------------------------------------------
+dynE = QuantumDynamics([UnitaryExponentialIntegrator(:Ũ⃗, :a, sys1, traj), DerivativeIntegrator(:a, :da, traj),
+                        DerivativeIntegrator(:da, :dda, traj)], traj)
+push!(verdicts, "Hessian of the exponential integrator is absent" => (dynE.μ∂²F === nothing))
+recE = Dict{String,Any}("Z" => traj.datavec, "F" => dynE.F(traj.datavec), "dF" => dynE.∂F(traj.datavec),
+                        "dF_rows" => first.(dynE.∂F_structure), "dF_cols" => last.(dynE.∂F_structure))
+open(io -> write(io, json(recE)), joinpath(out_dir, "ref_fixture_exponential.json"), "w")
+
+# ---- BASELINE configs 1 and 2 ---------------------------------------------------------------------------------
+for (name, system, gate, T) in (("config1", QuantumSystem(GATES[:Z], [GATES[:X], GATES[:Y]]), GATES[:H], 50),
+                                ("config2", QuantumSystem(0.1 * kron(PAULIS[:Z], PAULIS[:Z]),
+                                                          [kron(PAULIS[:X], PAULIS[:I]), kron(PAULIS[:Y], PAULIS[:I]),
+                                                           kron(PAULIS[:I], PAULIS[:X]), kron(PAULIS[:I], PAULIS[:Y])]), GATES[:CX], 200))
+    r, _ = reference_record(system, smooth_pulse_traj(system, gate, T, 0.2))
+    open(io -> write(io, json(r)), joinpath(out_dir, "ref_$(name).json"), "w")
+end
+
+println("\nreconcile.jl -- verdicts for INTEGRATION.md \"Choices this repository cannot verify\":")
+for (k, v) in verdicts
+    println("  ", rpad(k, 72), " => ", v)
+end
+println("wrote ref_fixture.json, ref_fixture_exponential.json, ref_config1.json, ref_config2.json to ", abspath(out_dir))
+println("now run:  python -m pytest tests/test_reference_golden.py -m gpu")

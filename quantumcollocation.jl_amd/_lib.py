@@ -197,6 +197,7 @@ SYMBOLS = {
     "qc_terms_eval": (C.c_int, [_H, _c_double_p, _c_double_p, _c_double_p, _c_double_p]),
     "qc_terms_eval_dev": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "qc_debug_read_stamps": (C.c_int, [_H, C.POINTER(C.c_uint64), C.c_int64]),
+    "qc_debug_host_expand_rate": (C.c_int, [_H, C.c_int32, _c_double_p]),
     "qc_version": (C.c_char_p, []),
     "qc_abi_version": (C.c_int32, []),
 }

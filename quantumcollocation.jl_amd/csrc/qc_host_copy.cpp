@@ -5,6 +5,7 @@
 #include <immintrin.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 namespace {
@@ -89,8 +90,40 @@ size_t qc_host_scan(const double* p, size_t n, unsigned long long sentinel) {
     return fn(p, n, sentinel);
 }
 
-// p[0 .. n) = sentinel (ordinary stores: the lines were just read by the same thread)
-void qc_host_fill(double* p, size_t n, unsigned long long sentinel) {
+namespace {
+__attribute__((target("avx512f"))) void fill_nt512(double* p, size_t n, unsigned long long s) {
     unsigned long long* u = (unsigned long long*)p;
-    for (size_t i = 0; i < n; ++i) u[i] = sentinel;
+    const __m512i sv = _mm512_set1_epi64((long long)s);
+    size_t i = 0;
+    while (i < n && ((uintptr_t)(u + i) & 63)) u[i++] = s;
+    for (; i + 8 <= n; i += 8) _mm512_stream_si512((__m512i*)(u + i), sv);
+    for (; i < n; ++i) u[i] = s;
+}
+__attribute__((target("avx2"))) void fill_nt256(double* p, size_t n, unsigned long long s) {
+    unsigned long long* u = (unsigned long long*)p;
+    const __m256i sv = _mm256_set1_epi64x((long long)s);
+    size_t i = 0;
+    while (i < n && ((uintptr_t)(u + i) & 31)) u[i++] = s;
+    for (; i + 4 <= n; i += 4) _mm256_stream_si256((__m256i*)(u + i), sv);
+    for (; i < n; ++i) u[i] = s;
+}
+void fill_plain(double* p, size_t n, unsigned long long s) {
+    unsigned long long* u = (unsigned long long*)p;
+    for (size_t i = 0; i < n; ++i) u[i] = s;
+}
+typedef void (*fill_fn)(double*, size_t, unsigned long long);
+fill_fn pick_fill(int mode) {
+    __builtin_cpu_init();
+    if (mode == 0) return fill_plain;
+    if (__builtin_cpu_supports("avx512f")) return fill_nt512;
+    if (__builtin_cpu_supports("avx2")) return fill_nt256;
+    return fill_plain;
+}
+}  // namespace
+
+// p[0 .. n) = sentinel.  Non-temporal stores (QC_HOST_FILL_NT=0: ordinary ones): the block is written next by the GPU's copy
+// engine, and a line left dirty in a CPU cache would have to be probed out of it first.
+void qc_host_fill(double* p, size_t n, unsigned long long sentinel) {
+    static const fill_fn fn = pick_fill(getenv("QC_HOST_FILL_NT") ? atoi(getenv("QC_HOST_FILL_NT")) : 1);
+    fn(p, n, sentinel);
 }

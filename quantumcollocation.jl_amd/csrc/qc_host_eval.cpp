@@ -3,6 +3,7 @@
 // (one process, N GPUs: per-shard threads / streams / pinned staging, optional in-library RCCL all-gather).
 // Descriptor validation, structures and handle lifetime are in qc_host.cpp.  No CPU evaluation path anywhere.
 #include <dlfcn.h>
+#include <pthread.h>
 #include <sched.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -279,8 +280,60 @@ struct HostGroup {   // completion of one call's jobs
     void done() { std::lock_guard<std::mutex> lk(mu); if (--outstanding == 0) cv.notify_all(); }
     void wait() { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return outstanding == 0; }); }
 };
+// CPU sets of the L3 domains (core complexes) on the NUMA node the device hangs off, from sysfs; empty when anything is unreadable.
+// A core complex of the MI355X hosts' EPYC has one link to the memory controllers (~30 - 60 GB/s of writes): the replication
+// team writes 41.5 MB per config-3 call and only keeps up with the PCIe link when its members sit on DIFFERENT complexes, next to
+// the memory the GPU's copy engine writes.  Left to the scheduler inside a 16-CPU quota on a 256-thread host they land anywhere,
+// often several to a complex and on the far socket (run-to-run spread 0.30 - 0.45 ms per call).
+static bool parse_cpulist(const char* path, cpu_set_t* set) {
+    FILE* f = fopen(path, "r");
+    if (!f) return false;
+    CPU_ZERO(set);
+    int a, b;
+    bool any = false;
+    for (;;) {
+        if (fscanf(f, "%d", &a) != 1) break;
+        b = a;
+        int c = fgetc(f);
+        if (c == '-') { if (fscanf(f, "%d", &b) != 1) break; c = fgetc(f); }
+        for (int i = a; i <= b && i < CPU_SETSIZE; ++i) { CPU_SET(i, set); any = true; }
+        if (c != ',') break;
+    }
+    fclose(f);
+    return any;
+}
+static std::vector<cpu_set_t> device_l3_domains(int device) {
+    std::vector<cpu_set_t> out;
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device) != hipSuccess) return out;
+    for (char* p = bus; *p; ++p) if (*p >= 'A' && *p <= 'F') *p = (char)(*p - 'A' + 'a');
+    char path[256];
+    snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bus);
+    int node = -1;
+    if (FILE* f = fopen(path, "r")) { if (fscanf(f, "%d", &node) != 1) node = -1; fclose(f); }
+    if (node < 0) return out;
+    cpu_set_t node_set, allowed;
+    snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+    if (!parse_cpulist(path, &node_set)) return out;
+    if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return out;
+    cpu_set_t seen;
+    CPU_ZERO(&seen);
+    for (int c = 0; c < CPU_SETSIZE; ++c) {
+        if (!CPU_ISSET(c, &node_set) || !CPU_ISSET(c, &allowed) || CPU_ISSET(c, &seen)) continue;
+        cpu_set_t dom;
+        snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", c);
+        if (!parse_cpulist(path, &dom)) return std::vector<cpu_set_t>();
+        cpu_set_t use;
+        CPU_AND(&use, &dom, &allowed);
+        CPU_OR(&seen, &seen, &dom);
+        if (CPU_COUNT(&use) > 0) out.push_back(use);
+    }
+    return out;
+}
+
 struct HostPool {
     std::vector<std::thread> th;
+    std::vector<cpu_set_t> domains;       // where the members go (device_l3_domains of the first device served), or empty
     std::mutex mu;
     std::condition_variable cv;
     std::deque<std::pair<std::function<void()>, HostGroup*>> q;
@@ -300,9 +353,19 @@ struct HostPool {
             lk.lock();
         }
     }
-    void ensure(int n) {
+    void ensure(int n, int device = -1) {
         std::lock_guard<std::mutex> lk(mu);
-        while ((int)th.size() < n) th.emplace_back([this] { run(); });
+        // QC_HOST_AFFINITY=0: leave the members to the scheduler
+        static const bool pin = !(getenv("QC_HOST_AFFINITY") && atoi(getenv("QC_HOST_AFFINITY")) == 0);
+        if (th.empty() && pin && device >= 0) domains = device_l3_domains(device);
+        while ((int)th.size() < n) {
+            th.emplace_back([this] { run(); });
+            if (!domains.empty()) {
+                // member i on complex (i + 1) mod n: complex 0 is left to the calling thread's side of the work when it happens to be there
+                const cpu_set_t& set = domains[(th.size()) % domains.size()];
+                (void)pthread_setaffinity_np(th.back().native_handle(), sizeof(cpu_set_t), &set);
+            }
+        }
     }
     void push(std::function<void()> fn, HostGroup* g) {
         g->add();
@@ -548,15 +611,20 @@ struct LandJob {
     std::unique_ptr<std::atomic<int>[]> claimed;
     std::atomic<int> remaining{0};
     std::atomic<int> done{0};                           // 1: the copy's completion event has been seen, 2: it reported an error
-    std::atomic<double> t_first_piece{0.0}, t_last_piece{0.0};   // trace (QC_HOST_TRACE)
+    std::atomic<double> t_first_piece{0.0}, t_last_piece{0.0}, t_event{0.0};   // trace (QC_HOST_TRACE)
+    std::atomic<int> pieces_at_event{0}, blocks_waited{0};       // trace: pieces done when the copy's end was seen; blocks a member had to wait for
+    std::atomic<int> n_members{0};
+    int member_cpu[64], member_pieces[64];                       // trace: where each team member ran, how many pieces it took
 };
 
 inline void cpu_pause() { __builtin_ia32_pause(); }
 
 inline void land_poll(LandJob& J, hipEvent_t ev) {   // calling thread only
     const hipError_t e = hipEventQuery(ev);
-    if (e == hipSuccess) J.done.store(1, std::memory_order_release);
-    else if (e != hipErrorNotReady) J.done.store(2, std::memory_order_release);
+    if (e == hipSuccess) {
+        if (host_trace() && !J.done.load()) { J.t_event.store(now_us()); J.pieces_at_event.store((int)J.bound.size() - 1 - J.remaining.load()); }
+        J.done.store(1, std::memory_order_release);
+    } else if (e != hipErrorNotReady) J.done.store(2, std::memory_order_release);
 }
 
 // spins until no word of p[0 .. n) holds the sentinel, or the copy is known to be complete (`poll`: this is the calling thread,
@@ -568,7 +636,9 @@ inline void land_wait(LandJob& J, const double* p, size_t n, hipEvent_t ev, bool
         off += qc_host_scan(p + off, n - off, kLandSentinel);
         if (off >= n) return;
         if (J.done.load(std::memory_order_acquire)) return;
-        if (poll && (++spins & 15) == 0) land_poll(J, ev);
+        if (spins == 0 && host_trace()) J.blocks_waited.fetch_add(1, std::memory_order_relaxed);
+        if (poll && (++spins & 15) == 15) land_poll(J, ev);
+        else ++spins;
         cpu_pause();
     }
 }
@@ -599,7 +669,8 @@ void land_piece(LandJob& J, int k, hipEvent_t ev, bool poll) {
 // unclaimed piece; any order would work), until none is left.  `poll`: the calling thread also polls the completion event.
 void land_consume(LandJob& J, hipEvent_t ev, bool poll) {
     const int np = (int)J.bound.size() - 1;
-    int lo = 0;
+    int lo = 0, mine = 0;
+    const int me = host_trace() ? J.n_members.fetch_add(1) : 0;
     while (J.remaining.load(std::memory_order_acquire) > 0) {
         bool got = false;
         const bool all = J.done.load(std::memory_order_acquire) != 0;
@@ -619,11 +690,13 @@ void land_consume(LandJob& J, hipEvent_t ev, bool poll) {
             }
             J.remaining.fetch_sub(1, std::memory_order_acq_rel);
             got = true;
+            ++mine;
             break;
         }
         if (poll && !all) land_poll(J, ev);
         if (!got) cpu_pause();
     }
+    if (host_trace() && me < 64) { J.member_cpu[me] = sched_getcpu(); J.member_pieces[me] = mine; }
 }
 
 int land_piece_intervals(size_t block_bytes) {   // ~128 KB of pinned block per piece, at least 2 intervals (QC_HOST_PIECE_KB)
@@ -661,7 +734,7 @@ static int wait_done(qc_handle* h, int shards) {
 static int land_run(qc_handle* h, LandJob& J, int shards, double t_begin, double t_issued) {
     HostPool& pool = host_pool();
     const int workers = pool_workers(shards);
-    pool.ensure(workers);
+    pool.ensure(workers, h->device);
     J.bound.assign(1, 0);
     const int per = land_piece_intervals(J.blk * sizeof(double));
     for (int b = per; b < J.n_int; b += per) J.bound.push_back(b);
@@ -687,8 +760,14 @@ static int land_run(qc_handle* h, LandJob& J, int shards, double t_begin, double
     if (J.done.load() != 1) rc = wait_done(h, shards);
     if (host_trace())
         fprintf(stderr, "qcolloc host trace (%d pieces, %d helpers): inputs, launch and copy issued +%.0f us, first piece done +%.0f, last piece done +%.0f, "
-                "team done +%.0f, event seen +%.0f us\n", np, helpers, t_issued - t_begin, J.t_first_piece.load() ? J.t_first_piece.load() - t_begin : 0.0,
-                J.t_last_piece.load() ? J.t_last_piece.load() - t_begin : 0.0, t_consumed - t_begin, now_us() - t_begin);
+                "team done +%.0f us; copy seen complete +%.0f with %d pieces done; %d of %d blocks were waited for\n", np, helpers, t_issued - t_begin,
+                J.t_first_piece.load() ? J.t_first_piece.load() - t_begin : 0.0, J.t_last_piece.load() ? J.t_last_piece.load() - t_begin : 0.0,
+                t_consumed - t_begin, J.t_event.load() ? J.t_event.load() - t_begin : -1.0, J.pieces_at_event.load(), J.blocks_waited.load(), J.n_int);
+    if (host_trace()) {
+        fprintf(stderr, "    members (cpu:pieces):");
+        for (int i = 0; i < std::min(64, J.n_members.load()); ++i) fprintf(stderr, " %d:%d", J.member_cpu[i], J.member_pieces[i]);
+        fprintf(stderr, "\n");
+    }
     if (rc || J.done.load() == 2) {
         h->hC_armed = false;
         if (!rc) { (void)hipStreamSynchronize(h->stream); rc = fail(&h->err, QC_ERR_HIP, "the evaluation failed on the device"); }
@@ -697,6 +776,40 @@ static int land_run(qc_handle* h, LandJob& J, int shards, double t_begin, double
 }
 
 static int eval_host_chunked(qc_handle* h, const double* Z, double* F, double* vals, int shards);
+
+extern "C" int qc_debug_host_expand_rate(qc_handle* h, int32_t reps, double* GBps) {
+    if (!h || !GBps || reps < 1) return fail(h ? &h->err : nullptr, QC_ERR_INVALID, "qc_debug_host_expand_rate: bad argument");
+    qc_handle* s = is_multi(h) ? h->shards[0] : h;
+    const QcParams& P = s->prm;
+    const CompactPlan cp = compact_plan(P);
+    if (!cp.useful || P.n_int == 0) return fail(&h->err, QC_ERR_UNSUPPORTED, "qc_debug_host_expand_rate: no replicated blocks in this handle's Jacobian");
+    const int n_int = P.n_int;
+    std::vector<double> comp((size_t)n_int * cp.comp_len, 1.0), vals((size_t)n_int * P.jac_nnz);
+    HostPool& pool = host_pool();
+    const int workers = pool_workers(1);
+    pool.ensure(workers);
+    const int per = land_piece_intervals((size_t)cp.comp_len * sizeof(double));
+    double best = 0.0;
+    for (int r = 0; r < reps + 1; ++r) {
+        std::atomic<int> next{0};
+        auto work = [&] {
+            for (;;) {
+                const int b0 = next.fetch_add(per);
+                if (b0 >= n_int) return;
+                expand_intervals(P, cp, comp.data(), vals.data(), b0, std::min(n_int, b0 + per));
+            }
+        };
+        HostGroup grp;
+        const double t0 = now_us();
+        pool.push_many(work, workers, &grp);
+        work();
+        grp.wait();
+        const double dt = now_us() - t0;
+        if (r > 0) best = std::max(best, (double)n_int * P.jac_nnz * sizeof(double) / dt / 1e3);   // (the first pass touches fresh pages)
+    }
+    *GBps = best;
+    return QC_OK;
+}
 
 static int eval_host(qc_handle* h, const double* Z, double* F, double* vals, int shards) {
     if (shares_values(h)) return fail(&h->err, QC_ERR_UNSUPPORTED, "composed handles write into shared vectors: use the _dev entry points");

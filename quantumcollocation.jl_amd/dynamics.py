@@ -335,6 +335,12 @@ class QuantumDynamics:
         is not read; stays in force until set_new_x(True) (qc_set_new_x)."""
         _lib.check(_lib.lib.qc_set_new_x(self._h, int(bool(new_x))), self._h)
 
+    def host_expand_rate(self, reps: int = 5) -> float:
+        """GB/s at which this host replicates the compact Jacobian form into the full value array (diagnostic, no GPU work)."""
+        r = C.c_double()
+        _lib.check(_lib.lib.qc_debug_host_expand_rate(self._h, reps, C.byref(r)), self._h)
+        return r.value
+
     # -- multi-device handles ---------------------------------------------------------------------
     @property
     def n_shards(self) -> int:

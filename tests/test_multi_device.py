@@ -180,6 +180,60 @@ def test_multi_handle_device_resident_and_all_gather(qc, oracle):
 
 
 @pytest.mark.gpu
+def test_multi_handle_on_distinct_devices_with_rccl_all_gather(qc, oracle):
+    """Runs wherever at least two GPUs are visible (the driver's 8-GPU box; skipped on the 1-GPU boxes): one shard per device,
+    qc_multi_eval_*_dev on each device's own vectors, then the in-library RCCL all-gather with one rank per device -- afterwards
+    EVERY device holds the full value vector, bit-identical to a single-device evaluation; the host-buffer entry points of the
+    same handle (N PCIe links) return the same arrays."""
+    ndev = torch.cuda.device_count()
+    if ndev < 2:
+        pytest.skip("needs at least two GPUs")
+    L = qc._lib
+    shards = min(ndev, 8)
+    T = 64 * shards + 1 + 5          # a short last shard
+    inp = qc.config_inputs(3, T=T)
+    Z = inp.traj.datavec
+    one = qc.QuantumDynamics(inp.integrators, inp.traj, device=0)
+    F1, J1 = one.F_dF(Z)
+    mu = np.random.default_rng(9).standard_normal(one.dims.n_rows)
+    H1 = one.mu_d2F(Z, mu)
+    many = qc.QuantumDynamics(inp.integrators, inp.traj, devices=list(range(shards)))
+    assert many.n_shards == shards and [many.shard_info(i)[0] for i in range(shards)] == list(range(shards))
+    # host buffers through N devices
+    Fm, Jm = many.F_dF(Z)
+    np.testing.assert_array_equal(Fm, F1)
+    np.testing.assert_array_equal(Jm, J1)
+    np.testing.assert_array_equal(many.mu_d2F(Z, mu), H1)
+    np.testing.assert_array_equal(many.F(Z), F1)
+    # device-resident + all-gather
+    nj, nf, nh = int(one.dims.jac_nnz_interval), int(one.dims.ddim), int(one.dims.hess_nnz_interval)
+    lens = {k: int(L.lib.qc_multi_padded_len(many._h, k)) for k in (nj, nf, nh)}
+    dZ, dmu, dJ, dF, dH = [], [], [], [], []
+    for i in range(shards):
+        dev = torch.device("cuda", i)
+        dZ.append(torch.from_numpy(Z).to(dev))
+        dmu.append(torch.from_numpy(mu).to(dev))
+        dJ.append(torch.full((lens[nj],), float("nan"), dtype=torch.float64, device=dev))
+        dF.append(torch.full((lens[nf],), float("nan"), dtype=torch.float64, device=dev))
+        dH.append(torch.full((lens[nh],), float("nan"), dtype=torch.float64, device=dev))
+    for i in range(shards):
+        torch.cuda.synchronize(i)      # qcolloc.h: inputs complete before qc_multi_eval_*_dev (internal streams)
+    arr = lambda ts: (C.c_void_p * shards)(*[t.data_ptr() for t in ts])
+    L.check(L.lib.qc_multi_eval_F_jac_dev(many._h, arr(dZ), arr(dF), arr(dJ)), many._h)
+    L.check(L.lib.qc_multi_eval_hess_dev(many._h, arr(dZ), arr(dmu), arr(dH)), many._h)
+    for bufs, per in ((dJ, nj), (dF, nf), (dH, nh)):
+        L.check(L.lib.qc_multi_all_gather_dev(many._h, arr(bufs), per), many._h)
+    L.check(L.lib.qc_multi_sync(many._h), many._h)
+    for i in range(shards):
+        np.testing.assert_array_equal(dJ[i].cpu().numpy()[:J1.size], J1)
+        np.testing.assert_array_equal(dF[i].cpu().numpy()[:F1.size], F1)
+        np.testing.assert_array_equal(dH[i].cpu().numpy()[:H1.size], H1)
+    assert torch.cuda.current_device() == 0      # the library left the caller's device alone
+    many.close()
+    one.close()
+
+
+@pytest.mark.gpu
 def test_sharded_dynamics_with_real_handles(qc, oracle):
     """The process-per-GPU flavour (sharding.ShardedDynamics) with its default rank-local evaluator, the HIP handle: two
     and three ranks' shards on device 0, concatenated = the full evaluation; an empty tail shard is a valid no-op handle."""
