@@ -470,7 +470,10 @@ extern "C" void qc_destroy(qc_handle* h) {
     if (h->hJc) (void)hipHostFree(h->hJc);
     if (h->hFc) (void)hipHostFree(h->hFc);
     if (h->hZ) (void)hipHostFree(h->hZ);
-    if (h->hC) (void)hipHostFree(h->hC);
+    for (int i = 0; i < 2; ++i) {
+        if (h->rearm[i]) qc_rearm_destroy(h->rearm[i]);     // (its jobs write into hC[i])
+        if (h->hC[i]) (void)hipHostFree(h->hC[i]);
+    }
     if (h->dC) (void)hipFree(h->dC);
     if (h->ev_done) (void)hipEventDestroy(h->ev_done);
     if (h->dBatch) (void)hipFree(h->dBatch);

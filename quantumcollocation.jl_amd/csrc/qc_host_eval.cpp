@@ -604,6 +604,7 @@ struct LandJob {
     // the watched pinned block: one sub-block of `blk` doubles per interval = [ residual rows (f_len) | compact Jacobian values ]
     double* src = nullptr;
     size_t blk = 0, f_len = 0;
+    bool rearm_inline = false;
     double* vals = nullptr;                             // caller's Jacobian values (replication target)
     double* F = nullptr;                                // caller's residuals, or nullptr
     int n_int = 0;
@@ -618,6 +619,15 @@ struct LandJob {
 };
 
 inline void cpu_pause() { __builtin_ia32_pause(); }
+
+bool land_inline_rearm() {   // QC_HOST_REARM=inline: every block re-armed by the member that consumed it, inside the call (A/B diagnostics)
+    static const bool v = getenv("QC_HOST_REARM") && !strcmp(getenv("QC_HOST_REARM"), "inline");
+    return v;
+}
+bool land_nowatch() {        // QC_HOST_NOWATCH=1: the team does not look at the block before the copy's completion event (how long does the copy take alone?)
+    static const bool v = getenv("QC_HOST_NOWATCH") && atoi(getenv("QC_HOST_NOWATCH"));
+    return v;
+}
 
 inline void land_poll(LandJob& J, hipEvent_t ev) {   // calling thread only
     const hipError_t e = hipEventQuery(ev);
@@ -660,7 +670,7 @@ void land_piece(LandJob& J, int k, hipEvent_t ev, bool poll) {
         for (int c = 0; c < J.cp.copies; ++c) cpy(dst + P.jo_F + (size_t)c * J.cp.n2, src, (size_t)J.cp.n2);
         for (int c = 0; c < J.cp.second_copies; ++c) cpy(dst + P.jo_B + (size_t)c * J.cp.n2, src + J.cp.n2, (size_t)J.cp.n2);
         cpy(dst + J.cp.tail_src, src + J.cp.head2, (size_t)J.cp.tail_len);
-        qc_host_fill(blk, J.blk, kLandSentinel);
+        if (J.rearm_inline) qc_host_fill(blk, J.blk, kLandSentinel);
     }
     qc_host_copy_fence();
 }
@@ -678,7 +688,7 @@ void land_consume(LandJob& J, hipEvent_t ev, bool poll) {
         // (only a few pieces beyond the frontier are looked at: reads of lines the copy engine is about to write cost it a snoop each)
         for (int k = lo; k < np && (all || k < lo + 4); ++k) {
             if (J.claimed[k].load(std::memory_order_relaxed)) continue;
-            if (!all && !land_started(J, J.bound[k])) continue;
+            if (!all && (land_nowatch() || !land_started(J, J.bound[k]))) continue;
             int expect = 0;
             if (!J.claimed[k].compare_exchange_strong(expect, 1, std::memory_order_acq_rel)) continue;
             land_piece(J, k, ev, poll);
@@ -768,11 +778,15 @@ static int land_run(qc_handle* h, LandJob& J, int shards, double t_begin, double
         for (int i = 0; i < std::min(64, J.n_members.load()); ++i) fprintf(stderr, " %d:%d", J.member_cpu[i], J.member_pieces[i]);
         fprintf(stderr, "\n");
     }
-    if (rc || J.done.load() == 2) {
-        h->hC_armed = false;
-        if (!rc) { (void)hipStreamSynchronize(h->stream); rc = fail(&h->err, QC_ERR_HIP, "the evaluation failed on the device"); }
-    }
+    if (!rc && J.done.load() == 2) { (void)hipStreamSynchronize(h->stream); rc = fail(&h->err, QC_ERR_HIP, "the evaluation failed on the device"); }
     return rc;
+}
+
+struct qc_rearm { HostGroup grp; };
+void qc_rearm_destroy(qc_rearm* r) {
+    if (!r) return;
+    r->grp.wait();
+    delete r;
 }
 
 static int eval_host_chunked(qc_handle* h, const double* Z, double* F, double* vals, int shards);
@@ -852,23 +866,40 @@ static int eval_host(qc_handle* h, const double* Z, double* F, double* vals, int
     J.F = F;
     const size_t cap = (size_t)P.n_int * ((size_t)P.F_stride + (size_t)cp.comp_len);
     if ((rc = ensure_zeroed(h, &h->dC, cap))) return rc;      // (zeroed once: residual rows no kernel writes are delivered as 0)
-    if ((rc = ensure_pinned(h, &h->hC, cap, false))) return rc;
-    if (!h->hC_armed) { qc_host_fill(h->hC, cap, kLandSentinel); h->hC_armed = true; }
-    J.src = h->hC;
+    const int ib = h->hC_next;
+    h->hC_next ^= 1;
+    if ((rc = ensure_pinned(h, &h->hC[ib], cap, false))) return rc;
+    if (h->rearm[ib]) h->rearm[ib]->grp.wait();               // the re-arm jobs of this block's previous use (normally long done)
+    if (!h->hC_armed[ib]) { qc_host_fill(h->hC[ib], cap, kLandSentinel); h->hC_armed[ib] = true; }
+    J.src = h->hC[ib];
+    J.rearm_inline = land_inline_rearm();
     QcParams C = compact_params(P, cp);
     C.J_stride = (long long)J.blk;
     C.J_off = (long long)J.f_len;
     C.F_stride = (long long)J.blk;
     const hipError_t e = qc_launch_mfma_F_jac(C, h->dZ, with_F ? h->dC : nullptr, h->dC, h->stream);
     if (e != hipSuccess) return fail(&h->err, QC_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
-    hipError_t ec = hipMemcpyAsync(h->hC, h->dC, (size_t)P.n_int * J.blk * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+    const size_t used = (size_t)P.n_int * J.blk;
+    hipError_t ec = hipMemcpyAsync(h->hC[ib], h->dC, used * sizeof(double), hipMemcpyDeviceToHost, h->stream);
     if (ec == hipSuccess) ec = hipEventRecord(h->ev_done, h->stream);
     if (ec != hipSuccess) {
         (void)hipStreamSynchronize(h->stream);
-        h->hC_armed = false;
+        h->hC_armed[ib] = false;
         return fail(&h->err, QC_ERR_HIP, std::string("copy of the compact values: ") + hipGetErrorString(ec));
     }
-    return land_run(h, J, shards, t_begin, now_us());
+    rc = land_run(h, J, shards, t_begin, now_us());
+    if (rc) { h->hC_armed[ib] = false; return rc; }
+    if (!J.rearm_inline) {
+        // the consumed part of the block is re-armed behind the caller's back, in a few pieces, by whichever workers are idle
+        if (!h->rearm[ib]) h->rearm[ib] = new qc_rearm();
+        double* base = h->hC[ib];
+        const size_t piece = std::max<size_t>(size_t(1) << 17, (used + 7) / 8);      // doubles: at most 8 jobs, at least 1 MB each
+        for (size_t o = 0; o < used; o += piece) {
+            const size_t len = std::min(piece, used - o);
+            host_pool().push([base, o, len] { qc_host_fill(base + o, len, kLandSentinel); qc_host_copy_fence(); }, &h->rearm[ib]->grp);
+        }
+    }
+    return QC_OK;
 }
 
 // The chunked host path of round 2 (one launch per chunk of intervals, events between them) -- what kernels that cannot write
@@ -972,10 +1003,11 @@ static int hess_host(qc_handle* h, const double* Z, const double* mu, double* hv
     if ((rc = upload_knots(h, Z))) return rc;
     const size_t m0 = (size_t)P.t_begin * P.F_stride, mn = (size_t)P.n_int * P.F_stride;
     // The values have no replicated blocks: kernel -> HBM, then the copy engine straight into the caller's array (14.7 MB at
-    // config 3: 0.27 ms at the link's 54.5 GB/s; the runtime pins the caller's pages in place).  The multipliers go up and the
-    // values come down in QC_HOST_HESS_CHUNKS pieces (default 4) on two streams, so that all but the first piece of the upload
-    // and all but the first kernel run under the download of the piece before.
-    static const int want = getenv("QC_HOST_HESS_CHUNKS") ? std::max(1, atoi(getenv("QC_HOST_HESS_CHUNKS"))) : 4;
+    // config 3: 0.27 ms at the link's 54.5 GB/s; the runtime pins the caller's pages in place, and the call blocks meanwhile).
+    // QC_HOST_HESS_CHUNKS > 1 sends the multipliers up and the values down in pieces on two streams; measured at config 3
+    // (profiles/r03_host_path.txt): 1 piece 0.344 ms, 2 pieces 0.405, 4 pieces 0.46 - 0.48, 8 pieces 0.66 -- a copy into pageable
+    // memory returns when it is done, so the pieces do not overlap and each pays its own set-up.  Default 1.
+    static const int want = getenv("QC_HOST_HESS_CHUNKS") ? std::max(1, atoi(getenv("QC_HOST_HESS_CHUNKS"))) : 1;
     const bool chunkable = h->kernel == QC_KERNEL_MFMA && qc_mfma_hess_supported(P) && !qc_mfma64_hess_supported(P) && !qc_mfma16_padeP_hess_supported(P) &&
                            h->host_compact != 0;
     const int n_chunks = chunkable ? std::max(1, std::min(want, P.n_int / 64)) : 1;

@@ -56,6 +56,8 @@ struct qc_fanout;
 void qc_fanout_destroy(qc_fanout* f);
 struct qc_rccl_state;
 void qc_rccl_destroy(qc_rccl_state* r);
+struct qc_rearm;
+void qc_rearm_destroy(qc_rearm* r);      // waits for the background re-arm jobs of a pinned block
 
 // Selects a HIP device for the lifetime of the object and restores the caller's current device afterwards (every entry
 // point uses one: the library never leaves the calling thread on another device than it found).
@@ -90,9 +92,14 @@ struct qc_handle {
     double* hZ = nullptr;      // pinned staging of this handle's knots for the host-to-device copy
     // One-launch host path ("landing watch", qc_host_eval.cpp): per interval [ residual rows | compact Jacobian values ], written by
     // the kernel into dC, copied into hC by the copy engine; hC holds a sentinel word wherever the copy has not arrived yet
+    // Two pinned blocks take turns: the one a call has consumed is re-armed with the sentinel by pool workers AFTER the call has
+    // returned (off the caller's critical path, and off the memory traffic next to the copy engine's writes); the next call
+    // that wants that block waits for its re-arm jobs first.
     double* dC = nullptr;
-    double* hC = nullptr;
-    bool hC_armed = false;     // hC is completely sentinel-filled (cleared when a call fails midway)
+    double* hC[2] = {nullptr, nullptr};
+    bool hC_armed[2] = {false, false};   // completely sentinel-filled once `rearm[i]` has drained (cleared when a call fails midway)
+    struct qc_rearm* rearm[2] = {nullptr, nullptr};
+    int hC_next = 0;
     int new_x = 1;             // qc_set_new_x: 0 = the knots on the device are current, Z is not read
     bool z_valid = false;      // dZ holds this handle's knots of SOME host-buffer call
     hipEvent_t ev_done = nullptr;    // end of the one launch of a host-buffer call
