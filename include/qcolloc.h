@@ -208,7 +208,8 @@ int qc_dims(const qc_handle* h, qc_dims_t* out);
 /* Names of the device kernels this handle's evaluations run on (diagnostic; static strings, never NULL):
  * which = 0: F / F + dF ("mfma16-pade4", "mfma16-padeP", "mfma32-pade4", "mfma64-pade4", "mfma16-exp", "mfma32-exp",
  * "lds", "lds-gws");  which = 1: mu_d2F ("mfma16-pade4-hess", "mfma16-padeP-hess", "mfma32-pade4-hess",
- * "mfma64-pade4-hess", "lds-hess", "lds-gws-hess", or "none" for the exponential integrator). */
+ * "mfma64-pade4-hess", "lds-hess", "lds-gws-hess", or "none" for the exponential integrator);  which = 2: qc_eval_F_jac_hess_dev
+ * ("mfma16-pade4-fused", or "two-launches"). */
 const char* qc_kernel_name(const qc_handle* h, int32_t which);
 int qc_jac_structure(const qc_handle* h, int64_t* rows, int64_t* cols, int one_based);
 int qc_hess_structure(const qc_handle* h, int64_t* rows, int64_t* cols, int one_based);
@@ -234,6 +235,12 @@ int qc_set_new_x(qc_handle* h, int new_x);
  * (interval t_begin first) and must be 8-byte aligned (the kernels issue 8-byte stores only). */
 int qc_eval_F_jac_dev(qc_handle* h, const double* dZ, double* dF, double* dvals, void* stream);
 int qc_eval_hess_dev(qc_handle* h, const double* dZ, const double* dmu, double* dhvals, void* stream);
+
+/* dynamics.dF(Z) and dynamics.mu_d2F(Z, mu) (and F) at the same Z in one call -- what Ipopt asks for at every accepted point
+ * (integrator_test_1qubit.jl:46,52).  One kernel launch where a fused kernel serves the handle (qc_kernel_name(h, 2):
+ * "mfma16-pade4-fused" -- order-4 Pade, a unitary on 8 levels, Hermitian Hamiltonians, up to 6 drives: BASELINE configs 3 / 4), else
+ * the two launches of qc_eval_F_jac_dev and qc_eval_hess_dev on `stream`; the values are bit-identical either way.  dF may be NULL. */
+int qc_eval_F_jac_hess_dev(qc_handle* h, const double* dZ, const double* dmu, double* dF, double* dvals, double* dhvals, void* stream);
 
 /* Several handles over the same trajectory in ONE launch: the K unitary integrators of a `UnitarySamplingProblem`
  * (reference unitary_sampling_problem.jl:134-155), each created with its slot of the shared per-interval blocks

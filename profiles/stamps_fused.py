@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Diagnostic timeline of the fused F + dF + mu_d2F kernel (qc_mfma_fused.hip, QC_STAMPS=1): per-wave s_memrealtime checkpoints of
+both roles.  Run on the GPU box:  python profiles/stamps_fused.py [T]"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["QC_STAMPS"] = "1"
+import __graft_entry__ as g
+
+qc = g.load_package()
+T = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+inp = qc.config_inputs(3, T=T)
+dyn = qc.QuantumDynamics(inp.integrators, inp.traj)
+Z = torch.from_numpy(inp.traj.datavec).cuda()
+mu = torch.from_numpy(np.random.default_rng(0).standard_normal(int(dyn.dims.n_rows))).cuda()
+nb = 16
+Fs = [torch.empty(dyn.dims.F_len, dtype=torch.float64, device="cuda") for _ in range(nb)]
+Js = [torch.empty(dyn.dims.jac_nnz, dtype=torch.float64, device="cuda") for _ in range(nb)]
+Hs = [torch.empty(dyn.dims.hess_nnz, dtype=torch.float64, device="cuda") for _ in range(nb)]
+for i in range(nb):
+    dyn.F_dF_mu_d2F_device(Z, mu, Fs[i], Js[i], Hs[i])
+torch.cuda.synchronize()
+n = dyn.dims.n_intervals
+out = np.zeros(n * 16, dtype=np.uint64)
+qc._lib.check(qc._lib.lib.qc_debug_read_stamps(dyn._h, out.ctypes.data_as(C.POINTER(C.c_uint64)), out.size), dyn._h)
+st = out.reshape(n, 16).astype(np.int64)
+names = {10: "copy wave: entry", 11: "copy wave: loads back, G assembled", 12: "copy wave: tile copies issued", 13: "copy wave: all its stores issued",
+         14: "copy wave: second barrier passed", 15: "copy wave: (a, a) sums stored, done",
+         0: "compute wave: entry", 1: "compute wave: hand-off received", 2: "compute wave: F + dF products, transposes done",
+         3: "compute wave: F + dF stores issued", 4: "compute wave: stage A done, tiles parked", 5: "compute wave: second barrier passed",
+         6: "compute wave: stage B issued", 7: "compute wave: Hessian matrix stores issued", 8: "compute wave: all stores issued", 9: "compute wave: drained"}
+t0 = st[st > 0].min()
+rel = (st - t0) * 10.0 / 1e3
+print(f"T={T}: {n} intervals; one call = {dyn.fused_kernel_name}; span (first entry -> last compute wave drained) = {rel[:, 9].max():.2f} us")
+for order in ([10, 11, 12, 13, 14, 15], [0, 1, 2, 3, 4, 5, 6, 7, 8, 9]):
+    prev = None
+    for k in order:
+        ok = st[:, k] > 0
+        if not ok.any():
+            continue
+        col = rel[:, k][ok]
+        step = "" if prev is None else f"   (+{np.median(rel[:, k][ok] - rel[:, prev][ok]):.2f} per wave)"
+        print(f"  {k:2d} {names[k]:52s} min {col.min():7.2f}  median {np.median(col):7.2f}  max {col.max():7.2f} us{step}")
+        prev = k

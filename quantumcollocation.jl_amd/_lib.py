@@ -162,6 +162,7 @@ SYMBOLS = {
     "qc_set_new_x": (C.c_int, [_H, C.c_int]),
     "qc_eval_F_jac_dev": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "qc_eval_hess_dev": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "qc_eval_F_jac_hess_dev": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "qc_eval_F_jac_dev_multi": (C.c_int, [C.POINTER(_H), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "qc_eval_hess_dev_multi": (C.c_int, [C.POINTER(_H), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "qc_create_multi": (C.c_int, [_DESC_P, C.c_int32, C.POINTER(C.c_int32), C.POINTER(_H)]),

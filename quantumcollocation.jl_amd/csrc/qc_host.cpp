@@ -470,7 +470,7 @@ extern "C" void qc_destroy(qc_handle* h) {
     if (h->hJc) (void)hipHostFree(h->hJc);
     if (h->hFc) (void)hipHostFree(h->hFc);
     if (h->hZ) (void)hipHostFree(h->hZ);
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < QC_HOST_RING; ++i) {
         if (h->rearm[i]) qc_rearm_destroy(h->rearm[i]);     // (its jobs write into hC[i])
         if (h->hC[i]) (void)hipHostFree(h->hC[i]);
     }
@@ -509,6 +509,7 @@ extern "C" const char* qc_kernel_name(const qc_handle* h, int32_t which) {
         return P.n > 32 ? "mfma64-pade4" : (P.n > 16 ? "mfma32-pade4" : "mfma16-pade4");
     }
     if (P.integrator != QC_PADE) return "none";
+    if (which == 2) return mfma && qc_mfma16_fused_supported(P) ? "mfma16-pade4-fused" : "two-launches";
     if (mfma && qc_mfma_hess_supported(P)) {
         if (qc_mfma16_padeP_hess_supported(P)) return "mfma16-padeP-hess";
         return P.n > 32 ? "mfma64-pade4-hess" : (P.n > 16 ? "mfma32-pade4-hess" : "mfma16-pade4-hess");

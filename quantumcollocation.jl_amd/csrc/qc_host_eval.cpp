@@ -171,6 +171,35 @@ extern "C" int qc_eval_hess_dev(qc_handle* h, const double* dZ, const double* dm
     return QC_OK;
 }
 
+// Jacobian and Hessian of the Lagrangian at one point in ONE launch where a fused kernel serves the handle (qc_mfma_fused.hip),
+// else the two launches, on the same stream: the result is the same bit for bit either way.
+extern "C" int qc_eval_F_jac_hess_dev(qc_handle* h, const double* dZ, const double* dmu, double* dF, double* dvals, double* dhvals, void* stream) {
+    if (!h) return fail(nullptr, QC_ERR_INVALID, "qc_eval_F_jac_hess_dev: NULL handle");
+    QC_NOT_MULTI(h, "qc_eval_F_jac_hess_dev");
+    if (h->prm.integrator != QC_PADE)
+        return fail(&h->err, QC_ERR_UNSUPPORTED, "no analytic Hessian for the exponential integrator (upstream has none either; use eval_hessian=false)");
+    if (!dZ || !dvals || (h->prm.hess_nnz && (!dmu || !dhvals))) return fail(&h->err, QC_ERR_INVALID, "qc_eval_F_jac_hess_dev: NULL buffer");
+    int rc;
+    if ((rc = check_align(h, dZ, 8, "dZ")) || (rc = check_align(h, dmu, 8, "dmu")) || (rc = check_align(h, dF, 8, "dF")) ||
+        (rc = check_align(h, dvals, 8, "dvals")) || (rc = check_align(h, dhvals, 8, "dhvals")))
+        return rc;
+    if (h->prm.n_int == 0) return QC_OK;
+    static const bool allow = !(getenv("QC_NO_FUSED") && atoi(getenv("QC_NO_FUSED")));
+    if (allow && h->kernel == QC_KERNEL_MFMA && qc_mfma16_fused_supported(h->prm)) {
+        qc_device_guard guard(h->device);
+        QC_HIP(h, guard.err);
+        const hipError_t e = qc_launch_mfma16_fused(h->prm, dZ, dmu, dF, dvals, dhvals, (hipStream_t)stream);
+        if (e != hipSuccess) return fail(&h->err, QC_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+        return QC_OK;
+    }
+    if (h->prm.hess_nnz == 0) return qc_eval_F_jac_dev(h, dZ, dF, dvals, stream);
+    // Two kernels, one after the other.  (mu_d2F on a second stream beside F + dF, between two events, was measured at config 5,
+    // where the first is bound by its stores and the second by the matrix pipes: 67 us against 53 -- the fork and join cost more
+    // than the overlap gives.)
+    if ((rc = qc_eval_F_jac_dev(h, dZ, dF, dvals, stream))) return rc;
+    return qc_eval_hess_dev(h, dZ, dmu, dhvals, stream);
+}
+
 // ------------------------------------------------------------------------------------------------
 //  Host-buffer evaluation (H2D -> kernel -> D2H, synchronous)
 // ------------------------------------------------------------------------------------------------
@@ -866,8 +895,9 @@ static int eval_host(qc_handle* h, const double* Z, double* F, double* vals, int
     J.F = F;
     const size_t cap = (size_t)P.n_int * ((size_t)P.F_stride + (size_t)cp.comp_len);
     if ((rc = ensure_zeroed(h, &h->dC, cap))) return rc;      // (zeroed once: residual rows no kernel writes are delivered as 0)
+    static const int ring = std::max(2, std::min(QC_HOST_RING, getenv("QC_HOST_NBUF") ? atoi(getenv("QC_HOST_NBUF")) : 3));
     const int ib = h->hC_next;
-    h->hC_next ^= 1;
+    h->hC_next = (ib + 1) % ring;
     if ((rc = ensure_pinned(h, &h->hC[ib], cap, false))) return rc;
     if (h->rearm[ib]) h->rearm[ib]->grp.wait();               // the re-arm jobs of this block's previous use (normally long done)
     if (!h->hC_armed[ib]) { qc_host_fill(h->hC[ib], cap, kLandSentinel); h->hC_armed[ib] = true; }
@@ -893,7 +923,11 @@ static int eval_host(qc_handle* h, const double* Z, double* F, double* vals, int
         // the consumed part of the block is re-armed behind the caller's back, in a few pieces, by whichever workers are idle
         if (!h->rearm[ib]) h->rearm[ib] = new qc_rearm();
         double* base = h->hC[ib];
-        const size_t piece = std::max<size_t>(size_t(1) << 17, (used + 7) / 8);      // doubles: at most 8 jobs, at least 1 MB each
+        // QC_HOST_REARM_JOBS workers share it (default 2: a trickle that the next call's transfers hardly notice, done well before
+        // the block's next turn in the ring of 3; eight workers re-arm in a burst that slowed the next call's upload of Z from 30
+        // to 100 - 190 us when calls follow each other without a pause)
+        static const size_t jobs = getenv("QC_HOST_REARM_JOBS") ? (size_t)std::max(1, atoi(getenv("QC_HOST_REARM_JOBS"))) : 2;
+        const size_t piece = std::max<size_t>(size_t(1) << 17, (used + jobs - 1) / jobs);      // doubles: at least 1 MB each
         for (size_t o = 0; o < used; o += piece) {
             const size_t len = std::min(piece, used - o);
             host_pool().push([base, o, len] { qc_host_fill(base + o, len, kLandSentinel); qc_host_copy_fence(); }, &h->rearm[ib]->grp);

@@ -56,6 +56,7 @@ struct qc_fanout;
 void qc_fanout_destroy(qc_fanout* f);
 struct qc_rccl_state;
 void qc_rccl_destroy(qc_rccl_state* r);
+#define QC_HOST_RING 4      // pinned blocks of the host path taking turns (QC_HOST_NBUF uses the first 2 .. 4 of them)
 struct qc_rearm;
 void qc_rearm_destroy(qc_rearm* r);      // waits for the background re-arm jobs of a pinned block
 
@@ -92,13 +93,13 @@ struct qc_handle {
     double* hZ = nullptr;      // pinned staging of this handle's knots for the host-to-device copy
     // One-launch host path ("landing watch", qc_host_eval.cpp): per interval [ residual rows | compact Jacobian values ], written by
     // the kernel into dC, copied into hC by the copy engine; hC holds a sentinel word wherever the copy has not arrived yet
-    // Two pinned blocks take turns: the one a call has consumed is re-armed with the sentinel by pool workers AFTER the call has
-    // returned (off the caller's critical path, and off the memory traffic next to the copy engine's writes); the next call
+    // Several pinned blocks take turns: the one a call has consumed is re-armed with the sentinel by pool workers AFTER the call
+    // has returned (off the caller's critical path, and off the memory traffic next to the copy engine's writes); the next call
     // that wants that block waits for its re-arm jobs first.
     double* dC = nullptr;
-    double* hC[2] = {nullptr, nullptr};
-    bool hC_armed[2] = {false, false};   // completely sentinel-filled once `rearm[i]` has drained (cleared when a call fails midway)
-    struct qc_rearm* rearm[2] = {nullptr, nullptr};
+    double* hC[QC_HOST_RING] = {};
+    bool hC_armed[QC_HOST_RING] = {};    // completely sentinel-filled once `rearm[i]` has drained (cleared when a call fails midway)
+    struct qc_rearm* rearm[QC_HOST_RING] = {};
     int hC_next = 0;
     int new_x = 1;             // qc_set_new_x: 0 = the knots on the device are current, Z is not read
     bool z_valid = false;      // dZ holds this handle's knots of SOME host-buffer call
@@ -177,6 +178,9 @@ bool qc_mfma32_exp_supported(const QcParams& P);
 hipError_t qc_launch_mfma32_exp(const QcParams& P, const double* dZ, double* dF, double* dJ, hipStream_t st);
 bool qc_mfma32_hess_supported(const QcParams& P);
 hipError_t qc_launch_mfma32_hess(const QcParams& P, const double* dZ, const double* dMu, double* dH, hipStream_t st);
+// F + dF + mu_d2F in one launch (qc_mfma_fused.hip): 2N = 16, a unitary on 8 levels, antisymmetric generators, 1 .. 6 drives
+bool qc_mfma16_fused_supported(const QcParams& P);
+hipError_t qc_launch_mfma16_fused(const QcParams& P, const double* dZ, const double* dMu, double* dF, double* dJ, double* dH, hipStream_t st);
 hipError_t qc_launch_mfma_hess(const QcParams& P, const double* dZ, const double* dMu, double* dH, hipStream_t st, int grid_limit = 0);
 
 hipError_t qc_launch_pack_jac(const double* dJ, double* dJc, int n_int, int jac_nnz, int comp_len, int n2, int jo_F, int jo_B, int head2,

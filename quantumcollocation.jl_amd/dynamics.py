@@ -383,6 +383,31 @@ class QuantumDynamics:
             _lib.lib.qc_eval_F_jac_dev, self._h, self._dev_ptr(Z, self.dims.Z_len, "Z"),
             self._dev_ptr(F, self.dims.F_len, "F"), self._dev_ptr(J, self.dims.jac_nnz, "J"), C.c_void_p(st.cuda_stream))
 
+    def bind_F_dF_mu_d2F_device(self, Z: torch.Tensor, mu: torch.Tensor, F: Optional[torch.Tensor], J: torch.Tensor, H: torch.Tensor, stream=None):
+        """Pre-validated launcher of qc_eval_F_jac_hess_dev: dF and mu_d2F (and F) at one point in one call -- one kernel launch
+        where a fused kernel serves the handle (`fused_kernel_name`), two otherwise, same values."""
+        import functools
+        st = stream if stream is not None else torch.cuda.current_stream(self.device)
+        return functools.partial(
+            _lib.lib.qc_eval_F_jac_hess_dev, self._h, self._dev_ptr(Z, self.dims.Z_len, "Z"), self._dev_ptr(mu, self.dims.n_rows, "mu"),
+            self._dev_ptr(F, self.dims.F_len, "F"), self._dev_ptr(J, self.dims.jac_nnz, "J"), self._dev_ptr(H, self.dims.hess_nnz, "H"),
+            C.c_void_p(st.cuda_stream))
+
+    def F_dF_mu_d2F_device(self, Z, mu, F, J, H, stream=None) -> None:
+        _lib.check(self.bind_F_dF_mu_d2F_device(Z, mu, F, J, H, stream)(), self._h)
+
+    @property
+    def fused_kernel_name(self) -> str:
+        return _lib.lib.qc_kernel_name(self._h, 2).decode()
+
+    def bind_mu_d2F_device(self, Z: torch.Tensor, mu: torch.Tensor, H: torch.Tensor, stream=None):
+        """Pre-validated launcher of mu_d2F_device (see bind_F_dF_device)."""
+        import functools
+        st = stream if stream is not None else torch.cuda.current_stream(self.device)
+        return functools.partial(
+            _lib.lib.qc_eval_hess_dev, self._h, self._dev_ptr(Z, self.dims.Z_len, "Z"), self._dev_ptr(mu, self.dims.n_rows, "mu"),
+            self._dev_ptr(H, self.dims.hess_nnz, "H"), C.c_void_p(st.cuda_stream))
+
     def mu_d2F_device(self, Z: torch.Tensor, mu: torch.Tensor, H: torch.Tensor, stream=None) -> None:
         st = stream if stream is not None else torch.cuda.current_stream(self.device)
         _lib.check(_lib.lib.qc_eval_hess_dev(
@@ -496,6 +521,9 @@ class ComposedQuantumDynamics(QuantumDynamics):
 
     def bind_F_dF_device(self, Z, F, J, stream=None):
         return lambda: (self.F_dF_device(Z, F, J, stream), 0)[1]
+
+    def bind_mu_d2F_device(self, Z, mu, H, stream=None):
+        return lambda: (self.mu_d2F_device(Z, mu, H, stream), 0)[1]
 
     def rollout(self, Z, init):
         raise NotImplementedError("rollouts of a sampling problem are per system: build a QuantumDynamics per unitary integrator")

@@ -789,6 +789,51 @@ def test_compact_host_transfer_equals_full_transfer(qc, oracle, case, monkeypatc
         assert (H is None and ref[2] is None) or np.array_equal(H, ref[2]), k
 
 
+@pytest.mark.parametrize("case", ["cfg3", "cfg3_long", "cfg3_fixed_dt", "m1", "m2", "m3", "m4", "m5", "cfg5", "cfg1"])
+def test_fused_launch_is_bit_identical(qc, case):
+    """qc_eval_F_jac_hess_dev: dF and mu_d2F (and F) at one point in one call.  Where the fused kernel serves the handle (2N = 16,
+    1 .. 6 drives, Hermitian Hamiltonians: BASELINE configs 3 / 4) it is ONE launch whose values equal the two launches' bit for bit;
+    elsewhere the call is the two launches."""
+    import torch
+    fused_expected = True
+    if case == "cfg3":
+        inp = qc.config_inputs(3, T=257)
+    elif case == "cfg3_long":
+        inp = qc.config_inputs(3, T=1100)                  # > 1024 intervals: two launches of the fused kernel
+    elif case == "cfg3_fixed_dt":
+        inp = qc.unitary_smooth_pulse_inputs(qc.multi_qubit_system(3), qc.GATES["TOFFOLI"], 40, free_time=False)
+    elif case in ("m1", "m2", "m3", "m4", "m5"):
+        m = int(case[1])
+        rng = np.random.default_rng(m)
+        herm = lambda: (lambda A: (A + A.conj().T) / 2)(rng.standard_normal((8, 8)) + 1j * rng.standard_normal((8, 8)))
+        inp = qc.unitary_smooth_pulse_inputs(qc.QuantumSystem(herm(), [herm() for _ in range(m)]), qc.GATES["TOFFOLI"], 31)
+    elif case == "cfg5":
+        inp, fused_expected = qc.config_inputs(5, T=20), False
+    else:
+        inp, fused_expected = qc.config_inputs(1, T=50), False
+    dyn = qc.QuantumDynamics(inp.integrators, inp.traj)
+    assert (dyn.fused_kernel_name == "mfma16-pade4-fused") == fused_expected, dyn.fused_kernel_name
+    rng = np.random.default_rng(1)
+    Z = torch.from_numpy(inp.traj.datavec + 1e-2 * rng.standard_normal(inp.traj.datavec.size)).cuda()
+    mu = torch.from_numpy(rng.standard_normal(int(dyn.dims.n_rows))).cuda()
+    new = lambda n: torch.full((int(n),), float("nan"), dtype=torch.float64, device="cuda")
+    F1, J1, H1 = new(dyn.dims.F_len), new(dyn.dims.jac_nnz), new(dyn.dims.hess_nnz)
+    F2, J2, H2 = new(dyn.dims.F_len), new(dyn.dims.jac_nnz), new(dyn.dims.hess_nnz)
+    dyn.F_dF_device(Z, F1, J1)
+    dyn.mu_d2F_device(Z, mu, H1)
+    dyn.F_dF_mu_d2F_device(Z, mu, F2, J2, H2)
+    torch.cuda.synchronize()
+    for a, b, what in ((F1, F2, "F"), (J1, J2, "dF"), (H1, H2, "mu_d2F")):
+        assert not torch.isnan(b).any(), what
+        assert torch.equal(a, b), f"{what}: {(a != b).sum().item()} of {a.numel()} values differ, max {(a - b).abs().max().item():.3e}"
+    # without the residuals
+    J3, H3 = new(dyn.dims.jac_nnz), new(dyn.dims.hess_nnz)
+    dyn.F_dF_mu_d2F_device(Z, mu, None, J3, H3)
+    torch.cuda.synchronize()
+    assert torch.equal(J3, J1) and torch.equal(H3, H1)
+    dyn.close()
+
+
 @pytest.mark.parametrize("cfg,T", [(3, 257), (5, 33), (1, 50)])
 def test_new_x_elision_and_unaligned_buffers(qc, cfg, T):
     """qc_set_new_x(h, 0): the knots on the device are used and Z is not read at all (handing in garbage proves it); caller
