@@ -270,7 +270,10 @@ int qc_multi_shard_info(const qc_handle* h, int32_t i, int32_t* device, int64_t*
 /* Device-resident evaluation of every shard, each on its own device and internal stream, asynchronous; dZ[i] / dF[i] /
  * dvals[i] are DEVICE pointers on shard i's device: dZ[i] the full Z vector, dF[i] / dvals[i] FULL-LENGTH vectors of
  * the multi handle's range (shard i writes its slice at its offset; a chunk-padded length, qc_multi_padded_len, is
- * needed for the all-gather).  dF or dvals may be NULL.  qc_multi_sync waits for all shards. */
+ * needed for the all-gather).  dF or dvals may be NULL.  qc_multi_sync waits for all shards.
+ * Ordering: the launches go out on each shard's INTERNAL stream, which knows nothing of the streams that produced dZ[i] / dmu[i]:
+ * the inputs must be complete on their devices before these calls (synchronise the producing streams or devices first), and the
+ * outputs may be read after qc_multi_sync. */
 int qc_multi_eval_F_jac_dev(qc_handle* h, const double* const* dZ, double* const* dF, double* const* dvals);
 int qc_multi_eval_hess_dev(qc_handle* h, const double* const* dZ, const double* const* dmu, double* const* dhvals);
 int qc_multi_sync(qc_handle* h);

@@ -12,7 +12,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # (--prewarm-seconds 0: one pass over the output ring only -- tens of thousands of back-to-back launches under the profiler
 #  inflate the traced kernel durations by 5 - 10 %: 9.39 against 8.57 us for the same kernel in the same call)
-ARGS="--steps 300 --warmup 30 --cpu-seconds 0 --prewarm-seconds 0 $*"
+ARGS="--steps 300 --warmup 30 --cpu-seconds 0 --prewarm-seconds 0 --no-host-visible $*"   # (host-buffer calls launch the same kernels in their compact form: kept out of the per-kernel averages)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/trace.log
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $R/bench.py $ARGS > $OUT/bench_fetch.json 2> $OUT/fetch.log
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $R/bench.py $ARGS > $OUT/bench_write.json 2> $OUT/write.log

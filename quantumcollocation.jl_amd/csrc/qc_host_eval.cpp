@@ -3,6 +3,7 @@
 // (one process, N GPUs: per-shard threads / streams / pinned staging, optional in-library RCCL all-gather).
 // Descriptor validation, structures and handle lifetime are in qc_host.cpp.  No CPU evaluation path anywhere.
 #include <dlfcn.h>
+#include <link.h>
 #include <pthread.h>
 #include <sched.h>
 #include <stdio.h>
@@ -1281,7 +1282,20 @@ RcclApi& rccl_api() {
     static RcclApi api;
     static std::once_flag once;
     std::call_once(once, [] {
-        // prefer a copy that is already in the process (torch bundles its own librccl): two RCCL runtimes must not mix
+        // A copy that is already in the process wins (torch bundles its own librccl under its own directory: a bare-name
+        // RTLD_NOLOAD probe does not find that one, and a second RCCL runtime next to it must not happen): walk the loaded objects
+        // and take the first whose file name starts with "librccl", by its full path.
+        std::string loaded;
+        dl_iterate_phdr([](struct dl_phdr_info* info, size_t, void* out) -> int {
+            const char* path = info->dlpi_name;
+            if (!path || !*path) return 0;
+            const char* base = strrchr(path, '/');
+            base = base ? base + 1 : path;
+            if (strncmp(base, "librccl", 7) != 0) return 0;
+            *static_cast<std::string*>(out) = path;
+            return 1;
+        }, &loaded);
+        if (!loaded.empty()) api.lib = dlopen(loaded.c_str(), RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
         const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
         for (const char* n : names) if (!api.lib) api.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
         for (const char* n : names) if (!api.lib) api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
