@@ -299,6 +299,8 @@ def config5_record(qc, dev_index, steps=300):
     hl = [dyn.bind_mu_d2F_device(Z, mu, Hb[i], st) for i in range(nh)]
     jac_us = timed(lambda i: jl[i % nb]())
     hess_us = timed(lambda i: hl[i % nh]())
+    both = [dyn.bind_F_dF_mu_d2F_device(Z, mu, Fb[i % nb], Jb[i % nb], Hb[i % nh], st) for i in range(int(np.lcm(nb, nh)))]
+    both_us = timed(lambda i: both[i % len(both)]())
     zdim, ddim = inp.traj.dim, int(dims.ddim)
     jac_bytes = 8 * (zdim * (n_int + 1) + (ddim + int(dims.jac_nnz_interval)) * n_int)
     hess_bytes = 8 * (zdim * (n_int + 1) + (ddim + int(dims.hess_nnz_interval)) * n_int)
@@ -306,6 +308,7 @@ def config5_record(qc, dev_index, steps=300):
     rec = {"workload": qc.CONFIGS[5].description + f"; T={inp.traj.T}", "kernels": list(dyn.kernel_names),
            "F_dF_us": jac_us, "F_dF_hbm_frac": jac_bytes / (jac_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
            "hess_us": hess_us, "hess_hbm_frac": hess_bytes / (hess_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+           "F_dF_hess_one_call_us": both_us, "F_dF_hess_kernel": dyn.fused_kernel_name,
            "mfma_peak_TFLOPs": peak_tf}
     counters, src = _mfma_counters()
     if counters and inp.traj.T == 500:

@@ -363,7 +363,7 @@ static std::vector<cpu_set_t> device_l3_domains(int device) {
 
 struct HostPool {
     std::vector<std::thread> th;
-    std::vector<cpu_set_t> domains;       // where the members go (device_l3_domains of the first device served), or empty
+    std::vector<cpu_set_t> domains;       // where the members go: the complexes next to every device served so far (or empty)
     std::mutex mu;
     std::condition_variable cv;
     std::deque<std::pair<std::function<void()>, HostGroup*>> q;
@@ -383,17 +383,27 @@ struct HostPool {
             lk.lock();
         }
     }
+    std::vector<int> devices_seen;        // devices whose NUMA node's complexes are in `domains`
     void ensure(int n, int device = -1) {
         std::lock_guard<std::mutex> lk(mu);
         // QC_HOST_AFFINITY=0: leave the members to the scheduler
         static const bool pin = !(getenv("QC_HOST_AFFINITY") && atoi(getenv("QC_HOST_AFFINITY")) == 0);
-        if (th.empty() && pin && device >= 0) domains = device_l3_domains(device);
-        while ((int)th.size() < n) {
-            th.emplace_back([this] { run(); });
-            if (!domains.empty()) {
-                // member i on complex (i + 1) mod n: complex 0 is left to the calling thread's side of the work when it happens to be there
-                const cpu_set_t& set = domains[(th.size()) % domains.size()];
-                (void)pthread_setaffinity_np(th.back().native_handle(), sizeof(cpu_set_t), &set);
+        bool repin = false;
+        if (pin && device >= 0 && std::find(devices_seen.begin(), devices_seen.end(), device) == devices_seen.end()) {
+            // a device not served before (the shards of a multi-device handle sit on both sockets): its node's complexes join the list
+            devices_seen.push_back(device);
+            for (const cpu_set_t& d : device_l3_domains(device)) {
+                bool known = false;
+                for (const cpu_set_t& e : domains) known = known || CPU_EQUAL(&d, &e);
+                if (!known) { domains.push_back(d); repin = true; }
+            }
+        }
+        while ((int)th.size() < n) { th.emplace_back([this] { run(); }); repin = true; }
+        if (repin && !domains.empty()) {
+            // member i on complex (i + 1) mod n: complex 0 is left to the calling thread's side of the work when it happens to be there
+            for (size_t i = 0; i < th.size(); ++i) {
+                const cpu_set_t& set = domains[(i + 1) % domains.size()];
+                (void)pthread_setaffinity_np(th[i].native_handle(), sizeof(cpu_set_t), &set);
             }
         }
     }

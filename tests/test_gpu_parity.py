@@ -789,6 +789,36 @@ def test_compact_host_transfer_equals_full_transfer(qc, oracle, case, monkeypatc
         assert (H is None and ref[2] is None) or np.array_equal(H, ref[2]), k
 
 
+def test_host_path_with_non_finite_inputs_and_the_sentinel_pattern(qc, monkeypatch):
+    """The one-copy host path watches its pinned block for a sentinel word (a signalling NaN).  Non-finite inputs are evaluated,
+    not rejected (Ipopt probes wild points) -- including inputs that carry the sentinel's own bit pattern: the call must return,
+    and return the bits of the plain full copy (QC_HOST_COMPACT=0)."""
+    inp = qc.config_inputs(3, T=130)
+    Z = inp.traj.datavec.copy()
+    sentinel = np.array([0x7FF4C0DEC0DE5A5A], dtype=np.uint64).view(np.float64)[0]
+    zdim = inp.traj.dim
+    Z[5 * zdim + 3] = np.nan                       # a state entry
+    Z[17 * zdim + inp.traj.offset("a") + 1] = np.inf
+    Z[40 * zdim + inp.traj.offset("da")] = sentinel
+    Z[41 * zdim + inp.traj.offset("dda") + 2] = -sentinel
+    Z[90 * zdim + 7] = sentinel
+    mu = np.random.default_rng(0).standard_normal(int(qc.QuantumDynamics(inp.integrators, inp.traj).dims.n_rows))
+    mu[11] = sentinel
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("QC_HOST_COMPACT", mode)
+        dyn = qc.QuantumDynamics(inp.integrators, inp.traj)
+        F, J = dyn.F_dF(Z)
+        H = dyn.mu_d2F(Z, mu)
+        F2, J2 = dyn.F_dF(Z)                       # the pinned blocks were re-armed: the second call sees the same
+        assert np.array_equal(F.view(np.uint64), F2.view(np.uint64)) and np.array_equal(J.view(np.uint64), J2.view(np.uint64))
+        out[mode] = (F, J, H)
+        dyn.close()
+    for a, b in zip(out["0"], out["1"]):
+        assert np.isnan(a).any()
+        assert np.array_equal(a.view(np.uint64), b.view(np.uint64))
+
+
 @pytest.mark.parametrize("case", ["cfg3", "cfg3_long", "cfg3_fixed_dt", "m1", "m2", "m3", "m4", "m5", "cfg5", "cfg1"])
 def test_fused_launch_is_bit_identical(qc, case):
     """qc_eval_F_jac_hess_dev: dF and mu_d2F (and F) at one point in one call.  Where the fused kernel serves the handle (2N = 16,
