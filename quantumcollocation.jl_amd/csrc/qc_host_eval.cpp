@@ -1216,6 +1216,19 @@ extern "C" int qc_create_multi(const qc_desc* d, int32_t n_shards, const int32_t
     }
     h->kernel = h->shards[0]->kernel;
     h->dims.kernel = h->kernel;
+    {
+        // Which way do the Jacobian values come home?  The compact form (one copy of the replicated blocks per link, 3.5x fewer
+        // bytes at config 3) leaves the replication to ONE host: N x 41.5 MB per evaluation at the 170 - 235 GB/s its threads reach.
+        // With the links working in parallel the plain full copy -- 41.5 MB per link at 54.5 GB/s, nothing for the host to do --
+        // overtakes that from about four devices on (0.76 ms per evaluation at any N, against 1.4 - 2 ms of replication at N = 8).
+        // QC_HOST_MULTI_FULL = the number of distinct devices from which the shards copy in full (default 4; 0 = never).
+        std::vector<int> distinct;
+        for (int i = 0; i < n_shards; ++i)
+            if (std::find(distinct.begin(), distinct.end(), device_ids[i]) == distinct.end()) distinct.push_back(device_ids[i]);
+        const int from = getenv("QC_HOST_MULTI_FULL") ? atoi(getenv("QC_HOST_MULTI_FULL")) : 4;
+        if (from > 0 && (int)distinct.size() >= from && !getenv("QC_HOST_COMPACT"))
+            for (qc_handle* sh : h->shards) sh->host_compact = 0;
+    }
     if (n_shards > 1) h->fan = new qc_fanout(n_shards);
     *out = h;
     return QC_OK;

@@ -95,10 +95,13 @@ def test_multi_create_fails_loudly_without_a_device(qc):
 #  GPU
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.gpu
-@pytest.mark.parametrize("cfg,T,shards", [(3, 100, 3), (3, 5, 8), (1, 50, 2), (5, 21, 3), (2, 37, 4)])
-def test_multi_handle_equals_single_handle(qc, oracle, cfg, T, shards):
+@pytest.mark.parametrize("cfg,T,shards,full_from", [(3, 100, 3, None), (3, 5, 8, None), (1, 50, 2, None), (5, 21, 3, None), (2, 37, 4, None), (3, 150, 4, "1")])
+def test_multi_handle_equals_single_handle(qc, oracle, cfg, T, shards, full_from, monkeypatch):
     """device_ids = [0] * shards: F, dF, mu_d2F, structures and dims bit-identical to the single-device handle (T = 5 with
-    8 shards leaves empty trailing shards)."""
+    8 shards leaves empty trailing shards).  full_from: QC_HOST_MULTI_FULL -- the shards copy the Jacobian values in full (what a
+    handle over four or more distinct devices does by default: N links beat one host's replication) instead of in the compact form."""
+    if full_from is not None:
+        monkeypatch.setenv("QC_HOST_MULTI_FULL", full_from)
     inp = qc.config_inputs(cfg, T=T)
     Z = inp.traj.datavec
     one = qc.QuantumDynamics(inp.integrators, inp.traj)
