@@ -222,8 +222,15 @@ def host_visible_record(qc, inp, dyn, Zs, cpu_rec, t1000_equiv=1.0):
         expand = None
     rec["host_expand_GBps"] = expand
     rec["pcie_copy_GBps"] = PCIE_COPY_GBS
-    link = PCIE_COPY_GBS * 1e9 * max(1, len(set(getattr(dyn, "devices", None) or [0])))   # one link per distinct device
+    n_links = max(1, len(set(getattr(dyn, "devices", None) or [0])))
+    link = PCIE_COPY_GBS * 1e9 * n_links                                     # one link per distinct device
     expand_ms = 8 * int(dims.jac_nnz) / (expand * 1e9) * 1e3 if expand else 0.0
+    # from four distinct devices on the library copies the Jacobian values in full over every link instead of replicating
+    # N x 41.5 MB on one host (qc_create_multi, QC_HOST_MULTI_FULL)
+    full = n_links >= int(os.environ.get("QC_HOST_MULTI_FULL", "4") or 0) > 0 and "QC_HOST_COMPACT" not in os.environ
+    rec["jacobian_transfer"] = "full copy over every link" if full else "compact form + host replication"
+    if full:
+        jc_bytes, expand_ms = 8 * int(dims.jac_nnz), 0.0
 
     def bound(up, down, host_ms=0.0):     # upload and download are serial (the kernel needs the whole upload)
         return max((up + down) / link * 1e3, host_ms)

@@ -622,7 +622,7 @@ extern "C" int qc_set_new_x(qc_handle* h, int new_x) {
 //     the caller's pages in place; the call then blocks for the duration); 1.2 MB host -> device take 30 us either way;
 //   * kernel stores into pinned host memory reach 44 - 47 GB/s whatever the grid, and they land in NO usable order: the L2
 //     acknowledges a store long before it crosses the link and writes back in its own order -- of one launch over 999 intervals
-//     the first complete interval is seen after 220 us of 440 (QC_HOST_LANDING=2 keeps that variant for comparison);
+//     the first complete interval is seen after 220 us of 440 (that variant was built first: 0.46 ms per call);
 //   * round 2's sixteen chunk launches with an event each: 36 - 47 GB/s and 16 launch latencies.
 // So: ONE kernel writes the call's compact output into HBM (3 - 9 us), ONE asynchronous copy brings it to a pinned block in
 // address order at the link's rate, and the data is its own completion flag -- the pinned block holds a sentinel word (a

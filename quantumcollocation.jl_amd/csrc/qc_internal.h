@@ -150,9 +150,7 @@ bool qc_mfma_hess_supported(const QcParams& P);
 bool qc_mfma_compact_supported(const QcParams& P);   // the F + dF kernel honours QcParams.copies (order-4 kernels, 2N <= 32)
 size_t qc_mfma_gx_doubles(const QcParams& P);
 void qc_mfma_pack_G(const QcParams& P, const double* G_host, double* Gx_host);
-// grid_limit > 0 (2N = 16 order-4 kernels only): at most that many workgroups, each walking its intervals in order -- the host
-// path's one launch, whose stores should reach the PCIe link roughly in interval order
-hipError_t qc_launch_mfma_F_jac(const QcParams& P, const double* dZ, double* dF, double* dJ, hipStream_t st, int grid_limit = 0);
+hipError_t qc_launch_mfma_F_jac(const QcParams& P, const double* dZ, double* dF, double* dJ, hipStream_t st);
 size_t qc_mfma32_gx_doubles(const QcParams& P);
 void qc_mfma32_pack_G(const QcParams& P, const double* G_host, double* Gx_host);
 hipError_t qc_launch_mfma32_F_jac(const QcParams& P, const double* dZ, double* dF, double* dJ, hipStream_t st);
@@ -181,7 +179,7 @@ hipError_t qc_launch_mfma32_hess(const QcParams& P, const double* dZ, const doub
 // F + dF + mu_d2F in one launch (qc_mfma_fused.hip): 2N = 16, a unitary on 8 levels, antisymmetric generators, 1 .. 6 drives
 bool qc_mfma16_fused_supported(const QcParams& P);
 hipError_t qc_launch_mfma16_fused(const QcParams& P, const double* dZ, const double* dMu, double* dF, double* dJ, double* dH, hipStream_t st);
-hipError_t qc_launch_mfma_hess(const QcParams& P, const double* dZ, const double* dMu, double* dH, hipStream_t st, int grid_limit = 0);
+hipError_t qc_launch_mfma_hess(const QcParams& P, const double* dZ, const double* dMu, double* dH, hipStream_t st);
 
 hipError_t qc_launch_pack_jac(const double* dJ, double* dJc, int n_int, int jac_nnz, int comp_len, int n2, int jo_F, int jo_B, int head2,
                               int tail_src, hipStream_t st);

@@ -665,12 +665,11 @@ static void launch_hess16(const QcParams& P, const double* dZ, const double* dMu
     else hipLaunchKernelGGL((qc_mfma16_pade4_hess_kernel<HM, KET, false>), dim3(grid), dim3(64), 0, st, P, dZ, dMu, dH, nullptr);
 }
 
-hipError_t qc_launch_mfma_hess(const QcParams& P, const double* dZ, const double* dMu, double* dH, hipStream_t st, int grid_limit) {
+hipError_t qc_launch_mfma_hess(const QcParams& P, const double* dZ, const double* dMu, double* dH, hipStream_t st) {
     if (qc_mfma16_padeP_hess_supported(P)) return qc_launch_mfma16_padeP_hess(P, dZ, dMu, dH, st);
     if (P.n > 32) return qc_launch_mfma64_hess(P, dZ, dMu, dH, st);
     if (P.n > 16) return qc_launch_mfma32_hess(P, dZ, dMu, dH, st);
-    int grid = P.n_int < 4096 ? P.n_int : 4096;
-    if (grid_limit > 0 && grid_limit < grid) grid = grid_limit;
+    const int grid = P.n_int < 4096 ? P.n_int : 4096;
     if (P.nc != 8 || P.n != 16) {
         if (P.m <= 2) launch_hess16<2, true>(P, dZ, dMu, dH, st, grid);
         else if (P.m <= 4) launch_hess16<4, true>(P, dZ, dMu, dH, st, grid);

@@ -648,14 +648,13 @@ hipError_t qc_launch_mfma16_F_jac_batch(const QcParams& P0, const QcParams* dPb,
     return hipGetLastError();
 }
 
-hipError_t qc_launch_mfma_F_jac(const QcParams& P, const double* dZ, double* dF, double* dJ, hipStream_t st, int grid_limit) {
+hipError_t qc_launch_mfma_F_jac(const QcParams& P, const double* dZ, double* dF, double* dJ, hipStream_t st) {
     if (P.integrator == QC_EXPONENTIAL) return P.n > 16 ? qc_launch_mfma32_exp(P, dZ, dF, dJ, st) : qc_launch_mfma_exp(P, dZ, dF, dJ, st);
     if (qc_mfma16_padeP_supported(P)) return qc_launch_mfma16_padeP(P, dZ, dF, dJ, st);
     if (P.n > 32) return qc_launch_mfma64_F_jac(P, dZ, dF, dJ, st);
     if (P.n > 16) return qc_launch_mfma32_F_jac(P, dZ, dF, dJ, st);
     const int n_wg = dJ ? (P.n_int + kIntervalsPerWG - 1) / kIntervalsPerWG : P.n_int;
-    int grid = n_wg < kMaxGrid ? n_wg : kMaxGrid;
-    if (grid_limit > 0 && grid_limit < grid) grid = grid_limit;
+    const int grid = n_wg < kMaxGrid ? n_wg : kMaxGrid;
     const bool diag = P.stamps != nullptr || P.dbg_skip != 0;
     if (dJ) { if (diag) launch16<true, true>(P, dZ, dF, dJ, st, grid, kThreads); else launch16<true, false>(P, dZ, dF, dJ, st, grid, kThreads); }
     else    { if (diag) launch16<false, true>(P, dZ, dF, dJ, st, grid, 64); else launch16<false, false>(P, dZ, dF, dJ, st, grid, 64); }
