@@ -19,7 +19,7 @@
 // stores waits for them); S / D of the scalar blocks re-read from LDS instead of held through the MFMA stages (244 registers, no
 // scratch) 14.5 us; the (a, a) sums -- three quarters of the scalar blocks -- handed to the copy wave, which has issued its stores by
 // then, 13.85 us; no tile copy before the hand-off (the F + dF kernel stores four there: its compute wave has slack, this one is the
-// critical path) 13.5 us = 59.6 MB at 4.4 TB/s.  Parking the compute wave's F + dF tiles in LDS until the Hessian's MFMA stages were
+// critical path) 13.5 us; stage A of the Hessian on the copy wave, between its tile copies, 13.1 us = 59.6 MB at 4.5 TB/s.  Parking the compute wave's F + dF tiles in LDS until the Hessian's MFMA stages were
 // through (its stores then leave after the copy waves' flood): slower, 15.3 us.
 // Two waves per interval as before, so T = 1000 still fits the device in one round (a third wave per interval would not: 3 x 999
 // waves > 2048 slots at this register budget); the arithmetic of both halves is the arithmetic of the two kernels, so the values are
@@ -129,7 +129,12 @@ __global__ __launch_bounds__(kFuThreads, 2) void qc_mfma16_pade4_fused_kernel(co
     constexpr int kTr1 = AACOPY ? (kMU + 1 < 4 ? kMU + 1 : 4) : kMU + 1, kTr2 = kMU + 1 - kTr1;
     constexpr int kScrTiles = kTr1 > kMU / 2 + 1 ? kTr1 : kMU / 2 + 1;
     constexpr int kLdsRedC = kLdsScr + kScrTiles * 272;                     // the copy wave's reduction rows ((a, a) sums)
-    constexpr int kLdsTotal = kLdsRedC + (AACOPY ? R::kAA * kFuStride : 0);
+    constexpr bool SACOPY = (VAR & 32) != 0;        // stage A of the Hessian on the copy wave too, between its tile copies (needs AACOPY)
+    static_assert(!SACOPY || AACOPY, "stage A on the copy wave goes with the (a, a) sums there");
+    // (SACOPY: the region also carries the tiles [-N_k | -N_k+1] and Y from the copy wave to the compute wave)
+    constexpr int kRedCLen = !AACOPY ? 0 : (SACOPY && (kMU / 2 + 1) * 256 > R::kAA * kFuStride ? (kMU / 2 + 1) * 256 : R::kAA * kFuStride);
+    constexpr int kLdsFlag = kLdsRedC + kRedCLen;                           // one word: "the compute wave has taken the hand-over tiles"
+    constexpr int kLdsTotal = kLdsFlag + (SACOPY ? 2 : 0);
     static_assert(kLdsTotal * 8 <= 40960, "four workgroups per CU");
     static_assert((AACOPY ? R::kPair + 1 : R::kRows) * kFuStride <= kScrTiles * 272, "the compute wave's reduction rows alias the transpose scratch");
     __shared__ __attribute__((aligned(16))) double sm[kLdsTotal];
@@ -210,8 +215,7 @@ __global__ __launch_bounds__(kFuThreads, 2) void qc_mfma16_pade4_fused_kernel(co
         }
         // copies stored before the hand-off: 4 in the F + dF kernel, where nothing waits for the compute wave; here the compute wave's
         // chain is twice as long and is what the launch waits for (profiles/r03_fused_timeline.txt)
-        constexpr int kEarlySel = (VAR >> 4) & 3;
-        constexpr int kEarly = kEarlySel == 0 ? 4 : (kEarlySel == 1 ? 0 : (kEarlySel == 2 ? 1 : 2));
+        constexpr int kEarly = (VAR & 16) ? 0 : 4;     // (1 and 2 copies: 13.6 / 13.9 us against 13.5 with none, 13.85 with four)
 #pragma unroll
         for (int q = 0; q < kEarly; ++q) {
             if (q < P.copies) {
@@ -226,8 +230,10 @@ __global__ __launch_bounds__(kFuThreads, 2) void qc_mfma16_pade4_fused_kernel(co
 #pragma unroll
         for (int u = 0; u < kMU; ++u)
             if (u < m) fu_lds_put(sm + kLdsGk + u * 256, lane, gk_img[u]);
+        if constexpr (SACOPY) { if (lane == 0) reinterpret_cast<int*>(sm + kLdsFlag)[0] = 0; }
         __syncthreads();
-        {
+        v4d Tq[kMU];                               // SACOPY: the stage-A tiles T_k = G_k [M | c2 h^2 D], kept for the (a, a) sums
+        if constexpr (!SACOPY) {
             double* pF = Jb + P.jo_F;
             double* pB = Jb + P.jo_B;
             const int ncop = P.copies;
@@ -235,6 +241,47 @@ __global__ __launch_bounds__(kFuThreads, 2) void qc_mfma16_pade4_fused_kernel(co
                 fu_store_tile_T(pF + q * 256, Fm, g, j);
                 fu_store_tile_T(pB + q * 256, Bm, g, j);
             }
+        } else {
+            // Stage A of the Hessian -- Y = G [M | c2 h^2 D] and T_k = G_k [M | c2 h^2 D]: this wave holds G, the images, M and the
+            // knots' tiles in registers -- rides between the tile copies: the wave issues a store every ~100 cycles because the CU's
+            // store queue is full, and the seven independent accumulator chains (mm16_multi's order, so the same bits) run in the
+            // shadow of those stalls.  The compute wave's chain is shorter by these 28 products.
+            static_assert(kEarly == 0, "all copies behind the hand-off");
+            v4d MD;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) MD[r] = left ? mt[r] : hc2 * (u1[r] - u0[r]);
+            const v4d zero = {0.0, 0.0, 0.0, 0.0};
+            v4d acc[kMU + 1];
+            double* pF = Jb + P.jo_F;
+            double* pB = Jb + P.jo_B;
+            const int ncop = P.copies;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ga[kk], MD[kk], kk ? acc[0] : zero, 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < kMU; ++u) acc[1 + u] = __builtin_amdgcn_mfma_f64_16x16x4f64(gk_img[u][kk], MD[kk], kk ? acc[1 + u] : zero, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 2 * kk; q < 2 * kk + 2; ++q) {
+                    if (q < ncop) {
+                        fu_store_tile_T(pF + q * 256, Fm, g, j);
+                        fu_store_tile_T(pB + q * 256, Bm, g, j);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            for (int q = 8; q < ncop; ++q) {       // (never: copies == N = 8 here)
+                fu_store_tile_T(pF + q * 256, Fm, g, j);
+                fu_store_tile_T(pB + q * 256, Bm, g, j);
+            }
+#pragma unroll
+            for (int u = 0; u < kMU; ++u) Tq[u] = acc[1 + u];
+            // hand-over to the compute wave's stage B: [-N_k | -N_k+1] per drive pair, and Y
+            double* __restrict__ hand = sm + kLdsRedC;
+#pragma unroll
+            for (int p2 = 0; p2 < kMU / 2; ++p2) fu_lds_put(hand + 256 * p2, lane, fu_sel(left, Tq[2 * p2], swap8(Tq[2 * p2 + 1])));
+            fu_lds_put(hand + 256 * (kMU / 2), lane, acc[0]);
+            __syncthreads();                       // second barrier: the compute wave is through its F + dF part by now
         }
         __builtin_amdgcn_s_setprio(0);
         QC_STAMP(P, b, lane, 12);                   // copy wave: the 2N tile copies issued
@@ -274,7 +321,34 @@ __global__ __launch_bounds__(kFuThreads, 2) void qc_mfma16_pade4_fused_kernel(co
             qc_hess_tail(P, mu, Hb, lane, 64);
         }
         QC_STAMP(P, b, lane, 13);                   // copy wave: every store of its own issued
-        if constexpr (AACOPY) {
+        if constexpr (AACOPY && SACOPY) {
+            // (a_u, a_v) = -sum T_u . swap8(T_v) over all lanes, from this wave's own registers; the rows go where the hand-over
+            // tiles were, once the compute wave says it has them
+            double* __restrict__ redc = sm + kLdsRedC;
+            double aa[R::kAA];
+#pragma unroll
+            for (int v = 0; v < kMU; ++v) {
+                const v4d Tsw = swap8(Tq[v]);
+#pragma unroll
+                for (int u = 0; u <= v; ++u) {
+                    // dot4(-T_u, swap8(T_v)) with the roundings qc_mfma16_pade4_hess_anti_kernel's compilation has (first product
+                    // rounded on its own, the other three fused in order): written out, because the compiler's choice of WHICH
+                    // product stays un-fused depends on the shape of the surrounding code, and the values must be the same bits
+                    const double t0 = Tq[u][0] * Tsw[0];
+                    double r = __builtin_fma(-Tq[u][1], Tsw[1], -t0);
+                    r = __builtin_fma(-Tq[u][2], Tsw[2], r);
+                    aa[v * (v + 1) / 2 + u] = __builtin_fma(-Tq[u][3], Tsw[3], r);
+                }
+            }
+            QC_STAMP(P, b, lane, 14);
+            while (__hip_atomic_load(reinterpret_cast<int*>(sm + kLdsFlag), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+            for (int i = 0; i < R::kAA; ++i) redc[i * kFuStride + lane] = aa[i];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            fu_reduce_rows<kMU>(P, redc, Hb, lane, m, ft, 0, R::kAA, 0);
+        } else if constexpr (AACOPY) {
             // (a_u, a_v) = -sum T_u . swap8(T_v) over all lanes, from the stage-A tiles the compute wave has parked in LDS: this wave's
             // stores are issued and it would only wait for them to drain
             __syncthreads();
@@ -433,33 +507,48 @@ __global__ __launch_bounds__(kFuThreads, 2) void qc_mfma16_pade4_fused_kernel(co
             Db[r] = u1[r] - u0[r];
             MD[r] = left ? mv[r] : hc2 * Db[r];
         }
-        // ---- stage A: G MD and G_k MD, interleaved
-        v4d Y, T[kMU];
-        {
-            constexpr int NA = 1 + kMU;
-            v4d aA[NA], bA[NA], dA[NA];
-            aA[0] = Ga;
-            bA[0] = MD;
+        v4d Y, PNn[kMU / 2];                               // G [M | c2 h^2 D];  [-N_k | -N_k+1] per drive pair
+        if constexpr (SACOPY) {
+            // stage A came from the copy wave (its registers held everything it needs; it ran between that wave's tile copies)
+            __syncthreads();
+            const double* __restrict__ hand = sm + kLdsRedC;
+#pragma unroll
+            for (int p2 = 0; p2 < kMU / 2; ++p2) PNn[p2] = fu_lds_get(hand + 256 * p2, lane);
+            Y = fu_lds_get(hand + 256 * (kMU / 2), lane);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the tiles are in registers: the copy wave may reuse the region
+            if (lane == 0) __hip_atomic_store(reinterpret_cast<int*>(sm + kLdsFlag), 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            QC_STAMP(P, b, lane, 5);              // compute wave: second barrier passed, hand-over taken
+        } else {
+            // ---- stage A: G MD and G_k MD, interleaved
+            v4d T[kMU];
+            {
+                constexpr int NA = 1 + kMU;
+                v4d aA[NA], bA[NA], dA[NA];
+                aA[0] = Ga;
+                bA[0] = MD;
+#pragma unroll
+                for (int u = 0; u < kMU; ++u) {
+                    aA[1 + u] = gA[u];
+                    bA[1 + u] = MD;
+                }
+                mm16_multi<NA>(aA, bA, dA);
+                Y = dA[0];
+#pragma unroll
+                for (int u = 0; u < kMU; ++u) T[u] = dA[1 + u];
+            }
 #pragma unroll
             for (int u = 0; u < kMU; ++u) {
-                aA[1 + u] = gA[u];
-                bA[1 + u] = MD;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) tsave[(u * 4 + r) * 64 + lane] = T[u][r];
             }
-            mm16_multi<NA>(aA, bA, dA);
-            Y = dA[0];
+            QC_STAMP(P, b, lane, 4);              // compute wave: stage A through, tiles parked
+            if constexpr (AACOPY) __syncthreads();    // the copy wave takes the (a, a) sums from here
+            QC_STAMP(P, b, lane, 5);              // compute wave: second barrier passed
 #pragma unroll
-            for (int u = 0; u < kMU; ++u) T[u] = dA[1 + u];
+            for (int p2 = 0; p2 < kMU / 2; ++p2) PNn[p2] = fu_sel(left, T[2 * p2], swap8(T[2 * p2 + 1]));
         }
-#pragma unroll
-        for (int u = 0; u < kMU; ++u) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) tsave[(u * 4 + r) * 64 + lane] = T[u][r];
-        }
-        QC_STAMP(P, b, lane, 4);                  // compute wave: stage A through, tiles parked
-        if constexpr (AACOPY) __syncthreads();        // the copy wave takes the (a, a) sums from here
-        QC_STAMP(P, b, lane, 5);                  // compute wave: second barrier passed
         // ---- stage B
-        v4d PNn[kMU / 2], Q[kMU / 2], Y2;                   // [-N_k | -N_k+1], 2 c2 h [N'' + N' pairs], [M2 | .]
+        v4d Q[kMU / 2], Y2;                                 // 2 c2 h [N'' + N' pairs], [M2 | .]
         {
             v4d YL, Gs;
 #pragma unroll
@@ -468,8 +557,6 @@ __global__ __launch_bounds__(kFuThreads, 2) void qc_mfma16_pade4_fused_kernel(co
                 Gs[r] = c2h2 * Ga[r];
             }
             const v4d YR = swap8(YL);                       // [0 | 2 c2 h (-M1)]
-#pragma unroll
-            for (int p2 = 0; p2 < kMU / 2; ++p2) PNn[p2] = fu_sel(left, T[2 * p2], swap8(T[2 * p2 + 1]));
             Y2 = __builtin_amdgcn_mfma_f64_16x16x4f64(Ga[0], Y[0], zero, 0, 0, 0);
 #pragma unroll
             for (int p2 = 0; p2 < kMU / 2; ++p2) Q[p2] = __builtin_amdgcn_mfma_f64_16x16x4f64(Gs[0], PNn[p2][0], zero, 0, 0, 0);
@@ -619,13 +706,16 @@ hipError_t qc_launch_mfma16_fused(const QcParams& P, const double* dZ, const dou
 #define QC_FU(MU_, V_) hipLaunchKernelGGL((qc_mfma16_pade4_fused_kernel<MU_, V_>), dim3(n), dim3(kFuThreads), 0, st, P.Gx, Zt, mu0, n, P.zdim, P.off_a, P.off_dt, \
                                           P.m, P.off_U, (int)P.F_stride, P, Fp, Jp, Hp)
         // VAR bits: 1 S / D of the scalar blocks re-read from LDS (no scratch spills), 4 the (a, a) sums on the copy wave, 8 time stamps,
-        // 16 no copy before the hand-off.  QC_FUSED_VARIANT=0: the plain composition of the two kernels, for comparison.
+        // 16 no copy before the hand-off, 32 stage A on the copy wave.  QC_FUSED_VARIANT=0: the plain composition of the two kernels,
+        // 21: everything but bit 32 -- for comparison.
         static const bool plain = getenv("QC_FUSED_VARIANT") && atoi(getenv("QC_FUSED_VARIANT")) == 0;
-        if (P.stamps != nullptr) QC_FU(6, 29);
-        else if (P.m <= 2) QC_FU(2, 21);
-        else if (P.m <= 4) QC_FU(4, 21);
+        static const int var = getenv("QC_FUSED_VARIANT") ? atoi(getenv("QC_FUSED_VARIANT")) : -1;
+        if (P.stamps != nullptr) QC_FU(6, 61);
+        else if (P.m <= 2) QC_FU(2, 53);
+        else if (P.m <= 4) QC_FU(4, 53);
         else if (plain) QC_FU(6, 0);
-        else QC_FU(6, 21);
+        else if (var == 21) QC_FU(6, 21);
+        else QC_FU(6, 53);
 #undef QC_FU
     }
     return hipGetLastError();
