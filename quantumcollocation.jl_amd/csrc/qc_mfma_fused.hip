@@ -6,14 +6,15 @@
 // transposes and reductions -- runs at a fifth of the HBM rate with nothing to overlap.  Here it rides on the F + dF kernel, which is
 // bound by its 42.6 MB of stores and leaves the matrix pipes idle:
 //
-//   wave 1 ("copy wave")     exactly the copy wave of qc_mfma16_pade4_kernel -- every global load of the interval in one batch, G,
-//                            (G^2)^T, B^T / F^T, the 2N tile copies, the derivative-integrator rows -- plus the interval's multipliers
-//                            (one more tile request in the same batch, handed over through LDS) and, at its very end, the Hessian's
-//                            derivative-integrator entries and padding
-//   wave 0 ("compute wave")  the compute wave of qc_mfma16_pade4_kernel (residual, d/dh, the drive columns), then -- with G, the
-//                            knots' state tiles, the multipliers and the generator images all in LDS already, no global load at
-//                            all -- the two MFMA stages, the LDS transposes, the stores and the scalar blocks of
-//                            qc_mfma16_pade4_hess_anti_kernel, instruction for instruction
+//   wave 1 ("copy wave")     the copy wave of qc_mfma16_pade4_kernel -- every global load of the interval in one batch, G, (G^2)^T,
+//                            B^T / F^T, the 2N tile copies, the derivative-integrator rows -- plus the interval's multipliers (one
+//                            more tile request in the same batch), and the parts of the Hessian it can do from what it holds in
+//                            registers while its stores drain: stage A (Y = G [M | c2 h^2 D], T_k = G_k [M | c2 h^2 D]) between
+//                            its tile copies, the (a, a) sums from the T_k, the derivative-integrator entries and the padding
+//   wave 0 ("compute wave")  the compute wave of qc_mfma16_pade4_kernel (residual, d/dh, the drive columns), then -- G, the knots'
+//                            tiles, the images in LDS, [-N_k | -N_k+1] and Y handed over by the copy wave: no global load at
+//                            all -- stage B, the LDS transposes, the matrix blocks' stores and the (a, h) / (h, h) sums of
+//                            qc_mfma16_pade4_hess_anti_kernel, operation for operation
 // Measured at config 3 (T = 1000; profiles/r03_fused_variants.txt, r03_fused_timeline.txt): two launches 16.9 us; the plain
 // composition 15.5 us (the compute wave at its 256-register budget spills 9 registers, and a scratch reload behind the wave's own
 // stores waits for them); S / D of the scalar blocks re-read from LDS instead of held through the MFMA stages (244 registers, no
