@@ -687,8 +687,7 @@ inline void land_wait(LandJob& J, const double* p, size_t n, hipEvent_t ev, bool
         if (off >= n) return;
         if (J.done.load(std::memory_order_acquire)) return;
         if (spins == 0 && host_trace()) J.blocks_waited.fetch_add(1, std::memory_order_relaxed);
-        if (poll && (++spins & 15) == 15) land_poll(J, ev);
-        else ++spins;
+        if (poll && (++spins & 15) == 0) land_poll(J, ev);
         cpu_pause();
     }
 }
