@@ -329,6 +329,31 @@ class QuantumDynamics:
         _lib.check(_lib.lib.qc_eval_hess(self._h, _lib.dptr(Z), _lib.dptr(mu), _lib.dptr(out)), self._h)
         return out
 
+    def bind_host(self, which: str, Z: np.ndarray, *, mu: Optional[np.ndarray] = None, F: Optional[np.ndarray] = None,
+                  J: Optional[np.ndarray] = None, H: Optional[np.ndarray] = None):
+        """Pre-validated host-buffer call: a zero-argument callable returning the C status code, for timing loops (the per-call
+        argument checks and pointer conversions of `F` / `dF` / `F_dF` / `mu_d2F` cost 8 - 10 us in Python, a tenth of a residual
+        evaluation; a `ccall` from Julia has none of that).  which = "F" | "dF" | "F_dF" | "mu_d2F"; the arrays must outlive it."""
+        import functools
+        Z = self._Z(Z)
+        if Z.ctypes.data % 8:
+            raise ValueError("Z must be 8-byte aligned")
+        zp = _lib.dptr(Z)
+        if which == "F":
+            return functools.partial(_lib.lib.qc_eval_F, self._h, zp, _lib.dptr(self._out("F", int(self.dims.F_len), F)))
+        if which == "dF":
+            return functools.partial(_lib.lib.qc_eval_jac, self._h, zp, _lib.dptr(self._out("J", int(self.dims.jac_nnz), J)))
+        if which == "F_dF":
+            return functools.partial(_lib.lib.qc_eval_F_jac, self._h, zp, _lib.dptr(self._out("F", int(self.dims.F_len), F)),
+                                     _lib.dptr(self._out("J", int(self.dims.jac_nnz), J)))
+        if which == "mu_d2F":
+            mu = np.ascontiguousarray(mu, dtype=np.float64)
+            if mu.size != self.dims.n_rows:
+                raise ValueError(f"mu has length {mu.size}, expected {self.dims.n_rows}")
+            self._keep_mu = mu
+            return functools.partial(_lib.lib.qc_eval_hess, self._h, zp, _lib.dptr(mu), _lib.dptr(self._out("H", int(self.dims.hess_nnz), H)))
+        raise ValueError(which)
+
     def set_new_x(self, new_x: bool) -> None:
         """Ipopt's `new_x`: False declares that the following host-buffer calls receive the x of the previous one (the accepted
         trial point: residuals, then Jacobian and Hessian at the same x), so the knots already on the device are used and Z
