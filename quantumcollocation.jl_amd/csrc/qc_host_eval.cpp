@@ -830,6 +830,41 @@ void qc_rearm_destroy(qc_rearm* r) {
 
 static int eval_host_chunked(qc_handle* h, const double* Z, double* F, double* vals, int shards);
 
+// The ring of pinned blocks: every block holds the watched output of this handle (residual rows + compact Jacobian values).
+// ring_take hands out the next block, armed (its re-arm jobs of the previous turn waited for).
+static size_t ring_capacity(const qc_handle* h) {
+    const QcParams& P = h->prm;
+    const CompactPlan cp = compact_plan(P);
+    const size_t jac = (size_t)P.F_stride + (size_t)(cp.useful ? cp.comp_len : P.jac_nnz);
+    return (size_t)P.n_int * jac;
+}
+static int ring_take(qc_handle* h, int* index) {
+    static const int ring = std::max(2, std::min(QC_HOST_RING, getenv("QC_HOST_NBUF") ? atoi(getenv("QC_HOST_NBUF")) : 3));
+    const int ib = h->hC_next;
+    h->hC_next = (ib + 1) % ring;
+    const size_t cap = ring_capacity(h);
+    int rc;
+    if ((rc = ensure_pinned(h, &h->hC[ib], cap, false))) return rc;
+    if (h->rearm[ib]) h->rearm[ib]->grp.wait();               // the re-arm jobs of this block's previous use (normally long done)
+    if (!h->hC_armed[ib]) { qc_host_fill(h->hC[ib], cap, kLandSentinel); h->hC_armed[ib] = true; }
+    *index = ib;
+    return QC_OK;
+}
+// the consumed part of a block is re-armed behind the caller's back by whichever workers are idle
+static void ring_rearm_later(qc_handle* h, int ib, size_t used) {
+    if (!h->rearm[ib]) h->rearm[ib] = new qc_rearm();
+    double* base = h->hC[ib];
+    // QC_HOST_REARM_JOBS workers share it (default 2: a trickle that the next call's transfers hardly notice, done well before
+    // the block's next turn in the ring of 3; eight workers re-arm in a burst that slowed the next call's upload of Z from 30
+    // to 100 - 190 us when calls follow each other without a pause)
+    static const size_t jobs = getenv("QC_HOST_REARM_JOBS") ? (size_t)std::max(1, atoi(getenv("QC_HOST_REARM_JOBS"))) : 2;
+    const size_t piece = std::max<size_t>(size_t(1) << 17, (used + jobs - 1) / jobs);      // doubles: at least 1 MB each
+    for (size_t o = 0; o < used; o += piece) {
+        const size_t len = std::min(piece, used - o);
+        host_pool().push([base, o, len] { qc_host_fill(base + o, len, kLandSentinel); qc_host_copy_fence(); }, &h->rearm[ib]->grp);
+    }
+}
+
 extern "C" int qc_debug_host_expand_rate(qc_handle* h, int32_t reps, double* GBps) {
     if (!h || !GBps || reps < 1) return fail(h ? &h->err : nullptr, QC_ERR_INVALID, "qc_debug_host_expand_rate: bad argument");
     qc_handle* s = is_multi(h) ? h->shards[0] : h;
@@ -905,12 +940,8 @@ static int eval_host(qc_handle* h, const double* Z, double* F, double* vals, int
     J.F = F;
     const size_t cap = (size_t)P.n_int * ((size_t)P.F_stride + (size_t)cp.comp_len);
     if ((rc = ensure_zeroed(h, &h->dC, cap))) return rc;      // (zeroed once: residual rows no kernel writes are delivered as 0)
-    static const int ring = std::max(2, std::min(QC_HOST_RING, getenv("QC_HOST_NBUF") ? atoi(getenv("QC_HOST_NBUF")) : 3));
-    const int ib = h->hC_next;
-    h->hC_next = (ib + 1) % ring;
-    if ((rc = ensure_pinned(h, &h->hC[ib], cap, false))) return rc;
-    if (h->rearm[ib]) h->rearm[ib]->grp.wait();               // the re-arm jobs of this block's previous use (normally long done)
-    if (!h->hC_armed[ib]) { qc_host_fill(h->hC[ib], cap, kLandSentinel); h->hC_armed[ib] = true; }
+    int ib;
+    if ((rc = ring_take(h, &ib))) return rc;
     J.src = h->hC[ib];
     J.rearm_inline = land_inline_rearm();
     QcParams C = compact_params(P, cp);
@@ -929,20 +960,7 @@ static int eval_host(qc_handle* h, const double* Z, double* F, double* vals, int
     }
     rc = land_run(h, J, shards, t_begin, now_us());
     if (rc) { h->hC_armed[ib] = false; return rc; }
-    if (!J.rearm_inline) {
-        // the consumed part of the block is re-armed behind the caller's back, in a few pieces, by whichever workers are idle
-        if (!h->rearm[ib]) h->rearm[ib] = new qc_rearm();
-        double* base = h->hC[ib];
-        // QC_HOST_REARM_JOBS workers share it (default 2: a trickle that the next call's transfers hardly notice, done well before
-        // the block's next turn in the ring of 3; eight workers re-arm in a burst that slowed the next call's upload of Z from 30
-        // to 100 - 190 us when calls follow each other without a pause)
-        static const size_t jobs = getenv("QC_HOST_REARM_JOBS") ? (size_t)std::max(1, atoi(getenv("QC_HOST_REARM_JOBS"))) : 2;
-        const size_t piece = std::max<size_t>(size_t(1) << 17, (used + jobs - 1) / jobs);      // doubles: at least 1 MB each
-        for (size_t o = 0; o < used; o += piece) {
-            const size_t len = std::min(piece, used - o);
-            host_pool().push([base, o, len] { qc_host_fill(base + o, len, kLandSentinel); qc_host_copy_fence(); }, &h->rearm[ib]->grp);
-        }
-    }
+    if (!J.rearm_inline) ring_rearm_later(h, ib, used);
     return QC_OK;
 }
 
@@ -1051,6 +1069,10 @@ static int hess_host(qc_handle* h, const double* Z, const double* mu, double* hv
     // QC_HOST_HESS_CHUNKS > 1 sends the multipliers up and the values down in pieces on two streams; measured at config 3
     // (profiles/r03_host_path.txt): 1 piece 0.344 ms, 2 pieces 0.405, 4 pieces 0.46 - 0.48, 8 pieces 0.66 -- a copy into pageable
     // memory returns when it is done, so the pieces do not overlap and each pays its own set-up.  Default 1.
+    // Also measured and not kept (profiles/r03_host_hess_watched.txt): the values through a pinned ring block with the team copying
+    // them out behind the copy engine as for the Jacobian, the first quarter's kernel and download started while the rest of the
+    // multipliers go up on the second stream -- bit-identical, 0.357 (one part) and 0.378 - 0.388 ms (two parts) against 0.346 for
+    // this path: an upload running beside the download slows it (49 against 54.5 GB/s) and the team finishes 20 us after the link.
     static const int want = getenv("QC_HOST_HESS_CHUNKS") ? std::max(1, atoi(getenv("QC_HOST_HESS_CHUNKS"))) : 1;
     const bool chunkable = h->kernel == QC_KERNEL_MFMA && qc_mfma_hess_supported(P) && !qc_mfma64_hess_supported(P) && !qc_mfma16_padeP_hess_supported(P) &&
                            h->host_compact != 0;
