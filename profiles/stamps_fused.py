@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Diagnostic timeline of the fused F + dF + mu_d2F kernel (qc_mfma_fused.hip, QC_STAMPS=1): per-wave s_memrealtime checkpoints of
-both roles.  Run on the GPU box:  python profiles/stamps_fused.py [T]"""
+both roles.  Run on the GPU box:  python profiles/stamps_fused.py [T] [hess]   (hess: the Hessian-only form, qc_eval_hess_dev)"""
 import ctypes as C
 import os
 import sys
@@ -22,8 +22,12 @@ nb = 16
 Fs = [torch.empty(dyn.dims.F_len, dtype=torch.float64, device="cuda") for _ in range(nb)]
 Js = [torch.empty(dyn.dims.jac_nnz, dtype=torch.float64, device="cuda") for _ in range(nb)]
 Hs = [torch.empty(dyn.dims.hess_nnz, dtype=torch.float64, device="cuda") for _ in range(nb)]
+hess_only = len(sys.argv) > 2 and sys.argv[2] == "hess"
 for i in range(nb):
-    dyn.F_dF_mu_d2F_device(Z, mu, Fs[i], Js[i], Hs[i])
+    if hess_only:
+        dyn.mu_d2F_device(Z, mu, Hs[i])
+    else:
+        dyn.F_dF_mu_d2F_device(Z, mu, Fs[i], Js[i], Hs[i])
 torch.cuda.synchronize()
 n = dyn.dims.n_intervals
 out = np.zeros(n * 16, dtype=np.uint64)
@@ -34,10 +38,15 @@ names = {10: "copy wave: entry", 11: "copy wave: loads back, G assembled", 12: "
          0: "compute wave: entry", 1: "compute wave: hand-off received", 2: "compute wave: F + dF products, transposes done",
          3: "compute wave: F + dF stores issued", 4: "compute wave: stage A done, tiles parked", 5: "compute wave: second barrier passed",
          6: "compute wave: stage B issued", 7: "compute wave: Hessian matrix stores issued", 8: "compute wave: all stores issued", 9: "compute wave: drained"}
+if hess_only:   # qc_mfma_hess2.hip: wave 0 does the one-wave kernel's work in a new order, wave 1 the (a, a) sums
+    names = {0: "wave 0: entry", 1: "wave 0: every load requested", 2: "wave 0: loads back", 3: "wave 0: stage A issued",
+             4: "wave 0: T_k parked, barrier passed", 5: "wave 0: stage B, first part issued", 6: "wave 0: first part's blocks stored",
+             7: "wave 0: every matrix block stored", 8: "wave 0: every store issued", 9: "wave 0: drained",
+             10: "wave 1: entry", 11: "wave 1: released", 14: "wave 1: its drive pair's blocks stored", 12: "wave 1: (a, a) products through", 13: "wave 1: done"}
 t0 = st[st > 0].min()
 rel = (st - t0) * 10.0 / 1e3
-print(f"T={T}: {n} intervals; one call = {dyn.fused_kernel_name}; span (first entry -> last compute wave drained) = {rel[:, 9].max():.2f} us")
-for order in ([10, 11, 12, 13, 14, 15], [0, 1, 2, 3, 4, 5, 6, 7, 8, 9]):
+print(f"T={T}: {n} intervals; one call = {dyn.kernel_names[1] if hess_only else dyn.fused_kernel_name}; span (first entry -> last compute wave drained) = {rel[:, 9].max():.2f} us, last stamp of any wave {rel[st > 0].max():.2f} us")
+for order in (([10, 11, 14, 12, 13] if hess_only else [10, 11, 12, 13, 14, 15]), [0, 1, 2, 3, 4, 5, 6, 7, 8, 9]):
     prev = None
     for k in order:
         ok = st[:, k] > 0

@@ -10,6 +10,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["QC_STAMPS"] = "1"
+os.environ.setdefault("QC_HESS_TWO_WAVES", "0")     # the one-wave kernel (the two-wave kernel: profiles/stamps_fused.py T hess)
 import __graft_entry__ as g
 
 qc = g.load_package()

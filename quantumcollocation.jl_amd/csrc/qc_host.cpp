@@ -512,6 +512,7 @@ extern "C" const char* qc_kernel_name(const qc_handle* h, int32_t which) {
     if (which == 2) return mfma && qc_mfma16_fused_supported(P) ? "mfma16-pade4-fused" : "two-launches";
     if (mfma && qc_mfma_hess_supported(P)) {
         if (qc_mfma16_padeP_hess_supported(P)) return "mfma16-padeP-hess";
+        if (qc_mfma16_hess2_supported(P)) return "mfma16-pade4-hess2";
         return P.n > 32 ? "mfma64-pade4-hess" : (P.n > 16 ? "mfma32-pade4-hess" : "mfma16-pade4-hess");
     }
     return P.use_ws ? "lds-gws-hess" : "lds-hess";

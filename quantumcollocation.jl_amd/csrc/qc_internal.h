@@ -178,6 +178,8 @@ bool qc_mfma32_hess_supported(const QcParams& P);
 hipError_t qc_launch_mfma32_hess(const QcParams& P, const double* dZ, const double* dMu, double* dH, hipStream_t st);
 // F + dF + mu_d2F in one launch (qc_mfma_fused.hip): 2N = 16, a unitary on 8 levels, antisymmetric generators, 1 .. 6 drives
 bool qc_mfma16_fused_supported(const QcParams& P);
+bool qc_mfma16_hess2_supported(const QcParams& P);
+hipError_t qc_launch_mfma16_hess2(const QcParams& P, const double* dZ, const double* dMu, double* dH, hipStream_t st);
 hipError_t qc_launch_mfma16_fused(const QcParams& P, const double* dZ, const double* dMu, double* dF, double* dJ, double* dH, hipStream_t st);
 hipError_t qc_launch_mfma_hess(const QcParams& P, const double* dZ, const double* dMu, double* dH, hipStream_t st);
 

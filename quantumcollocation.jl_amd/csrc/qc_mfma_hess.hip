@@ -669,6 +669,7 @@ hipError_t qc_launch_mfma_hess(const QcParams& P, const double* dZ, const double
     if (qc_mfma16_padeP_hess_supported(P)) return qc_launch_mfma16_padeP_hess(P, dZ, dMu, dH, st);
     if (P.n > 32) return qc_launch_mfma64_hess(P, dZ, dMu, dH, st);
     if (P.n > 16) return qc_launch_mfma32_hess(P, dZ, dMu, dH, st);
+    if (qc_mfma16_hess2_supported(P)) return qc_launch_mfma16_hess2(P, dZ, dMu, dH, st);     // two waves per interval, up to one round of the device (qc_mfma_hess2.hip)
     const int grid = P.n_int < 4096 ? P.n_int : 4096;
     if (P.nc != 8 || P.n != 16) {
         if (P.m <= 2) launch_hess16<2, true>(P, dZ, dMu, dH, st, grid);

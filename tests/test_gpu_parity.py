@@ -864,6 +864,32 @@ def test_fused_launch_is_bit_identical(qc, case):
     dyn.close()
 
 
+@pytest.mark.parametrize("m,free_time", [(6, True), (5, True), (3, False), (2, True), (1, True)])
+def test_two_wave_hessian_kernel_equals_the_one_wave_kernel(qc, oracle, m, free_time):
+    """mu_d2F at 2N = 16: launches of up to 1024 intervals take the two-wave kernel (qc_mfma_hess2.hip), longer ones the one-wave
+    kernel (qc_mfma_hess.hip).  A trajectory of 1030 knots in one handle (one-wave) and in two shards on device 0 (two-wave): the
+    same bits; a window of both against the oracle."""
+    from oracle_bridge import problem_from_inputs
+    rng = np.random.default_rng(10 + m)
+    herm = lambda: (lambda A: (A + A.conj().T) / 2)(rng.standard_normal((8, 8)) + 1j * rng.standard_normal((8, 8)))
+    system = qc.QuantumSystem(herm(), [herm() for _ in range(m)])
+    inp = qc.unitary_smooth_pulse_inputs(system, qc.GATES["TOFFOLI"], 1030, free_time=free_time)
+    inp_short = qc.unitary_smooth_pulse_inputs(system, qc.GATES["TOFFOLI"], 40, free_time=free_time)
+    one = qc.QuantumDynamics(inp.integrators, inp.traj)
+    two = qc.QuantumDynamics(inp.integrators, inp.traj, devices=[0, 0])
+    short = qc.QuantumDynamics(inp_short.integrators, inp_short.traj)
+    assert one.kernel_names[1] == "mfma16-pade4-hess" and short.kernel_names[1] == "mfma16-pade4-hess2", (one.kernel_names, short.kernel_names)
+    short.close()
+    Z = inp.traj.datavec + 1e-2 * rng.standard_normal(inp.traj.datavec.size)
+    mu = rng.standard_normal(int(one.dims.n_rows))
+    H1, H2 = one.mu_d2F(Z, mu), two.mu_d2F(Z, mu)
+    assert np.array_equal(H1.view(np.uint64), H2.view(np.uint64)), f"{(H1 != H2).sum()} of {H1.size} values differ, max {np.abs(H1 - H2).max():.3e}"
+    Ho = oracle.mu_d2F(problem_from_inputs(inp), Z, mu, 0, 3)
+    assert np.abs(H2[:Ho.size] - Ho).max() <= 1e-10 * max(1.0, np.abs(Ho).max())
+    one.close()
+    two.close()
+
+
 @pytest.mark.parametrize("cfg,T", [(3, 257), (5, 33), (1, 50)])
 def test_new_x_elision_and_unaligned_buffers(qc, cfg, T):
     """qc_set_new_x(h, 0): the knots on the device are used and Z is not read at all (handing in garbage proves it); caller
@@ -1367,7 +1393,7 @@ def test_any_order_mfma_kernel_matches_oracle(qc, oracle, order, N, m, ncol, fre
 def test_kernel_names_of_the_baseline_configurations(qc):
     """Which device kernels serve BASELINE.json's configurations (qc_kernel_name): the tuned MFMA kernels, not a generic path."""
     expect = {1: ("mfma16-pade4", "mfma16-pade4-hess"), 2: ("mfma16-pade4", "mfma16-pade4-hess"),
-              3: ("mfma16-pade4", "mfma16-pade4-hess"), 5: ("mfma32-pade4", "mfma32-pade4-hess")}
+              3: ("mfma16-pade4", "mfma16-pade4-hess2"), 5: ("mfma32-pade4", "mfma32-pade4-hess")}     # (hess2: two waves per interval, <= 1024 intervals)
     for cfg, names in expect.items():
         inp = qc.config_inputs(cfg, T=5)
         dyn = qc.QuantumDynamics(inp.integrators, inp.traj)
