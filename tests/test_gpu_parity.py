@@ -864,6 +864,39 @@ def test_fused_launch_is_bit_identical(qc, case):
     dyn.close()
 
 
+def test_device_entry_points_can_be_captured_in_a_hip_graph(qc):
+    """The _dev entry points only enqueue kernels on the caller's stream (after the first call has sized the handle's buffers): a HIP
+    graph captured around them replays to the same values.  (profiles/graph_probe.py: a replay of one iteration's two launches costs
+    22.5 us against 17.9 us for the stream launches -- a graph launch is dearer than the two launch gaps it saves.)"""
+    import torch
+    inp = qc.config_inputs(3, T=130)
+    dyn = qc.QuantumDynamics(inp.integrators, inp.traj)
+    d = dyn.dims
+    rng = np.random.default_rng(5)
+    Z = torch.from_numpy(inp.traj.datavec + 1e-2 * rng.standard_normal(inp.traj.datavec.size)).cuda()
+    mu = torch.from_numpy(rng.standard_normal(int(d.n_rows))).cuda()
+    new = lambda n: torch.full((int(n),), float("nan"), dtype=torch.float64, device="cuda")
+    F, J, H, F2 = new(d.F_len), new(d.jac_nnz), new(d.hess_nnz), new(d.F_len)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        dyn.F_dF_mu_d2F_device(Z, mu, F, J, H, s)
+        dyn.F_dF_device(Z, F2, None, s)
+        s.synchronize()
+        ref = (F.clone(), J.clone(), H.clone(), F2.clone())
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=s):
+            dyn.F_dF_mu_d2F_device(Z, mu, F, J, H, torch.cuda.current_stream())
+            dyn.F_dF_device(Z, F2, None, torch.cuda.current_stream())
+    for t in (F, J, H, F2):
+        t.fill_(float("nan"))
+    graph.replay()
+    torch.cuda.synchronize()
+    for a, b in zip((F, J, H, F2), ref):
+        assert torch.equal(a, b)
+    del graph
+    dyn.close()
+
+
 @pytest.mark.parametrize("m,free_time", [(6, True), (5, True), (3, False), (2, True), (1, True)])
 def test_two_wave_hessian_kernel_equals_the_one_wave_kernel(qc, oracle, m, free_time):
     """mu_d2F at 2N = 16: launches of up to 1024 intervals take the two-wave kernel (qc_mfma_hess2.hip), longer ones the one-wave
