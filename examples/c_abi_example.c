@@ -71,6 +71,22 @@ int main(void) {
     for (long long i = 0; i < dims.jac_nnz; ++i) sJ += J[i] * (1 + i % 11);
     for (long long i = 0; i < dims.hess_nnz; ++i) sH += H[i] * (1 + i % 13);
     printf("checksums F %.15e dF %.15e mu_d2F %.15e first entry (%lld,%lld) %s\n", sF, sJ, sH, (long long)rows[0], (long long)cols[0], qc_version());
+    /* Ipopt's order of calls: residuals at a new x, then the Jacobian and the Hessian of the Lagrangian at the
+       SAME x with new_x = false -- the knots already on the device are used, Z is not read or uploaded again. */
+    {
+        double* J2 = malloc((size_t)dims.jac_nnz * sizeof(double));
+        double* H2 = malloc((size_t)dims.hess_nnz * sizeof(double));
+        if (qc_abi_version() != QC_VERSION_MAJOR * 1000 + QC_VERSION_MINOR) { fprintf(stderr, "header / library mismatch\n"); return 1; }
+        CHECK(qc_set_new_x(h, 1));
+        CHECK(qc_eval_F(h, Z, F));
+        CHECK(qc_set_new_x(h, 0));
+        CHECK(qc_eval_jac(h, Z, J2));                 /* (Z is not read) */
+        CHECK(qc_eval_hess(h, Z, mu, H2));
+        CHECK(qc_set_new_x(h, 1));
+        printf("ipopt order: %s\n", memcmp(J, J2, (size_t)dims.jac_nnz * sizeof(double)) == 0 &&
+                                     memcmp(H, H2, (size_t)dims.hess_nnz * sizeof(double)) == 0 ? "same values" : "DIFFERENT VALUES");
+        free(J2); free(H2);
+    }
     qc_destroy(h);
     free(Z); free(F); free(J); free(H); free(mu); free(rows); free(cols);
     return 0;
