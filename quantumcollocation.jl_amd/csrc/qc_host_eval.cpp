@@ -786,7 +786,12 @@ static int land_run(qc_handle* h, LandJob& J, int shards, double t_begin, double
     pool.ensure(workers, h->device);
     J.bound.assign(1, 0);
     const int per = land_piece_intervals(J.blk * sizeof(double));
-    for (int b = per; b < J.n_int; b += per) J.bound.push_back(b);
+    // The last pieces are cut finer (QC_HOST_TAIL_SPLIT parts each, default 4; 1: uniform): when the copy's last bytes land every
+    // member is idle, and the call ends one piece's replication later -- a quarter piece instead of a whole one.
+    static const int tail_split = getenv("QC_HOST_TAIL_SPLIT") ? std::max(1, atoi(getenv("QC_HOST_TAIL_SPLIT"))) : 4;
+    const int fine = std::max(1, per / tail_split);
+    const int tail_from = tail_split > 1 ? std::max(0, J.n_int - 2 * per) : J.n_int;
+    for (int b = per; b < J.n_int; b += (b >= tail_from ? fine : per)) J.bound.push_back(b);
     J.bound.push_back(J.n_int);
     const int np = (int)J.bound.size() - 1;
     J.claimed.reset(new std::atomic<int>[np]);
