@@ -1,6 +1,7 @@
 // mu_d2F of every interval, order-4 Pade, 2N = 16 (a unitary on 8 levels: BASELINE configs 3 and 4), up to 6 drives, exactly
-// antisymmetric generators: the one-wave kernel of qc_mfma_hess.hip (qc_mfma16_pade4_hess_anti_kernel) with its back half re-ordered
-// and a second wave per interval that takes the (a, a) sums.  (Reference call site: test/scripts/integrator_test_1qubit.jl:50-52.)
+// antisymmetric generators: the one-wave kernel of qc_mfma_hess.hip (qc_mfma16_pade4_hess_anti_kernel) with a second wave per interval
+// that takes the last drive pair's share of the back half and the (a, a) sums.  Launches of up to 1024 intervals (one round of the
+// device); longer ones keep the one-wave kernel.  (Reference call site: test/scripts/integrator_test_1qubit.jl:50-52.)
 //
 // What a launch of the one-wave kernel waits for (tests/hip/launch_gap2.hip, profiles/r03_launch_gap2.txt: a launch = the waves'
 // lifetime + 1.1 us, and bytes stored at a wave's end drain for bytes / 6.8 TB/s AFTER it): the longest wave (7.4 - 8.1 us: loads 1.4,
@@ -8,15 +9,20 @@
 // stores leave between 4.9 and 6.3 us.  Both are moved here, with the arithmetic of every value unchanged (the same operations in the
 // same order: the same bits as the one-wave kernel and as the fused kernel of qc_mfma_fused.hip, tests/test_gpu_parity.py):
 //
-//   wave 0  loads, G, stage A as before; the T_k parked in LDS; barrier (never waits: wave 1 is already there).  Stage B in two
-//           parts -- Y2 and all drive pairs but the last, whose tiles ((U, h), (h, U) and the pairs' (U, a), (a, U) blocks: five
-//           sevenths of the bytes at six drives) are combined, transposed and STORED before the last pair's chain is issued --, then
-//           the last pair, the (a, h) and (h, h) sums
-//   wave 1  waits at the barrier, then the 21 (a, a) products from the parked T_k, their reduction and stores: three quarters of the
-//           one-wave kernel's 1.7 us tail, on another wave (its vector work overlaps the matrix work of the waves it shares a SIMD with)
+//   wave 0  loads, G, stage A as before; parks the T_k, G and Y in LDS; barrier (never waits: wave 1 is already there).  Stage B of Y2
+//           and of all drive pairs but the last; their tiles -- (U, h), (h, U) and the pairs' (U, a), (a, U) blocks: five sevenths of
+//           the bytes at six drives -- combined, transposed, stored; the (a, h) sums of those pairs and (h, h)
+//   wave 1  sleeps 1.3 us, then requests what it needs besides the parked tiles -- the two images of the LAST drive pair and the knots'
+//           tiles -- (requested at entry they queued in front of wave 0's loads in the CU's one vector-memory pipeline: its loads back at
+//           2.0 instead of 1.4 us); after the barrier the last pair's chain of twelve MFMAs, its transposes and stores, its (a, h) sum, and
+//           the 21 (a, a) products from the parked T_k with their reduction: three quarters of the one-wave kernel's 1.7 us tail
 //
-// LDS per workgroup (doubles, kMU = 6): parked T_k 6 x 256 | transposes 5 x 272 (wave 0's reduction rows alias them) | wave 1's
-// reduction rows 21 x 65 = 34.1 KB: four workgroups per CU.
+// Timeline (profiles/r03_hess2_timeline.txt, stamped build, T = 1000): wave 0's blocks stored at 5.2 us, wave 1's at 4.5, the waves
+// done at 6.3 / 6.1 (6.85 max) against 7.4 (8.2) in the one-wave kernel; launches 8.4 - 8.65 against 8.5 - 8.75 us at T = 1000, 7.0
+// against 7.5 at T = 500, 6.1 - 6.8 against 7.0 at T = 250 (DESIGN.md 5.1a has the three forms that were measured and not kept).
+//
+// LDS per workgroup (doubles, kMU = 6): parked T_k 6 x 256 | wave 0's transposes 5 x 272 (its reduction rows alias them) | wave 1's
+// reduction rows 22 x 65 (its transposes alias them) | G, Y 2 x 256 = 37.8 KB: four workgroups per CU.
 #include <stdlib.h>
 
 #include "qc_mfma_hess_common.h"
