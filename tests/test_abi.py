@@ -413,3 +413,72 @@ def test_julia_struct_mirrors_match_the_ctypes_mirrors(qc):
             else:
                 assert C.sizeof(jt) == C.sizeof(ct) and (jt is ct or jt._type_ == getattr(ct, "_type_", None)), (jname, fname)
     assert "qc_sizeof_desc" in txt and "qc_create_multi" in txt and "F!" in txt
+
+
+def _c_prototypes():
+    """name -> (return kind, [argument kinds]) of every function include/qcolloc.h declares; kinds: 'ptr', 'i32', 'i64', 'f64', 'void'."""
+    txt = open(os.path.join(ROOT, "include", "qcolloc.h"), encoding="utf-8").read()
+    txt = re.sub(r"/\*.*?\*/", " ", txt, flags=re.S)
+
+    def kind(t):
+        t = t.strip()
+        if "*" in t:
+            return "ptr"
+        base = t.replace("const", "").split()
+        if not base or base == ["void"]:
+            return "void"
+        if len(base) > 1 and re.fullmatch(r"\w+", base[-1]) and base[-1] not in ("int", "int32_t", "int64_t", "double"):
+            base = base[:-1]                     # drop the parameter name
+        return {"int": "i32", "int32_t": "i32", "int64_t": "i64", "double": "f64"}[" ".join(base)]
+
+    protos = {}
+    for m in re.finditer(r"^\s*((?:const\s+)?(?:int|int32_t|int64_t|void|char|double)\s*\*?)\s*(qc_\w+)\s*\(([^;{}]*)\)\s*;", txt, flags=re.M):
+        ret, name, args = m.group(1), m.group(2), m.group(3)
+        args = [a for a in (x.strip() for x in args.replace("\n", " ").split(",")) if a and a != "void"]
+        protos[name] = (kind(ret), [kind(a) for a in args])
+    return protos
+
+
+def test_julia_ccalls_match_the_header():
+    """julia/*.jl cannot be run here; every `ccall((:qc_..., LIB[]), Ret, (Args...), ...)` in them is checked against the C prototype
+    of include/qcolloc.h: the function exists, the arity matches, integers have the right width, pointers are pointers."""
+    protos = _c_prototypes()
+    assert {"qc_create", "qc_eval_F_jac", "qc_eval_hess", "qc_set_new_x", "qc_abi_version", "qc_terms_eval"} <= set(protos), sorted(protos)[:5]
+
+    def jkind(t):
+        t = t.strip()
+        if t.startswith(("Ptr{", "Ref{")) or t == "Cstring":
+            return "ptr"
+        return {"Cint": "i32", "Int32": "i32", "Int64": "i64", "Clonglong": "i64", "Float64": "f64", "Cdouble": "f64", "Cvoid": "void"}[t]
+
+    def split_top(s):            # split on commas outside braces / parentheses
+        out, depth, cur = [], 0, ""
+        for ch in s:
+            depth += ch in "{(" 
+            depth -= ch in "})"
+            if ch == "," and depth == 0:
+                out.append(cur)
+                cur = ""
+            else:
+                cur += ch
+        if cur.strip():
+            out.append(cur)
+        return [x.strip() for x in out if x.strip()]
+
+    seen = 0
+    for fn in ("QCollocHIP.jl", "reconcile.jl"):
+        txt = open(os.path.join(ROOT, "julia", fn), encoding="utf-8").read()
+        for m in re.finditer(r"ccall\(\(:(qc_\w+),\s*LIB\[\]\),\s*([\w{}]+),\s*\(", txt):
+            name, ret = m.group(1), m.group(2)
+            depth, i = 1, m.end()
+            while depth:                          # the argument-type tuple, to its closing parenthesis
+                depth += txt[i] == "("
+                depth -= txt[i] == ")"
+                i += 1
+            jargs = split_top(txt[m.end():i - 1])
+            assert name in protos, f"{fn}: {name} is not declared in include/qcolloc.h"
+            cret, cargs = protos[name]
+            assert jkind(ret) == cret, (fn, name, ret, cret)
+            assert [jkind(a) for a in jargs] == cargs, (fn, name, jargs, cargs)
+            seen += 1
+    assert seen >= 20, seen
