@@ -32,3 +32,31 @@ def test_interior_point_solve_with_exact_hessians(qc):
     # and one mu_d2F
     assert stats["F_dF"] + stats["dF"] == stats["mu_d2F"] and 10 <= stats["mu_d2F"] <= 60
     assert stats["F"] >= stats["mu_d2F"] and stats["uploads_elided"] >= stats["dF"]
+
+
+@pytest.mark.gpu
+def test_bench_line_keeps_the_driver_contract():
+    """`python bench.py --gpus 1 --steps K --warmup W` prints ONE JSON line with the keys the driver and the judge read: the metric of
+    BASELINE.json, whole-job throughput, K and W as given, the `roofline` and `cpu_baseline` objects -- here in a short run."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "7", "--warmup", "3", "--cpu-seconds", "0.6",
+                        "--prewarm-seconds", "0", "--no-config5"], capture_output=True, text=True, timeout=600, check=True, cwd=root)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-500:]
+    d = json.loads(lines[0])
+    base = json.load(open(os.path.join(root, "BASELINE.json")))
+    assert d["metric"].split(",")[0] in base["metric"] and "3-qubit" in d["metric"] and "T=1000" in d["metric"]
+    assert d["n_gpus"] == 1 and d["steps"] == 7 and d["warmup"] == 3 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["dtype"] == "f64" and d["vs_baseline"] is None and d["data"].startswith("synthetic") and "workload" in d["config"]
+    assert d["value"] > 1e4 and abs(d["value"] * d["ms_per_step"] * 1e-3 - 1.0) < 1e-6          # evals/s x s/step = 1 at N = 1
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    assert 0.2 < rf["frac"] < 1.0 and (rf["traffic"] is None or rf["traffic"] > 4e7)
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"] and cb["ms_per_ipopt_iter"] > 0
+    hv = d["host_visible"]
+    assert set(hv["bound_ms"]) <= set(hv["frac_of_bound"]) | {"ipopt_sequence_ms"} and 0 < hv["F_dF_ms"] < 5 and 0 < hv["hess_ms"] < 5
+    assert d["F_dF_hess_kernel"] == "mfma16-pade4-fused" and d["hess_us"] < 50 and d["ms_per_ipopt_iter_proxy_device"] < 0.1
