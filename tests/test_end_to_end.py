@@ -60,3 +60,29 @@ def test_bench_line_keeps_the_driver_contract():
     hv = d["host_visible"]
     assert set(hv["bound_ms"]) <= set(hv["frac_of_bound"]) | {"ipopt_sequence_ms"} and 0 < hv["F_dF_ms"] < 5 and 0 < hv["hess_ms"] < 5
     assert d["F_dF_hess_kernel"] == "mfma16-pade4-fused" and d["hess_us"] < 50 and d["ms_per_ipopt_iter_proxy_device"] < 0.1
+
+
+@pytest.mark.gpu
+def test_bench_line_at_two_ranks_is_complete():
+    """The N > 1 line (two gloo ranks sharing the one GPU: the code path, not scaling data) carries what the verdict of round 2 asked
+    for: rank 0's cpu_baseline, the host-visible speed-up in T = 1000 equivalents, the aggregate roofline, the all-gather figures."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, QC_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29541", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
+                        "--cpu-seconds", "0.6", "--prewarm-seconds", "0"], capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-1500:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-500:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["scaling"] == "weak" and d["rccl_ranks"] == 2 and d["collective_backend"] == "gloo"
+    assert d["cpu_baseline"] and d["cpu_baseline"]["value"] > 0 and d["speedup_vs_cpu_baseline"] > 1
+    rf = d["roofline"]
+    assert rf["aggregate_peak"] == 16000.0 and abs(rf["aggregate_frac"] - rf["aggregate_achieved"] / rf["aggregate_peak"]) < 1e-9
+    assert d["allgather_ms"] > 0 and d["xgmi_GBps_per_gpu_peak"] == 153.0
+    hv = d["host_visible"]
+    import torch
+    assert hv["devices"] == [r % torch.cuda.device_count() for r in range(2)] and hv["speedup_vs_cpu_baseline"] > 0 and hv["host_expand_GBps"] > 0 and hv["evals_per_s_T1000_equivalent"] > 0
