@@ -483,6 +483,38 @@ def test_full_size_hessian_properties(qc, oracle, cfg, T):
     dyn.close()
 
 
+@pytest.mark.parametrize("cfg", [3, 4])
+def test_full_size_every_value_against_the_c_oracle(qc, cfg):
+    """BASELINE configs 3 (T = 1000) and 4 (T = 8000, on one GPU) at full size: EVERY residual, Jacobian value and Hessian value of the
+    host-buffer entry points against the C restatement of the oracle (oracle/qc_oracle.c, OpenMP: milliseconds at these sizes; itself
+    checked against the numpy oracle in tests/test_oracle_c.py), rtol 1e-10; the device-resident one-call form gives the same bits."""
+    import torch
+    import oracle.qc_oracle_c as oc
+    inp = qc.config_inputs(cfg)
+    assert inp.traj.T == (1000 if cfg == 3 else 8000)
+    prob = problem_from_inputs(inp)
+    co = oc.COracle(prob)
+    rng = np.random.default_rng(cfg)
+    Z = inp.traj.datavec + 1e-2 * rng.standard_normal(inp.traj.datavec.size)
+    mu = rng.standard_normal(prob.n_rows)
+    dyn = qc.QuantumDynamics(inp.integrators, inp.traj)
+    F, J = dyn.F_dF(Z)
+    H = dyn.mu_d2F(Z, mu)
+    Fr, Jr = co.F_dF(Z)
+    Hr = co.mu_d2F(Z, mu)
+    assert F.shape == Fr.shape and J.shape == Jr.shape and H.shape == Hr.shape
+    assert_close(F, Fr, f"config {cfg} F")
+    assert_close(J, Jr, f"config {cfg} dF")
+    assert_close_h(H, Hr, f"config {cfg} mu_d2F")
+    assert_close(dyn.F(Z), Fr, f"config {cfg} F alone")
+    dZ, dmu = torch.from_numpy(Z).cuda(), torch.from_numpy(mu).cuda()
+    dF, dJ, dH = (torch.empty(int(n), dtype=torch.float64, device="cuda") for n in (dyn.dims.F_len, dyn.dims.jac_nnz, dyn.dims.hess_nnz))
+    dyn.F_dF_mu_d2F_device(dZ, dmu, dF, dJ, dH)
+    torch.cuda.synchronize()
+    assert np.array_equal(dF.cpu().numpy(), F) and np.array_equal(dJ.cpu().numpy(), J) and np.array_equal(dH.cpu().numpy(), H)
+    dyn.close()
+
+
 # ------------------------------------------------------------------------------------------------
 #  Exponential integrator (SURVEY A.6): residual, Jacobian, structure; no analytic Hessian
 # ------------------------------------------------------------------------------------------------
