@@ -670,7 +670,11 @@ hipError_t qc_launch_mfma_hess(const QcParams& P, const double* dZ, const double
     if (P.n > 32) return qc_launch_mfma64_hess(P, dZ, dMu, dH, st);
     if (P.n > 16) return qc_launch_mfma32_hess(P, dZ, dMu, dH, st);
     if (qc_mfma16_hess2_supported(P)) return qc_launch_mfma16_hess2(P, dZ, dMu, dH, st);     // two waves per interval, up to one round of the device (qc_mfma_hess2.hip)
-    const int grid = P.n_int < 4096 ? P.n_int : 4096;
+    // One interval per workgroup up to two rounds of the device (4 x 256 resident workgroups), a persistent grid of one round beyond:
+    // T = 2000 / 4000 / 8000 / 32000 take 15.1 / 25.4 / 46.1 / 173.8 us with 1024 workgroups against 15.1 / 26.5 / 47.7 / 173.8 with 4096
+    // (15.3 at T = 2000 with 1024: there the loop-free form stays).  QC_HESS_GRID overrides the persistent grid's size.
+    static const int grid_cap = getenv("QC_HESS_GRID") ? atoi(getenv("QC_HESS_GRID")) : 1024;
+    const int grid = P.n_int <= 2048 ? P.n_int : (P.n_int < grid_cap ? P.n_int : grid_cap);
     if (P.nc != 8 || P.n != 16) {
         if (P.m <= 2) launch_hess16<2, true>(P, dZ, dMu, dH, st, grid);
         else if (P.m <= 4) launch_hess16<4, true>(P, dZ, dMu, dH, st, grid);

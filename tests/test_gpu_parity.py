@@ -447,9 +447,9 @@ def test_antisymmetric_generator_path_matches_general_path(qc, monkeypatch, cfg,
     np.testing.assert_allclose(out[0], out[1], rtol=1e-11, atol=1e-12 * scale)
 
 
-@pytest.mark.parametrize("cfg,T", [(3, 1000), (5, 500), (3, 4300), (5, 1100)])
+@pytest.mark.parametrize("cfg,T", [(3, 1000), (5, 500), (3, 3000), (3, 4300), (5, 1100)])
 def test_full_size_hessian_properties(qc, oracle, cfg, T):
-    """Configs 3 (T=1000) and 5 (T=500) at full size, and stretched past the grids' caps (4 299 intervals on 4 096 persistent
+    """Configs 3 (T=1000) and 5 (T=500) at full size, and stretched past the grids' caps (2 999 and 4 299 intervals on 1 024 persistent
     workgroups at 2N = 16; five intervals per workgroup at 2N = 32): linearity in mu, directional second derivative against
     the Jacobian, an oracle window in the middle of the trajectory."""
     inp = qc.config_inputs(cfg, T=T)
