@@ -37,7 +37,11 @@ namespace {
 using namespace qc_mfma;
 
 constexpr int kFuThreads = 128;
-constexpr int kFuMaxGrid = 1024;             // one interval per workgroup; longer trajectories go out in several launches
+// One interval per workgroup, the whole trajectory in one launch.  (Rounds 3's first form sent longer trajectories out in launches of
+// 1024 workgroups -- one round of the device --: T = 2000 / 4000 / 8000 took 26.5 / 53.7 / 108.7 us against 25.9 / 46.1 / 84.1 us in one
+// launch, the hardware refilling each CU as its workgroups retire.)
+constexpr int kFuMaxGrid = 1 << 24;
+constexpr int kFuMaxStamped = 1024;          // the time-stamped build (QC_STAMPS=1) records one round
 constexpr int kFuDF = 4;                     // derivative integrators served from registers (F + dF part)
 constexpr int kLdsGa = 0, kLdsU0 = 256, kLdsU1 = 512, kLdsM = 768, kLdsGk = 1024;
 
@@ -625,7 +629,7 @@ __global__ __launch_bounds__(kFuThreads, 2) void qc_mfma16_pade4_fused_kernel(co
 
 bool qc_mfma16_fused_supported(const QcParams& P) {
     return P.integrator == QC_PADE && P.p == 2 && P.n == 16 && P.nc == 8 && P.antisym && P.m >= 1 && P.m <= 6 && P.hess_nnz > 0 && P.store_mode == 2 &&
-           (P.stamps == nullptr || (P.m > 4 && P.n_int <= kFuMaxGrid)) && P.dbg_skip == 0 && P.Gx != nullptr && P.copies == P.nc;
+           (P.stamps == nullptr || (P.m > 4 && P.n_int <= kFuMaxStamped)) && P.dbg_skip == 0 && P.Gx != nullptr && P.copies == P.nc;
 }
 
 hipError_t qc_launch_mfma16_fused(const QcParams& P, const double* dZ, const double* dMu, double* dF, double* dJ, double* dH, hipStream_t st) {

@@ -861,7 +861,7 @@ def test_fused_launch_is_bit_identical(qc, case):
     if case == "cfg3":
         inp = qc.config_inputs(3, T=257)
     elif case == "cfg3_long":
-        inp = qc.config_inputs(3, T=1100)                  # > 1024 intervals: two launches of the fused kernel
+        inp = qc.config_inputs(3, T=1100)                  # more than one round of the device (1024 workgroups)
     elif case == "cfg3_fixed_dt":
         inp = qc.unitary_smooth_pulse_inputs(qc.multi_qubit_system(3), qc.GATES["TOFFOLI"], 40, free_time=False)
     elif case in ("m1", "m2", "m3", "m4", "m5"):
