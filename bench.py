@@ -163,18 +163,19 @@ def host_visible_times(dyn, Zs, reps=30):
     Hh, mu = np.empty(int(dims.hess_nnz)), np.ones(int(dims.n_rows))
     nz = len(Zs)
 
-    def timed(fn):      # median of `reps` calls (the host is shared: one preempted call in thirty moves a mean by a tenth)
+    mins = {}
+
+    def timed(fn, key, n=reps):   # median of `n` calls (the host is shared: one preempted call in thirty moves a mean by a tenth)
         for i in range(3):
             fn(i)
         ts = []
-        for i in range(reps):
+        for i in range(n):
             t0 = time.perf_counter()
             fn(i)
             ts.append(time.perf_counter() - t0)
-        mins[len(mins)] = float(np.min(ts)) * 1e3
+        mins[key] = float(np.min(ts)) * 1e3
         return float(np.median(ts)) * 1e3
 
-    mins = {}
     has_h = bool(dims.hess_nnz)
     # pre-bound calls (QuantumDynamics.bind_host): the C entry point with its pointers, no per-call Python argument handling
     status = [0]
@@ -187,14 +188,14 @@ def host_visible_times(dyn, Zs, reps=30):
         status[0] |= c()
 
     dyn.set_new_x(True)
-    out = {"F_dF_ms": timed(lambda i: run(cFJ[i % nz])), "F_ms": timed(lambda i: run(cF[i % nz]))}
+    out = {"F_dF_ms": timed(lambda i: run(cFJ[i % nz]), "F_dF_ms"), "F_ms": timed(lambda i: run(cF[i % nz]), "F_ms")}
     if has_h:
-        out["hess_ms"] = timed(lambda i: run(cH[i % nz]))
+        out["hess_ms"] = timed(lambda i: run(cH[i % nz]), "hess_ms")
     run(cF[0])
     dyn.set_new_x(False)
-    out["jac_same_x_ms"] = timed(lambda i: run(cJ[0]))
+    out["jac_same_x_ms"] = timed(lambda i: run(cJ[0]), "jac_same_x_ms")
     if has_h:
-        out["hess_same_x_ms"] = timed(lambda i: run(cH[0]))
+        out["hess_same_x_ms"] = timed(lambda i: run(cH[0]), "hess_same_x_ms")
 
     def sequence(i):
         dyn.set_new_x(True)
@@ -204,10 +205,26 @@ def host_visible_times(dyn, Zs, reps=30):
         if has_h:
             run(cH[i % nz])
 
-    out["ipopt_sequence_ms"] = timed(sequence)
+    out["ipopt_sequence_ms"] = timed(sequence, "ipopt_sequence_ms")
     dyn.set_new_x(True)
-    out["fastest_call_ms"] = dict(zip([k for k in out], mins.values()))
+    out["fastest_call_ms"] = dict(mins)
     assert status[0] == 0, "a host-buffer call reported an error"
+    # The reference-shaped closures: dynamics.F(Z) / dF(Z) / mu_d2F(Z, mu) RETURN a vector (integrator_test_1qubit.jl:45-52), which is
+    # all QuantumCollocationCore's unchanged evaluator calls.  `closure_ms`: the bindings' default, each closure's ring of three result
+    # vectors faulted in when the ring is built; `closure_fresh_ms`: a newly allocated vector per call (fresh=True; what a binding
+    # without the ring does) -- the first touch of 40 MB of new pages, not the GPU, then sets the rate.  Through the Python mirror's
+    # no-`out=` methods, argument checks included.
+    if hasattr(dyn, "result_ring") and dyn.result_ring:
+        cl, fr = {}, {}
+        for name, call in (("F", lambda i, **kw: dyn.F(Zs[i % nz], **kw)), ("dF", lambda i, **kw: dyn.dF(Zs[i % nz], **kw)),
+                           ("F_dF", lambda i, **kw: dyn.F_dF(Zs[i % nz], **kw)),
+                           ("hess", (lambda i, **kw: dyn.mu_d2F(Zs[i % nz], mu, **kw)) if has_h else None)):
+            if call is None:
+                continue
+            cl[name] = timed(lambda i: call(i), "closure." + name)
+            fr[name] = timed(lambda i: call(i, fresh=True), "closure_fresh." + name, n=10)
+        out["closure_ms"], out["closure_fresh_ms"] = cl, fr
+        out["closure_result_ring"] = int(dyn.result_ring)
     return out
 
 

@@ -69,7 +69,7 @@ extern "C" {
 #endif
 
 #define QC_VERSION_MAJOR 0
-#define QC_VERSION_MINOR 3
+#define QC_VERSION_MINOR 4
 
 enum {
     QC_OK = 0,
@@ -228,6 +228,11 @@ int qc_eval_hess(qc_handle* h, const double* Z, const double* mu, double* hvals)
  * on the device are used and Z is not read at all.  Stays in force until qc_set_new_x(h, 1) (the default: every call copies
  * its Z).  A handle that has not seen a Z yet copies regardless.  Multi-device handles pass the flag on to their shards. */
 int qc_set_new_x(qc_handle* h, int new_x);
+/* How many times the handle has copied a trajectory vector's knots to the device so far (host-buffer calls with new_x = 1; -1 for a
+ * NULL handle).  A binding that elides uploads remembers the value after the call that put ITS x on the device and sets new_x = 0
+ * only while the value is unchanged: any other host-buffer call on the same handle in between (another closure, a second evaluator)
+ * moves it.  qc_rollout keeps its trajectory vector in a buffer of its own and does not count. */
+int64_t qc_knot_generation(const qc_handle* h);
 
 /* ---- evaluation, device-resident (asynchronous on `stream`, a hipStream_t) --------------------- */
 /* dZ: device pointer to the full Z vector (8-byte aligned).  dF may be NULL (skip residual store);
@@ -361,19 +366,20 @@ int qc_rollout_dev(qc_handle* h, const double* dZ, const double* dinit, double* 
  * the `QuadraticRegularizer(name, traj, R; baseline, timestep_name)` terms on a / da / dda (reference call sites
  * unitary_smooth_pulse_problem.jl:151-153) flattened into one list of regularised scalar entries of a knot, plus
  * `MinimumTimeObjective(traj; D)` (unitary_minimum_time_problem.jl:67-69; the last knot's timestep drives no
- * interval, hence min_time_knots = T-1 there).  QC_REG_DT_SCALED (0, the default of every binding) puts the timestep
+ * interval, hence min_time_knots = T-1 there).  QC_REG_DT_SCALED (2, the default of every binding) puts the timestep
  * inside the square: every problem template hands the regulariser the timestep's name
  * (`QuadraticRegularizer(name, traj, R; timestep_name=timestep_name)`, unitary_smooth_pulse_problem.jl:151-153,
  * unitary_sampling_problem.jl:116-118, quantum_state_sampling_problem.jl:82-84), which only a definition that reads dt_t
  * needs, and that is how QuantumCollocationCore 0.3 is recalled to define it (not vendored, SURVEY 8c;
- * julia/reconcile.jl settles it).  QC_REG_PLAIN (1) is the docstring's "1/2 sum_t R_a a_t^2 + ..."
- * (unitary_smooth_pulse_problem.jl:13).  The numeric values are those of ABI 0.1; ABI 0.2 had them swapped, which is
- * why bindings must compare qc_abi_version() with the version they were written for at load time.
+ * julia/reconcile.jl settles it).  QC_REG_PLAIN (3) is the docstring's "1/2 sum_t R_a a_t^2 + ..."
+ * (unitary_smooth_pulse_problem.jl:13).  The values 0 and 1 are RETIRED (ABI 0.1 - 0.3 gave them both meanings in turn): a
+ * descriptor that carries one of them is refused with QC_ERR_INVALID, so a binding built against an older header fails loudly
+ * instead of computing the other regulariser; bindings also compare qc_abi_version() at load time.
  * Gradient: dense, Z_len entries (zeros included).  Hessian: upper triangle, per knot
  * [ (v_k,v_k) k=0..n_reg-1 | (v_k,dt) k=0..n_reg-1 | (dt,dt) ]; the last two groups exist only for QC_REG_DT_SCALED
  * with a free timestep. */
-#define QC_REG_DT_SCALED 0
-#define QC_REG_PLAIN 1
+#define QC_REG_DT_SCALED 2
+#define QC_REG_PLAIN 3
 typedef struct qc_terms_desc {
     int64_t T;
     int32_t zdim;

@@ -14,7 +14,7 @@ using Libdl
 
 const LIB = Ref{String}(get(ENV, "QCOLLOC_HIP_LIB", "libqcolloc_hip.so"))
 const QC_MAX_DERIV = 8
-const QC_ABI_VERSION = 3      # QC_VERSION_MAJOR * 1000 + QC_VERSION_MINOR of the include/qcolloc.h these mirrors were written against
+const QC_ABI_VERSION = 4      # QC_VERSION_MAJOR * 1000 + QC_VERSION_MINOR of the include/qcolloc.h these mirrors were written against
 
 # mirror of `qc_desc` (include/qcolloc.h); field order and types must match the header -- `__init__` checks the sizes against
 # the library's own `sizeof` (qc_sizeof_desc / qc_sizeof_dims / qc_sizeof_terms_desc) when the module is loaded
@@ -53,7 +53,7 @@ struct QCFidelityDesc
 end
 
 function __init__()
-    # constants were renumbered between ABI 0.1 / 0.2 / 0.3 (QC_REG_*): the struct sizes do not show that, the version does
+    # constants were renumbered between ABI 0.1 / 0.2 / 0.3 and retired in 0.4 (QC_REG_*): the struct sizes do not show that, the version does
     abi = ccall(dlsym(dlopen(LIB[]), :qc_abi_version), Int32, ())
     abi == QC_ABI_VERSION || error("QCollocHIP: $(LIB[]) has ABI version $abi, this binding mirrors $QC_ABI_VERSION")
     # a stale mirror would corrupt memory silently: compare with the structs the library was compiled with
@@ -71,10 +71,28 @@ end
 
 pad8(v) = ntuple(i -> i <= length(v) ? Int32(v[i]) : Int32(0), QC_MAX_DERIV)
 
+# Result vectors of one closure, handed out in turn.  `zeros` writes every page here, once, so that no call pays for page faults.
+struct ResultRing
+    bufs::Vector{Vector{Float64}}
+    next::Base.RefValue{Int}
+end
+ResultRing(len::Integer, n::Integer) = ResultRing([zeros(Float64, len) for _ in 1:n], Ref(1))
+function next!(r::ResultRing, len::Integer, fresh::Bool)
+    (fresh || isempty(r.bufs)) && return Vector{Float64}(undef, len)
+    v = r.bufs[r.next[]]
+    r.next[] = r.next[] % length(r.bufs) + 1
+    return v
+end
+
 """
-Field-compatible stand-in for `QuantumDynamics` (QuantumCollocationCore.Dynamics).  `F`, `∂F`, `μ∂²F` return a FRESH vector
-per call (two results of the same closure never alias); `F!`, `∂F!`, `μ∂²F!` write into a caller-owned vector (what an MOI
-callback does with Ipopt's buffers: no allocation, no copy).
+Field-compatible stand-in for `QuantumDynamics` (QuantumCollocationCore.Dynamics).
+
+`F(Z⃗)`, `∂F(Z⃗)`, `μ∂²F(Z⃗, μ⃗)` -- the only shapes QuantumCollocationCore's evaluator uses (test/scripts/integrator_test_1qubit.jl:45-52)
+-- return the next vector of a ring of `result_ring` (default 3) result vectors per closure, written once when the ring is built:
+a result stays intact until the `result_ring`-th next call OF THE SAME CLOSURE (the evaluator copies it into Ipopt's buffer at once).
+A fresh `Vector{Float64}(undef, 5_034_960)` per `∂F` call costs 2.7 - 4 ms of first-touch page faults at BASELINE config 3, ten times
+the evaluation.  `∂F(Z⃗; fresh=true)` (or `result_ring = 0`) returns a newly allocated vector that is the caller's for good.
+`F!`, `∂F!`, `μ∂²F!` write into a caller-owned vector (what an evaluator that owns the MOI callbacks does with Ipopt's buffers).
 """
 mutable struct HIPDynamics
     handle::Ptr{Cvoid}
@@ -101,7 +119,7 @@ function state_row_offset(traj, name)
 end
 
 """
-    dynamics(integrators, traj, system; device=0, devices=nothing, eval_hessian=true, rows=:stacked, exact_structure=false)
+    dynamics(integrators, traj, system; device=0, devices=nothing, eval_hessian=true, rows=:stacked, exact_structure=false, result_ring=3)
 
 `integrators[1]` must be the `UnitaryPadeIntegrator` / `UnitaryExponentialIntegrator`, followed by
 `DerivativeIntegrator`s (the order of unitary_smooth_pulse_problem.jl:175-179).  `component_offset(traj, name)`
@@ -114,11 +132,13 @@ GPU copies its own contiguous slice of `∂F` into the caller's vector over its 
 what a `==` / `length` comparison with QuantumCollocationCore's own structure needs (julia/reconcile.jl); the default pads every
 interval's value block to whole cache lines with explicit zero duplicates, which MOI sums away.
 `set_new_x!(dyn, false)` is Ipopt's `new_x = false`: the following calls reuse the knots already on the device.
+`result_ring`: result vectors per closure handed out in turn by `F` / `∂F` / `μ∂²F` (0: a fresh vector per call; else >= 3).
 """
 function dynamics(integrators, traj, system; device::Int=0, devices=nothing, eval_hessian::Bool=true,
                   state_name=:Ũ⃗, control_name=:a, pade_order::Int=4, exponential::Bool=false,
                   derivative_pairs=[(:a, :da), (:da, :dda)], n_kets::Int=0, rows::Symbol=:stacked, hess_align::Int=0,
-                  exact_structure::Bool=false)
+                  exact_structure::Bool=false, result_ring::Int=3)
+    (result_ring == 0 || result_ring >= 3) || error("result_ring must be 0 (fresh vectors) or at least 3")
     exact_structure && (hess_align = 1)
     off(name) = first(traj.components[name]) - 1
     n = 2 * system.levels
@@ -161,8 +181,9 @@ function dynamics(integrators, traj, system; device::Int=0, devices=nothing, eva
         GC.@preserve Z⃗ out check(ccall((:qc_eval_jac, LIB[]), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), h[], Z⃗, out), h[])
         return out
     end
-    F = Z⃗ -> F!(Vector{Float64}(undef, d.F_len), Z⃗)
-    ∂F = Z⃗ -> ∂F!(Vector{Float64}(undef, d.jac_nnz), Z⃗)
+    ringF = ResultRing(d.F_len, result_ring); ring∂F = ResultRing(d.jac_nnz, result_ring)
+    F = (Z⃗; fresh::Bool=false) -> F!(next!(ringF, d.F_len, fresh), Z⃗)
+    ∂F = (Z⃗; fresh::Bool=false) -> ∂F!(next!(ring∂F, d.jac_nnz, fresh), Z⃗)
     μ∂²F = nothing; μ∂²F! = nothing; μ∂²F_structure = nothing
     if eval_hessian && d.hess_nnz > 0
         hr = Vector{Int64}(undef, d.hess_nnz); hc = similar(hr)
@@ -176,7 +197,8 @@ function dynamics(integrators, traj, system; device::Int=0, devices=nothing, eva
                 (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), h[], Z⃗, μ⃗, out), h[])
             return out
         end
-        μ∂²F = (Z⃗, μ⃗) -> μ∂²F!(Vector{Float64}(undef, d.hess_nnz), Z⃗, μ⃗)
+        ringH = ResultRing(d.hess_nnz, result_ring)
+        μ∂²F = (Z⃗, μ⃗; fresh::Bool=false) -> μ∂²F!(next!(ringH, d.hess_nnz, fresh), Z⃗, μ⃗)
     end
     dyn = HIPDynamics(h[], d, F, ∂F, ∂F_structure, μ∂²F, μ∂²F_structure, Int(bycomp ? traj.dims.states : d.ddim), F!, ∂F!, μ∂²F!)
     finalizer(x -> ccall((:qc_destroy, LIB[]), Cvoid, (Ptr{Cvoid},), x.handle), dyn)
@@ -185,6 +207,13 @@ end
 
 "Ipopt's `new_x`: `false` declares that the next host-buffer calls receive the x of the previous one (`qc_set_new_x`)."
 set_new_x!(dyn::HIPDynamics, new_x::Bool) = check(ccall((:qc_set_new_x, LIB[]), Cint, (Ptr{Cvoid}, Cint), dyn.handle, new_x ? 1 : 0), dyn.handle)
+
+"""
+Uploads of a trajectory vector this handle has done so far (`qc_knot_generation`).  An evaluator that elides uploads remembers it
+after the call that put ITS x on the device and passes `new_x = false` only while it is unchanged -- any other call on the same
+handle in between moves it -- and goes back to `set_new_x!(dyn, true)` right after the elided call.
+"""
+knot_generation(dyn::HIPDynamics) = ccall((:qc_knot_generation, LIB[]), Int64, (Ptr{Cvoid},), dyn.handle)
 
 # ---------------------------------------------------------------------------------------------------------------
 #  Objective terms and rollouts (SURVEY.md 8f): the same `ccall` pattern over qc_terms_* / qc_fidelity_* / qc_rollout
@@ -209,7 +238,7 @@ function regularizers(traj, names_and_R; D::Float64=0.0, device::Int=0, dt_scale
     h = Ref{Ptr{Cvoid}}(C_NULL)
     GC.@preserve idx R begin
         desc = Ref(QCTermsDesc(traj.T, traj.dim, free_time ? first(traj.components[traj.timestep]) - 1 : -1, traj.global_dim,
-                               free_time ? 0.0 : Float64(traj.timestep), length(idx), dt_scaled ? 0 : 1,   # QC_REG_DT_SCALED = 0 (templates pass timestep_name=), QC_REG_PLAIN = 1 (docstring form)
+                               free_time ? 0.0 : Float64(traj.timestep), length(idx), dt_scaled ? 2 : 3,   # QC_REG_DT_SCALED = 2 (templates pass timestep_name=), QC_REG_PLAIN = 3 (docstring form); 0 / 1 are retired
                                pointer(idx), pointer(R), C_NULL, D, D == 0.0 ? 0 : traj.T - 1, device, 0))
         rc = ccall((:qc_terms_create, LIB[]), Cint, (Ref{QCTermsDesc}, Ref{Ptr{Cvoid}}), desc, h)
         rc == 0 || error("qc_terms_create: " * unsafe_string(ccall((:qc_terms_last_error, LIB[]), Cstring, (Ptr{Cvoid},), C_NULL)))

@@ -35,9 +35,9 @@ QC_KERNEL_LDS = 1
 QC_KERNEL_MFMA = 2
 QC_MAX_DERIV = 8
 QC_FID_UNITARY, QC_FID_KET, QC_FID_DENSITY = 0, 1, 2
-QC_REG_DT_SCALED = 0
-QC_REG_PLAIN = 1
-QC_ABI_VERSION = 3          # QC_VERSION_MAJOR * 1000 + QC_VERSION_MINOR of the include/qcolloc.h this file mirrors
+QC_REG_DT_SCALED = 2       # (0 and 1 are retired values: the library refuses them)
+QC_REG_PLAIN = 3
+QC_ABI_VERSION = 4          # QC_VERSION_MAJOR * 1000 + QC_VERSION_MINOR of the include/qcolloc.h this file mirrors
 QC_FID_FORM_ABS, QC_FID_FORM_ABS2 = 0, 1
 QC_ROWS_STACKED = 0
 QC_ROWS_BY_COMPONENT = 1
@@ -160,6 +160,7 @@ SYMBOLS = {
     "qc_eval_F_jac": (C.c_int, [_H, _c_double_p, _c_double_p, _c_double_p]),
     "qc_eval_hess": (C.c_int, [_H, _c_double_p, _c_double_p, _c_double_p]),
     "qc_set_new_x": (C.c_int, [_H, C.c_int]),
+    "qc_knot_generation": (C.c_int64, [_H]),
     "qc_eval_F_jac_dev": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "qc_eval_hess_dev": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "qc_eval_F_jac_hess_dev": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -392,7 +392,7 @@ extern "C" int qc_create(const qc_desc* d, qc_handle** out) {
     // Outputs are written once and never re-read by the kernel: non-temporal stores measured fastest on
     // MI355X (profiles/README.md: plain 14.4, sc1 12.8, nt 11.9 us per config-3 evaluation).
     h->prm.store_mode = 2;
-    if (const char* e = getenv("QC_STORE_MODE")) h->prm.store_mode = atoi(e);   // diagnostic override
+    if (const char* e = getenv("QC_STORE_MODE")) h->prm.store_mode = std::max(0, std::min(2, atoi(e)));   // diagnostic override
     // Diagnostic ablation for the profiling scripts: it produces WRONG results, so it needs the explicit opt-in
     // QC_DIAGNOSTICS=1 next to it and says so on stderr every time a handle is created with it.
     if (const char* e = getenv("QC_DEBUG_SKIP")) {
@@ -435,8 +435,8 @@ extern "C" int qc_create(const qc_desc* d, qc_handle** out) {
             Q.ws_stride = (long long)per;
         }
     }
-    if (const char* e = getenv("QC_HOST_COMPACT")) h->host_compact = atoi(e);
-    if (const char* e = getenv("QC_HOST_LANDING")) h->host_landing = atoi(e);
+    if (const char* e = getenv("QC_HOST_COMPACT")) h->host_compact = std::max(0, std::min(2, atoi(e)));
+    if (const char* e = getenv("QC_HOST_LANDING")) h->host_landing = atoi(e) ? 1 : 0;
     if (const char* e = getenv("QC_STAMPS")) {
         if (atoi(e) && P.n_int > 0) {
             QC_HIP_C(hipMalloc((void**)&h->dStamps, (size_t)P.n_int * 16 * sizeof(unsigned long long)));
@@ -466,7 +466,7 @@ extern "C" void qc_destroy(qc_handle* h) {
     // both streams idle before any pinned or device block is freed (a failed call may have left chunk kernels in flight on either)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->stream2) (void)hipStreamSynchronize(h->stream2);
-    double* bufs[] = {h->dG, h->dGx, h->dZ, h->dF, h->dJ, h->dMu, h->dH, (double*)h->dStamps, h->dRE, h->dRQ, h->dRS, h->dRinit, h->dRout, h->dWs, h->dHs};
+    double* bufs[] = {h->dG, h->dGx, h->dZ, h->dF, h->dJ, h->dMu, h->dH, (double*)h->dStamps, h->dRE, h->dRQ, h->dRS, h->dRinit, h->dRout, h->dRZ, h->dWs, h->dHs};
     if (h->hJc) (void)hipHostFree(h->hJc);
     if (h->hFc) (void)hipHostFree(h->hFc);
     if (h->hZ) (void)hipHostFree(h->hZ);

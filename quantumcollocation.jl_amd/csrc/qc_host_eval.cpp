@@ -374,7 +374,7 @@ struct HostPool {
         std::unique_lock<std::mutex> lk(mu);
         for (;;) {
             cv.wait(lk, [&] { return stop || !q.empty(); });
-            if (stop) return;
+            if (q.empty()) return;   // (stop: only once the queue has drained -- re-arm jobs outlive their call, and their group is waited for)
             auto job = std::move(q.front());
             q.pop_front();
             lk.unlock();
@@ -613,6 +613,14 @@ extern "C" int qc_set_new_x(qc_handle* h, int new_x) {
     return QC_OK;
 }
 
+extern "C" int64_t qc_knot_generation(const qc_handle* h) {
+    if (!h) return -1;
+    if (h->shards.empty()) return (int64_t)h->z_gen;
+    unsigned long long g = 0;   // every shard uploads its knots in every call that uploads at all (empty shards never do)
+    for (const qc_handle* sh : h->shards) g = std::max(g, sh->z_gen);
+    return (int64_t)g;
+}
+
 // ------------------------------------------------------------------------------------------------
 //  One launch and one copy per host-buffer call, watched as it lands ("landing watch")
 // ------------------------------------------------------------------------------------------------
@@ -764,6 +772,7 @@ static int upload_knots(qc_handle* h, const double* Z) {
     const size_t o = (size_t)P.t_begin * P.zdim, n = (size_t)(P.n_int + 1) * P.zdim;
     QC_HIP(h, hipMemcpyAsync(h->dZ + o, Z + o, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
     h->z_valid = true;
+    ++h->z_gen;
     return QC_OK;
 }
 
@@ -851,7 +860,13 @@ static int ring_take(qc_handle* h, int* index) {
     int rc;
     if ((rc = ensure_pinned(h, &h->hC[ib], cap, false))) return rc;
     if (h->rearm[ib]) h->rearm[ib]->grp.wait();               // the re-arm jobs of this block's previous use (normally long done)
-    if (!h->hC_armed[ib]) { qc_host_fill(h->hC[ib], cap, kLandSentinel); h->hC_armed[ib] = true; }
+    if (!h->hC_armed[ib]) {
+        // (non-temporal stores: fenced before the copy engine may write the block, or a write-combining buffer draining late
+        //  would put the sentinel over words that have already landed)
+        qc_host_fill(h->hC[ib], cap, kLandSentinel);
+        qc_host_copy_fence();
+        h->hC_armed[ib] = true;
+    }
     *index = ib;
     return QC_OK;
 }
@@ -1027,11 +1042,11 @@ static int eval_host_chunked(qc_handle* h, const double* Z, double* F, double* v
             if (e != hipSuccess) return fail(&h->err, QC_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
             return QC_OK;
         }, two);
-        if (!rc && !z_skip) h->z_valid = true;
+        if (!z_skip) { h->z_valid = rc == QC_OK; ++h->z_gen; }
         return rc;
     }
     if ((rc = stage_knots(0, (size_t)P.n_int + 1))) return rc;
-    if (!z_skip) h->z_valid = true;
+    if (!z_skip) { h->z_valid = true; ++h->z_gen; }
     if (F && (rc = ensure_zeroed(h, &h->dF, (size_t)h->dims.F_len))) return rc;
     if (vals && (rc = ensure(h, &h->dJ, (size_t)h->dims.jac_nnz))) return rc;
     if ((rc = qc_eval_F_jac_dev(h, h->dZ, F ? h->dF : nullptr, vals ? h->dJ : nullptr, h->stream))) return rc;
@@ -1340,11 +1355,12 @@ RcclApi& rccl_api() {
             if (!path || !*path) return 0;
             const char* base = strrchr(path, '/');
             base = base ? base + 1 : path;
-            if (strncmp(base, "librccl", 7) != 0) return 0;
+            if (strncmp(base, "librccl.so", 10) != 0) return 0;   // (not librccl-net.so and friends)
             *static_cast<std::string*>(out) = path;
             return 1;
         }, &loaded);
         if (!loaded.empty()) api.lib = dlopen(loaded.c_str(), RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+        if (api.lib && !dlsym(api.lib, "ncclAllGather")) api.lib = nullptr;   // whatever that object was, it is not the collective library
         const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
         for (const char* n : names) if (!api.lib) api.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
         for (const char* n : names) if (!api.lib) api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
@@ -1469,12 +1485,14 @@ extern "C" int qc_rollout(qc_handle* h, const double* Z, const double* init, dou
     QC_HIP(h, guard.err);
     const size_t ns = (size_t)h->prm.n * h->prm.nc, T = (size_t)h->desc.T;
     int rc;
-    if ((rc = ensure(h, &h->dZ, (size_t)h->dims.Z_len))) return rc;
+    // The rollout's trajectory vector has a device buffer of its own: h->dZ holds the knots of the last EVALUATION, which a later
+    // call under qc_set_new_x(h, 0) reuses (on a multi-device handle only shard 0 would have seen the rollout's vector).
+    if ((rc = ensure(h, &h->dRZ, (size_t)h->dims.Z_len))) return rc;
     if ((rc = ensure(h, &h->dRinit, ns))) return rc;
     if ((rc = ensure(h, &h->dRout, ns * T))) return rc;
-    QC_HIP(h, hipMemcpyAsync(h->dZ, Z, (size_t)h->dims.Z_len * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    QC_HIP(h, hipMemcpyAsync(h->dRZ, Z, (size_t)h->dims.Z_len * sizeof(double), hipMemcpyHostToDevice, h->stream));
     QC_HIP(h, hipMemcpyAsync(h->dRinit, init, ns * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    if ((rc = qc_rollout_dev(h, h->dZ, h->dRinit, h->dRout, h->stream))) return rc;
+    if ((rc = qc_rollout_dev(h, h->dRZ, h->dRinit, h->dRout, h->stream))) return rc;
     QC_HIP(h, hipMemcpyAsync(out, h->dRout, ns * T * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     QC_HIP(h, hipStreamSynchronize(h->stream));
     return QC_OK;

@@ -103,6 +103,7 @@ struct qc_handle {
     int hC_next = 0;
     int new_x = 1;             // qc_set_new_x: 0 = the knots on the device are current, Z is not read
     bool z_valid = false;      // dZ holds this handle's knots of SOME host-buffer call
+    unsigned long long z_gen = 0;    // uploads of the knots so far (qc_knot_generation: what a binding that elides uploads compares)
     hipEvent_t ev_done = nullptr;    // end of the one launch of a host-buffer call
     int host_landing = 1;      // QC_HOST_LANDING=0: the chunked launches of round 2 instead of one watched copy (A/B diagnostics)
     QcParams* dBatch = nullptr;                // device copy of the parameter blocks of a batched launch led by this handle
@@ -118,7 +119,7 @@ struct qc_handle {
     int host_compact = 1;      // QC_HOST_COMPACT=0 disables the compact D2H path of the host-buffer entry points
     double* dWs = nullptr;     // global workspace of the LDS kernels for systems beyond the LDS budget
     double* dHs = nullptr;     // scratch of the 4 x 4-tile Hessian kernel (first Hessian call)
-    double *dRE = nullptr, *dRQ = nullptr, *dRS = nullptr, *dRinit = nullptr, *dRout = nullptr;   // rollout scratch / staging
+    double *dRE = nullptr, *dRQ = nullptr, *dRS = nullptr, *dRinit = nullptr, *dRout = nullptr, *dRZ = nullptr;   // rollout scratch / staging
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;   // odd chunks of the direct-to-host path (kernel boundaries of one stream overlap the other's stores)
     hipEvent_t ev_staged = nullptr;  // the knots are on the device (recorded on `stream`, waited for by `stream2`)

@@ -12,6 +12,8 @@
 // Left multiplication by a transpose uses the B-layout image as the A operand
 // (A-layout(X^T) = B-layout(X)); the B-layout tile of G is assembled from the B-layout images like the A-layout one, and
 // the transposes for the stores go through LDS.  MFMAs per interval: 8 + 8 m + 4 ceil(m/2) (68 for m = 6).
+#include <algorithm>
+
 #include "qc_mfma_common.h"
 
 namespace {
@@ -673,7 +675,7 @@ hipError_t qc_launch_mfma_hess(const QcParams& P, const double* dZ, const double
     // One interval per workgroup up to two rounds of the device (4 x 256 resident workgroups), a persistent grid of one round beyond:
     // T = 2000 / 4000 / 8000 / 32000 take 15.1 / 25.4 / 46.1 / 173.8 us with 1024 workgroups against 15.1 / 26.5 / 47.7 / 173.8 with 4096
     // (15.3 at T = 2000 with 1024: there the loop-free form stays).  QC_HESS_GRID overrides the persistent grid's size.
-    static const int grid_cap = getenv("QC_HESS_GRID") ? atoi(getenv("QC_HESS_GRID")) : 1024;
+    static const int grid_cap = getenv("QC_HESS_GRID") ? std::max(1, atoi(getenv("QC_HESS_GRID"))) : 1024;
     const int grid = P.n_int <= 2048 ? P.n_int : (P.n_int < grid_cap ? P.n_int : grid_cap);
     if (P.nc != 8 || P.n != 16) {
         if (P.m <= 2) launch_hess16<2, true>(P, dZ, dMu, dH, st, grid);

@@ -120,7 +120,7 @@ static int terms_validate(const qc_terms_desc* d, int* cross) {
         if (j < 0 || j >= d->zdim || j == d->off_dt || (k > 0 && j <= d->reg_index[k - 1]))
             return tfail(nullptr, QC_ERR_INVALID, "qc_terms: reg_index must be strictly increasing, inside the knot and not the timestep");
     }
-    if (d->weighting != QC_REG_DT_SCALED && d->weighting != QC_REG_PLAIN) return tfail(nullptr, QC_ERR_INVALID, "qc_terms: unknown weighting");
+    if (d->weighting != QC_REG_DT_SCALED && d->weighting != QC_REG_PLAIN) return tfail(nullptr, QC_ERR_INVALID, "qc_terms: unknown weighting (QC_REG_DT_SCALED = 2, QC_REG_PLAIN = 3; the values 0 and 1 of ABI <= 0.3 are retired)");
     if (d->min_time_D != 0.0 && d->off_dt < 0) return tfail(nullptr, QC_ERR_INVALID, "qc_terms: a minimum-time term needs a free timestep");
     if (d->min_time_knots < 0 || d->min_time_knots > d->T) return tfail(nullptr, QC_ERR_INVALID, "qc_terms: min_time_knots out of range");
     *cross = (d->weighting == QC_REG_DT_SCALED && d->off_dt >= 0 && d->n_reg > 0) ? 1 : 0;

@@ -8,6 +8,13 @@ field names and call shapes of reference test/scripts/integrator_test_1qubit.jl:
 
 (`getattr(dynamics, "∂F")` etc. resolve to the same members; `∂` is not a Python identifier.)
 Every evaluation is a call into libqcolloc_hip.so; this class only builds the C descriptor.
+
+RESULT LIFETIME of the vector-returning calls (the only shape the reference's evaluator uses, script lines 45-52): each of
+`F`, `dF`, `F_dF`, `mu_d2F` owns a ring of `result_ring` (default 3) result vectors, faulted in when the ring is built, and
+returns them in turn -- a result stays intact until the `result_ring`-th next call OF THE SAME CLOSURE (the evaluator copies
+it into Ipopt's buffer at once and never holds one that long).  A fresh 40 MB vector per call costs 2.7 - 4 ms of first-touch
+page faults at config 3, ten times the evaluation.  `fresh=True` on a call (or `result_ring=0` at construction) returns a
+newly allocated vector that is the caller's for good; `out=` writes into the caller's own array.
 """
 from __future__ import annotations
 
@@ -190,13 +197,16 @@ class QuantumDynamics:
 
     def __init__(self, integrators: Sequence, traj: NamedTrajectory, *, device: int = 0, kernel: str = "auto",
                  t_range: Optional[Tuple[int, int]] = None, eval_hessian: bool = True, devices: Optional[Sequence[int]] = None,
-                 rows: str = "stacked", hess_align: int = 0):
+                 rows: str = "stacked", hess_align: int = 0, result_ring: int = 3):
         """devices = [d0, d1, ...]: ONE evaluator over several GPUs (qc_create_multi): the interval range is split into
         len(devices) contiguous shards, shard i on HIP device devices[i] (ordinals may repeat); F / dF / mu_d2F behave
-        exactly as on one device and return the same arrays."""
+        exactly as on one device and return the same arrays.
+        result_ring: vectors per closure that the vector-returning calls hand out in turn (module docstring); 0 = a fresh
+        vector per call."""
         self.integrators = list(integrators)
         self.traj = traj
         self.eval_hessian = eval_hessian
+        self._init_ring(result_ring)
         self.devices = None if devices is None else [int(x) for x in devices]
         if self.devices is not None:
             if not self.devices:
@@ -291,41 +301,54 @@ class QuantumDynamics:
             raise ValueError(f"Z has length {Z.size}, expected {self.dims.Z_len}")
         return Z
 
-    def _out(self, name: str, n: int, out: Optional[np.ndarray] = None) -> np.ndarray:
-        """Result array of `n` doubles: the caller's `out` (hot loops: a fresh 40 MB array per call costs ~2.7 ms of page
-        faults at config 3, five times the evaluation itself), else a fresh array.  Nothing is recycled behind the caller's
-        back, so results of earlier calls are never overwritten."""
-        if out is None:
-            return np.empty(n)
-        if not (isinstance(out, np.ndarray) and out.dtype == np.float64 and out.flags.c_contiguous and out.size == n):
-            raise ValueError(f"out for {name} must be a contiguous float64 array of {n} elements")
-        return out
+    def _init_ring(self, result_ring: int) -> None:
+        if int(result_ring) < 0 or int(result_ring) == 1 or int(result_ring) == 2:
+            raise ValueError("result_ring must be 0 (fresh vectors) or at least 3 (the previous two results of a closure stay intact)")
+        self.result_ring = int(result_ring)
+        self._rings = {}           # closure slot -> [next index, [vectors]]
 
-    def F(self, Z, out: Optional[np.ndarray] = None) -> np.ndarray:
+    def _out(self, name: str, n: int, out: Optional[np.ndarray] = None, fresh: bool = False, slot: Optional[str] = None) -> np.ndarray:
+        """Result array of `n` doubles: the caller's `out`; else (fresh=True, or no ring) a newly allocated array; else the next
+        vector of closure `slot`'s ring (module docstring: valid until the `result_ring`-th next call of the same closure).  The ring's
+        vectors are written once when the ring is built, so no call pays for page faults (2.7 - 4 ms per 40 MB at config 3)."""
+        if out is not None:
+            if not (isinstance(out, np.ndarray) and out.dtype == np.float64 and out.flags.c_contiguous and out.size == n):
+                raise ValueError(f"out for {name} must be a contiguous float64 array of {n} elements")
+            return out
+        if fresh or not self.result_ring or n == 0:
+            return np.empty(n)
+        ring = self._rings.get(slot or name)
+        if ring is None:
+            ring = self._rings[slot or name] = [0, [np.zeros(n) for _ in range(self.result_ring)]]
+        i = ring[0]
+        ring[0] = (i + 1) % self.result_ring
+        return ring[1][i]
+
+    def F(self, Z, out: Optional[np.ndarray] = None, *, fresh: bool = False) -> np.ndarray:
         Z = self._Z(Z)
-        out = self._out("F", int(self.dims.F_len), out)
+        out = self._out("F", int(self.dims.F_len), out, fresh)
         _lib.check(_lib.lib.qc_eval_F(self._h, _lib.dptr(Z), _lib.dptr(out)), self._h)
         return out
 
-    def dF(self, Z, out: Optional[np.ndarray] = None) -> np.ndarray:
+    def dF(self, Z, out: Optional[np.ndarray] = None, *, fresh: bool = False) -> np.ndarray:
         Z = self._Z(Z)
-        out = self._out("J", int(self.dims.jac_nnz), out)
+        out = self._out("J", int(self.dims.jac_nnz), out, fresh)
         _lib.check(_lib.lib.qc_eval_jac(self._h, _lib.dptr(Z), _lib.dptr(out)), self._h)
         return out
 
-    def F_dF(self, Z, out: Optional[Tuple[np.ndarray, np.ndarray]] = None):
+    def F_dF(self, Z, out: Optional[Tuple[np.ndarray, np.ndarray]] = None, *, fresh: bool = False):
         Z = self._Z(Z)
-        F = self._out("F", int(self.dims.F_len), None if out is None else out[0])
-        J = self._out("J", int(self.dims.jac_nnz), None if out is None else out[1])
+        F = self._out("F", int(self.dims.F_len), None if out is None else out[0], fresh, "F_dF.F")
+        J = self._out("J", int(self.dims.jac_nnz), None if out is None else out[1], fresh, "F_dF.J")
         _lib.check(_lib.lib.qc_eval_F_jac(self._h, _lib.dptr(Z), _lib.dptr(F), _lib.dptr(J)), self._h)
         return F, J
 
-    def mu_d2F(self, Z, mu, out: Optional[np.ndarray] = None) -> np.ndarray:
+    def mu_d2F(self, Z, mu, out: Optional[np.ndarray] = None, *, fresh: bool = False) -> np.ndarray:
         Z = self._Z(Z)
         mu = np.ascontiguousarray(mu, dtype=np.float64)
         if mu.size != self.dims.n_rows:
             raise ValueError(f"mu has length {mu.size}, expected {self.dims.n_rows}")
-        out = self._out("H", int(self.dims.hess_nnz), out)
+        out = self._out("H", int(self.dims.hess_nnz), out, fresh)
         _lib.check(_lib.lib.qc_eval_hess(self._h, _lib.dptr(Z), _lib.dptr(mu), _lib.dptr(out)), self._h)
         return out
 
@@ -359,6 +382,12 @@ class QuantumDynamics:
         trial point: residuals, then Jacobian and Hessian at the same x), so the knots already on the device are used and Z
         is not read; stays in force until set_new_x(True) (qc_set_new_x)."""
         _lib.check(_lib.lib.qc_set_new_x(self._h, int(bool(new_x))), self._h)
+
+    def knot_generation(self) -> int:
+        """Uploads of a trajectory vector's knots this handle has done so far (qc_knot_generation).  A caller that elides uploads
+        (set_new_x(False)) remembers it after the call that put ITS x on the device and elides only while it is unchanged: any other
+        host-buffer call on the shared handle in between moves it."""
+        return int(_lib.lib.qc_knot_generation(self._h))
 
     def host_expand_rate(self, reps: int = 5) -> float:
         """GB/s at which this host replicates the compact Jacobian form into the full value array (diagnostic, no GPU work)."""
@@ -449,9 +478,10 @@ class ComposedQuantumDynamics(QuantumDynamics):
 
     def __init__(self, integrators: Sequence, traj: NamedTrajectory, *, device: int = 0, kernel: str = "auto",
                  t_range: Optional[Tuple[int, int]] = None, eval_hessian: bool = True, devices: Optional[Sequence[int]] = None,
-                 rows: str = "stacked", hess_align: int = 0):
+                 rows: str = "stacked", hess_align: int = 0, result_ring: int = 3):
         if devices is not None or rows != "stacked":
             raise NotImplementedError("several unitary integrators: one device, stacked rows")
+        self._init_ring(result_ring)
         self.integrators = list(integrators)
         self.traj = traj
         self.eval_hessian = eval_hessian
@@ -562,37 +592,37 @@ class ComposedQuantumDynamics(QuantumDynamics):
         dZ[:Zh.size].copy_(torch.from_numpy(Zh))
         return dZ
 
-    def _download(self, name: str, t: torch.Tensor, n: int, out: Optional[np.ndarray]) -> np.ndarray:
+    def _download(self, name: str, t: torch.Tensor, n: int, out: Optional[np.ndarray], fresh: bool = False, slot: Optional[str] = None) -> np.ndarray:
         """Device vector -> the caller's `out` (validated like the single-handle class: the evaluator hands Ipopt's own
-        buffers in and reads the result from them) or a fresh array."""
-        out = self._out(name, n, out)
+        buffers in and reads the result from them), the closure's next ring vector, or (fresh=True) a new array."""
+        out = self._out(name, n, out, fresh, slot)
         if n:
             torch.from_numpy(out).copy_(t[:n])
         return out
 
-    def F_dF(self, Z, out=None):
+    def F_dF(self, Z, out=None, *, fresh: bool = False):
         dZ = self._upload(Z)
         dF, dJ = self._buf("F", self.dims.F_len), self._buf("J", self.dims.jac_nnz)
         self.F_dF_device(dZ, dF, dJ)
         torch.cuda.synchronize(self._dev)
-        return (self._download("F", dF, int(self.dims.F_len), None if out is None else out[0]),
-                self._download("J", dJ, int(self.dims.jac_nnz), None if out is None else out[1]))
+        return (self._download("F", dF, int(self.dims.F_len), None if out is None else out[0], fresh, "F_dF.F"),
+                self._download("J", dJ, int(self.dims.jac_nnz), None if out is None else out[1], fresh, "F_dF.J"))
 
-    def F(self, Z, out=None):
+    def F(self, Z, out=None, *, fresh: bool = False):
         dZ = self._upload(Z)
         dF = self._buf("F", self.dims.F_len)
         self.F_dF_device(dZ, dF, None)
         torch.cuda.synchronize(self._dev)
-        return self._download("F", dF, int(self.dims.F_len), out)
+        return self._download("F", dF, int(self.dims.F_len), out, fresh)
 
-    def dF(self, Z, out=None):
+    def dF(self, Z, out=None, *, fresh: bool = False):
         dZ = self._upload(Z)
         dJ = self._buf("J", self.dims.jac_nnz)
         self.F_dF_device(dZ, None, dJ)
         torch.cuda.synchronize(self._dev)
-        return self._download("J", dJ, int(self.dims.jac_nnz), out)
+        return self._download("J", dJ, int(self.dims.jac_nnz), out, fresh)
 
-    def mu_d2F(self, Z, mu, out=None):
+    def mu_d2F(self, Z, mu, out=None, *, fresh: bool = False):
         mu = np.ascontiguousarray(mu, dtype=np.float64)
         if mu.size != self.dims.n_rows:
             raise ValueError(f"mu has length {mu.size}, expected {self.dims.n_rows}")
@@ -602,7 +632,10 @@ class ComposedQuantumDynamics(QuantumDynamics):
         dH = self._buf("H", self.dims.hess_nnz)
         self.mu_d2F_device(dZ, dmu, dH)
         torch.cuda.synchronize(self._dev)
-        return self._download("H", dH, int(self.dims.hess_nnz), out)
+        return self._download("H", dH, int(self.dims.hess_nnz), out, fresh)
+
+    def knot_generation(self) -> int:
+        return 0
 
     def set_new_x(self, new_x: bool) -> None:
         """Accepted for interface parity with QuantumDynamics.set_new_x; the composed evaluator uploads Z on every call."""

@@ -51,8 +51,9 @@ class QuantumControlEvaluator:
         self.n_constraints = self.n_dynamics_rows + sum(int(c.dim) for c in self.constraints)
         self._F = np.empty(self.n_dynamics_rows)
         self._x_F: Optional[np.ndarray] = None          # the x the cached residuals belong to == the x whose knots are on the device
+        self._gen_F = -1                                # ... as long as the handle's upload count is still this one (knot_generation)
         self.stats = {"F": 0, "F_dF": 0, "dF": 0, "mu_d2F": 0, "reused_F": 0, "uploads_elided": 0}
-        self._can_elide = hasattr(dynamics, "set_new_x")
+        self._can_elide = hasattr(dynamics, "set_new_x") and hasattr(dynamics, "knot_generation")
         # ---- Jacobian structure -------------------------------------------------------------------
         jr, jc = dynamics.dF_structure
         rows, cols = [np.asarray(jr, dtype=np.int64)], [np.asarray(jc, dtype=np.int64)]
@@ -145,7 +146,7 @@ class QuantumControlEvaluator:
             if self._can_elide:
                 self.dynamics.set_new_x(True)
             self.dynamics.F(x, out=self._F)            # residual-only launch: what a line-search trial costs
-            self._x_F = x.copy()
+            self._remember(x)
             self.stats["F"] += 1
         c[:n] = self._F
         off = n
@@ -153,9 +154,16 @@ class QuantumControlEvaluator:
             c[off:off + cobj.dim] = cobj.g(x)
             off += cobj.dim
 
+    def _remember(self, x: np.ndarray) -> None:
+        self._x_F = x.copy()
+        if self._can_elide:
+            self._gen_F = self.dynamics.knot_generation()
+
     def _at_device_x(self, x: np.ndarray) -> bool:
-        """True (and the library told so) when x is the vector the dynamics evaluated last: its knots are on the device."""
-        same = self._can_elide and self._same_x(x)
+        """True (and the library told so) when x is the vector the dynamics evaluated last: its knots are on the device.  The
+        handle may be shared (the same `QuantumDynamics` called directly, bound host calls, another evaluator): the upload is
+        elided only while the handle's own upload count is the one seen after this evaluator's last upload."""
+        same = self._can_elide and self._same_x(x) and self.dynamics.knot_generation() == self._gen_F
         if self._can_elide:
             self.dynamics.set_new_x(not same)
         if same:
@@ -171,7 +179,7 @@ class QuantumControlEvaluator:
         else:
             # fused: the residuals come with the Jacobian at no extra cost and refresh the cache
             self.dynamics.F_dF(x, out=(self._F, J[:self._jac_dyn]))
-            self._x_F = x.copy()
+            self._remember(x)
             self.stats["F_dF"] += 1
         if self._can_elide:
             self.dynamics.set_new_x(True)

@@ -1,0 +1,124 @@
+"""The vector-returning closures `dynamics.F(Z)`, `dynamics.dF(Z)`, `dynamics.mu_d2F(Z, mu)` -- the only call shapes the
+reference's evaluator uses (reference test/scripts/integrator_test_1qubit.jl:45-52) -- and the upload elision (`set_new_x`) when the
+handle behind them is shared: result-ring lifetime, `fresh=True`, and the handle's upload count (`qc_knot_generation`) as the guard."""
+import numpy as np
+import pytest
+
+from oracle_bridge import problem_from_inputs
+
+
+def test_retired_regulariser_ids_are_refused(qc):
+    """ABI 0.4: QC_REG_* are 2 / 3; the values 0 and 1, which ABI 0.1 - 0.3 gave both meanings in turn, fail loudly (no GPU needed:
+    the descriptor check runs before anything touches a device)."""
+    import ctypes as C
+    L = qc._lib
+    assert (L.QC_REG_DT_SCALED, L.QC_REG_PLAIN) == (2, 3) and L.lib.qc_abi_version() == 4
+    idx = np.array([8, 9], dtype=np.int32)
+    R = np.ones(2)
+    d = L.qc_terms_desc()
+    d.T, d.zdim, d.off_dt, d.n_reg, d.min_time_knots = 5, 15, 14, 2, 4
+    d.reg_index = idx.ctypes.data_as(C.POINTER(C.c_int32))
+    d.reg_R = L.dptr(R)
+    nnz = C.c_int64()
+    for w, ok in ((L.QC_REG_DT_SCALED, True), (L.QC_REG_PLAIN, True), (0, False), (1, False), (4, False)):
+        d.weighting = w
+        rc = L.lib.qc_terms_desc_hess_nnz(C.byref(d), C.byref(nnz))
+        assert (rc == 0) == ok, (w, rc)
+    assert L.lib.qc_knot_generation(None) == -1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg,T", [(1, 20), (3, 12)])
+def test_closure_results_stay_intact_for_two_more_calls(qc, oracle, cfg, T):
+    inp = qc.config_inputs(cfg, T=T)
+    dyn = qc.QuantumDynamics(inp.integrators, inp.traj)
+    prob = problem_from_inputs(inp)
+    rng = np.random.default_rng(cfg)
+    Zs = [inp.traj.datavec + 1e-2 * k * rng.standard_normal(inp.traj.datavec.size) for k in range(4)]
+    mu = rng.standard_normal(int(dyn.dims.n_rows))
+    want = {"F": [oracle.F(prob, Z) for Z in Zs], "dF": [oracle.dF(prob, Z) for Z in Zs], "H": [oracle.mu_d2F(prob, Z, mu) for Z in Zs]}
+    strip = lambda H: H                                       # (the oracle pads mu_d2F exactly as the library does)
+    for name, call in (("F", dyn.F), ("dF", dyn.dF), ("H", lambda Z: dyn.mu_d2F(Z, mu))):
+        got = [call(Z) for Z in Zs[:3]]
+        assert len({g.ctypes.data for g in got}) == 3         # three distinct vectors ...
+        for g, w in zip(got, want[name][:3]):                 # ... every one still holding its own result
+            np.testing.assert_allclose(strip(g), w, rtol=1e-10, atol=1e-13)
+        again = call(Zs[3])                                   # the third-next call of the closure takes the first vector back
+        assert again.ctypes.data == got[0].ctypes.data
+        np.testing.assert_allclose(strip(again), want[name][3], rtol=1e-10, atol=1e-13)
+        np.testing.assert_allclose(strip(got[1]), want[name][1], rtol=1e-10, atol=1e-13)
+        np.testing.assert_allclose(strip(got[2]), want[name][2], rtol=1e-10, atol=1e-13)
+    # the rings are per closure: a dF call between two F calls takes none of F's vectors
+    f0 = dyn.F(Zs[0]); dyn.dF(Zs[1]); dyn.mu_d2F(Zs[1], mu); f1 = dyn.F(Zs[1]); f2 = dyn.F(Zs[2])
+    np.testing.assert_allclose(f0, want["F"][0], rtol=1e-10, atol=1e-13)
+    F, J = dyn.F_dF(Zs[2])
+    assert F.ctypes.data not in {f0.ctypes.data, f1.ctypes.data, f2.ctypes.data}
+    np.testing.assert_array_equal(F, f2)
+    # fresh=True: the caller's for good
+    keep = dyn.dF(Zs[0], fresh=True)
+    for k in range(4):
+        assert dyn.dF(Zs[k]).ctypes.data != keep.ctypes.data
+    np.testing.assert_allclose(keep, want["dF"][0], rtol=1e-10, atol=1e-13)
+    # the ring's values are those of the caller-owned-buffer call, bit for bit
+    mine = np.empty(int(dyn.dims.jac_nnz))
+    dyn.dF(Zs[1], out=mine)
+    np.testing.assert_array_equal(mine, dyn.dF(Zs[1]))
+    dyn.close()
+    d0 = qc.QuantumDynamics(inp.integrators, inp.traj, result_ring=0)
+    a, b = d0.dF(Zs[0]), d0.dF(Zs[1])
+    assert a.ctypes.data != b.ctypes.data
+    np.testing.assert_allclose(a, want["dF"][0], rtol=1e-10, atol=1e-13)
+    d0.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices", [None, [0, 0, 0]])
+def test_upload_elision_is_guarded_by_the_handles_upload_count(qc, oracle, devices):
+    """between `eval_constraint(x)` and the Jacobian / Hessian at the same x, (a) a rollout through the same handle must
+    not replace the knots on the device -- on a multi-device handle it used to replace shard 0's only --, and (b) any other
+    host-buffer call through the shared handle (dyn.F at another point, a bound call) must make the evaluator upload again."""
+    inp = qc.config_inputs(1, T=40)
+    traj = inp.traj
+    dyn = qc.QuantumDynamics(inp.integrators, traj, devices=devices)
+    obj = qc.UnitaryInfidelityObjective("Ũ⃗", traj, Q=100.0)
+    ev = qc.QuantumControlEvaluator(dyn, [obj])
+    prob = problem_from_inputs(inp)
+    rng = np.random.default_rng(11)
+    x = traj.datavec + 1e-2 * rng.standard_normal(traj.datavec.size)
+    other = traj.datavec + 0.3 * rng.standard_normal(traj.datavec.size)
+    lam = rng.standard_normal(ev.n_constraints)
+    c, J, H = np.empty(ev.n_constraints), np.empty(ev.jac_nnz), np.empty(ev.hess_nnz)
+    off, cnt = ev._hess_dyn
+    J_ref, H_ref = oracle.dF(prob, x), oracle.mu_d2F(prob, x, lam[:ev.n_dynamics_rows])
+
+    # (a) a rollout of ANOTHER trajectory vector between the residuals and the derivatives
+    g0 = dyn.knot_generation()
+    ev.eval_constraint(c, x)
+    assert dyn.knot_generation() == g0 + 1
+    init = other[:traj.dim][traj.offset("Ũ⃗"):traj.offset("Ũ⃗") + 8].copy()
+    dyn.rollout(other, init)
+    assert dyn.knot_generation() == g0 + 1                    # the rollout has a device buffer of its own
+    ev.eval_constraint_jacobian(J, x)
+    ev.eval_hessian_lagrangian(H, x, 1.0, lam)
+    assert ev.stats["uploads_elided"] == 2                    # still elided -- and still right:
+    np.testing.assert_allclose(J, J_ref, rtol=1e-10, atol=1e-13)
+    np.testing.assert_allclose(H[off:off + cnt], H_ref, rtol=1e-10, atol=1e-13)
+
+    # (b) somebody else evaluates another point through the same handle
+    ev.eval_constraint(c, x)                                  # (served from the cache: same x)
+    dyn.F(other)
+    elided = ev.stats["uploads_elided"]
+    ev.eval_constraint_jacobian(J, x)
+    assert ev.stats["uploads_elided"] == elided and ev.stats["F_dF"] == 1      # not elided: the fused call sent x up again
+    np.testing.assert_allclose(J, J_ref, rtol=1e-10, atol=1e-13)
+    bound_F = np.empty(int(dyn.dims.F_len))
+    call = dyn.bind_host("F", other, F=bound_F)
+    ev.eval_constraint(c, x)                                  # cached residuals of x
+    assert call() == 0
+    ev.eval_hessian_lagrangian(H, x, 1.0, lam)
+    assert ev.stats["uploads_elided"] == elided
+    np.testing.assert_allclose(H[off:off + cnt], H_ref, rtol=1e-10, atol=1e-13)
+    # and the library itself is back at new_x = 1 after every evaluator call: a direct call at another point sees its own Z
+    np.testing.assert_allclose(dyn.dF(other), oracle.dF(prob, other), rtol=1e-10, atol=1e-13)
+    dyn.close()
+    obj.close()

@@ -51,26 +51,38 @@ def test_dynamics_requires_unitary_integrator_first(qc):
         qc.make_desc(inp.integrators[1:], inp.traj)
 
 
-def test_result_arrays_are_recycled_only_when_the_caller_let_go(qc):
-    """QuantumDynamics._out: results the caller still holds (or holds a view of) are never overwritten; released ones are
-    reused (two per kind, so that `J = dyn.dF(Z)` in a loop alternates between two arrays instead of allocating 40 MB)."""
+def test_result_ring_hands_out_prefaulted_vectors_in_turn(qc):
+    """QuantumDynamics._out (the vector-returning closures F / dF / F_dF / mu_d2F): a ring of `result_ring` vectors per closure,
+    written when the ring is built; the previous two results of a closure stay intact; `fresh=True` and `result_ring=0` allocate;
+    `out=` is validated and passed through.  (No GPU: the method only manages host arrays.)"""
     import types
     obj = types.SimpleNamespace()
-    out = lambda name, n: qc.QuantumDynamics._out(obj, name, n)
-    ids = []
-    J = None
-    for k in range(6):
+    qc.QuantumDynamics._init_ring(obj, 3)
+    out = lambda name, n, **kw: qc.QuantumDynamics._out(obj, name, n, **kw)
+    got = []
+    for k in range(7):
         J = out("J", 10)
+        if k >= 3:
+            assert J is got[k - 3]                                    # the ring comes round after three calls ...
+            assert got[k - 1][0] == k - 1 and got[k - 2][0] == k - 2  # ... and the previous two results are untouched
         J[:] = k
-        ids.append(id(J))
-    assert len(set(ids)) == 2
-    keep = []
-    for k in range(5):
-        a = out("J", 10)
-        a[:] = k
-        keep.append(a)
-    assert all(keep[k][0] == k for k in range(5)) and len({id(x) for x in keep}) == 5
-    v = out("H", 8)[:2]
-    w = out("H", 8)
-    assert not np.shares_memory(v, w)
-    assert out("J", 12).size == 12
+        got.append(J)
+    assert len({id(x) for x in got}) == 3
+    assert not np.shares_memory(out("H", 8), out("J", 10))            # one ring per closure
+    a, b = out("F", 6, slot="F_dF.F"), out("F", 6)                    # F_dF's residual vectors are not F's
+    assert not np.shares_memory(a, b)
+    f1, f2 = out("J", 10, fresh=True), out("J", 10, fresh=True)
+    assert all(not np.shares_memory(f1, x) for x in got) and not np.shares_memory(f1, f2)
+    mine = np.empty(10)
+    assert out("J", 10, out=mine) is mine
+    with pytest.raises(ValueError):
+        out("J", 10, out=np.empty(9))
+    with pytest.raises(ValueError):
+        out("J", 10, out=np.empty(10, dtype=np.float32))
+    none = types.SimpleNamespace()
+    qc.QuantumDynamics._init_ring(none, 0)
+    x, y = qc.QuantumDynamics._out(none, "J", 10), qc.QuantumDynamics._out(none, "J", 10)
+    assert not np.shares_memory(x, y)
+    for bad in (1, 2, -1):
+        with pytest.raises(ValueError):
+            qc.QuantumDynamics._init_ring(types.SimpleNamespace(), bad)
