@@ -361,6 +361,28 @@ def config5_record(qc, dev_index, steps=300):
     return rec
 
 
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher (the shape of the driver's N = 1 command): start
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <same arguments>`
+    as a CHILD process, pass its output through (rank 0 prints the one JSON line) and return its exit code.  Nothing in this process
+    has touched the GPU at this point, and it never replaces itself with another program: it waits for the child."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    child = subprocess.Popen(cmd, env=env)
+    try:
+        return child.wait()
+    except KeyboardInterrupt:
+        child.terminate()
+        return child.wait()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -385,13 +407,12 @@ def main():
                     help="at N = 1 also run BASELINE config 5 on the device and report its HBM / MFMA fractions (`config5` object)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))      # started without a launcher: this process becomes the parent of N ranks (no GPU call so far)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch multi-GPU runs as: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                     "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
         sys.exit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path)"
     # QC_BENCH_BACKEND=gloo lets several ranks share one GPU: a functional check of the sharded path on a 1-GPU box
@@ -408,10 +429,15 @@ def main():
         cpu_rec = cpu_baseline(qc, qc.config_inputs(3, T=T_PER_GPU), args.cpu_seconds)
     elif rank == 0 and args.cpu_seconds > 0 and world == 1:
         cpu_rec = cpu_baseline(qc, qc.config_inputs(args.config, T=args.T or None), args.cpu_seconds)
+    host_group = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
+            # Waits that last seconds (the other ranks idle while rank 0 times the multi-device handle ON THEIR GPUS) go through a
+            # host-side gloo group: a barrier on the RCCL backend is a kernel spinning on every waiting rank's device, exactly the
+            # devices being measured.
+            host_group = dist.new_group(backend="gloo")
         else:
             dist.init_process_group(backend)
 
@@ -641,7 +667,8 @@ def main():
                 # The reference's consumer is ONE process: rank 0 builds the in-library multi-device handle
                 # (qc_create_multi over all N GPUs) and times the same host-buffer calls on the whole T = 1000 N
                 # trajectory while the other ranks wait at the barrier; N PCIe links work in parallel.
-                dist.barrier()     # (the collective, not the spinning page of the timed region: the other ranks wait here for seconds)
+                torch.cuda.synchronize()            # this rank's GPU is idle ...
+                dist.barrier(group=host_group)      # ... and stays idle: the wait is in a socket, not in a kernel (host_group above)
                 if rank == 0:
                     try:   # (whatever happens here, rank 0 reaches the barrier the other ranks are waiting at)
                         devs = list(range(world)) if backend == "nccl" else [r % torch.cuda.device_count() for r in range(world)]
@@ -651,7 +678,7 @@ def main():
                         md.close()
                     except Exception as exc:   # noqa: BLE001
                         host_rec = {"error": repr(exc)[:300]}
-                dist.barrier()
+                dist.barrier(group=host_group)
         except Exception as exc:   # noqa: BLE001  (must not lose the metric line)
             host_rec = {"error": repr(exc)[:300]}
     c5 = None

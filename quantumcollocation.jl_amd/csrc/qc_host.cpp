@@ -410,6 +410,19 @@ extern "C" int qc_create(const qc_desc* d, qc_handle** out) {
         QC_HIP_C(hipMalloc((void**)&h->dGx, Gx.size() * sizeof(double)));
         QC_HIP_C(hipMemcpy(h->dGx, Gx.data(), Gx.size() * sizeof(double), hipMemcpyHostToDevice));
         h->prm.Gx = h->dGx;
+        // drive generators with at most two entries per row (Pauli strings, ladder pairs): row-gather tables for the kernels that
+        // never touch a dense drive image (QC_NO_ELL=1: the dense kernels, for A/B runs)
+        const bool no_ell = getenv("QC_NO_ELL") && atoi(getenv("QC_NO_ELL"));
+        std::vector<char> blob;
+        int L = 0;
+        const int R = no_ell ? 0 : qc_mfma32_ell_build(h->prm, G.data(), &blob, &L);
+        if (R > 0) {
+            QC_HIP_C(hipMalloc(&h->dEll, blob.size()));
+            QC_HIP_C(hipMemcpy(h->dEll, blob.data(), blob.size(), hipMemcpyHostToDevice));
+            h->prm.ell = h->dEll;
+            h->prm.ell_R = R;
+            h->prm.ell_L = L;
+        }
     }
     // LDS budget of the LDS kernels
     {
@@ -475,6 +488,7 @@ extern "C" void qc_destroy(qc_handle* h) {
         if (h->hC[i]) (void)hipHostFree(h->hC[i]);
     }
     if (h->dC) (void)hipFree(h->dC);
+    if (h->dEll) (void)hipFree(h->dEll);
     if (h->ev_done) (void)hipEventDestroy(h->ev_done);
     if (h->dBatch) (void)hipFree(h->dBatch);
     for (hipEvent_t ev : h->chunk_events) if (ev) (void)hipEventDestroy(ev);
@@ -513,6 +527,7 @@ extern "C" const char* qc_kernel_name(const qc_handle* h, int32_t which) {
     if (mfma && qc_mfma_hess_supported(P)) {
         if (qc_mfma16_padeP_hess_supported(P)) return "mfma16-padeP-hess";
         if (qc_mfma16_hess2_supported(P)) return "mfma16-pade4-hess2";
+        if (P.n > 16 && P.n <= 32 && P.ell) return "mfma32-pade4-hess-ell";
         return P.n > 32 ? "mfma64-pade4-hess" : (P.n > 16 ? "mfma32-pade4-hess" : "mfma16-pade4-hess");
     }
     return P.use_ws ? "lds-gws-hess" : "lds-hess";

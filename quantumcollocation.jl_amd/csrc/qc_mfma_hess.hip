@@ -670,7 +670,7 @@ static void launch_hess16(const QcParams& P, const double* dZ, const double* dMu
 hipError_t qc_launch_mfma_hess(const QcParams& P, const double* dZ, const double* dMu, double* dH, hipStream_t st) {
     if (qc_mfma16_padeP_hess_supported(P)) return qc_launch_mfma16_padeP_hess(P, dZ, dMu, dH, st);
     if (P.n > 32) return qc_launch_mfma64_hess(P, dZ, dMu, dH, st);
-    if (P.n > 16) return qc_launch_mfma32_hess(P, dZ, dMu, dH, st);
+    if (P.n > 16) return P.ell ? qc_launch_mfma32_ell_hess(P, dZ, dMu, dH, st) : qc_launch_mfma32_hess(P, dZ, dMu, dH, st);
     if (qc_mfma16_hess2_supported(P)) return qc_launch_mfma16_hess2(P, dZ, dMu, dH, st);     // two waves per interval, up to one round of the device (qc_mfma_hess2.hip)
     // One interval per workgroup up to two rounds of the device (4 x 256 resident workgroups), a persistent grid of one round beyond:
     // T = 2000 / 4000 / 8000 / 32000 take 15.1 / 25.4 / 46.1 / 173.8 us with 1024 workgroups against 15.1 / 26.5 / 47.7 / 173.8 with 4096

@@ -71,8 +71,10 @@ def test_bench_line_at_two_ranks_is_complete():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, QC_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29541", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
+    # started the way the driver starts its N = 1 run -- no launcher on the command line: bench.py starts its own ranks as a child
+    # `python -m torch.distributed.run` (launch_ranks) and passes the line and the exit code through
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
                         "--cpu-seconds", "0.6", "--prewarm-seconds", "0"], capture_output=True, text=True, timeout=900, cwd=root, env=env)
     assert r.returncode == 0, r.stderr[-1500:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -86,3 +88,34 @@ def test_bench_line_at_two_ranks_is_complete():
     hv = d["host_visible"]
     import torch
     assert hv["devices"] == [r % torch.cuda.device_count() for r in range(2)] and hv["speedup_vs_cpu_baseline"] > 0 and hv["host_expand_GBps"] > 0 and hv["evals_per_s_T1000_equivalent"] > 0
+    assert set(hv["closure_ms"]) == {"F", "dF", "F_dF", "hess"} == set(hv["closure_fresh_ms"])
+
+
+def test_bench_without_a_launcher_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment must not exit with a usage message (round 3 did): the parent
+    starts `python -m torch.distributed.run --nproc-per-node N ... bench.py <same arguments>` as a child and returns its exit code.
+    Checked here without a GPU: a stand-in `torch.distributed.run` on PYTHONPATH records how it was called."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fake = tmp_path / "torch" / "distributed"
+    fake.mkdir(parents=True)
+    (tmp_path / "torch" / "__init__.py").write_text("cuda = None\n")
+    (fake / "__init__.py").write_text("")
+    (fake / "run.py").write_text("import json, os, sys\nprint(json.dumps({'argv': sys.argv[1:], 'ipc': os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}))\nsys.exit(7)\n")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["PYTHONPATH"] = root
+    # the parent imports the real torch (bench.py does at its top); only the CHILD sees the stand-in package first on its path
+    probe = ("import os, sys, subprocess, json\n"
+             "sys.argv = ['bench.py', '--gpus', '8', '--steps', '20', '--warmup', '5']\n"
+             "import bench\n"
+             f"os.environ['PYTHONPATH'] = {str(tmp_path)!r}\n"
+             "sys.exit(bench.launch_ranks(8))\n")
+    r = subprocess.run([sys.executable, "-c", probe], capture_output=True, text=True, timeout=300, cwd=root, env=env)
+    assert r.returncode == 7, (r.returncode, r.stderr[-800:])                     # the child's exit code comes back
+    import json
+    rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    argv = rec["argv"]
+    assert argv[:2] == ["--nnodes=1", "--nproc-per-node"] and argv[2] == "8" and "--master-addr" in argv and "127.0.0.1" in argv
+    i = argv.index(os.path.join(root, "bench.py"))
+    assert argv[i + 1:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"] and rec["ipc"] == "0"
