@@ -414,14 +414,14 @@ extern "C" int qc_create(const qc_desc* d, qc_handle** out) {
         // never touch a dense drive image (QC_NO_ELL=1: the dense kernels, for A/B runs)
         const bool no_ell = getenv("QC_NO_ELL") && atoi(getenv("QC_NO_ELL"));
         std::vector<char> blob;
-        int L = 0;
-        const int R = no_ell ? 0 : qc_mfma32_ell_build(h->prm, G.data(), &blob, &L);
+        int slots = 0;
+        const int R = no_ell ? 0 : qc_mfma32_ell_build(h->prm, G.data(), &blob, &slots);
         if (R > 0) {
             QC_HIP_C(hipMalloc(&h->dEll, blob.size()));
             QC_HIP_C(hipMemcpy(h->dEll, blob.data(), blob.size(), hipMemcpyHostToDevice));
             h->prm.ell = h->dEll;
             h->prm.ell_R = R;
-            h->prm.ell_L = L;
+            h->prm.ell_slots = slots;
         }
     }
     // LDS budget of the LDS kernels

@@ -51,7 +51,7 @@ struct QcParams {
     double* hs;              // device: scratch of the 4 x 4-tile Hessian kernel (qc_mfma64_hess.hip), allocated on first use
     unsigned long long* stamps;  // diagnostic: 16 s_memrealtime slots per interval, or nullptr (normal)
     const void* ell;         // device: row-gather tables of sparse drive generators (qc_mfma32_ell.hip), or nullptr
-    int ell_R, ell_L;        // entries per generator row (1 or 2); padded length of a pair list
+    int ell_R, ell_slots;    // entries per generator row (1 or 2); drives touching one entry of G at most (0: G from the dense images)
 };
 
 struct qc_fanout;
@@ -180,7 +180,7 @@ bool qc_mfma32_exp_supported(const QcParams& P);
 hipError_t qc_launch_mfma32_exp(const QcParams& P, const double* dZ, double* dF, double* dJ, hipStream_t st);
 bool qc_mfma32_hess_supported(const QcParams& P);
 // sparse drive generators (at most 2 entries per row), 2N = 32, Hermitian Hamiltonians: qc_mfma32_ell.hip
-int qc_mfma32_ell_build(const QcParams& P, const double* G_host, std::vector<char>* blob, int* L_out);
+int qc_mfma32_ell_build(const QcParams& P, const double* G_host, std::vector<char>* blob, int* slots_out);
 hipError_t qc_launch_mfma32_ell_hess(const QcParams& P, const double* dZ, const double* dMu, double* dH, hipStream_t st);
 hipError_t qc_launch_mfma32_hess(const QcParams& P, const double* dZ, const double* dMu, double* dH, hipStream_t st);
 // F + dF + mu_d2F in one launch (qc_mfma_fused.hip): 2N = 16, a unitary on 8 levels, antisymmetric generators, 1 .. 6 drives

@@ -42,23 +42,25 @@ constexpr int kPS = 17;             // row stride of the plain 32 x 16 LDS copie
 constexpr int kQS = 33;             // row stride of the plain 32 x 32 Gram matrix
 
 // Byte offsets of the tables inside the device blob (host and device agree through this one function).
-//   p1w / p1c  [k][q][g][8]   pattern 1: rows a = 16 K + 4 kk + g (e = 4 K + kk) -- what lane group g needs for the operand layout
-//   p2w / p2c  [k][q][32]     pattern 2: row a = 16 J + j                        -- what lane j needs for the store layout
+//   tw / tc    [k][q][32]     row a of drive k: weight and column (pre-multiplied by kPS) of its q-th entry
 //   pw / po    [pair][L]      entries of G_i G_k + G_k G_i: weight, offset into the plain Gram matrix (row * kQS + col)
-// (column indices are pre-multiplied by kPS)
-struct EllLayout { size_t p1w, p2w, pw, p1c, p2c, po, bytes; };
-__host__ __device__ inline EllLayout ell_layout(int m, int R, int L) {
+//   gw / gk    [slot][1024]   assembly plan of G = G_0 + sum_k a_k G_k in the order of the A-layout image: the slot-th drive that
+//                             touches the entry (ascending k, so the sum has the order of the dense one) and its weight; k = 0, w = 0
+//                             where fewer drives do
+struct EllLayout { size_t tw, pw, gw, tc, po, gk, bytes; };
+__host__ __device__ inline EllLayout ell_layout(int m, int R, int L, int slots) {
     const size_t npairs = (size_t)m * (m + 1) / 2;
     EllLayout o;
-    o.p1w = 0;
-    o.p2w = o.p1w + (size_t)m * R * 32 * 8;
-    o.pw = o.p2w + (size_t)m * R * 32 * 8;
-    o.p1c = o.pw + npairs * L * 8;
-    o.p2c = o.p1c + (size_t)m * R * 32 * 4;
-    o.po = o.p2c + (size_t)m * R * 32 * 4;
-    o.bytes = o.po + npairs * L * 4;
+    o.tw = 0;
+    o.pw = o.tw + (size_t)m * R * 32 * 8;
+    o.gw = o.pw + npairs * L * 8;
+    o.tc = o.gw + (size_t)slots * 1024 * 8;
+    o.po = o.tc + (size_t)m * R * 32 * 4;
+    o.gk = o.po + npairs * L * 4;
+    o.bytes = o.gk + (size_t)slots * 1024 * 4;
     return o;
 }
+constexpr int kMaxSlots = 4;        // drives touching one entry of G beyond this: the dense images assemble G
 
 __device__ inline v4d tile_ld(const double* __restrict__ base, int tile, int lane) {   // [tile][pair][lane][2]
     const v2d* p = reinterpret_cast<const v2d*>(base) + tile * 128 + lane;
@@ -130,13 +132,48 @@ __device__ inline void store_T32(double* __restrict__ p, const v4d& x, int J, in
     for (int r = 0; r < 4; ++r) qc_st8m<2>(p + (4 * r + g) * 32 + 16 * J + j, x[r]);
 }
 
+// One row-gathered 32 x 16 product in the OPERAND layout (B/D layout: lane (g, j) reg kk of tile K = X[16 K + 4 kk + g][j], X = G_k S):
+// the row's R (weight, column) pairs come from the LDS tables (broadcast reads: four distinct rows per instruction)
+template <int R>
+__device__ __forceinline__ void gather_rows_operand(const double* __restrict__ tw, const int* __restrict__ tc, const double* __restrict__ src,
+                                                    int g, int j, v4d (&out)[2]) {
+#pragma unroll
+    for (int K = 0; K < 2; ++K) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int a = 16 * K + 4 * kk + g;
+            double y = tw[a] * src[tc[a] + j];
+#pragma unroll
+            for (int q = 1; q < R; ++q) y += tw[q * 32 + a] * src[tc[q * 32 + a] + j];
+            out[K][kk] = y;
+        }
+    }
+}
+// ... and in the STORE layout (lane (g, j) reg r of tile J = X[16 J + j][4 r + g]): row a = 16 J + j is the lane's own
+template <int R>
+__device__ __forceinline__ v4d gather_rows_store(const double* __restrict__ tw, const int* __restrict__ tc, const double* __restrict__ src,
+                                                 int J, int g, int j) {
+    const int a = 16 * J + j;
+    v4d out;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        double y = tw[a] * src[tc[a] + 4 * r + g];
+#pragma unroll
+        for (int q = 1; q < R; ++q) y += tw[q * 32 + a] * src[tc[q * 32 + a] + 4 * r + g];
+        out[r] = y;
+    }
+    return out;
+}
+
 template <int R, bool DIAG>
 __global__ __launch_bounds__(kEThreads, 2) void qc_mfma32_ell_hess_kernel(const double* __restrict__ hot_Gx, const double* __restrict__ hot_Zt,
                                                                           const double* __restrict__ hot_mu0, const char* __restrict__ hot_ell,
                                                                           const int hot_n_int, const int hot_zdim, const int hot_m,
                                                                           const int hot_off_a, const int hot_off_dt, const int hot_off_U,
-                                                                          const int hot_f_stride, const int hot_L, const QcParams Pk,
+                                                                          const int hot_f_stride, const int hot_slots, const QcParams Pk,
                                                                           double* __restrict__ H) {
+    constexpr int L = R == 1 ? 64 : 256;          // padded length of a pair list (fixed by R: at most 32 * 2 R^2 entries)
+    constexpr int kPairsPerWave = (kEMax * (kEMax + 1) / 2 + kEMax - 1) / kEMax;    // 5
     QcKernargTouch<sizeof(QcParams) + 96> touch;
     touch.request();
     __shared__ __attribute__((aligned(16))) double GL[4 * 256];      // G, A-layout tiles 2 I + K
@@ -148,6 +185,8 @@ __global__ __launch_bounds__(kEThreads, 2) void qc_mfma32_ell_hess_kernel(const 
     __shared__ __attribute__((aligned(16))) double WT[2 * 256];      // -c1 S + 2 c2 h G D
     __shared__ double Mp[32 * kPS], Dp[32 * kPS], Ep[32 * kPS];      // plain row-major copies: the gather sources
     __shared__ double Qp[32 * kQS];                                  // Q = M D^T
+    __shared__ double TW[kEMax * R * 32];                            // the drives' rows: weights ...
+    __shared__ int TC[kEMax * R * 32];                               // ... and columns (x kPS)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -165,28 +204,60 @@ __global__ __launch_bounds__(kEThreads, 2) void qc_mfma32_ell_hess_kernel(const 
 
     // ---- phase 0 ------------------------------------------------------------------------------------------------
     const double h = ft ? z0[hot_off_dt] : opaque_scalar(P.dt_fixed);
-    const EllLayout lay = ell_layout(m, R, hot_L);
-    const int kd = drive ? w : 0;                     // (waves beyond the drives load drive 0's rows and use none of them)
-    double w1[R][8], w2[R][2];
-    int c1i[R][8], c2i[R][2];
+    const EllLayout lay = ell_layout(m, R, L, hot_slots);
+    const int npairs = m * (m + 1) / 2;
+    double pwv[kPairsPerWave];        // R = 1: this wave's pair entries, one per lane and pair, requested with everything else
+    int pov[kPairsPerWave];
     {
-        const v2d* __restrict__ ab = reinterpret_cast<const v2d*>(hot_Gx) + (w >> 1) * 128 + (w & 1) * 64 + lane;
-        v2d img[kEMax + 1];
-        double ak[kEMax];
+        // half (w & 1) of A-layout tile (w >> 1) of G = G_0 + sum_k a_k G_k: two entries per lane, in image order
+        const int e0 = (w >> 1) * 256 + (w & 1) * 128 + 2 * lane;
+        v2d Gh = reinterpret_cast<const v2d*>(hot_Gx)[e0 >> 1];
+        if (hot_slots > 0) {          // sparse drives: the few drives that touch an entry, in ascending order (the dense sum's order)
+            const double* __restrict__ gw = reinterpret_cast<const double*>(hot_ell + lay.gw);
+            const int* __restrict__ gk = reinterpret_cast<const int*>(hot_ell + lay.gk);
+            // (the amplitudes by ONE vector load, lane u = a_u, handed to the lanes that need them through the LDS crossbar: a load
+            //  per entry would be a second round trip behind the plan's)
+            const double amp = z0[hot_off_a + (lane < m ? lane : 0)];
+            v2d wv[kMaxSlots];
+            int k0[kMaxSlots], k1[kMaxSlots];
 #pragma unroll
-        for (int u = 0; u <= kEMax; ++u) img[u] = ab[(size_t)(u <= m ? u : 0) * 512];
+            for (int sl = 0; sl < kMaxSlots; ++sl) {
+                const int so = sl < hot_slots ? sl : 0;
+                wv[sl] = reinterpret_cast<const v2d*>(gw + (size_t)so * 1024)[e0 >> 1];
+                k0[sl] = gk[(size_t)so * 1024 + e0];
+                k1[sl] = gk[(size_t)so * 1024 + e0 + 1];
+            }
 #pragma unroll
-        for (int u = 0; u < kEMax; ++u) ak[u] = z0[hot_off_a + (u < m ? u : 0)];
+            for (int sl = 0; sl < kMaxSlots; ++sl)
+                if (sl < hot_slots) Gh += v2d{__shfl(amp, k0[sl]), __shfl(amp, k1[sl])} * wv[sl];
+        } else {
+            const v2d* __restrict__ ab = reinterpret_cast<const v2d*>(hot_Gx) + (e0 >> 1);
+            v2d img[kEMax];
+            double ak[kEMax];
 #pragma unroll
-        for (int q = 0; q < R; ++q) {
-            const double* __restrict__ pw1 = reinterpret_cast<const double*>(hot_ell + lay.p1w) + ((kd * R + q) * 4 + g) * 8;
-            const int* __restrict__ pc1 = reinterpret_cast<const int*>(hot_ell + lay.p1c) + ((kd * R + q) * 4 + g) * 8;
+            for (int u = 0; u < kEMax; ++u) img[u] = ab[(size_t)(u < m ? u + 1 : 0) * 512];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { w1[q][e] = pw1[e]; c1i[q][e] = pc1[e]; }
-            const double* __restrict__ pw2 = reinterpret_cast<const double*>(hot_ell + lay.p2w) + (kd * R + q) * 32;
-            const int* __restrict__ pc2 = reinterpret_cast<const int*>(hot_ell + lay.p2c) + (kd * R + q) * 32;
+            for (int u = 0; u < kEMax; ++u) ak[u] = z0[hot_off_a + (u < m ? u : 0)];
 #pragma unroll
-            for (int J = 0; J < 2; ++J) { w2[q][J] = pw2[16 * J + j]; c2i[q][J] = pc2[16 * J + j]; }
+            for (int u = 0; u < kEMax; ++u) Gh += (u < m ? ak[u] : 0.0) * img[u + 0];
+        }
+        // this drive's rows -> LDS (one (weight, column) pair per lane)
+        double twv = 0.0;
+        int tcv = 0;
+        if (drive && lane < 32 * R) {
+            twv = reinterpret_cast<const double*>(hot_ell + lay.tw)[w * R * 32 + lane];
+            tcv = reinterpret_cast<const int*>(hot_ell + lay.tc)[w * R * 32 + lane];
+        }
+        if constexpr (R == 1) {
+            const double* __restrict__ pw = reinterpret_cast<const double*>(hot_ell + lay.pw);
+            const int* __restrict__ po = reinterpret_cast<const int*>(hot_ell + lay.po);
+#pragma unroll
+            for (int t = 0; t < kPairsPerWave; ++t) {
+                const int p = w + m * t;
+                const bool ok = drive && p < npairs;
+                pwv[t] = ok ? pw[(size_t)p * L + lane] : 0.0;
+                pov[t] = ok ? po[(size_t)p * L + lane] : 0;
+            }
         }
         if (w >= 4) {
             const int I = w & 1;
@@ -205,10 +276,8 @@ __global__ __launch_bounds__(kEThreads, 2) void qc_mfma32_ell_hess_kernel(const 
                 for (int r = 0; r < 4; ++r) Dp[(16 * I + 4 * r + g) * kPS + j] = dd[r];
             }
         }
-        v2d Gh = img[0];
-#pragma unroll
-        for (int u = 0; u < kEMax; ++u) Gh += (u < m ? ak[u] : 0.0) * img[u + 1];
-        reinterpret_cast<v2d*>(GL)[(w >> 1) * 128 + (w & 1) * 64 + lane] = Gh;
+        if (drive && lane < 32 * R) { TW[w * R * 32 + lane] = twv; TC[w * R * 32 + lane] = tcv; }
+        reinterpret_cast<v2d*>(GL)[e0 >> 1] = Gh;
     }
     touch.consume();
     double* __restrict__ Hb = H + (size_t)b * P.H_stride + P.H_off;
@@ -216,6 +285,8 @@ __global__ __launch_bounds__(kEThreads, 2) void qc_mfma32_ell_hess_kernel(const 
     QC_STAMP(P, b, lane, 1);
     __syncthreads();
     const double hc1 = h * c1, hc2 = h * h * c2, c2h2 = 2.0 * c2 * h;
+    const double* __restrict__ tw = TW + (drive ? w : 0) * R * 32;
+    const int* __restrict__ tc = TC + (drive ? w : 0) * R * 32;
     QC_STAMP(P, b, lane, 2);
 
     // ---- phase 1 ------------------------------------------------------------------------------------------------
@@ -241,18 +312,8 @@ __global__ __launch_bounds__(kEThreads, 2) void qc_mfma32_ell_hess_kernel(const 
     }
     v4d Yk[2], TY[2];
     if (drive) {
-        // Y_k = G_k M in the B/D layout: lane (g, j) reg kk of tile K = sum_q w[a][q] M[c[a][q]][j], a = 16 K + 4 kk + g
-#pragma unroll
-        for (int K = 0; K < 2; ++K) {
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                double y = w1[0][4 * K + kk] * Mp[c1i[0][4 * K + kk] + j];
-#pragma unroll
-                for (int q = 1; q < R; ++q) y += w1[q][4 * K + kk] * Mp[c1i[q][4 * K + kk] + j];
-                Yk[K][kk] = y;
-            }
-        }
-        // (G Y_k)^T: two accumulator chains per output tile are not needed -- the two tiles J interleave
+        gather_rows_operand<R>(tw, tc, Mp, g, j, Yk);               // Y_k = G_k M
+        // (G Y_k)^T: A = Y_k[K] (operand-layout registers read as an A operand are the transposed tile), B = G_A[2 J + K]
         const v4d z = {0.0, 0.0, 0.0, 0.0};
         v4d t0 = z, t1 = z;
 #pragma unroll
@@ -277,55 +338,38 @@ __global__ __launch_bounds__(kEThreads, 2) void qc_mfma32_ell_hess_kernel(const 
         double* __restrict__ paU = Hb + P.ho_aU + (size_t)w * 512;
 #pragma unroll
         for (int J = 0; J < 2; ++J) {
-            // lane (g, j) reg r = Y_k[16 J + j][4 r + g] and (G_k E)[16 J + j][4 r + g]: row a = 16 J + j of G_k
-            v4d yt, get;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                double y = w2[0][J] * Mp[c2i[0][J] + 4 * r + g];
-                double e = w2[0][J] * Ep[c2i[0][J] + 4 * r + g];
-#pragma unroll
-                for (int q = 1; q < R; ++q) {
-                    y += w2[q][J] * Mp[c2i[q][J] + 4 * r + g];
-                    e += w2[q][J] * Ep[c2i[q][J] + 4 * r + g];
-                }
-                yt[r] = y;
-                get[r] = e;
-            }
+            const v4d yt = gather_rows_store<R>(tw, tc, Mp, J, g, j);       // Y_k^T
+            const v4d get = gather_rows_store<R>(tw, tc, Ep, J, g, j);      // (G_k E)^T
             const v4d lin = hc1 * yt, qd = hc2 * (get + TY[J]);
             store_T32(pUa, lin - qd, J, g, j);
             store_T32(paU, lin + qd, J, g, j);
         }
         QC_STAMP(P, b, lane, 5);
         // (a_k, h) and this wave's pairs: one batched reduction
-        constexpr int kPairsPerWave = (kEMax * (kEMax + 1) / 2 + kEMax - 1) / kEMax;    // 5
         double pv[1 + kPairsPerWave];
         pv[0] = 0.0;
         if (ft) {
-            v4d Vk[2];                                   // V_k = G_k D, the same gather from the other source
-#pragma unroll
-            for (int K = 0; K < 2; ++K) {
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    double v = w1[0][4 * K + kk] * Dp[c1i[0][4 * K + kk] + j];
-#pragma unroll
-                    for (int q = 1; q < R; ++q) v += w1[q][4 * K + kk] * Dp[c1i[q][4 * K + kk] + j];
-                    Vk[K][kk] = v;
-                }
-            }
+            v4d Vk[2];
+            gather_rows_operand<R>(tw, tc, Dp, g, j, Vk);           // V_k = G_k D
             pv[0] = -(dot4(Yk[0], tile_ld(WT, 0, lane)) + dot4(Yk[1], tile_ld(WT, 1, lane))) -
                     c2h2 * (dot4(tile_ld(ET, 0, lane), Vk[0]) + dot4(tile_ld(ET, 1, lane), Vk[1]));
         }
-        const int npairs = m * (m + 1) / 2;
-        const double* __restrict__ pw = reinterpret_cast<const double*>(hot_ell + lay.pw);
-        const int* __restrict__ po = reinterpret_cast<const int*>(hot_ell + lay.po);
+        if constexpr (R == 1) {
 #pragma unroll
-        for (int t = 0; t < kPairsPerWave; ++t) {
-            const int p = w + m * t;                     // pairs dealt round-robin over the drive waves
-            double acc = 0.0;
-            if (p < npairs) {
-                for (int e = lane; e < hot_L; e += 64) acc += pw[(size_t)p * hot_L + e] * Qp[po[(size_t)p * hot_L + e]];
+            for (int t = 0; t < kPairsPerWave; ++t) pv[1 + t] = pwv[t] * Qp[pov[t]];
+        } else {
+            const double* __restrict__ pw = reinterpret_cast<const double*>(hot_ell + lay.pw);
+            const int* __restrict__ po = reinterpret_cast<const int*>(hot_ell + lay.po);
+#pragma unroll
+            for (int t = 0; t < kPairsPerWave; ++t) {
+                const int p = w + m * t;                 // pairs dealt round-robin over the drive waves
+                double acc = 0.0;
+                if (p < npairs) {
+#pragma unroll
+                    for (int e = 0; e < L / 64; ++e) acc += pw[(size_t)p * L + 64 * e + lane] * Qp[po[(size_t)p * L + 64 * e + lane]];
+                }
+                pv[1 + t] = acc;
             }
-            pv[1 + t] = acc;
         }
         wave_sum_multi<1 + kPairsPerWave>(pv);
         if (lane == 0) {
@@ -367,8 +411,8 @@ __global__ __launch_bounds__(kEThreads, 2) void qc_mfma32_ell_hess_kernel(const 
 
 // ---- host side: are the drives sparse enough, and the tables ---------------------------------------------------------
 // G: (m + 1) column-major n x n matrices, index 0 = drift (dense is fine: only the DRIVES are row-gathered).
-// Returns the ELL width R (1 or 2) and fills `blob` / `L`, or 0 when this kernel does not serve the handle.
-int qc_mfma32_ell_build(const QcParams& P, const double* G, std::vector<char>* blob, int* L_out) {
+// Returns the ELL width R (1 or 2) and fills `blob` / `slots`, or 0 when this kernel does not serve the handle.
+int qc_mfma32_ell_build(const QcParams& P, const double* G, std::vector<char>* blob, int* slots_out) {
     if (P.integrator != QC_PADE || P.p != 2 || P.n != 32 || P.nc != 16 || !P.antisym || P.m < 1 || P.m > kEMax || P.hess_nnz == 0) return 0;
     const int n = 32, m = P.m;
     auto Gk = [&](int k, int a, int c) { return G[(size_t)(k + 1) * n * n + (size_t)c * n + a]; };   // drive k, row a, column c
@@ -380,10 +424,10 @@ int qc_mfma32_ell_build(const QcParams& P, const double* G, std::vector<char>* b
             R = std::max(R, cnt);
         }
     if (R < 1 || R > 2) return 0;
+    const int L = R == 1 ? 64 : 256;
     // G_i G_k + G_k G_i, structurally (an entry that cancels to exactly zero is kept out: it adds nothing)
     const int npairs = m * (m + 1) / 2;
     std::vector<std::vector<std::pair<int, double>>> lists(npairs);
-    size_t longest = 0;
     for (int hi = 0; hi < m; ++hi)
         for (int lo = 0; lo <= hi; ++lo) {
             std::vector<double> Pm((size_t)n * n, 0.0);
@@ -397,28 +441,33 @@ int qc_mfma32_ell_build(const QcParams& P, const double* G, std::vector<char>* b
             for (int a = 0; a < n; ++a)
                 for (int d = 0; d < n; ++d)
                     if (Pm[(size_t)a * n + d] != 0.0) li.emplace_back(a * kQS + d, Pm[(size_t)a * n + d]);
-            longest = std::max(longest, li.size());
+            if ((int)li.size() > L) return 0;            // (cannot happen: at most 2 R^2 entries per row)
         }
-    const int L = (int)std::max<size_t>(64, (longest + 63) / 64 * 64);
-    const EllLayout lay = ell_layout(m, R, L);
+    // how many drives touch one entry of G
+    int slots = 0;
+    for (int a = 0; a < n; ++a)
+        for (int c = 0; c < n; ++c) {
+            int cnt = 0;
+            for (int k = 0; k < m; ++k) cnt += Gk(k, a, c) != 0.0;
+            slots = std::max(slots, cnt);
+        }
+    if (slots > kMaxSlots) slots = 0;                    // the kernel assembles G from the dense images then
+    const EllLayout lay = ell_layout(m, R, L, slots);
     blob->assign(lay.bytes, 0);
-    double* p1w = reinterpret_cast<double*>(blob->data() + lay.p1w);
-    double* p2w = reinterpret_cast<double*>(blob->data() + lay.p2w);
+    double* tw = reinterpret_cast<double*>(blob->data() + lay.tw);
     double* pw = reinterpret_cast<double*>(blob->data() + lay.pw);
-    int* p1c = reinterpret_cast<int*>(blob->data() + lay.p1c);
-    int* p2c = reinterpret_cast<int*>(blob->data() + lay.p2c);
+    double* gw = reinterpret_cast<double*>(blob->data() + lay.gw);
+    int* tc = reinterpret_cast<int*>(blob->data() + lay.tc);
     int* po = reinterpret_cast<int*>(blob->data() + lay.po);
+    int* gk = reinterpret_cast<int*>(blob->data() + lay.gk);
     for (int k = 0; k < m; ++k)
         for (int a = 0; a < n; ++a) {
             int q = 0;
             for (int c = 0; c < n; ++c) {
                 const double v = Gk(k, a, c);
                 if (v == 0.0) continue;
-                const int K = a >> 4, kk = (a & 15) >> 2, gg = a & 3;       // a = 16 K + 4 kk + g
-                p1w[((k * R + q) * 4 + gg) * 8 + 4 * K + kk] = v;
-                p1c[((k * R + q) * 4 + gg) * 8 + 4 * K + kk] = c * kPS;
-                p2w[(k * R + q) * 32 + a] = v;
-                p2c[(k * R + q) * 32 + a] = c * kPS;
+                tw[(k * R + q) * 32 + a] = v;
+                tc[(k * R + q) * 32 + a] = c * kPS;
                 ++q;
             }
             // (rows with fewer than R entries keep weight 0 and column 0: a valid address, a zero term)
@@ -428,14 +477,26 @@ int qc_mfma32_ell_build(const QcParams& P, const double* G, std::vector<char>* b
             po[(size_t)p * L + e] = lists[p][e].first;
             pw[(size_t)p * L + e] = lists[p][e].second;
         }
-    *L_out = L;
+    // assembly plan in the order of the A-layout image (qc_mfma32_pack_G): entry [tile = 2 I + K][pair][lane = 16 g + i][e] = X[16 I + i][16 K + 4 (2 pair + e) + g]
+    for (int tile = 0; tile < 4 && slots > 0; ++tile)
+        for (int pr = 0; pr < 2; ++pr)
+            for (int l = 0; l < 64; ++l)
+                for (int e = 0; e < 2; ++e) {
+                    const int gg = l >> 4, i = l & 15, kk = 2 * pr + e;
+                    const int a = 16 * (tile >> 1) + i, c = 16 * (tile & 1) + 4 * kk + gg;
+                    const int idx = (tile * 2 + pr) * 128 + l * 2 + e;
+                    int sl = 0;
+                    for (int k = 0; k < m; ++k)
+                        if (Gk(k, a, c) != 0.0) { gw[(size_t)sl * 1024 + idx] = Gk(k, a, c); gk[(size_t)sl * 1024 + idx] = k; ++sl; }
+                }
+    *slots_out = slots;
     return R;
 }
 
 hipError_t qc_launch_mfma32_ell_hess(const QcParams& P, const double* dZ, const double* dMu, double* dH, hipStream_t st) {
     const int grid = P.n_int;
 #define QC_ELL_ARGS P.Gx, dZ + P.t_begin * (long long)P.zdim, dMu + P.t_begin * P.F_stride + P.F_off, (const char*)P.ell, P.n_int, P.zdim, P.m, \
-                    P.off_a, P.off_dt, P.off_U, (int)P.F_stride, P.ell_L, P, dH
+                    P.off_a, P.off_dt, P.off_U, (int)P.F_stride, P.ell_slots, P, dH
     if (P.stamps != nullptr) {
         if (P.ell_R == 1) hipLaunchKernelGGL((qc_mfma32_ell_hess_kernel<1, true>), dim3(grid), dim3(kEThreads), 0, st, QC_ELL_ARGS);
         else hipLaunchKernelGGL((qc_mfma32_ell_hess_kernel<2, true>), dim3(grid), dim3(kEThreads), 0, st, QC_ELL_ARGS);

@@ -68,6 +68,42 @@ def random_problem(o, N, m, T, order=4, free_time=True, integrator=None, seed=0,
     return prob, Z
 
 
+def sparse_drive_problem(o, m, T, R=1, free_time=True, layout="standard", seed=0, N=16, dense_drift=True, kinds=("real", "imag", "diag")):
+    """Like random_problem, with SPARSE Hermitian drive Hamiltonians whose real-iso generators have exactly R entries per row:
+    R = 1: a perfect matching of the N levels with real or imaginary couplings (a Pauli-string-like signed permutation) or a real
+    diagonal; R = 2: complex couplings on a matching, or two matchings (a ladder pair a + a^dagger has this shape).  The drift
+    is dense unless dense_drift=False."""
+    prob, Z = random_problem(o, N=N, m=m, T=T, order=4, free_time=free_time, layout=layout, seed=seed)
+    rng = np.random.default_rng(1000 + seed)
+
+    def matching_H(kind):
+        perm = rng.permutation(N)
+        H = np.zeros((N, N), dtype=complex)
+        for a, b in zip(perm[0::2], perm[1::2]):
+            c = rng.uniform(0.5, 1.5) * rng.choice([-1.0, 1.0])
+            if kind == "imag":
+                c = 1j * c
+            elif kind == "complex":
+                c = c * np.exp(1j * rng.uniform(0.2, 1.2))
+            H[a, b], H[b, a] = c, np.conj(c)
+        return H
+
+    Hs = []
+    for k in range(m):
+        if R == 1:
+            kind = kinds[k % len(kinds)]
+            Hs.append(np.diag(rng.uniform(-1.5, 1.5, size=N)).astype(complex) if kind == "diag" else matching_H(kind))
+        else:
+            Hs.append(matching_H("complex") if k % 2 == 0 else matching_H("real") + matching_H("real" if k % 4 == 1 else "imag"))
+    n = 2 * N
+    prob.G_drives = np.array([o.generator(H) for H in Hs]).reshape(m, n, n)
+    if not dense_drift:
+        prob.G_drift = o.generator(np.diag(rng.uniform(-1.0, 1.0, size=N)).astype(complex))
+    per_row = max(int(np.count_nonzero(G, axis=1).max()) for G in prob.G_drives)
+    assert per_row <= R, per_row
+    return prob, Z
+
+
 def composed_oracle(inp):
     """Oracle evaluation of an integrator list with several unitary integrators (sampling problem): one oracle
     Problem per group, outputs interleaved per interval in integrator order."""

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from oracle_bridge import problem_from_inputs, random_problem
+from oracle_bridge import problem_from_inputs, random_problem, sparse_drive_problem
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
@@ -730,6 +730,46 @@ def test_mfma32_hessian_variants(qc, oracle, m, free_time, layout, hermitian):
         assert_close_h(h.hess(Z, mu), H_ref, "mfma32 hess")
         assert np.array_equal(h.hess(Z, mu), h.hess(Z, mu))      # fixed reduction order: bit-reproducible
         h.close()
+
+
+@pytest.mark.parametrize("R,m,free_time,layout,T,dense_drift", [(1, 8, True, "standard", 5, True), (1, 3, False, "shuffled", 4, True), (1, 1, True, "shuffled", 2, False),
+                                                                 (1, 6, True, "standard", 300, True), (2, 4, True, "standard", 6, True),
+                                                                 (2, 8, True, "shuffled", 3, True), (2, 7, False, "standard", 5, False), (1, 6, True, "standard", 7, True)])
+def test_sparse_drive_hessian_kernel(qc, oracle, monkeypatch, R, m, free_time, layout, T, dense_drift):
+    """Drive generators with at most two entries per row (Pauli strings, ladder pairs) at 2N = 32 take the row-gather kernel
+    (qc_mfma32_ell.hip: `mfma32-pade4-hess-ell`): against the oracle, against the dense-image kernel of the same handle shape
+    (QC_NO_ELL=1), and bit-reproducible."""
+    # (the last case: six diagonal drives touch the same entries of G -- more than the sparse assembly plan holds: G comes from the dense images)
+    prob, Z = sparse_drive_problem(oracle, m=m, T=T, R=R, free_time=free_time, layout=layout, seed=31 * m + R, dense_drift=dense_drift,
+                                   kinds=("diag",) if (R, m, T) == (1, 6, 7) else ("real", "imag", "diag"))
+    h = RawHandle(qc, prob, kernel="mfma")
+    assert qc._lib.lib.qc_kernel_name(h.h, 1) == b"mfma32-pade4-hess-ell"
+    monkeypatch.setenv("QC_NO_ELL", "1")
+    hd = RawHandle(qc, prob, kernel="mfma")
+    monkeypatch.delenv("QC_NO_ELL")
+    assert qc._lib.lib.qc_kernel_name(hd.h, 1) == b"mfma32-pade4-hess"
+    for mu in (np.ones(prob.n_rows), np.random.default_rng(m).standard_normal(prob.n_rows)):
+        H = h.hess(Z, mu)
+        if T <= 8:
+            assert_close_h(H, oracle.mu_d2F(prob, Z, mu), "mfma32 ell hess vs oracle")
+        assert_close_h(H, hd.hess(Z, mu), "mfma32 ell hess vs the dense-image kernel")
+        assert np.array_equal(H, h.hess(Z, mu))
+    h.close()
+    hd.close()
+
+
+def test_dense_drives_keep_the_dense_image_kernel(qc, oracle):
+    """Three entries in one generator row, or a non-Hermitian Hamiltonian, and the handle stays with qc_mfma32_hess.hip."""
+    prob, Z = sparse_drive_problem(oracle, m=3, T=3, R=2, seed=5)
+    prob.G_drives[1][3, :] = 0.0
+    prob.G_drives[1][:, 3] = 0.0
+    prob.G_drives[1][3, [5, 9, 11]] = (0.3, -0.2, 0.7)
+    prob.G_drives[1][[5, 9, 11], 3] = (-0.3, 0.2, -0.7)          # still antisymmetric, three entries in row 3
+    h = RawHandle(qc, prob, kernel="mfma")
+    assert qc._lib.lib.qc_kernel_name(h.h, 1) == b"mfma32-pade4-hess"
+    mu = np.random.default_rng(2).standard_normal(prob.n_rows)
+    assert_close_h(h.hess(Z, mu), oracle.mu_d2F(prob, Z, mu), "dense fallback")
+    h.close()
 
 
 def test_mfma32_hessian_large_T_matches_lds_kernel(qc):
@@ -1458,7 +1498,7 @@ def test_any_order_mfma_kernel_matches_oracle(qc, oracle, order, N, m, ncol, fre
 def test_kernel_names_of_the_baseline_configurations(qc):
     """Which device kernels serve BASELINE.json's configurations (qc_kernel_name): the tuned MFMA kernels, not a generic path."""
     expect = {1: ("mfma16-pade4", "mfma16-pade4-hess"), 2: ("mfma16-pade4", "mfma16-pade4-hess"),
-              3: ("mfma16-pade4", "mfma16-pade4-hess2"), 5: ("mfma32-pade4", "mfma32-pade4-hess")}     # (hess2: two waves per interval, <= 1024 intervals)
+              3: ("mfma16-pade4", "mfma16-pade4-hess2"), 5: ("mfma32-pade4", "mfma32-pade4-hess-ell")}     # (hess2: two waves per interval, <= 1024 intervals; ell: Pauli drives are row gathers)
     for cfg, names in expect.items():
         inp = qc.config_inputs(cfg, T=5)
         dyn = qc.QuantumDynamics(inp.integrators, inp.traj)
@@ -1563,7 +1603,7 @@ def test_config5_callback_set_on_one_stream(qc, oracle):
     integ = [qc.UnitaryPadeIntegrator("Ũ⃗", "a", inp.system, traj, order=4), qc.DerivativeIntegrator("a", "da", traj),
              qc.DerivativeIntegrator("da", "dda", traj)]
     dyn = qc.QuantumDynamics(integ, traj)
-    assert dyn.kernel_names == ("mfma32-pade4", "mfma32-pade4-hess") and dyn.dims.n_cols == traj.dim * T + 4
+    assert dyn.kernel_names == ("mfma32-pade4", "mfma32-pade4-hess-ell") and dyn.dims.n_cols == traj.dim * T + 4
     con = qc.FinalUnitaryFreePhaseFidelityConstraint("Ũ⃗", "ϕ", phase_ops, 0.99, traj)
     terms = qc.TrajectoryObjective(qc.QuadraticRegularizer("a", traj, 1e-2) + qc.QuadraticRegularizer("da", traj, 1e-2)
                                    + qc.QuadraticRegularizer("dda", traj, 1e-2) + qc.MinimumTimeObjective(traj, 1.0), traj)
