@@ -520,10 +520,11 @@ extern "C" const char* qc_kernel_name(const qc_handle* h, int32_t which) {
         if (!mfma) return P.use_ws ? "lds-gws" : "lds";
         if (P.integrator == QC_EXPONENTIAL) return P.n > 16 ? "mfma32-exp" : "mfma16-exp";
         if (qc_mfma16_padeP_supported(P)) return "mfma16-padeP";
+        if (P.n > 16 && P.n <= 32 && P.ell) return "mfma32-pade4-ell";
         return P.n > 32 ? "mfma64-pade4" : (P.n > 16 ? "mfma32-pade4" : "mfma16-pade4");
     }
     if (P.integrator != QC_PADE) return "none";
-    if (which == 2) return mfma && qc_mfma16_fused_supported(P) ? "mfma16-pade4-fused" : "two-launches";
+    if (which == 2) return mfma && qc_mfma16_fused_supported(P) ? "mfma16-pade4-fused" : (mfma && P.ell && P.hess_nnz ? "mfma32-pade4-fused-ell" : "two-launches");
     if (mfma && qc_mfma_hess_supported(P)) {
         if (qc_mfma16_padeP_hess_supported(P)) return "mfma16-padeP-hess";
         if (qc_mfma16_hess2_supported(P)) return "mfma16-pade4-hess2";

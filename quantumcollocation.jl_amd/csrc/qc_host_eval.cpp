@@ -193,6 +193,13 @@ extern "C" int qc_eval_F_jac_hess_dev(qc_handle* h, const double* dZ, const doub
         if (e != hipSuccess) return fail(&h->err, QC_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
         return QC_OK;
     }
+    if (allow && h->kernel == QC_KERNEL_MFMA && h->prm.ell && h->prm.hess_nnz) {      // sparse drive generators at 2N = 32: qc_mfma32_ell.hip
+        qc_device_guard guard(h->device);
+        QC_HIP(h, guard.err);
+        const hipError_t e = qc_launch_mfma32_ell_fused(h->prm, dZ, dmu, dF, dvals, dhvals, (hipStream_t)stream);
+        if (e != hipSuccess) return fail(&h->err, QC_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+        return QC_OK;
+    }
     if (h->prm.hess_nnz == 0) return qc_eval_F_jac_dev(h, dZ, dF, dvals, stream);
     // Two kernels, one after the other.  (mu_d2F on a second stream beside F + dF, between two events, was measured at config 5,
     // where the first is bound by its stores and the second by the matrix pipes: 67 us against 53 -- the fork and join cost more

@@ -182,6 +182,8 @@ bool qc_mfma32_hess_supported(const QcParams& P);
 // sparse drive generators (at most 2 entries per row), 2N = 32, Hermitian Hamiltonians: qc_mfma32_ell.hip
 int qc_mfma32_ell_build(const QcParams& P, const double* G_host, std::vector<char>* blob, int* slots_out);
 hipError_t qc_launch_mfma32_ell_hess(const QcParams& P, const double* dZ, const double* dMu, double* dH, hipStream_t st);
+hipError_t qc_launch_mfma32_ell_F_jac(const QcParams& P, const double* dZ, double* dF, double* dJ, hipStream_t st);
+hipError_t qc_launch_mfma32_ell_fused(const QcParams& P, const double* dZ, const double* dMu, double* dF, double* dJ, double* dH, hipStream_t st);
 hipError_t qc_launch_mfma32_hess(const QcParams& P, const double* dZ, const double* dMu, double* dH, hipStream_t st);
 // F + dF + mu_d2F in one launch (qc_mfma_fused.hip): 2N = 16, a unitary on 8 levels, antisymmetric generators, 1 .. 6 drives
 bool qc_mfma16_fused_supported(const QcParams& P);

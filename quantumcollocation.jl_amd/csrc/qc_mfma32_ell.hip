@@ -32,6 +32,11 @@
 
 #include "qc_mfma_common.h"
 
+// No fused multiply-adds of the compiler's choosing in this file: the Hessian values of the one-call instantiation must equal those of
+// the Hessian-only instantiation bit for bit (include/qcolloc.h, qc_eval_F_jac_hess_dev), and which a * b + c contracts depends on the
+// code around it.  (The products that matter are MFMAs; the vector arithmetic here is a few hundred instructions per wave.)
+#pragma clang fp contract(off)
+
 namespace {
 
 using namespace qc_mfma;
@@ -60,7 +65,7 @@ __host__ __device__ inline EllLayout ell_layout(int m, int R, int L, int slots) 
     o.bytes = o.gk + (size_t)slots * 1024 * 4;
     return o;
 }
-constexpr int kMaxSlots = 4;        // drives touching one entry of G beyond this: the dense images assemble G
+constexpr int kMaxSlots = 4;        // drives touching one entry of G beyond this: the handle stays with the dense-image kernels
 
 __device__ inline v4d tile_ld(const double* __restrict__ base, int tile, int lane) {   // [tile][pair][lane][2]
     const v2d* p = reinterpret_cast<const v2d*>(base) + tile * 128 + lane;
@@ -132,6 +137,43 @@ __device__ inline void store_T32(double* __restrict__ p, const v4d& x, int J, in
     for (int r = 0; r < 4; ++r) qc_st8m<2>(p + (4 * r + g) * 32 + 16 * J + j, x[r]);
 }
 
+// operand-layout (B/D) tile I of a plain row-major 32 x 16 matrix: lane (g, j) reg r = X[16 I + 4 r + g][j]
+__device__ __forceinline__ v4d plain_ld(const double* __restrict__ src, int I, int g, int j) {
+    v4d x;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) x[r] = src[(16 * I + 4 * r + g) * kPS + j];
+    return x;
+}
+__device__ __forceinline__ void plain_st(double* __restrict__ dst, int I, int g, int j, const v4d& x) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dst[(16 * I + 4 * r + g) * kPS + j] = x[r];
+}
+// ... and its transpose (store layout): lane (g, j) reg r = X[16 J + j][4 r + g]
+__device__ __forceinline__ v4d plain_ld_T(const double* __restrict__ src, int J, int g, int j) {
+    v4d x;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) x[r] = src[(16 * J + j) * kPS + 4 * r + g];
+    return x;
+}
+
+// load_col16_T (qc_mfma_common.h) in two halves: the request (32 contiguous bytes per lane) and, once the data is needed, the
+// transposition between lane groups and registers -- the loader waves must not wait for their knots in front of barrier A
+struct Col16Raw { double x0, x1, x2, x3; };
+__device__ __forceinline__ Col16Raw col16_request(const double* __restrict__ col, int g) {
+    typedef double v2d_ __attribute__((ext_vector_type(2)));
+    typedef v2d_ __attribute__((aligned(8))) v2d_u;
+    const v2d_u* q = reinterpret_cast<const v2d_u*>(col + 4 * g);
+    const v2d_ q0 = q[0], q1 = q[1];
+    return Col16Raw{q0[0], q0[1], q1[0], q1[1]};
+}
+__device__ __forceinline__ v4d col16_finish(Col16Raw r) {
+    swap32_f64(r.x0, r.x2);
+    swap32_f64(r.x1, r.x3);
+    swap16_rows_f64(r.x0, r.x1);
+    swap16_rows_f64(r.x2, r.x3);
+    return v4d{r.x0, r.x1, r.x2, r.x3};
+}
+
 // One row-gathered 32 x 16 product in the OPERAND layout (B/D layout: lane (g, j) reg kk of tile K = X[16 K + 4 kk + g][j], X = G_k S):
 // the row's R (weight, column) pairs come from the LDS tables (broadcast reads: four distinct rows per instruction)
 template <int R>
@@ -165,244 +207,419 @@ __device__ __forceinline__ v4d gather_rows_store(const double* __restrict__ tw, 
     return out;
 }
 
-template <int R, bool DIAG>
-__global__ __launch_bounds__(kEThreads, 2) void qc_mfma32_ell_hess_kernel(const double* __restrict__ hot_Gx, const double* __restrict__ hot_Zt,
-                                                                          const double* __restrict__ hot_mu0, const char* __restrict__ hot_ell,
-                                                                          const int hot_n_int, const int hot_zdim, const int hot_m,
-                                                                          const int hot_off_a, const int hot_off_dt, const int hot_off_U,
-                                                                          const int hot_f_stride, const int hot_slots, const QcParams Pk,
-                                                                          double* __restrict__ H) {
+// Two transposed tiles of the SAME columns, rows 0-15 (x0) and 16-31 (x1), as whole 256-byte columns (qc_mfma32_kernels.hip):
+// v_permlane16_swap exchanges the odd 16-lane rows of one register with the even rows of the other
+__device__ inline void swap16_f64(double a, double b, double& x, double& y) {
+    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    x = __hiloint2double((int)hi[0], (int)lo[0]);
+    y = __hiloint2double((int)hi[1], (int)lo[1]);
+}
+struct ColumnPair { v4d e, o; };
+__device__ inline ColumnPair merge_rows32(const v4d& x0, const v4d& x1) {
+    ColumnPair c;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        double x, y;
+        swap16_f64(x0[r], x1[r], x, y);
+        c.e[r] = x;
+        c.o[r] = y;
+    }
+    return c;
+}
+__device__ inline void store_T32_columns(double* __restrict__ p, const ColumnPair& c, int colbase, int g, int j) {
+    double* __restrict__ q = p + (colbase + (g & 2)) * 32 + 16 * (g & 1) + j;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        qc_st8m<2>(q + (4 * r) * 32, c.e[r]);
+        qc_st8m<2>(q + (4 * r + 1) * 32, c.o[r]);
+    }
+}
+
+// Hand-offs between the waves of a workgroup through counters in LDS (the copy waves of the fused kernel must not stand at a
+// workgroup barrier while the knots are still on their way from HBM: their stores are what the launch time follows).  A wave's LDS
+// operations execute in order, so data written before the counter is visible to whoever has seen the counter.
+enum { FL_U = 0, FL_M, FL_GD, FL_E, FL_Q, FL_COUNT };
+__device__ __forceinline__ void flag_signal(int* flags, int f, int lane) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) __hip_atomic_fetch_add(&flags[f], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void flag_wait(int* flags, int f, int count) {
+    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&flags[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < count) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// JAC: F + dF (the I_N (x) B / -I_N (x) F copies by two "copy waves", everything else by the six compute waves);
+// HESS: mu_d2F.  JAC && HESS: both in one launch -- every Hessian value by the same operations in the same order as the HESS-only
+// instantiation (bit-identical), the knots and multipliers read once.
+// SLOTS: how many drives touch one entry of G at most (1 for Pauli strings on distinct qubits; instantiated for 1, 2, 4)
+template <int R, bool JAC, bool HESS, bool DIAG, int SLOTS>
+__global__ __launch_bounds__(kEThreads, 4) void qc_mfma32_ell_kernel(const double* __restrict__ hot_Gx, const double* __restrict__ hot_Zt,
+                                                                     const double* __restrict__ hot_mu0, const char* __restrict__ hot_ell,
+                                                                     const int hot_n_int, const int hot_zdim, const int hot_m,
+                                                                     const int hot_off_a, const int hot_off_dt, const int hot_off_U,
+                                                                     const int hot_f_stride, const int hot_unused, const QcParams Pk,
+                                                                     double* __restrict__ F, double* __restrict__ Jv, double* __restrict__ H) {
     constexpr int L = R == 1 ? 64 : 256;          // padded length of a pair list (fixed by R: at most 32 * 2 R^2 entries)
-    constexpr int kPairsPerWave = (kEMax * (kEMax + 1) / 2 + kEMax - 1) / kEMax;    // 5
+    constexpr int kFirst = JAC ? 2 : 0;           // first compute wave (waves 0, 1 of a JAC instantiation are the copy waves)
+    constexpr int kCW = 8 - kFirst;               // compute waves
+    constexpr int kPairsPerWave = (kEMax * (kEMax + 1) / 2 + kCW - 1) / kCW;
+    constexpr int kDrivesPerWave = (kEMax + kCW - 1) / kCW;
+    // R = 1, mu_d2F alone: a wave's pair entries (one per lane and pair) are requested with the first loads.  The one-call form has
+    // no registers to hold them through its drives (the values would be spilled where they arrive -- a wait for every load in
+    // front of the spill) and no use for the head start: its time is the stores'.
+    constexpr bool kPrefetchPairs = HESS && !JAC && R == 1;
     QcKernargTouch<sizeof(QcParams) + 96> touch;
     touch.request();
     __shared__ __attribute__((aligned(16))) double GL[4 * 256];      // G, A-layout tiles 2 I + K
-    __shared__ __attribute__((aligned(16))) double MT[2 * 256];      // M, B/D-layout tiles
-    __shared__ __attribute__((aligned(16))) double DT[2 * 256];      // D
-    __shared__ __attribute__((aligned(16))) double ST[2 * 256];      // S
-    __shared__ __attribute__((aligned(16))) double ET[2 * 256];      // E = G M
-    __shared__ __attribute__((aligned(16))) double GDT[2 * 256];     // G D
-    __shared__ __attribute__((aligned(16))) double WT[2 * 256];      // -c1 S + 2 c2 h G D
-    __shared__ double Mp[32 * kPS], Dp[32 * kPS], Ep[32 * kPS];      // plain row-major copies: the gather sources
+    // the 32 x 16 matrices, plain row-major with rows of kPS doubles -- gather sources and operand tiles alike:
+    // M, D, S, E = G M, G D, W = -c1 S + 2 c2 h G D
+    __shared__ double Mp[32 * kPS], Dp[32 * kPS], Sp[32 * kPS], Ep[32 * kPS], GDp[32 * kPS], Wp[32 * kPS];
     __shared__ double Qp[32 * kQS];                                  // Q = M D^T
     __shared__ double TW[kEMax * R * 32];                            // the drives' rows: weights ...
     __shared__ int TC[kEMax * R * 32];                               // ... and columns (x kPS)
+    __shared__ int flags[FL_COUNT];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, j = lane & 15;
     const int m = hot_m;
     const bool ft = hot_off_dt >= 0;
-    const bool drive = w < m;
+    const int cw = w - kFirst;                    // compute-wave index (negative: copy wave)
     const int b = qc_xcd_remap((int)blockIdx.x, hot_n_int);
     const double* __restrict__ z0 = hot_Zt + (long long)b * hot_zdim;
     const double* __restrict__ z1 = z0 + hot_zdim;
     const double* __restrict__ mu = hot_mu0 + (long long)b * hot_f_stride;
     const QcParams& P = Pk;
+    // roles among the compute waves: the last four fetch the knots' state tiles and the multipliers and produce the shared products
+    const bool f_only = JAC && Jv == nullptr;                        // residuals alone (a line-search trial): the same operations, nothing else
+    const bool ld_m = HESS && (cw == kCW - 4 || cw == kCW - 3);      // M tile I = cw - (kCW - 4)
+    const bool ld_u = cw == kCW - 2 || cw == kCW - 1;                // U_t, U_t+1 tiles I = cw - (kCW - 2)
     QC_STAMP_DECL;
     QC_STAMP(P, b, lane, 0);
 
-    // ---- phase 0 ------------------------------------------------------------------------------------------------
+    // ---- phase 0: G (every wave its half tile), the tables, then the state (requested last: G must not wait for it) -----------
     const double h = ft ? z0[hot_off_dt] : opaque_scalar(P.dt_fixed);
-    const EllLayout lay = ell_layout(m, R, L, hot_slots);
+    const EllLayout lay = ell_layout(m, R, L, SLOTS);
     const int npairs = m * (m + 1) / 2;
     double pwv[kPairsPerWave];        // R = 1: this wave's pair entries, one per lane and pair, requested with everything else
     int pov[kPairsPerWave];
+    Col16Raw raw0 = {0.0, 0.0, 0.0, 0.0}, raw1 = raw0;      // loader waves: M tile, or U_t / U_t+1 tiles (as requested; transposed behind barrier A)
+    double mud[2] = {0.0, 0.0};
+    const bool dfast = ft && P.n_deriv <= 2 && P.ddim_i[0] <= 64 && P.ddim_i[1] <= 64;
     {
         // half (w & 1) of A-layout tile (w >> 1) of G = G_0 + sum_k a_k G_k: two entries per lane, in image order
         const int e0 = (w >> 1) * 256 + (w & 1) * 128 + 2 * lane;
+        // (no branch anywhere in the request phase: where paths meet the compiler cannot count what is outstanding and waits for all)
         v2d Gh = reinterpret_cast<const v2d*>(hot_Gx)[e0 >> 1];
-        if (hot_slots > 0) {          // sparse drives: the few drives that touch an entry, in ascending order (the dense sum's order)
-            const double* __restrict__ gw = reinterpret_cast<const double*>(hot_ell + lay.gw);
-            const int* __restrict__ gk = reinterpret_cast<const int*>(hot_ell + lay.gk);
-            // (the amplitudes by ONE vector load, lane u = a_u, handed to the lanes that need them through the LDS crossbar: a load
-            //  per entry would be a second round trip behind the plan's)
-            const double amp = z0[hot_off_a + (lane < m ? lane : 0)];
-            v2d wv[kMaxSlots];
-            int k0[kMaxSlots], k1[kMaxSlots];
+        // the amplitudes by ONE vector load, lane u = a_u, handed to the lanes that need them through the LDS crossbar (a load per
+        // entry would be a second round trip behind the plan's); the plan: the few drives that touch an entry, in ascending order
+        const double amp = z0[hot_off_a + (lane < m ? lane : 0)];
+        const double* __restrict__ gw = reinterpret_cast<const double*>(hot_ell + lay.gw);
+        const int* __restrict__ gk = reinterpret_cast<const int*>(hot_ell + lay.gk);
+        v2d wv[SLOTS];
+        int k0[SLOTS], k1[SLOTS];
 #pragma unroll
-            for (int sl = 0; sl < kMaxSlots; ++sl) {
-                const int so = sl < hot_slots ? sl : 0;
-                wv[sl] = reinterpret_cast<const v2d*>(gw + (size_t)so * 1024)[e0 >> 1];
-                k0[sl] = gk[(size_t)so * 1024 + e0];
-                k1[sl] = gk[(size_t)so * 1024 + e0 + 1];
-            }
-#pragma unroll
-            for (int sl = 0; sl < kMaxSlots; ++sl)
-                if (sl < hot_slots) Gh += v2d{__shfl(amp, k0[sl]), __shfl(amp, k1[sl])} * wv[sl];
-        } else {
-            const v2d* __restrict__ ab = reinterpret_cast<const v2d*>(hot_Gx) + (e0 >> 1);
-            v2d img[kEMax];
-            double ak[kEMax];
-#pragma unroll
-            for (int u = 0; u < kEMax; ++u) img[u] = ab[(size_t)(u < m ? u + 1 : 0) * 512];
-#pragma unroll
-            for (int u = 0; u < kEMax; ++u) ak[u] = z0[hot_off_a + (u < m ? u : 0)];
-#pragma unroll
-            for (int u = 0; u < kEMax; ++u) Gh += (u < m ? ak[u] : 0.0) * img[u + 0];
+        for (int sl = 0; sl < SLOTS; ++sl) {
+            wv[sl] = reinterpret_cast<const v2d*>(gw + (size_t)sl * 1024)[e0 >> 1];
+            k0[sl] = gk[(size_t)sl * 1024 + e0];
+            k1[sl] = gk[(size_t)sl * 1024 + e0 + 1];
         }
-        // this drive's rows -> LDS (one (weight, column) pair per lane)
-        double twv = 0.0;
-        int tcv = 0;
-        if (drive && lane < 32 * R) {
-            twv = reinterpret_cast<const double*>(hot_ell + lay.tw)[w * R * 32 + lane];
-            tcv = reinterpret_cast<const int*>(hot_ell + lay.tc)[w * R * 32 + lane];
-        }
-        if constexpr (R == 1) {
+        // drive w's rows -> LDS (one (weight, column) pair per lane; any wave will do, wave k takes drive k)
+        const int trow = (w < m ? w : 0) * R * 32 + (lane < 32 * R ? lane : 0);
+        const double twv = reinterpret_cast<const double*>(hot_ell + lay.tw)[trow];
+        const int tcv = reinterpret_cast<const int*>(hot_ell + lay.tc)[trow];
+        // ---- everything G needs has been requested; what follows is requested behind it and waited for later (loads return in
+        //      order: the assembly below waits for its own only -- the scheduling fences keep the compiler from mixing the two groups)
+        __builtin_amdgcn_sched_barrier(0);
+        // EVERY wave issues the same requests here, without a branch (a wave that has no use for one reads a harmless address):
+        // behind a branch the compiler cannot count what is outstanding where the paths meet, and waits for everything.
+        if constexpr (kPrefetchPairs) {
             const double* __restrict__ pw = reinterpret_cast<const double*>(hot_ell + lay.pw);
             const int* __restrict__ po = reinterpret_cast<const int*>(hot_ell + lay.po);
 #pragma unroll
             for (int t = 0; t < kPairsPerWave; ++t) {
-                const int p = w + m * t;
-                const bool ok = drive && p < npairs;
-                pwv[t] = ok ? pw[(size_t)p * L + lane] : 0.0;
-                pov[t] = ok ? po[(size_t)p * L + lane] : 0;
+                const int p = cw + kCW * t;
+                const int pe = p < npairs ? p : 0;        // (clamped: the value of a pair beyond the last is never stored)
+                pwv[t] = pw[(size_t)pe * L + lane];
+                pov[t] = po[(size_t)pe * L + lane];
             }
         }
-        if (w >= 4) {
-            const int I = w & 1;
-            if (w < 6) {
-                const v4d mt = load_col16_T(mu + j * 32 + 16 * I, g);        // lane (g, j) reg r = M[16 I + 4 r + g][j]
-                tile_st(MT, I, lane, mt);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) Mp[(16 * I + 4 * r + g) * kPS + j] = mt[r];
-            } else {
-                const v4d u0 = load_col16_T(z0 + hot_off_U + j * 32 + 16 * I, g);
-                const v4d u1 = load_col16_T(z1 + hot_off_U + j * 32 + 16 * I, g);
-                const v4d dd = u1 - u0;
-                tile_st(ST, I, lane, u1 + u0);
-                tile_st(DT, I, lane, dd);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) Dp[(16 * I + 4 * r + g) * kPS + j] = dd[r];
-            }
+        {
+            const int Iu = cw - (kCW - 2), Im = cw - (kCW - 4);
+            const double* pa = ld_u ? z0 + hot_off_U + j * 32 + 16 * Iu : (ld_m ? mu + j * 32 + 16 * Im : z0);
+            const double* pb = ld_u ? z1 + hot_off_U + j * 32 + 16 * Iu : z0;
+            raw0 = col16_request(pa, ld_u || ld_m ? g : 0);
+            raw1 = col16_request(pb, ld_u ? g : 0);
         }
-        if (drive && lane < 32 * R) { TW[w * R * 32 + lane] = twv; TC[w * R * 32 + lane] = tcv; }
+        if constexpr (HESS) {             // derivative integrators: d2/d(dx_i) dh = -mu_i, requested here, written at the end (wave cw = 0)
+#pragma unroll
+            for (int d = 0; d < 2; ++d) mud[d] = mu[dfast ? P.drow[d] + (lane < P.ddim_i[d] ? lane : 0) : 0];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int sl = 0; sl < SLOTS; ++sl) Gh += v2d{__shfl(amp, k0[sl]), __shfl(amp, k1[sl])} * wv[sl];
+        if (w < m && lane < 32 * R && !f_only) { TW[w * R * 32 + lane] = twv; TC[w * R * 32 + lane] = tcv; }
         reinterpret_cast<v2d*>(GL)[e0 >> 1] = Gh;
+        if (tid < FL_COUNT) flags[tid] = 0;
     }
     touch.consume();
-    double* __restrict__ Hb = H + (size_t)b * P.H_stride + P.H_off;
+    double* __restrict__ Hb = HESS ? H + (size_t)b * P.H_stride + P.H_off : nullptr;
+    double* __restrict__ Jb = (JAC && !f_only) ? Jv + (size_t)b * P.J_stride + P.J_off : nullptr;
+    double* __restrict__ Fb = (JAC && F) ? F + (size_t)b * P.F_stride + P.F_off : nullptr;
     const double c1 = P.c[1], c2 = P.c[2];
     QC_STAMP(P, b, lane, 1);
-    __syncthreads();
+    __syncthreads();                  // G, the tables and the zeroed counters; the state is still on its way
     const double hc1 = h * c1, hc2 = h * h * c2, c2h2 = 2.0 * c2 * h;
-    const double* __restrict__ tw = TW + (drive ? w : 0) * R * 32;
-    const int* __restrict__ tc = TC + (drive ? w : 0) * R * 32;
     QC_STAMP(P, b, lane, 2);
 
-    // ---- phase 1 ------------------------------------------------------------------------------------------------
-    if (w < 2) {                      // E tile I = w
-        const v4d e = gy_tile(GL, w, lane, tile_ld(MT, 0, lane), tile_ld(MT, 1, lane));
-        tile_st(ET, w, lane, e);
+    if (JAC && cw < 0) {
+        if (f_only) return;
+        // ================= copy wave: block row I of B^T and F^T (tiles (I, 0), (I, 1)), N copies each ======================
+        // B^T = I - hc1 G^T + hc2 (G^2)^T, -F^T = -(I + hc1 G^T + hc2 (G^2)^T); with G^T = -G the operands of
+        // (G^2)^T[I][J] = sum_K G^T[I][K] G^T[K][J] are A-layout tiles of G both: -(G_A[I][K] as A) x (G_A[J][K] as B)
+        const int I = w;
+        const v4d IdB = identity_B(g, j);
+        const v4d aI0 = tile_ld(GL, 2 * I, lane), aI1 = tile_ld(GL, 2 * I + 1, lane);
+        v4d Fm[2], Bm[2];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Ep[(16 * w + 4 * r + g) * kPS + j] = e[r];
-    } else if (w < 4) {               // (G D) tile I = w - 2, W tile
-        const int I = w - 2;
-        const v4d gd = gy_tile(GL, I, lane, tile_ld(DT, 0, lane), tile_ld(DT, 1, lane));
-        tile_st(GDT, I, lane, gd);
-        tile_st(WT, I, lane, (-c1) * tile_ld(ST, I, lane) + c2h2 * gd);
-    } else {                          // Q tile (I, J): Q[16 I + i][16 J + j] = sum_c M[16 I + i][c] D[16 J + j][c]
-        const int I = (w - 4) >> 1, J = (w - 4) & 1;
-        const v4d z = {0.0, 0.0, 0.0, 0.0};
-        v4d q = z;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk)   // A: lane (g, i) = M[16 I + i][4 kk + g];  B: lane (g, j) = D[16 J + j][4 kk + g]
-            q = __builtin_amdgcn_mfma_f64_16x16x4f64(Mp[(16 * I + j) * kPS + 4 * kk + g], Dp[(16 * J + j) * kPS + 4 * kk + g], q, 0, 0, 0);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Qp[(16 * I + 4 * r + g) * kQS + 16 * J + j] = q[r];
-    }
-    v4d Yk[2], TY[2];
-    if (drive) {
-        gather_rows_operand<R>(tw, tc, Mp, g, j, Yk);               // Y_k = G_k M
-        // (G Y_k)^T: A = Y_k[K] (operand-layout registers read as an A operand are the transposed tile), B = G_A[2 J + K]
-        const v4d z = {0.0, 0.0, 0.0, 0.0};
-        v4d t0 = z, t1 = z;
-#pragma unroll
-        for (int K = 0; K < 2; ++K) {
-            const v4d b0 = tile_ld(GL, K, lane), b1 = tile_ld(GL, 2 + K, lane);      // G_A tiles (J = 0, K), (J = 1, K)
+        for (int Jt = 0; Jt < 2; ++Jt) {
+            const v4d bJ0 = tile_ld(GL, 2 * Jt, lane), bJ1 = tile_ld(GL, 2 * Jt + 1, lane);
+            const v4d z = {0.0, 0.0, 0.0, 0.0};
+            v4d a0 = z, a1 = z;
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                t0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Yk[K][kk], b0[kk], t0, 0, 0, 0);
-                t1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Yk[K][kk], b1[kk], t1, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(aI0[kk], bJ0[kk], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(aI1[kk], bJ1[kk], a1, 0, 0, 0);
+            }
+            const v4d G2T = -(a0 + a1);
+            const v4d GT = tile_ld(GL, 2 * Jt + I, lane);     // B/D layout of (G^T)[I][Jt] = A layout of G[Jt][I]
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double ev = (I == Jt ? IdB[r] : 0.0) + hc2 * G2T[r];
+                Fm[Jt][r] = -(ev + hc1 * GT[r]);
+                Bm[Jt][r] = ev - hc1 * GT[r];
             }
         }
-        TY[0] = t0;
-        TY[1] = t1;
-    }
-    QC_STAMP(P, b, lane, 3);
-    __syncthreads();
-    QC_STAMP(P, b, lane, 4);
-
-    // ---- phase 2 ------------------------------------------------------------------------------------------------
-    if (drive) {
-        double* __restrict__ pUa = Hb + P.ho_Ua + (size_t)w * 512;
-        double* __restrict__ paU = Hb + P.ho_aU + (size_t)w * 512;
-#pragma unroll
-        for (int J = 0; J < 2; ++J) {
-            const v4d yt = gather_rows_store<R>(tw, tc, Mp, J, g, j);       // Y_k^T
-            const v4d get = gather_rows_store<R>(tw, tc, Ep, J, g, j);      // (G_k E)^T
-            const v4d lin = hc1 * yt, qd = hc2 * (get + TY[J]);
-            store_T32(pUa, lin - qd, J, g, j);
-            store_T32(paU, lin + qd, J, g, j);
+        // lane (g, j) reg r = B^T[16 I + 4 r + g][16 Jt + j] = B[16 Jt + j][16 I + 4 r + g]
+        double* __restrict__ pF = Jb + P.jo_F;
+        double* __restrict__ pB = Jb + P.jo_B;
+        const ColumnPair Fc = merge_rows32(Fm[0], Fm[1]), Bc = merge_rows32(Bm[0], Bm[1]);
+        QC_STAMP(P, b, lane, 3);
+        const int ncop = P.copies;    // N copies of each block; 1 when the host path asks for the compact form
+        for (int q = 0; q < ncop; ++q) {
+            store_T32_columns(pF + q * 1024, Fc, 16 * I, g, j);
+            store_T32_columns(pB + q * 1024, Bc, 16 * I, g, j);
         }
-        QC_STAMP(P, b, lane, 5);
-        // (a_k, h) and this wave's pairs: one batched reduction
-        double pv[1 + kPairsPerWave];
-        pv[0] = 0.0;
-        if (ft) {
-            v4d Vk[2];
-            gather_rows_operand<R>(tw, tc, Dp, g, j, Vk);           // V_k = G_k D
-            pv[0] = -(dot4(Yk[0], tile_ld(WT, 0, lane)) + dot4(Yk[1], tile_ld(WT, 1, lane))) -
-                    c2h2 * (dot4(tile_ld(ET, 0, lane), Vk[0]) + dot4(tile_ld(ET, 1, lane), Vk[1]));
+        QC_STAMP(P, b, lane, 4);
+    } else {
+        // ================= compute wave ====================================================================================
+        if (ld_m) {
+            const int I = cw - (kCW - 4);
+            plain_st(Mp, I, g, j, col16_finish(raw0));                         // lane (g, j) reg r = M[16 I + 4 r + g][j]
+            flag_signal(flags, FL_M, lane);
         }
-        if constexpr (R == 1) {
+        if (ld_u) {
+            const int I = cw - (kCW - 2);
+            const v4d st0 = col16_finish(raw0), st1 = col16_finish(raw1);
+            const v4d dd = st1 - st0, ss = st1 + st0;
+            plain_st(Dp, I, g, j, dd);
+            plain_st(Sp, I, g, j, ss);
+            flag_signal(flags, FL_U, lane);
+        }
+        flag_wait(flags, FL_U, 2);
+        if constexpr (HESS) flag_wait(flags, FL_M, 2);
+        QC_STAMP(P, b, lane, 3);
+        // ---- the shared products (their producers first: the other waves wait for them in their first drive's epilogue) ----
+        if (cw == kCW - 2) {              // G D (both tiles), W = -c1 S + 2 c2 h G D
+            const v4d d0 = plain_ld(Dp, 0, g, j), d1 = plain_ld(Dp, 1, g, j);
 #pragma unroll
-            for (int t = 0; t < kPairsPerWave; ++t) pv[1 + t] = pwv[t] * Qp[pov[t]];
-        } else {
-            const double* __restrict__ pw = reinterpret_cast<const double*>(hot_ell + lay.pw);
-            const int* __restrict__ po = reinterpret_cast<const int*>(hot_ell + lay.po);
+            for (int I = 0; I < 2; ++I) {
+                const v4d gd = gy_tile(GL, I, lane, d0, d1);
+                plain_st(GDp, I, g, j, gd);
+                if constexpr (HESS) plain_st(Wp, I, g, j, (-c1) * plain_ld(Sp, I, g, j) + c2h2 * gd);
+            }
+            flag_signal(flags, FL_GD, lane);
+        }
+        if (HESS && cw == kCW - 4) {      // E = G M
+            const v4d m0 = plain_ld(Mp, 0, g, j), m1 = plain_ld(Mp, 1, g, j);
 #pragma unroll
-            for (int t = 0; t < kPairsPerWave; ++t) {
-                const int p = w + m * t;                 // pairs dealt round-robin over the drive waves
-                double acc = 0.0;
-                if (p < npairs) {
+            for (int I = 0; I < 2; ++I) plain_st(Ep, I, g, j, gy_tile(GL, I, lane, m0, m1));
+            flag_signal(flags, FL_E, lane);
+        }
+        if (HESS && cw == kCW - 3) {      // Q[16 I + i][16 J + j] = sum_c M[16 I + i][c] D[16 J + j][c]
 #pragma unroll
-                    for (int e = 0; e < L / 64; ++e) acc += pw[(size_t)p * L + 64 * e + lane] * Qp[po[(size_t)p * L + 64 * e + lane]];
+            for (int IJ = 0; IJ < 4; ++IJ) {
+                const int I = IJ >> 1, J = IJ & 1;
+                v4d q = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)   // A: lane (g, i) = M[16 I + i][4 kk + g];  B: lane (g, j) = D[16 J + j][4 kk + g]
+                    q = __builtin_amdgcn_mfma_f64_16x16x4f64(Mp[(16 * I + j) * kPS + 4 * kk + g], Dp[(16 * J + j) * kPS + 4 * kk + g], q, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Qp[(16 * I + 4 * r + g) * kQS + 16 * J + j] = q[r];
+            }
+            flag_signal(flags, FL_Q, lane);
+        }
+        // ---- this wave's drives ---------------------------------------------------------------------------------------------
+        double pv[kDrivesPerWave + kPairsPerWave];
+#pragma unroll
+        for (int t = 0; t < kDrivesPerWave; ++t) {
+            pv[t] = 0.0;
+            const int k = cw + kCW * t;
+            if (k < m && !f_only) {
+                const double* __restrict__ tw = TW + k * R * 32;
+                const int* __restrict__ tc = TC + k * R * 32;
+                v4d Vk[2], Yk[2], TV[2], TY[2];
+                gather_rows_operand<R>(tw, tc, Dp, g, j, Vk);                   // V_k = G_k D
+                if constexpr (HESS) gather_rows_operand<R>(tw, tc, Mp, g, j, Yk);   // Y_k = G_k M
+                {   // (G V_k)^T and (G Y_k)^T: A = the gathered tiles (operand-layout registers read as an A operand are the transposed
+                    // tile), B = G_A[2 J + K]; the chains of the output tiles interleave
+                    const v4d z = {0.0, 0.0, 0.0, 0.0};
+                    v4d v0 = z, v1 = z, y0 = z, y1 = z;
+#pragma unroll
+                    for (int K = 0; K < 2; ++K) {
+                        const v4d b0 = tile_ld(GL, K, lane), b1 = tile_ld(GL, 2 + K, lane);      // G_A tiles (J = 0, K), (J = 1, K)
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) {
+                            if constexpr (JAC) {
+                                v0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Vk[K][kk], b0[kk], v0, 0, 0, 0);
+                                v1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Vk[K][kk], b1[kk], v1, 0, 0, 0);
+                            }
+                            if constexpr (HESS) {
+                                y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Yk[K][kk], b0[kk], y0, 0, 0, 0);
+                                y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Yk[K][kk], b1[kk], y1, 0, 0, 0);
+                            }
+                        }
+                    }
+                    TV[0] = v0; TV[1] = v1; TY[0] = y0; TY[1] = y1;
                 }
-                pv[1 + t] = acc;
+                if (t == 0) QC_STAMP(P, b, lane, 4);
+                flag_wait(flags, FL_GD, 1);
+                if constexpr (HESS) flag_wait(flags, FL_E, 1);
+                if (t == 0) QC_STAMP(P, b, lane, 5);
+                if constexpr (HESS) {     // (a_k, h), per lane: the last use of the gathered operand tiles
+                    if (ft)
+                        pv[t] = -(dot4(Yk[0], plain_ld(Wp, 0, g, j)) + dot4(Yk[1], plain_ld(Wp, 1, g, j))) -
+                                c2h2 * (dot4(plain_ld(Ep, 0, g, j), Vk[0]) + dot4(plain_ld(Ep, 1, g, j), Vk[1]));
+                }
+                if constexpr (JAC) {      // d/da_k = -c1 h G_k S + c2 h^2 (G_k (G D) + G (G_k D)), transposed for the store
+                    double* __restrict__ pa = Jb + P.jo_a + (size_t)k * 512;
+                    v4d yT[2];
+#pragma unroll
+                    for (int J = 0; J < 2; ++J)
+                        yT[J] = (-hc1) * gather_rows_store<R>(tw, tc, Sp, J, g, j) + hc2 * (gather_rows_store<R>(tw, tc, GDp, J, g, j) + TV[J]);
+                    store_T32_columns(pa, merge_rows32(yT[0], yT[1]), 0, g, j);
+                }
+                if constexpr (HESS) {
+                    double* __restrict__ pUa = Hb + P.ho_Ua + (size_t)k * 512;
+                    double* __restrict__ paU = Hb + P.ho_aU + (size_t)k * 512;
+                    v4d lo[2], hi[2];
+#pragma unroll
+                    for (int J = 0; J < 2; ++J) {
+                        const v4d yt = gather_rows_store<R>(tw, tc, Mp, J, g, j);       // Y_k^T
+                        const v4d get = gather_rows_store<R>(tw, tc, Ep, J, g, j);      // (G_k E)^T
+                        const v4d lin = hc1 * yt, qd = hc2 * (get + TY[J]);
+                        lo[J] = lin - qd;
+                        hi[J] = lin + qd;
+                    }
+                    store_T32_columns(pUa, merge_rows32(lo[0], lo[1]), 0, g, j);        // whole 256-byte columns per piece
+                    store_T32_columns(paU, merge_rows32(hi[0], hi[1]), 0, g, j);
+                }
+                if (t == 0) QC_STAMP(P, b, lane, 6);
             }
         }
-        wave_sum_multi<1 + kPairsPerWave>(pv);
-        if (lane == 0) {
-            if (ft) Hb[P.ho_ah + w] = pv[0];
+        if constexpr (HESS) {
+            // the (a_k, h) of this wave's drives and its share of the pair sums: one batched reduction
+            flag_wait(flags, FL_Q, 1);
+            if constexpr (kPrefetchPairs) {
 #pragma unroll
-            for (int t = 0; t < kPairsPerWave; ++t) {
-                const int p = w + m * t;
-                if (p < npairs) Hb[P.ho_aa + p] = hc2 * pv[1 + t];
+                for (int t = 0; t < kPairsPerWave; ++t) pv[kDrivesPerWave + t] = pwv[t] * Qp[pov[t]];
+            } else {
+                const double* __restrict__ pw = reinterpret_cast<const double*>(hot_ell + lay.pw);
+                const int* __restrict__ po = reinterpret_cast<const int*>(hot_ell + lay.po);
+#pragma unroll
+                for (int t = 0; t < kPairsPerWave; ++t) {
+                    const int p = cw + kCW * t;              // pairs dealt round-robin over the compute waves
+                    double acc = 0.0;
+                    if (p < npairs) {
+#pragma unroll
+                        for (int e = 0; e < L / 64; ++e) acc += pw[(size_t)p * L + 64 * e + lane] * Qp[po[(size_t)p * L + 64 * e + lane]];
+                    }
+                    pv[kDrivesPerWave + t] = acc;
+                }
+            }
+            wave_sum_multi<kDrivesPerWave + kPairsPerWave>(pv);
+            if (lane == 0) {
+#pragma unroll
+                for (int t = 0; t < kDrivesPerWave; ++t) {
+                    const int k = cw + kCW * t;
+                    if (ft && k < m) Hb[P.ho_ah + k] = pv[t];
+                }
+#pragma unroll
+                for (int t = 0; t < kPairsPerWave; ++t) {
+                    const int p = cw + kCW * t;
+                    if (p < npairs) Hb[P.ho_aa + p] = hc2 * pv[kDrivesPerWave + t];
+                }
             }
         }
-    }
-    QC_STAMP(P, b, lane, 6);
-    if (ft) {
-        if (w < 2) {                  // (U_t, h)^T and (h, U_t+1)^T, column block J = w
-            const int J = w;
-            const v4d ge = gyT_tile(GL, J, lane, tile_ld(ET, 0, lane), tile_ld(ET, 1, lane));     // (G E)^T[J]
-            v4d et;                                                                                // E^T[J]
+        // ---- the shared blocks ---------------------------------------------------------------------------------------------------
+        if (JAC && cw == kCW - 1) {       // residual and d/dh: D - hc1 G S + hc2 G (G D);  -c1 G S + 2 c2 h G (G D)
+            flag_wait(flags, FL_GD, 1);
+            const v4d gd0 = plain_ld(GDp, 0, g, j), gd1 = plain_ld(GDp, 1, g, j);
+            const v4d s0 = plain_ld(Sp, 0, g, j), s1 = plain_ld(Sp, 1, g, j);
+            v4d res[2], dh[2];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) et[r] = Ep[(16 * J + j) * kPS + 4 * r + g];
-            store_T32(Hb + P.ho_Uh, c1 * et - c2h2 * ge, J, g, j);
-            store_T32(Hb + P.ho_hU, c1 * et + c2h2 * ge, J, g, j);
-        } else if (w == 2) {          // (h, h)
-            double s[1] = {dot4(tile_ld(ET, 0, lane), tile_ld(GDT, 0, lane)) + dot4(tile_ld(ET, 1, lane), tile_ld(GDT, 1, lane))};
-            wave_sum_multi<1>(s);
-            if (lane == 0) Hb[P.ho_hh] = -2.0 * c2 * s[0];
+            for (int J = 0; J < 2; ++J) {
+                const v4d gs = gyT_tile(GL, J, lane, s0, s1);                   // (G S)^T[J]
+                const v4d ggd = gyT_tile(GL, J, lane, gd0, gd1);                // (G (G D))^T[J]
+                res[J] = plain_ld_T(Dp, J, g, j) - hc1 * gs + hc2 * ggd;        // D^T[J] - ...
+                dh[J] = (-c1) * gs + c2h2 * ggd;
+            }
+            if (Fb) store_T32_columns(Fb, merge_rows32(res[0], res[1]), 0, g, j);
+            if (ft && !f_only) store_T32_columns(Jb + P.jo_h, merge_rows32(dh[0], dh[1]), 0, g, j);
         }
-    }
-    if (w == 5) qc_hess_tail(Pk, mu, Hb, lane, 64);     // derivative integrators' (dx, h) entries and the alignment padding
-    if constexpr (DIAG) {
+        if (HESS && ft && cw == kCW - 4) {    // (U_t, h)^T and (h, U_t+1)^T: c1 E -+ 2 c2 h G E
+            const v4d e0 = plain_ld(Ep, 0, g, j), e1 = plain_ld(Ep, 1, g, j);
+            v4d lo[2], hi[2];
+#pragma unroll
+            for (int J = 0; J < 2; ++J) {
+                const v4d ge = gyT_tile(GL, J, lane, e0, e1);                   // (G E)^T[J]
+                const v4d et = plain_ld_T(Ep, J, g, j);                         // E^T[J]
+                lo[J] = c1 * et - c2h2 * ge;
+                hi[J] = c1 * et + c2h2 * ge;
+            }
+            store_T32_columns(Hb + P.ho_Uh, merge_rows32(lo[0], lo[1]), 0, g, j);
+            store_T32_columns(Hb + P.ho_hU, merge_rows32(hi[0], hi[1]), 0, g, j);
+        }
+        if (HESS && ft && cw == kCW - 3) {    // (h, h) = -2 c2 <E, G D>
+            flag_wait(flags, FL_GD, 1);
+            flag_wait(flags, FL_E, 1);
+            double s1[1] = {dot4(plain_ld(Ep, 0, g, j), plain_ld(GDp, 0, g, j)) + dot4(plain_ld(Ep, 1, g, j), plain_ld(GDp, 1, g, j))};
+            wave_sum_multi<1>(s1);
+            if (lane == 0) Hb[P.ho_hh] = -2.0 * c2 * s1[0];
+        }
+        if (HESS && cw == 0) {            // derivative integrators' (dx, h) entries and the alignment padding
+            if (dfast) {
+                int o = P.ho_d;
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    if (lane < P.ddim_i[d]) Hb[o + lane] = -mud[d];
+                    o += P.ddim_i[d];
+                }
+                for (int i = lane; i < P.h_pad; i += 64) Hb[P.hess_nnz + i] = 0.0;
+            } else {
+                qc_hess_tail(Pk, mu, Hb, lane, 64);
+            }
+        }
+        if (JAC && cw == 1) deriv_rows_generic(P, z0, z1, h, Fb, Jb, lane, false);   // derivative-integrator rows and their Jacobian entries
         QC_STAMP(P, b, lane, 7);
-        if (P.stamps != nullptr && lane == 0 && (w == 0 || w == 5)) {   // slots 0-7: wave 0, 8-15: wave 5
+    }
+    if constexpr (DIAG) {
+        // slots 0-7: the first compute wave; 8-15: wave 0 of a JAC instantiation (copy wave), else the last compute wave
+        const bool first = cw == 0, second = JAC ? w == 0 : w == 7;
+        if (P.stamps != nullptr && lane == 0 && (first || second)) {
 #pragma unroll
-            for (int k_ = 0; k_ < 8; ++k_) P.stamps[(size_t)b * 16 + (w == 0 ? 0 : 8) + k_] = qc_ts_[k_];
+            for (int k_ = 0; k_ < 8; ++k_) P.stamps[(size_t)b * 16 + (first ? 0 : 8) + k_] = qc_ts_[k_];
         }
     }
 }
@@ -451,7 +668,8 @@ int qc_mfma32_ell_build(const QcParams& P, const double* G, std::vector<char>* b
             for (int k = 0; k < m; ++k) cnt += Gk(k, a, c) != 0.0;
             slots = std::max(slots, cnt);
         }
-    if (slots > kMaxSlots) slots = 0;                    // the kernel assembles G from the dense images then
+    if (slots > kMaxSlots) return 0;                     // (e.g. five diagonal drives: the dense-image kernels serve the handle)
+    slots = slots <= 1 ? 1 : (slots <= 2 ? 2 : 4);      // the instantiated plan depths; unused slots carry weight 0
     const EllLayout lay = ell_layout(m, R, L, slots);
     blob->assign(lay.bytes, 0);
     double* tw = reinterpret_cast<double*>(blob->data() + lay.tw);
@@ -478,7 +696,7 @@ int qc_mfma32_ell_build(const QcParams& P, const double* G, std::vector<char>* b
             pw[(size_t)p * L + e] = lists[p][e].second;
         }
     // assembly plan in the order of the A-layout image (qc_mfma32_pack_G): entry [tile = 2 I + K][pair][lane = 16 g + i][e] = X[16 I + i][16 K + 4 (2 pair + e) + g]
-    for (int tile = 0; tile < 4 && slots > 0; ++tile)
+    for (int tile = 0; tile < 4; ++tile)
         for (int pr = 0; pr < 2; ++pr)
             for (int l = 0; l < 64; ++l)
                 for (int e = 0; e < 2; ++e) {
@@ -493,15 +711,34 @@ int qc_mfma32_ell_build(const QcParams& P, const double* G, std::vector<char>* b
     return R;
 }
 
+#define QC_ELL_ARGS(F_, J_, H_) P.Gx, dZ + P.t_begin * (long long)P.zdim, dMu ? dMu + P.t_begin * P.F_stride + P.F_off : nullptr, (const char*)P.ell, \
+                    P.n_int, P.zdim, P.m, P.off_a, P.off_dt, P.off_U, (int)P.F_stride, P.ell_slots, P, F_, J_, H_
+#define QC_ELL_GO(R_, JAC_, HESS_, DIAG_, S_, F_, J_, H_) \
+    hipLaunchKernelGGL((qc_mfma32_ell_kernel<R_, JAC_, HESS_, DIAG_, S_>), dim3(P.n_int), dim3(kEThreads), 0, st, QC_ELL_ARGS(F_, J_, H_))
+#define QC_ELL_LAUNCH(JAC_, HESS_, F_, J_, H_)                                                                                    \
+    do {                                                                                                                          \
+        const int S = P.ell_slots;                                                                                                \
+        if (P.stamps != nullptr && P.ell_R == 1 && S == 1) QC_ELL_GO(1, JAC_, HESS_, true, 1, F_, J_, H_);   /* diagnostic timeline */ \
+        else if (P.ell_R == 1 && S == 1) QC_ELL_GO(1, JAC_, HESS_, false, 1, F_, J_, H_);                                         \
+        else if (P.ell_R == 1 && S == 2) QC_ELL_GO(1, JAC_, HESS_, false, 2, F_, J_, H_);                                         \
+        else if (P.ell_R == 1) QC_ELL_GO(1, JAC_, HESS_, false, 4, F_, J_, H_);                                                   \
+        else if (S == 1) QC_ELL_GO(2, JAC_, HESS_, false, 1, F_, J_, H_);                                                         \
+        else if (S == 2) QC_ELL_GO(2, JAC_, HESS_, false, 2, F_, J_, H_);                                                         \
+        else QC_ELL_GO(2, JAC_, HESS_, false, 4, F_, J_, H_);                                                                     \
+    } while (0)
+
 hipError_t qc_launch_mfma32_ell_hess(const QcParams& P, const double* dZ, const double* dMu, double* dH, hipStream_t st) {
-    const int grid = P.n_int;
-#define QC_ELL_ARGS P.Gx, dZ + P.t_begin * (long long)P.zdim, dMu + P.t_begin * P.F_stride + P.F_off, (const char*)P.ell, P.n_int, P.zdim, P.m, \
-                    P.off_a, P.off_dt, P.off_U, (int)P.F_stride, P.ell_slots, P, dH
-    if (P.stamps != nullptr) {
-        if (P.ell_R == 1) hipLaunchKernelGGL((qc_mfma32_ell_hess_kernel<1, true>), dim3(grid), dim3(kEThreads), 0, st, QC_ELL_ARGS);
-        else hipLaunchKernelGGL((qc_mfma32_ell_hess_kernel<2, true>), dim3(grid), dim3(kEThreads), 0, st, QC_ELL_ARGS);
-    } else if (P.ell_R == 1) hipLaunchKernelGGL((qc_mfma32_ell_hess_kernel<1, false>), dim3(grid), dim3(kEThreads), 0, st, QC_ELL_ARGS);
-    else hipLaunchKernelGGL((qc_mfma32_ell_hess_kernel<2, false>), dim3(grid), dim3(kEThreads), 0, st, QC_ELL_ARGS);
-#undef QC_ELL_ARGS
+    QC_ELL_LAUNCH(false, true, nullptr, nullptr, dH);
+    return hipGetLastError();
+}
+// F + dF, or the residuals alone (dJ == NULL): the same instantiation, so the residuals are the same to the bit
+hipError_t qc_launch_mfma32_ell_F_jac(const QcParams& P, const double* dZ, double* dF, double* dJ, hipStream_t st) {
+    const double* dMu = nullptr;
+    QC_ELL_LAUNCH(true, false, dF, dJ, nullptr);
+    return hipGetLastError();
+}
+// F + dF + mu_d2F in one launch
+hipError_t qc_launch_mfma32_ell_fused(const QcParams& P, const double* dZ, const double* dMu, double* dF, double* dJ, double* dH, hipStream_t st) {
+    QC_ELL_LAUNCH(true, true, dF, dJ, dH);
     return hipGetLastError();
 }

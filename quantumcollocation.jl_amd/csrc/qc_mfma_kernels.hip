@@ -652,7 +652,12 @@ hipError_t qc_launch_mfma_F_jac(const QcParams& P, const double* dZ, double* dF,
     if (P.integrator == QC_EXPONENTIAL) return P.n > 16 ? qc_launch_mfma32_exp(P, dZ, dF, dJ, st) : qc_launch_mfma_exp(P, dZ, dF, dJ, st);
     if (qc_mfma16_padeP_supported(P)) return qc_launch_mfma16_padeP(P, dZ, dF, dJ, st);
     if (P.n > 32) return qc_launch_mfma64_F_jac(P, dZ, dF, dJ, st);
-    if (P.n > 16) return qc_launch_mfma32_F_jac(P, dZ, dF, dJ, st);
+    if (P.n > 16) {
+        // sparse drive generators: the row-gather kernel (qc_mfma32_ell.hip; QC_ELL_JAC=0: the dense-image kernel, for A/B runs);
+        static const bool ell_jac = !(getenv("QC_ELL_JAC") && atoi(getenv("QC_ELL_JAC")) == 0);
+        if (P.ell && ell_jac && P.n == 32 && P.nc == 16) return qc_launch_mfma32_ell_F_jac(P, dZ, dF, dJ, st);
+        return qc_launch_mfma32_F_jac(P, dZ, dF, dJ, st);
+    }
     const int n_wg = dJ ? (P.n_int + kIntervalsPerWG - 1) / kIntervalsPerWG : P.n_int;
     const int grid = n_wg < kMaxGrid ? n_wg : kMaxGrid;
     const bool diag = P.stamps != nullptr || P.dbg_skip != 0;

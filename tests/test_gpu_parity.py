@@ -734,14 +734,14 @@ def test_mfma32_hessian_variants(qc, oracle, m, free_time, layout, hermitian):
 
 @pytest.mark.parametrize("R,m,free_time,layout,T,dense_drift", [(1, 8, True, "standard", 5, True), (1, 3, False, "shuffled", 4, True), (1, 1, True, "shuffled", 2, False),
                                                                  (1, 6, True, "standard", 300, True), (2, 4, True, "standard", 6, True),
-                                                                 (2, 8, True, "shuffled", 3, True), (2, 7, False, "standard", 5, False), (1, 6, True, "standard", 7, True)])
+                                                                 (2, 8, True, "shuffled", 3, True), (2, 7, False, "standard", 5, False), (1, 4, True, "standard", 7, True)])
 def test_sparse_drive_hessian_kernel(qc, oracle, monkeypatch, R, m, free_time, layout, T, dense_drift):
     """Drive generators with at most two entries per row (Pauli strings, ladder pairs) at 2N = 32 take the row-gather kernel
     (qc_mfma32_ell.hip: `mfma32-pade4-hess-ell`): against the oracle, against the dense-image kernel of the same handle shape
     (QC_NO_ELL=1), and bit-reproducible."""
-    # (the last case: six diagonal drives touch the same entries of G -- more than the sparse assembly plan holds: G comes from the dense images)
+    # (the last case: four diagonal drives touch the same entries of G: the deepest assembly plan)
     prob, Z = sparse_drive_problem(oracle, m=m, T=T, R=R, free_time=free_time, layout=layout, seed=31 * m + R, dense_drift=dense_drift,
-                                   kinds=("diag",) if (R, m, T) == (1, 6, 7) else ("real", "imag", "diag"))
+                                   kinds=("diag",) if (R, m, T) == (1, 4, 7) else ("real", "imag", "diag"))
     h = RawHandle(qc, prob, kernel="mfma")
     assert qc._lib.lib.qc_kernel_name(h.h, 1) == b"mfma32-pade4-hess-ell"
     monkeypatch.setenv("QC_NO_ELL", "1")
@@ -754,12 +754,47 @@ def test_sparse_drive_hessian_kernel(qc, oracle, monkeypatch, R, m, free_time, l
             assert_close_h(H, oracle.mu_d2F(prob, Z, mu), "mfma32 ell hess vs oracle")
         assert_close_h(H, hd.hess(Z, mu), "mfma32 ell hess vs the dense-image kernel")
         assert np.array_equal(H, h.hess(Z, mu))
+    # F + dF by the same kernel family (`mfma32-pade4-ell`): the compact form of the host path, then the full value vector
+    assert qc._lib.lib.qc_kernel_name(h.h, 0) == b"mfma32-pade4-ell" and qc._lib.lib.qc_kernel_name(hd.h, 0) == b"mfma32-pade4"
+    F, J = h.F_jac(Z)
+    Fd, Jd = hd.F_jac(Z)
+    if T <= 8:
+        assert_close(F, oracle.F(prob, Z), "mfma32 ell F vs oracle")
+        assert_close(J, oracle.dF(prob, Z), "mfma32 ell dF vs oracle")
+    assert_close(F, Fd, "mfma32 ell F vs the dense-image kernel")
+    assert_close(J, Jd, "mfma32 ell dF vs the dense-image kernel")
+    assert np.array_equal(F, h.F(Z))                  # the residual-only launch: the same residuals to the bit
+    monkeypatch.setenv("QC_HOST_COMPACT", "0")
+    hf = RawHandle(qc, prob, kernel="mfma")
+    monkeypatch.delenv("QC_HOST_COMPACT")
+    F2, J2 = hf.F_jac(Z)
+    assert np.array_equal(F2, F) and np.array_equal(J2, J)
+    # ... and all three in one launch (`mfma32-pade4-fused-ell`), device-resident: the same bits as the two launches
+    assert qc._lib.lib.qc_kernel_name(h.h, 2) == b"mfma32-pade4-fused-ell"
+    import ctypes as C
+    mu = np.random.default_rng(m).standard_normal(prob.n_rows)
+    H = h.hess(Z, mu)
+    dZ, dmu = torch.from_numpy(Z).cuda(), torch.from_numpy(mu).cuda()
+    new = lambda n: torch.full((int(n),), float("nan"), dtype=torch.float64, device="cuda")
+    dF, dJ, dH = new(h.dims.F_len), new(h.dims.jac_nnz), new(h.dims.hess_nnz)
+    ptr = lambda t: C.c_void_p(t.data_ptr())
+    qc._lib.check(qc._lib.lib.qc_eval_F_jac_hess_dev(h.h, ptr(dZ), ptr(dmu), ptr(dF), ptr(dJ), ptr(dH), C.c_void_p(torch.cuda.current_stream().cuda_stream)), h.h)
+    torch.cuda.synchronize()
+    assert np.array_equal(dJ.cpu().numpy(), J) and np.array_equal(dH.cpu().numpy(), H)
+    assert_close(dF.cpu().numpy(), F, "one-call residuals")
     h.close()
     hd.close()
+    hf.close()
 
 
 def test_dense_drives_keep_the_dense_image_kernel(qc, oracle):
-    """Three entries in one generator row, or a non-Hermitian Hamiltonian, and the handle stays with qc_mfma32_hess.hip."""
+    """Three entries in one generator row, or five drives on the same entries of G, and the handle stays with qc_mfma32_hess.hip."""
+    prob, Z = sparse_drive_problem(oracle, m=5, T=3, R=1, seed=9, kinds=("diag",))
+    h = RawHandle(qc, prob, kernel="mfma")
+    assert qc._lib.lib.qc_kernel_name(h.h, 1) == b"mfma32-pade4-hess" and qc._lib.lib.qc_kernel_name(h.h, 0) == b"mfma32-pade4"
+    mu = np.random.default_rng(2).standard_normal(prob.n_rows)
+    assert_close_h(h.hess(Z, mu), oracle.mu_d2F(prob, Z, mu), "dense fallback, five diagonal drives")
+    h.close()
     prob, Z = sparse_drive_problem(oracle, m=3, T=3, R=2, seed=5)
     prob.G_drives[1][3, :] = 0.0
     prob.G_drives[1][:, 3] = 0.0
@@ -910,11 +945,12 @@ def test_fused_launch_is_bit_identical(qc, case):
         herm = lambda: (lambda A: (A + A.conj().T) / 2)(rng.standard_normal((8, 8)) + 1j * rng.standard_normal((8, 8)))
         inp = qc.unitary_smooth_pulse_inputs(qc.QuantumSystem(herm(), [herm() for _ in range(m)]), qc.GATES["TOFFOLI"], 31)
     elif case == "cfg5":
-        inp, fused_expected = qc.config_inputs(5, T=20), False
+        inp, fused_expected = qc.config_inputs(5, T=20), "mfma32-pade4-fused-ell"      # Pauli drives: the row-gather kernels (qc_mfma32_ell.hip)
     else:
         inp, fused_expected = qc.config_inputs(1, T=50), False
     dyn = qc.QuantumDynamics(inp.integrators, inp.traj)
-    assert (dyn.fused_kernel_name == "mfma16-pade4-fused") == fused_expected, dyn.fused_kernel_name
+    want = {True: "mfma16-pade4-fused", False: "two-launches"}.get(fused_expected, fused_expected)
+    assert dyn.fused_kernel_name == want, dyn.fused_kernel_name
     rng = np.random.default_rng(1)
     Z = torch.from_numpy(inp.traj.datavec + 1e-2 * rng.standard_normal(inp.traj.datavec.size)).cuda()
     mu = torch.from_numpy(rng.standard_normal(int(dyn.dims.n_rows))).cuda()
@@ -1005,8 +1041,8 @@ def test_new_x_elision_and_unaligned_buffers(qc, cfg, T):
     Z1 = inp.traj.datavec.copy()
     Z2 = Z1 + 1e-2 * rng.standard_normal(Z1.size)
     mu = rng.standard_normal(int(dyn.dims.n_rows))
-    ref1 = (dyn.F(Z1), dyn.dF(Z1), dyn.mu_d2F(Z1, mu))
-    ref2 = (dyn.F(Z2), dyn.dF(Z2), dyn.mu_d2F(Z2, mu))
+    ref1 = (dyn.F(Z1, fresh=True), dyn.dF(Z1, fresh=True), dyn.mu_d2F(Z1, mu, fresh=True))     # (held across many calls of the same closures:
+    ref2 = (dyn.F(Z2, fresh=True), dyn.dF(Z2, fresh=True), dyn.mu_d2F(Z2, mu, fresh=True))     #  not the ring's vectors)
     assert not np.array_equal(ref1[1], ref2[1])
     # Ipopt's order: residuals at a new x, then Jacobian and Hessian with new_x = false -- Z is not read
     garbage = np.full(Z1.size, np.nan)
@@ -1498,7 +1534,7 @@ def test_any_order_mfma_kernel_matches_oracle(qc, oracle, order, N, m, ncol, fre
 def test_kernel_names_of_the_baseline_configurations(qc):
     """Which device kernels serve BASELINE.json's configurations (qc_kernel_name): the tuned MFMA kernels, not a generic path."""
     expect = {1: ("mfma16-pade4", "mfma16-pade4-hess"), 2: ("mfma16-pade4", "mfma16-pade4-hess"),
-              3: ("mfma16-pade4", "mfma16-pade4-hess2"), 5: ("mfma32-pade4", "mfma32-pade4-hess-ell")}     # (hess2: two waves per interval, <= 1024 intervals; ell: Pauli drives are row gathers)
+              3: ("mfma16-pade4", "mfma16-pade4-hess2"), 5: ("mfma32-pade4-ell", "mfma32-pade4-hess-ell")}     # (hess2: two waves per interval, <= 1024 intervals; ell: Pauli drives are row gathers)
     for cfg, names in expect.items():
         inp = qc.config_inputs(cfg, T=5)
         dyn = qc.QuantumDynamics(inp.integrators, inp.traj)
@@ -1603,7 +1639,7 @@ def test_config5_callback_set_on_one_stream(qc, oracle):
     integ = [qc.UnitaryPadeIntegrator("Ũ⃗", "a", inp.system, traj, order=4), qc.DerivativeIntegrator("a", "da", traj),
              qc.DerivativeIntegrator("da", "dda", traj)]
     dyn = qc.QuantumDynamics(integ, traj)
-    assert dyn.kernel_names == ("mfma32-pade4", "mfma32-pade4-hess-ell") and dyn.dims.n_cols == traj.dim * T + 4
+    assert dyn.kernel_names == ("mfma32-pade4-ell", "mfma32-pade4-hess-ell") and dyn.dims.n_cols == traj.dim * T + 4
     con = qc.FinalUnitaryFreePhaseFidelityConstraint("Ũ⃗", "ϕ", phase_ops, 0.99, traj)
     terms = qc.TrajectoryObjective(qc.QuadraticRegularizer("a", traj, 1e-2) + qc.QuadraticRegularizer("da", traj, 1e-2)
                                    + qc.QuadraticRegularizer("dda", traj, 1e-2) + qc.MinimumTimeObjective(traj, 1.0), traj)
