@@ -207,6 +207,15 @@ def host_visible_times(dyn, Zs, reps=30):
 
     out["ipopt_sequence_ms"] = timed(sequence, "ipopt_sequence_ms")
     dyn.set_new_x(True)
+    # the residual-only call into an array the caller has announced once (qc_host_register; what the bindings do for the vectors their
+    # closures hand out and an evaluator for its residual cache): the kernel writes it in place, no device-to-host copy, no pinning
+    Fr = np.zeros(int(dims.F_len))
+    if hasattr(dyn, "register_host") and dyn.register_host(Fr):
+        cFr = [dyn.bind_host("F", Z, F=Fr) for Z in Zs]
+        out["F_registered_ms"] = timed(lambda i: run(cFr[i % nz]), "F_registered_ms")
+        run(cF[0])
+        run(cFr[0])
+        assert np.array_equal(Fr, Fh), "registered and plain residual arrays differ"
     out["fastest_call_ms"] = dict(mins)
     assert status[0] == 0, "a host-buffer call reported an error"
     # The reference-shaped closures: dynamics.F(Z) / dF(Z) / mu_d2F(Z, mu) RETURN a vector (integrator_test_1qubit.jl:45-52), which is

@@ -76,7 +76,16 @@ struct ResultRing
     bufs::Vector{Vector{Float64}}
     next::Base.RefValue{Int}
 end
-ResultRing(len::Integer, n::Integer) = ResultRing([zeros(Float64, len) for _ in 1:n], Ref(1))
+function ResultRing(len::Integer, n::Integer)
+    bufs = [zeros(Float64, len) for _ in 1:n]
+    # the ring's vectors live as long as the evaluator: pinned once (`qc_host_register`), so that `F` has the kernel write into them in
+    # place and the other closures' copies skip the per-call pinning; `unregister!` runs in the evaluator's finalizer, before `qc_destroy`
+    for v in bufs
+        len > 0 && ccall((:qc_host_register, LIB[]), Cint, (Ptr{Cvoid}, Int64), pointer(v), sizeof(v))      # (failure = not pinned: harmless)
+    end
+    return ResultRing(bufs, Ref(1))
+end
+unregister!(r::ResultRing) = foreach(v -> isempty(v) || ccall((:qc_host_unregister, LIB[]), Cint, (Ptr{Cvoid},), pointer(v)), r.bufs)
 function next!(r::ResultRing, len::Integer, fresh::Bool)
     (fresh || isempty(r.bufs)) && return Vector{Float64}(undef, len)
     v = r.bufs[r.next[]]
@@ -184,7 +193,7 @@ function dynamics(integrators, traj, system; device::Int=0, devices=nothing, eva
     ringF = ResultRing(d.F_len, result_ring); ring∂F = ResultRing(d.jac_nnz, result_ring)
     F = (Z⃗; fresh::Bool=false) -> F!(next!(ringF, d.F_len, fresh), Z⃗)
     ∂F = (Z⃗; fresh::Bool=false) -> ∂F!(next!(ring∂F, d.jac_nnz, fresh), Z⃗)
-    μ∂²F = nothing; μ∂²F! = nothing; μ∂²F_structure = nothing
+    μ∂²F = nothing; μ∂²F! = nothing; μ∂²F_structure = nothing; ringH = ResultRing(0, 0)
     if eval_hessian && d.hess_nnz > 0
         hr = Vector{Int64}(undef, d.hess_nnz); hc = similar(hr)
         check(ccall((:qc_hess_structure, LIB[]), Cint, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}, Cint), h[], hr, hc, 1), h[])
@@ -201,7 +210,11 @@ function dynamics(integrators, traj, system; device::Int=0, devices=nothing, eva
         μ∂²F = (Z⃗, μ⃗; fresh::Bool=false) -> μ∂²F!(next!(ringH, d.hess_nnz, fresh), Z⃗, μ⃗)
     end
     dyn = HIPDynamics(h[], d, F, ∂F, ∂F_structure, μ∂²F, μ∂²F_structure, Int(bycomp ? traj.dims.states : d.ddim), F!, ∂F!, μ∂²F!)
-    finalizer(x -> ccall((:qc_destroy, LIB[]), Cvoid, (Ptr{Cvoid},), x.handle), dyn)
+    rings = isnothing(μ∂²F) ? (ringF, ring∂F) : (ringF, ring∂F, ringH)
+    finalizer(dyn) do x
+        foreach(unregister!, rings)
+        ccall((:qc_destroy, LIB[]), Cvoid, (Ptr{Cvoid},), x.handle)
+    end
     return dyn
 end
 

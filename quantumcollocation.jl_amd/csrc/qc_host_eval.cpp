@@ -613,6 +613,52 @@ static void pool_memcpy(double* dst, const double* src, size_t n, int workers) {
     grp.wait();
 }
 
+// ------------------------------------------------------------------------------------------------
+//  Registered caller arrays (qc_host_register)
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct HostRange { char* base; size_t bytes; };
+std::mutex g_reg_mu;
+std::vector<HostRange> g_reg;
+// the registered range that holds [p, p + bytes), as a device pointer of the CURRENT device; nullptr when there is none
+double* registered_device_ptr(const void* p, size_t bytes) {
+    const char* q = static_cast<const char*>(p);
+    bool found = false;
+    {
+        std::lock_guard<std::mutex> lk(g_reg_mu);
+        for (const HostRange& r : g_reg) found = found || (q >= r.base && q + bytes <= r.base + r.bytes);
+    }
+    if (!found) return nullptr;
+    void* d = nullptr;
+    if (hipHostGetDevicePointer(&d, const_cast<void*>(p), 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return static_cast<double*>(d);
+}
+}  // namespace
+
+extern "C" int qc_host_register(void* p, int64_t bytes) {
+    if (!p || bytes <= 0) return fail(nullptr, QC_ERR_INVALID, "qc_host_register: NULL or empty range");
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    for (const HostRange& r : g_reg)
+        if (static_cast<char*>(p) < r.base + r.bytes && r.base < static_cast<char*>(p) + bytes)
+            return fail(nullptr, QC_ERR_INVALID, "qc_host_register: the range overlaps a registered one");
+    const hipError_t e = hipHostRegister(p, (size_t)bytes, hipHostRegisterPortable | hipHostRegisterMapped);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(nullptr, QC_ERR_HIP, std::string("hipHostRegister: ") + hipGetErrorString(e)); }
+    g_reg.push_back(HostRange{static_cast<char*>(p), (size_t)bytes});
+    return QC_OK;
+}
+
+extern "C" int qc_host_unregister(void* p) {
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    for (size_t i = 0; i < g_reg.size(); ++i) {
+        if (g_reg[i].base != static_cast<char*>(p)) continue;
+        g_reg.erase(g_reg.begin() + (long)i);
+        const hipError_t e = hipHostUnregister(p);
+        if (e != hipSuccess) { (void)hipGetLastError(); return fail(nullptr, QC_ERR_HIP, std::string("hipHostUnregister: ") + hipGetErrorString(e)); }
+        return QC_OK;
+    }
+    return fail(nullptr, QC_ERR_INVALID, "qc_host_unregister: not the start of a registered range");
+}
+
 extern "C" int qc_set_new_x(qc_handle* h, int new_x) {
     if (!h) return fail(nullptr, QC_ERR_INVALID, "qc_set_new_x: NULL handle");
     h->new_x = new_x ? 1 : 0;
@@ -943,6 +989,17 @@ static int eval_host(qc_handle* h, const double* Z, double* F, double* vals, int
     if (!vals) {
         // residuals only (a line-search trial): kernel -> HBM -> one copy into the caller's array.  (Rows no kernel writes --
         // QC_ROWS_BY_COMPONENT -- stay zero in the device vector.)
+        // A registered array (qc_host_register) takes the residuals straight from the kernel: no device-to-host copy, no pinning
+        // (QC_HOST_F_DIRECT=0: the copy, for A/B runs).  Not where the layout has rows no kernel writes: the copy delivers their zeros.
+        static const bool f_direct = !(getenv("QC_HOST_F_DIRECT") && atoi(getenv("QC_HOST_F_DIRECT")) == 0);
+        const bool rows_all_written = P.F_stride == P.ddim && P.F_off == 0;
+        if (double* Fdev = (f_direct && rows_all_written) ? registered_device_ptr(F, (size_t)h->dims.F_len * sizeof(double)) : nullptr) {
+            if ((rc = qc_eval_F_jac_dev(h, h->dZ, Fdev, nullptr, h->stream))) return rc;
+            QC_HIP(h, hipEventRecord(h->ev_done, h->stream));
+            rc = wait_done(h, shards);
+            if (host_trace()) fprintf(stderr, "qcolloc host trace (residuals only, written in place): done +%.0f us\n", now_us() - t_begin);
+            return rc;
+        }
         if ((rc = ensure_zeroed(h, &h->dF, (size_t)h->dims.F_len))) return rc;
         if ((rc = qc_eval_F_jac_dev(h, h->dZ, h->dF, nullptr, h->stream))) return rc;
         QC_HIP(h, hipMemcpyAsync(F, h->dF, (size_t)h->dims.F_len * sizeof(double), hipMemcpyDeviceToHost, h->stream));

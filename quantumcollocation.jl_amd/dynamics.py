@@ -229,10 +229,16 @@ class QuantumDynamics:
         self._structs = None
 
     # -- lifetime --------------------------------------------------------------------------------
+    def _unregister_all(self):
+        for arr in getattr(self, "_registered", []):
+            _lib.lib.qc_host_unregister(C.c_void_p(arr.ctypes.data))
+        self._registered = []
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
             _lib.lib.qc_destroy(self._h)
             self._h = None
+        self._unregister_all()
 
     def __del__(self):
         try:
@@ -306,6 +312,18 @@ class QuantumDynamics:
             raise ValueError("result_ring must be 0 (fresh vectors) or at least 3 (the previous two results of a closure stay intact)")
         self.result_ring = int(result_ring)
         self._rings = {}           # closure slot -> [next index, [vectors]]
+        self._registered = []      # arrays announced to the library (qc_host_register): unregistered by close()
+
+    def register_host(self, arr: np.ndarray) -> bool:
+        """Announce a long-lived float64 array to the library (qc_host_register): pinned once instead of per call; `F(Z, out=arr)`
+        then has the kernel write the residuals into it in place (no device-to-host copy).  The array must stay alive until `close()`
+        (this object keeps a reference).  Returns False where registration is not possible (no GPU, overlapping range)."""
+        if not (isinstance(arr, np.ndarray) and arr.dtype == np.float64 and arr.flags.c_contiguous and arr.size):
+            raise ValueError("register_host takes a non-empty contiguous float64 array")
+        if _lib.lib.qc_host_register(C.c_void_p(arr.ctypes.data), arr.nbytes) != 0:
+            return False
+        self._registered.append(arr)
+        return True
 
     def _out(self, name: str, n: int, out: Optional[np.ndarray] = None, fresh: bool = False, slot: Optional[str] = None) -> np.ndarray:
         """Result array of `n` doubles: the caller's `out`; else (fresh=True, or no ring) a newly allocated array; else the next
@@ -320,6 +338,9 @@ class QuantumDynamics:
         ring = self._rings.get(slot or name)
         if ring is None:
             ring = self._rings[slot or name] = [0, [np.zeros(n) for _ in range(self.result_ring)]]
+            if hasattr(self, "_h") or hasattr(self, "_parts"):       # (a live evaluator: the vectors are this object's, so it may pin them)
+                for v in ring[1]:
+                    QuantumDynamics.register_host(self, v)
         i = ring[0]
         ring[0] = (i + 1) % self.result_ring
         return ring[1][i]
@@ -533,6 +554,7 @@ class ComposedQuantumDynamics(QuantumDynamics):
             if h:
                 _lib.lib.qc_destroy(h)
         self._parts = []
+        self._unregister_all()
 
     def _structure(self, one_based=False):
         n_int = int(self.dims.n_intervals)

@@ -72,6 +72,59 @@ def test_closure_results_stay_intact_for_two_more_calls(qc, oracle, cfg, T):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cfg,T,devices", [(1, 20, None), (3, 300, None), (5, 9, None), (3, 300, [0, 0, 0])])
+def test_registered_arrays_take_the_residuals_in_place(qc, oracle, cfg, T, devices):
+    """qc_host_register: an array announced once is written by the residual kernel directly (no device-to-host copy); same bits as
+    the copy into an ordinary array; a slice of a registered array counts; unregistering restores the copy; a layout with rows no kernel
+    writes keeps the copy (its zeros must be delivered)."""
+    import ctypes as C
+    L = qc._lib
+    inp = qc.config_inputs(cfg, T=T)
+    dyn = qc.QuantumDynamics(inp.integrators, inp.traj, devices=devices, result_ring=0)
+    rng = np.random.default_rng(cfg)
+    Z = inp.traj.datavec + 1e-2 * rng.standard_normal(inp.traj.datavec.size)
+    n = int(dyn.dims.F_len)
+    plain = dyn.F(Z, out=np.full(n, np.nan))
+    big = np.full(n + 64, np.nan)
+    assert L.lib.qc_host_register(C.c_void_p(big.ctypes.data), big.nbytes) == 0
+    assert L.lib.qc_host_register(C.c_void_p(big.ctypes.data + 8), 64) != 0            # overlaps
+    assert L.lib.qc_host_unregister(C.c_void_p(big.ctypes.data + 8)) != 0              # not the start of a range
+    view = big[7:7 + n]
+    dyn.F(Z, out=view)
+    assert np.array_equal(view, plain) and np.isnan(big[:7]).all() and np.isnan(big[7 + n:]).all()
+    F2, J2 = dyn.F_dF(Z, out=(view, np.empty(int(dyn.dims.jac_nnz))))               # the other calls accept registered arrays as well
+    assert np.array_equal(F2, plain)
+    view[:] = np.nan
+    assert L.lib.qc_host_unregister(C.c_void_p(big.ctypes.data)) == 0
+    dyn.F(Z, out=view)
+    assert np.array_equal(view, plain)
+    dyn.close()
+    # the closures' own vectors are registered by the binding (and unregistered by close())
+    d2 = qc.QuantumDynamics(inp.integrators, inp.traj, devices=devices)
+    f = d2.F(Z)
+    assert np.array_equal(f, plain) and len(d2._registered) == 3
+    d2.close()
+    assert d2._registered == []
+    if cfg == 1 and devices is None:      # rows placed by component: a state component without an integrator leaves rows no kernel writes
+        from types import SimpleNamespace
+        tr = inp.traj
+        comps = {nm: tr.data[r.start:r.stop] for nm, r in tr.components.items()}
+        comps["g"] = rng.standard_normal((3, tr.T))
+        names = list(comps)
+        names.insert(1, names.pop(names.index("g")))
+        traj = qc.NamedTrajectory({k: comps[k] for k in names}, controls=tr.controls, timestep=tr.timestep)
+        integ = [qc.UnitaryPadeIntegrator("Ũ⃗", "a", inp.system, traj, order=4), qc.DerivativeIntegrator("a", "da", traj),
+                 qc.DerivativeIntegrator("da", "dda", traj)]
+        d3 = qc.QuantumDynamics(integ, traj, rows="by_component", result_ring=0)
+        ref = d3.F(traj.datavec, out=np.full(int(d3.dims.F_len), np.nan))
+        reg = np.full(int(d3.dims.F_len), np.nan)
+        assert d3.register_host(reg)
+        d3.F(traj.datavec, out=reg)
+        assert np.array_equal(reg, ref) and (ref.reshape(traj.T - 1, -1)[:, 8:11] == 0.0).all()
+        d3.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("devices", [None, [0, 0, 0]])
 def test_upload_elision_is_guarded_by_the_handles_upload_count(qc, oracle, devices):
     """between `eval_constraint(x)` and the Jacobian / Hessian at the same x, (a) a rollout through the same handle must
