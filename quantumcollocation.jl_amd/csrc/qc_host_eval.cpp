@@ -24,8 +24,19 @@
 #include <vector>
 
 #include "qc_internal.h"
+#include "qc_host_team.h"
 
 #define fail qc_fail
+using qc_team::HostGroup;
+using qc_team::HostPool;
+using qc_team::host_pool;
+using qc_team::host_copy;
+using qc_team::host_trace;
+using qc_team::now_us;
+using qc_team::cpu_pause;
+using qc_team::kLandSentinel;
+using qc_team::LandJob;
+using qc_team::land_piece_intervals;
 
 static int check_align(qc_handle* h, const void* p, size_t a, const char* what) {
     if (p && ((uintptr_t)p % a) != 0) return fail(&h->err, QC_ERR_INVALID, std::string(what) + " is not sufficiently aligned");
@@ -33,6 +44,15 @@ static int check_align(qc_handle* h, const void* p, size_t a, const char* what) 
 }
 
 static bool is_multi(const qc_handle* h) { return !h->shards.empty(); }
+
+// A wait on the device that ran into QC_HOST_TIMEOUT_MS: the call returns an error instead of spinning for ever.  Nothing is
+// synchronised here (a hung device would hang that, too): the handle's streams may still hold work, and its pinned blocks are re-armed
+// from scratch by the next call that gets that far.
+static int timed_out(qc_handle* h, const char* what) {
+    for (int i = 0; i < QC_HOST_RING; ++i) h->hC_armed[i] = false;
+    return fail(&h->err, QC_ERR_HIP, std::string("timed out after ") + std::to_string((long long)(qc_team::timeout_us() / 1e3)) +
+                                         " ms waiting for " + what + " on the device (QC_HOST_TIMEOUT_MS)");
+}
 
 #define QC_NOT_MULTI(h, name)                                                                                        \
     do {                                                                                                             \
@@ -267,20 +287,6 @@ static CompactPlan compact_plan(const QcParams& P) {
     return c;
 }
 
-// qc_host_copy.cpp: streaming copy (non-temporal stores where the CPU has them; QC_HOST_NT=0 -> memcpy, 2 -> 32-byte form)
-typedef void (*qc_copy_fn)(double*, const double*, size_t);
-void qc_host_copy_select(int mode, qc_copy_fn* fn);
-void qc_host_copy_fence();
-static qc_copy_fn host_copy() {
-    static qc_copy_fn fn = [] {
-        qc_copy_fn f = nullptr;
-        const char* ev = getenv("QC_HOST_NT");
-        qc_host_copy_select(ev ? atoi(ev) : 1, &f);
-        return f;
-    }();
-    return fn;
-}
-
 static void expand_intervals(const QcParams& P, const CompactPlan& cp, const double* comp, double* vals, int b0, int b1) {
     const qc_copy_fn cpy = host_copy();
     for (int b = b0; b < b1; ++b) {
@@ -305,18 +311,16 @@ static int usable_cores() {
     return std::max(1, n);
 }
 
-// Process-wide pool of replication workers, shared by every handle (the shards of a multi-device handle push into it
-// concurrently).  Workers block on a condition variable between jobs (threads spinning in hipEventSynchronize per chunk
-// were tried first: on a CPU-quota-limited host they starve the copying ones).
+static int pool_workers(int shards) {
+    static const int cores = usable_cores();
+    int w = std::min(cores, shards > 1 ? 16 : 8);   // measured best on the MI355X host (16-CPU quota): 8 workers, 16 chunks per handle
+    if (const char* ev = getenv("QC_HOST_THREADS")) w = std::max(1, std::min(64, atoi(ev)));
+    return std::max(1, w);
+}
+
+// The worker pool, the landing watch and the pinned ring's re-arm jobs are in qc_host_team.h: plain C++, no HIP, so that
+// tests/host_team_test.cpp can drive them on the CPU under -fsanitize=thread / address with a thread standing in for the copy engine.
 namespace {
-struct HostGroup {   // completion of one call's jobs
-    std::mutex mu;
-    std::condition_variable cv;
-    int outstanding = 0;
-    void add() { std::lock_guard<std::mutex> lk(mu); ++outstanding; }
-    void done() { std::lock_guard<std::mutex> lk(mu); if (--outstanding == 0) cv.notify_all(); }
-    void wait() { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return outstanding == 0; }); }
-};
 // CPU sets of the L3 domains (core complexes) on the NUMA node the device hangs off, from sysfs; empty when anything is unreadable.
 // A core complex of the MI355X hosts' EPYC has one link to the memory controllers (~30 - 60 GB/s of writes): the replication
 // team writes 41.5 MB per config-3 call and only keeps up with the PCIe link when its members sit on DIFFERENT complexes, next to
@@ -368,80 +372,6 @@ static std::vector<cpu_set_t> device_l3_domains(int device) {
     return out;
 }
 
-struct HostPool {
-    std::vector<std::thread> th;
-    std::vector<cpu_set_t> domains;       // where the members go: the complexes next to every device served so far (or empty)
-    std::mutex mu;
-    std::condition_variable cv;
-    std::deque<std::pair<std::function<void()>, HostGroup*>> q;
-    bool stop = false;
-    // (Workers that poll for ~100 us before blocking were measured on the 16-CPU-quota host: 0.55 instead of 0.48 ms per
-    // config-3 evaluation -- the polling threads eat the quota the launching thread needs.)
-    void run() {
-        std::unique_lock<std::mutex> lk(mu);
-        for (;;) {
-            cv.wait(lk, [&] { return stop || !q.empty(); });
-            if (q.empty()) return;   // (stop: only once the queue has drained -- re-arm jobs outlive their call, and their group is waited for)
-            auto job = std::move(q.front());
-            q.pop_front();
-            lk.unlock();
-            job.first();
-            job.second->done();
-            lk.lock();
-        }
-    }
-    std::vector<int> devices_seen;        // devices whose NUMA node's complexes are in `domains`
-    void ensure(int n, int device = -1) {
-        std::lock_guard<std::mutex> lk(mu);
-        // QC_HOST_AFFINITY=0: leave the members to the scheduler
-        static const bool pin = !(getenv("QC_HOST_AFFINITY") && atoi(getenv("QC_HOST_AFFINITY")) == 0);
-        bool repin = false;
-        if (pin && device >= 0 && std::find(devices_seen.begin(), devices_seen.end(), device) == devices_seen.end()) {
-            // a device not served before (the shards of a multi-device handle sit on both sockets): its node's complexes join the list
-            devices_seen.push_back(device);
-            for (const cpu_set_t& d : device_l3_domains(device)) {
-                bool known = false;
-                for (const cpu_set_t& e : domains) known = known || CPU_EQUAL(&d, &e);
-                if (!known) { domains.push_back(d); repin = true; }
-            }
-        }
-        while ((int)th.size() < n) { th.emplace_back([this] { run(); }); repin = true; }
-        if (repin && !domains.empty()) {
-            // member i on complex (i + 1) mod n: complex 0 is left to the calling thread's side of the work when it happens to be there
-            for (size_t i = 0; i < th.size(); ++i) {
-                const cpu_set_t& set = domains[(i + 1) % domains.size()];
-                (void)pthread_setaffinity_np(th[i].native_handle(), sizeof(cpu_set_t), &set);
-            }
-        }
-    }
-    void push(std::function<void()> fn, HostGroup* g) {
-        g->add();
-        { std::lock_guard<std::mutex> lk(mu); q.emplace_back(std::move(fn), g); }
-        cv.notify_one();
-    }
-    // `count` team members running the same function: one wake-up call for all of them (a notify per job is a futex call each)
-    void push_many(const std::function<void()>& fn, int count, HostGroup* g) {
-        if (count <= 0) return;
-        for (int i = 0; i < count; ++i) g->add();
-        { std::lock_guard<std::mutex> lk(mu); for (int i = 0; i < count; ++i) q.emplace_back(fn, g); }
-        cv.notify_all();
-    }
-    ~HostPool() {
-        { std::lock_guard<std::mutex> lk(mu); stop = true; }
-        cv.notify_all();
-        for (auto& t : th) t.join();
-    }
-};
-HostPool& host_pool() {
-    static HostPool* p = new HostPool();   // intentionally leaked: worker threads must not be joined from a static destructor
-    return *p;
-}
-int pool_workers(int shards) {
-    static const int cores = usable_cores();
-    int w = std::min(cores, shards > 1 ? 16 : 8);   // measured best on the MI355X host (16-CPU quota): 8 workers, 16 chunks per handle
-    if (const char* ev = getenv("QC_HOST_THREADS")) w = std::max(1, std::min(64, atoi(ev)));
-    return std::max(1, w);
-}
 }  // namespace
 
 // Chunks of the compact transfer: at most two per worker, at least 16 intervals and ~256 KB of compact values each -- a chunk is
@@ -485,10 +415,6 @@ static QcParams compact_params(const QcParams& P, const CompactPlan& cp) {
 
 // Chunked tail of a host evaluation: `produce(k, b0, b1)` enqueues the work that makes chunk k's compact values (and
 // residuals) appear in the pinned buffers; the worker pool expands each chunk into the caller's arrays as it lands.
-static double now_us() {
-    return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
-}
-static bool host_trace() { static const bool on = getenv("QC_HOST_TRACE") && atoi(getenv("QC_HOST_TRACE")); return on; }
 static thread_local double g_call_begin = 0.0;   // entry of the host-buffer call being traced (QC_HOST_TRACE)
 
 // (One launch over all intervals in order, with per-chunk completion counters added to by the kernel in pinned host memory and
@@ -551,7 +477,13 @@ static int run_chunks(qc_handle* h, const CompactPlan& cp, double* F, double* va
         const bool blocking_wait = blocking_env || shards > 1;
         hipError_t ew = hipSuccess;
         if (blocking_wait) ew = hipEventSynchronize(h->chunk_events[k]);
-        else while ((ew = hipEventQuery(h->chunk_events[k])) == hipErrorNotReady) __builtin_ia32_pause();
+        else {
+            unsigned spins = 0;
+            while ((ew = hipEventQuery(h->chunk_events[k])) == hipErrorNotReady) {
+                if ((++spins & 1023) == 0 && now_us() - t_begin > qc_team::timeout_us()) return timed_out(h, "a chunk of the compact transfer");
+                cpu_pause();
+            }
+        }
         if (ew != hipSuccess) { rc_wait = QC_ERR_HIP; break; }
         if (k == 0) t_first = now_us();
         if (k == n_chunks - 1) t_last = now_us();
@@ -694,127 +626,6 @@ extern "C" int64_t qc_knot_generation(const qc_handle* h) {
 // completion event, and once that has been seen every remaining word is taken as it is (a result that happens to equal the
 // sentinel -- possible only if the caller's input carries that NaN payload -- costs the overlap, not the answer).
 // Residual-only and Hessian calls need no host-side replication: their output goes device -> caller's array in one copy.
-size_t qc_host_scan(const double* p, size_t n, unsigned long long sentinel);   // qc_host_copy.cpp
-void qc_host_fill(double* p, size_t n, unsigned long long sentinel);
-namespace {
-constexpr unsigned long long kLandSentinel = 0x7FF4C0DEC0DE5A5Aull;
-
-struct LandJob {
-    const QcParams* P = nullptr;
-    CompactPlan cp{};
-    // the watched pinned block: one sub-block of `blk` doubles per interval = [ residual rows (f_len) | compact Jacobian values ]
-    double* src = nullptr;
-    size_t blk = 0, f_len = 0;
-    bool rearm_inline = false;
-    double* vals = nullptr;                             // caller's Jacobian values (replication target)
-    double* F = nullptr;                                // caller's residuals, or nullptr
-    int n_int = 0;
-    std::vector<int> bound;                             // piece k = intervals [bound[k], bound[k + 1])
-    std::unique_ptr<std::atomic<int>[]> claimed;
-    std::atomic<int> remaining{0};
-    std::atomic<int> done{0};                           // 1: the copy's completion event has been seen, 2: it reported an error
-    std::atomic<double> t_first_piece{0.0}, t_last_piece{0.0}, t_event{0.0};   // trace (QC_HOST_TRACE)
-    std::atomic<int> pieces_at_event{0}, blocks_waited{0};       // trace: pieces done when the copy's end was seen; blocks a member had to wait for
-    std::atomic<int> n_members{0};
-    int member_cpu[64], member_pieces[64];                       // trace: where each team member ran, how many pieces it took
-};
-
-inline void cpu_pause() { __builtin_ia32_pause(); }
-
-bool land_inline_rearm() {   // QC_HOST_REARM=inline: every block re-armed by the member that consumed it, inside the call (A/B diagnostics)
-    static const bool v = getenv("QC_HOST_REARM") && !strcmp(getenv("QC_HOST_REARM"), "inline");
-    return v;
-}
-bool land_nowatch() {        // QC_HOST_NOWATCH=1: the team does not look at the block before the copy's completion event (how long does the copy take alone?)
-    static const bool v = getenv("QC_HOST_NOWATCH") && atoi(getenv("QC_HOST_NOWATCH"));
-    return v;
-}
-
-inline void land_poll(LandJob& J, hipEvent_t ev) {   // calling thread only
-    const hipError_t e = hipEventQuery(ev);
-    if (e == hipSuccess) {
-        if (host_trace() && !J.done.load()) { J.t_event.store(now_us()); J.pieces_at_event.store((int)J.bound.size() - 1 - J.remaining.load()); }
-        J.done.store(1, std::memory_order_release);
-    } else if (e != hipErrorNotReady) J.done.store(2, std::memory_order_release);
-}
-
-// spins until no word of p[0 .. n) holds the sentinel, or the copy is known to be complete (`poll`: this is the calling thread,
-// the only one that asks the runtime -- it must keep asking while it waits for a block)
-inline void land_wait(LandJob& J, const double* p, size_t n, hipEvent_t ev, bool poll) {
-    size_t off = 0;
-    unsigned spins = 0;
-    while (off < n) {
-        off += qc_host_scan(p + off, n - off, kLandSentinel);
-        if (off >= n) return;
-        if (J.done.load(std::memory_order_acquire)) return;
-        if (spins == 0 && host_trace()) J.blocks_waited.fetch_add(1, std::memory_order_relaxed);
-        if (poll && (++spins & 15) == 0) land_poll(J, ev);
-        cpu_pause();
-    }
-}
-
-inline bool land_started(const LandJob& J, int b) {   // has interval b's block arrived?  (cheap: its first and last word)
-    const volatile unsigned long long* u = (const volatile unsigned long long*)(J.src + (size_t)b * J.blk);
-    return u[0] != kLandSentinel && u[J.blk - 1] != kLandSentinel;
-}
-
-void land_piece(LandJob& J, int k, hipEvent_t ev, bool poll) {
-    const QcParams& P = *J.P;
-    const qc_copy_fn cpy = host_copy();
-    for (int b = J.bound[k]; b < J.bound[k + 1]; ++b) {
-        double* blk = J.src + (size_t)b * J.blk;
-        land_wait(J, blk, J.blk, ev, poll);
-        if (J.F) memcpy(J.F + (size_t)b * J.f_len, blk, J.f_len * sizeof(double));
-        const double* src = blk + J.f_len;
-        double* dst = J.vals + (size_t)b * P.jac_nnz;
-        for (int c = 0; c < J.cp.copies; ++c) cpy(dst + P.jo_F + (size_t)c * J.cp.n2, src, (size_t)J.cp.n2);
-        for (int c = 0; c < J.cp.second_copies; ++c) cpy(dst + P.jo_B + (size_t)c * J.cp.n2, src + J.cp.n2, (size_t)J.cp.n2);
-        cpy(dst + J.cp.tail_src, src + J.cp.head2, (size_t)J.cp.tail_len);
-        if (J.rearm_inline) qc_host_fill(blk, J.blk, kLandSentinel);
-    }
-    qc_host_copy_fence();
-}
-
-// Team member: claims pieces whose first block has landed (the copy engine writes in address order, so that is the lowest
-// unclaimed piece; any order would work), until none is left.  `poll`: the calling thread also polls the completion event.
-void land_consume(LandJob& J, hipEvent_t ev, bool poll) {
-    const int np = (int)J.bound.size() - 1;
-    int lo = 0, mine = 0;
-    const int me = host_trace() ? J.n_members.fetch_add(1) : 0;
-    while (J.remaining.load(std::memory_order_acquire) > 0) {
-        bool got = false;
-        const bool all = J.done.load(std::memory_order_acquire) != 0;
-        while (lo < np && J.claimed[lo].load(std::memory_order_relaxed)) ++lo;
-        // (only a few pieces beyond the frontier are looked at: reads of lines the copy engine is about to write cost it a snoop each)
-        for (int k = lo; k < np && (all || k < lo + 4); ++k) {
-            if (J.claimed[k].load(std::memory_order_relaxed)) continue;
-            if (!all && (land_nowatch() || !land_started(J, J.bound[k]))) continue;
-            int expect = 0;
-            if (!J.claimed[k].compare_exchange_strong(expect, 1, std::memory_order_acq_rel)) continue;
-            land_piece(J, k, ev, poll);
-            if (host_trace()) {
-                const double t = now_us();
-                double z = 0.0;
-                J.t_first_piece.compare_exchange_strong(z, t);
-                J.t_last_piece.store(t);
-            }
-            J.remaining.fetch_sub(1, std::memory_order_acq_rel);
-            got = true;
-            ++mine;
-            break;
-        }
-        if (poll && !all) land_poll(J, ev);
-        if (!got) cpu_pause();
-    }
-    if (host_trace() && me < 64) { J.member_cpu[me] = sched_getcpu(); J.member_pieces[me] = mine; }
-}
-
-int land_piece_intervals(size_t block_bytes) {   // ~128 KB of pinned block per piece, at least 2 intervals (QC_HOST_PIECE_KB)
-    static const size_t kb = getenv("QC_HOST_PIECE_KB") ? (size_t)std::max(1, atoi(getenv("QC_HOST_PIECE_KB"))) : 128;
-    return (int)std::max<size_t>(2, (kb << 10) / std::max<size_t>(1, block_bytes));
-}
-}  // namespace
-
 // Brings this handle's knots [t_begin, t_end] to the device unless qc_set_new_x(h, 0) says they are there already.  From where
 // they lie: the runtime pins the caller's pages in place (30 us for config 3's 1.2 MB, the same as from pinned memory).
 static int upload_knots(qc_handle* h, const double* Z) {
@@ -833,7 +644,12 @@ static int upload_knots(qc_handle* h, const double* Z) {
 // multi-device handle yield between polls (N spinning shard threads next to the team would exceed a small CPU quota)
 static int wait_done(qc_handle* h, int shards) {
     hipError_t e;
-    while ((e = hipEventQuery(h->ev_done)) == hipErrorNotReady) { if (shards > 1) sched_yield(); else cpu_pause(); }
+    const double t0 = now_us();
+    unsigned spins = 0;
+    while ((e = hipEventQuery(h->ev_done)) == hipErrorNotReady) {
+        if ((++spins & 1023) == 0 && now_us() - t0 > qc_team::timeout_us()) return timed_out(h, "the evaluation");
+        if (shards > 1) sched_yield(); else cpu_pause();
+    }
     if (e != hipSuccess) {
         (void)hipStreamSynchronize(h->stream);
         return fail(&h->err, QC_ERR_HIP, std::string("the evaluation failed on the device: ") + hipGetErrorString(e));
@@ -845,38 +661,26 @@ static int wait_done(qc_handle* h, int shards) {
 static int land_run(qc_handle* h, LandJob& J, int shards, double t_begin, double t_issued) {
     HostPool& pool = host_pool();
     const int workers = pool_workers(shards);
-    pool.ensure(workers, h->device);
-    J.bound.assign(1, 0);
-    const int per = land_piece_intervals(J.blk * sizeof(double));
-    // The last pieces are cut finer (QC_HOST_TAIL_SPLIT parts each, default 4; 1: uniform): when the copy's last bytes land every
-    // member is idle, and the call ends one piece's replication later -- a quarter piece instead of a whole one.
-    static const int tail_split = getenv("QC_HOST_TAIL_SPLIT") ? std::max(1, atoi(getenv("QC_HOST_TAIL_SPLIT"))) : 4;
-    const int fine = std::max(1, per / tail_split);
-    const int tail_from = tail_split > 1 ? std::max(0, J.n_int - 2 * per) : J.n_int;
-    for (int b = per; b < J.n_int; b += (b >= tail_from ? fine : per)) J.bound.push_back(b);
-    J.bound.push_back(J.n_int);
-    const int np = (int)J.bound.size() - 1;
-    J.claimed.reset(new std::atomic<int>[np]);
-    for (int k = 0; k < np; ++k) J.claimed[k].store(0, std::memory_order_relaxed);
-    J.remaining.store(np, std::memory_order_release);
+    pool.ensure(workers, h->device, device_l3_domains);
     // helpers: enough to keep up with the link (the replication of config 3 writes 41.5 MB per call), never more than pieces;
     // small outputs are replicated by the calling thread alone (a worker's wake-up costs 20 - 40 us)
-    const size_t out_bytes = (size_t)J.n_int * ((size_t)J.P->jac_nnz + (J.F ? J.f_len : 0)) * sizeof(double);
+    const size_t out_bytes = (size_t)J.n_int * ((size_t)J.lay.jac_nnz + (J.F ? J.f_len : 0)) * sizeof(double);
     int helpers = std::max(0, workers / std::max(1, shards) - (shards > 1 ? 1 : 0));
     if (out_bytes <= (256u << 10)) helpers = 0;
-    helpers = std::max(0, std::min(helpers, np - 1));
-    HostGroup grp;
-    LandJob* Jp = &J;
+    J.t_begin = t_begin;
     const hipEvent_t ev = h->ev_done;
-    pool.push_many([Jp, ev] { land_consume(*Jp, ev, false); }, helpers, &grp);
-    land_consume(J, ev, true);
-    grp.wait();
+    const int done = qc_team::land_team(J, pool, helpers, [ev]() -> int {
+        const hipError_t e = hipEventQuery(ev);
+        return e == hipSuccess ? qc_team::LAND_DONE : (e == hipErrorNotReady ? qc_team::LAND_PENDING : qc_team::LAND_FAILED);
+    });
     const double t_consumed = now_us();
+    const int np = (int)J.bound.size() - 1;
     int rc = QC_OK;
-    if (J.done.load() != 1) rc = wait_done(h, shards);
+    if (done == qc_team::LAND_TIMEOUT) return timed_out(h, "the copy of the compact values");
+    if (done != qc_team::LAND_DONE && done != qc_team::LAND_FAILED) rc = wait_done(h, shards);      // (every piece consumed before the completion was seen)
     if (host_trace())
         fprintf(stderr, "qcolloc host trace (%d pieces, %d helpers): inputs, launch and copy issued +%.0f us, first piece done +%.0f, last piece done +%.0f, "
-                "team done +%.0f us; copy seen complete +%.0f with %d pieces done; %d of %d blocks were waited for\n", np, helpers, t_issued - t_begin,
+                "team done +%.0f us; copy seen complete +%.0f with %d pieces done; %d of %d blocks were waited for\n", np, std::min(helpers, np - 1), t_issued - t_begin,
                 J.t_first_piece.load() ? J.t_first_piece.load() - t_begin : 0.0, J.t_last_piece.load() ? J.t_last_piece.load() - t_begin : 0.0,
                 t_consumed - t_begin, J.t_event.load() ? J.t_event.load() - t_begin : -1.0, J.pieces_at_event.load(), J.blocks_waited.load(), J.n_int);
     if (host_trace()) {
@@ -884,14 +688,14 @@ static int land_run(qc_handle* h, LandJob& J, int shards, double t_begin, double
         for (int i = 0; i < std::min(64, J.n_members.load()); ++i) fprintf(stderr, " %d:%d", J.member_cpu[i], J.member_pieces[i]);
         fprintf(stderr, "\n");
     }
-    if (!rc && J.done.load() == 2) { (void)hipStreamSynchronize(h->stream); rc = fail(&h->err, QC_ERR_HIP, "the evaluation failed on the device"); }
+    if (!rc && done == qc_team::LAND_FAILED) { (void)hipStreamSynchronize(h->stream); rc = fail(&h->err, QC_ERR_HIP, "the evaluation failed on the device"); }
     return rc;
 }
 
-struct qc_rearm { HostGroup grp; };
+struct qc_rearm { qc_team::Rearm r; };
 void qc_rearm_destroy(qc_rearm* r) {
     if (!r) return;
-    r->grp.wait();
+    r->r.grp.wait();
     delete r;
 }
 
@@ -912,7 +716,7 @@ static int ring_take(qc_handle* h, int* index) {
     const size_t cap = ring_capacity(h);
     int rc;
     if ((rc = ensure_pinned(h, &h->hC[ib], cap, false))) return rc;
-    if (h->rearm[ib]) h->rearm[ib]->grp.wait();               // the re-arm jobs of this block's previous use (normally long done)
+    if (h->rearm[ib]) h->rearm[ib]->r.grp.wait();             // the re-arm jobs of this block's previous use (normally long done)
     if (!h->hC_armed[ib]) {
         // (non-temporal stores: fenced before the copy engine may write the block, or a write-combining buffer draining late
         //  would put the sentinel over words that have already landed)
@@ -923,19 +727,10 @@ static int ring_take(qc_handle* h, int* index) {
     *index = ib;
     return QC_OK;
 }
-// the consumed part of a block is re-armed behind the caller's back by whichever workers are idle
+// the consumed part of a block is re-armed behind the caller's back by whichever workers are idle (qc_host_team.h)
 static void ring_rearm_later(qc_handle* h, int ib, size_t used) {
     if (!h->rearm[ib]) h->rearm[ib] = new qc_rearm();
-    double* base = h->hC[ib];
-    // QC_HOST_REARM_JOBS workers share it (default 2: a trickle that the next call's transfers hardly notice, done well before
-    // the block's next turn in the ring of 3; eight workers re-arm in a burst that slowed the next call's upload of Z from 30
-    // to 100 - 190 us when calls follow each other without a pause)
-    static const size_t jobs = getenv("QC_HOST_REARM_JOBS") ? (size_t)std::max(1, atoi(getenv("QC_HOST_REARM_JOBS"))) : 2;
-    const size_t piece = std::max<size_t>(size_t(1) << 17, (used + jobs - 1) / jobs);      // doubles: at least 1 MB each
-    for (size_t o = 0; o < used; o += piece) {
-        const size_t len = std::min(piece, used - o);
-        host_pool().push([base, o, len] { qc_host_fill(base + o, len, kLandSentinel); qc_host_copy_fence(); }, &h->rearm[ib]->grp);
-    }
+    qc_team::rearm_later(host_pool(), h->rearm[ib]->r, h->hC[ib], used);
 }
 
 extern "C" int qc_debug_host_expand_rate(qc_handle* h, int32_t reps, double* GBps) {
@@ -1011,8 +806,8 @@ static int eval_host(qc_handle* h, const double* Z, double* F, double* vals, int
     // residuals + compact Jacobian values, interleaved per interval in ONE device block, so that one copy brings both and a
     // team member finds everything an interval needs in one place
     LandJob J;
-    J.P = &h->prm;
-    J.cp = cp;
+    J.lay.jac_nnz = P.jac_nnz; J.lay.jo_F = P.jo_F; J.lay.jo_B = P.jo_B; J.lay.n2 = cp.n2; J.lay.copies = cp.copies;
+    J.lay.second_copies = cp.second_copies; J.lay.head2 = cp.head2; J.lay.tail_src = cp.tail_src; J.lay.tail_len = cp.tail_len;
     J.n_int = P.n_int;
     // (a layout with rows no kernel writes keeps its residual rows in the block even when only the values are asked for: the block
     //  layout of such a handle must not change between calls, or stale values would show through the never-written rows)
@@ -1027,7 +822,7 @@ static int eval_host(qc_handle* h, const double* Z, double* F, double* vals, int
     int ib;
     if ((rc = ring_take(h, &ib))) return rc;
     J.src = h->hC[ib];
-    J.rearm_inline = land_inline_rearm();
+    J.rearm_inline = qc_team::land_inline_rearm();
     QcParams C = compact_params(P, cp);
     C.J_stride = (long long)J.blk;
     C.J_off = (long long)J.f_len;
