@@ -7,6 +7,11 @@
 #   fixture : the reference's data fixture (test/test_utils.jl:54-70, free time) with the system of test_utils.jl:123
 #   config1 : 1-qubit Hadamard, T = 50, dt = 0.2, X / Y drives        (BASELINE config 1)
 #   config2 : 2-qubit CNOT, T = 200, order-4 Pade                      (BASELINE config 2)
+#   toffoli3: 3-qubit Toffoli, T = 12                                   (BASELINE configs 3 / 4 in small: the 2N = 16 MFMA kernels,
+#                                                                        `mfma16-pade4`, `mfma16-pade4-hess2`, `mfma16-pade4-fused`)
+#   qft4    : 4-qubit QFT, T = 6                                        (BASELINE config 5 in small: the 2N = 32 sparse-drive kernels,
+#                                                                        `mfma32-pade4-ell`, `-hess-ell`, `-fused-ell`)
+#   order6  : 2-qubit CNOT, T = 10, order-6 Pade                        (the any-order kernels, `mfma16-padeP`, `mfma16-padeP-hess`)
 # and writes tests/golden/ref_<case>.json: Z, mu, F, dF / mu_d2F values AND structures, plus the scalar definitions this
 # repository could only recall (INTEGRATION.md "Choices this repository cannot verify").  tests/test_reference_golden.py
 # picks the files up (COO comparison as sets of (row, col) -> summed value, hess_align = 1, rtol 1e-10) and the verdict of
@@ -106,9 +111,23 @@ for (name, system, gate, T) in (("config1", QuantumSystem(GATES[:Z], [GATES[:X],
     open(io -> write(io, json(r)), joinpath(out_dir, "ref_$(name).json"), "w")
 end
 
+# ---- the MFMA paths of the metric workloads, in small (tests/test_reference_golden.py asserts which kernel served each file) ----
+pauli_on(P, i, n) = reduce(kron, [k == i ? PAULIS[P] : PAULIS[:I] for k in 1:n])             # P on qubit i of n
+function qubit_system(n)    # drift 0.1 sum_i Z_i Z_i+1, drives X_i, Y_i: the systems of this repository's BASELINE configs 2 - 5
+    H0 = sum(0.1 * pauli_on(:Z, i, n) * pauli_on(:Z, i + 1, n) for i in 1:n-1)
+    return QuantumSystem(H0, reduce(vcat, [[pauli_on(:X, i, n), pauli_on(:Y, i, n)] for i in 1:n]))
+end
+toffoli = Matrix{ComplexF64}(I, 8, 8); toffoli[7:8, 7:8] = [0 1; 1 0]
+qft16 = [exp(2π * im * j * k / 16) / 4 for j in 0:15, k in 0:15]
+for (name, system, gate, T, order) in (("toffoli3", qubit_system(3), toffoli, 12, 4), ("qft4", qubit_system(4), qft16, 6, 4),
+                                       ("order6", qubit_system(2), GATES[:CX], 10, 6))
+    r, _ = reference_record(system, smooth_pulse_traj(system, gate, T, 0.2); order=order)
+    open(io -> write(io, json(r)), joinpath(out_dir, "ref_$(name).json"), "w")
+end
+
 println("\nreconcile.jl -- verdicts for INTEGRATION.md \"Choices this repository cannot verify\":")
 for (k, v) in verdicts
     println("  ", rpad(k, 72), " => ", v)
 end
-println("wrote ref_fixture.json, ref_fixture_exponential.json, ref_config1.json, ref_config2.json to ", abspath(out_dir))
+println("wrote ref_fixture.json, ref_fixture_exponential.json, ref_config1.json, ref_config2.json, ref_toffoli3.json, ref_qft4.json, ref_order6.json to ", abspath(out_dir))
 println("now run:  python -m pytest tests/test_reference_golden.py -m gpu")

@@ -18,8 +18,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, "tests", "golden")
 FILES = sorted(f for f in glob.glob(os.path.join(GOLD, "ref_*.json")) if not f.endswith("_exponential.json"))
 RTOL = 1e-10
+needs_files = pytest.mark.skipif(not FILES, reason="no tests/golden/ref_*.json: run julia/reconcile.jl where Julia and QuantumCollocationCore 0.3 exist")
+# which device kernels a reconcile.jl record must have been served by (F + dF, mu_d2F, the one-call form): the point of the small
+# Toffoli / QFT / order-6 records is to pin the MFMA kernels of the metric workloads, not the generic path
+EXPECTED_KERNELS = {
+    "ref_fixture.json": ("mfma16-pade4", "mfma16-pade4-hess", "two-launches"),
+    "ref_config1.json": ("mfma16-pade4", "mfma16-pade4-hess", "two-launches"),
+    "ref_config2.json": ("mfma16-pade4", "mfma16-pade4-hess", "two-launches"),
+    "ref_toffoli3.json": ("mfma16-pade4", "mfma16-pade4-hess2", "mfma16-pade4-fused"),
+    "ref_qft4.json": ("mfma32-pade4-ell", "mfma32-pade4-hess-ell", "mfma32-pade4-fused-ell"),
+    "ref_order6.json": ("mfma16-padeP", "mfma16-padeP-hess", "two-launches"),
+}
 
-pytestmark = pytest.mark.skipif(not FILES, reason="no tests/golden/ref_*.json: run julia/reconcile.jl where Julia and QuantumCollocationCore 0.3 exist")
 
 
 def coo_sum(rows, cols, vals, one_based):
@@ -64,6 +74,7 @@ def problem_from_record(qc, rec):
     return integ, traj, Z
 
 
+@needs_files
 @pytest.mark.parametrize("path", FILES, ids=[os.path.basename(f) for f in FILES])
 def test_oracle_against_reference_outputs(qc, oracle, path):
     """The CPU oracle against Core's numbers: this is what pins the oracle (and, through the GPU parity tests, the kernels)."""
@@ -87,13 +98,13 @@ def test_oracle_against_reference_outputs(qc, oracle, path):
                          np.abs(Hr).max())
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("path", FILES, ids=[os.path.basename(f) for f in FILES])
-def test_hip_path_against_reference_outputs(qc, path):
-    """The HIP path, through the C ABI, directly against Core's numbers (hess_align = 1: exactly the structural entries)."""
+def check_hip_path_against_record(qc, path):
     rec = json.load(open(path))
     integ, traj, Z = problem_from_record(qc, rec)
     dyn = qc.QuantumDynamics(integ, traj, hess_align=1)
+    want = EXPECTED_KERNELS.get(os.path.basename(path))
+    if want is not None:
+        assert dyn.kernel_names + (dyn.fused_kernel_name,) == want, (os.path.basename(path), dyn.kernel_names, dyn.fused_kernel_name)
     F, J = dyn.F_dF(Z)
     Fr, Jr = np.asarray(rec["F"], dtype=float), np.asarray(rec["dF"], dtype=float)
     np.testing.assert_allclose(F, Fr, rtol=RTOL, atol=RTOL * max(1.0, np.abs(Fr).max()))
@@ -108,7 +119,63 @@ def test_hip_path_against_reference_outputs(qc, path):
         ours = {(int(r), int(c)) for r, c in zip(hr, hc)}
         ref = {(int(r) - 1, int(c) - 1) for r, c in zip(rec["mu_d2F_rows"], rec["mu_d2F_cols"])}
         assert ref <= ours or ours <= ref, "Hessian structures are not nested"
+        # ... and the one-call form (a kernel of its own where `fused_kernel_name` says so), device-resident
+        import torch
+        dZ, dmu = torch.from_numpy(Z).cuda(), torch.from_numpy(mu).cuda()
+        dF, dJ, dH = (torch.empty(int(k), dtype=torch.float64, device="cuda") for k in (dyn.dims.F_len, dyn.dims.jac_nnz, dyn.dims.hess_nnz))
+        dyn.F_dF_mu_d2F_device(dZ, dmu, dF, dJ, dH)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(dF.cpu().numpy(), Fr, rtol=RTOL, atol=RTOL * max(1.0, np.abs(Fr).max()))
+        assert_coo_equal(coo_sum(jr, jc, dJ.cpu().numpy(), False), coo_sum(rec["dF_rows"], rec["dF_cols"], Jr, True), "dF (one call)", np.abs(Jr).max())
+        assert_coo_equal(coo_sum(hr, hc, dH.cpu().numpy(), False), coo_sum(rec["mu_d2F_rows"], rec["mu_d2F_cols"], Hr, True), "mu_d2F (one call)", np.abs(Hr).max())
     dyn.close()
+
+
+@needs_files
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", FILES, ids=[os.path.basename(f) for f in FILES])
+def test_hip_path_against_reference_outputs(qc, path):
+    """The HIP path, through the C ABI, directly against Core's numbers (hess_align = 1: exactly the structural entries)."""
+    check_hip_path_against_record(qc, path)
+
+
+def write_mock_record(qc, oracle, path, n_qubits, gate, T, order, shuffle_seed):
+    """A record in reconcile.jl's schema whose numbers come from THIS repository's CPU oracle ("MOCK: build oracle, not reference
+    output"), with the COO entries of every interval in a shuffled order -- Core's order need not be this library's.  Only to prove
+    that the machinery above (schema, 1-based structures, COO-set comparison, kernel expectations) works before anybody has Julia."""
+    from oracle_bridge import problem_from_inputs
+    system = qc.multi_qubit_system(n_qubits)
+    inp = qc.unitary_smooth_pulse_inputs(system, gate, T, pade_order=order)
+    traj, Z = inp.traj, inp.traj.datavec
+    prob = problem_from_inputs(inp)
+    prob.hess_align = 1
+    rng = np.random.default_rng(shuffle_seed)
+    mu = rng.standard_normal(prob.n_rows)
+    jr, jc = oracle.jac_structure(prob)
+    hr, hc = oracle.hess_structure(prob)
+    J, H = oracle.dF(prob, Z), oracle.mu_d2F(prob, Z, mu)
+    pj, ph = rng.permutation(J.size), rng.permutation(H.size)
+    col = lambda M: np.asarray(M).reshape(-1, order="F")
+    rec = {"MOCK": "numbers of this repository's CPU oracle, NOT reference output", "T": traj.T, "dim": traj.dim, "global_dim": 0,
+           "names": list(traj.names), "components": {n: [int(i) + 1 for i in range(r.start, r.stop)] for n, r in traj.components.items()},
+           "timestep": traj.timestep, "pade_order": order, "levels": system.levels,
+           "H_drift_re": col(system.H_drift.real).tolist(), "H_drift_im": col(system.H_drift.imag).tolist(),
+           "H_drives_re": [col(Hk.real).tolist() for Hk in system.H_drives], "H_drives_im": [col(Hk.imag).tolist() for Hk in system.H_drives],
+           "Z": Z.tolist(), "mu": mu.tolist(), "F": oracle.F(prob, Z).tolist(), "rows_declared": int(prob.n_rows),
+           "dF": J[pj].tolist(), "dF_rows": (jr[pj] + 1).tolist(), "dF_cols": (jc[pj] + 1).tolist(),
+           "mu_d2F": H[ph].tolist(), "mu_d2F_rows": (hr[ph] + 1).tolist(), "mu_d2F_cols": (hc[ph] + 1).tolist()}
+    json.dump(rec, open(path, "w"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,n_qubits,gate,T,order", [("ref_toffoli3.json", 3, "TOFFOLI", 12, 4), ("ref_qft4.json", 4, "QFT16", 6, 4),
+                                                        ("ref_order6.json", 2, "CNOT", 10, 6), ("ref_config1.json", 1, "H", 50, 4)])
+def test_reference_record_machinery_with_mock_records(qc, oracle, tmp_path, name, n_qubits, gate, T, order):
+    """The records julia/reconcile.jl will write, stood in for by mock records made from the build's own oracle: the comparison code
+    runs end to end on the GPU, and the kernel that serves each record is the one the record is meant to pin."""
+    path = str(tmp_path / name)
+    write_mock_record(qc, oracle, path, n_qubits, qc.GATES[gate], T, order, shuffle_seed=len(name))
+    check_hip_path_against_record(qc, path)
 
 
 def test_scalar_definitions_against_reference(qc, oracle):
