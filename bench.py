@@ -356,15 +356,22 @@ def config5_record(qc, dev_index, steps=300):
            "mfma_peak_TFLOPs": peak_tf}
     counters, src = _mfma_counters()
     if counters and inp.traj.T == 500:
-        pick = {"F_dF": [v for k, v in counters.items() if k.startswith("config5 qc_mfma32_pade4_kernel<true")],
-                "hess": [v for k, v in counters.items() if k.startswith("config5 qc_mfma32_pade4_hess_kernel<")]}
-        if dyn.kernel_names == ("mfma32-pade4", "mfma32-pade4-hess") and all(len(v) == 1 for v in pick.values()):
-            ext = {"source": src, "note": "external: rocprofv3 --pmc passes recorded in that file, not measured by this run"}
-            for name, us in (("F_dF", jac_us), ("hess", hess_us)):
-                c = pick[name][0]
-                ext[name + "_mfma_instructions_per_launch"] = c["SQ_INSTS_VALU_MFMA_F64"]
-                ext[name + "_MfmaUtil_percent"] = c["MfmaUtil_percent"]
-                rec[name + "_mfma_frac"] = c["SQ_INSTS_VALU_MFMA_F64"] * 2048 / (us * 1e-6) / 1e12 / peak_tf
+        # the newest profiles/r*_mfma_util.json: per kernel template instantiation of config 5 (dense-image kernels: qc_mfma32_pade4_*;
+        # sparse-drive kernels: qc_mfma32_ell_kernel<R, JAC, HESS, ...>)
+        ell = dyn.kernel_names[0].endswith("-ell")
+        keys = {"F_dF": "config5 qc_mfma32_ell_kernel<1, true, false" if ell else "config5 qc_mfma32_pade4_kernel<true",
+                "hess": "config5 qc_mfma32_ell_kernel<1, false, true" if ell else "config5 qc_mfma32_pade4_hess_kernel<",
+                "F_dF_hess_one_call": "config5 qc_mfma32_ell_kernel<1, true, true" if ell else None}
+        ext = {"source": src, "note": "external: rocprofv3 --pmc passes recorded in that file, not measured by this run"}
+        for name, us in (("F_dF", jac_us), ("hess", hess_us), ("F_dF_hess_one_call", both_us)):
+            hits = [v for k, v in counters.items() if keys[name] and k.startswith(keys[name])]
+            if len(hits) != 1:
+                continue
+            c = hits[0]
+            ext[name + "_mfma_instructions_per_launch"] = c["SQ_INSTS_VALU_MFMA_F64"]
+            ext[name + "_MfmaUtil_percent"] = c["MfmaUtil_percent"]
+            rec[name + "_mfma_frac"] = c["SQ_INSTS_VALU_MFMA_F64"] * 2048 / (us * 1e-6) / 1e12 / peak_tf
+        if len(ext) > 2:
             rec["mfma_counters"] = ext
     dyn.close()
     return rec
