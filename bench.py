@@ -153,7 +153,7 @@ class NodeBarrier:
 PCIE_COPY_GBS = 54.5    # what the copy engine moves device -> host on this host (tests/hip/landing_probe.hip, profiles/r03_landing_probe.txt)
 
 
-def host_visible_times(dyn, Zs, reps=30):
+def host_visible_times(qc, dyn, Zs, reps=30):
     """PCIe-inclusive times of the host-buffer entry points (what the reference's consumer, a CPU Ipopt process, sees), caller-owned
     numpy arrays, milliseconds per call (median of `reps`).  `*_ms`: every call receives a NEW trajectory vector (Z goes up each
     time); `*_same_x_ms`: after qc_set_new_x(h, 0), the way Ipopt asks for the Jacobian and the Hessian at its accepted point;
@@ -207,15 +207,15 @@ def host_visible_times(dyn, Zs, reps=30):
 
     out["ipopt_sequence_ms"] = timed(sequence, "ipopt_sequence_ms")
     dyn.set_new_x(True)
-    # the residual-only call into an array the caller has announced once (qc_host_register; what the bindings do for the vectors their
-    # closures hand out and an evaluator for its residual cache): the kernel writes it in place, no device-to-host copy, no pinning
-    Fr = np.zeros(int(dims.F_len))
-    if hasattr(dyn, "register_host") and dyn.register_host(Fr):
+    # the residual-only call into pinned memory of the library (qc_host_alloc; where the bindings take the vectors their closures hand
+    # out and an evaluator its residual cache): the kernel writes it in place, no device-to-host copy, no pinning per call
+    Fr = qc.pinned_zeros(int(dims.F_len))
+    if type(Fr.base).__name__ == "_PinnedBlock":
         cFr = [dyn.bind_host("F", Z, F=Fr) for Z in Zs]
-        out["F_registered_ms"] = timed(lambda i: run(cFr[i % nz]), "F_registered_ms")
+        out["F_pinned_ms"] = timed(lambda i: run(cFr[i % nz]), "F_pinned_ms")
         run(cF[0])
         run(cFr[0])
-        assert np.array_equal(Fr, Fh), "registered and plain residual arrays differ"
+        assert np.array_equal(Fr, Fh), "pinned and plain residual arrays differ"
     out["fastest_call_ms"] = dict(mins)
     assert status[0] == 0, "a host-buffer call reported an error"
     # The reference-shaped closures: dynamics.F(Z) / dF(Z) / mu_d2F(Z, mu) RETURN a vector (integrator_test_1qubit.jl:45-52), which is
@@ -242,7 +242,7 @@ def host_visible_record(qc, inp, dyn, Zs, cpu_rec, t1000_equiv=1.0):
     it is measured against: the larger of the PCIe floor (bytes that must cross the link at the copy engine's measured rate) and,
     for the Jacobian, the host-replication floor (the value array written at the rate this host's worker team reaches)."""
     dims = dyn.dims
-    t = host_visible_times(dyn, Zs)
+    t = host_visible_times(qc, dyn, Zs)
     n_int = int(dims.n_intervals)
     n = 2 * inp.system.levels
     nc = inp.system.levels

@@ -234,18 +234,18 @@ int qc_set_new_x(qc_handle* h, int new_x);
  * moves it.  qc_rollout keeps its trajectory vector in a buffer of its own and does not count. */
 int64_t qc_knot_generation(const qc_handle* h);
 
-/* Long-lived caller arrays (optional).  The host-buffer calls move Z, mu, the residuals and the Hessian values between the caller's
- * arrays and the device with the GPU's copy engine; for ordinary (pageable) memory the runtime pins the pages for the duration of every
- * call.  An array announced here is pinned ONCE (hipHostRegister, visible to every device) and from then on
- *   - qc_eval_F writes the residuals into it straight from the kernel -- no device-to-host copy at all (config 3: 0.06 ms per call
- *     instead of 0.085, profiles/r04_f_path_probe.txt); rows no kernel writes (QC_ROWS_BY_COMPONENT) keep the copy;
+/* Pinned host memory for long-lived arrays (optional).  The host-buffer calls move Z, mu, the residuals and the Hessian values between
+ * the caller's arrays and the device with the GPU's copy engine; for ordinary (pageable) memory the runtime pins the pages for the
+ * duration of every call.  Memory from qc_host_alloc is pinned for good (hipHostMalloc, visible to every device):
+ *   - qc_eval_F writes the residuals into it straight from the kernel -- no device-to-host copy at all (config 3: 0.07 ms per call
+ *     instead of 0.09, profiles/r04_f_path_probe.txt); layouts with rows no kernel writes (QC_ROWS_BY_COMPONENT) keep the copy;
  *   - every other transfer from / into it skips the per-call pinning.
- * The values are the same to the bit.  The range must stay allocated until qc_host_unregister(p) (same p; ~0.4 ms) -- registering an
- * array and freeing it without unregistering leaves the GPU writing into pages the process no longer sees.  The bindings register the
- * result vectors their closures hand out (they own them); an evaluator does the same for its residual cache.  Process-wide,
- * thread-safe; not tied to a handle. */
-int qc_host_register(void* p, int64_t bytes);
-int qc_host_unregister(void* p);
+ * The values are the same to the bit.  The bindings take the result vectors their closures hand out from here, an evaluator its
+ * residual cache.  (Pinning arrays the CALLER allocated -- hipHostRegister -- was built first and withdrawn: under allocator churn in a
+ * long-running process the GPU's writes into such ranges faulted intermittently, profiles/NOTES.md.)  Process-wide, thread-safe, not
+ * tied to a handle; QC_ERR_NO_DEVICE without a GPU. */
+int qc_host_alloc(int64_t bytes, void** out);
+int qc_host_free(void* p);
 
 /* ---- evaluation, device-resident (asynchronous on `stream`, a hipStream_t) --------------------- */
 /* dZ: device pointer to the full Z vector (8-byte aligned).  dF may be NULL (skip residual store);

@@ -76,16 +76,18 @@ struct ResultRing
     bufs::Vector{Vector{Float64}}
     next::Base.RefValue{Int}
 end
-function ResultRing(len::Integer, n::Integer)
-    bufs = [zeros(Float64, len) for _ in 1:n]
-    # the ring's vectors live as long as the evaluator: pinned once (`qc_host_register`), so that `F` has the kernel write into them in
-    # place and the other closures' copies skip the per-call pinning; `unregister!` runs in the evaluator's finalizer, before `qc_destroy`
-    for v in bufs
-        len > 0 && ccall((:qc_host_register, LIB[]), Cint, (Ptr{Cvoid}, Int64), pointer(v), sizeof(v))      # (failure = not pinned: harmless)
-    end
-    return ResultRing(bufs, Ref(1))
+# A Float64 vector in pinned host memory of the library (`qc_host_alloc`): the copy engine moves data from / into it without pinning
+# pages per call, and `F` has the kernel write the residuals into it in place.  Freed (`qc_host_free`, process-wide) when the vector is
+# garbage-collected -- a result the caller still holds outlives the evaluator.  Ordinary zeros for small vectors or without a GPU.
+function pinned_zeros(len::Integer)
+    len * 8 >= 65536 || return zeros(Float64, len)
+    p = Ref{Ptr{Cvoid}}(C_NULL)
+    ccall((:qc_host_alloc, LIB[]), Cint, (Int64, Ptr{Ptr{Cvoid}}), len * 8, p) == 0 || return zeros(Float64, len)
+    v = unsafe_wrap(Array, Ptr{Float64}(p[]), len; own=false)
+    finalizer(_ -> ccall((:qc_host_free, LIB[]), Cint, (Ptr{Cvoid},), p[]), v)
+    return fill!(v, 0.0)
 end
-unregister!(r::ResultRing) = foreach(v -> isempty(v) || ccall((:qc_host_unregister, LIB[]), Cint, (Ptr{Cvoid},), pointer(v)), r.bufs)
+ResultRing(len::Integer, n::Integer) = ResultRing([pinned_zeros(len) for _ in 1:(len > 0 ? n : 0)], Ref(1))
 function next!(r::ResultRing, len::Integer, fresh::Bool)
     (fresh || isempty(r.bufs)) && return Vector{Float64}(undef, len)
     v = r.bufs[r.next[]]
@@ -97,7 +99,7 @@ end
 Field-compatible stand-in for `QuantumDynamics` (QuantumCollocationCore.Dynamics).
 
 `F(Z⃗)`, `∂F(Z⃗)`, `μ∂²F(Z⃗, μ⃗)` -- the only shapes QuantumCollocationCore's evaluator uses (test/scripts/integrator_test_1qubit.jl:45-52)
--- return the next vector of a ring of `result_ring` (default 3) result vectors per closure, written once when the ring is built:
+-- return the next vector of a ring of `result_ring` (default 3) result vectors per closure, pinned and written once when the ring is built:
 a result stays intact until the `result_ring`-th next call OF THE SAME CLOSURE (the evaluator copies it into Ipopt's buffer at once).
 A fresh `Vector{Float64}(undef, 5_034_960)` per `∂F` call costs 2.7 - 4 ms of first-touch page faults at BASELINE config 3, ten times
 the evaluation.  `∂F(Z⃗; fresh=true)` (or `result_ring = 0`) returns a newly allocated vector that is the caller's for good.
@@ -210,11 +212,7 @@ function dynamics(integrators, traj, system; device::Int=0, devices=nothing, eva
         μ∂²F = (Z⃗, μ⃗; fresh::Bool=false) -> μ∂²F!(next!(ringH, d.hess_nnz, fresh), Z⃗, μ⃗)
     end
     dyn = HIPDynamics(h[], d, F, ∂F, ∂F_structure, μ∂²F, μ∂²F_structure, Int(bycomp ? traj.dims.states : d.ddim), F!, ∂F!, μ∂²F!)
-    rings = isnothing(μ∂²F) ? (ringF, ring∂F) : (ringF, ring∂F, ringH)
-    finalizer(dyn) do x
-        foreach(unregister!, rings)
-        ccall((:qc_destroy, LIB[]), Cvoid, (Ptr{Cvoid},), x.handle)
-    end
+    finalizer(x -> ccall((:qc_destroy, LIB[]), Cvoid, (Ptr{Cvoid},), x.handle), dyn)
     return dyn
 end
 

@@ -7,7 +7,7 @@ of include/qcolloc.h.  The directory name carries a dot, so load it through
 from . import _lib
 from ._lib import QCollocError
 from .evaluator import QuantumControlEvaluator
-from .dynamics import ComposedQuantumDynamics, QuantumDynamics, desc_dims, desc_structures, make_desc, split_groups, state_row_offset
+from .dynamics import ComposedQuantumDynamics, QuantumDynamics, desc_dims, desc_structures, make_desc, pinned_zeros, split_groups, state_row_offset
 from .gates import GATES, PAULIS, operator_from_string
 from .integrators import (DensityOperatorExponentialIntegrator, DerivativeIntegrator, QuantumStateExponentialIntegrator, QuantumStatePadeIntegrator,
                           UnitaryExponentialIntegrator, UnitaryPadeIntegrator)

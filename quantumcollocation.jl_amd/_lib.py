@@ -161,8 +161,8 @@ SYMBOLS = {
     "qc_eval_hess": (C.c_int, [_H, _c_double_p, _c_double_p, _c_double_p]),
     "qc_set_new_x": (C.c_int, [_H, C.c_int]),
     "qc_knot_generation": (C.c_int64, [_H]),
-    "qc_host_register": (C.c_int, [C.c_void_p, C.c_int64]),
-    "qc_host_unregister": (C.c_int, [C.c_void_p]),
+    "qc_host_alloc": (C.c_int, [C.c_int64, C.POINTER(C.c_void_p)]),
+    "qc_host_free": (C.c_int, [C.c_void_p]),
     "qc_eval_F_jac_dev": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "qc_eval_hess_dev": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "qc_eval_F_jac_hess_dev": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -546,13 +546,13 @@ static void pool_memcpy(double* dst, const double* src, size_t n, int workers) {
 }
 
 // ------------------------------------------------------------------------------------------------
-//  Registered caller arrays (qc_host_register)
+//  Pinned blocks handed to the caller (qc_host_alloc)
 // ------------------------------------------------------------------------------------------------
 namespace {
 struct HostRange { char* base; size_t bytes; };
 std::mutex g_reg_mu;
 std::vector<HostRange> g_reg;
-// the registered range that holds [p, p + bytes), as a device pointer of the CURRENT device; nullptr when there is none
+// [p, p + bytes) inside a block of qc_host_alloc: its device pointer on the CURRENT device; nullptr when it is ordinary memory
 double* registered_device_ptr(const void* p, size_t bytes) {
     const char* q = static_cast<const char*>(p);
     bool found = false;
@@ -567,28 +567,33 @@ double* registered_device_ptr(const void* p, size_t bytes) {
 }
 }  // namespace
 
-extern "C" int qc_host_register(void* p, int64_t bytes) {
-    if (!p || bytes <= 0) return fail(nullptr, QC_ERR_INVALID, "qc_host_register: NULL or empty range");
+extern "C" int qc_host_alloc(int64_t bytes, void** out) {
+    if (!out || bytes <= 0) return fail(nullptr, QC_ERR_INVALID, "qc_host_alloc: NULL output or empty size");
+    *out = nullptr;
+    void* p = nullptr;
+    const hipError_t e = hipHostMalloc(&p, (size_t)bytes, hipHostMallocPortable | hipHostMallocMapped);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(nullptr, e == hipErrorNoDevice || e == hipErrorInvalidDevice ? QC_ERR_NO_DEVICE : QC_ERR_HIP, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+    }
     std::lock_guard<std::mutex> lk(g_reg_mu);
-    for (const HostRange& r : g_reg)
-        if (static_cast<char*>(p) < r.base + r.bytes && r.base < static_cast<char*>(p) + bytes)
-            return fail(nullptr, QC_ERR_INVALID, "qc_host_register: the range overlaps a registered one");
-    const hipError_t e = hipHostRegister(p, (size_t)bytes, hipHostRegisterPortable | hipHostRegisterMapped);
-    if (e != hipSuccess) { (void)hipGetLastError(); return fail(nullptr, QC_ERR_HIP, std::string("hipHostRegister: ") + hipGetErrorString(e)); }
     g_reg.push_back(HostRange{static_cast<char*>(p), (size_t)bytes});
+    *out = p;
     return QC_OK;
 }
 
-extern "C" int qc_host_unregister(void* p) {
-    std::lock_guard<std::mutex> lk(g_reg_mu);
-    for (size_t i = 0; i < g_reg.size(); ++i) {
-        if (g_reg[i].base != static_cast<char*>(p)) continue;
+extern "C" int qc_host_free(void* p) {
+    if (!p) return QC_OK;
+    {
+        std::lock_guard<std::mutex> lk(g_reg_mu);
+        size_t i = 0;
+        for (; i < g_reg.size(); ++i) if (g_reg[i].base == static_cast<char*>(p)) break;
+        if (i == g_reg.size()) return fail(nullptr, QC_ERR_INVALID, "qc_host_free: not a block of qc_host_alloc");
         g_reg.erase(g_reg.begin() + (long)i);
-        const hipError_t e = hipHostUnregister(p);
-        if (e != hipSuccess) { (void)hipGetLastError(); return fail(nullptr, QC_ERR_HIP, std::string("hipHostUnregister: ") + hipGetErrorString(e)); }
-        return QC_OK;
     }
-    return fail(nullptr, QC_ERR_INVALID, "qc_host_unregister: not the start of a registered range");
+    const hipError_t e = hipHostFree(p);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(nullptr, QC_ERR_HIP, std::string("hipHostFree: ") + hipGetErrorString(e)); }
+    return QC_OK;
 }
 
 extern "C" int qc_set_new_x(qc_handle* h, int new_x) {
@@ -784,7 +789,7 @@ static int eval_host(qc_handle* h, const double* Z, double* F, double* vals, int
     if (!vals) {
         // residuals only (a line-search trial): kernel -> HBM -> one copy into the caller's array.  (Rows no kernel writes --
         // QC_ROWS_BY_COMPONENT -- stay zero in the device vector.)
-        // A registered array (qc_host_register) takes the residuals straight from the kernel: no device-to-host copy, no pinning
+        // Memory of qc_host_alloc takes the residuals straight from the kernel: no device-to-host copy, no pinning
         // (QC_HOST_F_DIRECT=0: the copy, for A/B runs).  Not where the layout has rows no kernel writes: the copy delivers their zeros.
         static const bool f_direct = !(getenv("QC_HOST_F_DIRECT") && atoi(getenv("QC_HOST_F_DIRECT")) == 0);
         const bool rows_all_written = P.F_stride == P.ddim && P.F_off == 0;

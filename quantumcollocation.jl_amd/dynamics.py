@@ -19,6 +19,8 @@ newly allocated vector that is the caller's for good; `out=` writes into the cal
 from __future__ import annotations
 
 import ctypes as C
+import os
+import sys
 from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -31,6 +33,38 @@ from .named_trajectory import NamedTrajectory
 
 _KERNELS = {"auto": _lib.QC_KERNEL_AUTO, "lds": _lib.QC_KERNEL_LDS, "mfma": _lib.QC_KERNEL_MFMA}
 _ALIASES = {"∂F": "dF", "μ∂²F": "mu_d2F", "∂F_structure": "dF_structure", "μ∂²F_structure": "mu_d2F_structure"}
+
+
+class _PinnedBlock:
+    """Owner of one block of qc_host_alloc, and its array-interface front: numpy keeps this object as the base of every array that
+    views the block, so the block is freed when the last of them is gone (never during interpreter shutdown)."""
+
+    def __init__(self, ptr: int, n: int):
+        self.ptr = ptr
+        self.__array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 3}
+
+    def __del__(self):
+        try:
+            if self.ptr and not sys.is_finalizing():
+                _lib.lib.qc_host_free(C.c_void_p(self.ptr))
+        except Exception:   # noqa: BLE001
+            pass
+        self.ptr = 0
+
+
+def pinned_zeros(n: int) -> np.ndarray:
+    """A float64 vector of n zeros in pinned host memory of the library (qc_host_alloc): the copy engine moves data from / into it
+    without pinning pages per call, and `F(Z, out=...)` has the kernel write the residuals into it in place.  Ordinary zeros where there
+    is no GPU (or n is too small to matter).  The memory is freed when the last view of it is garbage-collected."""
+    n = int(n)
+    if n * 8 < (64 << 10) or os.environ.get("QC_NO_PINNED"):
+        return np.zeros(n)
+    p = C.c_void_p()
+    if _lib.lib.qc_host_alloc(n * 8, C.byref(p)) != 0 or not p.value:
+        return np.zeros(n)
+    out = np.asarray(_PinnedBlock(p.value, n))
+    out[:] = 0.0
+    return out
 
 
 def split_groups(integrators: Sequence):
@@ -229,16 +263,10 @@ class QuantumDynamics:
         self._structs = None
 
     # -- lifetime --------------------------------------------------------------------------------
-    def _unregister_all(self):
-        for arr in getattr(self, "_registered", []):
-            _lib.lib.qc_host_unregister(C.c_void_p(arr.ctypes.data))
-        self._registered = []
-
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
             _lib.lib.qc_destroy(self._h)
             self._h = None
-        self._unregister_all()
 
     def __del__(self):
         try:
@@ -312,18 +340,6 @@ class QuantumDynamics:
             raise ValueError("result_ring must be 0 (fresh vectors) or at least 3 (the previous two results of a closure stay intact)")
         self.result_ring = int(result_ring)
         self._rings = {}           # closure slot -> [next index, [vectors]]
-        self._registered = []      # arrays announced to the library (qc_host_register): unregistered by close()
-
-    def register_host(self, arr: np.ndarray) -> bool:
-        """Announce a long-lived float64 array to the library (qc_host_register): pinned once instead of per call; `F(Z, out=arr)`
-        then has the kernel write the residuals into it in place (no device-to-host copy).  The array must stay alive until `close()`
-        (this object keeps a reference).  Returns False where registration is not possible (no GPU, overlapping range)."""
-        if not (isinstance(arr, np.ndarray) and arr.dtype == np.float64 and arr.flags.c_contiguous and arr.size):
-            raise ValueError("register_host takes a non-empty contiguous float64 array")
-        if _lib.lib.qc_host_register(C.c_void_p(arr.ctypes.data), arr.nbytes) != 0:
-            return False
-        self._registered.append(arr)
-        return True
 
     def _out(self, name: str, n: int, out: Optional[np.ndarray] = None, fresh: bool = False, slot: Optional[str] = None) -> np.ndarray:
         """Result array of `n` doubles: the caller's `out`; else (fresh=True, or no ring) a newly allocated array; else the next
@@ -337,10 +353,7 @@ class QuantumDynamics:
             return np.empty(n)
         ring = self._rings.get(slot or name)
         if ring is None:
-            ring = self._rings[slot or name] = [0, [np.zeros(n) for _ in range(self.result_ring)]]
-            if hasattr(self, "_h") or hasattr(self, "_parts"):       # (a live evaluator: the vectors are this object's, so it may pin them)
-                for v in ring[1]:
-                    QuantumDynamics.register_host(self, v)
+            ring = self._rings[slot or name] = [0, [pinned_zeros(n) for _ in range(self.result_ring)]]
         i = ring[0]
         ring[0] = (i + 1) % self.result_ring
         return ring[1][i]
@@ -554,7 +567,6 @@ class ComposedQuantumDynamics(QuantumDynamics):
             if h:
                 _lib.lib.qc_destroy(h)
         self._parts = []
-        self._unregister_all()
 
     def _structure(self, one_based=False):
         n_int = int(self.dims.n_intervals)

@@ -50,8 +50,9 @@ class QuantumControlEvaluator:
         self.n_dynamics_rows = int(d.n_rows)
         self.n_constraints = self.n_dynamics_rows + sum(int(c.dim) for c in self.constraints)
         self._F = np.zeros(self.n_dynamics_rows)
-        if hasattr(dynamics, "register_host") and self._F.size:
-            dynamics.register_host(self._F)             # the residual cache lives as long as the dynamics: pinned once, written in place
+        if hasattr(dynamics, "result_ring"):            # the library's dynamics: the residual cache in pinned memory, written in place by the kernel
+            from .dynamics import pinned_zeros
+            self._F = pinned_zeros(self.n_dynamics_rows)
         self._x_F: Optional[np.ndarray] = None          # the x the cached residuals belong to == the x whose knots are on the device
         self._gen_F = -1                                # ... as long as the handle's upload count is still this one (knot_generation)
         self.stats = {"F": 0, "F_dF": 0, "dF": 0, "mu_d2F": 0, "reused_F": 0, "uploads_elided": 0}

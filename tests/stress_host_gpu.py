@@ -43,6 +43,8 @@ for trial in range(trials):
     kets = int(rng.integers(1, min(N, 6) + 1)) if rng.random() < 0.25 else 0
     system = qc.QuantumSystem(herm(N), [herm(N) for _ in range(max(m, 1))][:m] if m else [])
     tag = f"trial {trial}: N={N} m={m} T={T} ft={free_time} kets={kets}"
+    if os.environ.get("QC_STRESS_VERBOSE"):
+        print(tag, flush=True)
     try:
         if kets:
             basis = np.eye(N, dtype=complex)

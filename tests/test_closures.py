@@ -73,11 +73,12 @@ def test_closure_results_stay_intact_for_two_more_calls(qc, oracle, cfg, T):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("cfg,T,devices", [(1, 20, None), (3, 300, None), (5, 9, None), (3, 300, [0, 0, 0])])
-def test_registered_arrays_take_the_residuals_in_place(qc, oracle, cfg, T, devices):
-    """qc_host_register: an array announced once is written by the residual kernel directly (no device-to-host copy); same bits as
-    the copy into an ordinary array; a slice of a registered array counts; unregistering restores the copy; a layout with rows no kernel
-    writes keeps the copy (its zeros must be delivered)."""
+def test_pinned_arrays_take_the_residuals_in_place(qc, oracle, cfg, T, devices):
+    """qc_host_alloc: memory the library has pinned is written by the residual kernel directly (no device-to-host copy); same bits as
+    the copy into an ordinary array; a slice of a block counts; a layout with rows no kernel writes keeps the copy (its zeros must
+    be delivered); the closures' own vectors come from there."""
     import ctypes as C
+    import gc
     L = qc._lib
     inp = qc.config_inputs(cfg, T=T)
     dyn = qc.QuantumDynamics(inp.integrators, inp.traj, devices=devices, result_ring=0)
@@ -85,40 +86,49 @@ def test_registered_arrays_take_the_residuals_in_place(qc, oracle, cfg, T, devic
     Z = inp.traj.datavec + 1e-2 * rng.standard_normal(inp.traj.datavec.size)
     n = int(dyn.dims.F_len)
     plain = dyn.F(Z, out=np.full(n, np.nan))
-    big = np.full(n + 64, np.nan)
-    assert L.lib.qc_host_register(C.c_void_p(big.ctypes.data), big.nbytes) == 0
-    assert L.lib.qc_host_register(C.c_void_p(big.ctypes.data + 8), 64) != 0            # overlaps
-    assert L.lib.qc_host_unregister(C.c_void_p(big.ctypes.data + 8)) != 0              # not the start of a range
+    p = C.c_void_p()
+    assert L.lib.qc_host_alloc((n + 64) * 8, C.byref(p)) == 0 and p.value
+    big = np.ctypeslib.as_array((C.c_double * (n + 64)).from_address(p.value))
+    big[:] = np.nan
     view = big[7:7 + n]
     dyn.F(Z, out=view)
     assert np.array_equal(view, plain) and np.isnan(big[:7]).all() and np.isnan(big[7 + n:]).all()
-    F2, J2 = dyn.F_dF(Z, out=(view, np.empty(int(dyn.dims.jac_nnz))))               # the other calls accept registered arrays as well
+    F2, J2 = dyn.F_dF(Z, out=(view, np.empty(int(dyn.dims.jac_nnz))))               # the other calls accept pinned arrays as well
     assert np.array_equal(F2, plain)
-    view[:] = np.nan
-    assert L.lib.qc_host_unregister(C.c_void_p(big.ctypes.data)) == 0
-    dyn.F(Z, out=view)
-    assert np.array_equal(view, plain)
+    if dyn.dims.hess_nnz:
+        mu = rng.standard_normal(int(dyn.dims.n_rows))
+        Hp = qc.pinned_zeros(int(dyn.dims.hess_nnz))
+        assert np.array_equal(dyn.mu_d2F(Z, mu, out=Hp), dyn.mu_d2F(Z, mu, out=np.empty(Hp.size)))
+    assert L.lib.qc_host_free(C.c_void_p(p.value + 8)) != 0                          # not the start of a block
+    del view, big, F2
+    assert L.lib.qc_host_free(p) == 0 and L.lib.qc_host_free(p) != 0                 # (a second free of the same block is refused)
     dyn.close()
-    # the closures' own vectors are registered by the binding (and unregistered by close())
+    # the closures' own vectors are pinned blocks (for sizes where it matters), released when the last reference goes
     d2 = qc.QuantumDynamics(inp.integrators, inp.traj, devices=devices)
     f = d2.F(Z)
-    assert np.array_equal(f, plain) and len(d2._registered) == 3
+    assert np.array_equal(f, plain)
+    assert (type(f.base).__name__ == "_PinnedBlock") == (f.nbytes >= (64 << 10))
     d2.close()
-    assert d2._registered == []
+    assert np.array_equal(f, plain)                   # a result outlives its evaluator
+    del f, d2
+    gc.collect()
     if cfg == 1 and devices is None:      # rows placed by component: a state component without an integrator leaves rows no kernel writes
-        from types import SimpleNamespace
         tr = inp.traj
+        Tl = 600                          # (long enough for the residual vector to be worth pinning)
+        inl = qc.config_inputs(1, T=Tl)
+        tr = inl.traj
         comps = {nm: tr.data[r.start:r.stop] for nm, r in tr.components.items()}
         comps["g"] = rng.standard_normal((3, tr.T))
         names = list(comps)
         names.insert(1, names.pop(names.index("g")))
         traj = qc.NamedTrajectory({k: comps[k] for k in names}, controls=tr.controls, timestep=tr.timestep)
-        integ = [qc.UnitaryPadeIntegrator("Ũ⃗", "a", inp.system, traj, order=4), qc.DerivativeIntegrator("a", "da", traj),
+        integ = [qc.UnitaryPadeIntegrator("Ũ⃗", "a", inl.system, traj, order=4), qc.DerivativeIntegrator("a", "da", traj),
                  qc.DerivativeIntegrator("da", "dda", traj)]
         d3 = qc.QuantumDynamics(integ, traj, rows="by_component", result_ring=0)
         ref = d3.F(traj.datavec, out=np.full(int(d3.dims.F_len), np.nan))
-        reg = np.full(int(d3.dims.F_len), np.nan)
-        assert d3.register_host(reg)
+        reg = qc.pinned_zeros(int(d3.dims.F_len))
+        assert type(reg.base).__name__ == "_PinnedBlock"
+        reg[:] = np.nan
         d3.F(traj.datavec, out=reg)
         assert np.array_equal(reg, ref) and (ref.reshape(traj.T - 1, -1)[:, 8:11] == 0.0).all()
         d3.close()
