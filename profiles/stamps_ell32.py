@@ -57,5 +57,5 @@ for name, off, labels in (("first compute wave", 0, comp), ("copy wave 0" if whi
             continue
         col = rel[ok, off + k]
         step = "" if prev is None else f"  (+{np.median(rel[ok, off + k] - rel[ok, off + prev]):.2f})"
-        print(f"   {name:18s} {k} {labels[k]:44s} min {col.min():6.2f} median {np.median(col):6.2f}  max {col.max():6.2f} us{step}")
+        print(f"   {name:18s} {k} {labels[k]:44s} min {col.min():6.2f} median {np.median(col):6.2f}  90% {np.quantile(col, 0.9):6.2f}  99% {np.quantile(col, 0.99):6.2f}  max {col.max():6.2f} us{step}")
         prev = k

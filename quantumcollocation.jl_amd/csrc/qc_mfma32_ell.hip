@@ -258,7 +258,7 @@ __global__ __launch_bounds__(kEThreads, 4) void qc_mfma32_ell_kernel(const doubl
                                                                      const double* __restrict__ hot_mu0, const char* __restrict__ hot_ell,
                                                                      const int hot_n_int, const int hot_zdim, const int hot_m,
                                                                      const int hot_off_a, const int hot_off_dt, const int hot_off_U,
-                                                                     const int hot_f_stride, const int hot_unused, const QcParams Pk,
+                                                                     const int hot_f_stride, const int hot_flags, const QcParams Pk,
                                                                      double* __restrict__ F, double* __restrict__ Jv, double* __restrict__ H) {
     constexpr int L = R == 1 ? 64 : 256;          // padded length of a pair list (fixed by R: at most 32 * 2 R^2 entries)
     constexpr int kFirst = JAC ? 2 : 0;           // first compute wave (waves 0, 1 of a JAC instantiation are the copy waves)
@@ -414,6 +414,9 @@ __global__ __launch_bounds__(kEThreads, 4) void qc_mfma32_ell_kernel(const doubl
         QC_STAMP(P, b, lane, 4);
     } else {
         // ================= compute wave ====================================================================================
+        // (hot_flags bit 0, QC_ELL_FLAGS: the compute waves of a launch with copy waves issue at a higher priority -- their stores are a
+        //  quarter of the bytes and sit on the critical path of the workgroup, the copy waves' stream fills whatever is left)
+        if (JAC && (hot_flags & 1)) __builtin_amdgcn_s_setprio(2);
         if (ld_m) {
             const int I = cw - (kCW - 4);
             plain_st(Mp, I, g, j, col16_finish(raw0));                         // lane (g, j) reg r = M[16 I + 4 r + g][j]
@@ -712,7 +715,11 @@ int qc_mfma32_ell_build(const QcParams& P, const double* G, std::vector<char>* b
 }
 
 #define QC_ELL_ARGS(F_, J_, H_) P.Gx, dZ + P.t_begin * (long long)P.zdim, dMu ? dMu + P.t_begin * P.F_stride + P.F_off : nullptr, (const char*)P.ell, \
-                    P.n_int, P.zdim, P.m, P.off_a, P.off_dt, P.off_U, (int)P.F_stride, P.ell_slots, P, F_, J_, H_
+                    P.n_int, P.zdim, P.m, P.off_a, P.off_dt, P.off_U, (int)P.F_stride, ell_flags(), P, F_, J_, H_
+static int ell_flags() {
+    static const int v = getenv("QC_ELL_FLAGS") ? atoi(getenv("QC_ELL_FLAGS")) : 0;
+    return v;
+}
 #define QC_ELL_GO(R_, JAC_, HESS_, DIAG_, S_, F_, J_, H_) \
     hipLaunchKernelGGL((qc_mfma32_ell_kernel<R_, JAC_, HESS_, DIAG_, S_>), dim3(P.n_int), dim3(kEThreads), 0, st, QC_ELL_ARGS(F_, J_, H_))
 #define QC_ELL_LAUNCH(JAC_, HESS_, F_, J_, H_)                                                                                    \
