@@ -964,6 +964,14 @@ def test_fused_launch_is_bit_identical(qc, case):
     for a, b, what in ((F1, F2, "F"), (J1, J2, "dF"), (H1, H2, "mu_d2F")):
         assert not torch.isnan(b).any(), what
         assert torch.equal(a, b), f"{what}: {(a != b).sum().item()} of {a.numel()} values differ, max {(a - b).abs().max().item():.3e}"
+    if inp.traj.T <= 64:      # ... and the one-call values against the ORACLE directly (every fused instantiation, not only through the two launches)
+        import __graft_entry__ as g
+        o = g.load_oracle()
+        prob = problem_from_inputs(inp)
+        Zh, muh = Z.cpu().numpy(), mu.cpu().numpy()
+        assert_close(F2.cpu().numpy(), o.F(prob, Zh), f"{case}: one-call F vs oracle")
+        assert_close(J2.cpu().numpy(), o.dF(prob, Zh), f"{case}: one-call dF vs oracle")
+        assert_close_h(H2.cpu().numpy(), o.mu_d2F(prob, Zh, muh), f"{case}: one-call mu_d2F vs oracle")
     # without the residuals
     J3, H3 = new(dyn.dims.jac_nnz), new(dyn.dims.hess_nnz)
     dyn.F_dF_mu_d2F_device(Z, mu, None, J3, H3)
@@ -1020,6 +1028,10 @@ def test_two_wave_hessian_kernel_equals_the_one_wave_kernel(qc, oracle, m, free_
     two = qc.QuantumDynamics(inp.integrators, inp.traj, devices=[0, 0])
     short = qc.QuantumDynamics(inp_short.integrators, inp_short.traj)
     assert one.kernel_names[1] == "mfma16-pade4-hess" and short.kernel_names[1] == "mfma16-pade4-hess2", (one.kernel_names, short.kernel_names)
+    # the two-wave kernel against the oracle directly, every value (not only through the one-wave kernel)
+    Zs = inp_short.traj.datavec + 1e-2 * rng.standard_normal(inp_short.traj.datavec.size)
+    mus = rng.standard_normal(int(short.dims.n_rows))
+    assert_close_h(short.mu_d2F(Zs, mus), oracle.mu_d2F(problem_from_inputs(inp_short), Zs, mus), "two-wave kernel vs oracle")
     short.close()
     Z = inp.traj.datavec + 1e-2 * rng.standard_normal(inp.traj.datavec.size)
     mu = rng.standard_normal(int(one.dims.n_rows))
