@@ -258,17 +258,22 @@ __global__ __launch_bounds__(kEThreads, 4) void qc_mfma32_ell_kernel(const doubl
                                                                      const double* __restrict__ hot_mu0, const char* __restrict__ hot_ell,
                                                                      const int hot_n_int, const int hot_zdim, const int hot_m,
                                                                      const int hot_off_a, const int hot_off_dt, const int hot_off_U,
-                                                                     const int hot_f_stride, const int hot_flags, const QcParams Pk,
+                                                                     const int hot_f_stride, const int hot_unused, const QcParams Pk,
                                                                      double* __restrict__ F, double* __restrict__ Jv, double* __restrict__ H) {
     constexpr int L = R == 1 ? 64 : 256;          // padded length of a pair list (fixed by R: at most 32 * 2 R^2 entries)
     constexpr int kFirst = JAC ? 2 : 0;           // first compute wave (waves 0, 1 of a JAC instantiation are the copy waves)
     constexpr int kCW = 8 - kFirst;               // compute waves
     constexpr int kPairsPerWave = (kEMax * (kEMax + 1) / 2 + kCW - 1) / kCW;
     constexpr int kDrivesPerWave = (kEMax + kCW - 1) / kCW;
-    // R = 1, mu_d2F alone: a wave's pair entries (one per lane and pair) are requested with the first loads.  The one-call form has
-    // no registers to hold them through its drives (the values would be spilled where they arrive -- a wait for every load in
-    // front of the spill) and no use for the head start: its time is the stores'.
-    constexpr bool kPrefetchPairs = HESS && !JAC && R == 1;
+    // The pair sums.  R = 1: the entries (one per lane and pair) are requested with the first loads.  mu_d2F alone sums them at the very
+    // end, in one batched reduction with the (a_k, h) sums (measured: summing them before the first drive delays every drive's
+    // products by 1 us and the launch by 0.7).  The one-call form sums them EARLY -- as soon as Q is there, before the wave's first
+    // drive: it has no registers to hold the entries through its drives, and on this hardware a load waits for every store the wave
+    // has issued before it (one in-order counter), so a request behind the drives' stores would hold the wave until its whole backlog
+    // has reached HBM.  R = 2 (four entries per lane and pair): requested behind the state flags, summed early.
+    constexpr bool kPrefetchPairs = HESS && R == 1;
+    constexpr bool kEarlyPairs = HESS && (JAC || R != 1);
+    constexpr int kDF = 2;                        // derivative integrators whose data is requested early and parked in LDS (JAC): the templates have two
     QcKernargTouch<sizeof(QcParams) + 96> touch;
     touch.request();
     __shared__ __attribute__((aligned(16))) double GL[4 * 256];      // G, A-layout tiles 2 I + K
@@ -279,6 +284,7 @@ __global__ __launch_bounds__(kEThreads, 4) void qc_mfma32_ell_kernel(const doubl
     __shared__ double TW[kEMax * R * 32];                            // the drives' rows: weights ...
     __shared__ int TC[kEMax * R * 32];                               // ... and columns (x kPS)
     __shared__ int flags[FL_COUNT];
+    __shared__ double DerL[2 * kDF * 64];                            // derivative-integrator data (JAC), parked from the first loads to the end
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -306,7 +312,11 @@ __global__ __launch_bounds__(kEThreads, 4) void qc_mfma32_ell_kernel(const doubl
     int pov[kPairsPerWave];
     Col16Raw raw0 = {0.0, 0.0, 0.0, 0.0}, raw1 = raw0;      // loader waves: M tile, or U_t / U_t+1 tiles (as requested; transposed behind barrier A)
     double mud[2] = {0.0, 0.0};
+    double dvx[kDF], dva[kDF], dvb[kDF];
     const bool dfast = ft && P.n_deriv <= 2 && P.ddim_i[0] <= 64 && P.ddim_i[1] <= 64;
+    bool rows_fast = JAC && P.n_deriv <= kDF;     // every derivative integrator fits a wave: its rows come from the early requests
+#pragma unroll
+    for (int d = 0; d < kDF; ++d) rows_fast = rows_fast && P.ddim_i[d] <= 64;
     {
         // half (w & 1) of A-layout tile (w >> 1) of G = G_0 + sum_k a_k G_k: two entries per lane, in image order
         const int e0 = (w >> 1) * 256 + (w & 1) * 128 + 2 * lane;
@@ -356,6 +366,15 @@ __global__ __launch_bounds__(kEThreads, 4) void qc_mfma32_ell_kernel(const doubl
 #pragma unroll
             for (int d = 0; d < 2; ++d) mud[d] = mu[dfast ? P.drow[d] + (lane < P.ddim_i[d] ? lane : 0) : 0];
         }
+        if constexpr (JAC) {              // derivative integrators' rows: dx_t, x_t, x_t+1 (every wave asks, wave cw = 1 uses them)
+#pragma unroll
+            for (int d = 0; d < kDF; ++d) {   // (unused slots have zero offsets and dimensions: the requests stay in bounds)
+                const int i = (rows_fast && lane < P.ddim_i[d]) ? lane : 0;
+                dvx[d] = z0[P.dx_off[d] + i];
+                dva[d] = z0[P.x_off[d] + i];
+                dvb[d] = z1[P.x_off[d] + i];
+            }
+        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int sl = 0; sl < SLOTS; ++sl) Gh += v2d{__shfl(amp, k0[sl]), __shfl(amp, k1[sl])} * wv[sl];
@@ -369,6 +388,10 @@ __global__ __launch_bounds__(kEThreads, 4) void qc_mfma32_ell_kernel(const doubl
     double* __restrict__ Fb = (JAC && F) ? F + (size_t)b * P.F_stride + P.F_off : nullptr;
     const double c1 = P.c[1], c2 = P.c[2];
     QC_STAMP(P, b, lane, 1);
+#ifdef QC_ELL_STAMP_BARRIER
+    // diagnostic build (profiles/stamps_ell32_barrier.py): when does EACH wave arrive at barrier A?  slots 0 - 7 = waves 0 - 7
+    if constexpr (DIAG) { if (P.stamps != nullptr && lane == 0) P.stamps[(size_t)b * 16 + w] = qc_ts_[1]; }
+#endif
     __syncthreads();                  // G, the tables and the zeroed counters; the state is still on its way
     const double hc1 = h * c1, hc2 = h * h * c2, c2h2 = 2.0 * c2 * h;
     QC_STAMP(P, b, lane, 2);
@@ -414,9 +437,6 @@ __global__ __launch_bounds__(kEThreads, 4) void qc_mfma32_ell_kernel(const doubl
         QC_STAMP(P, b, lane, 4);
     } else {
         // ================= compute wave ====================================================================================
-        // (hot_flags bit 0, QC_ELL_FLAGS: the compute waves of a launch with copy waves issue at a higher priority -- their stores are a
-        //  quarter of the bytes and sit on the critical path of the workgroup, the copy waves' stream fills whatever is left)
-        if (JAC && (hot_flags & 1)) __builtin_amdgcn_s_setprio(2);
         if (ld_m) {
             const int I = cw - (kCW - 4);
             plain_st(Mp, I, g, j, col16_finish(raw0));                         // lane (g, j) reg r = M[16 I + 4 r + g][j]
@@ -429,6 +449,13 @@ __global__ __launch_bounds__(kEThreads, 4) void qc_mfma32_ell_kernel(const doubl
             plain_st(Dp, I, g, j, dd);
             plain_st(Sp, I, g, j, ss);
             flag_signal(flags, FL_U, lane);
+        }
+        if (JAC && cw == 1 && rows_fast) {
+#pragma unroll
+            for (int d = 0; d < kDF; ++d) {
+                DerL[(2 * d) * 64 + lane] = dvx[d];
+                DerL[(2 * d + 1) * 64 + lane] = dvb[d] - dva[d];
+            }
         }
         flag_wait(flags, FL_U, 2);
         if constexpr (HESS) flag_wait(flags, FL_M, 2);
@@ -463,8 +490,44 @@ __global__ __launch_bounds__(kEThreads, 4) void qc_mfma32_ell_kernel(const doubl
             }
             flag_signal(flags, FL_Q, lane);
         }
+        if constexpr (kEarlyPairs) {
+            // ---- this wave's share of the pair sums, early (see kPrefetchPairs) -----------------------------------------------------
+            double wq[kPairsPerWave][L / 64];
+            int oq[kPairsPerWave][L / 64];
+            if constexpr (kPrefetchPairs) {
+#pragma unroll
+                for (int t = 0; t < kPairsPerWave; ++t) { wq[t][0] = pwv[t]; oq[t][0] = pov[t]; }
+            } else {
+                const double* __restrict__ pw = reinterpret_cast<const double*>(hot_ell + lay.pw);
+                const int* __restrict__ po = reinterpret_cast<const int*>(hot_ell + lay.po);
+#pragma unroll
+                for (int t = 0; t < kPairsPerWave; ++t) {
+                    const int p = cw + kCW * t;
+                    const int pe = p < npairs ? p : 0;
+#pragma unroll
+                    for (int e = 0; e < L / 64; ++e) { wq[t][e] = pw[(size_t)pe * L + 64 * e + lane]; oq[t][e] = po[(size_t)pe * L + 64 * e + lane]; }
+                }
+            }
+            flag_wait(flags, FL_Q, 1);
+            double ps[kPairsPerWave];
+#pragma unroll
+            for (int t = 0; t < kPairsPerWave; ++t) {
+                double acc = wq[t][0] * Qp[oq[t][0]];
+#pragma unroll
+                for (int e = 1; e < L / 64; ++e) acc += wq[t][e] * Qp[oq[t][e]];
+                ps[t] = acc;
+            }
+            wave_sum_multi<kPairsPerWave>(ps);
+            if (lane == 0) {
+#pragma unroll
+                for (int t = 0; t < kPairsPerWave; ++t) {
+                    const int p = cw + kCW * t;
+                    if (p < npairs) Hb[P.ho_aa + p] = hc2 * ps[t];
+                }
+            }
+        }
         // ---- this wave's drives ---------------------------------------------------------------------------------------------
-        double pv[kDrivesPerWave + kPairsPerWave];
+        double pv[kDrivesPerWave];
 #pragma unroll
         for (int t = 0; t < kDrivesPerWave; ++t) {
             pv[t] = 0.0;
@@ -531,37 +594,37 @@ __global__ __launch_bounds__(kEThreads, 4) void qc_mfma32_ell_kernel(const doubl
                 if (t == 0) QC_STAMP(P, b, lane, 6);
             }
         }
-        if constexpr (HESS) {
-            // the (a_k, h) of this wave's drives and its share of the pair sums: one batched reduction
-            flag_wait(flags, FL_Q, 1);
-            if constexpr (kPrefetchPairs) {
+        if constexpr (HESS) {     // the (a_k, h) of this wave's drives -- and, where they have not been summed early, its pair sums: one batched reduction
+            if constexpr (kEarlyPairs) {
+                if (ft) {
+                    wave_sum_multi<kDrivesPerWave>(pv);
+                    if (lane == 0) {
 #pragma unroll
-                for (int t = 0; t < kPairsPerWave; ++t) pv[kDrivesPerWave + t] = pwv[t] * Qp[pov[t]];
-            } else {
-                const double* __restrict__ pw = reinterpret_cast<const double*>(hot_ell + lay.pw);
-                const int* __restrict__ po = reinterpret_cast<const int*>(hot_ell + lay.po);
-#pragma unroll
-                for (int t = 0; t < kPairsPerWave; ++t) {
-                    const int p = cw + kCW * t;              // pairs dealt round-robin over the compute waves
-                    double acc = 0.0;
-                    if (p < npairs) {
-#pragma unroll
-                        for (int e = 0; e < L / 64; ++e) acc += pw[(size_t)p * L + 64 * e + lane] * Qp[po[(size_t)p * L + 64 * e + lane]];
+                        for (int t = 0; t < kDrivesPerWave; ++t) {
+                            const int k = cw + kCW * t;
+                            if (k < m) Hb[P.ho_ah + k] = pv[t];
+                        }
                     }
-                    pv[kDrivesPerWave + t] = acc;
                 }
-            }
-            wave_sum_multi<kDrivesPerWave + kPairsPerWave>(pv);
-            if (lane == 0) {
+            } else {
+                double pq[kDrivesPerWave + kPairsPerWave];
 #pragma unroll
-                for (int t = 0; t < kDrivesPerWave; ++t) {
-                    const int k = cw + kCW * t;
-                    if (ft && k < m) Hb[P.ho_ah + k] = pv[t];
-                }
+                for (int t = 0; t < kDrivesPerWave; ++t) pq[t] = pv[t];
+                flag_wait(flags, FL_Q, 1);
 #pragma unroll
-                for (int t = 0; t < kPairsPerWave; ++t) {
-                    const int p = cw + kCW * t;
-                    if (p < npairs) Hb[P.ho_aa + p] = hc2 * pv[kDrivesPerWave + t];
+                for (int t = 0; t < kPairsPerWave; ++t) pq[kDrivesPerWave + t] = pwv[t] * Qp[pov[t]];
+                wave_sum_multi<kDrivesPerWave + kPairsPerWave>(pq);
+                if (lane == 0) {
+#pragma unroll
+                    for (int t = 0; t < kDrivesPerWave; ++t) {
+                        const int k = cw + kCW * t;
+                        if (ft && k < m) Hb[P.ho_ah + k] = pq[t];
+                    }
+#pragma unroll
+                    for (int t = 0; t < kPairsPerWave; ++t) {
+                        const int p = cw + kCW * t;
+                        if (p < npairs) Hb[P.ho_aa + p] = hc2 * pq[kDrivesPerWave + t];
+                    }
                 }
             }
         }
@@ -614,9 +677,33 @@ __global__ __launch_bounds__(kEThreads, 4) void qc_mfma32_ell_kernel(const doubl
                 qc_hess_tail(Pk, mu, Hb, lane, 64);
             }
         }
-        if (JAC && cw == 1) deriv_rows_generic(P, z0, z1, h, Fb, Jb, lane, false);   // derivative-integrator rows and their Jacobian entries
+        if (JAC && cw == 1) {             // derivative-integrator rows and their Jacobian entries
+            if (rows_fast) {
+                int jo = P.jo_d;
+#pragma unroll
+                for (int d = 0; d < kDF; ++d) {
+                    if (d < P.n_deriv) {
+                        const int dim = P.ddim_i[d], r0 = P.drow[d];
+                        if (lane < dim) {
+                            const double dx = DerL[(2 * d) * 64 + lane], df = DerL[(2 * d + 1) * 64 + lane];
+                            if (Fb) Fb[r0 + lane] = df - h * dx;
+                            if (Jb) {
+                                Jb[jo + lane] = -1.0;
+                                Jb[jo + dim + lane] = 1.0;
+                                Jb[jo + 2 * dim + lane] = -h;
+                                if (ft) Jb[jo + 3 * dim + lane] = -dx;
+                            }
+                        }
+                        jo += (ft ? 4 : 3) * dim;
+                    }
+                }
+            } else {
+                deriv_rows_generic(P, z0, z1, h, Fb, Jb, lane, false);
+            }
+        }
         QC_STAMP(P, b, lane, 7);
     }
+#ifndef QC_ELL_STAMP_BARRIER
     if constexpr (DIAG) {
         // slots 0-7: the first compute wave; 8-15: wave 0 of a JAC instantiation (copy wave), else the last compute wave
         const bool first = cw == 0, second = JAC ? w == 0 : w == 7;
@@ -625,6 +712,7 @@ __global__ __launch_bounds__(kEThreads, 4) void qc_mfma32_ell_kernel(const doubl
             for (int k_ = 0; k_ < 8; ++k_) P.stamps[(size_t)b * 16 + (first ? 0 : 8) + k_] = qc_ts_[k_];
         }
     }
+#endif
 }
 
 }  // namespace
@@ -715,11 +803,7 @@ int qc_mfma32_ell_build(const QcParams& P, const double* G, std::vector<char>* b
 }
 
 #define QC_ELL_ARGS(F_, J_, H_) P.Gx, dZ + P.t_begin * (long long)P.zdim, dMu ? dMu + P.t_begin * P.F_stride + P.F_off : nullptr, (const char*)P.ell, \
-                    P.n_int, P.zdim, P.m, P.off_a, P.off_dt, P.off_U, (int)P.F_stride, ell_flags(), P, F_, J_, H_
-static int ell_flags() {
-    static const int v = getenv("QC_ELL_FLAGS") ? atoi(getenv("QC_ELL_FLAGS")) : 0;
-    return v;
-}
+                    P.n_int, P.zdim, P.m, P.off_a, P.off_dt, P.off_U, (int)P.F_stride, 0, P, F_, J_, H_
 #define QC_ELL_GO(R_, JAC_, HESS_, DIAG_, S_, F_, J_, H_) \
     hipLaunchKernelGGL((qc_mfma32_ell_kernel<R_, JAC_, HESS_, DIAG_, S_>), dim3(P.n_int), dim3(kEThreads), 0, st, QC_ELL_ARGS(F_, J_, H_))
 #define QC_ELL_LAUNCH(JAC_, HESS_, F_, J_, H_)                                                                                    \
