@@ -79,13 +79,25 @@ int main(void) {
         if (qc_abi_version() != QC_VERSION_MAJOR * 1000 + QC_VERSION_MINOR) { fprintf(stderr, "header / library mismatch\n"); return 1; }
         CHECK(qc_set_new_x(h, 1));
         CHECK(qc_eval_F(h, Z, F));
-        CHECK(qc_set_new_x(h, 0));
-        CHECK(qc_eval_jac(h, Z, J2));                 /* (Z is not read) */
-        CHECK(qc_eval_hess(h, Z, mu, H2));
-        CHECK(qc_set_new_x(h, 1));
+        {
+            const int64_t gen = qc_knot_generation(h);    /* uploads so far: the elision below is valid while nobody else has uploaded */
+            CHECK(qc_set_new_x(h, 0));
+            CHECK(qc_eval_jac(h, Z, J2));                 /* (Z is not read) */
+            CHECK(qc_eval_hess(h, Z, mu, H2));
+            CHECK(qc_set_new_x(h, 1));
+            if (qc_knot_generation(h) != gen) { fprintf(stderr, "an elided call uploaded\n"); return 1; }
+        }
         printf("ipopt order: %s\n", memcmp(J, J2, (size_t)dims.jac_nnz * sizeof(double)) == 0 &&
                                      memcmp(H, H2, (size_t)dims.hess_nnz * sizeof(double)) == 0 ? "same values" : "DIFFERENT VALUES");
         free(J2); free(H2);
+    }
+    /* A long-lived result array in pinned memory of the library: the residual kernel writes it in place (no device-to-host copy). */
+    {
+        void* p = NULL;
+        CHECK(qc_host_alloc((int64_t)dims.F_len * (int64_t)sizeof(double), &p));
+        CHECK(qc_eval_F(h, Z, (double*)p));
+        printf("pinned residuals: %s\n", memcmp(F, p, (size_t)dims.F_len * sizeof(double)) == 0 ? "same values" : "DIFFERENT VALUES");
+        CHECK(qc_host_free(p));
     }
     qc_destroy(h);
     free(Z); free(F); free(J); free(H); free(mu); free(rows); free(cols);

@@ -284,6 +284,7 @@ def test_c_example_matches_the_python_mirror(qc, tmp_path):
     r = subprocess.run([str(exe)], capture_output=True, text=True, check=True)
     m = re.search(r"checksums F (\S+) dF (\S+) mu_d2F (\S+) first entry \((\d+),(\d+)\)", r.stdout)
     assert m, r.stdout
+    assert "pinned residuals: same values" in r.stdout, r.stdout                       # qc_host_alloc: residuals written in place by the kernel
     assert "ipopt order: same values" in r.stdout, r.stdout          # qc_set_new_x(h, 0): Jacobian / Hessian at the point of the last F call
     N, M, T = 2, 2, 6
     S = 2 * N * N

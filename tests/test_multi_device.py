@@ -278,7 +278,7 @@ def test_sharded_dynamics_with_real_handles(qc, oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nq", [1, 3])
+@pytest.mark.parametrize("nq", [1, 3, 4])      # (4 qubits: the sparse-drive kernels of qc_mfma32_ell.hip, one derivative integrator)
 def test_rows_by_component_on_the_device(qc, oracle, nq):
     """The reference harness layout (state component g without an integrator): F has Z.dims.states rows per interval with
     zeros in the empty rows, mu of that length is accepted, values equal the oracle's; also through a multi-device handle."""
