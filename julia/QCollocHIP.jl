@@ -71,7 +71,8 @@ end
 
 pad8(v) = ntuple(i -> i <= length(v) ? Int32(v[i]) : Int32(0), QC_MAX_DERIV)
 
-# Result vectors of one closure, handed out in turn.  `zeros` writes every page here, once, so that no call pays for page faults.
+# Result vectors of one closure, handed out in turn: allocated (pinned) and written once when the ring is built, so that no call pays for
+# page faults or per-call pinning.
 struct ResultRing
     bufs::Vector{Vector{Float64}}
     next::Base.RefValue{Int}
@@ -87,7 +88,7 @@ function pinned_zeros(len::Integer)
     finalizer(_ -> ccall((:qc_host_free, LIB[]), Cint, (Ptr{Cvoid},), p[]), v)
     return fill!(v, 0.0)
 end
-ResultRing(len::Integer, n::Integer) = ResultRing([pinned_zeros(len) for _ in 1:(len > 0 ? n : 0)], Ref(1))
+ResultRing(len::Integer, n::Integer) = ResultRing(Vector{Float64}[pinned_zeros(len) for _ in 1:(len > 0 ? n : 0)], Ref(1))
 function next!(r::ResultRing, len::Integer, fresh::Bool)
     (fresh || isempty(r.bufs)) && return Vector{Float64}(undef, len)
     v = r.bufs[r.next[]]
