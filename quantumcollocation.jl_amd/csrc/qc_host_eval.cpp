@@ -480,7 +480,7 @@ static int run_chunks(qc_handle* h, const CompactPlan& cp, double* F, double* va
         else {
             unsigned spins = 0;
             while ((ew = hipEventQuery(h->chunk_events[k])) == hipErrorNotReady) {
-                if ((++spins & 1023) == 0 && now_us() - t_begin > qc_team::timeout_us()) return timed_out(h, "a chunk of the compact transfer");
+                if ((++spins & qc_team::deadline_check_mask()) == 0 && now_us() - t_begin > qc_team::timeout_us()) return timed_out(h, "a chunk of the compact transfer");
                 cpu_pause();
             }
         }
@@ -652,7 +652,7 @@ static int wait_done(qc_handle* h, int shards) {
     const double t0 = now_us();
     unsigned spins = 0;
     while ((e = hipEventQuery(h->ev_done)) == hipErrorNotReady) {
-        if ((++spins & 1023) == 0 && now_us() - t0 > qc_team::timeout_us()) return timed_out(h, "the evaluation");
+        if ((++spins & qc_team::deadline_check_mask()) == 0 && now_us() - t0 > qc_team::timeout_us()) return timed_out(h, "the evaluation");
         if (shards > 1) sched_yield(); else cpu_pause();
     }
     if (e != hipSuccess) {

@@ -49,6 +49,9 @@ inline double timeout_us() {
     return o > 0.0 ? o : v;
 }
 
+// the clock is read every 1024th turn of a spin loop (a deadline below a millisecond -- tests -- is checked on every turn)
+inline unsigned deadline_check_mask() { return timeout_us() < 1e3 ? 0u : 1023u; }
+
 inline qc_copy_fn host_copy() {
     static qc_copy_fn fn = [] {
         qc_copy_fn f = nullptr;
@@ -227,7 +230,7 @@ inline void land_wait(LandJob& J, const double* p, size_t n, const land_poll_fn*
         if (spins == 0 && host_trace()) J.blocks_waited.fetch_add(1, std::memory_order_relaxed);
         ++spins;
         if (poll && (spins & 15) == 0) land_poll(J, *poll);
-        if ((spins & 1023) == 0) land_check_deadline(J);
+        if ((spins & deadline_check_mask()) == 0) land_check_deadline(J);
         cpu_pause();
     }
 }
@@ -286,7 +289,7 @@ inline void land_consume(LandJob& J, const land_poll_fn* poll) {
         }
         if (poll && !all) land_poll(J, *poll);
         if (!got) {
-            if ((++idle & 1023) == 0) land_check_deadline(J);
+            if ((++idle & deadline_check_mask()) == 0) land_check_deadline(J);
             cpu_pause();
         }
     }

@@ -185,3 +185,35 @@ def test_upload_elision_is_guarded_by_the_handles_upload_count(qc, oracle, devic
     np.testing.assert_allclose(dyn.dF(other), oracle.dF(prob, other), rtol=1e-10, atol=1e-13)
     dyn.close()
     obj.close()
+
+
+@pytest.mark.gpu
+def test_deadline_turns_a_lost_copy_into_an_error(qc):
+    """QC_HOST_TIMEOUT_MS: every host-side wait on the device has a deadline.  With a deadline of half a microsecond the watched copy of
+    a config-3 evaluation (0.3 ms) cannot make it: the call must come back with QC_ERR_HIP and a message -- not hang, not crash --, and
+    the handle must still close.  (The lock-free team itself is exercised with a stalling stand-in engine under the sanitizers on the
+    CPU: tests/test_host_team.py.)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "import __graft_entry__ as g\n"
+        "qc = g.load_package()\n"
+        "inp = qc.config_inputs(3, T=1000)\n"
+        "dyn = qc.QuantumDynamics(inp.integrators, inp.traj)\n"
+        "for k in range(3):\n"                      # (the first call spends milliseconds allocating: its copy has landed before anybody waits)
+        "    try:\n"
+        "        dyn.F_dF(inp.traj.datavec)\n"
+        "        print('NO ERROR')\n"
+        "    except qc._lib.QCollocError as e:\n"
+        "        print('ERROR:', e)\n"
+        "dyn.close()\n"
+        "print('closed')\n")
+    env = dict(os.environ, QC_HOST_TIMEOUT_MS="0.0005")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-800:]
+    assert r.stdout.count("ERROR:") >= 2 and "timed out" in r.stdout and "QC_HOST_TIMEOUT_MS" in r.stdout, r.stdout
+    assert "closed" in r.stdout
