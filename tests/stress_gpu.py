@@ -11,7 +11,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import __graft_entry__ as g
-from oracle_bridge import random_problem
+from oracle_bridge import random_problem, sparse_drive_problem
 from test_gpu_parity import RawHandle, kernels_for
 
 qc, o = g.load_package(), g.load_oracle()
@@ -25,11 +25,19 @@ for trial in range(trials):
     m = int(rng.integers(0, 13 if N > 16 else 9))
     order = int(rng.choice([4, 4, 4, 2, 6]))
     integ = o.EXPONENTIAL if rng.random() < 0.3 else o.PADE
+    if os.environ.get("QC_STRESS_SPARSE"):      # every trial a sparse-drive problem at 16 levels (qc_mfma32_ell.hip)
+        N, m, order, integ = 16, int(rng.integers(1, 9)), 4, o.PADE
     T = int(rng.integers(2, 6))
     free_time = bool(rng.integers(0, 2))
-    ncol = int(rng.integers(1, min(N, 16) + 1)) if rng.random() < 0.3 else 0
+    ncol = int(rng.integers(1, min(N, 16) + 1)) if rng.random() < 0.3 and not os.environ.get("QC_STRESS_SPARSE") else 0
     prob, Z = random_problem(o, N=N, m=max(m, 1), T=T, order=order, free_time=free_time, integrator=integ, seed=int(rng.integers(1 << 30)),
                              ncol=ncol, layout=str(rng.choice(["standard", "shuffled"])), hermitian=bool(rng.random() < 0.7))
+    sparse = N == 16 and m >= 1 and integ == o.PADE and order == 4 and ncol == 0 and (rng.random() < 0.6 or bool(os.environ.get("QC_STRESS_SPARSE")))
+    if sparse:      # sparse drive generators at 16 levels: the row-gather kernels (qc_mfma32_ell.hip) for F + dF, mu_d2F and the one-call form
+        prob, Z = sparse_drive_problem(o, m=min(m, 8), T=T, R=int(rng.integers(1, 3)), free_time=free_time, layout=str(rng.choice(["standard", "shuffled"])),
+                                       seed=int(rng.integers(1 << 30)), dense_drift=bool(rng.random() < 0.7),
+                                       kinds=tuple(rng.choice(["real", "imag", "diag"], size=3)))
+        m = prob.m
     if m == 0:
         prob.m = 0
         prob.G_drives = prob.G_drives[:0]
@@ -38,7 +46,7 @@ for trial in range(trials):
         Z[prob.off_dt::prob.zdim] *= rng.choice([0.01, 3.0, 10.0])
     tag = f"trial {trial}: N={N} m={m} order={order} integ={integ} T={T} ft={free_time} ncol={ncol}"
     Fr, Jr = o.F(prob, Z), o.dF(prob, Z)
-    do_h = integ == o.PADE and N <= 12
+    do_h = integ == o.PADE and (N <= 12 or sparse)
     cross_h = integ == o.PADE and order == 4 and N > 16       # 4 x 4-tile Hessian kernel against the global-workspace kernel
     if do_h or cross_h:
         mu = rng.standard_normal(prob.n_rows)
@@ -63,6 +71,9 @@ for trial in range(trials):
             worst["H"] = max(worst["H"], eH)
         if cross_h and int(h.dims.hess_nnz):
             Hk[kernel] = h.hess(Z, mu)
+        if sparse and kernel == "mfma":
+            ell = qc._lib.lib.qc_kernel_name(h.h, 1) == b"mfma32-pade4-hess-ell"       # (not when five drives share an entry of G)
+            count["mfma32-ell"] = count.get("mfma32-ell", 0) + int(ell)
         count[kernel] = count.get(kernel, 0) + 1
         h.close()
     if len(Hk) == 2:
