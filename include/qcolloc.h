@@ -131,7 +131,8 @@ typedef struct qc_desc {
     /* Composition (all 0 = this handle is the whole dynamics).  A problem whose integrator list holds several
      * unitary integrators (UnitarySamplingProblem: one per system over a merged trajectory,
      * unitary_sampling_problem.jl:134-155) is served by one handle per unitary integrator; each handle's rows and
-     * values are placed inside the problem's per-interval blocks.  Only the "_dev" entry points accept composed handles. */
+     * values are placed inside the problem's per-interval blocks.  Composed handles are evaluated through the "_dev" / "_dev_multi"
+     * entry points (device buffers) or the "_list" entry points (host buffers), never through qc_eval_F / _jac / _hess. */
     int64_t rows_per_interval;  /* dynamics rows of the whole problem per interval (Z.dims.states) */
     int64_t row_offset;         /* first row of this handle inside that block */
     int64_t jac_per_interval;   /* Jacobian values of the whole problem per interval */
@@ -266,6 +267,20 @@ int qc_eval_F_jac_hess_dev(qc_handle* h, const double* dZ, const double* dmu, do
  * kernels differ are evaluated one launch each, with the same result. */
 int qc_eval_F_jac_dev_multi(qc_handle* const* hs, int32_t count, const double* dZ, double* dF, double* dvals, void* stream);
 int qc_eval_hess_dev_multi(qc_handle* const* hs, int32_t count, const double* dZ, const double* dmu, double* dhvals, void* stream);
+
+/* The same integrator lists with HOST buffers -- what a CPU consumer (Ipopt through the MOI evaluator) of a
+ * `UnitarySamplingProblem` (unitary_sampling_problem.jl:134-155: [U_1 .. U_K, D, D], shared controls), a
+ * `UnitaryDirectSumProblem` (unitary_direct_sum_problem.jl:127-130: [U_1, D, D, U_2, D, D, ...], own controls per member) or
+ * a `QuantumStateSamplingProblem` (quantum_state_sampling_problem.jl:98-122) calls as dynamics.F(Z), dynamics.dF(Z),
+ * dynamics.mu_d2F(Z, mu).  `hs` = the composed handles of the list in integrator order, all on one device over one
+ * trajectory and interval range.  Z is uploaded once, the handles are evaluated as in the "_dev_multi" calls, and F / vals /
+ * hvals receive the whole problem's vectors: rows_per_interval, jac_per_interval, hess_per_interval values per interval,
+ * interval-major.  The calls return when the arrays are complete.  qc_set_new_x(hs[0], 0) / qc_knot_generation(hs[0])
+ * apply to the list (hs[0] owns the staging).  Errors are recorded on hs[0]. */
+int qc_eval_F_list(qc_handle* const* hs, int32_t count, const double* Z, double* F);
+int qc_eval_jac_list(qc_handle* const* hs, int32_t count, const double* Z, double* vals);
+int qc_eval_F_jac_list(qc_handle* const* hs, int32_t count, const double* Z, double* F, double* vals);
+int qc_eval_hess_list(qc_handle* const* hs, int32_t count, const double* Z, const double* mu, double* hvals);
 
 /* ---- one handle over several GPUs ("n_gpus, device_ids[]"; 8e) ------------------------------------ */
 /* The reference's consumer is ONE process (Julia + Ipopt, unitary_smooth_pulse_problem.jl:181-190, solve! at :219), so

@@ -217,6 +217,115 @@ function dynamics(integrators, traj, system; device::Int=0, devices=nothing, eva
     return dyn
 end
 
+"""
+    dynamics_list(parts, traj; device=0, eval_hessian=true, exact_structure=false, result_ring=3)
+
+The integrator lists with SEVERAL state integrators -- `UnitarySamplingProblem` ([U_1 .. U_K, D, D], shared controls:
+unitary_sampling_problem.jl:134-155), `UnitaryDirectSumProblem` ([U_1, D, D, U_2, D, D, ...], own controls per member:
+unitary_direct_sum_problem.jl:127-130), `QuantumStateSamplingProblem` (quantum_state_sampling_problem.jl:98-122) -- as ONE
+`HIPDynamics` with the fields and call shapes of `dynamics`.  `parts` holds one named tuple per state integrator in list order,
+each with the derivative integrators that FOLLOW it in the list:
+
+    (system = sys, state_name = :Ũ⃗_system_1, control_name = :a, derivative_pairs = [], pade_order = 4, exponential = false, n_kets = 0)
+
+(only `system` and `state_name` are required).  One composed handle per part; rows and values come out interval-major, in integrator
+order inside an interval (the order `QuantumDynamics` stacks them in).  The evaluations go through `qc_eval_*_list`: one upload
+of `Z⃗`, one batched launch where the parts' shapes allow it, results copied straight into the result vectors.
+"""
+function dynamics_list(parts, traj; device::Int=0, eval_hessian::Bool=true, exact_structure::Bool=false, result_ring::Int=3)
+    (result_ring == 0 || result_ring >= 3) || error("result_ring must be 0 (fresh vectors) or at least 3")
+    length(parts) >= 1 || error("dynamics_list: no state integrators")
+    off(name) = first(traj.components[name]) - 1
+    free_time = traj.timestep isa Symbol
+    opt(p, k, default) = haskey(p, k) ? p[k] : default
+    keep = Any[]                                               # generator matrices the descriptors point at
+    function desc_of(p, place)
+        sys = p.system
+        pairs = opt(p, :derivative_pairs, [])
+        expo = opt(p, :exponential, false)
+        G0 = Matrix{Float64}(sys.G_drift)
+        Gd = reduce(hcat, [vec(Matrix{Float64}(G)) for G in sys.G_drives])
+        push!(keep, G0); push!(keep, Gd)
+        xs = [off(q[1]) for q in pairs]; dxs = [off(q[2]) for q in pairs]; dms = [length(traj.components[q[1]]) for q in pairs]
+        return QCDesc(sys.levels, length(sys.G_drives), traj.T, traj.dim, traj.global_dim,
+                      off(p.state_name), off(opt(p, :control_name, :a)), free_time ? off(traj.timestep) : -1,
+                      free_time ? 0.0 : Float64(traj.timestep),
+                      expo ? 1 : 0, expo ? 0 : opt(p, :pade_order, 4), length(pairs),
+                      pad8(xs), pad8(dxs), pad8(dms), pointer(G0), pointer(Gd),
+                      device, 0, 0, 0, opt(p, :n_kets, 0), 1,
+                      place[1], place[2], place[3], place[4], place[5], place[6], 0, place[7], pad8(Int[]))
+    end
+    # pass 1: every part's own sizes (no device work), hence its slot in the shared per-interval blocks
+    own = QCDims[]
+    for p in parts
+        d = Ref{QCDims}()
+        GC.@preserve keep check(ccall((:qc_desc_dims, LIB[]), Cint, (Ref{QCDesc}, Ref{QCDims}), Ref(desc_of(p, (0, 0, 0, 0, 0, 0, 0))), d))
+        push!(own, d[])
+    end
+    rows = sum(x.ddim for x in own); jac = sum(x.jac_nnz_interval for x in own)
+    with_hess = eval_hessian && all(x.hess_nnz_interval > 0 for x in own)
+    hess_own = with_hess ? sum(x.hess_nnz_interval for x in own) : 0
+    al = exact_structure ? 1 : 16                              # the shared Hessian block is padded as a whole, through its last handle
+    hess = cld(hess_own, al) * al
+    handles = Ptr{Cvoid}[]
+    ro = jo = ho = 0
+    for (i, (p, x)) in enumerate(zip(parts, own))
+        tail = (with_hess && i == length(parts)) ? hess - hess_own : 0
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        GC.@preserve keep check(ccall((:qc_create, LIB[]), Cint, (Ref{QCDesc}, Ref{Ptr{Cvoid}}),
+                                      Ref(desc_of(p, (rows, ro, jac, jo, with_hess ? hess : 0, with_hess ? ho : 0, tail))), h))
+        push!(handles, h[])
+        ro += x.ddim; jo += x.jac_nnz_interval; ho += x.hess_nnz_interval
+    end
+    h0 = handles[1]
+    n_int = Int(own[1].n_intervals)
+    F_len = rows * n_int; jac_nnz = jac * n_int; hess_nnz = hess * n_int
+    # structures: every handle reports its own entries with the problem's row / column numbers; interleave them per interval
+    function structure(fn, per)
+        rs = Matrix{Int64}[]; cs = Matrix{Int64}[]
+        for (h, n) in zip(handles, per)
+            r = Vector{Int64}(undef, n * n_int); c = similar(r)
+            check(ccall((fn, LIB[]), Cint, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}, Cint), h, r, c, 1), h)
+            push!(rs, reshape(r, n, n_int)); push!(cs, reshape(c, n, n_int))
+        end
+        return collect(zip(Int.(vec(reduce(vcat, rs))), Int.(vec(reduce(vcat, cs)))))
+    end
+    ∂F_structure = structure(:qc_jac_structure, [Int(x.jac_nnz_interval) for x in own])
+    nh = length(handles)
+    F! = function (out::AbstractVector{Float64}, Z⃗::AbstractVector{Float64})
+        length(out) == F_len || error("F!: output has length $(length(out)), expected $F_len")
+        GC.@preserve Z⃗ out handles check(ccall((:qc_eval_F_list, LIB[]), Cint, (Ptr{Ptr{Cvoid}}, Int32, Ptr{Float64}, Ptr{Float64}), handles, nh, Z⃗, out), h0)
+        return out
+    end
+    ∂F! = function (out::AbstractVector{Float64}, Z⃗::AbstractVector{Float64})
+        length(out) == jac_nnz || error("∂F!: output has length $(length(out)), expected $jac_nnz")
+        GC.@preserve Z⃗ out handles check(ccall((:qc_eval_jac_list, LIB[]), Cint, (Ptr{Ptr{Cvoid}}, Int32, Ptr{Float64}, Ptr{Float64}), handles, nh, Z⃗, out), h0)
+        return out
+    end
+    ringF = ResultRing(F_len, result_ring); ring∂F = ResultRing(jac_nnz, result_ring)
+    F = (Z⃗; fresh::Bool=false) -> F!(next!(ringF, F_len, fresh), Z⃗)
+    ∂F = (Z⃗; fresh::Bool=false) -> ∂F!(next!(ring∂F, jac_nnz, fresh), Z⃗)
+    μ∂²F = nothing; μ∂²F! = nothing; μ∂²F_structure = nothing
+    if with_hess
+        per = [Int(x.hess_nnz_interval) for x in own]; per[end] += hess - hess_own
+        μ∂²F_structure = structure(:qc_hess_structure, per)
+        μ∂²F! = function (out::AbstractVector{Float64}, Z⃗::AbstractVector{Float64}, μ⃗::AbstractVector{Float64})
+            length(out) == hess_nnz || error("μ∂²F!: output has length $(length(out)), expected $hess_nnz")
+            length(μ⃗) == F_len || error("μ∂²F!: μ has length $(length(μ⃗)), expected $F_len")
+            GC.@preserve Z⃗ μ⃗ out handles check(ccall((:qc_eval_hess_list, LIB[]), Cint,
+                (Ptr{Ptr{Cvoid}}, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), handles, nh, Z⃗, μ⃗, out), h0)
+            return out
+        end
+        ringH = ResultRing(hess_nnz, result_ring)
+        μ∂²F = (Z⃗, μ⃗; fresh::Bool=false) -> μ∂²F!(next!(ringH, hess_nnz, fresh), Z⃗, μ⃗)
+    end
+    d0 = own[1]
+    d = QCDims(F_len, d0.n_cols, rows, jac, hess, n_int, F_len, jac_nnz, hess_nnz, d0.Z_len, d0.kernel, 0)
+    dyn = HIPDynamics(h0, d, F, ∂F, ∂F_structure, μ∂²F, μ∂²F_structure, Int(rows), F!, ∂F!, μ∂²F!)
+    finalizer(_ -> foreach(h -> ccall((:qc_destroy, LIB[]), Cvoid, (Ptr{Cvoid},), h), handles), dyn)   # `handles` lives in the closures
+    return dyn
+end
+
 "Ipopt's `new_x`: `false` declares that the next host-buffer calls receive the x of the previous one (`qc_set_new_x`)."
 set_new_x!(dyn::HIPDynamics, new_x::Bool) = check(ccall((:qc_set_new_x, LIB[]), Cint, (Ptr{Cvoid}, Cint), dyn.handle, new_x ? 1 : 0), dyn.handle)
 

@@ -19,7 +19,7 @@ from .objectives import (DensityOperatorPureStateInfidelityObjective, FinalQuant
                          TrajectoryObjective, UnitaryInfidelityObjective, iso_vec_unitary_fidelity, iso_vec_unitary_free_phase_fidelity,
                          UnitaryFreePhaseInfidelityObjective, FinalUnitaryFreePhaseFidelityConstraint)
 from .problems import (CONFIGS, config_inputs, density_operator_smooth_pulse_inputs, multi_qubit_system, quantum_state_sampling_inputs, quantum_state_smooth_pulse_inputs,
-                       unitary_sampling_inputs, unitary_smooth_pulse_inputs)
+                       unitary_bang_bang_inputs, unitary_direct_sum_inputs, unitary_sampling_inputs, unitary_smooth_pulse_inputs)
 from .quantum_systems import OpenQuantumSystem, QuantumSystem
 from .rollouts import open_rollout, rollout, unitary_rollout, unitary_rollout_fidelity
 from .trajectory_initialization import initialize_trajectory, unitary_geodesic
@@ -28,7 +28,7 @@ __all__ = [
     "QuantumControlEvaluator",
     "QuantumDynamics", "QuantumSystem", "NamedTrajectory", "UnitaryPadeIntegrator",
     "UnitaryExponentialIntegrator", "DerivativeIntegrator", "QuantumStatePadeIntegrator",
-    "QuantumStateExponentialIntegrator", "quantum_state_smooth_pulse_inputs", "quantum_state_sampling_inputs", "unitary_sampling_inputs", "ComposedQuantumDynamics", "split_groups", "operator_to_iso_vec", "iso_vec_to_operator",
+    "QuantumStateExponentialIntegrator", "quantum_state_smooth_pulse_inputs", "quantum_state_sampling_inputs", "unitary_sampling_inputs", "unitary_bang_bang_inputs", "unitary_direct_sum_inputs", "ComposedQuantumDynamics", "split_groups", "operator_to_iso_vec", "iso_vec_to_operator",
     "iso_generator", "pade_coefficients", "GATES", "PAULIS", "operator_from_string", "config_inputs",
     "unitary_smooth_pulse_inputs", "multi_qubit_system", "CONFIGS", "initialize_trajectory",
     "unitary_geodesic", "iso_vec_unitary_fidelity", "iso_vec_unitary_free_phase_fidelity", "UnitaryFreePhaseInfidelityObjective",

@@ -168,6 +168,10 @@ SYMBOLS = {
     "qc_eval_F_jac_hess_dev": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "qc_eval_F_jac_dev_multi": (C.c_int, [C.POINTER(_H), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "qc_eval_hess_dev_multi": (C.c_int, [C.POINTER(_H), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "qc_eval_F_list": (C.c_int, [C.POINTER(_H), C.c_int32, _c_double_p, _c_double_p]),
+    "qc_eval_jac_list": (C.c_int, [C.POINTER(_H), C.c_int32, _c_double_p, _c_double_p]),
+    "qc_eval_F_jac_list": (C.c_int, [C.POINTER(_H), C.c_int32, _c_double_p, _c_double_p, _c_double_p]),
+    "qc_eval_hess_list": (C.c_int, [C.POINTER(_H), C.c_int32, _c_double_p, _c_double_p, _c_double_p]),
     "qc_create_multi": (C.c_int, [_DESC_P, C.c_int32, C.POINTER(C.c_int32), C.POINTER(_H)]),
     "qc_multi_count": (C.c_int32, [_H]),
     "qc_multi_shard": (_H, [_H, C.c_int32]),

@@ -1316,6 +1316,87 @@ extern "C" int qc_eval_hess(qc_handle* h, const double* Z, const double* mu, dou
 }
 
 // ------------------------------------------------------------------------------------------------
+//  Integrator lists with several state integrators, host buffers (UnitarySamplingProblem, UnitaryDirectSumProblem,
+//  QuantumStateSamplingProblem): one composed handle per state integrator, ONE upload of the knots, the batched launch where
+//  the handles allow it, and the whole-problem value vectors copied straight into the caller's arrays.  hs[0] owns the
+//  staging buffers and the stream; qc_set_new_x / qc_knot_generation on hs[0] mean what they mean on a single handle.
+// ------------------------------------------------------------------------------------------------
+static int list_check(qc_handle* const* hs, int32_t count, const char* who) {
+    if (!hs || count < 1) return fail(nullptr, QC_ERR_INVALID, std::string(who) + ": no handles");
+    for (int i = 0; i < count; ++i) {
+        if (!hs[i]) return fail(nullptr, QC_ERR_INVALID, std::string(who) + ": NULL handle");
+        if (is_multi(hs[i])) return fail(&hs[0]->err, QC_ERR_UNSUPPORTED, std::string(who) + ": multi-device handles are not composed");
+    }
+    const qc_handle* h0 = hs[0];
+    const QcParams& P0 = h0->prm;
+    for (int i = 1; i < count; ++i) {
+        const QcParams& P = hs[i]->prm;
+        if (hs[i]->device != h0->device || P.zdim != P0.zdim || hs[i]->desc.T != h0->desc.T || P.t_begin != P0.t_begin || P.n_int != P0.n_int ||
+            hs[i]->dims.Z_len != h0->dims.Z_len || P.F_stride != P0.F_stride || P.J_stride != P0.J_stride)
+            return fail(&hs[0]->err, QC_ERR_INVALID, std::string(who) + ": the handles do not describe one problem (device, trajectory, interval range "
+                        "or the per-interval block sizes differ)");
+    }
+    return QC_OK;
+}
+
+static int list_eval(qc_handle* const* hs, int32_t count, const double* Z, const double* mu, double* F, double* vals, double* hvals, const char* who) {
+    int rc;
+    if ((rc = list_check(hs, count, who))) return rc;
+    qc_handle* h = hs[0];
+    const QcParams& P = h->prm;
+    if (!Z || (!F && !vals && !hvals) || (hvals && !mu)) return fail(&h->err, QC_ERR_INVALID, std::string(who) + ": NULL buffer");
+    if (hvals) {
+        for (int i = 0; i < count; ++i)
+            if (hs[i]->prm.integrator != QC_PADE)
+                return fail(&h->err, QC_ERR_UNSUPPORTED, "no analytic Hessian for the exponential integrator (upstream has none either; use eval_hessian=false)");
+        for (int i = 1; i < count; ++i)
+            if ((hs[i]->prm.hess_nnz != 0) != (P.hess_nnz != 0) || (P.hess_nnz && hs[i]->prm.H_stride != P.H_stride))
+                return fail(&h->err, QC_ERR_INVALID, std::string(who) + ": the handles do not share one per-interval Hessian block");
+        if (P.hess_nnz == 0) hvals = nullptr;     // linear constraints: nothing to write
+    }
+    if (P.n_int == 0) return QC_OK;
+    qc_device_guard guard(h->device);
+    QC_HIP(h, guard.err);
+    const size_t n_int = (size_t)P.n_int;
+    const size_t nF = n_int * (size_t)P.F_stride, nJ = n_int * (size_t)P.J_stride, nH = hvals ? n_int * (size_t)P.H_stride : 0;
+    if ((rc = upload_knots(h, Z))) return rc;
+    if (F && (rc = ensure_zeroed(h, &h->dF, nF))) return rc;       // rows no handle of the list owns stay 0
+    if (vals && (rc = ensure_zeroed(h, &h->dJ, nJ))) return rc;
+    if (F || vals) {
+        if ((rc = qc_eval_F_jac_dev_multi(hs, count, h->dZ, F ? h->dF : nullptr, vals ? h->dJ : nullptr, h->stream))) return rc;
+        if (F) QC_HIP(h, hipMemcpyAsync(F, h->dF, nF * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        if (vals) QC_HIP(h, hipMemcpyAsync(vals, h->dJ, nJ * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    }
+    if (hvals) {
+        const size_t nMu = n_int * (size_t)P.F_stride;
+        if ((rc = ensure(h, &h->dMu, nMu))) return rc;
+        if ((rc = ensure_zeroed(h, &h->dH, nH))) return rc;
+        QC_HIP(h, hipMemcpyAsync(h->dMu, mu, nMu * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        if ((rc = qc_eval_hess_dev_multi(hs, count, h->dZ, h->dMu, h->dH, h->stream))) return rc;
+        QC_HIP(h, hipMemcpyAsync(hvals, h->dH, nH * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    }
+    QC_HIP(h, hipEventRecord(h->ev_done, h->stream));
+    return wait_done(h, 1);
+}
+
+extern "C" int qc_eval_F_list(qc_handle* const* hs, int32_t count, const double* Z, double* F) {
+    if (hs && count >= 1 && hs[0] && !F) return fail(&hs[0]->err, QC_ERR_INVALID, "qc_eval_F_list: NULL buffer");
+    return list_eval(hs, count, Z, nullptr, F, nullptr, nullptr, "qc_eval_F_list");
+}
+extern "C" int qc_eval_jac_list(qc_handle* const* hs, int32_t count, const double* Z, double* vals) {
+    if (hs && count >= 1 && hs[0] && !vals) return fail(&hs[0]->err, QC_ERR_INVALID, "qc_eval_jac_list: NULL buffer");
+    return list_eval(hs, count, Z, nullptr, nullptr, vals, nullptr, "qc_eval_jac_list");
+}
+extern "C" int qc_eval_F_jac_list(qc_handle* const* hs, int32_t count, const double* Z, double* F, double* vals) {
+    if (hs && count >= 1 && hs[0] && (!F || !vals)) return fail(&hs[0]->err, QC_ERR_INVALID, "qc_eval_F_jac_list: NULL buffer");
+    return list_eval(hs, count, Z, nullptr, F, vals, nullptr, "qc_eval_F_jac_list");
+}
+extern "C" int qc_eval_hess_list(qc_handle* const* hs, int32_t count, const double* Z, const double* mu, double* hvals) {
+    if (hs && count >= 1 && hs[0] && !hvals) return fail(&hs[0]->err, QC_ERR_INVALID, "qc_eval_hess_list: NULL buffer");
+    return list_eval(hs, count, Z, mu, nullptr, nullptr, hvals, "qc_eval_hess_list");
+}
+
+// ------------------------------------------------------------------------------------------------
 //  Rollouts
 // ------------------------------------------------------------------------------------------------
 extern "C" int qc_rollout_dev(qc_handle* h, const double* dZ, const double* dinit, double* dout, void* stream) {

@@ -68,30 +68,36 @@ def pinned_zeros(n: int) -> np.ndarray:
 
 
 def split_groups(integrators: Sequence):
-    """Integrator list -> groups, one per unitary integrator (or run of ket integrators); the derivative integrators
-    (which must come last: unitary_smooth_pulse_problem.jl:175-179, unitary_sampling_problem.jl:149-155) go with the
-    last group so that their rows follow it."""
-    groups, cur = [], []
-    i = 0
-    n = len(integrators)
-    while i < n and isinstance(integrators[i], (_UnitaryIntegrator, _KetIntegrator, DensityOperatorExponentialIntegrator)):
-        if isinstance(integrators[i], (_UnitaryIntegrator, DensityOperatorExponentialIntegrator)):
-            groups.append([integrators[i]])
+    """Integrator list -> groups, one per unitary integrator (or run of ket integrators of one system); derivative
+    integrators go with the state integrator they follow, so that their rows follow its rows.  Covers the lists the
+    reference's templates build: [U, D, D] (unitary_smooth_pulse_problem.jl:175-179), [U_1 .. U_K, D, D]
+    (unitary_sampling_problem.jl:149-155), [U, D] (unitary_bang_bang_problem.jl:171-175) and the direct sum's
+    [U_1, D, D, U_2, D, D, ...] (unitary_direct_sum_problem.jl:127-130)."""
+    state_types = (_UnitaryIntegrator, _KetIntegrator, DensityOperatorExponentialIntegrator)
+    groups = []
+    i, n = 0, len(integrators)
+    while i < n:
+        I = integrators[i]
+        if isinstance(I, (_UnitaryIntegrator, DensityOperatorExponentialIntegrator)):
+            groups.append([I])
             i += 1
-        else:
-            run = [integrators[i]]
+        elif isinstance(I, _KetIntegrator):
+            run = [I]
             i += 1
             while i < n and isinstance(integrators[i], _KetIntegrator) and integrators[i].system is run[0].system:
                 run.append(integrators[i])
                 i += 1
             groups.append(run)
-    rest = list(integrators[i:])
+        elif isinstance(I, DerivativeIntegrator):
+            if not groups:
+                raise NotImplementedError("the integrator list must start with a unitary or ket integrator")
+            groups[-1].append(I)
+            i += 1
+        else:
+            raise NotImplementedError("only DerivativeIntegrators may follow the state integrators")
     if not groups:
         raise NotImplementedError("the integrator list must start with a unitary or ket integrator")
-    for D in rest:
-        if not isinstance(D, DerivativeIntegrator):
-            raise NotImplementedError("only DerivativeIntegrators may follow the state integrators")
-    groups[-1] = groups[-1] + rest
+    assert all(isinstance(g[0], state_types) for g in groups)
     return groups
 
 
@@ -560,7 +566,6 @@ class ComposedQuantumDynamics(QuantumDynamics):
         self._h = None
         self._structs = None
         self._dev = torch.device("cuda", device)
-        self._bufs = {}
 
     def close(self):
         for _, _, h, _ in getattr(self, "_parts", []):
@@ -585,13 +590,6 @@ class ComposedQuantumDynamics(QuantumDynamics):
                 hc_l.append(hc.reshape(n_int, -1))
         cat = lambda L: np.ascontiguousarray(np.concatenate(L, axis=1).reshape(-1)) if L else np.empty(0, dtype=np.int64)
         return cat(jr_l), cat(jc_l), cat(hr_l), cat(hc_l)
-
-    def _buf(self, name, n):
-        t = self._bufs.get(name)
-        if t is None or t.numel() < n:
-            t = torch.empty(max(n, 1), dtype=torch.float64, device=self._dev)
-            self._bufs[name] = t
-        return t
 
     def F_dF_device(self, Z: torch.Tensor, F: Optional[torch.Tensor], J: Optional[torch.Tensor], stream=None) -> None:
         st = stream if stream is not None else torch.cuda.current_stream(self.device)
@@ -620,56 +618,40 @@ class ComposedQuantumDynamics(QuantumDynamics):
     def F_dF_into(self, Z, F, J):
         self.F_dF(Z, out=(F, J))
 
-    def _upload(self, Z):
-        Zh = self._Z(Z)
-        dZ = self._buf("Z", Zh.size)
-        dZ[:Zh.size].copy_(torch.from_numpy(Zh))
-        return dZ
-
-    def _download(self, name: str, t: torch.Tensor, n: int, out: Optional[np.ndarray], fresh: bool = False, slot: Optional[str] = None) -> np.ndarray:
-        """Device vector -> the caller's `out` (validated like the single-handle class: the evaluator hands Ipopt's own
-        buffers in and reads the result from them), the closure's next ring vector, or (fresh=True) a new array."""
-        out = self._out(name, n, out, fresh, slot)
-        if n:
-            torch.from_numpy(out).copy_(t[:n])
-        return out
-
+    # -- host buffers: the "_list" entry points of the C ABI (one upload, the batched launch, copies straight into the arrays) ----
     def F_dF(self, Z, out=None, *, fresh: bool = False):
-        dZ = self._upload(Z)
-        dF, dJ = self._buf("F", self.dims.F_len), self._buf("J", self.dims.jac_nnz)
-        self.F_dF_device(dZ, dF, dJ)
-        torch.cuda.synchronize(self._dev)
-        return (self._download("F", dF, int(self.dims.F_len), None if out is None else out[0], fresh, "F_dF.F"),
-                self._download("J", dJ, int(self.dims.jac_nnz), None if out is None else out[1], fresh, "F_dF.J"))
+        Z = self._Z(Z)
+        F = self._out("F", int(self.dims.F_len), None if out is None else out[0], fresh, "F_dF.F")
+        J = self._out("dF", int(self.dims.jac_nnz), None if out is None else out[1], fresh, "F_dF.J")
+        _lib.check(_lib.lib.qc_eval_F_jac_list(self._handles, len(self._parts), _lib.dptr(Z), _lib.dptr(F), _lib.dptr(J)), self._parts[0][2])
+        return F, J
 
     def F(self, Z, out=None, *, fresh: bool = False):
-        dZ = self._upload(Z)
-        dF = self._buf("F", self.dims.F_len)
-        self.F_dF_device(dZ, dF, None)
-        torch.cuda.synchronize(self._dev)
-        return self._download("F", dF, int(self.dims.F_len), out, fresh)
+        Z = self._Z(Z)
+        F = self._out("F", int(self.dims.F_len), out, fresh)
+        _lib.check(_lib.lib.qc_eval_F_list(self._handles, len(self._parts), _lib.dptr(Z), _lib.dptr(F)), self._parts[0][2])
+        return F
 
     def dF(self, Z, out=None, *, fresh: bool = False):
-        dZ = self._upload(Z)
-        dJ = self._buf("J", self.dims.jac_nnz)
-        self.F_dF_device(dZ, None, dJ)
-        torch.cuda.synchronize(self._dev)
-        return self._download("J", dJ, int(self.dims.jac_nnz), out, fresh)
+        Z = self._Z(Z)
+        J = self._out("dF", int(self.dims.jac_nnz), out, fresh)
+        _lib.check(_lib.lib.qc_eval_jac_list(self._handles, len(self._parts), _lib.dptr(Z), _lib.dptr(J)), self._parts[0][2])
+        return J
 
     def mu_d2F(self, Z, mu, out=None, *, fresh: bool = False):
+        if not self.dims.hess_nnz:
+            raise _lib.QCollocError(_lib.QC_ERR_UNSUPPORTED, "no analytic Hessian for this integrator list")
+        Z = self._Z(Z)
         mu = np.ascontiguousarray(mu, dtype=np.float64)
         if mu.size != self.dims.n_rows:
             raise ValueError(f"mu has length {mu.size}, expected {self.dims.n_rows}")
-        dZ = self._upload(Z)
-        dmu = self._buf("mu", mu.size)
-        dmu[:mu.size].copy_(torch.from_numpy(mu))
-        dH = self._buf("H", self.dims.hess_nnz)
-        self.mu_d2F_device(dZ, dmu, dH)
-        torch.cuda.synchronize(self._dev)
-        return self._download("H", dH, int(self.dims.hess_nnz), out, fresh)
+        H = self._out("mu_d2F", int(self.dims.hess_nnz), out, fresh)
+        _lib.check(_lib.lib.qc_eval_hess_list(self._handles, len(self._parts), _lib.dptr(Z), _lib.dptr(mu), _lib.dptr(H)), self._parts[0][2])
+        return H
 
     def knot_generation(self) -> int:
-        return 0
+        return int(_lib.lib.qc_knot_generation(self._parts[0][2]))
 
     def set_new_x(self, new_x: bool) -> None:
-        """Accepted for interface parity with QuantumDynamics.set_new_x; the composed evaluator uploads Z on every call."""
+        """Ipopt's `new_x` for the whole list (the list's first handle owns the knots on the device)."""
+        _lib.check(_lib.lib.qc_set_new_x(self._parts[0][2], int(bool(new_x))), self._parts[0][2])

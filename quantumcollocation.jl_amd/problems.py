@@ -222,3 +222,85 @@ def quantum_state_sampling_inputs(systems, psi_inits, psi_goals, T: int, dt: flo
     integrators = [cls(nm, "a", sys_, traj, **kw) for row, sys_ in zip(names, systems) for nm in row]
     integrators += [DerivativeIntegrator("a", "da", traj), DerivativeIntegrator("da", "dda", traj)]
     return HotPathInputs(systems[0], traj, integrators)
+
+
+def unitary_bang_bang_inputs(system: QuantumSystem, U_goal: np.ndarray, T: int, dt: float = 0.2, *, free_time: bool = True,
+                             integrator: str = "pade", pade_order: int = 4, control_name: str = "a",
+                             seed: int = SEED) -> HotPathInputs:
+    """Inputs of `UnitaryBangBangProblem` (reference unitary_bang_bang_problem.jl:73-188): ONE control derivative
+    (`initialize_trajectory(..., (a_bounds, da_bounds))`, :102-121), the unitary integrator and a single
+    `DerivativeIntegrator(a, da)` (:163-175).  The L1 regulariser on `da` appends two slack components of the size of `da`
+    to the trajectory (`L1Regularizer!(constraints, control_names[2], traj, ...)`, :149-152; their names come from
+    QuantumCollocationCore and are a choice of this build): the dynamics never read them, they only widen the knots.
+    The reference's own test runs this template with `pade_order=12` and `control_name=:u` (:205-215)."""
+    rng = np.random.default_rng(seed)
+    m = system.n_drives
+    base = initialize_trajectory(U_goal, T, dt, m, ([1.0] * m, [1.0] * m), free_time=free_time, rng=rng)
+    a, da = control_name, "d" + control_name
+    names = {"a": a, "da": da}
+    comps = {}
+    for nm in base.names:
+        comps[names.get(nm, nm)] = np.array(base[nm])
+    comps[f"s1_{da}"] = np.maximum(comps[da], 0.0)
+    comps[f"s2_{da}"] = np.maximum(-comps[da], 0.0)
+    controls = tuple(names.get(c, c) for c in base.controls) + (f"s1_{da}", f"s2_{da}")
+    tstep = base.timestep
+    traj = NamedTrajectory(comps, controls=controls, timestep=tstep,
+                           goal={names.get(k, k): v for k, v in base.goal.items()})
+    if integrator == "pade":
+        U_int = UnitaryPadeIntegrator("Ũ⃗", a, system, traj, order=pade_order)
+    elif integrator == "exponential":
+        U_int = UnitaryExponentialIntegrator("Ũ⃗", a, system, traj)
+    else:
+        raise ValueError("integrator must be one of ('pade', 'exponential')")
+    return HotPathInputs(system, traj, [U_int, DerivativeIntegrator(a, da, traj)])
+
+
+def unitary_direct_sum_inputs(parts, labels=None) -> HotPathInputs:
+    """Inputs of `UnitaryDirectSumProblem` (reference unitary_direct_sum_problem.jl:48-186) from the hot-path inputs of its
+    member problems (smooth-pulse problems only, :72): the members' trajectories merged with their labels as suffixes
+    (`merge([add_suffix(p.trajectory, l) ...])`, :104) and every member's integrators re-pointed at the merged
+    trajectory, member after member (:127-130) -- [U_1, D, D, U_2, D, D, ...]: every member keeps its OWN controls, unlike
+    the sampling problem.  The reference's test builds the members with `free_time=false` (:196: a constant timestep, no
+    `Δt` rows); with free time this build keeps ONE shared, un-suffixed timestep component after the members' components
+    (what the merge does with several timestep rows is NamedTrajectories' business and unverified here)."""
+    from .integrators import _UnitaryIntegrator
+    labels = [str(i + 1) for i in range(len(parts))] if labels is None else [str(l) for l in labels]
+    if len(labels) != len(parts) or len(parts) < 2:
+        raise ValueError("at least two problems, one label each")
+    T = parts[0].traj.T
+    free = [isinstance(p.traj.timestep, str) for p in parts]
+    if any(free) and not all(free):
+        raise ValueError("members must all have a free timestep or all a fixed one")
+    if not free[0] and len({float(p.traj.timestep) for p in parts}) != 1:
+        raise ValueError("members with fixed timesteps must share the timestep")
+    comps, controls, goal = {}, [], {}
+    for p, l in zip(parts, labels):
+        if p.traj.T != T:
+            raise ValueError("the member trajectories must have the same number of knots")
+        if "dda" not in p.traj.names:
+            raise ValueError("Only smooth pulse problems are supported.")
+        for nm in p.traj.names:
+            if nm != p.traj.timestep:
+                comps[nm + l] = np.array(p.traj[nm])
+        controls += [c + l for c in p.traj.controls if c != p.traj.timestep]
+        goal.update({k + l: v for k, v in p.traj.goal.items()})
+    if free[0]:
+        tname = parts[0].traj.timestep
+        comps[tname] = np.array(parts[0].traj[tname])
+        controls.append(tname)
+        tstep = tname
+    else:
+        tstep = float(parts[0].traj.timestep)
+    traj = NamedTrajectory(comps, controls=tuple(controls), timestep=tstep, goal=goal)
+    integrators = []
+    for p, l in zip(parts, labels):
+        for I in p.integrators:
+            if isinstance(I, _UnitaryIntegrator):
+                kw = {"order": I.order} if isinstance(I, UnitaryPadeIntegrator) else {}
+                integrators.append(type(I)(I.state_name + l, I.control_name + l, I.system, traj, **kw))
+            elif isinstance(I, DerivativeIntegrator):
+                integrators.append(DerivativeIntegrator(I.x + l, I.dx + l, traj))
+            else:
+                raise NotImplementedError("direct sums of unitary smooth-pulse problems")
+    return HotPathInputs(parts[0].system, traj, integrators)

@@ -1,0 +1,273 @@
+"""The integrator lists of the reference's other templates on the path: `UnitaryBangBangProblem` ([U, D] over a trajectory
+with one control derivative and the L1 slack components, unitary_bang_bang_problem.jl:102-121,149-152,163-175; its own test
+runs Pade order 12 with `control_name=:u`, :205-215) and `UnitaryDirectSumProblem` ([U_1, D, D, U_2, D, D, ...] over the
+members' merged, suffixed trajectories, every member with its own controls, unitary_direct_sum_problem.jl:104,127-130).
+
+CPU part: the oracle on these lists against the members evaluated on their own trajectories and against finite differences.
+GPU part (`-m gpu`): the HIP path through the C ABI against the oracle, rtol 1e-10, structures array_equal."""
+import numpy as np
+import pytest
+
+from oracle_bridge import composed_oracle, problem_from_inputs
+
+RTOL = 1e-10
+
+
+def close(got, ref, what="", atol=1e-12):
+    scale = max(1.0, float(np.max(np.abs(ref)))) if ref.size else 1.0
+    np.testing.assert_allclose(got, ref, rtol=RTOL, atol=atol * scale, err_msg=what)
+
+
+def direct_sum_members(qc, free_time, T=7, orders=(4, 4), exp_second=False):
+    p1 = qc.unitary_smooth_pulse_inputs(qc.multi_qubit_system(1), qc.GATES["X"], T, free_time=free_time, pade_order=orders[0])
+    kw = dict(integrator="exponential") if exp_second else dict(pade_order=orders[1])
+    p2 = qc.unitary_smooth_pulse_inputs(qc.multi_qubit_system(2), qc.GATES["CNOT"], T, free_time=free_time, seed=3, **kw)
+    if free_time:   # the direct sum shares one timestep row: give the members the same one
+        p2.traj.data[p2.traj.components["Δt"].start, :] = p1.traj["Δt"][0]
+    return p1, p2
+
+
+# ------------------------------------------------------------------------------------------------
+#  CPU: the lists, and the oracle over them
+# ------------------------------------------------------------------------------------------------
+def test_integrator_lists_of_every_template_split_into_groups(qc):
+    s1 = qc.multi_qubit_system(1)
+    smooth = qc.unitary_smooth_pulse_inputs(s1, qc.GATES["H"], 5)
+    assert [len(g) for g in qc.split_groups(smooth.integrators)] == [3]
+    samp = qc.unitary_sampling_inputs([s1, s1, s1], qc.GATES["H"], 5)
+    assert [len(g) for g in qc.split_groups(samp.integrators)] == [1, 1, 3]
+    bang = qc.unitary_bang_bang_inputs(s1, qc.GATES["H"], 5, control_name="u")
+    assert [len(g) for g in qc.split_groups(bang.integrators)] == [2]
+    assert bang.traj.names == ("Ũ⃗", "u", "du", "Δt", "s1_du", "s2_du")
+    assert bang.traj.dims.states == 8 + 2                     # the slacks are controls: no dynamics rows
+    ds = qc.unitary_direct_sum_inputs(direct_sum_members(qc, False))
+    assert [len(g) for g in qc.split_groups(ds.integrators)] == [3, 3]
+    assert ds.traj.names == ("Ũ⃗1", "a1", "da1", "dda1", "Ũ⃗2", "a2", "da2", "dda2")
+    assert ds.traj.dims.states == (8 + 4) + (32 + 8)
+    with pytest.raises(NotImplementedError):
+        qc.split_groups(smooth.integrators[1:])               # a list starting with a derivative integrator
+    with pytest.raises(ValueError):
+        qc.unitary_direct_sum_inputs([smooth])                # "At least two problems are required" (:69)
+    bb = qc.unitary_bang_bang_inputs(s1, qc.GATES["H"], 5)
+    with pytest.raises(ValueError):
+        qc.unitary_direct_sum_inputs([bb, bb])                # "Only smooth pulse problems are supported." (:72)
+
+
+@pytest.mark.parametrize("free_time", [False, True])
+def test_direct_sum_oracle_equals_members_on_their_own(qc, oracle, free_time):
+    """A direct sum is its members side by side: values equal the members' own evaluations, and the structure is the
+    members' structure with rows / columns moved to the merged trajectory's positions."""
+    p1, p2 = direct_sum_members(qc, free_time)
+    ds = qc.unitary_direct_sum_inputs([p1, p2], labels=["a", "b"])
+    ref = composed_oracle(ds)
+    Z = ds.traj.datavec
+    T = ds.traj.T
+    members = [(problem_from_inputs(p), p) for p in (p1, p2)]
+    Fm = [oracle.F(pr, p.traj.datavec).reshape(T - 1, -1) for pr, p in members]
+    np.testing.assert_array_equal(ref.F(Z), np.concatenate(Fm, axis=1).reshape(-1))
+    Jm = [oracle.dF(pr, p.traj.datavec).reshape(T - 1, -1) for pr, p in members]
+    np.testing.assert_array_equal(ref.dF(Z), np.concatenate(Jm, axis=1).reshape(-1))
+    # structure: dense Jacobian of the sum = block placement of the members' dense Jacobians
+    rr, rc = ref.structure()
+    J = np.zeros((ref.rows * (T - 1), Z.size))
+    np.add.at(J, (rr, rc), ref.dF(Z))
+    ro = 0
+    for (pr, p), lab in zip(members, "ab"):
+        r, c = oracle.jac_structure(pr)
+        Jd = np.zeros((pr.n_rows, p.traj.datavec.size))
+        np.add.at(Jd, (r, c), oracle.dF(pr, p.traj.datavec))
+        # member column (knot t, row i of component nm) -> merged column
+        col = np.empty(p.traj.dim, dtype=np.int64)
+        for nm in p.traj.names:
+            tgt = nm if nm == p.traj.timestep else nm + lab
+            col[list(p.traj.components[nm])] = list(ds.traj.components[tgt])
+        rows = (np.arange(T - 1)[:, None] * ref.rows + ro + np.arange(pr.ddim)[None, :]).reshape(-1)
+        cols = (np.arange(T)[:, None] * ds.traj.dim + col[None, :]).reshape(-1)
+        np.testing.assert_array_equal(J[np.ix_(rows, cols)], Jd)
+        J[np.ix_(rows, cols)] = 0.0
+        ro += pr.ddim
+    assert not J.any()                                         # nothing outside the members' blocks
+    # Lagrangian Hessian: sum of the members' (the shared timestep row collects both)
+    rng = np.random.default_rng(0)
+    mu = rng.standard_normal(ref.rows * (T - 1))
+    hr, hc = ref.hess_structure()
+    H = np.zeros((Z.size, Z.size))
+    np.add.at(H, (hr, hc), ref.mu_d2F(Z, mu))
+    eps = 1e-6
+    v = rng.standard_normal(Z.size)
+
+    def grad(z):
+        g = np.zeros(Z.size)
+        np.add.at(g, rc, ref.dF(z) * mu[rr])
+        return g
+    Hs = H + H.T - np.diag(np.diag(H))
+    np.testing.assert_allclose(Hs @ v, (grad(Z + eps * v) - grad(Z - eps * v)) / (2 * eps), rtol=2e-6, atol=2e-7)
+
+
+@pytest.mark.parametrize("order,free_time", [(12, True), (4, False)])
+def test_bang_bang_oracle_never_touches_the_slacks(qc, oracle, order, free_time):
+    inp = qc.unitary_bang_bang_inputs(qc.multi_qubit_system(1), qc.GATES["H"], 9, pade_order=order, free_time=free_time, control_name="u")
+    prob = problem_from_inputs(inp)
+    assert prob.ddim == inp.traj.dims.states == 10 and prob.order == order and len(prob.derivs) == 1
+    Z = inp.traj.datavec
+    r, c = oracle.jac_structure(prob)
+    slack = np.concatenate([np.array(inp.traj.components[n]) for n in ("s1_du", "s2_du")])
+    assert not np.isin(c % inp.traj.dim, slack).any()
+    hr, hc = oracle.hess_structure(prob)
+    assert not np.isin(hr % inp.traj.dim, slack).any() and not np.isin(hc % inp.traj.dim, slack).any()
+    rng = np.random.default_rng(1)
+    Z2 = Z.copy().reshape(inp.traj.T, inp.traj.dim)
+    Z2[:, slack] = rng.standard_normal((inp.traj.T, slack.size))
+    np.testing.assert_array_equal(oracle.F(prob, Z2.reshape(-1)), oracle.F(prob, Z))
+    v = rng.standard_normal(Z.size)
+    eps = 1e-6
+    Jv = np.zeros(prob.n_rows)
+    np.add.at(Jv, r, oracle.dF(prob, Z) * v[c])
+    np.testing.assert_allclose(Jv, (oracle.F(prob, Z + eps * v) - oracle.F(prob, Z - eps * v)) / (2 * eps), rtol=1e-6, atol=1e-8)
+
+
+# ------------------------------------------------------------------------------------------------
+#  GPU: the HIP path on the same lists
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("nq,order,free_time,integrator", [(1, 12, True, "pade"), (1, 12, False, "pade"), (2, 4, True, "pade"),
+                                                            (3, 4, True, "pade"), (3, 12, True, "pade"), (2, 4, True, "exponential"),
+                                                            (4, 4, True, "pade")])
+def test_bang_bang_problem_parity(qc, oracle, nq, order, free_time, integrator):
+    gate = {1: "H", 2: "CNOT", 3: "TOFFOLI", 4: "QFT16"}[nq]
+    T = 51 if nq == 1 else 9           # the reference's test: T = 51 (unitary_bang_bang_problem.jl:203)
+    inp = qc.unitary_bang_bang_inputs(qc.multi_qubit_system(nq), qc.GATES[gate], T, pade_order=order, free_time=free_time,
+                                      integrator=integrator, control_name="u")
+    prob = problem_from_inputs(inp)
+    dyn = qc.QuantumDynamics(inp.integrators, inp.traj)
+    Z = inp.traj.datavec
+    assert dyn.dim == inp.traj.dims.states == prob.ddim
+    F, J = dyn.F_dF(Z, fresh=True)
+    close(F, oracle.F(prob, Z), "bang-bang F")
+    close(J, oracle.dF(prob, Z), "bang-bang dF")
+    close(dyn.F(Z, fresh=True), oracle.F(prob, Z), "bang-bang F alone")
+    jr, jc = dyn.dF_structure
+    r, c = oracle.jac_structure(prob)
+    np.testing.assert_array_equal(jr, r)
+    np.testing.assert_array_equal(jc, c)
+    if integrator == "pade":            # no analytic Hessian of the exponential integrator upstream
+        rng = np.random.default_rng(2)
+        for mu in (np.ones(prob.n_rows), rng.standard_normal(prob.n_rows)):
+            close(dyn.mu_d2F(Z, mu, fresh=True), oracle.mu_d2F(prob, Z, mu), "bang-bang hessian", atol=1e-11)
+        hr, hc = dyn.mu_d2F_structure
+        orr, oc = oracle.hess_structure(prob)
+        np.testing.assert_array_equal(hr, orr)
+        np.testing.assert_array_equal(hc, oc)
+    dyn.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("free_time,orders,exp_second", [(False, (4, 4), False), (True, (4, 4), False), (False, (12, 6), False),
+                                                         (False, (4, 4), True)])
+def test_direct_sum_problem_parity(qc, oracle, free_time, orders, exp_second):
+    p1, p2 = direct_sum_members(qc, free_time, T=11, orders=orders, exp_second=exp_second)
+    ds = qc.unitary_direct_sum_inputs([p1, p2])
+    dyn = qc.QuantumDynamics(ds.integrators, ds.traj, eval_hessian=not exp_second)
+    assert isinstance(dyn, qc.ComposedQuantumDynamics) and len(dyn._parts) == 2
+    ref = composed_oracle(ds)
+    Z = ds.traj.datavec
+    assert dyn.dim == ref.rows == ds.traj.dims.states
+    F, J = dyn.F_dF(Z, fresh=True)
+    close(F, ref.F(Z), "direct sum F")
+    close(J, ref.dF(Z), "direct sum dF")
+    jr, jc = dyn.dF_structure
+    rr, rc = ref.structure()
+    np.testing.assert_array_equal(jr, rr)
+    np.testing.assert_array_equal(jc, rc)
+    # the members through their own handles, on their own trajectories: the same numbers, bit for bit
+    T = ds.traj.T
+    own = []
+    for p in (p1, p2):
+        d1 = qc.QuantumDynamics(p.integrators, p.traj, eval_hessian=not exp_second)
+        own.append(d1.F(p.traj.datavec, fresh=True).reshape(T - 1, -1))
+        d1.close()
+    np.testing.assert_array_equal(F, np.concatenate(own, axis=1).reshape(-1))
+    if not exp_second:
+        rng = np.random.default_rng(4)
+        mu = rng.standard_normal(dyn.dims.n_rows)
+        close(dyn.mu_d2F(Z, mu, fresh=True), ref.mu_d2F(Z, mu), "direct sum hessian", atol=1e-11)
+        hr, hc = dyn.mu_d2F_structure
+        orr, oc = ref.hess_structure()
+        np.testing.assert_array_equal(hr, orr)
+        np.testing.assert_array_equal(hc, oc)
+    dyn.close()
+
+
+@pytest.mark.gpu
+def test_direct_sum_of_three_through_the_evaluator(qc, oracle):
+    """`UnitaryDirectSumProblem([prob1, prob2, prob1], ...)` (unitary_direct_sum_problem.jl:254) behind the MOI-shaped evaluator."""
+    p1, p2 = direct_sum_members(qc, False, T=8)
+    ds = qc.unitary_direct_sum_inputs([p1, p2, p1])
+    assert ds.traj.names[-4:] == ("Ũ⃗3", "a3", "da3", "dda3")
+    dyn = qc.QuantumDynamics(ds.integrators, ds.traj)
+    ref = composed_oracle(ds)
+    ev = qc.QuantumControlEvaluator(dyn, [])
+    Z = ds.traj.datavec
+    g = np.zeros(ev.n_constraints)
+    ev.eval_constraint(g, Z)
+    close(g, ref.F(Z), "evaluator constraint")
+    vals = np.zeros(ev.jac_nnz)
+    ev.eval_constraint_jacobian(vals, Z)
+    close(vals, ref.dF(Z), "evaluator jacobian")
+    dyn.close()
+
+
+@pytest.mark.gpu
+def test_list_entry_points_error_behaviour_and_new_x(qc, oracle):
+    """`qc_eval_*_list` through ctypes: refusals with messages (never a crash), Ipopt's new_x = false on the list's first handle,
+    and the upload count a binding compares before it elides."""
+    import ctypes as C
+    L = qc._lib
+    p1, p2 = direct_sum_members(qc, False, T=6)
+    ds = qc.unitary_direct_sum_inputs([p1, p2])
+    dyn = qc.QuantumDynamics(ds.integrators, ds.traj)
+    ref = composed_oracle(ds)
+    hs, n = dyn._handles, len(dyn._parts)
+    Z = ds.traj.datavec
+    F = np.zeros(int(dyn.dims.F_len))
+    J = np.zeros(int(dyn.dims.jac_nnz))
+    assert L.lib.qc_eval_F_jac_list(hs, n, L.dptr(Z), L.dptr(F), L.dptr(J)) == L.QC_OK
+    close(F, ref.F(Z), "list F")
+    close(J, ref.dF(Z), "list dF")
+    # single-handle host entry points refuse a composed handle, and say where to go
+    assert L.lib.qc_eval_F(dyn._parts[0][2], L.dptr(Z), L.dptr(F)) == L.QC_ERR_UNSUPPORTED
+    assert b"composed" in L.lib.qc_last_error(dyn._parts[0][2])
+    # refusals
+    assert L.lib.qc_eval_F_list(None, 0, L.dptr(Z), L.dptr(F)) == L.QC_ERR_INVALID
+    assert L.lib.qc_eval_F_list(hs, n, None, L.dptr(F)) == L.QC_ERR_INVALID
+    assert L.lib.qc_eval_F_list(hs, n, L.dptr(Z), None) == L.QC_ERR_INVALID
+    assert b"NULL buffer" in L.lib.qc_last_error(dyn._parts[0][2])
+    other = qc.QuantumDynamics(p1.integrators, p1.traj)          # a handle over another trajectory
+    mixed = (C.c_void_p * 2)(dyn._parts[0][2], other._h)
+    assert L.lib.qc_eval_F_list(mixed, 2, L.dptr(Z), L.dptr(F)) == L.QC_ERR_INVALID
+    assert b"do not describe one problem" in L.lib.qc_last_error(dyn._parts[0][2])
+    other.close()
+    # new_x = false: the knots of the last call are reused, Z is not read (a poisoned vector gives the same Jacobian)
+    g0 = dyn.knot_generation()
+    dyn.F(Z)
+    assert dyn.knot_generation() == g0 + 1
+    dyn.set_new_x(False)
+    J2 = dyn.dF(np.full_like(Z, np.nan), fresh=True)
+    assert dyn.knot_generation() == g0 + 1
+    np.testing.assert_array_equal(J2, J)
+    mu = np.random.default_rng(0).standard_normal(int(dyn.dims.n_rows))
+    H2 = dyn.mu_d2F(np.full_like(Z, np.nan), mu, fresh=True)
+    dyn.set_new_x(True)
+    close(H2, ref.mu_d2F(Z, mu), "list hessian at the device's knots", atol=1e-11)
+    np.testing.assert_array_equal(dyn.mu_d2F(Z, mu, fresh=True), H2)
+    dyn.close()
+    # no analytic Hessian with an exponential integrator in the list (upstream has none either)
+    p1, p2 = direct_sum_members(qc, False, T=6, exp_second=True)
+    ds = qc.unitary_direct_sum_inputs([p1, p2])
+    dyn = qc.QuantumDynamics(ds.integrators, ds.traj, eval_hessian=False)
+    H = np.zeros(8)
+    mu = np.zeros(int(dyn.dims.n_rows))
+    assert L.lib.qc_eval_hess_list(dyn._handles, 2, L.dptr(ds.traj.datavec), L.dptr(mu), L.dptr(H)) == L.QC_ERR_UNSUPPORTED
+    with pytest.raises(L.QCollocError):
+        dyn.mu_d2F(ds.traj.datavec, mu)
+    dyn.close()
