@@ -669,7 +669,7 @@ static int land_run(qc_handle* h, LandJob& J, int shards, double t_begin, double
     pool.ensure(workers, h->device, device_l3_domains);
     // helpers: enough to keep up with the link (the replication of config 3 writes 41.5 MB per call), never more than pieces;
     // small outputs are replicated by the calling thread alone (a worker's wake-up costs 20 - 40 us)
-    const size_t out_bytes = (size_t)J.n_int * ((size_t)J.lay.jac_nnz + (J.F ? J.f_len : 0)) * sizeof(double);
+    const size_t out_bytes = (size_t)J.n_int * ((J.dst_stride ? J.dst_stride : (size_t)J.lay.jac_nnz) + (J.F ? J.f_len : 0)) * sizeof(double);
     int helpers = std::max(0, workers / std::max(1, shards) - (shards > 1 ? 1 : 0));
     if (out_bytes <= (256u << 10)) helpers = 0;
     J.t_begin = t_begin;
@@ -714,11 +714,11 @@ static size_t ring_capacity(const qc_handle* h) {
     const size_t jac = (size_t)P.F_stride + (size_t)(cp.useful ? cp.comp_len : P.jac_nnz);
     return (size_t)P.n_int * jac;
 }
-static int ring_take(qc_handle* h, int* index) {
+static int ring_take(qc_handle* h, int* index, size_t cap = 0) {
     static const int ring = std::max(2, std::min(QC_HOST_RING, getenv("QC_HOST_NBUF") ? atoi(getenv("QC_HOST_NBUF")) : 3));
     const int ib = h->hC_next;
     h->hC_next = (ib + 1) % ring;
-    const size_t cap = ring_capacity(h);
+    if (!cap) cap = ring_capacity(h);
     int rc;
     if ((rc = ensure_pinned(h, &h->hC[ib], cap, false))) return rc;
     if (h->rearm[ib]) h->rearm[ib]->r.grp.wait();             // the re-arm jobs of this block's previous use (normally long done)
@@ -1339,6 +1339,102 @@ static int list_check(qc_handle* const* hs, int32_t count, const char* who) {
     return QC_OK;
 }
 
+// The Jacobian values of a list through the compact form and the landing watch (eval_host's mechanism): per interval ONE block
+// [ the problem's residual rows | handle 0's values | handle 1's values | ... ] in HBM, every handle that can write the compact form
+// of its values itself (one copy of the N replicated blocks) does, one copy brings the blocks to a pinned ring block of hs[0],
+// and the host team replicates segment by segment into the caller's array.  Returns 1 when it served the call, 0 when the
+// list has nothing to gain from it (the plain copies follow), < 0 on error.
+static int list_eval_landing(qc_handle* const* hs, int32_t count, double* F, double* vals) {
+    qc_handle* h = hs[0];
+    const QcParams& P0 = h->prm;
+    if (!vals || h->host_landing != 1 || h->host_compact != 1) return 0;
+    struct Seg { CompactPlan cp; bool direct; size_t len, off; };
+    std::vector<Seg> seg((size_t)count);
+    const size_t f_len = (size_t)P0.F_stride;       // always in the block: its layout must not depend on what a call asks for
+    size_t blk = f_len;
+    bool any = false;
+    for (int i = 0; i < count; ++i) {
+        const QcParams& P = hs[i]->prm;
+        Seg& S = seg[(size_t)i];
+        S.cp = compact_plan(P);
+        S.direct = S.cp.useful && hs[i]->kernel == QC_KERNEL_MFMA && qc_mfma_compact_supported(P);
+        S.len = S.direct ? (size_t)S.cp.comp_len : (size_t)P.jac_nnz;
+        S.off = blk;
+        blk += S.len;
+        any = any || S.direct;
+    }
+    if (!any) return 0;
+    const double t_begin = now_us();
+    const size_t n_int = (size_t)P0.n_int, cap = n_int * blk;
+    int rc;
+    if (h->list_blk != blk || h->list_int != n_int) {   // another list led by this handle before: its blocks do not fit
+        for (int i = 0; i < QC_HOST_RING; ++i) {
+            if (h->rearm[i]) h->rearm[i]->r.grp.wait();
+            if (h->hC[i]) { (void)hipHostFree(h->hC[i]); h->hC[i] = nullptr; }
+            h->hC_armed[i] = false;
+        }
+        if (h->dC) { QC_HIP(h, hipStreamSynchronize(h->stream)); (void)hipFree(h->dC); h->dC = nullptr; }
+        h->list_blk = blk;
+        h->list_int = n_int;
+    }
+    if ((rc = ensure_zeroed(h, &h->dC, cap))) return rc;      // (zeroed once: rows no handle of the list owns are delivered as 0)
+    int ib;
+    if ((rc = ring_take(h, &ib, cap))) return rc;
+    for (int i = 0; i < count; ++i) {
+        const Seg& S = seg[(size_t)i];
+        QcParams C = S.direct ? compact_params(hs[i]->prm, S.cp) : hs[i]->prm;
+        C.J_stride = (long long)blk;
+        C.J_off = (long long)S.off;
+        C.F_stride = (long long)blk;                          // (F_off = the handle's first row inside the problem's rows: unchanged)
+        const hipError_t e = hs[i]->kernel == QC_KERNEL_MFMA ? qc_launch_mfma_F_jac(C, h->dZ, h->dC, h->dC, h->stream)
+                                                              : qc_launch_lds_F_jac(C, h->dZ, h->dC, h->dC, hs[i]->lds_bytes_jac, h->stream);
+        if (e != hipSuccess) {
+            (void)hipStreamSynchronize(h->stream);
+            return fail(&h->err, QC_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+        }
+    }
+    hipError_t ec = hipMemcpyAsync(h->hC[ib], h->dC, cap * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+    if (ec == hipSuccess) ec = hipEventRecord(h->ev_done, h->stream);
+    if (ec != hipSuccess) {
+        (void)hipStreamSynchronize(h->stream);
+        h->hC_armed[ib] = false;
+        return fail(&h->err, QC_ERR_HIP, std::string("copy of the compact values: ") + hipGetErrorString(ec));
+    }
+    LandJob J;
+    auto layout_of = [](const QcParams& P, const Seg& S) {
+        qc_team::LandLayout L;
+        L.jac_nnz = P.jac_nnz;
+        if (S.direct) {
+            L.jo_F = P.jo_F; L.jo_B = P.jo_B; L.n2 = S.cp.n2; L.copies = S.cp.copies; L.second_copies = S.cp.second_copies;
+            L.head2 = S.cp.head2; L.tail_src = S.cp.tail_src; L.tail_len = S.cp.tail_len;
+        } else {
+            L.tail_len = P.jac_nnz;                           // nothing replicated: the segment is the values
+        }
+        return L;
+    };
+    J.lay = layout_of(P0, seg[0]);
+    J.dst_stride = (size_t)P0.J_stride;
+    J.dst_off0 = (size_t)P0.J_off;
+    for (int i = 1; i < count; ++i) {
+        qc_team::LandSeg S;
+        S.lay = layout_of(hs[i]->prm, seg[(size_t)i]);
+        S.src_off = seg[(size_t)i].off;
+        S.dst_off = (size_t)hs[i]->prm.J_off;
+        J.more.push_back(S);
+    }
+    J.n_int = (int)n_int;
+    J.f_len = f_len;
+    J.blk = blk;
+    J.vals = vals;
+    J.F = F;
+    J.src = h->hC[ib];
+    J.rearm_inline = qc_team::land_inline_rearm();
+    rc = land_run(h, J, 1, t_begin, now_us());
+    if (rc) { h->hC_armed[ib] = false; return rc; }
+    if (!J.rearm_inline) ring_rearm_later(h, ib, cap);
+    return 1;
+}
+
 static int list_eval(qc_handle* const* hs, int32_t count, const double* Z, const double* mu, double* F, double* vals, double* hvals, const char* who) {
     int rc;
     if ((rc = list_check(hs, count, who))) return rc;
@@ -1360,6 +1456,14 @@ static int list_eval(qc_handle* const* hs, int32_t count, const double* Z, const
     const size_t n_int = (size_t)P.n_int;
     const size_t nF = n_int * (size_t)P.F_stride, nJ = n_int * (size_t)P.J_stride, nH = hvals ? n_int * (size_t)P.H_stride : 0;
     if ((rc = upload_knots(h, Z))) return rc;
+    if (vals) {
+        if ((rc = list_eval_landing(hs, count, F, vals)) < 0) return rc;
+        if (rc == 1) {
+            if (!hvals) return QC_OK;
+            vals = nullptr;
+            F = nullptr;
+        }
+    }
     if (F && (rc = ensure_zeroed(h, &h->dF, nF))) return rc;       // rows no handle of the list owns stay 0
     if (vals && (rc = ensure_zeroed(h, &h->dJ, nJ))) return rc;
     if (F || vals) {

@@ -169,6 +169,12 @@ constexpr unsigned long long kLandSentinel = 0x7FF4C0DEC0DE5A5Aull;
 struct LandLayout {
     int jac_nnz = 0, jo_F = 0, jo_B = 0, n2 = 0, copies = 0, second_copies = 0, head2 = 0, tail_src = 0, tail_len = 0;
 };
+// A further value segment of the interval blocks (integrator lists: one segment per state integrator): its compact values start
+// `src_off` doubles into the interval's block and are replicated to `dst_off` doubles into the interval's values.
+struct LandSeg {
+    LandLayout lay;
+    size_t src_off = 0, dst_off = 0;
+};
 
 enum { LAND_PENDING = 0, LAND_DONE = 1, LAND_FAILED = 2, LAND_TIMEOUT = 3 };
 typedef std::function<int()> land_poll_fn;   // LAND_PENDING / LAND_DONE / LAND_FAILED: has the copy into the block completed?  (calling thread only)
@@ -180,6 +186,8 @@ struct LandJob {
     size_t blk = 0, f_len = 0;
     bool rearm_inline = false;
     double* vals = nullptr;                             // caller's Jacobian values (replication target)
+    size_t dst_stride = 0, dst_off0 = 0;                // values per interval in `vals` (0: lay.jac_nnz) and where `lay`'s values start in them
+    std::vector<LandSeg> more;                          // segments behind the first (`lay`, at f_len)
     double* F = nullptr;                                // caller's residuals, or nullptr
     int n_int = 0;
     double t_begin = 0.0;                               // the deadline counts from here
@@ -240,6 +248,11 @@ inline bool land_started(const LandJob& J, int b) {   // has interval b's block 
     return u[0] != kLandSentinel && u[J.blk - 1] != kLandSentinel;
 }
 
+inline void land_replicate(const LandLayout& L, const double* src, double* dst, qc_copy_fn cpy) {
+    for (int c = 0; c < L.copies; ++c) cpy(dst + L.jo_F + (size_t)c * L.n2, src, (size_t)L.n2);
+    for (int c = 0; c < L.second_copies; ++c) cpy(dst + L.jo_B + (size_t)c * L.n2, src + L.n2, (size_t)L.n2);
+    cpy(dst + L.tail_src, src + L.head2, (size_t)L.tail_len);
+}
 inline void land_piece(LandJob& J, int k, const land_poll_fn* poll) {
     const LandLayout& L = J.lay;
     const qc_copy_fn cpy = host_copy();
@@ -248,11 +261,9 @@ inline void land_piece(LandJob& J, int k, const land_poll_fn* poll) {
         land_wait(J, blk, J.blk, poll);
         if (land_gave_up(J)) return;                       // (what is in the block is not a result)
         if (J.F) memcpy(J.F + (size_t)b * J.f_len, blk, J.f_len * sizeof(double));
-        const double* src = blk + J.f_len;
-        double* dst = J.vals + (size_t)b * L.jac_nnz;
-        for (int c = 0; c < L.copies; ++c) cpy(dst + L.jo_F + (size_t)c * L.n2, src, (size_t)L.n2);
-        for (int c = 0; c < L.second_copies; ++c) cpy(dst + L.jo_B + (size_t)c * L.n2, src + L.n2, (size_t)L.n2);
-        cpy(dst + L.tail_src, src + L.head2, (size_t)L.tail_len);
+        double* row = J.vals + (size_t)b * (J.dst_stride ? J.dst_stride : (size_t)L.jac_nnz);
+        land_replicate(L, blk + J.f_len, row + J.dst_off0, cpy);
+        for (const LandSeg& S : J.more) land_replicate(S.lay, blk + S.src_off, row + S.dst_off, cpy);
         if (J.rearm_inline) qc_host_fill(blk, J.blk, kLandSentinel);
     }
     qc_host_copy_fence();

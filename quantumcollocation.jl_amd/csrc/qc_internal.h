@@ -104,6 +104,7 @@ struct qc_handle {
     bool hC_armed[QC_HOST_RING] = {};    // completely sentinel-filled once `rearm[i]` has drained (cleared when a call fails midway)
     struct qc_rearm* rearm[QC_HOST_RING] = {};
     int hC_next = 0;
+    size_t list_blk = 0, list_int = 0;   // qc_eval_*_list led by this handle: doubles per interval block and intervals dC / hC[] were sized for
     int new_x = 1;             // qc_set_new_x: 0 = the knots on the device are current, Z is not read
     bool z_valid = false;      // dZ holds this handle's knots of SOME host-buffer call
     unsigned long long z_gen = 0;    // uploads of the knots so far (qc_knot_generation: what a binding that elides uploads compares)

@@ -118,6 +118,62 @@ void one_call(Ring& ring, const Shape& s, Mode mode, unsigned seed, int helpers,
     rearm_later(host_pool(), ring.rearm[ib], block, used);
 }
 
+// an integrator list: three value segments per interval block (compact, plain, compact), one replicated array of all three
+void one_list_call(Mode mode, unsigned seed, int helpers, bool with_F) {
+    const int n_int = 90, f_len = 52;
+    LandLayout big = config3_like(1).lay, plain, small;
+    plain.jac_nnz = 300; plain.tail_len = 300;                                  // nothing replicated: the segment is the values
+    small.n2 = 16; small.copies = 2; small.second_copies = 2; small.jo_F = 0; small.jo_B = 32; small.head2 = 32;
+    small.tail_src = 64; small.tail_len = 40; small.jac_nnz = 104;
+    const LandLayout lays[3] = {big, plain, small};
+    size_t comp[3], src_off[3], dst_off[3], blk = f_len, stride = 0;
+    for (int i = 0; i < 3; ++i) {
+        comp[i] = (size_t)lays[i].head2 + lays[i].tail_len;
+        src_off[i] = blk; blk += comp[i];
+        dst_off[i] = stride; stride += lays[i].jac_nnz;
+    }
+    const size_t used = (size_t)n_int * blk;
+    Ring ring(used);
+    const int ib = ring.take();
+    double* block = ring.blk[ib];
+    std::vector<double> payload(used), vals((size_t)n_int * stride, -1.0), F((size_t)n_int * f_len, -1.0);
+    std::mt19937_64 rng(seed);
+    std::uniform_real_distribution<double> u(-1.0, 1.0);
+    for (double& x : payload) x = u(rng);
+    std::atomic<int> complete{0};
+    std::atomic<bool> release{false};
+    std::thread engine(fake_engine_write, block, payload.data(), used, mode, seed, &complete, &release);
+    LandJob J;
+    J.lay = lays[0];
+    J.dst_stride = stride;
+    J.dst_off0 = dst_off[0];
+    for (int i = 1; i < 3; ++i) { LandSeg S; S.lay = lays[i]; S.src_off = src_off[i]; S.dst_off = dst_off[i]; J.more.push_back(S); }
+    J.n_int = n_int;
+    J.f_len = f_len;                                                            // (a list's blocks always carry the residual rows)
+    J.blk = blk;
+    J.src = block;
+    J.vals = vals.data();
+    J.F = with_F ? F.data() : nullptr;
+    J.t_begin = now_us();
+    const int done = land_team(J, host_pool(), helpers, [&]() -> int { return complete.load(std::memory_order_acquire) ? LAND_DONE : LAND_PENDING; });
+    engine.join();
+    EXPECT(done == LAND_DONE || done == LAND_PENDING, "list: state %d", done);
+    EXPECT(J.remaining.load() == 0, "list: %d pieces left", J.remaining.load());
+    size_t bad = 0;
+    for (int b = 0; b < n_int; ++b)
+        for (int i = 0; i < 3; ++i) {
+            const LandLayout& L = lays[i];
+            const double* src = payload.data() + (size_t)b * blk + src_off[i];
+            const double* v = vals.data() + (size_t)b * stride + dst_off[i];
+            for (int c = 0; c < L.copies; ++c) bad += memcmp(v + L.jo_F + (size_t)c * L.n2, src, L.n2 * 8) != 0;
+            for (int c = 0; c < L.second_copies; ++c) bad += memcmp(v + L.jo_B + (size_t)c * L.n2, src + L.n2, L.n2 * 8) != 0;
+            bad += memcmp(v + L.tail_src, src + L.head2, L.tail_len * 8) != 0;
+        }
+    for (int b = 0; with_F && b < n_int; ++b) bad += memcmp(F.data() + (size_t)b * f_len, payload.data() + (size_t)b * blk, f_len * 8) != 0;
+    EXPECT(bad == 0, "list: %zu replicated blocks differ (mode %d, seed %u, helpers %d)", bad, (int)mode, seed, helpers);
+    rearm_later(host_pool(), ring.rearm[ib], block, used);
+}
+
 void caller(int id, int iterations) {
     const Shape s = config3_like(160 + 37 * id);
     Ring ring((size_t)s.n_int * (s.f_len + s.comp_len));
@@ -148,6 +204,8 @@ int main(int argc, char** argv) {
         timeout_override_us().store(20e6);
         for (int k = 0; k < 4; ++k) one_call(ring, s, k & 1 ? RANDOM_ORDER : IN_ORDER, 10 + k, 2, true, false);
     }
+    // the value segments of an integrator list
+    for (int k = 0; k < 6; ++k) one_list_call(k % 3 == 1 ? RANDOM_ORDER : IN_ORDER, 40 + k, k % 4, k % 2 == 0);
     // queued jobs are not dropped when a pool stops: its destructor drains the queue before the workers leave
     {
         std::atomic<int> ran{0};

@@ -234,6 +234,18 @@ def test_list_entry_points_error_behaviour_and_new_x(qc, oracle):
     assert L.lib.qc_eval_F_jac_list(hs, n, L.dptr(Z), L.dptr(F), L.dptr(J)) == L.QC_OK
     close(F, ref.F(Z), "list F")
     close(J, ref.dF(Z), "list dF")
+    # the first handle leading a shorter list (its staging blocks are re-made), then the full list again
+    F1 = np.full_like(F, 7.0)
+    J1 = np.full_like(J, 7.0)
+    assert L.lib.qc_eval_F_jac_list(hs, 1, L.dptr(Z), L.dptr(F1), L.dptr(J1)) == L.QC_OK
+    own_rows, own_vals = int(dyn._parts[0][3].ddim), int(dyn._parts[0][3].jac_nnz_interval)
+    np.testing.assert_array_equal(F1.reshape(5, -1)[:, :own_rows], F.reshape(5, -1)[:, :own_rows])
+    np.testing.assert_array_equal(J1.reshape(5, -1)[:, :own_vals], J.reshape(5, -1)[:, :own_vals])
+    assert not F1.reshape(5, -1)[:, own_rows:].any()            # rows of integrators outside the list: delivered as 0
+    F2, J2 = np.zeros_like(F), np.zeros_like(J)
+    assert L.lib.qc_eval_F_jac_list(hs, n, L.dptr(Z), L.dptr(F2), L.dptr(J2)) == L.QC_OK
+    np.testing.assert_array_equal(F2, F)
+    np.testing.assert_array_equal(J2, J)
     # single-handle host entry points refuse a composed handle, and say where to go
     assert L.lib.qc_eval_F(dyn._parts[0][2], L.dptr(Z), L.dptr(F)) == L.QC_ERR_UNSUPPORTED
     assert b"composed" in L.lib.qc_last_error(dyn._parts[0][2])
