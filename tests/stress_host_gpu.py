@@ -6,7 +6,9 @@ Random Hermitian systems with 1 .. 16 levels and 0 .. 8 drives, unitaries and ke
     full copy (QC_HOST_COMPACT=0), bit for bit, over several calls with changing and unchanged x;
   * a multi-device handle with 2 .. 5 shards on device 0 against the single handle, bit for bit;
   * qc_eval_F_jac_hess_dev against the two launches, bit for bit (one fused launch where the handle has one);
-  * a window of the result against the numpy oracle (rtol 1e-10)."""
+  * a window of the result against the numpy oracle (rtol 1e-10);
+  * integrator lists (sampling problems, direct sums of unequal members) through qc_eval_*_list: the compact, watched transfer against
+    plain copies bit for bit, new_x on the list, and against the oracle."""
 import os
 import sys
 import time
@@ -131,4 +133,49 @@ for trial in range(trials):
         stats["fused" if dyn.fused_kernel_name.endswith("fused") else "two_launches"] += 1
     dyn.close()
     ref.close()
+    # ---- an integrator list (sampling problem: shared controls; direct sum: own controls per member) through qc_eval_*_list -------
+    if not kets and rng.random() < 0.35 and N <= 8:
+        from oracle_bridge import composed_oracle
+        K = int(rng.integers(2, 4))
+        Tl = min(T, 300)
+        if rng.random() < 0.5:
+            systems = [qc.QuantumSystem(herm(N), system.H_drives) for _ in range(K)]
+            lst = qc.unitary_sampling_inputs(systems, np.eye(N, dtype=complex), Tl, free_time=free_time, seed=int(rng.integers(1 << 30)))
+            kind = "sampling"
+        else:
+            ft = bool(free_time and rng.random() < 0.5)
+            parts = []
+            for k in range(K):
+                Nk = int(rng.choice([1, 2, 4, N]))
+                sk = qc.QuantumSystem(herm(Nk), [herm(Nk) for _ in range(int(rng.integers(1, 4)))])
+                parts.append(qc.unitary_smooth_pulse_inputs(sk, np.eye(Nk, dtype=complex), Tl, free_time=ft, seed=int(rng.integers(1 << 30)),
+                                                            pade_order=int(rng.choice([4, 4, 6]))))
+            if ft:
+                for pk in parts[1:]:
+                    pk.traj.data[pk.traj.components["Δt"].start, :] = parts[0].traj["Δt"][0]
+            lst = qc.unitary_direct_sum_inputs(parts)
+            kind = "direct sum"
+        os.environ["QC_HOST_LANDING"] = "0"
+        lref = qc.QuantumDynamics(lst.integrators, lst.traj)
+        os.environ.pop("QC_HOST_LANDING")
+        ldyn = qc.QuantumDynamics(lst.integrators, lst.traj)
+        Zl = lst.traj.datavec
+        lmu = rng.standard_normal(int(ldyn.dims.n_rows))
+        for rep in range(3):
+            Zr = Zl + 1e-2 * rep * rng.standard_normal(Zl.size)
+            Fr, Jr = lref.F_dF(Zr, fresh=True)
+            Fl, Jl = ldyn.F_dF(Zr, fresh=True)
+            assert np.array_equal(bits(Fl), bits(Fr)) and np.array_equal(bits(Jl), bits(Jr)), (tag, kind, "list F_dF", rep)
+            ldyn.set_new_x(False)
+            assert np.array_equal(bits(ldyn.dF(np.full_like(Zr, np.nan), fresh=True)), bits(Jr)), (tag, kind, "list dF at the device's knots")
+            ldyn.set_new_x(True)
+            if ldyn.dims.hess_nnz:
+                assert np.array_equal(bits(ldyn.mu_d2F(Zr, lmu, fresh=True)), bits(lref.mu_d2F(Zr, lmu, fresh=True))), (tag, kind, "list H")
+        oref = composed_oracle(lst)
+        eF = np.abs(Fr - oref.F(Zr)).max() / max(1.0, np.abs(Fr).max())
+        eJ = np.abs(Jr - oref.dF(Zr)).max() / max(1.0, np.abs(Jr).max())
+        assert eF < 1e-10 and eJ < 1e-10, (tag, kind, "list oracle", eF, eJ)
+        stats["lists"] = stats.get("lists", 0) + 1
+        ldyn.close()
+        lref.close()
 print(f"{trials} trials ok in {time.time() - t0:.0f} s; {stats}")
