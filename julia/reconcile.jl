@@ -12,6 +12,10 @@
 #   qft4    : 4-qubit QFT, T = 6                                        (BASELINE config 5 in small: the 2N = 32 sparse-drive kernels,
 #                                                                        `mfma32-pade4-ell`, `-hess-ell`, `-fused-ell`)
 #   order6  : 2-qubit CNOT, T = 10, order-6 Pade                        (the any-order kernels, `mfma16-padeP`, `mfma16-padeP-hess`)
+#   sampling2 / directsum2 / bangbang: the integrator lists of UnitarySamplingProblem (two systems, shared controls),
+#             UnitaryDirectSumProblem (two members, own controls) and UnitaryBangBangProblem (one derivative integrator, L1 slack
+#             components, Pade order 12) exactly as the templates build them (`prob.integrators`, `prob.trajectory`): they pin the ROW
+#             ORDER of lists with several integrators, which this repository takes to be the integrators' order
 # and writes tests/golden/ref_<case>.json: Z, mu, F, dF / mu_d2F values AND structures, plus the scalar definitions this
 # repository could only recall (INTEGRATION.md "Choices this repository cannot verify").  tests/test_reference_golden.py
 # picks the files up (COO comparison as sets of (row, col) -> summed value, hess_align = 1, rtol 1e-10) and the verdict of
@@ -33,9 +37,11 @@ json(x::AbstractDict) = "{" * join(("$(repr(String(k))):$(json(v))" for (k, v) i
 json(::Nothing) = "null"
 
 "The harness of integrator_test_1qubit.jl:41-52 on (system, traj): Core's own closures, nothing of this repository."
-function reference_record(system, traj; order=4, seed=1)
-    P = UnitaryPadeIntegrator(:Ũ⃗, :a, system, traj; order=order)                       # unitary_smooth_pulse_problem.jl:165-167
-    integrators = [P, DerivativeIntegrator(:a, :da, traj), DerivativeIntegrator(:da, :dda, traj)]   # :175-179
+function reference_record(system, traj; order=4, seed=1, integrators=nothing, described=nothing, systems=nothing)
+    if isnothing(integrators)
+        P = UnitaryPadeIntegrator(:Ũ⃗, :a, system, traj; order=order)                   # unitary_smooth_pulse_problem.jl:165-167
+        integrators = [P, DerivativeIntegrator(:a, :da, traj), DerivativeIntegrator(:da, :dda, traj)]   # :175-179
+    end
     dynamics = QuantumDynamics(integrators, traj)
     Z⃗ = traj.datavec
     F = dynamics.F(Z⃗)
@@ -49,7 +55,13 @@ function reference_record(system, traj; order=4, seed=1)
         "H_drives_re" => [real.(H) for H in system.H_drives], "H_drives_im" => [imag.(H) for H in system.H_drives],
         "levels" => size(system.H_drift, 1), "Z" => Z⃗, "mu" => μ, "F" => F,
         "dF" => ∂F, "dF_rows" => first.(dynamics.∂F_structure), "dF_cols" => last.(dynamics.∂F_structure),   # 1-based, Core's order
-        "rows_declared" => traj.dims.states * (traj.T - 1))
+        "rows_declared" => traj.dims.states * (traj.T - 1), "control_names" => collect(traj.control_names))
+    if !isnothing(described)      # an integrator list written down by hand from the template's source (the structs' fields are Core's business)
+        rec["integrators"] = described
+        rec["systems"] = [Dict{String,Any}("levels" => size(s.H_drift, 1), "H_drift_re" => real.(s.H_drift), "H_drift_im" => imag.(s.H_drift),
+                                           "H_drives_re" => [real.(H) for H in s.H_drives], "H_drives_im" => [imag.(H) for H in s.H_drives])
+                          for s in systems]
+    end
     if dynamics.μ∂²F !== nothing
         rec["mu_d2F"] = dynamics.μ∂²F(Z⃗, μ)
         rec["mu_d2F_rows"] = first.(dynamics.μ∂²F_structure)
@@ -125,9 +137,35 @@ for (name, system, gate, T, order) in (("toffoli3", qubit_system(3), toffoli, 12
     open(io -> write(io, json(r)), joinpath(out_dir, "ref_$(name).json"), "w")
 end
 
+# ---- integrator lists of the other templates: the row order of lists with several integrators ----------------------------
+quiet = (ipopt_options=IpoptOptions(print_level=1), piccolo_options=PiccoloOptions(verbose=false))
+upade(state, control, k; order=4) = Dict{String,Any}("kind" => "unitary_pade", "state" => String(state), "control" => String(control), "system" => k, "order" => order)
+deriv(x, dx) = Dict{String,Any}("kind" => "derivative", "x" => String(x), "dx" => String(dx))
+# UnitarySamplingProblem: [U_1, U_2, D(a, da), D(da, dda)] over components Ũ⃗_system_k, shared controls (unitary_sampling_problem.jl:103-107,134-155)
+sysA = QuantumSystem(0.3 * GATES[:Z], [GATES[:X], GATES[:Y]]); sysB = QuantumSystem(-0.3 * GATES[:Z], [GATES[:X], GATES[:Y]])
+probS = UnitarySamplingProblem([sysA, sysB], GATES[:H], 8, 0.2; quiet...)
+r, _ = reference_record(sysA, probS.trajectory; integrators=probS.integrators, systems=[sysA, sysB],
+                        described=[upade(:Ũ⃗_system_1, :a, 1), upade(:Ũ⃗_system_2, :a, 2), deriv(:a, :da), deriv(:da, :dda)])
+open(io -> write(io, json(r)), joinpath(out_dir, "ref_sampling2.json"), "w")
+# UnitaryDirectSumProblem: [U_1, D, D, U_2, D, D] over the members' suffixed components, own controls (unitary_direct_sum_problem.jl:104,127-130)
+fixed = (ipopt_options=IpoptOptions(print_level=1), piccolo_options=PiccoloOptions(verbose=false, free_time=false))   # as its own test (:196)
+sysD = QuantumSystem(0.01 * GATES[:Z], [GATES[:X], GATES[:Y]])
+probD = UnitaryDirectSumProblem([UnitarySmoothPulseProblem(sysD, GATES[:X], 8, 0.2; fixed...), UnitarySmoothPulseProblem(sysD, GATES[:Y], 8, 0.2; fixed...)], 0.99;
+                                ipopt_options=IpoptOptions(print_level=1))
+r, _ = reference_record(sysD, probD.trajectory; integrators=probD.integrators, systems=[sysD, sysD],
+                        described=[upade(:Ũ⃗1, :a1, 1), deriv(:a1, :da1), deriv(:da1, :dda1), upade(:Ũ⃗2, :a2, 2), deriv(:a2, :da2), deriv(:da2, :dda2)])
+open(io -> write(io, json(r)), joinpath(out_dir, "ref_directsum2.json"), "w")
+# UnitaryBangBangProblem: [U, D(u, du)], Pade order 12, control_name = :u as in its own test (unitary_bang_bang_problem.jl:163-175,205-215)
+probB = UnitaryBangBangProblem(sysD, GATES[:H], 8, 0.2; R_bang_bang=10.0, ipopt_options=IpoptOptions(print_level=1),
+                               piccolo_options=PiccoloOptions(verbose=false, pade_order=12), control_name=:u)
+r, _ = reference_record(sysD, probB.trajectory; integrators=probB.integrators, systems=[sysD],
+                        described=[upade(:Ũ⃗, :u, 1; order=12), deriv(:u, :du)])
+open(io -> write(io, json(r)), joinpath(out_dir, "ref_bangbang.json"), "w")
+
 println("\nreconcile.jl -- verdicts for INTEGRATION.md \"Choices this repository cannot verify\":")
 for (k, v) in verdicts
     println("  ", rpad(k, 72), " => ", v)
 end
-println("wrote ref_fixture.json, ref_fixture_exponential.json, ref_config1.json, ref_config2.json, ref_toffoli3.json, ref_qft4.json, ref_order6.json to ", abspath(out_dir))
+println("wrote ref_fixture.json, ref_fixture_exponential.json, ref_config1.json, ref_config2.json, ref_toffoli3.json, ref_qft4.json, ref_order6.json, ",
+        "ref_sampling2.json, ref_directsum2.json, ref_bangbang.json to ", abspath(out_dir))
 println("now run:  python -m pytest tests/test_reference_golden.py -m gpu")

@@ -104,7 +104,7 @@ def sparse_drive_problem(o, m, T, R=1, free_time=True, layout="standard", seed=0
     return prob, Z
 
 
-def composed_oracle(inp):
+def composed_oracle(inp, hess_align=16):
     """Oracle evaluation of an integrator list with several unitary integrators (sampling problem): one oracle
     Problem per group, outputs interleaved per interval in integrator order."""
     import __graft_entry__ as g
@@ -117,7 +117,7 @@ def composed_oracle(inp):
         p.hess_align = 1          # the groups share one per-interval block: it is padded as a whole (below), not per group
     T = inp.traj.T
     hess_total = sum(len(o.hess_structure_local(p)) for p in probs)
-    hess_padn = (-hess_total) % 16 if all(len(o.hess_structure_local(p)) for p in probs) else 0
+    hess_padn = (-hess_total) % max(1, hess_align) if all(len(o.hess_structure_local(p)) for p in probs) else 0
 
     def interleave(parts):
         return np.concatenate([p.reshape(T - 1, -1) for p in parts], axis=1).reshape(-1)

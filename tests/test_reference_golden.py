@@ -28,6 +28,7 @@ EXPECTED_KERNELS = {
     "ref_toffoli3.json": ("mfma16-pade4", "mfma16-pade4-hess2", "mfma16-pade4-fused"),
     "ref_qft4.json": ("mfma32-pade4-ell", "mfma32-pade4-hess-ell", "mfma32-pade4-fused-ell"),
     "ref_order6.json": ("mfma16-padeP", "mfma16-padeP-hess", "two-launches"),
+    "ref_bangbang.json": ("mfma16-padeP", "mfma16-padeP-hess", "two-launches"),
 }
 
 
@@ -68,33 +69,62 @@ def problem_from_record(qc, rec):
         assert idx.tolist() == list(range(row, row + idx.size)), f"component {name} is not contiguous / in order"
         row += idx.size
     ts = rec["timestep"]
-    traj = qc.NamedTrajectory(comps, controls=("dda",), timestep=ts if isinstance(ts, str) else float(ts))
+    controls = tuple(rec["control_names"]) if "control_names" in rec else ("dda",)
+    traj = qc.NamedTrajectory(comps, controls=controls, timestep=ts if isinstance(ts, str) else float(ts))
+    if "integrators" in rec:
+        # an integrator list of another template (sampling, direct sum, bang-bang), as reconcile.jl wrote it down
+        systems = []
+        for sr in rec["systems"]:
+            n = int(sr["levels"])
+            c2 = lambda re, im, n=n: (np.asarray(re, dtype=float) + 1j * np.asarray(im, dtype=float)).reshape(n, n, order="F")
+            systems.append(qc.QuantumSystem(c2(sr["H_drift_re"], sr["H_drift_im"]), [c2(r, i) for r, i in zip(sr["H_drives_re"], sr["H_drives_im"])]))
+        integ = []
+        for d in rec["integrators"]:
+            if d["kind"] == "unitary_pade":
+                integ.append(qc.UnitaryPadeIntegrator(d["state"], d["control"], systems[int(d["system"]) - 1], traj, order=int(d["order"])))
+            elif d["kind"] == "derivative":
+                integ.append(qc.DerivativeIntegrator(d["x"], d["dx"], traj))
+            else:
+                raise ValueError(f"unknown integrator kind {d['kind']!r} in the record")
+        return integ, traj, Z
     integ = [qc.UnitaryPadeIntegrator("Ũ⃗", "a", system, traj, order=int(rec["pade_order"])), qc.DerivativeIntegrator("a", "da", traj),
              qc.DerivativeIntegrator("da", "dda", traj)]
     return integ, traj, Z
+
+
+def oracle_of_record(qc, oracle, integ, traj):
+    """(F, dF, structure, mu_d2F, hess_structure) closures of the CPU oracle for a record's integrator list (hess_align = 1)."""
+    from types import SimpleNamespace
+
+    from oracle_bridge import composed_oracle, problem_from_inputs
+    inp = SimpleNamespace(integrators=integ, traj=traj)
+    if len(qc.split_groups(integ)) > 1:
+        return composed_oracle(inp, hess_align=1)
+    prob = problem_from_inputs(inp)
+    prob.hess_align = 1
+    return SimpleNamespace(F=lambda Z: oracle.F(prob, Z), dF=lambda Z: oracle.dF(prob, Z), structure=lambda: oracle.jac_structure(prob),
+                           mu_d2F=lambda Z, mu: oracle.mu_d2F(prob, Z, mu), hess_structure=lambda: oracle.hess_structure(prob), rows=prob.ddim)
 
 
 @needs_files
 @pytest.mark.parametrize("path", FILES, ids=[os.path.basename(f) for f in FILES])
 def test_oracle_against_reference_outputs(qc, oracle, path):
     """The CPU oracle against Core's numbers: this is what pins the oracle (and, through the GPU parity tests, the kernels)."""
-    from oracle_bridge import problem_from_inputs
     rec = json.load(open(path))
     integ, traj, Z = problem_from_record(qc, rec)
-    prob = problem_from_inputs(type("I", (), {"integrators": integ, "traj": traj})())
-    prob.hess_align = 1
-    F = oracle.F(prob, Z)
+    ref = oracle_of_record(qc, oracle, integ, traj)
+    F = ref.F(Z)
     Fr = np.asarray(rec["F"], dtype=float)
     assert F.size == Fr.size == int(rec["rows_declared"])
     np.testing.assert_allclose(F, Fr, rtol=RTOL, atol=RTOL * max(1.0, np.abs(Fr).max()))
-    jr, jc = oracle.jac_structure(prob)
+    jr, jc = ref.structure()
     Jr = np.asarray(rec["dF"], dtype=float)
-    assert_coo_equal(coo_sum(jr, jc, oracle.dF(prob, Z), False), coo_sum(rec["dF_rows"], rec["dF_cols"], Jr, True), "dF", np.abs(Jr).max())
+    assert_coo_equal(coo_sum(jr, jc, ref.dF(Z), False), coo_sum(rec["dF_rows"], rec["dF_cols"], Jr, True), "dF", np.abs(Jr).max())
     if "mu_d2F" in rec:
         mu = np.asarray(rec["mu"], dtype=float)
-        hr, hc = oracle.hess_structure(prob)
+        hr, hc = ref.hess_structure()
         Hr = np.asarray(rec["mu_d2F"], dtype=float)
-        assert_coo_equal(coo_sum(hr, hc, oracle.mu_d2F(prob, Z, mu), False), coo_sum(rec["mu_d2F_rows"], rec["mu_d2F_cols"], Hr, True), "mu_d2F",
+        assert_coo_equal(coo_sum(hr, hc, ref.mu_d2F(Z, mu), False), coo_sum(rec["mu_d2F_rows"], rec["mu_d2F_cols"], Hr, True), "mu_d2F",
                          np.abs(Hr).max())
 
 
@@ -103,7 +133,7 @@ def check_hip_path_against_record(qc, path):
     integ, traj, Z = problem_from_record(qc, rec)
     dyn = qc.QuantumDynamics(integ, traj, hess_align=1)
     want = EXPECTED_KERNELS.get(os.path.basename(path))
-    if want is not None:
+    if want is not None and not isinstance(dyn, qc.ComposedQuantumDynamics):
         assert dyn.kernel_names + (dyn.fused_kernel_name,) == want, (os.path.basename(path), dyn.kernel_names, dyn.fused_kernel_name)
     F, J = dyn.F_dF(Z)
     Fr, Jr = np.asarray(rec["F"], dtype=float), np.asarray(rec["dF"], dtype=float)
@@ -119,6 +149,9 @@ def check_hip_path_against_record(qc, path):
         ours = {(int(r), int(c)) for r, c in zip(hr, hc)}
         ref = {(int(r) - 1, int(c) - 1) for r, c in zip(rec["mu_d2F_rows"], rec["mu_d2F_cols"])}
         assert ref <= ours or ours <= ref, "Hessian structures are not nested"
+        if isinstance(dyn, qc.ComposedQuantumDynamics):       # (lists have no one-call form)
+            dyn.close()
+            return
         # ... and the one-call form (a kernel of its own where `fused_kernel_name` says so), device-resident
         import torch
         dZ, dmu = torch.from_numpy(Z).cuda(), torch.from_numpy(mu).cuda()
@@ -175,6 +208,69 @@ def test_reference_record_machinery_with_mock_records(qc, oracle, tmp_path, name
     runs end to end on the GPU, and the kernel that serves each record is the one the record is meant to pin."""
     path = str(tmp_path / name)
     write_mock_record(qc, oracle, path, n_qubits, qc.GATES[gate], T, order, shuffle_seed=len(name))
+    check_hip_path_against_record(qc, path)
+
+
+def write_mock_list_record(qc, oracle, path, kind, shuffle_seed):
+    """Mock record (this repository's oracle, NOT reference output) of one of reconcile.jl's integrator-list cases, in its schema."""
+    s1 = qc.multi_qubit_system(1)
+    upade = lambda state, control, k, order=4: {"kind": "unitary_pade", "state": state, "control": control, "system": k, "order": order}
+    deriv = lambda x, dx: {"kind": "derivative", "x": x, "dx": dx}
+    if kind == "sampling2":
+        systems = [qc.QuantumSystem(0.3 * qc.PAULIS["Z"], s1.H_drives), qc.QuantumSystem(-0.3 * qc.PAULIS["Z"], s1.H_drives)]
+        inp = qc.unitary_sampling_inputs(systems, qc.GATES["H"], 8)
+        described = [upade("Ũ⃗_system_1", "a", 1), upade("Ũ⃗_system_2", "a", 2), deriv("a", "da"), deriv("da", "dda")]
+    elif kind == "directsum2":
+        systems = [s1, s1]
+        inp = qc.unitary_direct_sum_inputs([qc.unitary_smooth_pulse_inputs(s1, qc.GATES["X"], 8, free_time=False),
+                                            qc.unitary_smooth_pulse_inputs(s1, qc.GATES["Y"], 8, free_time=False, seed=9)])
+        described = [upade("Ũ⃗1", "a1", 1), deriv("a1", "da1"), deriv("da1", "dda1"), upade("Ũ⃗2", "a2", 2), deriv("a2", "da2"), deriv("da2", "dda2")]
+    else:
+        systems = [s1]
+        inp = qc.unitary_bang_bang_inputs(s1, qc.GATES["H"], 8, pade_order=12, control_name="u")
+        described = [upade("Ũ⃗", "u", 1, 12), deriv("u", "du")]
+    traj, Z = inp.traj, inp.traj.datavec
+    ref = oracle_of_record(qc, oracle, inp.integrators, traj)
+    rng = np.random.default_rng(shuffle_seed)
+    F = ref.F(Z)
+    mu = rng.standard_normal(F.size)
+    jr, jc = ref.structure()
+    hr, hc = ref.hess_structure()
+    J, H = ref.dF(Z), ref.mu_d2F(Z, mu)
+    pj, ph = rng.permutation(J.size), rng.permutation(H.size)
+    col = lambda M: np.asarray(M).reshape(-1, order="F")
+    sysrec = lambda s: {"levels": s.levels, "H_drift_re": col(s.H_drift.real).tolist(), "H_drift_im": col(s.H_drift.imag).tolist(),
+                        "H_drives_re": [col(Hk.real).tolist() for Hk in s.H_drives], "H_drives_im": [col(Hk.imag).tolist() for Hk in s.H_drives]}
+    rec = {"MOCK": "numbers of this repository's CPU oracle, NOT reference output", "T": traj.T, "dim": traj.dim, "global_dim": 0,
+           "names": list(traj.names), "components": {n: [int(i) + 1 for i in range(r.start, r.stop)] for n, r in traj.components.items()},
+           "control_names": list(traj.controls), "timestep": traj.timestep, "pade_order": 4, **sysrec(systems[0]),
+           "systems": [sysrec(s) for s in systems], "integrators": described,
+           "Z": Z.tolist(), "mu": mu.tolist(), "F": F.tolist(), "rows_declared": int(F.size),
+           "dF": J[pj].tolist(), "dF_rows": (np.asarray(jr)[pj] + 1).tolist(), "dF_cols": (np.asarray(jc)[pj] + 1).tolist(),
+           "mu_d2F": H[ph].tolist(), "mu_d2F_rows": (np.asarray(hr)[ph] + 1).tolist(), "mu_d2F_cols": (np.asarray(hc)[ph] + 1).tolist()}
+    json.dump(rec, open(path, "w"))
+
+
+@pytest.mark.parametrize("kind", ["sampling2", "directsum2", "bangbang"])
+def test_list_record_machinery_on_the_cpu(qc, oracle, tmp_path, kind):
+    """reconcile.jl's integrator-list records, stood in for by mock records: schema -> mirror constructors -> oracle -> COO-set
+    comparison runs end to end without a GPU (the record's own numbers come back)."""
+    path = str(tmp_path / f"ref_{kind}.json")
+    write_mock_list_record(qc, oracle, path, kind, shuffle_seed=3)
+    rec = json.load(open(path))
+    integ, traj, Z = problem_from_record(qc, rec)
+    ref = oracle_of_record(qc, oracle, integ, traj)
+    np.testing.assert_array_equal(ref.F(Z), np.asarray(rec["F"]))
+    jr, jc = ref.structure()
+    assert_coo_equal(coo_sum(jr, jc, ref.dF(Z), False), coo_sum(rec["dF_rows"], rec["dF_cols"], rec["dF"], True), "dF", 1.0)
+    assert len(qc.split_groups(integ)) == {"sampling2": 2, "directsum2": 2, "bangbang": 1}[kind]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["sampling2", "directsum2", "bangbang"])
+def test_list_record_machinery_with_mock_records(qc, oracle, tmp_path, kind):
+    path = str(tmp_path / f"ref_{kind}.json")
+    write_mock_list_record(qc, oracle, path, kind, shuffle_seed=5)
     check_hip_path_against_record(qc, path)
 
 
