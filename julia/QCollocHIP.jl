@@ -241,16 +241,16 @@ function dynamics_list(parts, traj; device::Int=0, eval_hessian::Bool=true, exac
     keep = Any[]                                               # generator matrices the descriptors point at
     function desc_of(p, place)
         sys = p.system
-        pairs = opt(p, :derivative_pairs, [])
+        dpairs = opt(p, :derivative_pairs, [])
         expo = opt(p, :exponential, false)
         G0 = Matrix{Float64}(sys.G_drift)
         Gd = reduce(hcat, [vec(Matrix{Float64}(G)) for G in sys.G_drives])
         push!(keep, G0); push!(keep, Gd)
-        xs = [off(q[1]) for q in pairs]; dxs = [off(q[2]) for q in pairs]; dms = [length(traj.components[q[1]]) for q in pairs]
+        xs = [off(q[1]) for q in dpairs]; dxs = [off(q[2]) for q in dpairs]; dms = [length(traj.components[q[1]]) for q in dpairs]
         return QCDesc(sys.levels, length(sys.G_drives), traj.T, traj.dim, traj.global_dim,
                       off(p.state_name), off(opt(p, :control_name, :a)), free_time ? off(traj.timestep) : -1,
                       free_time ? 0.0 : Float64(traj.timestep),
-                      expo ? 1 : 0, expo ? 0 : opt(p, :pade_order, 4), length(pairs),
+                      expo ? 1 : 0, expo ? 0 : opt(p, :pade_order, 4), length(dpairs),
                       pad8(xs), pad8(dxs), pad8(dms), pointer(G0), pointer(Gd),
                       device, 0, 0, 0, opt(p, :n_kets, 0), 1,
                       place[1], place[2], place[3], place[4], place[5], place[6], 0, place[7], pad8(Int[]))
@@ -281,16 +281,20 @@ function dynamics_list(parts, traj; device::Int=0, eval_hessian::Bool=true, exac
     n_int = Int(own[1].n_intervals)
     F_len = rows * n_int; jac_nnz = jac * n_int; hess_nnz = hess * n_int
     # structures: every handle reports its own entries with the problem's row / column numbers; interleave them per interval
-    function structure(fn, per)
+    function structure(hessian::Bool, per)
         rs = Matrix{Int64}[]; cs = Matrix{Int64}[]
         for (h, n) in zip(handles, per)
             r = Vector{Int64}(undef, n * n_int); c = similar(r)
-            check(ccall((fn, LIB[]), Cint, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}, Cint), h, r, c, 1), h)
+            if hessian
+                check(ccall((:qc_hess_structure, LIB[]), Cint, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}, Cint), h, r, c, 1), h)
+            else
+                check(ccall((:qc_jac_structure, LIB[]), Cint, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}, Cint), h, r, c, 1), h)
+            end
             push!(rs, reshape(r, n, n_int)); push!(cs, reshape(c, n, n_int))
         end
         return collect(zip(Int.(vec(reduce(vcat, rs))), Int.(vec(reduce(vcat, cs)))))
     end
-    ∂F_structure = structure(:qc_jac_structure, [Int(x.jac_nnz_interval) for x in own])
+    ∂F_structure = structure(false, [Int(x.jac_nnz_interval) for x in own])
     nh = length(handles)
     F! = function (out::AbstractVector{Float64}, Z⃗::AbstractVector{Float64})
         length(out) == F_len || error("F!: output has length $(length(out)), expected $F_len")
@@ -308,7 +312,7 @@ function dynamics_list(parts, traj; device::Int=0, eval_hessian::Bool=true, exac
     μ∂²F = nothing; μ∂²F! = nothing; μ∂²F_structure = nothing
     if with_hess
         per = [Int(x.hess_nnz_interval) for x in own]; per[end] += hess - hess_own
-        μ∂²F_structure = structure(:qc_hess_structure, per)
+        μ∂²F_structure = structure(true, per)
         μ∂²F! = function (out::AbstractVector{Float64}, Z⃗::AbstractVector{Float64}, μ⃗::AbstractVector{Float64})
             length(out) == hess_nnz || error("μ∂²F!: output has length $(length(out)), expected $hess_nnz")
             length(μ⃗) == F_len || error("μ∂²F!: μ has length $(length(μ⃗)), expected $F_len")
