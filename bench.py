@@ -295,6 +295,35 @@ def host_visible_record(qc, inp, dyn, Zs, cpu_rec, t1000_equiv=1.0):
     return rec
 
 
+def integrator_list_record(qc, cpu_rec, K=3, reps=15):
+    """Host-buffer times of an integrator list with several state integrators -- a `UnitarySamplingProblem` over K copies of the
+    metric's 3-qubit system with scattered drifts, shared controls, T = 1000 (reference unitary_sampling_problem.jl:134-155) -- through
+    `qc_eval_*_list` (one upload, the compact watched transfer of every member's Jacobian values), the vector-returning calls of the
+    Python mirror.  Extra object of `host_visible`; never `value`."""
+    rng = np.random.default_rng(11)
+    base = qc.multi_qubit_system(3)
+    systems = [qc.QuantumSystem(base.H_drift * (1.0 + 0.1 * rng.standard_normal()), base.H_drives) for _ in range(K)]
+    inp = qc.unitary_sampling_inputs(systems, qc.GATES["TOFFOLI"], T_PER_GPU)
+    dyn = qc.QuantumDynamics(inp.integrators, inp.traj)
+    Zs = [inp.traj.datavec + 1e-3 * k * rng.standard_normal(inp.traj.datavec.size) for k in range(3)]
+    mu = np.ones(int(dyn.dims.n_rows))
+    out = {"workload": f"UnitarySamplingProblem, {K} x 3-qubit systems, shared controls, T = {T_PER_GPU}", "K": K,
+           "values_MB": {"F": 8e-6 * int(dyn.dims.F_len), "dF": 8e-6 * int(dyn.dims.jac_nnz), "mu_d2F": 8e-6 * int(dyn.dims.hess_nnz)}}
+    for name, f in (("F_ms", lambda i: dyn.F(Zs[i % 3])), ("F_dF_ms", lambda i: dyn.F_dF(Zs[i % 3])), ("hess_ms", lambda i: dyn.mu_d2F(Zs[i % 3], mu))):
+        for i in range(3):
+            f(i)
+        ts = []
+        for i in range(reps):
+            t0 = time.perf_counter()
+            f(i)
+            ts.append(time.perf_counter() - t0)
+        out[name] = float(np.median(ts)) * 1e3
+    if cpu_rec and "F_dF_ms" in cpu_rec:
+        out["F_dF_speedup_vs_cpu_baseline"] = K * cpu_rec["F_dF_ms"] / out["F_dF_ms"]      # (the stand-in evaluates the K systems one after the other)
+    dyn.close()
+    return out
+
+
 def _mfma_counters():
     """Counter-based MFMA figures of the newest profiles/r*_mfma_util.json (rocprofv3 --pmc runs, external to this process)."""
     import glob
@@ -679,6 +708,11 @@ def main():
             if world == 1:
                 host_rec = host_visible_record(qc, inp, dyn, Zhs, cpu_rec, t1000_equiv)
                 host_rec["devices"] = [dev_index]
+                if args.config in (3, 4):
+                    try:
+                        host_rec["integrator_list"] = integrator_list_record(qc, cpu_rec)
+                    except Exception as exc:   # noqa: BLE001
+                        host_rec["integrator_list"] = {"error": repr(exc)[:300]}
             else:
                 # The reference's consumer is ONE process: rank 0 builds the in-library multi-device handle
                 # (qc_create_multi over all N GPUs) and times the same host-buffer calls on the whole T = 1000 N
