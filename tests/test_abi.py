@@ -310,6 +310,29 @@ def test_c_example_matches_the_python_mirror(qc, tmp_path):
     jr, jc = dyn.dF_structure
     assert (int(m.group(4)), int(m.group(5))) == (int(jr[0]) + 1, int(jc[0]) + 1)
     dyn.close()
+    # the example's integrator list (two systems, shared controls) against the same list through the Python mirror
+    ml = re.search(r"list checksums F (\S+) dF (\S+) mu_d2F (\S+) sizes (\d+) (\d+) (\d+)", r.stdout)
+    assert ml, r.stdout
+    Z2 = np.zeros((T, 2 * S + 3 * M + 1))
+    for t in range(T):
+        for k in range(2):
+            th = (0.3 + 0.05 * k) * t
+            Z2[t, k * S:(k + 1) * S] = [np.cos(th), 0, 0, -np.sin(th), 0, np.cos(th), -np.sin(th), 0]
+        Z2[t, 2 * S:2 * S + 3 * M] = [0.1 * np.sin(1.0 + t + 0.7 * k) for k in range(3 * M)]
+        Z2[t, 2 * S + 3 * M] = 0.2
+    comps = {"Ũ⃗_system_1": Z2[:, :8].T, "Ũ⃗_system_2": Z2[:, 8:16].T, "a": Z2[:, 16:18].T, "da": Z2[:, 18:20].T, "dda": Z2[:, 20:22].T,
+             "Δt": Z2[:, 22:23].T}
+    traj2 = qc.NamedTrajectory(comps, controls=("dda", "Δt"), timestep="Δt")
+    sys_b = qc.QuantumSystem(-0.1 * qc.PAULIS["Z"], [qc.PAULIS["X"], qc.PAULIS["Y"]])
+    lst = qc.QuantumDynamics([qc.UnitaryPadeIntegrator("Ũ⃗_system_1", "a", sys_, traj2), qc.UnitaryPadeIntegrator("Ũ⃗_system_2", "a", sys_b, traj2),
+                              qc.DerivativeIntegrator("a", "da", traj2), qc.DerivativeIntegrator("da", "dda", traj2)], traj2, hess_align=1)
+    F2, J2 = lst.F_dF(traj2.datavec)
+    H2 = lst.mu_d2F(traj2.datavec, np.ones(int(lst.dims.n_rows)))
+    assert (int(ml.group(4)), int(ml.group(5)), int(ml.group(6))) == (F2.size, J2.size, H2.size)
+    for got, arr, mod in zip(ml.groups()[:3], (F2, J2, H2), (7, 11, 13)):
+        ref = float(np.sum(arr * (1 + np.arange(arr.size) % mod)))
+        assert abs(float(got) - ref) <= 1e-11 * max(1.0, abs(ref)), (got, ref)
+    lst.close()
 
 
 def test_descriptor_fuzz_never_crashes(qc):
