@@ -160,10 +160,12 @@ __global__ __launch_bounds__(kRT) void qc_rollout_states_kernel(RollParams R, co
     double* Et = sm + 2 * ns;
     const int c = blockIdx.x;
     const int t0 = c * R.chunk, t1 = min(R.n_int, t0 + R.chunk);
+    // (the first knot of chunk c > 0 is the last knot the previous chunk steps to: ONE workgroup writes that column -- the two values
+    //  differ in the last bit, S_c being a product in another order, and two writers made the result depend on which came last)
     for (int idx = tid; idx < ns; idx += kRT) {
         const double v = S[(size_t)c * ns + idx];
         Xa[idx] = v;
-        out[(size_t)t0 * ns + idx] = v;
+        if (c == 0) out[idx] = v;
     }
     __syncthreads();
     double* cur = Xa;

@@ -612,8 +612,18 @@ class ComposedQuantumDynamics(QuantumDynamics):
     def bind_mu_d2F_device(self, Z, mu, H, stream=None):
         return lambda: (self.mu_d2F_device(Z, mu, H, stream), 0)[1]
 
-    def rollout(self, Z, init):
-        raise NotImplementedError("rollouts of a sampling problem are per system: build a QuantumDynamics per unitary integrator")
+    def rollout(self, Z, init, part: int = 0):
+        """Rollout under the system and controls of the list's `part`-th state integrator (`unitary_rollout_fidelity(traj, sys_k)` of a
+        sampling problem, reference unitary_sampling_problem.jl:187-193; a member of a direct sum): the (2N cols) x T state matrix."""
+        desc, _, h, _ = self._parts[part]
+        Z = self._Z(Z)
+        init = np.ascontiguousarray(init, dtype=np.float64).ravel()
+        s = 2 * desc.N * (desc.state_cols or desc.N)
+        if init.size != s:
+            raise ValueError(f"initial state has length {init.size}, expected {s}")
+        out = np.empty((desc.T, s))
+        _lib.check(_lib.lib.qc_rollout(h, _lib.dptr(Z), _lib.dptr(init), _lib.dptr(out)), h)
+        return np.ascontiguousarray(out.T)
 
     def F_dF_into(self, Z, F, J):
         self.F_dF(Z, out=(F, J))

@@ -106,3 +106,19 @@ def test_unitary_rollout_fidelity(qc, oracle):
     R = oracle.rollout(prob, inp.traj.datavec, qc.operator_to_iso_vec(np.eye(2, dtype=complex)))
     assert abs(f - oracle.iso_vec_unitary_fidelity(R[:, -1], inp.traj.goal["Ũ⃗"])) < 1e-12
     assert 0.0 <= f <= 1.0 + 1e-12
+
+
+@pytest.mark.gpu
+def test_rollout_is_bit_reproducible(qc, oracle):
+    """Every knot's state is written by ONE workgroup: until round 4 the first knot of a scan chunk was written twice (by the chunk that
+    starts there and by the one that ends there, products in different orders, one ulp apart) and repeated calls differed in the last
+    bit at the chunk boundaries."""
+    for cfg, T in [(2, 9), (2, 50), (3, 101), (1, 17)]:
+        inp = qc.config_inputs(cfg, T=T)
+        dyn = qc.QuantumDynamics(inp.integrators, inp.traj)
+        N = inp.system.levels
+        init = qc.operator_to_iso_vec(np.eye(N, dtype=complex))
+        first = dyn.rollout(inp.traj.datavec, init)
+        for _ in range(6):
+            np.testing.assert_array_equal(dyn.rollout(inp.traj.datavec, init), first)
+        dyn.close()

@@ -283,3 +283,33 @@ def test_list_entry_points_error_behaviour_and_new_x(qc, oracle):
     with pytest.raises(L.QCollocError):
         dyn.mu_d2F(ds.traj.datavec, mu)
     dyn.close()
+
+
+@pytest.mark.gpu
+def test_rollouts_of_a_list_are_per_member(qc, oracle):
+    """`unitary_rollout_fidelity(prob.trajectory, sys_k)` of a sampling problem (unitary_sampling_problem.jl:187-193) and the members of a
+    direct sum: the rollout of the list's k-th state integrator uses ITS system and ITS controls."""
+    rng = np.random.default_rng(8)
+    base = qc.multi_qubit_system(2)
+    systems = [qc.QuantumSystem(base.H_drift * (1.0 + 0.3 * k), base.H_drives) for k in range(3)]
+    inp = qc.unitary_sampling_inputs(systems, qc.GATES["CNOT"], 21)
+    dyn = qc.QuantumDynamics(inp.integrators, inp.traj)
+    Z = inp.traj.datavec
+    init = qc.operator_to_iso_vec(np.eye(4, dtype=complex))
+    groups = qc.split_groups(inp.integrators)
+    from types import SimpleNamespace
+    for k in range(3):
+        prob = problem_from_inputs(SimpleNamespace(integrators=groups[k], traj=inp.traj))
+        np.testing.assert_allclose(dyn.rollout(Z, init, part=k), oracle.rollout(prob, Z, init), rtol=1e-10, atol=1e-11)
+    assert not np.allclose(dyn.rollout(Z, init, part=0), dyn.rollout(Z, init, part=2))
+    dyn.close()
+    p1, p2 = direct_sum_members(qc, False, T=9)
+    ds = qc.unitary_direct_sum_inputs([p1, p2])
+    dyn = qc.QuantumDynamics(ds.integrators, ds.traj)
+    for k, p in enumerate((p1, p2)):
+        n = p.system.levels
+        own = qc.QuantumDynamics(p.integrators, p.traj)
+        i0 = qc.operator_to_iso_vec(np.eye(n, dtype=complex))
+        np.testing.assert_array_equal(dyn.rollout(ds.traj.datavec, i0, part=k), own.rollout(p.traj.datavec, i0))
+        own.close()
+    dyn.close()
