@@ -24,24 +24,35 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as g
 
 
-def solve(max_iter: int = 80, T: int = 50, verbose: bool = True, tol: float = 1e-6):
+def solve(max_iter: int = 80, T: int = 50, verbose: bool = True, tol: float = 1e-6, drift_scales=None):
+    """drift_scales = None: BASELINE config 1.  drift_scales = (0.7, 1.3, ...): a `UnitarySamplingProblem` over copies of the config-1
+    system whose drifts are scaled so (reference unitary_sampling_problem.jl:44-167: one pulse that makes the gate on EVERY system) --
+    an integrator list with several state integrators, evaluated through qc_eval_*_list, one infidelity objective per system."""
     qc = g.load_package()
-    inp = qc.config_inputs(1, T=T)
-    traj = inp.traj
     U_goal = qc.GATES["H"]
+    if drift_scales is None:
+        inp = qc.config_inputs(1, T=T)
+        state_names = ["Ũ⃗"]
+    else:
+        base = qc.multi_qubit_system(1)
+        systems = [qc.QuantumSystem(base.H_drift * float(sc), base.H_drives) for sc in drift_scales]
+        inp = qc.unitary_sampling_inputs(systems, U_goal, T)
+        state_names = [f"Ũ⃗_system_{k + 1}" for k in range(len(systems))]
+    traj = inp.traj
     dyn = qc.QuantumDynamics(inp.integrators, traj)
-    obj = qc.UnitaryInfidelityObjective("Ũ⃗", traj, Q=100.0, form="abs2")      # smooth at the optimum
+    objs = [qc.UnitaryInfidelityObjective(nm, traj, Q=100.0, form="abs2") for nm in state_names]      # smooth at the optimum
     R = 1e-2
     reg = qc.TrajectoryObjective(qc.QuadraticRegularizer("a", traj, R) + qc.QuadraticRegularizer("da", traj, R)
                                  + qc.QuadraticRegularizer("dda", traj, R), traj)
-    ev = qc.QuantumControlEvaluator(dyn, [obj, reg])
+    ev = qc.QuantumControlEvaluator(dyn, objs + [reg])
     nv, m = ev.n_variables, ev.n_constraints
     zdim, comps = traj.dim, traj.components
 
     # pinned variables (initial state, initial / final controls) are eliminated; bounds as in the problem template
     z_full = traj.datavec.copy()
     pinned = np.zeros(nv, dtype=bool)
-    pinned[comps["Ũ⃗"].start:comps["Ũ⃗"].stop] = True
+    for nm in state_names:
+        pinned[comps[nm].start:comps[nm].stop] = True
     for t_pin in (0, T - 1):
         pinned[t_pin * zdim + comps["a"].start:t_pin * zdim + comps["a"].stop] = True
     free = np.flatnonzero(~pinned)
@@ -76,9 +87,11 @@ def solve(max_iter: int = 80, T: int = 50, verbose: bool = True, tol: float = 1e
     def barrier(x, mu):
         return -mu * (np.log(x[has_lo] - lo[has_lo]).sum() + np.log(hi[has_hi] - x[has_hi]).sum())
 
-    def rollout_fidelity(z):
-        states = dyn.rollout(z, qc.operator_to_iso_vec(np.eye(U_goal.shape[0], dtype=complex)))
-        return qc.iso_vec_unitary_fidelity(states[:, -1], qc.operator_to_iso_vec(U_goal))
+    def rollout_fidelity(z):          # of the pulse under every system's own generators: the smallest
+        init, goal = qc.operator_to_iso_vec(np.eye(U_goal.shape[0], dtype=complex)), qc.operator_to_iso_vec(U_goal)
+        if drift_scales is None:
+            return qc.iso_vec_unitary_fidelity(dyn.rollout(z, init)[:, -1], goal)
+        return min(qc.iso_vec_unitary_fidelity(dyn.rollout(z, init, part=k)[:, -1], goal) for k in range(len(state_names)))
 
     with np.errstate(invalid="ignore"):                 # (inf - inf on the unbounded variables, masked by the where)
         width = np.where(has_lo & has_hi, hi - lo, 1.0)
@@ -157,10 +170,11 @@ def solve(max_iter: int = 80, T: int = 50, verbose: bool = True, tol: float = 1e
     if verbose:
         print(f"iterations {it}  launches {ev.stats}  rollout fidelity {f_before:.6f} -> {f_after:.6f}  max |dynamics residual| {viol:.2e}")
     stats = dict(ev.stats)
-    for o in (dyn, obj, reg):
+    for o in [dyn, reg] + objs:
         o.close()
     return f_before, f_after, viol, stats
 
 
 if __name__ == "__main__":
-    solve(int(sys.argv[1]) if len(sys.argv) > 1 else 80)
+    # python examples/ipm_solve.py [max_iter] [drift scale ...]     e.g.  ipm_solve.py 80 0.7 1.3  = a two-system sampling problem
+    solve(int(sys.argv[1]) if len(sys.argv) > 1 else 80, drift_scales=[float(x) for x in sys.argv[2:]] or None)

@@ -35,6 +35,20 @@ def test_interior_point_solve_with_exact_hessians(qc):
 
 
 @pytest.mark.gpu
+def test_interior_point_solve_of_a_sampling_problem(qc):
+    """A two-system `UnitarySamplingProblem` (reference unitary_sampling_problem.jl:44-167; its own test: "Sample robustness test", :204)
+    through the same solve: the integrator list [U_1, U_2, D, D] evaluated by qc_eval_*_list, one infidelity objective per system,
+    ONE pulse that makes the gate on both systems."""
+    sys.path.insert(0, os.path.join(ROOT, "examples"))
+    import ipm_solve
+    before, after, viol, stats = ipm_solve.solve(max_iter=150, T=30, verbose=False, drift_scales=(0.5, 1.5))
+    assert after > before + 0.5 and after > 0.97, (before, after)  # the smaller of the two systems' rollout fidelities: 0.28 -> 0.99
+    assert viol < 1e-2, viol
+    assert stats["F_dF"] + stats["dF"] == stats["mu_d2F"] and stats["mu_d2F"] >= 5
+    assert stats["uploads_elided"] >= stats["dF"]                  # new_x = false on the list's first handle
+
+
+@pytest.mark.gpu
 def test_bench_line_keeps_the_driver_contract():
     """`python bench.py --gpus 1 --steps K --warmup W` prints ONE JSON line with the keys the driver and the judge read: the metric of
     BASELINE.json, whole-job throughput, K and W as given, the `roofline` and `cpu_baseline` objects -- here in a short run."""
