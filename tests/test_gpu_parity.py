@@ -1369,12 +1369,14 @@ def test_mfma32_kernels_on_padded_systems(qc, oracle, N, m, integrator):
     h.close()
 
 
-@pytest.mark.parametrize("N,m,integrator", [(20, 3, "pade"), (24, 2, "exponential"), (32, 2, "pade"), (32, 2, "exponential")])
+@pytest.mark.parametrize("N,m,integrator", [(20, 3, "pade"), (24, 2, "exponential"), (32, 2, "pade"), (32, 2, "exponential"),
+                                            (40, 2, "pade"), (40, 1, "exponential"), (48, 1, "pade")])
 def test_systems_beyond_the_lds_budget_use_the_global_workspace(qc, oracle, N, m, integrator):
     """More than ~18 levels (5 qubits: N = 32) do not fit 160 KB of LDS per interval: the same kernels run with their
-    scratch in a global-memory workspace.  F, dF, mu_d2F against the oracle."""
+    scratch in a global-memory workspace -- beyond 32 levels too (two 7-level transmons: N = 49; the library refuses no size).
+    F, dF, mu_d2F against the oracle."""
     integ = oracle.PADE if integrator == "pade" else oracle.EXPONENTIAL
-    prob, Z = random_problem(oracle, N=N, m=m, T=3, order=4, integrator=integ, seed=N + m)
+    prob, Z = random_problem(oracle, N=N, m=m, T=3 if N <= 32 else 2, order=4, integrator=integ, seed=N + m)
     h = RawHandle(qc, prob, kernel="lds")      # (order-4 Pade would otherwise take the 4 x 4-tile MFMA kernel)
     assert h.dims.kernel == qc._lib.QC_KERNEL_LDS
     F, J = h.F_jac(Z)
@@ -1382,9 +1384,29 @@ def test_systems_beyond_the_lds_budget_use_the_global_workspace(qc, oracle, N, m
     np.testing.assert_allclose(F, Fr, rtol=RTOL, atol=1e-11 * max(1.0, np.abs(Fr).max()))
     np.testing.assert_allclose(J, Jr, rtol=RTOL, atol=1e-11 * max(1.0, np.abs(Jr).max()))
     np.testing.assert_array_equal(h.F(Z), F)
-    if integrator == "pade" and N <= 20:
+    if integrator == "pade" and (N <= 20 or N == 40):
         mu = np.random.default_rng(N).standard_normal(prob.n_rows)
         assert_close_h(h.hess(Z, mu), oracle.mu_d2F(prob, Z, mu), "hess")
+    h.close()
+
+
+def test_six_qubits_are_not_refused(qc, oracle):
+    """64 levels (2N = 128, 8192 state entries per knot, 2.1 M Jacobian values per interval): the generic kernel with its scratch in the
+    global workspace; residuals against the oracle (whose dense Jacobian blocks would need 0.5 GB per interval), the Jacobian through its
+    action on a direction against finite differences of the residuals."""
+    prob, Z = random_problem(oracle, N=64, m=1, T=2, order=4, integrator=oracle.PADE, seed=64)
+    h = RawHandle(qc, prob)
+    F, J = h.F_jac(Z)
+    Fr = oracle.F(prob, Z)
+    np.testing.assert_allclose(F, Fr, rtol=RTOL, atol=1e-11 * max(1.0, np.abs(Fr).max()))
+    jr, jc = h.structure()
+    rng = np.random.default_rng(0)
+    v = rng.standard_normal(Z.size)
+    eps = 1e-6
+    Jv = np.zeros(F.size)
+    np.add.at(Jv, jr, J * v[jc])
+    fd = (h.F(Z + eps * v) - h.F(Z - eps * v)) / (2 * eps)
+    np.testing.assert_allclose(Jv, fd, rtol=1e-6, atol=1e-7 * max(1.0, np.abs(fd).max()))
     h.close()
 
 
