@@ -217,3 +217,50 @@ def test_deadline_turns_a_lost_copy_into_an_error(qc):
     assert r.returncode == 0, r.stderr[-800:]
     assert r.stdout.count("ERROR:") >= 2 and "timed out" in r.stdout and "QC_HOST_TIMEOUT_MS" in r.stdout, r.stdout
     assert "closed" in r.stdout
+
+
+@pytest.mark.gpu
+def test_handles_are_independent_across_threads(qc):
+    """INTEGRATION.md "Ownership, errors, threading": a handle may be used from any thread (one evaluation in flight at a time), and
+    DIFFERENT handles may be used at the same time -- Julia may run Ipopt's callbacks on another OS thread than the one that built the
+    problem, and two solves in one process share the library's worker pool.  Three threads, each with a handle of its own (created on
+    the main thread), hammer the host-buffer entry points concurrently; every result equals the single-threaded one bit for bit."""
+    import threading
+    cases = []
+    for cfg, T in ((3, 400), (2, 150), (5, 40)):
+        inp = qc.config_inputs(cfg, T=T)
+        dyn = qc.QuantumDynamics(inp.integrators, inp.traj)
+        Z = inp.traj.datavec
+        mu = np.random.default_rng(cfg).standard_normal(int(dyn.dims.n_rows))
+        F, J = dyn.F_dF(Z, fresh=True)
+        H = dyn.mu_d2F(Z, mu, fresh=True)
+        cases.append((dyn, Z, mu, F, J, H))
+    errors = []
+
+    def work(case, reps):
+        dyn, Z, mu, F, J, H = case
+        try:
+            Fo, Jo, Ho = np.empty_like(F), np.empty_like(J), np.empty_like(H)
+            for r in range(reps):
+                Fo[:] = 0.0
+                dyn.F_dF(Z, out=(Fo, Jo))
+                dyn.mu_d2F(Z, mu, out=Ho)
+                if not (np.array_equal(Fo, F) and np.array_equal(Jo, J) and np.array_equal(Ho, H)):
+                    errors.append(("values differ", int(dyn.dims.ddim), r))
+                    return
+                dyn.F(Z, out=Fo)
+                if not np.array_equal(Fo, F):
+                    errors.append(("F differs", int(dyn.dims.ddim), r))
+                    return
+        except Exception as exc:   # noqa: BLE001
+            errors.append(repr(exc))
+
+    threads = [threading.Thread(target=work, args=(c, 25)) for c in cases]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in threads), "a thread is stuck"
+    assert not errors, errors
+    for c in cases:
+        c[0].close()
