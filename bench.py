@@ -785,6 +785,12 @@ def main():
                                      "aggregate_achieved": agg, "aggregate_peak": world * HBM_PEAK_GBS,
                                      "aggregate_frac": agg / (world * HBM_PEAK_GBS),
                                      "step_us_stream_events_max_over_ranks": stream_ms_max * 1e3 / args.steps})
+        # rank 0's wall-clock region taken apart (microseconds after the opening synchronize): the K launch calls, the last step's
+        # completion as the event poll saw it, the return of the contract's closing torch.cuda.synchronize().  At small K the first
+        # launch's dispatch latency and that synchronize (a marker round trip although the work is done) are a visible share of the
+        # region (profiles/r04_sync_cost.txt); `roofline.step_us_stream_events` is the same K steps without them.
+        line["timed_region_us"] = {"launches_issued": (tb - t0) * 1e6, "last_step_seen_done": (tc - t0) * 1e6,
+                                   "synchronize_returned": (td - t0) * 1e6, "per_step_stream_events": kernel_us_stream}
         line.update(extra)
         line["value_device_resident_evals_per_s"] = value
         if rccl_ranks is not None:
