@@ -27,6 +27,30 @@ def unitary_geodesic(U_init: np.ndarray, U_goal: np.ndarray, times: Union[int, S
     return (out, H) if return_generator else out
 
 
+def unitary_linear_interpolation(U_init: np.ndarray, U_goal: np.ndarray, samples: int) -> np.ndarray:
+    """Iso-vecs on the straight line between the two iso-vecs (reference trajectory_initialization.jl:35-45: `geodesic=false`)."""
+    u0, u1 = operator_to_iso_vec(U_init), operator_to_iso_vec(U_goal)
+    lam = np.linspace(0.0, 1.0, int(samples))
+    return u0[:, None] + (u1 - u0)[:, None] * lam[None, :]
+
+
+def control_derivatives_from_guess(a: np.ndarray, dts, n_derivatives: int):
+    """[a, da, dda, ...] from a control guess (reference trajectory_initialization.jl:225-244): every derivative by differences of the
+    one before it such that the DerivativeIntegrator rows x_{t+1} - x_t - dt_t dx_t vanish at the initial point -- what the reference's
+    fix-up of the last column is there for (":to avoid constraint violation error at initial iteration")."""
+    a = np.array(a, dtype=float)
+    T = a.shape[1]
+    dts = np.full(T, float(dts)) if np.isscalar(dts) else np.asarray(dts, dtype=float).ravel()
+    out = [a]
+    for _ in range(n_derivatives):
+        x = out[-1]
+        dx = np.zeros_like(x)
+        dx[:, :T - 1] = (x[:, 1:] - x[:, :T - 1]) / dts[None, :T - 1]
+        dx[:, T - 1] = dx[:, T - 2] if T > 1 else 0.0
+        out.append(dx)
+    return out
+
+
 def initialize_control_trajectory(n_drives: int, n_derivatives: int, T: int, bounds: Sequence[float],
                                   drive_derivative_sigma: float, rng: np.random.Generator):
     """a: zeros at both ends, Uniform(-b, b) inside; derivatives N(0, sigma^2)
@@ -45,17 +69,30 @@ def initialize_trajectory(U_goal: np.ndarray, T: int, dt: float, n_drives: int,
                           state_name: str = "Ũ⃗", control_name: str = "a", timestep_name: str = "Δt",
                           dt_bounds: Optional[tuple] = None, drive_derivative_sigma: float = 0.1,
                           state_noise: float = 0.0, rng: Optional[np.random.Generator] = None,
-                          U_init: Optional[np.ndarray] = None) -> NamedTrajectory:
+                          U_init: Optional[np.ndarray] = None, a_guess: Optional[np.ndarray] = None, system=None,
+                          geodesic: bool = True, device: int = 0) -> NamedTrajectory:
     """Unitary trajectory in the reference's component order [U~, a, da, dda, dt]
-    (reference trajectory_initialization.jl:357-382,389-444)."""
+    (reference trajectory_initialization.jl:357-382,389-444).  With `a_guess` (and its `system`) the states are the ROLLOUT of the
+    guess, `unitary_rollout(U~_init, a_guess, timesteps, system)` (:422-426) -- on the GPU (qc_rollout) -- and the control
+    derivatives its differences (:225-244); `geodesic=False` interpolates the iso-vecs linearly (:176-188)."""
     rng = rng if rng is not None else np.random.default_rng()
     N = U_goal.shape[0]
     U_init = np.eye(N, dtype=complex) if U_init is None else U_init
-    states = unitary_geodesic(U_init, U_goal, T)
+    n_deriv = len(control_bounds) - 1
+    if a_guess is not None:
+        if system is None:
+            raise ValueError("System must be provided if a_guess is provided.")
+        from .rollouts import unitary_rollout
+        a_guess = np.asarray(a_guess, dtype=float)
+        if a_guess.shape != (n_drives, T):
+            raise ValueError(f"a_guess has shape {a_guess.shape}, expected ({n_drives}, {T})")
+        states = unitary_rollout(operator_to_iso_vec(U_init), a_guess, np.full(T, float(dt)), system, device=device)
+        ctrl = control_derivatives_from_guess(a_guess, dt, n_deriv)
+    else:
+        states = unitary_geodesic(U_init, U_goal, T) if geodesic else unitary_linear_interpolation(U_init, U_goal, T)
+        ctrl = initialize_control_trajectory(n_drives, n_deriv, T, control_bounds[0], drive_derivative_sigma, rng)
     if state_noise:
         states = states + rng.standard_normal(states.shape) * state_noise
-    n_deriv = len(control_bounds) - 1
-    ctrl = initialize_control_trajectory(n_drives, n_deriv, T, control_bounds[0], drive_derivative_sigma, rng)
     names = [control_name] + ["d" * i + control_name for i in range(1, n_deriv + 1)]
     comps = {state_name: states}
     for nm, c in zip(names, ctrl):

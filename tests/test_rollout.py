@@ -122,3 +122,49 @@ def test_rollout_is_bit_reproducible(qc, oracle):
         for _ in range(6):
             np.testing.assert_array_equal(dyn.rollout(inp.traj.datavec, init), first)
         dyn.close()
+
+
+def test_control_guess_derivatives_and_linear_interpolation(qc):
+    """Host side of `initialize_trajectory(...; a_guess, geodesic=false)` (reference trajectory_initialization.jl:176-188,225-244)."""
+    from qcolloc_amd.trajectory_initialization import control_derivatives_from_guess, unitary_linear_interpolation
+    rng = np.random.default_rng(2)
+    a = rng.standard_normal((3, 9))
+    dts = rng.uniform(0.1, 0.3, 9)
+    a0, da, dda = control_derivatives_from_guess(a, dts, 2)
+    np.testing.assert_array_equal(a0, a)
+    np.testing.assert_allclose(a[:, 1:] - a[:, :-1] - dts[:-1] * da[:, :-1], 0.0, atol=1e-15)         # DerivativeIntegrator(a, da) rows
+    np.testing.assert_allclose(da[:, 1:] - da[:, :-1] - dts[:-1] * dda[:, :-1], 0.0, atol=1e-14)     # DerivativeIntegrator(da, dda)
+    U = qc.GATES["CNOT"]
+    lin = unitary_linear_interpolation(np.eye(4, dtype=complex), U, 5)
+    np.testing.assert_array_equal(lin[:, 0], qc.operator_to_iso_vec(np.eye(4, dtype=complex)))
+    np.testing.assert_allclose(lin[:, -1], qc.operator_to_iso_vec(U), atol=1e-15)
+    np.testing.assert_allclose(lin[:, 2], 0.5 * (lin[:, 0] + lin[:, -1]), atol=1e-15)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nq,T,free_time", [(1, 20, True), (2, 33, False), (3, 50, True)])
+def test_trajectory_from_a_control_guess_satisfies_the_exponential_dynamics(qc, oracle, nq, T, free_time):
+    """`initialize_trajectory(U_goal, T, dt, ...; a_guess, system)` rolls the guess out (reference trajectory_initialization.jl:422-426):
+    the rollout kernel's states are a zero of the exponential integrator's residual kernel (x_{t+1} = exp(dt G(a_t)) x_t on both
+    sides, two independent implementations: scan of propagators vs per-interval expm), and the differenced controls a zero of the
+    derivative rows."""
+    from qcolloc_amd.trajectory_initialization import initialize_trajectory
+    system = qc.multi_qubit_system(nq)
+    m = system.n_drives
+    rng = np.random.default_rng(nq)
+    a_guess = 0.5 * np.sin(np.linspace(0, 3, T))[None, :] * rng.uniform(0.5, 1.0, (m, 1))
+    gate = {1: "H", 2: "CNOT", 3: "TOFFOLI"}[nq]
+    traj = initialize_trajectory(qc.GATES[gate], T, 0.2, m, ([1.0] * m, [np.inf] * m, [1.0] * m), free_time=free_time,
+                                 a_guess=a_guess, system=system)
+    integ = [qc.UnitaryExponentialIntegrator("Ũ⃗", "a", system, traj), qc.DerivativeIntegrator("a", "da", traj), qc.DerivativeIntegrator("da", "dda", traj)]
+    dyn = qc.QuantumDynamics(integ, traj, eval_hessian=False)
+    F = dyn.F(traj.datavec)
+    assert np.abs(F).max() < 5e-13, np.abs(F).max()
+    dyn.close()
+    # ... and of the order-12 Pade residual to its truncation error, of the order-4 residual only to O(dt^5)
+    integ12 = [qc.UnitaryPadeIntegrator("Ũ⃗", "a", system, traj, order=12)] + integ[1:]
+    dyn12 = qc.QuantumDynamics(integ12, traj)
+    assert np.abs(dyn12.F(traj.datavec)).max() < 1e-12
+    dyn12.close()
+    with pytest.raises(ValueError):
+        initialize_trajectory(qc.GATES[gate], T, 0.2, m, ([1.0] * m, [np.inf] * m, [1.0] * m), a_guess=a_guess)     # no system
