@@ -21,7 +21,7 @@ from .objectives import (DensityOperatorPureStateInfidelityObjective, FinalQuant
 from .problems import (CONFIGS, config_inputs, density_operator_smooth_pulse_inputs, multi_qubit_system, quantum_state_sampling_inputs, quantum_state_smooth_pulse_inputs,
                        unitary_bang_bang_inputs, unitary_direct_sum_inputs, unitary_sampling_inputs, unitary_smooth_pulse_inputs)
 from .quantum_systems import OpenQuantumSystem, QuantumSystem
-from .rollouts import open_rollout, rollout, unitary_rollout, unitary_rollout_fidelity
+from .rollouts import open_rollout, rollout, rollout_fidelity, unitary_rollout, unitary_rollout_fidelity
 from .trajectory_initialization import initialize_trajectory, unitary_geodesic
 
 __all__ = [
@@ -35,5 +35,5 @@ __all__ = [
     "FinalUnitaryFreePhaseFidelityConstraint", "UnitaryInfidelityObjective", "FinalUnitaryFidelityConstraint", "QuantumStateObjective", "FinalQuantumStateFidelityConstraint", "DensityOperatorPureStateInfidelityObjective", "iso_fidelity",
     "QuadraticRegularizer", "MinimumTimeObjective", "TrajectoryObjective", "TimeStepsAllEqualConstraint",
     "OpenQuantumSystem", "DensityOperatorExponentialIntegrator", "density_operator_smooth_pulse_inputs",
-    "density_to_iso_vec", "iso_vec_to_density", "iso_operator", "unitary_rollout", "rollout", "open_rollout", "unitary_rollout_fidelity", "make_desc", "desc_dims", "desc_structures", "state_row_offset", "QCollocError",
+    "density_to_iso_vec", "iso_vec_to_density", "iso_operator", "unitary_rollout", "rollout", "open_rollout", "unitary_rollout_fidelity", "rollout_fidelity", "make_desc", "desc_dims", "desc_structures", "state_row_offset", "QCollocError",
 ]

@@ -104,6 +104,7 @@ def quantum_state_smooth_pulse_inputs(system: QuantumSystem, psi_inits, psi_goal
     m, N = system.n_drives, system.levels
     comps = {}
     names = []
+    inits, goals = {}, {}
     for k, (p0, p1) in enumerate(zip(psi_inits, psi_goals)):
         p0 = np.asarray(p0, dtype=complex)
         p1 = np.asarray(p1, dtype=complex)
@@ -113,6 +114,7 @@ def quantum_state_smooth_pulse_inputs(system: QuantumSystem, psi_inits, psi_goal
         name = f"ψ̃{k + 1}" if len(psi_inits) > 1 else "ψ̃"
         comps[name] = iso0 * (1 - lam) + iso1 * lam + 1e-2 * rng.standard_normal((2 * N, T))
         names.append(name)
+        inits[name], goals[name] = iso0[:, 0], iso1[:, 0]
     a = np.zeros((m, T))
     a[:, 1:T - 1] = rng.uniform(-1, 1, size=(m, T - 2))
     comps["a"] = a
@@ -120,7 +122,8 @@ def quantum_state_smooth_pulse_inputs(system: QuantumSystem, psi_inits, psi_goal
     comps["dda"] = 0.1 * rng.standard_normal((m, T))
     if free_time:
         comps["Δt"] = np.full((1, T), dt)
-    traj = NamedTrajectory(comps, controls=("dda", "Δt") if free_time else ("dda",), timestep="Δt" if free_time else dt)
+    traj = NamedTrajectory(comps, controls=("dda", "Δt") if free_time else ("dda",), timestep="Δt" if free_time else dt,
+                           initial=inits, goal=goals)
     cls = QuantumStatePadeIntegrator if integrator == "pade" else QuantumStateExponentialIntegrator
     kw = {"order": pade_order} if integrator == "pade" else {}
     integrators = [cls(nm, "a", system, traj, **kw) for nm in names]

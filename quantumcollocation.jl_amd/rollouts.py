@@ -83,3 +83,16 @@ def unitary_rollout_fidelity(traj: NamedTrajectory, system, state_name: str = "Å
     dts = traj[traj.timestep].ravel() if isinstance(traj.timestep, str) else float(traj.timestep)
     U = unitary_rollout(np.asarray(init, dtype=np.float64), traj[control_name], dts, system, device)
     return iso_vec_unitary_fidelity(U[:, -1], np.asarray(traj.goal[state_name], dtype=np.float64), subspace, device)
+
+
+def rollout_fidelity(traj: NamedTrajectory, system, state_name: str = "ÏˆÌƒ", control_name: str = "a", device: int = 0) -> float:
+    """`rollout_fidelity(traj, system; state_name)` for a ket component (reference quantum_state_smooth_pulse_problem.jl:247-249,
+    quantum_state_sampling_problem.jl:187-189): the ket rolled out from its first knot under the trajectory's controls, |<goal|psi_T>|^2
+    with `traj.goal[state_name]`."""
+    from .objectives import iso_fidelity
+    init = traj.initial.get(state_name) if getattr(traj, "initial", None) else None
+    if init is None:
+        init = traj[state_name][:, 0]
+    dts = traj[traj.timestep].ravel() if isinstance(traj.timestep, str) else float(traj.timestep)
+    psi = rollout(np.ascontiguousarray(init, dtype=np.float64), traj[control_name], dts, system, device)
+    return iso_fidelity(psi[:, -1], np.asarray(traj.goal[state_name], dtype=np.float64), device)

@@ -168,3 +168,22 @@ def test_trajectory_from_a_control_guess_satisfies_the_exponential_dynamics(qc, 
     dyn12.close()
     with pytest.raises(ValueError):
         initialize_trajectory(qc.GATES[gate], T, 0.2, m, ([1.0] * m, [np.inf] * m, [1.0] * m), a_guess=a_guess)     # no system
+
+
+@pytest.mark.gpu
+def test_ket_rollout_fidelity(qc, oracle):
+    """`rollout_fidelity(prob.trajectory, sys; state_name)` (reference quantum_state_smooth_pulse_problem.jl:247-249,
+    quantum_state_sampling_problem.jl:187-189) against a scipy rollout of the same controls."""
+    system = qc.multi_qubit_system(2)
+    basis = np.eye(4, dtype=complex)
+    inp = qc.quantum_state_smooth_pulse_inputs(system, [basis[:, 0], basis[:, 1]], [basis[:, 3], (basis[:, 0] + 1j * basis[:, 2]) / np.sqrt(2)], 31)
+    a, dts = inp.traj["a"], inp.traj["Δt"].ravel()
+    for k, name in enumerate(("ψ̃1", "ψ̃2")):
+        v = basis[:, k].copy()
+        for t in range(inp.traj.T - 1):
+            H = system.H_drift + sum(x * Hk for x, Hk in zip(a[:, t], system.H_drives))
+            v = sla.expm(-1j * dts[t] * H) @ v
+        goal = inp.traj.goal[name]
+        want = abs(np.vdot(goal[:4] + 1j * goal[4:], v)) ** 2
+        got = qc.rollout_fidelity(inp.traj, system, state_name=name)
+        assert abs(got - want) < 1e-12, (name, got, want)
