@@ -87,12 +87,14 @@ def initialize_trajectory(U_goal: np.ndarray, T: int, dt: float, n_drives: int,
         if a_guess.shape != (n_drives, T):
             raise ValueError(f"a_guess has shape {a_guess.shape}, expected ({n_drives}, {T})")
         states = unitary_rollout(operator_to_iso_vec(U_init), a_guess, np.full(T, float(dt)), system, device=device)
+        if state_noise:
+            states = states + rng.standard_normal(states.shape) * state_noise
         ctrl = control_derivatives_from_guess(a_guess, dt, n_deriv)
     else:
         states = unitary_geodesic(U_init, U_goal, T) if geodesic else unitary_linear_interpolation(U_init, U_goal, T)
+        if state_noise:     # (drawn BEFORE the controls: the seeded synthetic inputs of bench.py and of the tests depend on the order)
+            states = states + rng.standard_normal(states.shape) * state_noise
         ctrl = initialize_control_trajectory(n_drives, n_deriv, T, control_bounds[0], drive_derivative_sigma, rng)
-    if state_noise:
-        states = states + rng.standard_normal(states.shape) * state_noise
     names = [control_name] + ["d" * i + control_name for i in range(1, n_deriv + 1)]
     comps = {state_name: states}
     for nm, c in zip(names, ctrl):
