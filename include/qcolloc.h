@@ -28,8 +28,13 @@
  *   dynamics.mu_d2F(Z.datavec, mu)      (:52)            qc_eval_hess     / qc_eval_hess_dev
  *   dynamics.mu_d2F_structure           (:52)            qc_hess_structure
  *   shapes (Z.dims.states*(Z.T-1), Z.dim*Z.T+Z.global_dim)  (:44,48)   qc_dims
- *   K unitary integrators of a UnitarySamplingProblem    qc_eval_F_jac_dev_multi / qc_eval_hess_dev_multi
- *       (unitary_sampling_problem.jl:134-155)                (one handle per integrator, qc_desc.rows_per_interval ...)
+ *   K unitary integrators of a UnitarySamplingProblem    qc_eval_F_list / _jac_list / _F_jac_list / _hess_list (host buffers),
+ *       (unitary_sampling_problem.jl:134-155), the           qc_eval_F_jac_dev_multi / qc_eval_hess_dev_multi (device buffers)
+ *       members of a UnitaryDirectSumProblem                  (one handle per state integrator, qc_desc.rows_per_interval ...)
+ *       (unitary_direct_sum_problem.jl:127-130), the kets
+ *       x systems of a QuantumStateSamplingProblem
+ *   UnitaryBangBangProblem's [U, D(a, da)], order 12      one handle: n_deriv = 1, pade_order = 12; the slack components only
+ *       (unitary_bang_bang_problem.jl:163-175,205-215)        widen zdim
  *   DensityOperatorExponentialIntegrator                 qc_desc{N = levels^2, state_cols = 1, QC_EXPONENTIAL}
  *       (density_operator_smooth_pulse_problem.jl:104-106)   with the Lindblad generators as G_drift / G_drives
  *   iso_vec_unitary_fidelity, UnitaryInfidelityObjective,  qc_fidelity_create / qc_fidelity_eval(_dev)
