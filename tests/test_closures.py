@@ -1,10 +1,15 @@
 """The vector-returning closures `dynamics.F(Z)`, `dynamics.dF(Z)`, `dynamics.mu_d2F(Z, mu)` -- the only call shapes the
 reference's evaluator uses (reference test/scripts/integrator_test_1qubit.jl:45-52) -- and the upload elision (`set_new_x`) when the
 handle behind them is shared: result-ring lifetime, `fresh=True`, and the handle's upload count (`qc_knot_generation`) as the guard."""
+import os
+import sys
+
 import numpy as np
 import pytest
 
 from oracle_bridge import problem_from_inputs
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_retired_regulariser_ids_are_refused(qc):
@@ -264,3 +269,68 @@ def test_handles_are_independent_across_threads(qc):
     assert not errors, errors
     for c in cases:
         c[0].close()
+
+
+KNOBS = ["QC_HOST_COMPACT", "QC_FUSED_VARIANT", "QC_STORE_MODE", "QC_NO_FUSED", "QC_NO_ELL", "QC_NO_ANTISYM", "QC_HOST_WAIT", "QC_HOST_THREADS",
+         "QC_HOST_TAPER", "QC_HOST_TAIL_SPLIT", "QC_HOST_STREAMS", "QC_HOST_REARM_JOBS", "QC_HOST_REARM", "QC_HOST_PIECE_KB", "QC_HOST_PIECES",
+         "QC_HOST_NT", "QC_HOST_NOWATCH", "QC_HOST_NBUF", "QC_HOST_MULTI_FULL", "QC_HOST_LANDING", "QC_HOST_HESS_CHUNKS", "QC_HOST_F_DIRECT",
+         "QC_HOST_F_CHUNKS", "QC_HOST_FILL_NT", "QC_HOST_CHUNKS", "QC_HOST_AFFINITY", "QC_HESS_TWO_WAVES", "QC_HESS_GRID", "QC_ELL_JAC",
+         "QC_DEBUG_SKIP", "QC_HOST_TIMEOUT_MS", "QC_HOST_TRACE"]
+_KNOB_SCRIPT = r"""
+import sys, json
+sys.path[:0] = [%(root)r, %(tests)r]
+import numpy as np
+import __graft_entry__ as g
+qc = g.load_package()
+out = {}
+for cfg, T in ((3, 70), (5, 6), (1, 9)):
+    inp = qc.config_inputs(cfg, T=T)
+    dyn = qc.QuantumDynamics(inp.integrators, inp.traj)
+    Z = inp.traj.datavec
+    mu = np.cos(np.arange(int(dyn.dims.n_rows)))
+    for rep in range(3):                     # (the ring of pinned blocks turns)
+        F, J = dyn.F_dF(Z, fresh=True)
+        H = dyn.mu_d2F(Z, mu, fresh=True)
+        F1 = dyn.F(Z, fresh=True)
+    dyn.set_new_x(False)
+    J2 = dyn.dF(Z, fresh=True)
+    dyn.set_new_x(True)
+    many = qc.QuantumDynamics(inp.integrators, inp.traj, devices=[0, 0, 0])
+    Fm, Jm = many.F_dF(Z, fresh=True)
+    w = lambda a, k: float(np.sum(a * (1 + np.arange(a.size) %% k)))
+    out[str(cfg)] = [w(F, 7), w(J, 11), w(H, 13), w(F1, 7), w(J2, 11), w(Fm, 7), w(Jm, 11)]
+    many.close(); dyn.close()
+base = qc.multi_qubit_system(1)
+lst = qc.unitary_sampling_inputs([base, qc.QuantumSystem(base.H_drift * 1.3, base.H_drives)], qc.GATES["H"], 40)
+dyn = qc.QuantumDynamics(lst.integrators, lst.traj)
+F, J = dyn.F_dF(lst.traj.datavec, fresh=True)
+out["list"] = [float(np.sum(F * (1 + np.arange(F.size) %% 7))), float(np.sum(J * (1 + np.arange(J.size) %% 11)))]
+dyn.close()
+print("RESULT " + json.dumps(out))
+"""
+
+
+@pytest.mark.gpu
+def test_environment_knobs_with_nonsense_values_never_break_a_result(qc):
+    """the product reads ~30 QC_* environment knobs and validated none.  Every knob set to the same nonsense value at once
+    (0, a negative number, text, a huge number): the evaluations either run to the default run's values (rtol 1e-10 -- a knob may pick
+    another kernel or transfer path, never another answer) or fail with a library error; no crash, no hang."""
+    import json
+    import subprocess
+    script = _KNOB_SCRIPT % {"root": ROOT, "tests": os.path.join(ROOT, "tests")}
+
+    def run(value):
+        env = {k: v for k, v in os.environ.items() if not k.startswith("QC_")}
+        if value is not None:
+            env.update({k: value for k in KNOBS})
+        r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, (value, r.stderr[-1500:])
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")]
+        assert line, (value, r.stdout[-500:], r.stderr[-500:])
+        return json.loads(line[-1][7:])
+
+    ref = run(None)
+    for value in ("0", "-7", "abc", "1000000000", "1", "2"):
+        got = run(value)
+        for key in ref:
+            np.testing.assert_allclose(got[key], ref[key], rtol=1e-10, err_msg=f"knobs = {value!r}, {key}")
