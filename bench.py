@@ -31,6 +31,11 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as g  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+# The device-resident legs use the line-aligned layout of the Hessian values (qc_desc.hess_align = QC_HESS_ALIGN_LINE: every interval's
+# block padded to whole 128-byte lines with explicit zeros), the documented opt-in of "_dev" consumers; the host-visible legs use the
+# library's default, exactly the reference's structural entries (1 832 per interval at config 3).  The metric (F + dF) has no
+# Hessian in it and is the same under both.
+DEVICE_HESS_ALIGN = 16
 T_PER_GPU = 1000
 RING_BYTES = 640 << 20
 
@@ -304,7 +309,7 @@ def integrator_list_record(qc, cpu_rec, K=3, reps=15):
     base = qc.multi_qubit_system(3)
     systems = [qc.QuantumSystem(base.H_drift * (1.0 + 0.1 * rng.standard_normal()), base.H_drives) for _ in range(K)]
     inp = qc.unitary_sampling_inputs(systems, qc.GATES["TOFFOLI"], T_PER_GPU)
-    dyn = qc.QuantumDynamics(inp.integrators, inp.traj)
+    dyn = qc.QuantumDynamics(inp.integrators, inp.traj, result_ring=3)
     Zs = [inp.traj.datavec + 1e-3 * k * rng.standard_normal(inp.traj.datavec.size) for k in range(3)]
     mu = np.ones(int(dyn.dims.n_rows))
     out = {"workload": f"UnitarySamplingProblem, {K} x 3-qubit systems, shared controls, T = {T_PER_GPU}", "K": K,
@@ -342,7 +347,7 @@ def config5_record(qc, dev_index, steps=300):
     launch, 2048 FLOP per v_mfma_f64_16x16x4_f64) and the counter-based MfmaUtil come from the newest
     profiles/r*_mfma_util.json and are labelled as external; they are omitted when that file does not hold these kernels."""
     inp = qc.config_inputs(5)
-    dyn = qc.QuantumDynamics(inp.integrators, inp.traj, device=dev_index)
+    dyn = qc.QuantumDynamics(inp.integrators, inp.traj, device=dev_index, hess_align=DEVICE_HESS_ALIGN)
     dev = torch.device("cuda", dev_index)
     dims = dyn.dims
     n_int = int(dims.n_intervals)
@@ -406,6 +411,90 @@ def config5_record(qc, dev_index, steps=300):
     return rec
 
 
+KERNEL_SOURCES = ("quantumcollocation.jl_amd/csrc/qc_mfma_kernels.hip", "quantumcollocation.jl_amd/csrc/qc_mfma_common.h",
+                  "quantumcollocation.jl_amd/csrc/qc_internal.h")
+
+
+def kernel_source_hash() -> str:
+    """sha256 over the sources of the metric's kernel (qc_mfma16_pade4_kernel): what profiles/pmc_traffic.json is stamped with."""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def recorded_traffic(kernel, config, T):
+    """HBM bytes per launch of the metric's kernel from profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes,
+    external to this run).  Dropped -- null, with the reason -- when the record is for another workload or when the kernel's
+    sources have changed since the counters were collected (the record carries their sha256 and the commit)."""
+    tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(tj):
+        return None, None
+    try:
+        rec = json.load(open(tj))
+    except Exception:   # noqa: BLE001
+        return None, "profiles/pmc_traffic.json unreadable"
+    if not (rec.get("kernel") == kernel and rec.get("config") == config and rec.get("T") == T):
+        return None, None
+    if rec.get("kernel_source_sha256") != kernel_source_hash():
+        return None, ("profiles/pmc_traffic.json dropped: the kernel sources have changed since its counters were collected "
+                      f"(commit {rec.get('commit', '?')})")
+    return rec.get("hbm_bytes_per_launch"), (f"profiles/pmc_traffic.json (rocprofv3 --pmc passes at commit {rec.get('commit', '?')}, kernel sources unchanged "
+                                              "since; not measured by this run)")
+
+
+def long_trajectory_record(qc, dev_index, T=8000, steps=200):
+    """BASELINE config 4's trajectory (3-qubit Toffoli, T = 8000) on ONE GPU: the long-trajectory regime of the metric's kernel
+    (persistent grid) while no 8-GPU node is available -- F + dF, mu_d2F and the one-call form, stream events over rings of
+    output vectors beyond 2 x the Infinity Cache."""
+    inp = qc.config_inputs(4, T=T)
+    dyn = qc.QuantumDynamics(inp.integrators, inp.traj, device=dev_index, hess_align=DEVICE_HESS_ALIGN)
+    dev = torch.device("cuda", dev_index)
+    dims = dyn.dims
+    n_int = int(dims.n_intervals)
+    rng = np.random.default_rng(4)
+    Zs = [torch.from_numpy(inp.traj.datavec + (1e-3 * rng.standard_normal(inp.traj.datavec.size) if k else 0.0)).to(dev) for k in range(2)]
+    mu = torch.from_numpy(rng.standard_normal(int(dims.n_rows))).to(dev)
+    nb = max(2, -(-RING_BYTES // (8 * int(dims.jac_nnz))))      # 2 x 322 MB of Jacobian values
+    nh = max(2, -(-RING_BYTES // (8 * int(dims.hess_nnz))))
+    Fb = [torch.empty(int(dims.F_len), dtype=torch.float64, device=dev) for _ in range(nb)]
+    Jb = [torch.empty(int(dims.jac_nnz), dtype=torch.float64, device=dev) for _ in range(nb)]
+    Hb = [torch.empty(int(dims.hess_nnz), dtype=torch.float64, device=dev) for _ in range(nh)]
+    st = torch.cuda.current_stream(dev)
+    status = [0]
+
+    def timed(calls):
+        for i in range(10):
+            status[0] |= calls[i % len(calls)]()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        for i in range(steps):
+            status[0] |= calls[i % len(calls)]()
+        e1.record(st)
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / steps
+
+    jac_us = timed([dyn.bind_F_dF_device(Zs[i & 1], Fb[i % nb], Jb[i % nb], st) for i in range(2 * nb)])
+    hess_us = timed([dyn.bind_mu_d2F_device(Zs[i & 1], mu, Hb[i % nh], st) for i in range(2 * nh)])
+    both_us = timed([dyn.bind_F_dF_mu_d2F_device(Zs[i & 1], mu, Fb[i % nb], Jb[i % nb], Hb[i % nh], st) for i in range(int(np.lcm(nb, nh)) * 2)])
+    assert status[0] == 0, "a device-resident launch of the T = 8000 record reported an error"
+    zdim, ddim = inp.traj.dim, int(dims.ddim)
+    jac_bytes = 8 * (zdim * (n_int + 1) + (ddim + int(dims.jac_nnz_interval)) * n_int)
+    hess_bytes = 8 * (zdim * (n_int + 1) + (ddim + int(dims.hess_nnz_interval)) * n_int)
+    both_bytes = jac_bytes + 8 * (ddim + int(dims.hess_nnz_interval)) * n_int
+    frac = lambda b, us: b / (us * 1e-6) / 1e9 / HBM_PEAK_GBS   # noqa: E731
+    rec = {"workload": f"{qc.CONFIGS[4].description}; T={T} knots on ONE GPU", "kernels": list(dyn.kernel_names),
+           "F_dF_us": jac_us, "hbm_frac": frac(jac_bytes, jac_us), "algorithmic_bytes_per_launch": jac_bytes,
+           "evals_per_s_T1000_equivalent": n_int / (T_PER_GPU - 1) / (jac_us * 1e-6),
+           "hess_us": hess_us, "hess_hbm_frac": frac(hess_bytes, hess_us),
+           "F_dF_hess_one_call_us": both_us, "F_dF_hess_one_call_hbm_frac": frac(both_bytes, both_us), "F_dF_hess_kernel": dyn.fused_kernel_name}
+    dyn.close()
+    return rec
+
+
 def launch_ranks(n: int) -> int:
     """`python bench.py --gpus N` without a launcher (the shape of the driver's N = 1 command): start
     `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <same arguments>`
@@ -448,6 +537,8 @@ def main():
                     "(independent evaluations overlapping their launch/drain phases; reported as an extra field, never `value`)")
     ap.add_argument("--host-visible", action=argparse.BooleanOptionalAction, default=True,
                     help="also time the host-buffer entry points (PCIe-inclusive; the `host_visible` object, never `value`)")
+    ap.add_argument("--config4", action=argparse.BooleanOptionalAction, default=True,
+                    help="at N = 1 also run BASELINE config 4's T = 8000 trajectory on the one device (`config4_one_gpu` object)")
     ap.add_argument("--config5", action=argparse.BooleanOptionalAction, default=True,
                     help="at N = 1 also run BASELINE config 5 on the device and report its HBM / MFMA fractions (`config5` object)")
     args = ap.parse_args()
@@ -492,7 +583,7 @@ def main():
     t_per_gpu = args.T or (T_PER_GPU if args.config in (3, 4) else spec.T)
     T_total = t_per_gpu * world
     inp = qc.config_inputs(args.config, T=T_total)
-    sd = ShardedDynamics(inp.integrators, inp.traj, rank, world, device=dev_index, kernel=args.kernel)
+    sd = ShardedDynamics(inp.integrators, inp.traj, rank, world, device=dev_index, kernel=args.kernel, hess_align=DEVICE_HESS_ALIGN)
     dyn = sd.local
     dims = dyn.dims
     n_int = int(dims.n_intervals)
@@ -706,8 +797,12 @@ def main():
     if args.host_visible:
         try:
             if world == 1:
-                host_rec = host_visible_record(qc, inp, dyn, Zhs, cpu_rec, t1000_equiv)
+                # a handle of its own in the bindings' default layout: mu_d2F_structure is the reference's, entry for entry
+                hdyn = qc.QuantumDynamics(inp.integrators, inp.traj, device=dev_index, kernel=args.kernel, result_ring=3)
+                host_rec = host_visible_record(qc, inp, hdyn, Zhs, cpu_rec, t1000_equiv)
                 host_rec["devices"] = [dev_index]
+                host_rec["hess_nnz_interval"] = int(hdyn.dims.hess_nnz_interval)
+                hdyn.close()
                 if args.config in (3, 4):
                     try:
                         host_rec["integrator_list"] = integrator_list_record(qc, cpu_rec)
@@ -722,7 +817,7 @@ def main():
                 if rank == 0:
                     try:   # (whatever happens here, rank 0 reaches the barrier the other ranks are waiting at)
                         devs = list(range(world)) if backend == "nccl" else [r % torch.cuda.device_count() for r in range(world)]
-                        md = qc.QuantumDynamics(inp.integrators, inp.traj, devices=devs, kernel=args.kernel)
+                        md = qc.QuantumDynamics(inp.integrators, inp.traj, devices=devs, kernel=args.kernel, result_ring=3)
                         host_rec = host_visible_record(qc, inp, md, Zhs, cpu_rec, t1000_equiv)
                         host_rec["devices"] = devs
                         md.close()
@@ -738,17 +833,16 @@ def main():
         except Exception as exc:   # noqa: BLE001
             c5 = {"error": repr(exc)[:300]}
 
+    c4 = None
+    if args.config4 and world == 1 and rank == 0 and args.config in (3, 4) and t_per_gpu == T_PER_GPU:
+        try:
+            c4 = long_trajectory_record(qc, dev_index)
+        except Exception as exc:   # noqa: BLE001
+            c4 = {"error": repr(exc)[:300]}
+
     value = args.steps * t1000_equiv / elapsed
     if rank == 0:
-        traffic = None
-        tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tj):
-            try:
-                rec = json.load(open(tj))
-                if rec.get("kernel") == dyn.kernel and rec.get("config") == args.config and rec.get("T") == t_per_gpu:
-                    traffic = rec.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        traffic, traffic_note = recorded_traffic(dyn.kernel, args.config, t_per_gpu)
         # kernel duration: HIP events around the timed region on the launch stream / steps (includes the
         # ~1.5 us inter-kernel boundary, so it is an upper bound of rocprofv3's per-kernel average)
         achieved = bytes_per_launch / (kernel_us_stream * 1e-6) / 1e9
@@ -772,8 +866,12 @@ def main():
                        "kernel": dyn.kernel, "parallelism": f"knot-shard x{world}", "output_ring_buffers": nbuf},
             "knot_evals_per_s": args.steps * total_intervals / elapsed,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc passes recorded there, not measured by this run)" if traffic else None,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         # `frac` follows from the stream-event step time (the K kernels back to back on the launch stream);
+                         # `frac_wall` from this line's own ms_per_step (the contract's wall clock: launch latency of the first
+                         # step and the closing synchronize included), so that the line can be checked against itself
+                         "frac_wall": bytes_per_launch / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
+                         "traffic": traffic, "traffic_source": traffic_note,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "kernel_us_event_pairs": kernel_us_pairs, "step_us_stream_events": kernel_us_stream},
         }
@@ -799,6 +897,8 @@ def main():
             line["timing_barrier"] = node_barrier.kind
         if host_rec is not None:
             line["host_visible"] = host_rec
+        if c4 is not None:
+            line["config4_one_gpu"] = c4
         if c5 is not None:
             line["config5"] = c5
         if cpu_rec is not None:

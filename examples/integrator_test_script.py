@@ -52,7 +52,10 @@ def harness(name, H_drift, H_drives, U_goal, T, dt):
     D = qc.DerivativeIntegrator("a", "da", Z)
     # the script's `g` component is a state WITHOUT an integrator: rows = "by_component" puts every integrator's rows at its state
     # component's position and leaves g's rows structurally empty, so the shapes are exactly the script's
-    dynamics = qc.QuantumDynamics([P, D], Z, rows="by_component")
+    # (the constructor call itself is the script's line 41, `dynamics = QuantumDynamics(f, Z)`: the list and the trajectory, nothing else --
+    #  `QCollocHIP.QuantumDynamics(f, Z)` on the Julia side)
+    f = [P, D]
+    dynamics = qc.QuantumDynamics(f, Z, rows="by_component")
     shape = (Z.dims.states * (Z.T - 1), Z.dim * Z.T + Z.global_dim)
     assert (int(dynamics.dims.n_rows), int(dynamics.dims.n_cols)) == shape
     z = Z.datavec

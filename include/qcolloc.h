@@ -74,7 +74,7 @@ extern "C" {
 #endif
 
 #define QC_VERSION_MAJOR 0
-#define QC_VERSION_MINOR 4
+#define QC_VERSION_MINOR 5
 
 enum {
     QC_OK = 0,
@@ -94,6 +94,7 @@ enum { QC_PADE = 0, QC_EXPONENTIAL = 1 };
 enum { QC_KERNEL_AUTO = 0, QC_KERNEL_LDS = 1, QC_KERNEL_MFMA = 2 };
 
 #define QC_MAX_DERIV 8
+#define QC_HESS_ALIGN_LINE 16   /* qc_desc.hess_align of the line-aligned (padded) Hessian value layout */
 enum { QC_ROWS_STACKED = 0, QC_ROWS_BY_COMPONENT = 1 };
 
 typedef struct qc_handle qc_handle;
@@ -127,11 +128,17 @@ typedef struct qc_desc {
                              * K >= 1 = K kets psi~ = [Re psi; Im psi] stored back to back (2N x K, length 2NK), i.e.
                              * K QuantumStatePadeIntegrators over the same system
                              * (quantum_state_smooth_pulse_problem.jl:146-152).  off_U is the first ket's offset. */
-    int32_t hess_align;     /* The Hessian value block of an interval is padded with explicit zeros to a multiple of this many
-                             * doubles, so that every interval's block starts on a cache-line boundary (partial lines written by two
-                             * workgroups cost 1.1 - 1.4x the HBM write traffic).  0 = default (16 doubles = 128 B),
-                             * 1 = no padding.  The padding entries appear in the structure as duplicates of the interval's first
-                             * structure entry with value 0 (COO duplicates are summed: reference test/test_utils.jl:14-20).
+    int32_t hess_align;     /* 0 (default) or 1: the Hessian value block of an interval holds EXACTLY the structural entries -- the
+                             * reference's mu_d2F_structure, entry for entry (config 3: 1 832 per interval; observable as
+                             * length(dynamics.mu_d2F_structure), test/scripts/integrator_test_1qubit.jl:48-52).  This is what every
+                             * host-buffer entry point and both bindings use unless told otherwise (ABI 0.5; through ABI 0.4 the value
+                             * 0 meant 16).
+                             * k > 1 (QC_HESS_ALIGN_LINE = 16 doubles = 128 B for device-resident consumers): the block is padded with
+                             * explicit zeros to a multiple of k doubles, so that every interval's block starts on a cache-line
+                             * boundary (partial lines written by two workgroups cost 1.1 - 1.4x the HBM write traffic).
+                             * The padding entries appear in the structure as duplicates of the interval's first structure entry with
+                             * value 0 (COO duplicates are summed: reference test/test_utils.jl:14-20).  An opt-in of "_dev" consumers
+                             * that own their sparse assembly; a host-buffer call is bound by PCIe and gains nothing from it.
                              * Ignored for composed handles (hess_per_interval > 0): see hess_tail_zeros. */
     /* Composition (all 0 = this handle is the whole dynamics).  A problem whose integrator list holds several
      * unitary integrators (UnitarySamplingProblem: one per system over a merged trajectory,

@@ -3,18 +3,18 @@
 # UNTESTED IN THIS REPOSITORY'S CI: the build image has no Julia.  It is the binding a maintainer of
 # QuantumCollocation.jl would add; it builds an object with the fields the MOI evaluator of
 # QuantumCollocationCore consumes — `F`, `∂F`, `∂F_structure`, `μ∂²F`, `μ∂²F_structure`, `dim` —
-# exactly as they are used in test/scripts/integrator_test_1qubit.jl:41-52, so that
+# exactly as they are used in test/scripts/integrator_test_1qubit.jl:41-52, so that replacing the constructor call of that script,
 #
-#     prob.dynamics = QCollocHIP.dynamics(prob.integrators, prob.trajectory, prob.system)
+#     dynamics = QuantumDynamics(f, Z)        ->        dynamics = QCollocHIP.QuantumDynamics(f, Z)
 #
-# swaps the CPU per-knot loop for the MI355X kernels while Ipopt keeps driving the solve unchanged.
+# (line 41; the same positional arguments) swaps the CPU per-knot loop for the MI355X kernels while Ipopt keeps driving the solve unchanged.
 module QCollocHIP
 
 using Libdl
 
 const LIB = Ref{String}(get(ENV, "QCOLLOC_HIP_LIB", "libqcolloc_hip.so"))
 const QC_MAX_DERIV = 8
-const QC_ABI_VERSION = 4      # QC_VERSION_MAJOR * 1000 + QC_VERSION_MINOR of the include/qcolloc.h these mirrors were written against
+const QC_ABI_VERSION = 5      # QC_VERSION_MAJOR * 1000 + QC_VERSION_MINOR of the include/qcolloc.h these mirrors were written against
 
 # mirror of `qc_desc` (include/qcolloc.h); field order and types must match the header -- `__init__` checks the sizes against
 # the library's own `sizeof` (qc_sizeof_desc / qc_sizeof_dims / qc_sizeof_terms_desc) when the module is loaded
@@ -26,7 +26,7 @@ struct QCDesc
     G_drift::Ptr{Float64}; G_drives::Ptr{Float64}
     device::Int32; kernel::Int32; t_begin::Int64; t_end::Int64
     state_cols::Int32                       # 0 = unitary iso-vec; K = K ket integrators stored back to back
-    hess_align::Int32                       # 0 = default (interval blocks of the Hessian values padded to 16 doubles), 1 = none
+    hess_align::Int32                       # 0 / 1 = exactly the structural entries (default); 16 = interval blocks padded to whole 128-byte lines
     rows_per_interval::Int64; row_offset::Int64; jac_per_interval::Int64; jac_offset::Int64   # composition (all 0 =
     hess_per_interval::Int64; hess_offset::Int64                                               # this handle is the whole dynamics)
     row_placement::Int32                    # 0 = rows stacked in integrator order, 1 = rows at the state components' positions
@@ -71,24 +71,29 @@ end
 
 pad8(v) = ntuple(i -> i <= length(v) ? Int32(v[i]) : Int32(0), QC_MAX_DERIV)
 
-# Result vectors of one closure, handed out in turn: allocated (pinned) and written once when the ring is built, so that no call pays for
-# page faults or per-call pinning.
+# Pinned host memory of the library (`qc_host_alloc`) for the optional result rings.  The blocks belong to ONE owner object that the
+# `HIPDynamics` references and that frees them in its own finalizer, after `qc_destroy` (ADVICE round 4): `reshape` / `vec` of a
+# result on Julia >= 1.11 share the memory without keeping the wrapping Array alive, so a per-array finalizer could free a block under
+# a live alias.  RING RESULTS MUST NOT OUTLIVE THE DYNAMICS OBJECT; `fresh = true` (and the default `result_ring = 0`) return ordinary
+# Julia vectors with no such condition.
+mutable struct PinnedOwner
+    blocks::Vector{Ptr{Cvoid}}
+end
+free_pinned!(o::PinnedOwner) = (foreach(p -> ccall((:qc_host_free, LIB[]), Cint, (Ptr{Cvoid},), p), o.blocks); empty!(o.blocks); nothing)
+function pinned_zeros!(o::PinnedOwner, len::Integer)
+    len * 8 >= 65536 || return zeros(Float64, len)
+    p = Ref{Ptr{Cvoid}}(C_NULL)
+    ccall((:qc_host_alloc, LIB[]), Cint, (Int64, Ptr{Ptr{Cvoid}}), len * 8, p) == 0 || return zeros(Float64, len)
+    push!(o.blocks, p[])
+    return fill!(unsafe_wrap(Array, Ptr{Float64}(p[]), len; own=false), 0.0)
+end
+# Result vectors of one closure, handed out in turn (opt-in): allocated (pinned) and written once when the ring is built, so that no call
+# pays for page faults or per-call pinning.
 struct ResultRing
     bufs::Vector{Vector{Float64}}
     next::Base.RefValue{Int}
 end
-# A Float64 vector in pinned host memory of the library (`qc_host_alloc`): the copy engine moves data from / into it without pinning
-# pages per call, and `F` has the kernel write the residuals into it in place.  Freed (`qc_host_free`, process-wide) when the vector is
-# garbage-collected -- a result the caller still holds outlives the evaluator.  Ordinary zeros for small vectors or without a GPU.
-function pinned_zeros(len::Integer)
-    len * 8 >= 65536 || return zeros(Float64, len)
-    p = Ref{Ptr{Cvoid}}(C_NULL)
-    ccall((:qc_host_alloc, LIB[]), Cint, (Int64, Ptr{Ptr{Cvoid}}), len * 8, p) == 0 || return zeros(Float64, len)
-    v = unsafe_wrap(Array, Ptr{Float64}(p[]), len; own=false)
-    finalizer(_ -> ccall((:qc_host_free, LIB[]), Cint, (Ptr{Cvoid},), p[]), v)
-    return fill!(v, 0.0)
-end
-ResultRing(len::Integer, n::Integer) = ResultRing(Vector{Float64}[pinned_zeros(len) for _ in 1:(len > 0 ? n : 0)], Ref(1))
+ResultRing(o::PinnedOwner, len::Integer, n::Integer) = ResultRing(Vector{Float64}[pinned_zeros!(o, len) for _ in 1:(len > 0 ? n : 0)], Ref(1))
 function next!(r::ResultRing, len::Integer, fresh::Bool)
     (fresh || isempty(r.bufs)) && return Vector{Float64}(undef, len)
     v = r.bufs[r.next[]]
@@ -100,10 +105,11 @@ end
 Field-compatible stand-in for `QuantumDynamics` (QuantumCollocationCore.Dynamics).
 
 `F(Z⃗)`, `∂F(Z⃗)`, `μ∂²F(Z⃗, μ⃗)` -- the only shapes QuantumCollocationCore's evaluator uses (test/scripts/integrator_test_1qubit.jl:45-52)
--- return the next vector of a ring of `result_ring` (default 3) result vectors per closure, pinned and written once when the ring is built:
-a result stays intact until the `result_ring`-th next call OF THE SAME CLOSURE (the evaluator copies it into Ipopt's buffer at once).
+-- return a newly allocated vector that is the caller's for good, as the reference's closures do (`result_ring = 0`, the default).
 A fresh `Vector{Float64}(undef, 5_034_960)` per `∂F` call costs 2.7 - 4 ms of first-touch page faults at BASELINE config 3, ten times
-the evaluation.  `∂F(Z⃗; fresh=true)` (or `result_ring = 0`) returns a newly allocated vector that is the caller's for good.
+the evaluation: an evaluator that copies each result into Ipopt's buffer at once (Core's does) opts in to `result_ring = 3` -- the next
+vector of a ring of three per closure, pinned and written once when the ring is built; such a result stays intact until the third-next
+call OF THE SAME CLOSURE and must not outlive the dynamics object; `∂F(Z⃗; fresh=true)` still allocates.
 `F!`, `∂F!`, `μ∂²F!` write into a caller-owned vector (what an evaluator that owns the MOI callbacks does with Ipopt's buffers).
 """
 mutable struct HIPDynamics
@@ -118,6 +124,15 @@ mutable struct HIPDynamics
     F!::Function
     ∂F!::Function
     μ∂²F!::Union{Function,Nothing}
+    handles::Vector{Ptr{Cvoid}}      # every qc_handle this object owns (one; one per state integrator for `dynamics_list`)
+    pinned::PinnedOwner              # the result rings' memory
+end
+# handles first, then the pinned blocks (nothing of the library refers to them once the handles are gone)
+function release!(dyn::HIPDynamics)
+    foreach(h -> ccall((:qc_destroy, LIB[]), Cvoid, (Ptr{Cvoid},), h), dyn.handles)
+    empty!(dyn.handles)
+    dyn.handle = C_NULL
+    free_pinned!(dyn.pinned)
 end
 
 # first row of state component `name` among the trajectory's state components (controls carry no dynamics rows)
@@ -131,7 +146,7 @@ function state_row_offset(traj, name)
 end
 
 """
-    dynamics(integrators, traj, system; device=0, devices=nothing, eval_hessian=true, rows=:stacked, exact_structure=false, result_ring=3)
+    dynamics(integrators, traj, system; device=0, devices=nothing, eval_hessian=true, rows=:stacked, padded=false, result_ring=0)
 
 `integrators[1]` must be the `UnitaryPadeIntegrator` / `UnitaryExponentialIntegrator`, followed by
 `DerivativeIntegrator`s (the order of unitary_smooth_pulse_problem.jl:175-179).  `component_offset(traj, name)`
@@ -140,22 +155,26 @@ is `first(traj.components[name]) - 1`.
 `devices = 0:7` builds ONE evaluator over several GPUs (`qc_create_multi`): the knots are sharded inside the library, each
 GPU copies its own contiguous slice of `∂F` into the caller's vector over its own PCIe link; everything else is unchanged.
 `rows = :by_component` places every integrator's rows at its state component's position (`Z.dims.states` rows per interval).
-`exact_structure = true` (= `hess_align = 1`): `μ∂²F_structure` holds exactly the structural entries, no alignment padding --
-what a `==` / `length` comparison with QuantumCollocationCore's own structure needs (julia/reconcile.jl); the default pads every
-interval's value block to whole cache lines with explicit zero duplicates, which MOI sums away.
+`μ∂²F_structure` holds exactly the structural entries (config 3: 1 832 per interval), so `length` and `==` comparisons with
+QuantumCollocationCore's own structure are meaningful (julia/reconcile.jl).  `padded = true` (= `hess_align = 16`) is the layout of
+device-resident consumers: every interval's value block padded to whole cache lines with explicit zero duplicates, which a COO
+consumer sums away -- a host-buffer call is bound by PCIe and gains nothing from it.
 `set_new_x!(dyn, false)` is Ipopt's `new_x = false`: the following calls reuse the knots already on the device.
-`result_ring`: result vectors per closure handed out in turn by `F` / `∂F` / `μ∂²F` (0: a fresh vector per call; else >= 3).
+`result_ring`: 0 (default) = `F` / `∂F` / `μ∂²F` return fresh vectors; n >= 3 = rings of n pinned result vectors per closure (see `HIPDynamics`).
 """
 function dynamics(integrators, traj, system; device::Int=0, devices=nothing, eval_hessian::Bool=true,
                   state_name=:Ũ⃗, control_name=:a, pade_order::Int=4, exponential::Bool=false,
                   derivative_pairs=[(:a, :da), (:da, :dda)], n_kets::Int=0, rows::Symbol=:stacked, hess_align::Int=0,
-                  exact_structure::Bool=false, result_ring::Int=3)
+                  padded::Bool=false, result_ring::Int=0, offsets=nothing, generators=nothing)
     (result_ring == 0 || result_ring >= 3) || error("result_ring must be 0 (fresh vectors) or at least 3")
-    exact_structure && (hess_align = 1)
-    off(name) = first(traj.components[name]) - 1
-    n = 2 * system.levels
-    G0 = Matrix{Float64}(system.G_drift)                       # column-major n x n
-    Gd = reduce(hcat, [vec(Matrix{Float64}(G)) for G in system.G_drives])   # n^2 x m, column j = vec(G_j)
+    padded && (hess_align = 16)
+    # `offsets` (0-based positions inside a knot, keyed by name) and `generators` = (G_drift, [G_1 .. G_m]) override what is read from
+    # `traj.components` and `system`: what `QuantumDynamics(integrators, traj)` below passes after reading the integrator objects
+    off(name) = (!isnothing(offsets) && haskey(offsets, name)) ? Int(offsets[name]) : first(traj.components[name]) - 1
+    G0 = Matrix{Float64}(isnothing(generators) ? system.G_drift : generators[1])                       # column-major n x n
+    Gs = isnothing(generators) ? system.G_drives : generators[2]
+    Gd = reduce(hcat, [vec(Matrix{Float64}(G)) for G in Gs])   # n^2 x m, column j = vec(G_j)
+    levels = size(G0, 1) ÷ 2
     free_time = traj.timestep isa Symbol
     xs = [off(p[1]) for p in derivative_pairs]; dxs = [off(p[2]) for p in derivative_pairs]
     dms = [length(traj.components[p[1]]) for p in derivative_pairs]
@@ -164,7 +183,7 @@ function dynamics(integrators, traj, system; device::Int=0, devices=nothing, eva
     dims = Ref{QCDims}()
     devs = isnothing(devices) ? Int32[] : Int32.(collect(devices))
     GC.@preserve G0 Gd devs begin
-        desc = Ref(QCDesc(system.levels, length(system.G_drives), traj.T, traj.dim, traj.global_dim,
+        desc = Ref(QCDesc(levels, length(Gs), traj.T, traj.dim, traj.global_dim,
                           off(state_name), off(control_name), free_time ? off(traj.timestep) : -1,
                           free_time ? 0.0 : Float64(traj.timestep),
                           exponential ? 1 : 0, exponential ? 0 : pade_order, length(derivative_pairs),
@@ -193,15 +212,16 @@ function dynamics(integrators, traj, system; device::Int=0, devices=nothing, eva
         GC.@preserve Z⃗ out check(ccall((:qc_eval_jac, LIB[]), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), h[], Z⃗, out), h[])
         return out
     end
-    ringF = ResultRing(d.F_len, result_ring); ring∂F = ResultRing(d.jac_nnz, result_ring)
+    pinned = PinnedOwner(Ptr{Cvoid}[])
+    ringF = ResultRing(pinned, d.F_len, result_ring); ring∂F = ResultRing(pinned, d.jac_nnz, result_ring)
     F = (Z⃗; fresh::Bool=false) -> F!(next!(ringF, d.F_len, fresh), Z⃗)
     ∂F = (Z⃗; fresh::Bool=false) -> ∂F!(next!(ring∂F, d.jac_nnz, fresh), Z⃗)
-    μ∂²F = nothing; μ∂²F! = nothing; μ∂²F_structure = nothing; ringH = ResultRing(0, 0)
+    μ∂²F = nothing; μ∂²F! = nothing; μ∂²F_structure = nothing
     if eval_hessian && d.hess_nnz > 0
         hr = Vector{Int64}(undef, d.hess_nnz); hc = similar(hr)
         check(ccall((:qc_hess_structure, LIB[]), Cint, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}, Cint), h[], hr, hc, 1), h[])
-        μ∂²F_structure = collect(zip(Int.(hr), Int.(hc)))       # upper triangle, as test/test_utils.jl:14-27 expects; the
-                                                                # alignment padding repeats an entry with value 0 (duplicates are summed)
+        μ∂²F_structure = collect(zip(Int.(hr), Int.(hc)))       # upper triangle, as test/test_utils.jl:14-27 expects; with
+                                                                # `padded` the padding repeats an entry with value 0 (duplicates are summed)
         μ∂²F! = function (out::AbstractVector{Float64}, Z⃗::AbstractVector{Float64}, μ⃗::AbstractVector{Float64})
             length(out) == d.hess_nnz || error("μ∂²F!: output has length $(length(out)), expected $(d.hess_nnz)")
             length(μ⃗) == d.n_rows || error("μ∂²F!: μ has length $(length(μ⃗)), expected $(d.n_rows)")
@@ -209,16 +229,135 @@ function dynamics(integrators, traj, system; device::Int=0, devices=nothing, eva
                 (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), h[], Z⃗, μ⃗, out), h[])
             return out
         end
-        ringH = ResultRing(d.hess_nnz, result_ring)
+        ringH = ResultRing(pinned, d.hess_nnz, result_ring)
         μ∂²F = (Z⃗, μ⃗; fresh::Bool=false) -> μ∂²F!(next!(ringH, d.hess_nnz, fresh), Z⃗, μ⃗)
     end
-    dyn = HIPDynamics(h[], d, F, ∂F, ∂F_structure, μ∂²F, μ∂²F_structure, Int(bycomp ? traj.dims.states : d.ddim), F!, ∂F!, μ∂²F!)
-    finalizer(x -> ccall((:qc_destroy, LIB[]), Cvoid, (Ptr{Cvoid},), x.handle), dyn)
+    dyn = HIPDynamics(h[], d, F, ∂F, ∂F_structure, μ∂²F, μ∂²F_structure, Int(bycomp ? traj.dims.states : d.ddim), F!, ∂F!, μ∂²F!,
+                      Ptr{Cvoid}[h[]], pinned)
+    finalizer(release!, dyn)
     return dyn
 end
 
+# ---------------------------------------------------------------------------------------------------------------
+#  The reference's own constructor call: QuantumDynamics(integrators, traj)        (test/scripts/integrator_test_1qubit.jl:41)
+# ---------------------------------------------------------------------------------------------------------------
+
+# first of `names` that is a property of `x` (nothing when none is): the integrator structs of QuantumCollocationCore are not vendored
+# with the reference, so every field is looked up under the names recalled for 0.3.x (SURVEY Appendix B) AND has a keyword fallback
+function field_of(x, names...)
+    for nm in names
+        hasproperty(x, nm) && return getproperty(x, nm)
+    end
+    return nothing
+end
+type_name(x) = String(nameof(typeof(x)))
+is_derivative_integrator(x) = occursin("DerivativeIntegrator", type_name(x))
+is_state_integrator(x) = !is_derivative_integrator(x) && (occursin("Pade", type_name(x)) || occursin("Exponential", type_name(x)))
+# trajectory component whose index range starts at `first_index` (1-based position inside a knot)
+function component_at(traj, first_index::Integer)
+    for nm in traj.names
+        first(traj.components[nm]) == first_index && return nm
+    end
+    error("QCollocHIP.QuantumDynamics: no trajectory component starts at knot position $first_index")
+end
+# (G_drift, [G_1 .. G_m]) from the integrator's generator closure G(a) = G_drift + sum_j a_j G_j (affine in a: m + 1 evaluations)
+function generators_from_closure(G, m::Integer)
+    G0 = Matrix{Float64}(G(zeros(m)))
+    return G0, [Matrix{Float64}(G([j == k ? 1.0 : 0.0 for k in 1:m])) - G0 for j in 1:m]
+end
+
 """
-    dynamics_list(parts, traj; device=0, eval_hessian=true, exact_structure=false, result_ring=3)
+    QuantumDynamics(integrators, traj; system=nothing, state_name=nothing, control_name=nothing, pade_order=nothing,
+                    derivative_pairs=nothing, kwargs...)
+
+The positional arguments of the reference's own constructor call, `dynamics = QuantumDynamics(f, Z)` with `f = [P, D]`
+(test/scripts/integrator_test_1qubit.jl:39-41; `QuantumControlProblem` makes the same call with `prob.integrators`,
+unitary_smooth_pulse_problem.jl:175-190): qualifying that one call with `QCollocHIP.` is the whole change to the script.
+Everything `dynamics(integrators, traj, system; ...)` needs is read from the integrator objects:
+
+| needed                         | read from (first that exists)                                                  | keyword fallback     |
+|--------------------------------|--------------------------------------------------------------------------------|----------------------|
+| state component                | `P.unitary_components` / `P.state_components` (index range inside a knot), `P.unitary_name` / `P.state_name` / `P.state_symb` | `state_name`  |
+| control component              | `P.drive_components`, `P.control_name` / `P.drive_name` / `P.drive_symb`      | `control_name`       |
+| generators `G_drift, G_drives` | `P.system` (`.G_drift`, `.G_drives`), else `P.G_drift` / `P.G_drives`, else the closure `P.G` evaluated at `0` and the unit vectors | `system` |
+| Padé order                     | `P.order` (an `...ExponentialIntegrator` type name selects the exponential)    | `pade_order`         |
+| derivative integrators         | `D.variable_components` / `D.derivative_components`, or `D.variable` / `D.derivative` names, of every element whose type name contains `DerivativeIntegrator` | `derivative_pairs` |
+
+The field names are those recalled for QuantumCollocationCore 0.3.x (not vendored with the reference, SURVEY Appendix B): a field that
+is absent under every listed name raises an error naming the keyword that supplies it.  Lists with several state integrators (sampling
+and direct-sum problems) go to `dynamics_list`.  Remaining keywords (`device`, `devices`, `eval_hessian`, `rows`, `padded`,
+`result_ring`) are `dynamics`' own.
+"""
+function QuantumDynamics(integrators::AbstractVector, traj; system=nothing, state_name=nothing, control_name=nothing,
+                         pade_order=nothing, derivative_pairs=nothing, kwargs...)
+    states = [I for I in integrators if is_state_integrator(I)]
+    derivs = [I for I in integrators if is_derivative_integrator(I)]
+    length(states) + length(derivs) == length(integrators) || error("QCollocHIP.QuantumDynamics: an integrator is neither a Padé / exponential state integrator nor a DerivativeIntegrator")
+    isempty(states) && error("QCollocHIP.QuantumDynamics: the list holds no state integrator")
+    need(x, what, kw) = isnothing(x) ? error("QCollocHIP.QuantumDynamics: cannot read $what from $(type_name(states[1])); pass `$kw = ...`") : x
+    component(I, range_fields, name_fields, given, what, kw) = begin
+        !isnothing(given) && return given
+        r = field_of(I, range_fields...)
+        !isnothing(r) && return component_at(traj, first(r))
+        need(field_of(I, name_fields...), what, kw)
+    end
+    part_of(P) = begin
+        sname = component(P, (:unitary_components, :state_components, :ket_components), (:unitary_name, :state_name, :state_symb, :unitary_symb),
+                          length(states) == 1 ? state_name : nothing, "the state component", "state_name")
+        cname = component(P, (:drive_components, :control_components), (:control_name, :drive_name, :drive_symb),
+                          control_name, "the control component", "control_name")
+        expo = occursin("Exponential", type_name(P))
+        ord = expo ? 0 : Int(need(isnothing(pade_order) ? field_of(P, :order) : pade_order, "the Padé order", "pade_order"))
+        m = length(traj.components[cname])
+        gens = begin
+            sys = isnothing(system) ? field_of(P, :system, :sys) : system
+            if !isnothing(sys)
+                (sys.G_drift, collect(sys.G_drives))
+            elseif !isnothing(field_of(P, :G_drift)) && !isnothing(field_of(P, :G_drives))
+                (P.G_drift, collect(P.G_drives))
+            else
+                generators_from_closure(need(field_of(P, :G), "the generators (no `system`, `G_drift` / `G_drives` or `G` field)", "system"), m)
+            end
+        end
+        (sname, cname, expo, ord, gens)
+    end
+    pairs = if !isnothing(derivative_pairs)
+        collect(derivative_pairs)
+    else
+        map(derivs) do D
+            x = field_of(D, :variable_components); dx = field_of(D, :derivative_components)
+            if !isnothing(x) && !isnothing(dx)
+                (component_at(traj, first(x)), component_at(traj, first(dx)))
+            else
+                v = field_of(D, :variable, :variable_name, :x); dv = field_of(D, :derivative, :derivative_name, :dx)
+                (isnothing(v) || isnothing(dv)) && error("QCollocHIP.QuantumDynamics: cannot read the components of $(type_name(D)); pass `derivative_pairs = [(:a, :da), ...]`")
+                (Symbol(v), Symbol(dv))
+            end
+        end
+    end
+    if length(states) == 1
+        sname, cname, expo, ord, gens = part_of(states[1])
+        return dynamics(integrators, traj, nothing; state_name=sname, control_name=cname, pade_order=expo ? 4 : ord, exponential=expo,
+                        derivative_pairs=pairs, generators=gens, kwargs...)
+    end
+    # several state integrators: each with the derivative integrators that follow it in the list (the order QuantumDynamics stacks rows in)
+    parts = []
+    for (i, I) in enumerate(integrators)
+        if is_state_integrator(I)
+            sname, cname, expo, ord, gens = part_of(I)
+            push!(parts, (system=(G_drift=gens[1], G_drives=gens[2], levels=size(gens[1], 1) ÷ 2), state_name=sname, control_name=cname,
+                          derivative_pairs=Tuple{Symbol,Symbol}[], pade_order=expo ? 4 : ord, exponential=expo, n_kets=0))
+        else
+            k = count(is_derivative_integrator, integrators[1:i])
+            push!(parts[end].derivative_pairs, pairs[k])
+        end
+    end
+    allowed = (:device, :eval_hessian, :padded, :result_ring)
+    return dynamics_list(parts, traj; (k => v for (k, v) in kwargs if k in allowed)...)
+end
+
+"""
+    dynamics_list(parts, traj; device=0, eval_hessian=true, padded=false, result_ring=0)
 
 The integrator lists with SEVERAL state integrators -- `UnitarySamplingProblem` ([U_1 .. U_K, D, D], shared controls:
 unitary_sampling_problem.jl:134-155), `UnitaryDirectSumProblem` ([U_1, D, D, U_2, D, D, ...], own controls per member:
@@ -232,7 +371,7 @@ each with the derivative integrators that FOLLOW it in the list:
 order inside an interval (the order `QuantumDynamics` stacks them in).  The evaluations go through `qc_eval_*_list`: one upload
 of `Z⃗`, one batched launch where the parts' shapes allow it, results copied straight into the result vectors.
 """
-function dynamics_list(parts, traj; device::Int=0, eval_hessian::Bool=true, exact_structure::Bool=false, result_ring::Int=3)
+function dynamics_list(parts, traj; device::Int=0, eval_hessian::Bool=true, padded::Bool=false, result_ring::Int=0)
     (result_ring == 0 || result_ring >= 3) || error("result_ring must be 0 (fresh vectors) or at least 3")
     length(parts) >= 1 || error("dynamics_list: no state integrators")
     off(name) = first(traj.components[name]) - 1
@@ -247,7 +386,7 @@ function dynamics_list(parts, traj; device::Int=0, eval_hessian::Bool=true, exac
         Gd = reduce(hcat, [vec(Matrix{Float64}(G)) for G in sys.G_drives])
         push!(keep, G0); push!(keep, Gd)
         xs = [off(q[1]) for q in dpairs]; dxs = [off(q[2]) for q in dpairs]; dms = [length(traj.components[q[1]]) for q in dpairs]
-        return QCDesc(sys.levels, length(sys.G_drives), traj.T, traj.dim, traj.global_dim,
+        return QCDesc(size(G0, 1) ÷ 2, length(sys.G_drives), traj.T, traj.dim, traj.global_dim,
                       off(p.state_name), off(opt(p, :control_name, :a)), free_time ? off(traj.timestep) : -1,
                       free_time ? 0.0 : Float64(traj.timestep),
                       expo ? 1 : 0, expo ? 0 : opt(p, :pade_order, 4), length(dpairs),
@@ -265,7 +404,7 @@ function dynamics_list(parts, traj; device::Int=0, eval_hessian::Bool=true, exac
     rows = sum(x.ddim for x in own); jac = sum(x.jac_nnz_interval for x in own)
     with_hess = eval_hessian && all(x.hess_nnz_interval > 0 for x in own)
     hess_own = with_hess ? sum(x.hess_nnz_interval for x in own) : 0
-    al = exact_structure ? 1 : 16                              # the shared Hessian block is padded as a whole, through its last handle
+    al = padded ? 16 : 1                                       # `padded`: the shared Hessian block is padded as a whole, through its last handle
     hess = cld(hess_own, al) * al
     handles = Ptr{Cvoid}[]
     ro = jo = ho = 0
@@ -306,7 +445,8 @@ function dynamics_list(parts, traj; device::Int=0, eval_hessian::Bool=true, exac
         GC.@preserve Z⃗ out handles check(ccall((:qc_eval_jac_list, LIB[]), Cint, (Ptr{Ptr{Cvoid}}, Int32, Ptr{Float64}, Ptr{Float64}), handles, nh, Z⃗, out), h0)
         return out
     end
-    ringF = ResultRing(F_len, result_ring); ring∂F = ResultRing(jac_nnz, result_ring)
+    pinned = PinnedOwner(Ptr{Cvoid}[])
+    ringF = ResultRing(pinned, F_len, result_ring); ring∂F = ResultRing(pinned, jac_nnz, result_ring)
     F = (Z⃗; fresh::Bool=false) -> F!(next!(ringF, F_len, fresh), Z⃗)
     ∂F = (Z⃗; fresh::Bool=false) -> ∂F!(next!(ring∂F, jac_nnz, fresh), Z⃗)
     μ∂²F = nothing; μ∂²F! = nothing; μ∂²F_structure = nothing
@@ -320,13 +460,13 @@ function dynamics_list(parts, traj; device::Int=0, eval_hessian::Bool=true, exac
                 (Ptr{Ptr{Cvoid}}, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), handles, nh, Z⃗, μ⃗, out), h0)
             return out
         end
-        ringH = ResultRing(hess_nnz, result_ring)
+        ringH = ResultRing(pinned, hess_nnz, result_ring)
         μ∂²F = (Z⃗, μ⃗; fresh::Bool=false) -> μ∂²F!(next!(ringH, hess_nnz, fresh), Z⃗, μ⃗)
     end
     d0 = own[1]
     d = QCDims(F_len, d0.n_cols, rows, jac, hess, n_int, F_len, jac_nnz, hess_nnz, d0.Z_len, d0.kernel, 0)
-    dyn = HIPDynamics(h0, d, F, ∂F, ∂F_structure, μ∂²F, μ∂²F_structure, Int(rows), F!, ∂F!, μ∂²F!)
-    finalizer(_ -> foreach(h -> ccall((:qc_destroy, LIB[]), Cvoid, (Ptr{Cvoid},), h), handles), dyn)   # `handles` lives in the closures
+    dyn = HIPDynamics(h0, d, F, ∂F, ∂F_structure, μ∂²F, μ∂²F_structure, Int(rows), F!, ∂F!, μ∂²F!, handles, pinned)
+    finalizer(release!, dyn)
     return dyn
 end
 

@@ -18,7 +18,8 @@
 #             ORDER of lists with several integrators, which this repository takes to be the integrators' order
 # and writes tests/golden/ref_<case>.json: Z, mu, F, dF / mu_d2F values AND structures, plus the scalar definitions this
 # repository could only recall (INTEGRATION.md "Choices this repository cannot verify").  tests/test_reference_golden.py
-# picks the files up (COO comparison as sets of (row, col) -> summed value, hess_align = 1, rtol 1e-10) and the verdict of
+# picks the files up (values as (row, col) -> summed value at rtol 1e-10; structures by `length` and, sorted, `==`: the default layout of
+# the bindings is exactly the structural entries) and the verdict of
 # every row of that table is printed below.  Nothing here runs in the build container (no Julia): keep it in step with the
 # harness script when Core's constructors change.
 using QuantumCollocation, NamedTrajectories, LinearAlgebra, Random
@@ -36,8 +37,31 @@ json(x::AbstractArray) = "[" * join(json.(vec(collect(x))), ",") * "]"
 json(x::AbstractDict) = "{" * join(("$(repr(String(k))):$(json(v))" for (k, v) in x), ",") * "}"
 json(::Nothing) = "null"
 
+# With QCOLLOC_HIP_LIB set (a machine that has Julia, Core AND an MI355X), every record is also checked on the spot against the GPU
+# library through the one-line change INTEGRATION.md describes -- `QCollocHIP.QuantumDynamics(integrators, traj)` with exactly the
+# arguments Core's constructor got: values at rtol 1e-10, structures by `length` and sorted `==`.
+const HIP = haskey(ENV, "QCOLLOC_HIP_LIB")
+HIP && include(joinpath(@__DIR__, "QCollocHIP.jl"))
+hip_verdicts = Pair{String,Any}[]
+function hip_check(name, integrators, traj, dynamics, Z⃗, μ)
+    HIP || return
+    hip = QCollocHIP.QuantumDynamics(integrators, traj)
+    close(a, b) = maximum(abs.(a .- b)) <= 1e-10 * max(1.0, maximum(abs.(b)))
+    coo(vals, st) = (d = Dict{Tuple{Int,Int},Float64}(); foreach(((v, k),) -> d[k] = get(d, k, 0.0) + v, zip(vals, st)); d)
+    same_coo(a, b) = all(abs(get(a, k, 0.0) - get(b, k, 0.0)) <= 1e-10 * max(1.0, maximum(abs.(values(b)))) for k in union(keys(a), keys(b)))
+    push!(hip_verdicts, "$name: F" => close(hip.F(Z⃗), dynamics.F(Z⃗)))
+    push!(hip_verdicts, "$name: length(∂F_structure)" => (length(hip.∂F_structure), length(dynamics.∂F_structure)))
+    push!(hip_verdicts, "$name: sort(∂F_structure) ==" => (sort(hip.∂F_structure) == sort(collect(dynamics.∂F_structure))))
+    push!(hip_verdicts, "$name: ∂F values" => same_coo(coo(hip.∂F(Z⃗), hip.∂F_structure), coo(dynamics.∂F(Z⃗), dynamics.∂F_structure)))
+    if dynamics.μ∂²F !== nothing && hip.μ∂²F !== nothing
+        push!(hip_verdicts, "$name: length(μ∂²F_structure)" => (length(hip.μ∂²F_structure), length(dynamics.μ∂²F_structure)))
+        push!(hip_verdicts, "$name: sort(μ∂²F_structure) ==" => (sort(hip.μ∂²F_structure) == sort(collect(dynamics.μ∂²F_structure))))
+        push!(hip_verdicts, "$name: μ∂²F values" => same_coo(coo(hip.μ∂²F(Z⃗, μ), hip.μ∂²F_structure), coo(dynamics.μ∂²F(Z⃗, μ), dynamics.μ∂²F_structure)))
+    end
+end
+
 "The harness of integrator_test_1qubit.jl:41-52 on (system, traj): Core's own closures, nothing of this repository."
-function reference_record(system, traj; order=4, seed=1, integrators=nothing, described=nothing, systems=nothing)
+function reference_record(system, traj; order=4, seed=1, integrators=nothing, described=nothing, systems=nothing, name="record")
     if isnothing(integrators)
         P = UnitaryPadeIntegrator(:Ũ⃗, :a, system, traj; order=order)                   # unitary_smooth_pulse_problem.jl:165-167
         integrators = [P, DerivativeIntegrator(:a, :da, traj), DerivativeIntegrator(:da, :dda, traj)]   # :175-179
@@ -67,6 +91,7 @@ function reference_record(system, traj; order=4, seed=1, integrators=nothing, de
         rec["mu_d2F_rows"] = first.(dynamics.μ∂²F_structure)
         rec["mu_d2F_cols"] = last.(dynamics.μ∂²F_structure)
     end
+    hip_check(name, integrators, traj, dynamics, Z⃗, μ)
     return rec, dynamics
 end
 
@@ -82,7 +107,7 @@ mkpath(out_dir)
 # ---- fixture --------------------------------------------------------------------------------------------------
 sys1 = QuantumSystem(0.1 * PAULIS[:Z], [PAULIS[:X], PAULIS[:Y]])                          # test_utils.jl:123
 traj = named_trajectory_type_1(free_time=true)
-rec, dyn = reference_record(sys1, traj)
+rec, dyn = reference_record(sys1, traj; name="fixture")
 push!(verdicts, "rows of an interval: length(F) == Z.dims.states * (T - 1)" => (length(rec["F"]) == rec["rows_declared"]))
 push!(verdicts, "COO order inside an interval: first 6 (row, col) of dF_structure" => collect(zip(rec["dF_rows"][1:6], rec["dF_cols"][1:6])))
 push!(verdicts, "Hessian structure is upper-triangular" => all(r <= c for (r, c) in zip(rec["mu_d2F_rows"], rec["mu_d2F_cols"])))
@@ -119,7 +144,7 @@ for (name, system, gate, T) in (("config1", QuantumSystem(GATES[:Z], [GATES[:X],
                                 ("config2", QuantumSystem(0.1 * kron(PAULIS[:Z], PAULIS[:Z]),
                                                           [kron(PAULIS[:X], PAULIS[:I]), kron(PAULIS[:Y], PAULIS[:I]),
                                                            kron(PAULIS[:I], PAULIS[:X]), kron(PAULIS[:I], PAULIS[:Y])]), GATES[:CX], 200))
-    r, _ = reference_record(system, smooth_pulse_traj(system, gate, T, 0.2))
+    r, _ = reference_record(system, smooth_pulse_traj(system, gate, T, 0.2); name=name)
     open(io -> write(io, json(r)), joinpath(out_dir, "ref_$(name).json"), "w")
 end
 
@@ -133,7 +158,7 @@ toffoli = Matrix{ComplexF64}(I, 8, 8); toffoli[7:8, 7:8] = [0 1; 1 0]
 qft16 = [exp(2π * im * j * k / 16) / 4 for j in 0:15, k in 0:15]
 for (name, system, gate, T, order) in (("toffoli3", qubit_system(3), toffoli, 12, 4), ("qft4", qubit_system(4), qft16, 6, 4),
                                        ("order6", qubit_system(2), GATES[:CX], 10, 6))
-    r, _ = reference_record(system, smooth_pulse_traj(system, gate, T, 0.2); order=order)
+    r, _ = reference_record(system, smooth_pulse_traj(system, gate, T, 0.2); order=order, name=name)
     open(io -> write(io, json(r)), joinpath(out_dir, "ref_$(name).json"), "w")
 end
 
@@ -144,7 +169,7 @@ deriv(x, dx) = Dict{String,Any}("kind" => "derivative", "x" => String(x), "dx" =
 # UnitarySamplingProblem: [U_1, U_2, D(a, da), D(da, dda)] over components Ũ⃗_system_k, shared controls (unitary_sampling_problem.jl:103-107,134-155)
 sysA = QuantumSystem(0.3 * GATES[:Z], [GATES[:X], GATES[:Y]]); sysB = QuantumSystem(-0.3 * GATES[:Z], [GATES[:X], GATES[:Y]])
 probS = UnitarySamplingProblem([sysA, sysB], GATES[:H], 8, 0.2; quiet...)
-r, _ = reference_record(sysA, probS.trajectory; integrators=probS.integrators, systems=[sysA, sysB],
+r, _ = reference_record(sysA, probS.trajectory; integrators=probS.integrators, systems=[sysA, sysB], name="sampling2",
                         described=[upade(:Ũ⃗_system_1, :a, 1), upade(:Ũ⃗_system_2, :a, 2), deriv(:a, :da), deriv(:da, :dda)])
 open(io -> write(io, json(r)), joinpath(out_dir, "ref_sampling2.json"), "w")
 # UnitaryDirectSumProblem: [U_1, D, D, U_2, D, D] over the members' suffixed components, own controls (unitary_direct_sum_problem.jl:104,127-130)
@@ -152,19 +177,25 @@ fixed = (ipopt_options=IpoptOptions(print_level=1), piccolo_options=PiccoloOptio
 sysD = QuantumSystem(0.01 * GATES[:Z], [GATES[:X], GATES[:Y]])
 probD = UnitaryDirectSumProblem([UnitarySmoothPulseProblem(sysD, GATES[:X], 8, 0.2; fixed...), UnitarySmoothPulseProblem(sysD, GATES[:Y], 8, 0.2; fixed...)], 0.99;
                                 ipopt_options=IpoptOptions(print_level=1))
-r, _ = reference_record(sysD, probD.trajectory; integrators=probD.integrators, systems=[sysD, sysD],
+r, _ = reference_record(sysD, probD.trajectory; integrators=probD.integrators, systems=[sysD, sysD], name="directsum2",
                         described=[upade(:Ũ⃗1, :a1, 1), deriv(:a1, :da1), deriv(:da1, :dda1), upade(:Ũ⃗2, :a2, 2), deriv(:a2, :da2), deriv(:da2, :dda2)])
 open(io -> write(io, json(r)), joinpath(out_dir, "ref_directsum2.json"), "w")
 # UnitaryBangBangProblem: [U, D(u, du)], Pade order 12, control_name = :u as in its own test (unitary_bang_bang_problem.jl:163-175,205-215)
 probB = UnitaryBangBangProblem(sysD, GATES[:H], 8, 0.2; R_bang_bang=10.0, ipopt_options=IpoptOptions(print_level=1),
                                piccolo_options=PiccoloOptions(verbose=false, pade_order=12), control_name=:u)
-r, _ = reference_record(sysD, probB.trajectory; integrators=probB.integrators, systems=[sysD],
+r, _ = reference_record(sysD, probB.trajectory; integrators=probB.integrators, systems=[sysD], name="bangbang",
                         described=[upade(:Ũ⃗, :u, 1; order=12), deriv(:u, :du)])
 open(io -> write(io, json(r)), joinpath(out_dir, "ref_bangbang.json"), "w")
 
 println("\nreconcile.jl -- verdicts for INTEGRATION.md \"Choices this repository cannot verify\":")
 for (k, v) in verdicts
     println("  ", rpad(k, 72), " => ", v)
+end
+if HIP
+    println("\nQCollocHIP.QuantumDynamics(integrators, traj) against Core's QuantumDynamics on the same arguments (libqcolloc_hip.so on this machine):")
+    for (k, v) in hip_verdicts
+        println("  ", rpad(k, 72), " => ", v)
+    end
 end
 println("wrote ref_fixture.json, ref_fixture_exponential.json, ref_config1.json, ref_config2.json, ref_toffoli3.json, ref_qft4.json, ref_order6.json, ",
         "ref_sampling2.json, ref_directsum2.json, ref_bangbang.json to ", abspath(out_dir))

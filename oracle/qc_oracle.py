@@ -86,8 +86,9 @@ class Problem:
     global_dim: int = 0
     ncol: int = 0                # columns of the iso state: 0 -> N (unitary); K -> K kets stored back to back
                                  # (QuantumStatePadeIntegrator per ket, reference quantum_state_smooth_pulse_problem.jl:146-152)
-    hess_align: int = 16         # the per-interval Hessian value block is padded with explicit zeros (structure: duplicates
-                                 # of its first entry) to a multiple of this many entries; 1 = none (qc_desc.hess_align)
+    hess_align: int = 1          # 1 (default, as qc_desc.hess_align = 0): exactly the structural entries; k > 1: the per-interval
+                                 # Hessian value block is padded with explicit zeros (structure: duplicates of its first entry) to
+                                 # a multiple of k entries (qc_desc.hess_align = k, the layout of device-resident consumers)
     # Row placement (qc_desc.row_placement = QC_ROWS_BY_COMPONENT): rows_per_interval = Z.dims.states, the state
     # integrator's rows at row_offset, derivative integrator i's rows at deriv_rows[i]; rows of state components without an
     # integrator stay structurally empty (reference test/scripts/integrator_test_script.jl:23-44).  None = stacked rows.

@@ -34,10 +34,11 @@ QC_KERNEL_AUTO = 0
 QC_KERNEL_LDS = 1
 QC_KERNEL_MFMA = 2
 QC_MAX_DERIV = 8
+QC_HESS_ALIGN_LINE = 16     # qc_desc.hess_align of the line-aligned (padded) Hessian value layout (device-resident consumers)
 QC_FID_UNITARY, QC_FID_KET, QC_FID_DENSITY = 0, 1, 2
 QC_REG_DT_SCALED = 2       # (0 and 1 are retired values: the library refuses them)
 QC_REG_PLAIN = 3
-QC_ABI_VERSION = 4          # QC_VERSION_MAJOR * 1000 + QC_VERSION_MINOR of the include/qcolloc.h this file mirrors
+QC_ABI_VERSION = 5          # QC_VERSION_MAJOR * 1000 + QC_VERSION_MINOR of the include/qcolloc.h this file mirrors
 QC_FID_FORM_ABS, QC_FID_FORM_ABS2 = 0, 1
 QC_ROWS_STACKED = 0
 QC_ROWS_BY_COMPONENT = 1

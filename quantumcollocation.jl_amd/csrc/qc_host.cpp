@@ -204,7 +204,7 @@ int qc_build_params(const qc_desc* d, QcParams* P, qc_dims_t* dims, std::string*
     if (d->hess_per_interval > 0) {
         P->h_pad = P->hess_nnz ? d->hess_tail_zeros : 0;
     } else {
-        const int al = d->hess_align == 0 ? 16 : d->hess_align;
+        const int al = d->hess_align == 0 ? 1 : d->hess_align;   // 0 = the reference's structure, no padding (ABI 0.5)
         P->h_pad = P->hess_nnz ? (al - P->hess_nnz % al) % al : 0;
     }
     P->H_stride = d->hess_per_interval > 0 ? d->hess_per_interval : P->hess_nnz + P->h_pad;

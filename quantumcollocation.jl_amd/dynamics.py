@@ -9,12 +9,15 @@ field names and call shapes of reference test/scripts/integrator_test_1qubit.jl:
 (`getattr(dynamics, "∂F")` etc. resolve to the same members; `∂` is not a Python identifier.)
 Every evaluation is a call into libqcolloc_hip.so; this class only builds the C descriptor.
 
-RESULT LIFETIME of the vector-returning calls (the only shape the reference's evaluator uses, script lines 45-52): each of
-`F`, `dF`, `F_dF`, `mu_d2F` owns a ring of `result_ring` (default 3) result vectors, faulted in when the ring is built, and
-returns them in turn -- a result stays intact until the `result_ring`-th next call OF THE SAME CLOSURE (the evaluator copies
-it into Ipopt's buffer at once and never holds one that long).  A fresh 40 MB vector per call costs 2.7 - 4 ms of first-touch
-page faults at config 3, ten times the evaluation.  `fresh=True` on a call (or `result_ring=0` at construction) returns a
-newly allocated vector that is the caller's for good; `out=` writes into the caller's own array.
+RESULT LIFETIME of the vector-returning calls (the only shape the reference's evaluator uses, script lines 45-52): a returned
+vector is the caller's for as long as the caller holds it (or any view of it), exactly as with the reference's closures, which
+return a fresh vector.  What is recycled is only what the caller has LET GO OF: each closure keeps up to `result_ring` (default 3)
+pinned, already-faulted-in vectors and hands one out again once nothing outside the ring refers to it any more (its reference
+count says so); while every vector of the ring is still held -- `[dyn.F(Z + h * e_i) for i in ...]` -- the call returns a newly
+allocated array instead.  The evaluator's pattern (copy into Ipopt's buffer, drop) therefore never pays the 2.7 - 4 ms of
+first-touch page faults a fresh 40 MB vector costs at config 3, ten times the evaluation, and nobody ever sees a result change
+under their hands.  `fresh=True` on a call (or `result_ring=0` at construction) always allocates; `out=` writes into the caller's
+own array.  `dF` and `F_dF` share one ring of Jacobian vectors; `close()` releases the rings.
 """
 from __future__ import annotations
 
@@ -41,23 +44,46 @@ class _PinnedBlock:
 
     def __init__(self, ptr: int, n: int):
         self.ptr = ptr
+        self.nbytes = 8 * n
+        _pinned_live[0] += self.nbytes
         self.__array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 3}
 
     def __del__(self):
         try:
             if self.ptr and not sys.is_finalizing():
                 _lib.lib.qc_host_free(C.c_void_p(self.ptr))
+                _pinned_live[0] -= self.nbytes
         except Exception:   # noqa: BLE001
             pass
         self.ptr = 0
 
 
+_pinned_live = [0]           # bytes of qc_host_alloc memory currently owned by _PinnedBlocks of this process
+_pinned_warned = [False]
+
+
+def pinned_cap_bytes() -> int:
+    """Upper limit of page-locked result memory this process takes from the library (QC_PINNED_CAP_MB, default 2048): pinned pages
+    cannot be swapped, and every dynamics object keeps a few result vectors (config 3: 40 MB each)."""
+    try:
+        return max(0, int(float(os.environ.get("QC_PINNED_CAP_MB", "2048")) * (1 << 20)))
+    except ValueError:
+        return 2048 << 20
+
+
 def pinned_zeros(n: int) -> np.ndarray:
     """A float64 vector of n zeros in pinned host memory of the library (qc_host_alloc): the copy engine moves data from / into it
     without pinning pages per call, and `F(Z, out=...)` has the kernel write the residuals into it in place.  Ordinary zeros where there
-    is no GPU (or n is too small to matter).  The memory is freed when the last view of it is garbage-collected."""
+    is no GPU, n is too small to matter, or the process-wide cap (`pinned_cap_bytes`) is reached -- said once on stderr, since the
+    calls then pay the runtime's per-call pinning.  The memory is freed when the last view of it is garbage-collected."""
     n = int(n)
     if n * 8 < (64 << 10) or os.environ.get("QC_NO_PINNED"):
+        return np.zeros(n)
+    if _pinned_live[0] + n * 8 > pinned_cap_bytes():
+        if not _pinned_warned[0]:
+            _pinned_warned[0] = True
+            print(f"qcolloc: {_pinned_live[0] >> 20} MiB of pinned result memory in use, the cap is {pinned_cap_bytes() >> 20} MiB "
+                  "(QC_PINNED_CAP_MB): further result vectors are ordinary (pageable) arrays", file=sys.stderr)
         return np.zeros(n)
     p = C.c_void_p()
     if _lib.lib.qc_host_alloc(n * 8, C.byref(p)) != 0 or not p.value:
@@ -125,7 +151,8 @@ def make_desc(integrators: Sequence, traj: NamedTrajectory, *, device: int = 0, 
     template produces, since it lists one integrator per state component in component order).  rows = "by_component":
     every integrator's rows sit at its state component's position inside Z.dims.states rows per interval; state components
     without an integrator leave structurally empty rows (qc_desc.row_placement = QC_ROWS_BY_COMPONENT).
-    hess_align: qc_desc.hess_align (0 = library default, 16 doubles; 1 = no padding)."""
+    hess_align: qc_desc.hess_align (0 / 1 = exactly the structural entries, the reference's structure and the default; 16 = every
+    interval's value block padded to whole 128-byte lines with explicit zero duplicates, for device-resident consumers)."""
     if not integrators or not isinstance(integrators[0], (_UnitaryIntegrator, _KetIntegrator, DensityOperatorExponentialIntegrator)):
         raise NotImplementedError("the first integrator must be the unitary (or the first ket) integrator "
                                   "(row order of reference unitary_smooth_pulse_problem.jl:175-179)")
@@ -241,8 +268,8 @@ class QuantumDynamics:
         """devices = [d0, d1, ...]: ONE evaluator over several GPUs (qc_create_multi): the interval range is split into
         len(devices) contiguous shards, shard i on HIP device devices[i] (ordinals may repeat); F / dF / mu_d2F behave
         exactly as on one device and return the same arrays.
-        result_ring: vectors per closure that the vector-returning calls hand out in turn (module docstring); 0 = a fresh
-        vector per call."""
+        result_ring: vectors per closure that the vector-returning calls recycle once the caller has let go of them (module
+        docstring); 0 = a fresh vector per call."""
         self.integrators = list(integrators)
         self.traj = traj
         self.eval_hessian = eval_hessian
@@ -273,6 +300,7 @@ class QuantumDynamics:
         if getattr(self, "_h", None) is not None and self._h:
             _lib.lib.qc_destroy(self._h)
             self._h = None
+        self._drop_rings()
 
     def __del__(self):
         try:
@@ -342,27 +370,35 @@ class QuantumDynamics:
         return Z
 
     def _init_ring(self, result_ring: int) -> None:
-        if int(result_ring) < 0 or int(result_ring) == 1 or int(result_ring) == 2:
-            raise ValueError("result_ring must be 0 (fresh vectors) or at least 3 (the previous two results of a closure stay intact)")
+        if int(result_ring) < 0:
+            raise ValueError("result_ring must be 0 (a fresh vector per call) or the number of recycled vectors per closure")
         self.result_ring = int(result_ring)
-        self._rings = {}           # closure slot -> [next index, [vectors]]
+        self._rings = {}           # closure slot -> [vectors]  (at most result_ring each, built as they are needed)
+
+    def _drop_rings(self) -> None:
+        self._rings = {}           # vectors the caller still holds live on; the pinned blocks go with their last view
 
     def _out(self, name: str, n: int, out: Optional[np.ndarray] = None, fresh: bool = False, slot: Optional[str] = None) -> np.ndarray:
-        """Result array of `n` doubles: the caller's `out`; else (fresh=True, or no ring) a newly allocated array; else the next
-        vector of closure `slot`'s ring (module docstring: valid until the `result_ring`-th next call of the same closure).  The ring's
-        vectors are written once when the ring is built, so no call pays for page faults (2.7 - 4 ms per 40 MB at config 3)."""
+        """Result array of `n` doubles: the caller's `out`; else (fresh=True, or no ring) a newly allocated array; else a vector of
+        closure `slot`'s ring that nobody outside the ring refers to any more (module docstring) -- a result is never written
+        under a holder's hands.  The ring's vectors are written once when they are made, so a recycled one costs no page faults
+        (2.7 - 4 ms per 40 MB at config 3); with every vector of a full ring still held the call allocates."""
         if out is not None:
             if not (isinstance(out, np.ndarray) and out.dtype == np.float64 and out.flags.c_contiguous and out.size == n):
                 raise ValueError(f"out for {name} must be a contiguous float64 array of {n} elements")
             return out
         if fresh or not self.result_ring or n == 0:
             return np.empty(n)
-        ring = self._rings.get(slot or name)
-        if ring is None:
-            ring = self._rings[slot or name] = [0, [pinned_zeros(n) for _ in range(self.result_ring)]]
-        i = ring[0]
-        ring[0] = (i + 1) % self.result_ring
-        return ring[1][i]
+        ring = self._rings.setdefault(slot or name, [])
+        for k in range(len(ring)):
+            # references to a free vector: the ring's list, and getrefcount's own argument (views count: their base is the vector)
+            if sys.getrefcount(ring[k]) == 2:
+                ring.append(ring.pop(k))       # least recently handed out first
+                return ring[-1]
+        if len(ring) < self.result_ring:
+            ring.append(pinned_zeros(n))
+            return ring[-1]
+        return np.empty(n)
 
     def F(self, Z, out: Optional[np.ndarray] = None, *, fresh: bool = False) -> np.ndarray:
         Z = self._Z(Z)
@@ -378,8 +414,8 @@ class QuantumDynamics:
 
     def F_dF(self, Z, out: Optional[Tuple[np.ndarray, np.ndarray]] = None, *, fresh: bool = False):
         Z = self._Z(Z)
-        F = self._out("F", int(self.dims.F_len), None if out is None else out[0], fresh, "F_dF.F")
-        J = self._out("J", int(self.dims.jac_nnz), None if out is None else out[1], fresh, "F_dF.J")
+        F = self._out("F", int(self.dims.F_len), None if out is None else out[0], fresh)
+        J = self._out("J", int(self.dims.jac_nnz), None if out is None else out[1], fresh)
         _lib.check(_lib.lib.qc_eval_F_jac(self._h, _lib.dptr(Z), _lib.dptr(F), _lib.dptr(J)), self._h)
         return F, J
 
@@ -535,8 +571,8 @@ class ComposedQuantumDynamics(QuantumDynamics):
         rows = sum(int(x.ddim) for x in own)
         jac = sum(int(x.jac_nnz_interval) for x in own)
         hess_own = sum(int(x.hess_nnz_interval) for x in own) if all(x.hess_nnz_interval for x in own) else 0
-        # the shared per-interval Hessian block is padded to whole 128-byte lines through its LAST handle (qc_desc.hess_tail_zeros)
-        al = 16 if hess_align == 0 else max(1, int(hess_align))
+        # with hess_align > 1 the shared per-interval Hessian block is padded through its LAST handle (qc_desc.hess_tail_zeros)
+        al = max(1, int(hess_align))        # 0 / 1: exactly the structural entries (the default)
         hess = -(-hess_own // al) * al if hess_own else 0
         self._parts = []
         ro = jo = ho = 0
@@ -572,6 +608,7 @@ class ComposedQuantumDynamics(QuantumDynamics):
             if h:
                 _lib.lib.qc_destroy(h)
         self._parts = []
+        self._drop_rings()
 
     def _structure(self, one_based=False):
         n_int = int(self.dims.n_intervals)
@@ -631,8 +668,8 @@ class ComposedQuantumDynamics(QuantumDynamics):
     # -- host buffers: the "_list" entry points of the C ABI (one upload, the batched launch, copies straight into the arrays) ----
     def F_dF(self, Z, out=None, *, fresh: bool = False):
         Z = self._Z(Z)
-        F = self._out("F", int(self.dims.F_len), None if out is None else out[0], fresh, "F_dF.F")
-        J = self._out("dF", int(self.dims.jac_nnz), None if out is None else out[1], fresh, "F_dF.J")
+        F = self._out("F", int(self.dims.F_len), None if out is None else out[0], fresh)
+        J = self._out("J", int(self.dims.jac_nnz), None if out is None else out[1], fresh)
         _lib.check(_lib.lib.qc_eval_F_jac_list(self._handles, len(self._parts), _lib.dptr(Z), _lib.dptr(F), _lib.dptr(J)), self._parts[0][2])
         return F, J
 
@@ -644,7 +681,7 @@ class ComposedQuantumDynamics(QuantumDynamics):
 
     def dF(self, Z, out=None, *, fresh: bool = False):
         Z = self._Z(Z)
-        J = self._out("dF", int(self.dims.jac_nnz), out, fresh)
+        J = self._out("J", int(self.dims.jac_nnz), out, fresh)
         _lib.check(_lib.lib.qc_eval_jac_list(self._handles, len(self._parts), _lib.dptr(Z), _lib.dptr(J)), self._parts[0][2])
         return J
 
@@ -655,7 +692,7 @@ class ComposedQuantumDynamics(QuantumDynamics):
         mu = np.ascontiguousarray(mu, dtype=np.float64)
         if mu.size != self.dims.n_rows:
             raise ValueError(f"mu has length {mu.size}, expected {self.dims.n_rows}")
-        H = self._out("mu_d2F", int(self.dims.hess_nnz), out, fresh)
+        H = self._out("H", int(self.dims.hess_nnz), out, fresh)
         _lib.check(_lib.lib.qc_eval_hess_list(self._handles, len(self._parts), _lib.dptr(Z), _lib.dptr(mu), _lib.dptr(H)), self._parts[0][2])
         return H
 

@@ -35,7 +35,7 @@ class ShardedDynamics:
     """
 
     def __init__(self, integrators, traj, rank: int, world: int, device: int = 0,
-                 make_local: Optional[Callable] = None, kernel: str = "auto"):
+                 make_local: Optional[Callable] = None, kernel: str = "auto", hess_align: int = 0):
         self.rank, self.world = rank, world
         self.T = traj.T
         self.shards = knot_shards(traj.T, world)
@@ -45,7 +45,7 @@ class ShardedDynamics:
             from .dynamics import QuantumDynamics
 
             def make_local(t0, t1):
-                return QuantumDynamics(integrators, traj, device=device, kernel=kernel, t_range=(t0, t1))
+                return QuantumDynamics(integrators, traj, device=device, kernel=kernel, t_range=(t0, t1), hess_align=hess_align)
         # an empty tail shard (more ranks than intervals) gets a zero-interval evaluator: t_begin = t_end = T-1 > 0 is a valid
         # range, its dims are all zero-length and its launches are no-ops, so every rank runs the same code path
         self.empty = self.t1 == self.t0

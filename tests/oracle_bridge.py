@@ -104,7 +104,7 @@ def sparse_drive_problem(o, m, T, R=1, free_time=True, layout="standard", seed=0
     return prob, Z
 
 
-def composed_oracle(inp, hess_align=16):
+def composed_oracle(inp, hess_align=1):
     """Oracle evaluation of an integrator list with several unitary integrators (sampling problem): one oracle
     Problem per group, outputs interleaved per interval in integrator order."""
     import __graft_entry__ as g

@@ -223,8 +223,8 @@ def test_random_descriptors_structure_properties(qc, oracle):
         d.integrator, d.pade_order, d.n_deriv, d.state_cols = prob.integrator, prob.order, len(prob.derivs), ncol
         for i, dv in enumerate(prob.derivs):
             d.deriv_x_off[i], d.deriv_dx_off[i], d.deriv_dim[i] = dv.x_off, dv.dx_off, dv.dim
-        d.hess_align = int(rng.choice([0, 1, 8, 16, 24]))          # 0 = the library default (16 doubles)
-        prob.hess_align = d.hess_align or 16
+        d.hess_align = int(rng.choice([0, 1, 8, 16, 24]))          # 0 = the library default: exactly the structural entries (ABI 0.5)
+        prob.hess_align = d.hess_align or 1
         tag = f"trial {trial}: N={N} m={m} T={T} order={order} ft={free_time} integ={integ} ncol={ncol} align={d.hess_align}"
         dims = qc.desc_dims(d)
         assert dims.n_rows == prob.n_rows and dims.n_cols == prob.n_vars, tag
@@ -274,7 +274,7 @@ def test_c_example_compiles_as_c99_and_fails_loudly_without_a_device(qc, tmp_pat
     and stops at qc_create with QC_ERR_NO_DEVICE (no CPU path)."""
     exe = _build_c_example(tmp_path)
     r = subprocess.run([str(exe)], capture_output=True, text=True)
-    assert r.returncode == 1 and "rows 60 cols 90 jac_nnz 520 hess_nnz 320" in r.stdout   # 58 values per interval, padded to 64 (hess_align)
+    assert r.returncode == 1 and "rows 60 cols 90 jac_nnz 520 hess_nnz 290" in r.stdout   # 58 values per interval: exactly the structural entries (hess_align = 0)
     assert "no HIP device" in r.stderr
 
 

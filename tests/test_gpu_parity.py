@@ -409,14 +409,16 @@ def test_hessian_fixture_golden_and_exponential_unsupported(qc, oracle):
     sys_ = qc.QuantumSystem(0.1 * qc.PAULIS["Z"], [qc.PAULIS["X"], qc.PAULIS["Y"]])
     integ = [qc.UnitaryPadeIntegrator("Ũ⃗", "a", sys_, traj, order=4), qc.DerivativeIntegrator("a", "da", traj),
              qc.DerivativeIntegrator("da", "dda", traj)]
-    dyn = qc.QuantumDynamics(integ, traj, hess_align=1)   # the golden vectors are the unpadded layout
+    dyn = qc.QuantumDynamics(integ, traj)   # the default layout is the reference's: exactly the structural entries (the golden vectors)
+    assert dyn.dims.hess_nnz_interval == 58
     assert_close_h(dyn.mu_d2F(traj.datavec, np.ones(dyn.dims.n_rows)), gold["mu_d2F"])
     hr, hc = dyn.mu_d2F_structure
     np.testing.assert_array_equal(hr, gold["mu_d2F_rows"])
     np.testing.assert_array_equal(hc, gold["mu_d2F_cols"])
     dyn.close()
-    # default layout: every interval's 58 values padded to 64 with explicit zeros that duplicate the interval's first entry
-    dyn = qc.QuantumDynamics(integ, traj)
+    # line-aligned layout of device-resident consumers (hess_align = 16): every interval's 58 values padded to 64 with explicit zeros
+    # that duplicate the interval's first entry
+    dyn = qc.QuantumDynamics(integ, traj, hess_align=16)
     own = gold["mu_d2F"].size // (traj.T - 1)
     Hp = dyn.mu_d2F(traj.datavec, np.ones(dyn.dims.n_rows)).reshape(traj.T - 1, -1)
     assert Hp.shape[1] == 64 and own == 58 and not Hp[:, own:].any()
@@ -447,15 +449,15 @@ def test_antisymmetric_generator_path_matches_general_path(qc, monkeypatch, cfg,
     np.testing.assert_allclose(out[0], out[1], rtol=1e-11, atol=1e-12 * scale)
 
 
-@pytest.mark.parametrize("cfg,T", [(3, 1000), (5, 500), (3, 3000), (3, 4300), (5, 1100)])
-def test_full_size_hessian_properties(qc, oracle, cfg, T):
+@pytest.mark.parametrize("cfg,T,align", [(3, 1000, 0), (3, 1000, 16), (5, 500, 0), (5, 500, 16), (3, 3000, 16), (3, 4300, 0), (5, 1100, 16)])
+def test_full_size_hessian_properties(qc, oracle, cfg, T, align):
     """Configs 3 (T=1000) and 5 (T=500) at full size, and stretched past the grids' caps (2 999 and 4 299 intervals on 1 024 persistent
     workgroups at 2N = 16; five intervals per workgroup at 2N = 32): linearity in mu, directional second derivative against
     the Jacobian, an oracle window in the middle of the trajectory."""
     inp = qc.config_inputs(cfg, T=T)
     prob = problem_from_inputs(inp)
     Z = inp.traj.datavec
-    dyn = qc.QuantumDynamics(inp.integrators, inp.traj)
+    dyn = qc.QuantumDynamics(inp.integrators, inp.traj, hess_align=align)
     rng = np.random.default_rng(11)
     mu1, mu2 = rng.standard_normal(prob.n_rows), rng.standard_normal(prob.n_rows)
     H1, H2, H12 = dyn.mu_d2F(Z, mu1), dyn.mu_d2F(Z, mu2), dyn.mu_d2F(Z, 2.0 * mu1 - 3.0 * mu2)
@@ -477,14 +479,15 @@ def test_full_size_hessian_properties(qc, oracle, cfg, T):
     np.testing.assert_allclose(Hv, fd, rtol=2e-6, atol=2e-6)
     t0 = T // 2
     nn = dyn.dims.hess_nnz_interval
-    assert nn % 16 == 0                      # interval blocks start on 128-byte lines (qc_desc.hess_align)
+    own = len(oracle.hess_structure_local(prob))
+    assert nn == (own if align == 0 else -(-own // 16) * 16)   # exactly the structural entries by default; hess_align = 16: whole 128-byte lines
     ref = oracle.mu_d2F(prob, Z, mu1, t0, t0 + (2 if cfg == 3 else 1))
     np.testing.assert_allclose(H1[t0 * nn:t0 * nn + ref.size], ref, rtol=1e-10, atol=1e-11)
     dyn.close()
 
 
-@pytest.mark.parametrize("cfg", [3, 4])
-def test_full_size_every_value_against_the_c_oracle(qc, cfg):
+@pytest.mark.parametrize("cfg,align", [(3, 0), (3, 16), (4, 0)])
+def test_full_size_every_value_against_the_c_oracle(qc, cfg, align):
     """BASELINE configs 3 (T = 1000) and 4 (T = 8000, on one GPU) at full size: EVERY residual, Jacobian value and Hessian value of the
     host-buffer entry points against the C restatement of the oracle (oracle/qc_oracle.c, OpenMP: milliseconds at these sizes; itself
     checked against the numpy oracle in tests/test_oracle_c.py), rtol 1e-10; the device-resident one-call form gives the same bits."""
@@ -493,11 +496,13 @@ def test_full_size_every_value_against_the_c_oracle(qc, cfg):
     inp = qc.config_inputs(cfg)
     assert inp.traj.T == (1000 if cfg == 3 else 8000)
     prob = problem_from_inputs(inp)
+    prob.hess_align = align or 1
     co = oc.COracle(prob)
     rng = np.random.default_rng(cfg)
     Z = inp.traj.datavec + 1e-2 * rng.standard_normal(inp.traj.datavec.size)
     mu = rng.standard_normal(prob.n_rows)
-    dyn = qc.QuantumDynamics(inp.integrators, inp.traj)
+    dyn = qc.QuantumDynamics(inp.integrators, inp.traj, hess_align=align)
+    assert dyn.dims.hess_nnz_interval == (1832 if align == 0 else 1840)    # SURVEY 8's table: 1 832 structural entries per interval
     F, J = dyn.F_dF(Z)
     H = dyn.mu_d2F(Z, mu)
     Fr, Jr = co.F_dF(Z)

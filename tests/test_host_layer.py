@@ -51,28 +51,42 @@ def test_dynamics_requires_unitary_integrator_first(qc):
         qc.make_desc(inp.integrators[1:], inp.traj)
 
 
-def test_result_ring_hands_out_prefaulted_vectors_in_turn(qc):
-    """QuantumDynamics._out (the vector-returning closures F / dF / F_dF / mu_d2F): a ring of `result_ring` vectors per closure,
-    written when the ring is built; the previous two results of a closure stay intact; `fresh=True` and `result_ring=0` allocate;
-    `out=` is validated and passed through.  (No GPU: the method only manages host arrays.)"""
+def test_result_vectors_are_recycled_only_when_the_caller_let_go(qc):
+    """QuantumDynamics._out (the vector-returning closures F / dF / F_dF / mu_d2F): a returned vector is never handed out again
+    while the caller holds it or a view of it (the reference's closures return fresh vectors); once released, one of up
+    to `result_ring` pre-faulted vectors per closure is recycled; `fresh=True` and `result_ring=0` allocate; `out=` is validated and
+    passed through.  (No GPU: the method only manages host arrays.)"""
     import types
     obj = types.SimpleNamespace()
     qc.QuantumDynamics._init_ring(obj, 3)
     out = lambda name, n, **kw: qc.QuantumDynamics._out(obj, name, n, **kw)
-    got = []
+    # the evaluator's pattern: use the result, drop it -> the same few vectors come round, none is allocated per call
+    seen = set()
+    for k in range(9):
+        J = out("J", 10)
+        J[:] = k
+        seen.add(J.ctypes.data)
+        del J
+    assert len(seen) == 1                                                      # (one vector suffices for that pattern)
+    # results that are HELD are never written again: a finite-difference loop keeps every one of its vectors
+    held = []
     for k in range(7):
         J = out("J", 10)
-        if k >= 3:
-            assert J is got[k - 3]                                    # the ring comes round after three calls ...
-            assert got[k - 1][0] == k - 1 and got[k - 2][0] == k - 2  # ... and the previous two results are untouched
-        J[:] = k
-        got.append(J)
-    assert len({id(x) for x in got}) == 3
-    assert not np.shares_memory(out("H", 8), out("J", 10))            # one ring per closure
-    a, b = out("F", 6, slot="F_dF.F"), out("F", 6)                    # F_dF's residual vectors are not F's
-    assert not np.shares_memory(a, b)
+        J[:] = 100 + k
+        held.append(J)
+    assert len({x.ctypes.data for x in held}) == 7 and [int(x[0]) for x in held] == [100 + k for k in range(7)]
+    ring_ptrs = {v.ctypes.data for v in obj._rings["J"]}
+    assert len(ring_ptrs) == 3 and seen <= ring_ptrs and sum(x.ctypes.data in ring_ptrs for x in held) == 3   # the ring's three, then fresh arrays
+    view = held[0][2:5]                                                        # a view keeps its vector out of circulation ...
+    p0 = held[0].ctypes.data
+    del held
+    got = [out("J", 10) for _ in range(3)]
+    assert p0 not in {g.ctypes.data for g in got} and int(view[0]) == 100
+    del view, got
+    assert p0 in {out("J", 10).ctypes.data for _ in range(3)}                  # ... and releases it with itself
+    assert not np.shares_memory(out("H", 8), out("J", 10))                     # one ring per closure
     f1, f2 = out("J", 10, fresh=True), out("J", 10, fresh=True)
-    assert all(not np.shares_memory(f1, x) for x in got) and not np.shares_memory(f1, f2)
+    assert f1.ctypes.data not in ring_ptrs and not np.shares_memory(f1, f2)
     mine = np.empty(10)
     assert out("J", 10, out=mine) is mine
     with pytest.raises(ValueError):
@@ -83,9 +97,10 @@ def test_result_ring_hands_out_prefaulted_vectors_in_turn(qc):
     qc.QuantumDynamics._init_ring(none, 0)
     x, y = qc.QuantumDynamics._out(none, "J", 10), qc.QuantumDynamics._out(none, "J", 10)
     assert not np.shares_memory(x, y)
-    for bad in (1, 2, -1):
-        with pytest.raises(ValueError):
-            qc.QuantumDynamics._init_ring(types.SimpleNamespace(), bad)
+    with pytest.raises(ValueError):
+        qc.QuantumDynamics._init_ring(types.SimpleNamespace(), -1)
+    qc.QuantumDynamics._drop_rings(obj)
+    assert obj._rings == {}
 
 
 def test_seeded_synthetic_inputs_are_pinned(qc):

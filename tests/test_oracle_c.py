@@ -57,7 +57,9 @@ def test_oracles_reproduce_the_golden_vectors(oracle, coracle):
     mu = np.ones(prob.n_rows)
     np.testing.assert_allclose(oracle.F(prob, Zv), gold["F"], rtol=1e-14, atol=1e-16)
     np.testing.assert_allclose(oracle.dF(prob, Zv), gold["dF"], rtol=1e-14, atol=1e-16)
-    # the golden Hessian vector is the unpadded one (hess_align = 1); the default layout pads every interval's 58 values to 64
+    # the golden Hessian vector is the default layout (exactly the structural entries); hess_align = 16 pads every interval's 58 values to 64
+    np.testing.assert_allclose(oracle.mu_d2F(prob, Zv, mu), gold["mu_d2F"], rtol=1e-13, atol=1e-16)
+    prob.hess_align = 16
     Hp = oracle.mu_d2F(prob, Zv, mu).reshape(prob.T - 1, -1)
     own = len(oracle.hess_structure_local(prob))
     assert Hp.shape[1] == 64 and own == 58 and not Hp[:, own:].any()

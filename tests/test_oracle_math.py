@@ -165,9 +165,9 @@ def test_nnz_formulas_match_survey_table(oracle):
         assert prob.zdim == s + 3 * m + 1 and prob.ddim == ddim
         assert oracle.jac_nnz_interval(prob) == jn == 2 * N * n * n + s * m + s + 8 * m
         assert len(oracle.hess_structure_local(prob)) == hn == m * (m + 1) // 2 + 2 * s * m + m + 2 * s + 1 + 2 * m
-        assert oracle.hess_nnz_interval(prob) == -(-hn // 16) * 16       # default layout: padded to whole 128-byte lines
-        prob.hess_align = 1
-        assert oracle.hess_nnz_interval(prob) == hn
+        assert oracle.hess_nnz_interval(prob) == hn                      # default layout: exactly SURVEY's structural entries
+        prob.hess_align = 16
+        assert oracle.hess_nnz_interval(prob) == -(-hn // 16) * 16       # line-aligned layout: padded to whole 128-byte lines
 
 
 @pytest.mark.parametrize("integrator", ["pade", "exp"])

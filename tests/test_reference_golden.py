@@ -52,6 +52,24 @@ def assert_coo_equal(ours, ref, what, scale):
     assert not missing, f"{what}: {len(missing)} non-zero reference positions are not in this library's structure, e.g. {missing[:3]}"
 
 
+def assert_structure_equal(rows, cols, ref_rows, ref_cols, what):
+    """north_star: "bit-exact on sparsity structure".  The two structure vectors must have the same LENGTH and, sorted, be EQUAL
+    entry for entry (the order of the entries inside an interval is Core's own business: the values are compared position by position
+    above); `length(dynamics.mu_d2F_structure)` is observable at the boundary (reference test/scripts/integrator_test_1qubit.jl:48-52).
+    QC_STRUCTURE_NESTED_OK=1 relaxes this to nested position sets, for the one foreseeable outcome -- Core dropping the structural
+    zeros of B / F for sparse generators -- so that the value comparison can still be read while that is being settled."""
+    ours = sorted(zip(np.asarray(rows).tolist(), np.asarray(cols).tolist()))
+    ref = sorted((int(r) - 1, int(c) - 1) for r, c in zip(ref_rows, ref_cols))
+    if os.environ.get("QC_STRUCTURE_NESTED_OK"):
+        so, sr = set(ours), set(ref)
+        assert sr <= so or so <= sr, f"{what}: structures are not even nested"
+        return
+    diff = sorted(set(ours) ^ set(ref))
+    assert len(ours) == len(ref), (f"{what}: this library lists {len(ours)} structure entries, the reference {len(ref)}; "
+                                   f"{len(diff)} positions are in one and not the other, e.g. {diff[:4]}")
+    assert ours == ref, f"{what}: same length, different positions ({len(diff)} differ), e.g. {diff[:4]}"
+
+
 def problem_from_record(qc, rec):
     """(integrators, traj) of a reconcile.jl record, through the mirror constructors (reference call order
     unitary_smooth_pulse_problem.jl:163-179)."""
@@ -120,18 +138,20 @@ def test_oracle_against_reference_outputs(qc, oracle, path):
     jr, jc = ref.structure()
     Jr = np.asarray(rec["dF"], dtype=float)
     assert_coo_equal(coo_sum(jr, jc, ref.dF(Z), False), coo_sum(rec["dF_rows"], rec["dF_cols"], Jr, True), "dF", np.abs(Jr).max())
+    assert_structure_equal(jr, jc, rec["dF_rows"], rec["dF_cols"], "dF_structure (oracle)")
     if "mu_d2F" in rec:
         mu = np.asarray(rec["mu"], dtype=float)
         hr, hc = ref.hess_structure()
         Hr = np.asarray(rec["mu_d2F"], dtype=float)
         assert_coo_equal(coo_sum(hr, hc, ref.mu_d2F(Z, mu), False), coo_sum(rec["mu_d2F_rows"], rec["mu_d2F_cols"], Hr, True), "mu_d2F",
                          np.abs(Hr).max())
+        assert_structure_equal(hr, hc, rec["mu_d2F_rows"], rec["mu_d2F_cols"], "mu_d2F_structure (oracle)")
 
 
 def check_hip_path_against_record(qc, path):
     rec = json.load(open(path))
     integ, traj, Z = problem_from_record(qc, rec)
-    dyn = qc.QuantumDynamics(integ, traj, hess_align=1)
+    dyn = qc.QuantumDynamics(integ, traj)      # the bindings' default layout: exactly the structural entries
     want = EXPECTED_KERNELS.get(os.path.basename(path))
     if want is not None and not isinstance(dyn, qc.ComposedQuantumDynamics):
         assert dyn.kernel_names + (dyn.fused_kernel_name,) == want, (os.path.basename(path), dyn.kernel_names, dyn.fused_kernel_name)
@@ -140,15 +160,14 @@ def check_hip_path_against_record(qc, path):
     np.testing.assert_allclose(F, Fr, rtol=RTOL, atol=RTOL * max(1.0, np.abs(Fr).max()))
     jr, jc = dyn.dF_structure
     assert_coo_equal(coo_sum(jr, jc, J, False), coo_sum(rec["dF_rows"], rec["dF_cols"], Jr, True), "dF", np.abs(Jr).max())
+    assert_structure_equal(jr, jc, rec["dF_rows"], rec["dF_cols"], "dF_structure")
     if "mu_d2F" in rec:
         mu = np.asarray(rec["mu"], dtype=float)
         hr, hc = dyn.mu_d2F_structure
         Hr = np.asarray(rec["mu_d2F"], dtype=float)
         assert_coo_equal(coo_sum(hr, hc, dyn.mu_d2F(Z, mu), False), coo_sum(rec["mu_d2F_rows"], rec["mu_d2F_cols"], Hr, True), "mu_d2F", np.abs(Hr).max())
-        # bit-exact sparsity structure, as north_star words it: the same SET of positions (modulo explicit zeros either side lists)
-        ours = {(int(r), int(c)) for r, c in zip(hr, hc)}
-        ref = {(int(r) - 1, int(c) - 1) for r, c in zip(rec["mu_d2F_rows"], rec["mu_d2F_cols"])}
-        assert ref <= ours or ours <= ref, "Hessian structures are not nested"
+        # bit-exact sparsity structure, as north_star words it: same length, and equal entry for entry once sorted
+        assert_structure_equal(hr, hc, rec["mu_d2F_rows"], rec["mu_d2F_cols"], "mu_d2F_structure")
         if isinstance(dyn, qc.ComposedQuantumDynamics):       # (lists have no one-call form)
             dyn.close()
             return
@@ -168,7 +187,7 @@ def check_hip_path_against_record(qc, path):
 @pytest.mark.gpu
 @pytest.mark.parametrize("path", FILES, ids=[os.path.basename(f) for f in FILES])
 def test_hip_path_against_reference_outputs(qc, path):
-    """The HIP path, through the C ABI, directly against Core's numbers (hess_align = 1: exactly the structural entries)."""
+    """The HIP path, through the C ABI, directly against Core's numbers (the default layout: exactly the structural entries)."""
     check_hip_path_against_record(qc, path)
 
 
