@@ -62,6 +62,11 @@
  *   - "_dev" entry points take DEVICE pointers and a hipStream_t (passed as void*) and are
  *     asynchronous on that stream.  The plain entry points take HOST pointers and return after the
  *     results are in the caller's buffers.
+ *   - Every wait of a host-buffer call on the device has a deadline (environment QC_HOST_TIMEOUT_MS, default 30 s).  A call that runs
+ *     into it returns QC_ERR_HIP WITHOUT synchronising (a hung device would hang that, too): work of that call may still be queued and
+ *     may still write into the output buffers it was given and into memory of qc_host_alloc.  Those buffers must stay allocated and
+ *     are not to be read until the handle's next call has returned (it drains the handle's streams before it reuses anything) or the
+ *     handle has been destroyed (qc_destroy drains them too).
  *   - There is no CPU fallback: without a visible gfx950 device qc_create fails with QC_ERR_NO_DEVICE.
  */
 #ifndef QCOLLOC_H

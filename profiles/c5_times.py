@@ -14,7 +14,7 @@ qc = g.load_package()
 Ts = [int(x) for x in sys.argv[1:]] or [500]
 for T in Ts:
     inp = qc.config_inputs(5, T=T)
-    dyn = qc.QuantumDynamics(inp.integrators, inp.traj)
+    dyn = qc.QuantumDynamics(inp.integrators, inp.traj, hess_align=int(os.environ.get("QC_BENCH_HESS_ALIGN", "16")))   # the device consumers' layout
     d = dyn.dims
     Z = torch.from_numpy(inp.traj.datavec).cuda()
     mu = torch.from_numpy(np.random.default_rng(5).standard_normal(int(d.n_rows))).cuda()

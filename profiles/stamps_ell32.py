@@ -17,7 +17,7 @@ qc = g.load_package()
 which = sys.argv[1] if len(sys.argv) > 1 else "fused"
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 500
 inp = qc.config_inputs(5, T=T)
-dyn = qc.QuantumDynamics(inp.integrators, inp.traj)
+dyn = qc.QuantumDynamics(inp.integrators, inp.traj, hess_align=int(os.environ.get("QC_BENCH_HESS_ALIGN", "16")))
 d = dyn.dims
 Z = torch.from_numpy(inp.traj.datavec).cuda()
 mu = torch.from_numpy(np.random.default_rng(0).standard_normal(int(d.n_rows))).cuda()
@@ -41,6 +41,8 @@ n = int(d.n_intervals)
 out = np.zeros(n * 16, dtype=np.uint64)
 qc._lib.check(qc._lib.lib.qc_debug_read_stamps(dyn._h, out.ctypes.data_as(C.POINTER(C.c_uint64)), out.size), dyn._h)
 s = out.reshape(n, 16).astype(np.int64)
+if os.environ.get("QC_STAMP_DUMP"):      # raw stamps (row = interval index b = qc_xcd_remap(blockIdx.x, n)) for offline analysis
+    np.save(os.environ["QC_STAMP_DUMP"], s)
 t0 = s[s > 0].min()
 rel = (s - t0) * 10.0 / 1e3
 print(f"{which}, T={T}: {n} intervals, one per workgroup; kernels {dyn.kernel_names} / {dyn.fused_kernel_name}; launch-to-launch of this (stamped) "

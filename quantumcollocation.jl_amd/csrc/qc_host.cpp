@@ -491,6 +491,7 @@ extern "C" void qc_destroy(qc_handle* h) {
     if (h->dEll) (void)hipFree(h->dEll);
     if (h->ev_done) (void)hipEventDestroy(h->ev_done);
     if (h->dBatch) (void)hipFree(h->dBatch);
+    if (h->dBatchLand) (void)hipFree(h->dBatchLand);
     for (hipEvent_t ev : h->chunk_events) if (ev) (void)hipEventDestroy(ev);
     for (double* b : bufs) if (b) (void)hipFree(b);
     if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }

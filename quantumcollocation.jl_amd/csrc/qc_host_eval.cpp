@@ -46,12 +46,24 @@ static int check_align(qc_handle* h, const void* p, size_t a, const char* what) 
 static bool is_multi(const qc_handle* h) { return !h->shards.empty(); }
 
 // A wait on the device that ran into QC_HOST_TIMEOUT_MS: the call returns an error instead of spinning for ever.  Nothing is
-// synchronised here (a hung device would hang that, too): the handle's streams may still hold work, and its pinned blocks are re-armed
-// from scratch by the next call that gets that far.
+// synchronised here (a hung device would hang that, too): the handle's streams may still hold work that writes into the call's output
+// buffers (an asynchronous copy into the caller's array, the residual kernel writing into pinned memory in place) and into the
+// handle's staging.  The handle remembers (needs_drain): its next call -- or qc_destroy -- waits for the streams before anything is
+// reused, and qcolloc.h tells the caller to keep the failed call's output buffers allocated until then.
 static int timed_out(qc_handle* h, const char* what) {
     for (int i = 0; i < QC_HOST_RING; ++i) h->hC_armed[i] = false;
+    h->needs_drain = true;
     return fail(&h->err, QC_ERR_HIP, std::string("timed out after ") + std::to_string((long long)(qc_team::timeout_us() / 1e3)) +
                                          " ms waiting for " + what + " on the device (QC_HOST_TIMEOUT_MS)");
+}
+
+// first thing of every host-buffer call (device selected): finish what a timed-out call left on the streams
+static int drain_if_needed(qc_handle* h) {
+    if (!h->needs_drain) return QC_OK;
+    QC_HIP(h, hipStreamSynchronize(h->stream));
+    if (h->stream2) QC_HIP(h, hipStreamSynchronize(h->stream2));
+    h->needs_drain = false;
+    return QC_OK;
 }
 
 #define QC_NOT_MULTI(h, name)                                                                                        \
@@ -706,6 +718,21 @@ void qc_rearm_destroy(qc_rearm* r) {
 
 static int eval_host_chunked(qc_handle* h, const double* Z, double* F, double* vals, int shards);
 
+// dC / hC[] change hands between layouts (the handle's own host-buffer calls, a list it leads, another list): taken afresh
+static int claim_staging(qc_handle* h, unsigned long long tag, size_t cap) {
+    if (h->stage_tag == tag && h->stage_cap == cap) return QC_OK;
+    for (int i = 0; i < QC_HOST_RING; ++i) {
+        if (h->rearm[i]) h->rearm[i]->r.grp.wait();
+        if (h->hC[i]) { (void)hipHostFree(h->hC[i]); h->hC[i] = nullptr; }
+        h->hC_armed[i] = false;
+    }
+    if (h->dC) { QC_HIP(h, hipStreamSynchronize(h->stream)); (void)hipFree(h->dC); h->dC = nullptr; }
+    h->stage_tag = tag;
+    h->stage_cap = cap;
+    return QC_OK;
+}
+
+
 // The ring of pinned blocks: every block holds the watched output of this handle (residual rows + compact Jacobian values).
 // ring_take hands out the next block, armed (its re-arm jobs of the previous turn waited for).
 static size_t ring_capacity(const qc_handle* h) {
@@ -785,6 +812,7 @@ static int eval_host(qc_handle* h, const double* Z, double* F, double* vals, int
     qc_device_guard guard(h->device);
     QC_HIP(h, guard.err);
     int rc;
+    if ((rc = drain_if_needed(h))) return rc;
     if ((rc = upload_knots(h, Z))) return rc;
     if (!vals) {
         // residuals only (a line-search trial): kernel -> HBM -> one copy into the caller's array.  (Rows no kernel writes --
@@ -823,7 +851,8 @@ static int eval_host(qc_handle* h, const double* Z, double* F, double* vals, int
     J.vals = vals;
     J.F = F;
     const size_t cap = (size_t)P.n_int * ((size_t)P.F_stride + (size_t)cp.comp_len);
-    if ((rc = ensure_zeroed(h, &h->dC, cap))) return rc;      // (zeroed once: residual rows no kernel writes are delivered as 0)
+    if ((rc = claim_staging(h, 1, cap))) return rc;           // (the blocks may have been a list's: ADVICE round 4)
+    if ((rc = ensure_zeroed(h, &h->dC, cap))) return rc;      // (zeroed once per layout: residual rows no kernel writes are delivered as 0)
     int ib;
     if ((rc = ring_take(h, &ib))) return rc;
     J.src = h->hC[ib];
@@ -856,6 +885,7 @@ static int eval_host_chunked(qc_handle* h, const double* Z, double* F, double* v
     qc_device_guard guard(h->device);
     QC_HIP(h, guard.err);
     int rc;
+    if ((rc = drain_if_needed(h))) return rc;
     // Only the knots this handle touches cross PCIe: [t_begin, t_end] inclusive, through a pinned staging buffer (an
     // asynchronous copy from pageable memory is staged by the runtime in small pieces and blocks the calling thread).
     const size_t z0 = (size_t)P.t_begin * P.zdim;
@@ -944,6 +974,7 @@ static int hess_host(qc_handle* h, const double* Z, const double* mu, double* hv
     qc_device_guard guard(h->device);
     QC_HIP(h, guard.err);
     int rc;
+    if ((rc = drain_if_needed(h))) return rc;
     if ((rc = ensure(h, &h->dMu, (size_t)h->dims.n_rows))) return rc;
     if ((rc = ensure(h, &h->dH, (size_t)h->dims.hess_nnz))) return rc;
     if ((rc = upload_knots(h, Z))) return rc;
@@ -1088,8 +1119,9 @@ extern "C" int qc_create_multi(const qc_desc* d, int32_t n_shards, const int32_t
     QcParams P; qc_dims_t dims; std::string err;
     int rc = qc_build_params(d, &P, &dims, &err);
     if (rc) return rc;
-    if (d->hess_per_interval > 0 || d->jac_per_interval > 0 || d->jac_offset || d->hess_offset || (d->row_placement == QC_ROWS_STACKED && (d->rows_per_interval > 0 || d->row_offset)))
-        return fail(nullptr, QC_ERR_UNSUPPORTED, "qc_create_multi: composed descriptors (shared value vectors) are served by one handle per device and integrator");
+    // Composed descriptors (one handle per state integrator of a sampling / direct-sum problem, qc_desc.rows_per_interval ...) are
+    // sharded like any other: every member of the list is created with the SAME device list, so that shard s of every member covers
+    // the same intervals on the same device, and the "_list" entry points evaluate shard by shard (list_eval_multi below).
     qc_handle* h = new qc_handle();
     h->desc = *d;
     h->desc.G_drift = nullptr;
@@ -1325,7 +1357,7 @@ static int list_check(qc_handle* const* hs, int32_t count, const char* who) {
     if (!hs || count < 1) return fail(nullptr, QC_ERR_INVALID, std::string(who) + ": no handles");
     for (int i = 0; i < count; ++i) {
         if (!hs[i]) return fail(nullptr, QC_ERR_INVALID, std::string(who) + ": NULL handle");
-        if (is_multi(hs[i])) return fail(&hs[0]->err, QC_ERR_UNSUPPORTED, std::string(who) + ": multi-device handles are not composed");
+        if (is_multi(hs[i])) return fail(&hs[0]->err, QC_ERR_INVALID, std::string(who) + ": single- and multi-device handles cannot be mixed in one list");
     }
     const qc_handle* h0 = hs[0];
     const QcParams& P0 = h0->prm;
@@ -1344,7 +1376,23 @@ static int list_check(qc_handle* const* hs, int32_t count, const char* who) {
 // of its values itself (one copy of the N replicated blocks) does, one copy brings the blocks to a pinned ring block of hs[0],
 // and the host team replicates segment by segment into the caller's array.  Returns 1 when it served the call, 0 when the
 // list has nothing to gain from it (the plain copies follow), < 0 on error.
-static int list_eval_landing(qc_handle* const* hs, int32_t count, double* F, double* vals) {
+// The members' landing-layout parameter blocks in device memory, for the ONE batched launch (gridDim.y = count) that writes every
+// member's segment of the per-interval blocks: cached on hs[0] while the members and the block layout stay the same.
+static int land_batch_params(qc_handle* const* hs, int32_t count, const std::vector<QcParams>& blocks, size_t blk) {
+    qc_handle* h0 = hs[0];
+    bool same = h0->dBatchLand != nullptr && (int)h0->land_members.size() == count && h0->land_blk == blk;
+    for (int i = 0; same && i < count; ++i) same = h0->land_members[i] == hs[i]->serial;
+    if (same) return QC_OK;
+    if (h0->dBatchLand) { QC_HIP(h0, hipStreamSynchronize(h0->stream)); (void)hipFree(h0->dBatchLand); h0->dBatchLand = nullptr; }
+    QC_HIP(h0, hipMalloc((void**)&h0->dBatchLand, sizeof(QcParams) * count));
+    QC_HIP(h0, hipMemcpy(h0->dBatchLand, blocks.data(), sizeof(QcParams) * count, hipMemcpyHostToDevice));
+    h0->land_members.clear();
+    for (int i = 0; i < count; ++i) h0->land_members.push_back(hs[i]->serial);
+    h0->land_blk = blk;
+    return QC_OK;
+}
+
+static int list_eval_landing(qc_handle* const* hs, int32_t count, double* F, double* vals, int shards) {
     qc_handle* h = hs[0];
     const QcParams& P0 = h->prm;
     if (!vals || h->host_landing != 1 || h->host_compact != 1) return 0;
@@ -1367,30 +1415,48 @@ static int list_eval_landing(qc_handle* const* hs, int32_t count, double* F, dou
     const double t_begin = now_us();
     const size_t n_int = (size_t)P0.n_int, cap = n_int * blk;
     int rc;
-    if (h->list_blk != blk || h->list_int != n_int) {   // another list led by this handle before: its blocks do not fit
-        for (int i = 0; i < QC_HOST_RING; ++i) {
-            if (h->rearm[i]) h->rearm[i]->r.grp.wait();
-            if (h->hC[i]) { (void)hipHostFree(h->hC[i]); h->hC[i] = nullptr; }
-            h->hC_armed[i] = false;
-        }
-        if (h->dC) { QC_HIP(h, hipStreamSynchronize(h->stream)); (void)hipFree(h->dC); h->dC = nullptr; }
-        h->list_blk = blk;
-        h->list_int = n_int;
-    }
-    if ((rc = ensure_zeroed(h, &h->dC, cap))) return rc;      // (zeroed once: rows no handle of the list owns are delivered as 0)
+    // the layout's identity: the members (a recycled address is not the same handle: serial numbers), their row / value placement and
+    // the block size -- two lists with equal block sizes but different row ownership must not share a zeroed-once block
+    unsigned long long tag = 1469598103934665603ull;
+    auto mix = [&tag](unsigned long long v) { tag = (tag ^ v) * 1099511628211ull; };
+    mix((unsigned long long)count); mix((unsigned long long)blk); mix((unsigned long long)n_int);
+    for (int i = 0; i < count; ++i) { mix(hs[i]->serial); mix((unsigned long long)hs[i]->prm.F_off); mix((unsigned long long)seg[(size_t)i].off); }
+    tag |= 2ull;                                              // (never 0 = untouched, never 1 = the handle's own calls)
+    if ((rc = claim_staging(h, tag, cap))) return rc;
+    if ((rc = ensure_zeroed(h, &h->dC, cap))) return rc;      // (zeroed once per layout: rows no handle of the list owns are delivered as 0)
     int ib;
     if ((rc = ring_take(h, &ib, cap))) return rc;
+    std::vector<QcParams> Cs((size_t)count);
+    // one launch for every member where the batched kernel serves them all (2N <= 16, order 4, equal shapes: the K systems of a
+    // sampling problem, the members of a direct sum of equal systems), as the "_dev_multi" entry points do; else one launch each
+    bool batch = count >= 2 && count <= 65535;
+    static const bool no_batch = getenv("QC_LIST_BATCH") && atoi(getenv("QC_LIST_BATCH")) == 0;     // A/B diagnostics
     for (int i = 0; i < count; ++i) {
         const Seg& S = seg[(size_t)i];
-        QcParams C = S.direct ? compact_params(hs[i]->prm, S.cp) : hs[i]->prm;
+        QcParams& C = Cs[(size_t)i];
+        C = S.direct ? compact_params(hs[i]->prm, S.cp) : hs[i]->prm;
         C.J_stride = (long long)blk;
         C.J_off = (long long)S.off;
         C.F_stride = (long long)blk;                          // (F_off = the handle's first row inside the problem's rows: unchanged)
-        const hipError_t e = hs[i]->kernel == QC_KERNEL_MFMA ? qc_launch_mfma_F_jac(C, h->dZ, h->dC, h->dC, h->stream)
-                                                              : qc_launch_lds_F_jac(C, h->dZ, h->dC, h->dC, hs[i]->lds_bytes_jac, h->stream);
+        const QcParams& Pi = hs[i]->prm;
+        batch = batch && !no_batch && S.direct && hs[i]->kernel == QC_KERNEL_MFMA && qc_mfma16_batchable(Pi) && Pi.m == P0.m && Pi.n == P0.n && Pi.nc == P0.nc;
+    }
+    if (batch) {
+        if ((rc = land_batch_params(hs, count, Cs, blk))) return rc;
+        const hipError_t e = qc_launch_mfma16_F_jac_batch(Cs[0], h->dBatchLand, count, h->dZ, h->dC, h->dC, h->stream);
         if (e != hipSuccess) {
             (void)hipStreamSynchronize(h->stream);
             return fail(&h->err, QC_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+        }
+    } else {
+        for (int i = 0; i < count; ++i) {
+            const QcParams& C = Cs[(size_t)i];
+            const hipError_t e = hs[i]->kernel == QC_KERNEL_MFMA ? qc_launch_mfma_F_jac(C, h->dZ, h->dC, h->dC, h->stream)
+                                                                  : qc_launch_lds_F_jac(C, h->dZ, h->dC, h->dC, hs[i]->lds_bytes_jac, h->stream);
+            if (e != hipSuccess) {
+                (void)hipStreamSynchronize(h->stream);
+                return fail(&h->err, QC_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+            }
         }
     }
     hipError_t ec = hipMemcpyAsync(h->hC[ib], h->dC, cap * sizeof(double), hipMemcpyDeviceToHost, h->stream);
@@ -1429,14 +1495,45 @@ static int list_eval_landing(qc_handle* const* hs, int32_t count, double* F, dou
     J.F = F;
     J.src = h->hC[ib];
     J.rearm_inline = qc_team::land_inline_rearm();
-    rc = land_run(h, J, 1, t_begin, now_us());
+    rc = land_run(h, J, shards, t_begin, now_us());
     if (rc) { h->hC_armed[ib] = false; return rc; }
     if (!J.rearm_inline) ring_rearm_later(h, ib, cap);
     return 1;
 }
 
-static int list_eval(qc_handle* const* hs, int32_t count, const double* Z, const double* mu, double* F, double* vals, double* hvals, const char* who) {
+static int list_eval(qc_handle* const* hs, int32_t count, const double* Z, const double* mu, double* F, double* vals, double* hvals, const char* who,
+                     int shards = 1);
+
+// A list of multi-device handles (every member created by qc_create_multi with the same device list): shard s of every member covers
+// the same intervals on the same device, so the list is evaluated shard by shard -- one host thread per shard (the leader's), each
+// uploading its knots, launching on its device and landing its slice of the caller's arrays over its own PCIe link.  Z and mu are the
+// full vectors; F / vals / hvals the whole problem's.
+static int list_eval_multi(qc_handle* const* hs, int32_t count, const double* Z, const double* mu, double* F, double* vals, double* hvals, const char* who) {
+    qc_handle* h0 = hs[0];
+    const int n = (int)h0->shards.size();
+    for (int i = 0; i < count; ++i) {
+        if (!hs[i]) return fail(nullptr, QC_ERR_INVALID, std::string(who) + ": NULL handle");
+        if (!is_multi(hs[i]) || (int)hs[i]->shards.size() != n)
+            return fail(&h0->err, QC_ERR_INVALID, std::string(who) + ": every member of a multi-device list must be a multi-device handle over the same device list");
+        if (hs[i]->prm.F_stride != h0->prm.F_stride || hs[i]->prm.J_stride != h0->prm.J_stride)
+            return fail(&h0->err, QC_ERR_INVALID, std::string(who) + ": the handles do not describe one problem (per-interval block sizes differ)");
+    }
+    if (!Z || (!F && !vals && !hvals) || (hvals && !mu)) return fail(&h0->err, QC_ERR_INVALID, std::string(who) + ": NULL buffer");
+    std::vector<std::vector<qc_handle*>> sub((size_t)n, std::vector<qc_handle*>((size_t)count));
+    for (int sidx = 0; sidx < n; ++sidx)
+        for (int i = 0; i < count; ++i) sub[(size_t)sidx][(size_t)i] = hs[i]->shards[(size_t)sidx];
+    return multi_run(h0, [&](int sidx) {
+        // (offsets in doubles of shard sidx's slice: the same for every member, they share the per-interval strides)
+        const long long b0 = std::min<long long>(h0->prm.n_int, (long long)sidx * h0->shard_chunk);
+        return list_eval(sub[(size_t)sidx].data(), count, Z, mu, F ? F + b0 * h0->prm.F_stride : nullptr, vals ? vals + b0 * h0->prm.J_stride : nullptr,
+                         hvals ? hvals + b0 * h0->prm.H_stride : nullptr, who, n);
+    });
+}
+
+static int list_eval(qc_handle* const* hs, int32_t count, const double* Z, const double* mu, double* F, double* vals, double* hvals, const char* who,
+                     int shards) {
     int rc;
+    if (hs && count >= 1 && hs[0] && is_multi(hs[0])) return list_eval_multi(hs, count, Z, mu, F, vals, hvals, who);
     if ((rc = list_check(hs, count, who))) return rc;
     qc_handle* h = hs[0];
     const QcParams& P = h->prm;
@@ -1455,13 +1552,26 @@ static int list_eval(qc_handle* const* hs, int32_t count, const double* Z, const
     QC_HIP(h, guard.err);
     const size_t n_int = (size_t)P.n_int;
     const size_t nF = n_int * (size_t)P.F_stride, nJ = n_int * (size_t)P.J_stride, nH = hvals ? n_int * (size_t)P.H_stride : 0;
+    if ((rc = drain_if_needed(h))) return rc;
     if ((rc = upload_knots(h, Z))) return rc;
     if (vals) {
-        if ((rc = list_eval_landing(hs, count, F, vals)) < 0) return rc;
+        if ((rc = list_eval_landing(hs, count, F, vals, shards)) < 0) return rc;
         if (rc == 1) {
             if (!hvals) return QC_OK;
             vals = nullptr;
             F = nullptr;
+        }
+    }
+    {   // dF / dJ / dH are zeroed when they are made; a DIFFERENT list led by this handle (other members: other rows and values
+        // owned) must not see the previous one's numbers where it writes nothing
+        unsigned long long tag = 1469598103934665603ull;
+        for (int i = 0; i < count; ++i) tag = (tag ^ hs[i]->serial) * 1099511628211ull;
+        tag |= 2ull;
+        if (h->plain_tag != tag) {
+            if (h->dF) QC_HIP(h, hipMemsetAsync(h->dF, 0, nF * sizeof(double), h->stream));
+            if (h->dJ) QC_HIP(h, hipMemsetAsync(h->dJ, 0, nJ * sizeof(double), h->stream));
+            if (h->dH) QC_HIP(h, hipMemsetAsync(h->dH, 0, n_int * (size_t)P.H_stride * sizeof(double), h->stream));
+            h->plain_tag = tag;
         }
     }
     if (F && (rc = ensure_zeroed(h, &h->dF, nF))) return rc;       // rows no handle of the list owns stay 0
@@ -1472,15 +1582,16 @@ static int list_eval(qc_handle* const* hs, int32_t count, const double* Z, const
         if (vals) QC_HIP(h, hipMemcpyAsync(vals, h->dJ, nJ * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     }
     if (hvals) {
-        const size_t nMu = n_int * (size_t)P.F_stride;
-        if ((rc = ensure(h, &h->dMu, nMu))) return rc;
+        // (the kernels index the multipliers from interval 0 of the trajectory: this handle's slice goes to its place in a full-length vector)
+        const size_t nMu = n_int * (size_t)P.F_stride, m0 = (size_t)P.t_begin * (size_t)P.F_stride;
+        if ((rc = ensure(h, &h->dMu, (size_t)(h->desc.T - 1) * (size_t)P.F_stride))) return rc;
         if ((rc = ensure_zeroed(h, &h->dH, nH))) return rc;
-        QC_HIP(h, hipMemcpyAsync(h->dMu, mu, nMu * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        QC_HIP(h, hipMemcpyAsync(h->dMu + m0, mu + m0, nMu * sizeof(double), hipMemcpyHostToDevice, h->stream));
         if ((rc = qc_eval_hess_dev_multi(hs, count, h->dZ, h->dMu, h->dH, h->stream))) return rc;
         QC_HIP(h, hipMemcpyAsync(hvals, h->dH, nH * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     }
     QC_HIP(h, hipEventRecord(h->ev_done, h->stream));
-    return wait_done(h, 1);
+    return wait_done(h, shards);
 }
 
 extern "C" int qc_eval_F_list(qc_handle* const* hs, int32_t count, const double* Z, double* F) {

@@ -104,7 +104,13 @@ struct qc_handle {
     bool hC_armed[QC_HOST_RING] = {};    // completely sentinel-filled once `rearm[i]` has drained (cleared when a call fails midway)
     struct qc_rearm* rearm[QC_HOST_RING] = {};
     int hC_next = 0;
-    size_t list_blk = 0, list_int = 0;   // qc_eval_*_list led by this handle: doubles per interval block and intervals dC / hC[] were sized for
+    // Who laid out dC / hC[] last: 1 = this handle's own host-buffer calls, else a hash of the list it led (members, block layout,
+    // intervals) -- and for how many doubles.  A different layout takes the blocks afresh (zeroed dC, re-armed hC[]): rows that the new
+    // layout's kernels never write must not show the previous layout's values.
+    unsigned long long stage_tag = 0;
+    size_t stage_cap = 0;
+    unsigned long long plain_tag = 0;   // the list (members) whose rows / values dF, dJ, dH hold: zeroed again when another list takes them
+    bool needs_drain = false;  // a wait on the device ran into QC_HOST_TIMEOUT_MS: the streams still hold that call's work -- the next call drains them first
     int new_x = 1;             // qc_set_new_x: 0 = the knots on the device are current, Z is not read
     bool z_valid = false;      // dZ holds this handle's knots of SOME host-buffer call
     unsigned long long z_gen = 0;    // uploads of the knots so far (qc_knot_generation: what a binding that elides uploads compares)
@@ -112,6 +118,9 @@ struct qc_handle {
     int host_landing = 1;      // QC_HOST_LANDING=0: the chunked launches of round 2 instead of one watched copy (A/B diagnostics)
     QcParams* dBatch = nullptr;                // device copy of the parameter blocks of a batched launch led by this handle
     std::vector<unsigned long long> batch_members;   // serial numbers of the handles the cached blocks belong to
+    QcParams* dBatchLand = nullptr;            // ... and of the batched launch of a host-buffer list call (the landing layout of qc_eval_*_list)
+    std::vector<unsigned long long> land_members;
+    size_t land_blk = 0;
     unsigned long long serial = 0;             // unique per created handle (a recycled address is not the same handle)
     // multi-device handle (qc_create_multi): no device state of its own, `shards` own the devices
     std::vector<qc_handle*> shards;

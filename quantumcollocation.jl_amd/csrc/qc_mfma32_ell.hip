@@ -48,20 +48,16 @@ constexpr int kQS = 33;             // row stride of the plain 32 x 32 Gram matr
 
 // Byte offsets of the tables inside the device blob (host and device agree through this one function).
 //   tw / tc    [k][q][32]     row a of drive k: weight and column (pre-multiplied by kPS) of its q-th entry
-//   pw / po    [pair][L]      entries of G_i G_k + G_k G_i: weight, offset into the plain Gram matrix (row * kQS + col)
 //   gw / gk    [slot][1024]   assembly plan of G = G_0 + sum_k a_k G_k in the order of the A-layout image: the slot-th drive that
 //                             touches the entry (ascending k, so the sum has the order of the dense one) and its weight; k = 0, w = 0
 //                             where fewer drives do
-struct EllLayout { size_t tw, pw, gw, tc, po, gk, bytes; };
-__host__ __device__ inline EllLayout ell_layout(int m, int R, int L, int slots) {
-    const size_t npairs = (size_t)m * (m + 1) / 2;
+struct EllLayout { size_t tw, gw, tc, gk, bytes; };
+__host__ __device__ inline EllLayout ell_layout(int m, int R, int slots) {
     EllLayout o;
     o.tw = 0;
-    o.pw = o.tw + (size_t)m * R * 32 * 8;
-    o.gw = o.pw + npairs * L * 8;
+    o.gw = o.tw + (size_t)m * R * 32 * 8;
     o.tc = o.gw + (size_t)slots * 1024 * 8;
-    o.po = o.tc + (size_t)m * R * 32 * 4;
-    o.gk = o.po + npairs * L * 4;
+    o.gk = o.tc + (size_t)m * R * 32 * 4;
     o.bytes = o.gk + (size_t)slots * 1024 * 4;
     return o;
 }
@@ -236,6 +232,38 @@ __device__ inline void store_T32_columns(double* __restrict__ p, const ColumnPai
     }
 }
 
+// The (a_lo, a_hi) entry of the Hessian is c2 h^2 <G_lo G_hi + G_hi G_lo, Q>, Q = M D^T.  With R entries per generator row,
+//   (G_x G_y)[a][d] = sum_{q, q'} w_x[q][a] w_y[q'][c] at d = c_y[q'][c], c = c_x[q][a],
+// so the sum runs over 2 * 32 * R^2 terms (both orders x rows x entry choices): lane = (order, row), R^2 terms per lane, every factor
+// made from the drives' rows in LDS (TW: weights, TCr: raw columns) right behind barrier A, while the state is still on its way
+// (pair_consts: a weight and an offset into the plain Gram matrix per term), and multiplied with Q's entries later.  (Rounds 3 - 4 tabulated the merged
+// entries of G_lo G_hi + G_hi G_lo per pair at create time and every workgroup fetched its 28 KB of them from L2 with its first
+// loads: a third of the bytes of the request phase, 1.35 us of the config-5 launch -- profiles/r05_ell32_load_volume.txt.)
+// Rows with fewer than R entries carry weight 0 and column 0: a zero term.
+template <int R>
+__device__ __forceinline__ void pair_consts(const double* __restrict__ TW, const int* __restrict__ TCr, int lo, int hi, int lane, double (&wq)[R * R], int (&oq)[R * R]) {
+    const int a = lane & 31;
+    const bool second = (lane & 32) != 0;
+    const int x = second ? hi : lo, y = second ? lo : hi;       // (G_x G_y): the first factor's drive, the second's
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+        const double w1 = TW[(x * R + q) * 32 + a];
+        const int c = TCr[(x * R + q) * 32 + a];
+#pragma unroll
+        for (int q2 = 0; q2 < R; ++q2) {
+            wq[q * R + q2] = w1 * TW[(y * R + q2) * 32 + c];
+            oq[q * R + q2] = a * kQS + TCr[(y * R + q2) * 32 + c];
+        }
+    }
+}
+// pair index p = hi (hi + 1) / 2 + lo, lo <= hi  ->  (lo, hi)   (wave-uniform)
+// (branch-free: a loop here would put every pair's LDS reads into a basic block of their own, one round trip after the other)
+__device__ __forceinline__ void pair_decode(int p, int& lo, int& hi) {
+    static_assert(kEMax <= 8, "thresholds below: hi < 8");
+    hi = (p >= 1) + (p >= 3) + (p >= 6) + (p >= 10) + (p >= 15) + (p >= 21) + (p >= 28);
+    lo = p - hi * (hi + 1) / 2;
+}
+
 // Hand-offs between the waves of a workgroup through counters in LDS (the copy waves of the fused kernel must not stand at a
 // workgroup barrier while the knots are still on their way from HBM: their stores are what the launch time follows).  A wave's LDS
 // operations execute in order, so data written before the counter is visible to whoever has seen the counter.
@@ -260,18 +288,14 @@ __global__ __launch_bounds__(kEThreads, 4) void qc_mfma32_ell_kernel(const doubl
                                                                      const int hot_off_a, const int hot_off_dt, const int hot_off_U,
                                                                      const int hot_f_stride, const int hot_unused, const QcParams Pk,
                                                                      double* __restrict__ F, double* __restrict__ Jv, double* __restrict__ H) {
-    constexpr int L = R == 1 ? 64 : 256;          // padded length of a pair list (fixed by R: at most 32 * 2 R^2 entries)
     constexpr int kFirst = JAC ? 2 : 0;           // first compute wave (waves 0, 1 of a JAC instantiation are the copy waves)
     constexpr int kCW = 8 - kFirst;               // compute waves
     constexpr int kPairsPerWave = (kEMax * (kEMax + 1) / 2 + kCW - 1) / kCW;
     constexpr int kDrivesPerWave = (kEMax + kCW - 1) / kCW;
-    // The pair sums.  R = 1: the entries (one per lane and pair) are requested with the first loads.  mu_d2F alone sums them at the very
-    // end, in one batched reduction with the (a_k, h) sums (measured: summing them before the first drive delays every drive's
-    // products by 1 us and the launch by 0.7).  The one-call form sums them EARLY -- as soon as Q is there, before the wave's first
-    // drive: it has no registers to hold the entries through its drives, and on this hardware a load waits for every store the wave
-    // has issued before it (one in-order counter), so a request behind the drives' stores would hold the wave until its whole backlog
-    // has reached HBM.  R = 2 (four entries per lane and pair): requested behind the state flags, summed early.
-    constexpr bool kPrefetchPairs = HESS && R == 1;
+    // The pair sums: their constants (pair_consts: LDS only, no loads) are made right behind barrier A.  mu_d2F alone with R = 1 holds
+    // them (one weight and one offset per pair) through its drives and sums at the very end, in one batched reduction with the (a_k, h)
+    // sums (measured: summing them before the first drive delays every drive's products by 1 us and the launch by 0.7).  The one-call
+    // form and R = 2 (four terms per lane and pair) have no registers for that: they sum EARLY, as soon as Q is there.
     constexpr bool kEarlyPairs = HESS && (JAC || R != 1);
     constexpr int kDF = 2;                        // derivative integrators whose data is requested early and parked in LDS (JAC): the templates have two
     QcKernargTouch<sizeof(QcParams) + 96> touch;
@@ -283,6 +307,7 @@ __global__ __launch_bounds__(kEThreads, 4) void qc_mfma32_ell_kernel(const doubl
     __shared__ double Qp[32 * kQS];                                  // Q = M D^T
     __shared__ double TW[kEMax * R * 32];                            // the drives' rows: weights ...
     __shared__ int TC[kEMax * R * 32];                               // ... and columns (x kPS)
+    __shared__ int TCr[kEMax * R * 32];                              // ... and the raw columns (pair sums)
     __shared__ int flags[FL_COUNT];
     __shared__ double DerL[2 * kDF * 64];                            // derivative-integrator data (JAC), parked from the first loads to the end
     const int tid = threadIdx.x;
@@ -306,10 +331,8 @@ __global__ __launch_bounds__(kEThreads, 4) void qc_mfma32_ell_kernel(const doubl
 
     // ---- phase 0: G (every wave its half tile), the tables, then the state (requested last: G must not wait for it) -----------
     const double h = ft ? z0[hot_off_dt] : opaque_scalar(P.dt_fixed);
-    const EllLayout lay = ell_layout(m, R, L, SLOTS);
+    const EllLayout lay = ell_layout(m, R, SLOTS);
     const int npairs = m * (m + 1) / 2;
-    double pwv[kPairsPerWave];        // R = 1: this wave's pair entries, one per lane and pair, requested with everything else
-    int pov[kPairsPerWave];
     Col16Raw raw0 = {0.0, 0.0, 0.0, 0.0}, raw1 = raw0;      // loader waves: M tile, or U_t / U_t+1 tiles (as requested; transposed behind barrier A)
     double mud[2] = {0.0, 0.0};
     double dvx[kDF], dva[kDF], dvb[kDF];
@@ -344,17 +367,6 @@ __global__ __launch_bounds__(kEThreads, 4) void qc_mfma32_ell_kernel(const doubl
         __builtin_amdgcn_sched_barrier(0);
         // EVERY wave issues the same requests here, without a branch (a wave that has no use for one reads a harmless address):
         // behind a branch the compiler cannot count what is outstanding where the paths meet, and waits for everything.
-        if constexpr (kPrefetchPairs) {
-            const double* __restrict__ pw = reinterpret_cast<const double*>(hot_ell + lay.pw);
-            const int* __restrict__ po = reinterpret_cast<const int*>(hot_ell + lay.po);
-#pragma unroll
-            for (int t = 0; t < kPairsPerWave; ++t) {
-                const int p = cw + kCW * t;
-                const int pe = p < npairs ? p : 0;        // (clamped: the value of a pair beyond the last is never stored)
-                pwv[t] = pw[(size_t)pe * L + lane];
-                pov[t] = po[(size_t)pe * L + lane];
-            }
-        }
         {
             const int Iu = cw - (kCW - 2), Im = cw - (kCW - 4);
             const double* pa = ld_u ? z0 + hot_off_U + j * 32 + 16 * Iu : (ld_m ? mu + j * 32 + 16 * Im : z0);
@@ -378,7 +390,7 @@ __global__ __launch_bounds__(kEThreads, 4) void qc_mfma32_ell_kernel(const doubl
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int sl = 0; sl < SLOTS; ++sl) Gh += v2d{__shfl(amp, k0[sl]), __shfl(amp, k1[sl])} * wv[sl];
-        if (w < m && lane < 32 * R && !f_only) { TW[w * R * 32 + lane] = twv; TC[w * R * 32 + lane] = tcv; }
+        if (w < m && lane < 32 * R && !f_only) { TW[w * R * 32 + lane] = twv; TC[w * R * 32 + lane] = tcv; TCr[w * R * 32 + lane] = tcv / kPS; }
         reinterpret_cast<v2d*>(GL)[e0 >> 1] = Gh;
         if (tid < FL_COUNT) flags[tid] = 0;
     }
@@ -395,6 +407,20 @@ __global__ __launch_bounds__(kEThreads, 4) void qc_mfma32_ell_kernel(const doubl
     __syncthreads();                  // G, the tables and the zeroed counters; the state is still on its way
     const double hc1 = h * c1, hc2 = h * h * c2, c2h2 = 2.0 * c2 * h;
     QC_STAMP(P, b, lane, 2);
+    double wq[kPairsPerWave][R * R];      // this wave's pairs: the constants of their terms
+    int oq[kPairsPerWave][R * R];
+    auto make_pair_consts = [&]() {
+#pragma unroll
+        for (int t = 0; t < kPairsPerWave; ++t) {
+            const int p = cw + kCW * t;
+            int lo, hi;
+            pair_decode(p < npairs ? p : 0, lo, hi);          // (clamped: the value of a pair beyond the last is never stored)
+            pair_consts<R>(TW, TCr, lo, hi, lane, wq[t], oq[t]);
+        }
+    };
+    // Made right in front of their use, as straight-line code (the reads of all pairs batch up: three LDS round trips in all).  Making
+    // them early -- behind barrier A, in the shadow of the state's round trip -- was measured: the registers they go to are the
+    // destinations of loads still in flight (the late group), so the wave waits for those first, and the state is published 1.1 us later.
 
     if (JAC && cw < 0) {
         if (f_only) return;
@@ -491,30 +517,15 @@ __global__ __launch_bounds__(kEThreads, 4) void qc_mfma32_ell_kernel(const doubl
             flag_signal(flags, FL_Q, lane);
         }
         if constexpr (kEarlyPairs) {
-            // ---- this wave's share of the pair sums, early (see kPrefetchPairs) -----------------------------------------------------
-            double wq[kPairsPerWave][L / 64];
-            int oq[kPairsPerWave][L / 64];
-            if constexpr (kPrefetchPairs) {
-#pragma unroll
-                for (int t = 0; t < kPairsPerWave; ++t) { wq[t][0] = pwv[t]; oq[t][0] = pov[t]; }
-            } else {
-                const double* __restrict__ pw = reinterpret_cast<const double*>(hot_ell + lay.pw);
-                const int* __restrict__ po = reinterpret_cast<const int*>(hot_ell + lay.po);
-#pragma unroll
-                for (int t = 0; t < kPairsPerWave; ++t) {
-                    const int p = cw + kCW * t;
-                    const int pe = p < npairs ? p : 0;
-#pragma unroll
-                    for (int e = 0; e < L / 64; ++e) { wq[t][e] = pw[(size_t)pe * L + 64 * e + lane]; oq[t][e] = po[(size_t)pe * L + 64 * e + lane]; }
-                }
-            }
+            // ---- this wave's share of the pair sums, early -----------------------------------------------------------------------------
+            make_pair_consts();
             flag_wait(flags, FL_Q, 1);
             double ps[kPairsPerWave];
 #pragma unroll
             for (int t = 0; t < kPairsPerWave; ++t) {
                 double acc = wq[t][0] * Qp[oq[t][0]];
 #pragma unroll
-                for (int e = 1; e < L / 64; ++e) acc += wq[t][e] * Qp[oq[t][e]];
+                for (int e = 1; e < R * R; ++e) acc += wq[t][e] * Qp[oq[t][e]];
                 ps[t] = acc;
             }
             wave_sum_multi<kPairsPerWave>(ps);
@@ -610,9 +621,10 @@ __global__ __launch_bounds__(kEThreads, 4) void qc_mfma32_ell_kernel(const doubl
                 double pq[kDrivesPerWave + kPairsPerWave];
 #pragma unroll
                 for (int t = 0; t < kDrivesPerWave; ++t) pq[t] = pv[t];
+                make_pair_consts();
                 flag_wait(flags, FL_Q, 1);
 #pragma unroll
-                for (int t = 0; t < kPairsPerWave; ++t) pq[kDrivesPerWave + t] = pwv[t] * Qp[pov[t]];
+                for (int t = 0; t < kPairsPerWave; ++t) pq[kDrivesPerWave + t] = wq[t][0] * Qp[oq[t][0]];
                 wave_sum_multi<kDrivesPerWave + kPairsPerWave>(pq);
                 if (lane == 0) {
 #pragma unroll
@@ -732,25 +744,6 @@ int qc_mfma32_ell_build(const QcParams& P, const double* G, std::vector<char>* b
             R = std::max(R, cnt);
         }
     if (R < 1 || R > 2) return 0;
-    const int L = R == 1 ? 64 : 256;
-    // G_i G_k + G_k G_i, structurally (an entry that cancels to exactly zero is kept out: it adds nothing)
-    const int npairs = m * (m + 1) / 2;
-    std::vector<std::vector<std::pair<int, double>>> lists(npairs);
-    for (int hi = 0; hi < m; ++hi)
-        for (int lo = 0; lo <= hi; ++lo) {
-            std::vector<double> Pm((size_t)n * n, 0.0);
-            for (int a = 0; a < n; ++a)
-                for (int c = 0; c < n; ++c) {
-                    const double x = Gk(lo, a, c), y = Gk(hi, a, c);
-                    if (x != 0.0) for (int d = 0; d < n; ++d) Pm[(size_t)a * n + d] += x * Gk(hi, c, d);
-                    if (y != 0.0) for (int d = 0; d < n; ++d) Pm[(size_t)a * n + d] += y * Gk(lo, c, d);
-                }
-            auto& li = lists[hi * (hi + 1) / 2 + lo];
-            for (int a = 0; a < n; ++a)
-                for (int d = 0; d < n; ++d)
-                    if (Pm[(size_t)a * n + d] != 0.0) li.emplace_back(a * kQS + d, Pm[(size_t)a * n + d]);
-            if ((int)li.size() > L) return 0;            // (cannot happen: at most 2 R^2 entries per row)
-        }
     // how many drives touch one entry of G
     int slots = 0;
     for (int a = 0; a < n; ++a)
@@ -761,13 +754,11 @@ int qc_mfma32_ell_build(const QcParams& P, const double* G, std::vector<char>* b
         }
     if (slots > kMaxSlots) return 0;                     // (e.g. five diagonal drives: the dense-image kernels serve the handle)
     slots = slots <= 1 ? 1 : (slots <= 2 ? 2 : 4);      // the instantiated plan depths; unused slots carry weight 0
-    const EllLayout lay = ell_layout(m, R, L, slots);
+    const EllLayout lay = ell_layout(m, R, slots);
     blob->assign(lay.bytes, 0);
     double* tw = reinterpret_cast<double*>(blob->data() + lay.tw);
-    double* pw = reinterpret_cast<double*>(blob->data() + lay.pw);
     double* gw = reinterpret_cast<double*>(blob->data() + lay.gw);
     int* tc = reinterpret_cast<int*>(blob->data() + lay.tc);
-    int* po = reinterpret_cast<int*>(blob->data() + lay.po);
     int* gk = reinterpret_cast<int*>(blob->data() + lay.gk);
     for (int k = 0; k < m; ++k)
         for (int a = 0; a < n; ++a) {
@@ -780,11 +771,6 @@ int qc_mfma32_ell_build(const QcParams& P, const double* G, std::vector<char>* b
                 ++q;
             }
             // (rows with fewer than R entries keep weight 0 and column 0: a valid address, a zero term)
-        }
-    for (int p = 0; p < npairs; ++p)
-        for (size_t e = 0; e < lists[p].size(); ++e) {
-            po[(size_t)p * L + e] = lists[p][e].first;
-            pw[(size_t)p * L + e] = lists[p][e].second;
         }
     // assembly plan in the order of the A-layout image (qc_mfma32_pack_G): entry [tile = 2 I + K][pair][lane = 16 g + i][e] = X[16 I + i][16 K + 4 (2 pair + e) + g]
     for (int tile = 0; tile < 4; ++tile)

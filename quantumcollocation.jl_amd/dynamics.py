@@ -555,14 +555,22 @@ class ComposedQuantumDynamics(QuantumDynamics):
     def __init__(self, integrators: Sequence, traj: NamedTrajectory, *, device: int = 0, kernel: str = "auto",
                  t_range: Optional[Tuple[int, int]] = None, eval_hessian: bool = True, devices: Optional[Sequence[int]] = None,
                  rows: str = "stacked", hess_align: int = 0, result_ring: int = 3):
-        if devices is not None or rows != "stacked":
-            raise NotImplementedError("several unitary integrators: one device, stacked rows")
+        """devices = [d0, d1, ...]: every member of the list is created over the same device list (qc_create_multi on a composed
+        descriptor), so shard s of every member covers the same intervals on the same GPU; the host-buffer calls (`F`, `dF`, `F_dF`,
+        `mu_d2F`: the "_list" entry points) then evaluate shard by shard, each GPU landing its slice of the caller's arrays over its
+        own PCIe link.  Same arrays, bit for bit, as on one device."""
+        if rows != "stacked":
+            raise NotImplementedError("several unitary integrators: stacked rows")
         self._init_ring(result_ring)
         self.integrators = list(integrators)
         self.traj = traj
         self.eval_hessian = eval_hessian
+        self.devices = None if devices is None else [int(x) for x in devices]
+        if self.devices is not None:
+            if not self.devices:
+                raise ValueError("devices must name at least one device")
+            device = self.devices[0]
         self.device = device
-        self.devices = None
         groups = split_groups(integrators)
         own = []
         for g in groups:
@@ -582,7 +590,11 @@ class ComposedQuantumDynamics(QuantumDynamics):
                          hess_tail_zeros=(hess - hess_own) if (hess and gi == len(groups) - 1) else 0)
             desc, keep = make_desc(g, traj, device=device, kernel=kernel, t_range=t_range, placement=place)
             h = C.c_void_p()
-            _lib.check(_lib.lib.qc_create(C.byref(desc), C.byref(h)))
+            if self.devices is None:
+                _lib.check(_lib.lib.qc_create(C.byref(desc), C.byref(h)))
+            else:
+                ids = (C.c_int32 * len(self.devices))(*self.devices)
+                _lib.check(_lib.lib.qc_create_multi(C.byref(desc), len(self.devices), ids, C.byref(h)))
             dims = _lib.qc_dims_t()
             _lib.check(_lib.lib.qc_dims(h, C.byref(dims)), h)
             self._parts.append((desc, keep, h, dims))
@@ -602,6 +614,15 @@ class ComposedQuantumDynamics(QuantumDynamics):
         self._h = None
         self._structs = None
         self._dev = torch.device("cuda", device)
+
+    @property
+    def n_shards(self) -> int:
+        return int(_lib.lib.qc_multi_count(self._parts[0][2]))
+
+    def shard_info(self, i: int) -> Tuple[int, int, int]:
+        dev, t0, t1 = C.c_int32(), C.c_int64(), C.c_int64()
+        _lib.check(_lib.lib.qc_multi_shard_info(self._parts[0][2], i, C.byref(dev), C.byref(t0), C.byref(t1)), self._parts[0][2])
+        return dev.value, t0.value, t1.value
 
     def close(self):
         for _, _, h, _ in getattr(self, "_parts", []):
@@ -629,7 +650,7 @@ class ComposedQuantumDynamics(QuantumDynamics):
         return cat(jr_l), cat(jc_l), cat(hr_l), cat(hc_l)
 
     def F_dF_device(self, Z: torch.Tensor, F: Optional[torch.Tensor], J: Optional[torch.Tensor], stream=None) -> None:
-        st = stream if stream is not None else torch.cuda.current_stream(self.device)
+        st = stream if stream is not None else torch.cuda.current_stream(self.device)     # (a list over several devices: _dev_ptr refuses)
         # one launch for all systems when their shapes allow it (qc_eval_F_jac_dev_multi falls back to one per handle)
         _lib.check(_lib.lib.qc_eval_F_jac_dev_multi(
             self._handles, len(self._parts), self._dev_ptr(Z, self.dims.Z_len, "Z"), self._dev_ptr(F, self.dims.F_len, "F"),

@@ -203,7 +203,8 @@ def test_deadline_turns_a_lost_copy_into_an_error(qc):
         "qc = g.load_package()\n"
         "inp = qc.config_inputs(3, T=1000)\n"
         "dyn = qc.QuantumDynamics(inp.integrators, inp.traj)\n"
-        "for k in range(3):\n"                      # (the first call spends milliseconds allocating: its copy has landed before anybody waits)
+        "for k in range(10):\n"                     # (the first calls spend milliseconds allocating pinned blocks, and a call whose thread the host's
+                                                    #  CPU quota puts to sleep behind the launch finds its copy landed: no wait, no deadline -- seen once in ten runs)
         "    try:\n"
         "        dyn.F_dF(inp.traj.datavec)\n"
         "        print('NO ERROR')\n"

@@ -456,6 +456,7 @@ def test_full_size_hessian_properties(qc, oracle, cfg, T, align):
     the Jacobian, an oracle window in the middle of the trajectory."""
     inp = qc.config_inputs(cfg, T=T)
     prob = problem_from_inputs(inp)
+    prob.hess_align = align or 1
     Z = inp.traj.datavec
     dyn = qc.QuantumDynamics(inp.integrators, inp.traj, hess_align=align)
     rng = np.random.default_rng(11)

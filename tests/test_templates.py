@@ -313,3 +313,109 @@ def test_rollouts_of_a_list_are_per_member(qc, oracle):
         np.testing.assert_array_equal(dyn.rollout(ds.traj.datavec, i0, part=k), own.rollout(p.traj.datavec, i0))
         own.close()
     dyn.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["sampling3", "directsum", "sampling_cfg5", "sampling_order6"])
+def test_integrator_lists_over_several_devices_are_bit_identical(qc, oracle, kind):
+    """The integrator lists of the sampling / direct-sum templates on a multi-device evaluator (missing 3): every member
+    created over the same device list (qc_create_multi on a composed descriptor), the "_list" entry points evaluating shard by shard.
+    devices = [0, 0, 0] on the one-GPU box: the same arrays as one device, bit for bit, whatever kernels serve the members
+    (reference unitary_sampling_problem.jl:134-155, unitary_direct_sum_problem.jl:127-130)."""
+    rng = np.random.default_rng(3)
+    if kind == "sampling3":          # three 3-qubit systems, shared controls: the batched 2N = 16 launch on every shard
+        base = qc.multi_qubit_system(3)
+        systems = [qc.QuantumSystem(base.H_drift * (1.0 + 0.1 * k), base.H_drives) for k in range(3)]
+        inp = qc.unitary_sampling_inputs(systems, qc.GATES["TOFFOLI"], 41)
+    elif kind == "sampling_cfg5":    # two 4-qubit systems: the sparse-drive 2N = 32 kernels, one launch per member
+        base = qc.multi_qubit_system(4)
+        systems = [qc.QuantumSystem(base.H_drift * (1.0 + 0.2 * k), base.H_drives) for k in range(2)]
+        inp = qc.unitary_sampling_inputs(systems, qc.GATES["QFT16"], 11)
+    elif kind == "sampling_order6":  # any-order kernels
+        base = qc.multi_qubit_system(2)
+        systems = [qc.QuantumSystem(base.H_drift * (1.0 + 0.3 * k), base.H_drives) for k in range(2)]
+        inp = qc.unitary_sampling_inputs(systems, qc.GATES["CNOT"], 14, pade_order=6)
+    else:
+        p1, p2 = direct_sum_members(qc, True, T=23)
+        inp = qc.unitary_direct_sum_inputs([p1, p2])
+    Z = inp.traj.datavec
+    one = qc.QuantumDynamics(inp.integrators, inp.traj)
+    many = qc.QuantumDynamics(inp.integrators, inp.traj, devices=[0, 0, 0])
+    assert isinstance(many, qc.ComposedQuantumDynamics) and many.n_shards == 3
+    n_int = inp.traj.T - 1
+    chunk = -(-n_int // 3)
+    assert [many.shard_info(i)[1:] for i in range(3)] == [(min(i * chunk, n_int), min((i + 1) * chunk, n_int)) for i in range(3)]
+    for a, b in zip(one.dF_structure + one.mu_d2F_structure, many.dF_structure + many.mu_d2F_structure):
+        np.testing.assert_array_equal(a, b)
+    mu = rng.standard_normal(int(one.dims.n_rows))
+    F1, J1 = one.F_dF(Z, fresh=True)
+    H1 = one.mu_d2F(Z, mu, fresh=True)
+    ref = composed_oracle(inp)
+    close(F1, ref.F(Z), kind + " F")
+    close(J1, ref.dF(Z), kind + " dF")
+    close(H1, ref.mu_d2F(Z, mu), kind + " mu_d2F", atol=1e-11)
+    for rep in range(2):             # (the second round runs on warm staging: pinned ring blocks re-armed, parameter blocks cached)
+        Fm, Jm = many.F_dF(Z, fresh=True)
+        np.testing.assert_array_equal(Fm, F1)
+        np.testing.assert_array_equal(Jm, J1)
+        np.testing.assert_array_equal(many.mu_d2F(Z, mu, fresh=True), H1)
+        np.testing.assert_array_equal(many.F(Z, fresh=True), F1)
+        np.testing.assert_array_equal(many.dF(Z, fresh=True), J1)
+    # Ipopt's new_x = false on the sharded list: every shard reuses the knots it has
+    g0 = many.knot_generation()
+    many.F(Z)
+    assert many.knot_generation() == g0 + 1
+    many.set_new_x(False)
+    np.testing.assert_array_equal(many.dF(np.full_like(Z, np.nan), fresh=True), J1)
+    np.testing.assert_array_equal(many.mu_d2F(np.full_like(Z, np.nan), mu, fresh=True), H1)
+    assert many.knot_generation() == g0 + 1
+    many.set_new_x(True)
+    # mixing single- and multi-device members is refused with a message
+    L = qc._lib
+    import ctypes as C
+    mixed = (C.c_void_p * 2)(many._parts[0][2], one._parts[1][2])
+    assert L.lib.qc_eval_F_list(mixed, 2, L.dptr(Z), L.dptr(np.zeros(int(one.dims.F_len)))) == L.QC_ERR_INVALID
+    with pytest.raises(ValueError):
+        import torch
+        many.F_dF_device(torch.from_numpy(Z).cuda(), None, torch.empty(int(one.dims.jac_nnz), dtype=torch.float64, device="cuda"))
+    many.close()
+    one.close()
+
+
+@pytest.mark.gpu
+def test_a_shorter_list_never_sees_the_longer_lists_values(qc, oracle):
+    """Rows and values that no handle of a list owns are delivered as 0 -- also when the handle that leads the list led ANOTHER list just
+    before (the zeroed-once device blocks change hands: ADVICE round 4), on the plain-copy path (F alone, mu_d2F) as on the watched one."""
+    import ctypes as C
+    L = qc._lib
+    p1, p2 = direct_sum_members(qc, True, T=9)
+    ds = qc.unitary_direct_sum_inputs([p1, p2])
+    dyn = qc.QuantumDynamics(ds.integrators, ds.traj)
+    hs, n = dyn._handles, len(dyn._parts)
+    Z = ds.traj.datavec
+    n_int = ds.traj.T - 1
+    F, J = dyn.F_dF(Z, fresh=True)
+    mu = np.random.default_rng(1).standard_normal(int(dyn.dims.n_rows))
+    H = dyn.mu_d2F(Z, mu, fresh=True)
+    Fa = dyn.F(Z, fresh=True)
+    np.testing.assert_array_equal(Fa, F)
+    own_rows, own_vals, own_h = (int(dyn._parts[0][3].ddim), int(dyn._parts[0][3].jac_nnz_interval), int(dyn._parts[0][3].hess_nnz_interval))
+    for rep in range(2):
+        F1, J1, H1 = np.full_like(F, 7.0), np.full_like(J, 7.0), np.full_like(H, 7.0)
+        assert L.lib.qc_eval_F_list(hs, 1, L.dptr(Z), L.dptr(F1)) == L.QC_OK                    # plain-copy path
+        assert L.lib.qc_eval_hess_list(hs, 1, L.dptr(Z), L.dptr(mu), L.dptr(H1)) == L.QC_OK
+        assert L.lib.qc_eval_jac_list(hs, 1, L.dptr(Z), L.dptr(J1)) == L.QC_OK                  # watched path
+        for what, got, full, own in (("F", F1, F, own_rows), ("dF", J1, J, own_vals), ("mu_d2F", H1, H, own_h)):
+            g2, f2 = got.reshape(n_int, -1), full.reshape(n_int, -1)
+            np.testing.assert_array_equal(g2[:, :own], f2[:, :own], err_msg=what)
+            # what the list does not own: zeros (rows; values on the plain-copy path) or left as the caller had it (values on the
+            # watched path, which writes the members' segments only) -- never the longer list's numbers
+            rest = g2[:, own:]
+            assert not rest.any() or (what == "dF" and (rest == 7.0).all()), what
+        F2, J2 = np.zeros_like(F), np.zeros_like(J)                                              # ... and the whole list again
+        assert L.lib.qc_eval_F_jac_list(hs, n, L.dptr(Z), L.dptr(F2), L.dptr(J2)) == L.QC_OK
+        np.testing.assert_array_equal(F2, F)
+        np.testing.assert_array_equal(J2, J)
+        np.testing.assert_array_equal(dyn.mu_d2F(Z, mu, fresh=True), H)
+        np.testing.assert_array_equal(dyn.F(Z, fresh=True), F)
+    dyn.close()
