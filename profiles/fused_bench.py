@@ -15,7 +15,7 @@ qc = g.load_package()
 cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 inp = qc.config_inputs(cfg, T=T or None)
-dyn = qc.QuantumDynamics(inp.integrators, inp.traj)
+dyn = qc.QuantumDynamics(inp.integrators, inp.traj, hess_align=int(os.environ.get("QC_BENCH_HESS_ALIGN", "16")))   # the device consumers' layout
 d = dyn.dims
 dev = torch.device("cuda", 0)
 rng = np.random.default_rng(0)

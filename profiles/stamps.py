@@ -15,7 +15,7 @@ import __graft_entry__ as g
 qc = g.load_package()
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 inp = qc.config_inputs(3, T=T)
-dyn = qc.QuantumDynamics(inp.integrators, inp.traj)
+dyn = qc.QuantumDynamics(inp.integrators, inp.traj, hess_align=16)
 Z = torch.from_numpy(inp.traj.datavec).cuda()
 Fs = [torch.empty(dyn.dims.F_len, dtype=torch.float64, device="cuda") for _ in range(20)]
 Js = [torch.empty(dyn.dims.jac_nnz, dtype=torch.float64, device="cuda") for _ in range(20)]

@@ -15,7 +15,7 @@ import __graft_entry__ as g
 qc = g.load_package()
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 inp = qc.config_inputs(3, T=T)
-dyn = qc.QuantumDynamics(inp.integrators, inp.traj)
+dyn = qc.QuantumDynamics(inp.integrators, inp.traj, hess_align=int(os.environ.get("QC_BENCH_HESS_ALIGN", "16")))
 Z = torch.from_numpy(inp.traj.datavec).cuda()
 mu = torch.from_numpy(np.random.default_rng(0).standard_normal(int(dyn.dims.n_rows))).cuda()
 nb = 16

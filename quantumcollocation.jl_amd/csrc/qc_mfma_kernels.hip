@@ -548,7 +548,8 @@ __global__ __launch_bounds__(JAC ? kThreads : 64, 2) void qc_mfma16_pade4_kernel
                 QC_STAMP_CYCLES(14);
             }
             if constexpr (DIAG) qc_ts_[15] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | (1ull << 40);   // HW_REG_HW_ID
-            QC_STAMP_FLUSH(P, b, lane, 4, 15);
+            QC_STAMP_FLUSH(P, b, lane, 4, 8);        // (slots 9 - 11 are the copy wave's: kernel entry, arguments read, HW_ID)
+            QC_STAMP_FLUSH(P, b, lane, 12, 15);
         }
         if constexpr (JAC && !ONCE) __syncthreads();   // pairs with the copy wave's end-of-interval barrier
     } while (!ONCE && (vb += gridDim.x) < n_wg);
