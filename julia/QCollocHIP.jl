@@ -352,12 +352,12 @@ function QuantumDynamics(integrators::AbstractVector, traj; system=nothing, stat
             push!(parts[end].derivative_pairs, pairs[k])
         end
     end
-    allowed = (:device, :eval_hessian, :padded, :result_ring)
+    allowed = (:device, :devices, :eval_hessian, :padded, :result_ring)
     return dynamics_list(parts, traj; (k => v for (k, v) in kwargs if k in allowed)...)
 end
 
 """
-    dynamics_list(parts, traj; device=0, eval_hessian=true, padded=false, result_ring=0)
+    dynamics_list(parts, traj; device=0, devices=nothing, eval_hessian=true, padded=false, result_ring=0)
 
 The integrator lists with SEVERAL state integrators -- `UnitarySamplingProblem` ([U_1 .. U_K, D, D], shared controls:
 unitary_sampling_problem.jl:134-155), `UnitaryDirectSumProblem` ([U_1, D, D, U_2, D, D, ...], own controls per member:
@@ -370,10 +370,15 @@ each with the derivative integrators that FOLLOW it in the list:
 (only `system` and `state_name` are required).  One composed handle per part; rows and values come out interval-major, in integrator
 order inside an interval (the order `QuantumDynamics` stacks them in).  The evaluations go through `qc_eval_*_list`: one upload
 of `Z⃗`, one batched launch where the parts' shapes allow it, results copied straight into the result vectors.
+`devices = 0:7`: every part is created over the same device list (`qc_create_multi` on its composed descriptor), so shard s of every part
+covers the same intervals on the same GPU, and the list is evaluated shard by shard -- each GPU lands its slice of the result vectors
+over its own PCIe link (a K-system robust-control problem is the workload that wants eight GPUs).
 """
-function dynamics_list(parts, traj; device::Int=0, eval_hessian::Bool=true, padded::Bool=false, result_ring::Int=0)
+function dynamics_list(parts, traj; device::Int=0, devices=nothing, eval_hessian::Bool=true, padded::Bool=false, result_ring::Int=0)
     (result_ring == 0 || result_ring >= 3) || error("result_ring must be 0 (fresh vectors) or at least 3")
     length(parts) >= 1 || error("dynamics_list: no state integrators")
+    devs = isnothing(devices) ? Int32[] : Int32.(collect(devices))
+    isempty(devs) || (device = Int(devs[1]))
     off(name) = first(traj.components[name]) - 1
     free_time = traj.timestep isa Symbol
     opt(p, k, default) = haskey(p, k) ? p[k] : default
@@ -411,8 +416,13 @@ function dynamics_list(parts, traj; device::Int=0, eval_hessian::Bool=true, padd
     for (i, (p, x)) in enumerate(zip(parts, own))
         tail = (with_hess && i == length(parts)) ? hess - hess_own : 0
         h = Ref{Ptr{Cvoid}}(C_NULL)
-        GC.@preserve keep check(ccall((:qc_create, LIB[]), Cint, (Ref{QCDesc}, Ref{Ptr{Cvoid}}),
-                                      Ref(desc_of(p, (rows, ro, jac, jo, with_hess ? hess : 0, with_hess ? ho : 0, tail))), h))
+        place = (rows, ro, jac, jo, with_hess ? hess : 0, with_hess ? ho : 0, tail)
+        if isempty(devs)
+            GC.@preserve keep check(ccall((:qc_create, LIB[]), Cint, (Ref{QCDesc}, Ref{Ptr{Cvoid}}), Ref(desc_of(p, place)), h))
+        else
+            GC.@preserve keep devs check(ccall((:qc_create_multi, LIB[]), Cint, (Ref{QCDesc}, Int32, Ptr{Int32}, Ref{Ptr{Cvoid}}),
+                                               Ref(desc_of(p, place)), length(devs), devs, h))
+        end
         push!(handles, h[])
         ro += x.ddim; jo += x.jac_nnz_interval; ho += x.hess_nnz_interval
     end
