@@ -321,7 +321,7 @@ function QuantumDynamics(integrators::AbstractVector, traj; system=nothing, stat
         end
         (sname, cname, expo, ord, gens)
     end
-    pairs = if !isnothing(derivative_pairs)
+    dpairs = if !isnothing(derivative_pairs)
         collect(derivative_pairs)
     else
         map(derivs) do D
@@ -335,10 +335,13 @@ function QuantumDynamics(integrators::AbstractVector, traj; system=nothing, stat
             end
         end
     end
+    any(I -> occursin("DensityOperator", type_name(I)), states) &&
+        error("QCollocHIP.QuantumDynamics: density-operator integrators need the Lindblad generators: call `dynamics(...; n_kets = 1, generators = ...)`")
+    kets_of(I) = occursin("QuantumState", type_name(I)) ? 1 : 0          # a QuantumState...Integrator propagates one ket (2N x 1 iso state)
     if length(states) == 1
         sname, cname, expo, ord, gens = part_of(states[1])
         return dynamics(integrators, traj, nothing; state_name=sname, control_name=cname, pade_order=expo ? 4 : ord, exponential=expo,
-                        derivative_pairs=pairs, generators=gens, kwargs...)
+                        derivative_pairs=dpairs, generators=gens, n_kets=kets_of(states[1]), kwargs...)
     end
     # several state integrators: each with the derivative integrators that follow it in the list (the order QuantumDynamics stacks rows in)
     parts = []
@@ -346,10 +349,10 @@ function QuantumDynamics(integrators::AbstractVector, traj; system=nothing, stat
         if is_state_integrator(I)
             sname, cname, expo, ord, gens = part_of(I)
             push!(parts, (system=(G_drift=gens[1], G_drives=gens[2], levels=size(gens[1], 1) ÷ 2), state_name=sname, control_name=cname,
-                          derivative_pairs=Tuple{Symbol,Symbol}[], pade_order=expo ? 4 : ord, exponential=expo, n_kets=0))
+                          derivative_pairs=Tuple{Symbol,Symbol}[], pade_order=expo ? 4 : ord, exponential=expo, n_kets=kets_of(I)))
         else
             k = count(is_derivative_integrator, integrators[1:i])
-            push!(parts[end].derivative_pairs, pairs[k])
+            push!(parts[end].derivative_pairs, dpairs[k])
         end
     end
     allowed = (:device, :devices, :eval_hessian, :padded, :result_ring)
