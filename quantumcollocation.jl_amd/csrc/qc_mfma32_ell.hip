@@ -419,8 +419,11 @@ __global__ __launch_bounds__(kEThreads, 4) void qc_mfma32_ell_kernel(const doubl
         }
     };
     // Made right in front of their use, as straight-line code (the reads of all pairs batch up: three LDS round trips in all).  Making
-    // them early -- behind barrier A, in the shadow of the state's round trip -- was measured: the registers they go to are the
-    // destinations of loads still in flight (the late group), so the wave waits for those first, and the state is published 1.1 us later.
+    // them early -- behind barrier A, in the shadow of the state's round trip -- was measured twice: as it stands the registers they go
+    // to are the destinations of loads still in flight (the late group), so the wave waits for those first and the state is published
+    // 1.1 us later; with those registers kept out of the allocator's hands up to the state flags the loader waves of the SECOND workgroup
+    // of the compute unit, which run in the issue slots the first one's waves leave, finish their constants only at 6.2 us and their drive
+    // as late as before: 13.5 - 13.6 against 13.6 - 13.8 us, not worth 27 registers (profiles/NOTES.md, round 5).
 
     if (JAC && cw < 0) {
         if (f_only) return;
@@ -571,24 +574,15 @@ __global__ __launch_bounds__(kEThreads, 4) void qc_mfma32_ell_kernel(const doubl
                     TV[0] = v0; TV[1] = v1; TY[0] = y0; TY[1] = y1;
                 }
                 if (t == 0) QC_STAMP(P, b, lane, 4);
-                // mu_d2F alone (registers to spare): what needs neither E nor the products -- Y_k^T, gathered in the store layout -- is
-                // requested while the products run (LDS reads issue beside the wave's own MFMAs), and the (a_k, h) partial, which only
-                // the closing reduction needs, follows the drive's stores instead of standing in front of them
-                constexpr bool kStoresFirst = HESS && !JAC;
-                v4d ytE[2];
-                if constexpr (kStoresFirst) {
-#pragma unroll
-                    for (int J = 0; J < 2; ++J) ytE[J] = gather_rows_store<R>(tw, tc, Mp, J, g, j);
-                }
                 flag_wait(flags, FL_GD, 1);
                 if constexpr (HESS) flag_wait(flags, FL_E, 1);
                 if (t == 0) QC_STAMP(P, b, lane, 5);
-                auto partial_ah = [&]() {      // (a_k, h), per lane: the last use of the gathered operand tiles
+                if constexpr (HESS) {     // (a_k, h), per lane: the last use of the gathered operand tiles.  (Behind the drive's stores
+                                          // instead, with Y_k^T gathered while the products run: 0.1 us for mu_d2F alone, 48 registers.)
                     if (ft)
                         pv[t] = -(dot4(Yk[0], plain_ld(Wp, 0, g, j)) + dot4(Yk[1], plain_ld(Wp, 1, g, j))) -
                                 c2h2 * (dot4(plain_ld(Ep, 0, g, j), Vk[0]) + dot4(plain_ld(Ep, 1, g, j), Vk[1]));
-                };
-                if constexpr (HESS && !kStoresFirst) partial_ah();
+                }
                 if constexpr (JAC) {      // d/da_k = -c1 h G_k S + c2 h^2 (G_k (G D) + G (G_k D)), transposed for the store
                     double* __restrict__ pa = Jb + P.jo_a + (size_t)k * 512;
                     v4d yT[2];
@@ -603,8 +597,7 @@ __global__ __launch_bounds__(kEThreads, 4) void qc_mfma32_ell_kernel(const doubl
                     v4d lo[2], hi[2];
 #pragma unroll
                     for (int J = 0; J < 2; ++J) {
-                        v4d yt;                                                         // Y_k^T
-                        if constexpr (kStoresFirst) yt = ytE[J]; else yt = gather_rows_store<R>(tw, tc, Mp, J, g, j);
+                        const v4d yt = gather_rows_store<R>(tw, tc, Mp, J, g, j);       // Y_k^T
                         const v4d get = gather_rows_store<R>(tw, tc, Ep, J, g, j);      // (G_k E)^T
                         const v4d lin = hc1 * yt, qd = hc2 * (get + TY[J]);
                         lo[J] = lin - qd;
@@ -613,7 +606,6 @@ __global__ __launch_bounds__(kEThreads, 4) void qc_mfma32_ell_kernel(const doubl
                     store_T32_columns(pUa, merge_rows32(lo[0], lo[1]), 0, g, j);        // whole 256-byte columns per piece
                     store_T32_columns(paU, merge_rows32(hi[0], hi[1]), 0, g, j);
                 }
-                if constexpr (kStoresFirst) partial_ah();
                 if (t == 0) QC_STAMP(P, b, lane, 6);
             }
         }
