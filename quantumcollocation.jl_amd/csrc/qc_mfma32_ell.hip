@@ -328,6 +328,13 @@ __global__ __launch_bounds__(kEThreads, 4) void qc_mfma32_ell_kernel(const doubl
     const bool ld_u = cw == kCW - 2 || cw == kCW - 1;                // U_t, U_t+1 tiles I = cw - (kCW - 2)
     QC_STAMP_DECL;
     QC_STAMP(P, b, lane, 0);
+    // mu_d2F alone -- issue priority by phase (round 5).  Two workgroups share a compute unit and the second runs in the issue slots
+    // the first one's (older) waves leave (profiles/NOTES.md: it trails by 2.5 - 3 us at every stage).  Up to its drive's stores a wave
+    // runs at priority 1, in its tail (pair sums, reductions, scalar stores: nothing the launch waits for) at 0: the second workgroup's
+    // products and epilogue then outrank the first one's tail, its blocks leave 0.6 us earlier (8.1 -> 7.5 us) and the launch takes 13.1
+    // instead of 13.7 us.  (Priorities by the workgroup's place alone changed nothing; a wave stepping down once its products are
+    // issued, or the producers of G D / E stepping up, neither.)
+    if constexpr (HESS && !JAC) __builtin_amdgcn_s_setprio(1);
 
     // ---- phase 0: G (every wave its half tile), the tables, then the state (requested last: G must not wait for it) -----------
     const double h = ft ? z0[hot_off_dt] : opaque_scalar(P.dt_fixed);
@@ -609,6 +616,7 @@ __global__ __launch_bounds__(kEThreads, 4) void qc_mfma32_ell_kernel(const doubl
                 if (t == 0) QC_STAMP(P, b, lane, 6);
             }
         }
+        if constexpr (HESS && !JAC) __builtin_amdgcn_s_setprio(0);      // the tail (see the kernel's entry)
         if constexpr (HESS) {     // the (a_k, h) of this wave's drives -- and, where they have not been summed early, its pair sums: one batched reduction
             if constexpr (kEarlyPairs) {
                 if (ft) {
@@ -660,7 +668,12 @@ __global__ __launch_bounds__(kEThreads, 4) void qc_mfma32_ell_kernel(const doubl
             if (Fb) store_T32_columns(Fb, merge_rows32(res[0], res[1]), 0, g, j);
             if (ft && !f_only) store_T32_columns(Jb + P.jo_h, merge_rows32(dh[0], dh[1]), 0, g, j);
         }
-        if (HESS && ft && cw == kCW - 4) {    // (U_t, h)^T and (h, U_t+1)^T: c1 E -+ 2 c2 h G E
+        // mu_d2F alone: on the wave that shares its SIMD with a loader wave and carries no shared product (waves w and w + 4 share a
+        // SIMD: E sits on wave 4 beside wave 0, Q on 5 beside 1, G D on 6 beside 2) -- 48 MFMAs per SIMD everywhere instead of 64 / 32:
+        // 12.7 instead of 13.2 us (on wave 1, beside Q: no gain).  The one-call form keeps it with E's producer.
+        constexpr int kUhWave = JAC ? kCW - 4 : 3;
+        if (HESS && ft && cw == kUhWave) {    // (U_t, h)^T and (h, U_t+1)^T: c1 E -+ 2 c2 h G E
+            if (kUhWave != kCW - 4) flag_wait(flags, FL_E, 1);
             const v4d e0 = plain_ld(Ep, 0, g, j), e1 = plain_ld(Ep, 1, g, j);
             v4d lo[2], hi[2];
 #pragma unroll
