@@ -581,15 +581,27 @@ __global__ __launch_bounds__(kEThreads, 4) void qc_mfma32_ell_kernel(const doubl
                     TV[0] = v0; TV[1] = v1; TY[0] = y0; TY[1] = y1;
                 }
                 if (t == 0) QC_STAMP(P, b, lane, 4);
+                // mu_d2F alone with one entry per row: the drive's first store is what the launch follows (HBM is busy from it to the end), and
+                // the epilogue in front of it was nine LDS round trips one after the other (the compiler keeps the register count low and
+                // reuses the destinations).  Here: the two store-layout rows of the drive are fetched while the products run, the eight
+                // gathered values per lane go out as one batch behind the flags, the blocks are stored, and the (a_k, h) partial -- which only
+                // the closing reduction needs -- comes last.  Same operations on the same values as the other order: the same bits.
+                constexpr bool kStoresFirst = HESS && !JAC && R == 1;
+                double tws[2] = {0.0, 0.0};
+                int tcs[2] = {0, 0};
+                if constexpr (kStoresFirst) {
+#pragma unroll
+                    for (int J = 0; J < 2; ++J) { tws[J] = tw[16 * J + j]; tcs[J] = tc[16 * J + j]; }
+                }
                 flag_wait(flags, FL_GD, 1);
                 if constexpr (HESS) flag_wait(flags, FL_E, 1);
                 if (t == 0) QC_STAMP(P, b, lane, 5);
-                if constexpr (HESS) {     // (a_k, h), per lane: the last use of the gathered operand tiles.  (Behind the drive's stores
-                                          // instead, with Y_k^T gathered while the products run: 0.1 us for mu_d2F alone, 48 registers.)
+                auto partial_ah = [&]() {     // (a_k, h), per lane: the last use of the gathered operand tiles
                     if (ft)
                         pv[t] = -(dot4(Yk[0], plain_ld(Wp, 0, g, j)) + dot4(Yk[1], plain_ld(Wp, 1, g, j))) -
                                 c2h2 * (dot4(plain_ld(Ep, 0, g, j), Vk[0]) + dot4(plain_ld(Ep, 1, g, j), Vk[1]));
-                }
+                };
+                if constexpr (HESS && !kStoresFirst) partial_ah();
                 if constexpr (JAC) {      // d/da_k = -c1 h G_k S + c2 h^2 (G_k (G D) + G (G_k D)), transposed for the store
                     double* __restrict__ pa = Jb + P.jo_a + (size_t)k * 512;
                     v4d yT[2];
@@ -602,17 +614,36 @@ __global__ __launch_bounds__(kEThreads, 4) void qc_mfma32_ell_kernel(const doubl
                     double* __restrict__ pUa = Hb + P.ho_Ua + (size_t)k * 512;
                     double* __restrict__ paU = Hb + P.ho_aU + (size_t)k * 512;
                     v4d lo[2], hi[2];
+                    if constexpr (kStoresFirst) {
+                        v4d ms[2], es[2];         // M and E at the drive's columns, the lane's rows: every read requested before the first use
 #pragma unroll
-                    for (int J = 0; J < 2; ++J) {
-                        const v4d yt = gather_rows_store<R>(tw, tc, Mp, J, g, j);       // Y_k^T
-                        const v4d get = gather_rows_store<R>(tw, tc, Ep, J, g, j);      // (G_k E)^T
-                        const v4d lin = hc1 * yt, qd = hc2 * (get + TY[J]);
-                        lo[J] = lin - qd;
-                        hi[J] = lin + qd;
+                        for (int J = 0; J < 2; ++J) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) { ms[J][r] = Mp[tcs[J] + 4 * r + g]; es[J][r] = Ep[tcs[J] + 4 * r + g]; }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int J = 0; J < 2; ++J) {
+                            const v4d yt = tws[J] * ms[J];                                  // Y_k^T      (gather_rows_store<1>'s products)
+                            const v4d get = tws[J] * es[J];                                 // (G_k E)^T
+                            const v4d lin = hc1 * yt, qd = hc2 * (get + TY[J]);
+                            lo[J] = lin - qd;
+                            hi[J] = lin + qd;
+                        }
+                    } else {
+#pragma unroll
+                        for (int J = 0; J < 2; ++J) {
+                            const v4d yt = gather_rows_store<R>(tw, tc, Mp, J, g, j);       // Y_k^T
+                            const v4d get = gather_rows_store<R>(tw, tc, Ep, J, g, j);      // (G_k E)^T
+                            const v4d lin = hc1 * yt, qd = hc2 * (get + TY[J]);
+                            lo[J] = lin - qd;
+                            hi[J] = lin + qd;
+                        }
                     }
                     store_T32_columns(pUa, merge_rows32(lo[0], lo[1]), 0, g, j);        // whole 256-byte columns per piece
                     store_T32_columns(paU, merge_rows32(hi[0], hi[1]), 0, g, j);
                 }
+                if constexpr (kStoresFirst) partial_ah();
                 if (t == 0) QC_STAMP(P, b, lane, 6);
             }
         }
