@@ -339,8 +339,9 @@ static void interval_hess(const qco_problem* P, const qco_ws* w, const double* z
     memset(w->Gp, 0, n2 * 8);
     for (int i = 0; i < n; ++i) w->Gp[(size_t)i * n + i] = 1.0;
     for (int k = 1; k <= p; ++k) mm(w->Gp + (size_t)k * n2, w->Gp + (size_t)(k - 1) * n2, w->G, n, n, n);
-    int o_Ua = 0, o_aU = s * m, o_aa = 2 * s * m, o_ah = o_aa + m * (m + 1) / 2;
-    int o_Uh = o_ah + (ft ? m : 0), o_hU = o_Uh + (ft ? s : 0), o_hh = o_hU + (ft ? s : 0), o_d = o_hh + (ft ? 1 : 0);
+    /* hess_structure_local's order: (U, a) | (a, U) | (U, h) | (h, U) | (a, a) | (a, h) | (h, h) | (dx, h) */
+    int o_Ua = 0, o_aU = s * m, o_Uh = 2 * s * m, o_hU = o_Uh + (ft ? s : 0), o_aa = o_hU + (ft ? s : 0);
+    int o_ah = o_aa + m * (m + 1) / 2, o_hh = o_ah + (ft ? m : 0), o_d = o_hh + (ft ? 1 : 0);
     for (int j = 0; j < m; ++j) {
         const double* Gj = P->G_drives + (size_t)j * n2;
         /* (U, a_j): vec(dB^T M), -vec(dF^T M) */

@@ -419,16 +419,17 @@ def hess_structure_local(prob: Problem) -> List[Tuple[int, int]]:
     for j in range(m):                       # 2. (a_j, U_{t+1})
         for i in range(s):
             up(prob.off_a + j, zd + prob.off_U + i)
-    for j in range(m):                       # 3. (a_i, a_j), i <= j
+    if prob.free_time:
+        for i in range(s):                   # 3. (U_t, h)
+            up(prob.off_U + i, prob.off_dt)
+        for i in range(s):                   # 4. (h, U_{t+1})
+            up(prob.off_dt, zd + prob.off_U + i)
+    for j in range(m):                       # 5. (a_i, a_j), i <= j
         for i in range(j + 1):
             up(prob.off_a + i, prob.off_a + j)
     if prob.free_time:
-        for j in range(m):                   # 4. (a_j, h)
+        for j in range(m):                   # 6. (a_j, h)
             up(prob.off_a + j, prob.off_dt)
-        for i in range(s):                   # 5. (U_t, h)
-            up(prob.off_U + i, prob.off_dt)
-        for i in range(s):                   # 6. (h, U_{t+1})
-            up(prob.off_dt, zd + prob.off_U + i)
         up(prob.off_dt, prob.off_dt)         # 7. (h, h)
         for d in prob.derivs:                # 8. (dx_i, h)
             for i in range(d.dim):

@@ -5,8 +5,8 @@
 set -e
 cd "$(dirname "$0")/../quantumcollocation.jl_amd/csrc"
 name=$1; src=$2; flags=$3
-obj=${src%.hip}
+obj=${src%.*}
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I../../include -Wall -Wno-unused-function $flags -c $src -o /tmp/${obj}.${name}.o
-objs=$(ls *.o | grep -v "^${obj}.o$" | tr '\n' ' ')
+objs=$(ls *.o | grep -v "^${obj}\.o$" | tr '\n' ' ')
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o libqcolloc_hip.${name}.so $objs /tmp/${obj}.${name}.o -ldl -lpthread
 echo built libqcolloc_hip.${name}.so

@@ -23,12 +23,23 @@ Fs = [torch.empty(dyn.dims.F_len, dtype=torch.float64, device="cuda") for _ in r
 Js = [torch.empty(dyn.dims.jac_nnz, dtype=torch.float64, device="cuda") for _ in range(nb)]
 Hs = [torch.empty(dyn.dims.hess_nnz, dtype=torch.float64, device="cuda") for _ in range(nb)]
 hess_only = len(sys.argv) > 2 and sys.argv[2] == "hess"
-for i in range(nb):
+def call(i):
     if hess_only:
         dyn.mu_d2F_device(Z, mu, Hs[i])
     else:
         dyn.F_dF_mu_d2F_device(Z, mu, Fs[i], Js[i], Hs[i])
+
+
+for i in range(3 * nb):
+    call(i % nb)
 torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for i in range(10 * nb):
+    call(i % nb)
+e1.record()
+torch.cuda.synchronize()
+l2l = e0.elapsed_time(e1) * 1e3 / (10 * nb)
 n = dyn.dims.n_intervals
 out = np.zeros(n * 16, dtype=np.uint64)
 qc._lib.check(qc._lib.lib.qc_debug_read_stamps(dyn._h, out.ctypes.data_as(C.POINTER(C.c_uint64)), out.size), dyn._h)
@@ -43,8 +54,11 @@ if hess_only:   # qc_mfma_hess2.hip: wave 0 does the one-wave kernel's work in a
              4: "wave 0: T_k parked, barrier passed", 5: "wave 0: stage B, first part issued", 6: "wave 0: first part's blocks stored",
              7: "wave 0: every matrix block stored", 8: "wave 0: every store issued", 9: "wave 0: drained",
              10: "wave 1: entry", 11: "wave 1: released", 14: "wave 1: its drive pair's blocks stored", 12: "wave 1: (a, a) products through", 13: "wave 1: done"}
+if os.environ.get("QC_STAMP_DUMP"):      # raw stamps (row = interval index b = qc_xcd_remap(blockIdx.x, n)) for offline analysis
+    np.save(os.environ["QC_STAMP_DUMP"], st)
 t0 = st[st > 0].min()
 rel = (st - t0) * 10.0 / 1e3
+print(f"launch-to-launch of this (stamped) instantiation: {l2l:.2f} us")
 print(f"T={T}: {n} intervals; one call = {dyn.kernel_names[1] if hess_only else dyn.fused_kernel_name}; span (first entry -> last compute wave drained) = {rel[:, 9].max():.2f} us, last stamp of any wave {rel[st > 0].max():.2f} us")
 for order in (([10, 11, 14, 12, 13] if hess_only else [10, 11, 12, 13, 14, 15]), [0, 1, 2, 3, 4, 5, 6, 7, 8, 9]):
     prev = None

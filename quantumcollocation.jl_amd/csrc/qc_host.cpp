@@ -180,12 +180,15 @@ int qc_build_params(const qc_desc* d, QcParams* P, qc_dims_t* dims, std::string*
     // Hessian block offsets (analytic Hessian: Pade only)
     o = 0;
     if (P->integrator == QC_PADE) {
+        // the four kinds of matrix blocks first -- whole 128-byte lines each when the interval's block is line-aligned (hess_align = 16,
+        // 2N x N a multiple of 16) --, then the scalar blocks as ONE contiguous run that the kernels assemble and store in one piece
+        // (round 5: the scalar entries used to sit between the blocks; partly written lines at the tail of the one-call launch cost 0.7 us)
         P->ho_Ua = o;  o += s * m;
         P->ho_aU = o;  o += s * m;
-        P->ho_aa = o;  o += m * (m + 1) / 2;
-        P->ho_ah = o;  o += ft ? m : 0;
         P->ho_Uh = o;  o += ft ? s : 0;
         P->ho_hU = o;  o += ft ? s : 0;
+        P->ho_aa = o;  o += m * (m + 1) / 2;
+        P->ho_ah = o;  o += ft ? m : 0;
         P->ho_hh = o;  o += ft ? 1 : 0;
         P->ho_d = o;
         if (ft) for (int i = 0; i < P->n_deriv; ++i) o += P->ddim_i[i];
@@ -267,11 +270,13 @@ void qc_local_hess_structure(const QcParams& P, std::vector<int32_t>* R, std::ve
     auto up = [&](int i, int j) { R->push_back(std::min(i, j)); C->push_back(std::max(i, j)); };
     for (int j = 0; j < m; ++j) for (int i = 0; i < s; ++i) up(P.off_U + i, P.off_a + j);
     for (int j = 0; j < m; ++j) for (int i = 0; i < s; ++i) up(P.off_a + j, zd + P.off_U + i);
+    if (ft) {
+        for (int i = 0; i < s; ++i) up(P.off_U + i, P.off_dt);
+        for (int i = 0; i < s; ++i) up(P.off_dt, zd + P.off_U + i);
+    }
     for (int j = 0; j < m; ++j) for (int i = 0; i <= j; ++i) up(P.off_a + i, P.off_a + j);
     if (ft) {
         for (int j = 0; j < m; ++j) up(P.off_a + j, P.off_dt);
-        for (int i = 0; i < s; ++i) up(P.off_U + i, P.off_dt);
-        for (int i = 0; i < s; ++i) up(P.off_dt, zd + P.off_U + i);
         up(P.off_dt, P.off_dt);
         for (int d = 0; d < P.n_deriv; ++d) for (int i = 0; i < P.ddim_i[d]; ++i) up(P.dx_off[d] + i, P.off_dt);
     }

@@ -71,7 +71,8 @@ __global__ __launch_bounds__(kFuThreads, 2) void qc_mfma16_pade4_fused_kernel(co
     // (SACOPY: the region also carries the tiles [-N_k | -N_k+1] and Y from the copy wave to the compute wave)
     constexpr int kRedCLen = !AACOPY ? 0 : (SACOPY && (kMU / 2 + 1) * 256 > R::kAA * kFuStride ? (kMU / 2 + 1) * 256 : R::kAA * kFuStride);
     constexpr int kLdsFlag = kLdsRedC + kRedCLen;                           // one word: "the compute wave has taken the hand-over tiles"
-    constexpr int kLdsTotal = kLdsFlag + (SACOPY ? 2 : 0);
+    constexpr int kLdsScal = kLdsFlag + 2;                                  // ([0] that flag, [1] fu_scalar_run_store's counter;) the staged scalar run
+    constexpr int kLdsTotal = kLdsScal + kFuScalMax;
     static_assert(kLdsTotal * 8 <= 40960, "four workgroups per CU");
     static_assert((AACOPY ? R::kPair + 1 : R::kRows) * kFuStride <= kScrTiles * 272, "the compute wave's reduction rows alias the transpose scratch");
     __shared__ __attribute__((aligned(16))) double sm[kLdsTotal];
@@ -111,6 +112,12 @@ __global__ __launch_bounds__(kFuThreads, 2) void qc_mfma16_pade4_fused_kernel(co
     double* __restrict__ Fb = F ? F + (size_t)b * P.F_stride + P.F_off : nullptr;
     double* __restrict__ Hb = H + (size_t)b * P.H_stride + P.H_off;
     const double hc1 = h * c1, hc2 = h * h * c2;
+    // the Hessian block's scalar entries leave in one piece (fu_scalar_run_store) where the copy wave's register path serves the
+    // derivative integrators' entries; otherwise one by one, as qc_mfma16_pade4_hess_anti_kernel stores them
+    const bool hfast = ft && P.n_deriv <= 2 && P.ddim_i[0] <= 64 && P.ddim_i[1] <= 64;
+    const bool staged = hfast && fu_scalar_run_len(P) <= kFuScalMax;
+    double* __restrict__ scal = sm + kLdsScal;
+    int* __restrict__ scal_count = reinterpret_cast<int*>(sm + kLdsFlag) + 1;
 
     if (role == 1) {
         // ================= copy wave (qc_mfma16_pade4_kernel's, plus the multipliers) ======================================
@@ -128,7 +135,6 @@ __global__ __launch_bounds__(kFuThreads, 2) void qc_mfma16_pade4_fused_kernel(co
             dfv[d] = z1[P.x_off[d] + i] - z0[P.x_off[d] + i];
         }
         // multipliers of the derivative integrators' rows (the Hessian's closing entries -mu_i), with the batch as well
-        const bool hfast = ft && P.n_deriv <= 2 && P.ddim_i[0] <= 64 && P.ddim_i[1] <= 64;
         double mud[2] = {0.0, 0.0};
         if (hfast) {
 #pragma unroll
@@ -167,7 +173,10 @@ __global__ __launch_bounds__(kFuThreads, 2) void qc_mfma16_pade4_fused_kernel(co
 #pragma unroll
         for (int u = 0; u < kMU; ++u)
             if (u < m) fu_lds_put(sm + kLdsGk + u * 256, lane, gk_img[u]);
-        if constexpr (SACOPY) { if (lane == 0) reinterpret_cast<int*>(sm + kLdsFlag)[0] = 0; }
+        if (lane == 0) {
+            if constexpr (SACOPY) reinterpret_cast<int*>(sm + kLdsFlag)[0] = 0;
+            scal_count[0] = 0;
+        }
         __syncthreads();
         v4d Tq[kMU];                               // SACOPY: the stage-A tiles T_k = G_k [M | c2 h^2 D], kept for the (a, a) sums
         if constexpr (!SACOPY) {
@@ -247,13 +256,23 @@ __global__ __launch_bounds__(kFuThreads, 2) void qc_mfma16_pade4_fused_kernel(co
         }
         // the Hessian block's derivative-integrator entries d2/d(dx_i) dh = -mu_i and its alignment padding
         if (hfast) {
+            // (one run with the other scalar entries when they are staged: see fu_scalar_run_store)
             int o = P.ho_d;
+            if (staged) {
 #pragma unroll
-            for (int d = 0; d < 2; ++d) {
-                if (lane < P.ddim_i[d]) Hb[o + lane] = -mud[d];
-                o += P.ddim_i[d];
+                for (int d = 0; d < 2; ++d) {
+                    if (lane < P.ddim_i[d]) scal[o - P.ho_aa + lane] = -mud[d];
+                    o += P.ddim_i[d];
+                }
+                for (int i = lane; i < P.h_pad; i += 64) scal[P.hess_nnz - P.ho_aa + i] = 0.0;
+            } else {
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    if (lane < P.ddim_i[d]) Hb[o + lane] = -mud[d];
+                    o += P.ddim_i[d];
+                }
+                for (int i = lane; i < P.h_pad; i += 64) Hb[P.hess_nnz + i] = 0.0;
             }
-            for (int i = lane; i < P.h_pad; i += 64) Hb[P.hess_nnz + i] = 0.0;
         } else {
             qc_hess_tail(P, mu, Hb, lane, 64);
         }
@@ -284,7 +303,7 @@ __global__ __launch_bounds__(kFuThreads, 2) void qc_mfma16_pade4_fused_kernel(co
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            fu_reduce_rows<kMU>(P, redc, Hb, lane, m, ft, 0, R::kAA, 0);
+            fu_reduce_rows<kMU>(P, redc, Hb, lane, m, ft, 0, R::kAA, 0, staged, scal);
         } else if constexpr (AACOPY) {
             // (a_u, a_v) = -sum T_u . swap8(T_v) over all lanes, from the stage-A tiles the compute wave has parked in LDS: this wave's
             // stores are issued and it would only wait for them to drain
@@ -309,8 +328,9 @@ __global__ __launch_bounds__(kFuThreads, 2) void qc_mfma16_pade4_fused_kernel(co
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            fu_reduce_rows<kMU>(P, redc, Hb, lane, m, ft, 0, R::kAA, 0);
+            fu_reduce_rows<kMU>(P, redc, Hb, lane, m, ft, 0, R::kAA, 0, staged, scal);
         }
+        if (staged) fu_scalar_run_store(P, scal, scal_count, Hb, lane);
         QC_STAMP(P, b, lane, 15);                   // copy wave: done
         QC_STAMP_FLUSH(P, b, lane, 10, 15);
         return;
@@ -615,7 +635,8 @@ __global__ __launch_bounds__(kFuThreads, 2) void qc_mfma16_pade4_fused_kernel(co
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        fu_reduce_rows<kMU>(P, red, Hb, lane, m, ft, kRowShift, R::kRows, kRowShift);
+        fu_reduce_rows<kMU>(P, red, Hb, lane, m, ft, kRowShift, R::kRows, kRowShift, staged, scal);
+        if (staged) fu_scalar_run_store(P, scal, scal_count, Hb, lane);
         QC_STAMP(P, b, lane, 8);                  // compute wave: every store issued
         if constexpr (DIAG) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -43,7 +43,7 @@ struct FuRows {
 // order of qc_mfma16_pade4_hess_anti_kernel -- lanes l and l + 32 take the left / right lanes' columns of row l -- and stores them.
 template <int kMU>
 __device__ __forceinline__ void fu_reduce_rows(const QcParams& P, const double* __restrict__ red, double* __restrict__ Hb, int lane, int m, bool ft,
-                                               int row_begin, int row_end, int row_shift) {
+                                               int row_begin, int row_end, int row_shift, bool staged = false, double* __restrict__ scal = nullptr) {
     using R = FuRows<kMU>;
     const int naa = m * (m + 1) / 2;
     const int half = lane >> 5;
@@ -65,13 +65,43 @@ __device__ __forceinline__ void fu_reduce_rows(const QcParams& P, const double* 
         const double own = (a0 + a1) + (a2 + a3);
         const double both = own + __shfl_xor(own, 32, 64);
         if (wanted) {
-            if (row < naa) {
-                if (half == 0) Hb[P.ho_aa + row] = both;
-            } else if (row >= R::kAA) {
-                Hb[pair_row ? P.ho_ah + drive : P.ho_hh] = own;
+            // staged: the interval's scalar run [(a, a) | (a, h) | (h, h) | (dx, h) | padding] is collected in LDS (`scal`, P.ho_aa at
+            // index 0) and stored in one piece by fu_scalar_run_store; otherwise the entries go out one by one.  (Two branches, not one
+            // store through a selected pointer: that would be a FLAT store, which queues behind every global store of the wave.)
+            if (staged) {
+                if (row < naa) {
+                    if (half == 0) scal[row] = both;
+                } else if (row >= R::kAA) {
+                    scal[(pair_row ? P.ho_ah + drive : P.ho_hh) - P.ho_aa] = own;
+                }
+            } else {
+                if (row < naa) {
+                    if (half == 0) Hb[P.ho_aa + row] = both;
+                } else if (row >= R::kAA) {
+                    Hb[pair_row ? P.ho_ah + drive : P.ho_hh] = own;
+                }
             }
         }
     }
+}
+
+// The scalar entries of an interval's Hessian block -- (a, a), (a, h), (h, h), the derivative integrators' (dx, h) and the alignment
+// padding: one contiguous run behind the matrix blocks (qc_host.cpp) -- come from both waves of the workgroup, a few lanes at a time,
+// at the very end of their lives.  Stored where they arise they are a dozen partly written lines per interval at the tail of the launch:
+// 0.7 us of the one-call launch at config 3 (profiles/NOTES.md, round 5).  Here each wave leaves its entries in LDS (`scal`, P.ho_aa
+// at index 0) and calls this; the wave that arrives LAST stores the run in one piece (three whole lines at config 3).  `count`: one
+// LDS word, zero before either wave can get here.  Same values, same bits.
+constexpr int kFuScalMax = 96;               // entries of the staged run (48 at config 3; the one-call kernel has 105 doubles of LDS to spare at six drives)
+__device__ __forceinline__ int fu_scalar_run_len(const QcParams& P) { return P.hess_nnz + P.h_pad - P.ho_aa; }
+__device__ __forceinline__ void fu_scalar_run_store(const QcParams& P, const double* __restrict__ scal, int* __restrict__ count, double* __restrict__ Hb, int lane) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    int old = 0;
+    if (lane == 0) old = __hip_atomic_fetch_add(count, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+    old = __builtin_amdgcn_readfirstlane(old);
+    if (old == 0) return;                    // the other wave is still at work: it stores
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const int n = fu_scalar_run_len(P);
+    for (int i = lane; i < n; i += 64) Hb[P.ho_aa + i] = scal[i];
 }
 
 }  // namespace qc_mfma
