@@ -81,6 +81,26 @@ __device__ __forceinline__ void lds_transpose16_multi(double* __restrict__ scr, 
     __builtin_amdgcn_wave_barrier();
 }
 
+// The same in rounds of at most kRound tiles through a scratch of kRound tiles (less LDS; each round is one write / read trip).
+template <int N, int kRound>
+__device__ __forceinline__ void lds_transpose16_rounds(double* __restrict__ scr, const v4d (&x)[N], v4d (&y)[N], int g, int j) {
+    if constexpr (N <= kRound) {
+        lds_transpose16_multi<N>(scr, x, y, g, j);
+    } else {
+        v4d a[kRound], b[kRound], c[N - kRound], d[N - kRound];
+#pragma unroll
+        for (int q = 0; q < kRound; ++q) a[q] = x[q];
+#pragma unroll
+        for (int q = 0; q < N - kRound; ++q) c[q] = x[kRound + q];
+        lds_transpose16_multi<kRound>(scr, a, b, g, j);
+        lds_transpose16_rounds<N - kRound, kRound>(scr, c, d, g, j);
+#pragma unroll
+        for (int q = 0; q < kRound; ++q) y[q] = b[q];
+#pragma unroll
+        for (int q = 0; q < N - kRound; ++q) y[kRound + q] = d[q];
+    }
+}
+
 // Drive amplitudes of a knot.  Written as `a_k = z0[off_a + k]` per drive, the compiler emits one SCALAR load per amplitude,
 // each behind its own `s_waitcnt lgkmcnt(0)` (the offset is re-read from the kernel arguments under a branch on k < m): the
 // m loads then return one after the other -- m dependent HBM round trips in front of the first product of every wave.  Here

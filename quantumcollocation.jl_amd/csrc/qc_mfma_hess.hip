@@ -331,9 +331,16 @@ __global__ __launch_bounds__(64) void qc_mfma16_pade4_hess_anti_kernel(const dou
         QC_STAMP(Pk, 0, 0, 10);                   // kernel arguments in the scalar cache
     }
     using R = HessAntiRows<kHM>;
-    __shared__ double red[R::kRows * kHStride];
-    __shared__ double tscr[(kHM + 1) * 16 * 17];
+    // LDS: the parked stage-A tiles, and ONE scratch region that serves the transposes (in rounds of at most four tiles) and then the
+    // reduction rows of the scalar blocks, which are written when the transposed tiles are back in registers.  26.8 KB at six drives:
+    // SIX workgroups per CU instead of the four that three separate arrays (40.5 KB) allowed -- a long trajectory is bound by how many
+    // intervals are in flight (one wave each, a 4.7 us latency chain), not by HBM.
+    constexpr int kTrRound = 4;
+    constexpr int kScrTiles = kHM + 1 < kTrRound ? kHM + 1 : kTrRound;
+    constexpr int kScrLen = kScrTiles * 272 > R::kRows * kHStride ? kScrTiles * 272 : R::kRows * kHStride;
     __shared__ double tsave[kHM * 256];           // the stage-A tiles T_k, parked for the (a, a) sums (registers: see below)
+    __shared__ double tscr[kScrLen];
+    double* __restrict__ red = tscr;
     const int lane = threadIdx.x;
     const int m = BATCH ? P.m : hot_m;
     const int g = lane >> 4, j = lane & 15, jj = j & 7;
@@ -484,7 +491,7 @@ __global__ __launch_bounds__(64) void qc_mfma16_pade4_hess_anti_kernel(const dou
                     tin[2 + 2 * p2][r] = __builtin_fma(hh2, Q[p2][r], lin[r]);
                 }
             }
-            lds_transpose16_multi<kHM + 1>(tscr, tin, tout, g, j);
+            lds_transpose16_rounds<kHM + 1, kTrRound>(tscr, tin, tout, g, j);
             if constexpr (DIAG) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             QC_STAMP(P, b, lane, 6);              // tiles transposed
             ET = tout[0];
@@ -672,11 +679,16 @@ hipError_t qc_launch_mfma_hess(const QcParams& P, const double* dZ, const double
     if (P.n > 32) return qc_launch_mfma64_hess(P, dZ, dMu, dH, st);
     if (P.n > 16) return P.ell ? qc_launch_mfma32_ell_hess(P, dZ, dMu, dH, st) : qc_launch_mfma32_hess(P, dZ, dMu, dH, st);
     if (qc_mfma16_hess2_supported(P)) return qc_launch_mfma16_hess2(P, dZ, dMu, dH, st);     // two waves per interval, up to one round of the device (qc_mfma_hess2.hip)
-    // One interval per workgroup up to two rounds of the device (4 x 256 resident workgroups), a persistent grid of one round beyond:
-    // T = 2000 / 4000 / 8000 / 32000 take 15.1 / 25.4 / 46.1 / 173.8 us with 1024 workgroups against 15.1 / 26.5 / 47.7 / 173.8 with 4096
-    // (15.3 at T = 2000 with 1024: there the loop-free form stays).  QC_HESS_GRID overrides the persistent grid's size.
+    // One interval per workgroup at any length (round 5: the loop-free instantiation needs 228 registers and 25.3 KB of LDS at six
+    // drives -- six workgroups per CU, the hardware refilling each CU as its workgroups retire; the persistent loop's instantiation
+    // needs 308 registers, four per CU).  T = 3000 / 4000 / 8000 / 32000: 20.1 / 25.8 / 45.9 / 156.9 us against 20.8 / 25.9 / 47.0 / 172.8
+    // with the persistent grid of 1024 (profiles/r05_hess_long.txt).  QC_HESS_ONCE_MAX=2048 QC_HESS_GRID=<n>: the persistent grid beyond 2048 intervals.
     static const int grid_cap = getenv("QC_HESS_GRID") ? std::max(1, atoi(getenv("QC_HESS_GRID"))) : 1024;
-    const int grid = P.n_int <= 2048 ? P.n_int : (P.n_int < grid_cap ? P.n_int : grid_cap);
+    static const int once_max = getenv("QC_HESS_ONCE_MAX") ? atoi(getenv("QC_HESS_ONCE_MAX")) : (1 << 30);
+    // Six workgroups per CU live 8.2 instead of 6.5 - 7.4 us each: between 1.5 and 2 rounds of the device that is a loss (two rounds either
+    // way: T = 2000 17.7 against 15.4 us) -- there the persistent instantiation (four per CU) with one round of workgroups stays.
+    const bool window = P.antisym && P.m > 4 && P.m <= 6 && P.n_int > 1536 && P.n_int <= 2048;
+    const int grid = (P.n_int <= once_max && !window) ? P.n_int : (P.n_int < grid_cap ? P.n_int : grid_cap);
     if (P.nc != 8 || P.n != 16) {
         if (P.m <= 2) launch_hess16<2, true>(P, dZ, dMu, dH, st, grid);
         else if (P.m <= 4) launch_hess16<4, true>(P, dZ, dMu, dH, st, grid);
