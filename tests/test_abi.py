@@ -82,6 +82,38 @@ def test_dims_and_structure_match_oracle(qc, oracle, cfg, T):
     np.testing.assert_array_equal(jc1, jc + 1)
 
 
+@pytest.mark.parametrize("cfg", [3, 5])
+def test_hessian_matrix_blocks_sit_on_whole_lines_and_the_scalar_entries_are_one_run(qc, cfg):
+    """The per-interval value layout of mu_d2F: the four kinds of matrix blocks first -- each a multiple of 16
+    entries when 2N x N is, so that with hess_align = 16 every block store covers whole 128-byte lines --, then every scalar entry
+    ((a,a), (a,dt), (dt,dt), (dx,dt)) as ONE contiguous run, which the one-call kernel stores in one piece."""
+    inp = qc.config_inputs(cfg, T=4)
+    traj = inp.traj
+    desc, keep = qc.make_desc(inp.integrators, traj, hess_align=16)
+    dims = qc.desc_dims(desc)
+    _, _, hr, hc = qc.desc_structures(desc)
+    k = dims.hess_nnz_interval
+    assert k % 16 == 0
+    r, c = hr[:k], hc[:k]                      # interval 0: local indices over [z_0 ; z_1]
+    zd = traj.dim
+    U = set(range(traj.components["Ũ⃗"].start, traj.components["Ũ⃗"].stop)) if hasattr(traj, "components") else None
+    if U is None:
+        pytest.skip("trajectory without a component table")
+    s = len(U)
+    while k > 1 and (r[k - 1], c[k - 1]) == (r[0], c[0]):      # the alignment padding: duplicates of the first entry at the very end
+        k -= 1
+    kinds = np.array([(r[i] % zd in U) != (c[i] % zd in U) for i in range(k)])     # a matrix-block entry pairs a state entry with a drive or dt
+    n_matrix = int(kinds.sum())
+    assert n_matrix % s == 0 and s % 16 == 0
+    assert kinds[:n_matrix].all() and not kinds[n_matrix:].any()        # matrix blocks first, the scalar run behind them
+    # every block of s entries has one fixed partner index (a drive or dt) and runs over the whole state block
+    for b0 in range(0, n_matrix, s):
+        rows, cols = r[b0:b0 + s], c[b0:b0 + s]
+        state_side = rows if len(set(rows)) == s else cols
+        other = cols if state_side is rows else rows
+        assert len(set(other)) == 1 and sorted(x % zd for x in state_side) == sorted(U)
+
+
 def test_structure_of_a_shard(qc, oracle):
     inp = qc.config_inputs(2, T=20)
     desc, keep = qc.make_desc(inp.integrators, inp.traj, t_range=(7, 13))
