@@ -428,6 +428,12 @@ extern "C" int qc_create(const qc_desc* d, qc_handle** out) {
             h->prm.ell_R = R;
             h->prm.ell_slots = slots;
         }
+        std::vector<char> blob16;
+        if (!no_ell && qc_mfma16_ell_build(h->prm, G.data(), &blob16)) {
+            QC_HIP_C(hipMalloc(&h->dEll16, blob16.size()));
+            QC_HIP_C(hipMemcpy(h->dEll16, blob16.data(), blob16.size(), hipMemcpyHostToDevice));
+            h->prm.ell16 = h->dEll16;
+        }
     }
     // LDS budget of the LDS kernels
     {
@@ -494,6 +500,7 @@ extern "C" void qc_destroy(qc_handle* h) {
     }
     if (h->dC) (void)hipFree(h->dC);
     if (h->dEll) (void)hipFree(h->dEll);
+    if (h->dEll16) (void)hipFree(h->dEll16);
     if (h->ev_done) (void)hipEventDestroy(h->ev_done);
     if (h->dBatch) (void)hipFree(h->dBatch);
     if (h->dBatchLand) (void)hipFree(h->dBatchLand);
@@ -530,7 +537,7 @@ extern "C" const char* qc_kernel_name(const qc_handle* h, int32_t which) {
         return P.n > 32 ? "mfma64-pade4" : (P.n > 16 ? "mfma32-pade4" : "mfma16-pade4");
     }
     if (P.integrator != QC_PADE) return "none";
-    if (which == 2) return mfma && qc_mfma16_fused_supported(P) ? "mfma16-pade4-fused" : (mfma && P.ell && P.hess_nnz ? "mfma32-pade4-fused-ell" : "two-launches");
+    if (which == 2) return mfma && qc_mfma16_fused_supported(P) ? (qc_mfma16_fused_gathers(P) ? "mfma16-pade4-fused-gather" : "mfma16-pade4-fused") : (mfma && P.ell && P.hess_nnz ? "mfma32-pade4-fused-ell" : "two-launches");
     if (mfma && qc_mfma_hess_supported(P)) {
         if (qc_mfma16_padeP_hess_supported(P)) return "mfma16-padeP-hess";
         if (qc_mfma16_hess2_supported(P)) return "mfma16-pade4-hess2";

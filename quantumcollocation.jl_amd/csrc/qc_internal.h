@@ -52,6 +52,8 @@ struct QcParams {
     unsigned long long* stamps;  // diagnostic: 16 s_memrealtime slots per interval, or nullptr (normal)
     const void* ell;         // device: row-gather tables of sparse drive generators (qc_mfma32_ell.hip), or nullptr
     int ell_R, ell_slots;    // entries per generator row (1 or 2); drives touching one entry of G at most (0: G from the dense images)
+    const void* ell16;       // device: rows of the drive generators of a 2N = 16 handle whose drives have ONE entry per row (Pauli strings):
+                             // [drive][16] weights (doubles), then [drive][16] columns x 17 (ints) -- qc_mfma_fused.hip; else nullptr
 };
 
 struct qc_fanout;
@@ -88,6 +90,7 @@ struct qc_handle {
     double* dG = nullptr;
     double* dGx = nullptr;
     void* dEll = nullptr;      // tables of the sparse-drive kernels (qc_mfma32_ell.hip)
+    void* dEll16 = nullptr;    // ... and of the 2N = 16 one-call kernel (qc_mfma_fused.hip)
     // staging for the host-pointer entry points
     double *dZ = nullptr, *dF = nullptr, *dJ = nullptr, *dMu = nullptr, *dH = nullptr;
     unsigned long long* dStamps = nullptr;
@@ -191,6 +194,8 @@ hipError_t qc_launch_mfma32_exp(const QcParams& P, const double* dZ, double* dF,
 bool qc_mfma32_hess_supported(const QcParams& P);
 // sparse drive generators (at most 2 entries per row), 2N = 32, Hermitian Hamiltonians: qc_mfma32_ell.hip
 int qc_mfma32_ell_build(const QcParams& P, const double* G_host, std::vector<char>* blob, int* slots_out);
+bool qc_mfma16_ell_build(const QcParams& P, const double* G_host, std::vector<char>* blob);   // 2N = 16, one entry per drive row: qc_mfma_fused.hip
+bool qc_mfma16_fused_gathers(const QcParams& P);     // ... and whether the one-call launch of this handle takes the row-gather form
 hipError_t qc_launch_mfma32_ell_hess(const QcParams& P, const double* dZ, const double* dMu, double* dH, hipStream_t st);
 hipError_t qc_launch_mfma32_ell_F_jac(const QcParams& P, const double* dZ, double* dF, double* dJ, hipStream_t st);
 hipError_t qc_launch_mfma32_ell_fused(const QcParams& P, const double* dZ, const double* dMu, double* dF, double* dJ, double* dH, hipStream_t st);

@@ -28,7 +28,18 @@
 // LDS per workgroup (doubles): G 256 | U_t 256 | U_t+1 256 | M 256 | images kMU x 256 (rewritten with the stage-A tiles T_k once the
 // images are in registers) | scratch (kMU + 1) x 272 (transposes of both halves; the reduction rows alias it) = 35.7 KB at kMU = 6:
 // four workgroups per CU, as the F + dF kernel has.  (kMU = 8 would need 44 KB: seven and eight drives take two launches.)
+// ELL (round 5): drive generators with ONE entry per row -- Pauli strings, what configs 3 and 4 drive with.  Every product with a drive
+// image, G_k X, is then a row gather from a row-major LDS copy of X: T_k[a][j] = w_k[a] X[c_k[a]][j].  v_mfma_f64_16x16x4_f64 is an
+// ascending-k chain of fused multiply-adds (tests/hip/mfma_f64_fma_probe.hip), so with the other fifteen entries of the row exact zeros
+// the dense product's accumulator holds fma(w, x, acc) and nothing else: the gathered form has the SAME BITS as the dense-image kernels
+// (finite inputs), and the one call stays bit-identical to the two launches.  120 f64 MFMAs per interval (64 cycles each on the SIMD's
+// one matrix pipe: 3.6 us of pipe time per SIMD at T = 1000, in front of and between the stores of a store-bound kernel) become 48; the
+// copy wave's stage A no longer paces its tile copies; the compute wave holds no image in a register.  Used for trajectories of more
+// than one and up to four device rounds (qc_mfma16_fused_gathers below): within one round the launch follows its store stream and the images
+// are faster; beyond four rounds the box decides.
 #include <stdlib.h>
+
+#include <vector>
 
 #include "qc_mfma_hess_common.h"
 
@@ -44,11 +55,38 @@ constexpr int kFuMaxGrid = 1 << 24;
 constexpr int kFuMaxStamped = 1024;          // the time-stamped build (QC_STAMPS=1) records one round
 constexpr int kFuDF = 4;                     // derivative integrators served from registers (F + dF part)
 constexpr int kLdsGa = 0, kLdsU0 = 256, kLdsU1 = 512, kLdsM = 768, kLdsGk = 1024;
+constexpr int kXS = 17;                      // row stride of the row-major LDS copies the gathers read (doubles)
+
+// T_u = G_u X for every drive, G_u with one entry per row: lane (g, j) reg r = w_u[4 r + g] * X[c_u[4 r + g]][j], X from its row-major
+// copy xs (tw: [u][16] weights, tc: [u][16] columns x kXS, both in LDS; unused drive slots carry weight 0, column 0).  fma(w, x, +0):
+// what the dense product's accumulator chain holds.
+template <int kMU>
+__device__ __forceinline__ void fu_gather_all(const double* __restrict__ tw, const int* __restrict__ tc, const double* __restrict__ xs, int g, int j,
+                                              v4d (&out)[kMU]) {
+#pragma unroll
+    for (int u = 0; u < kMU; ++u) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = u * 16 + 4 * r + g;
+            out[u][r] = __builtin_fma(tw[row], xs[tc[row] + j], 0.0);
+        }
+    }
+}
+// lane (g, j) reg r = X[4 r + g][j]  ->  xs[(4 r + g) * kXS + j]
+__device__ __forceinline__ void fu_put_rows(double* __restrict__ xs, const v4d& x, int g, int j) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xs[(4 * r + g) * kXS + j] = x[r];
+}
+__device__ __forceinline__ void fu_lds_order() {     // a wave's LDS operations execute in order; this keeps the compiler from reordering them
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 // Leading arguments = what the first load requests depend on; preloaded into scalar registers at wave launch (Makefile:
 // -amdgpu-kernarg-preload-count, as for the two kernels this one is made of).  Zt / mu0: the first knot / the first interval's
 // multipliers of THIS launch.
-template <int kMU, int VAR>
+template <int kMU, int VAR, bool ELL>
 __global__ __launch_bounds__(kFuThreads, 2) void qc_mfma16_pade4_fused_kernel(const double* __restrict__ hot_Gx, const double* __restrict__ hot_Zt,
                                                                              const double* __restrict__ hot_mu0, int hot_n_int, int hot_zdim,
                                                                              int hot_off_a, int hot_off_dt, int hot_m, int hot_off_U,
@@ -68,6 +106,7 @@ __global__ __launch_bounds__(kFuThreads, 2) void qc_mfma16_pade4_fused_kernel(co
     constexpr int kLdsRedC = kLdsScr + kScrTiles * 272;                     // the copy wave's reduction rows ((a, a) sums)
     constexpr bool SACOPY = (VAR & 32) != 0;        // stage A of the Hessian on the copy wave too, between its tile copies (needs AACOPY)
     static_assert(!SACOPY || AACOPY, "stage A on the copy wave goes with the (a, a) sums there");
+    static_assert(!ELL || SACOPY, "the row-gather form is built on the final variant");
     // (SACOPY: the region also carries the tiles [-N_k | -N_k+1] and Y from the copy wave to the compute wave)
     constexpr int kRedCLen = !AACOPY ? 0 : (SACOPY && (kMU / 2 + 1) * 256 > R::kAA * kFuStride ? (kMU / 2 + 1) * 256 : R::kAA * kFuStride);
     constexpr int kLdsFlag = kLdsRedC + kRedCLen;                           // one word: "the compute wave has taken the hand-over tiles"
@@ -89,6 +128,8 @@ __global__ __launch_bounds__(kFuThreads, 2) void qc_mfma16_pade4_fused_kernel(co
 
     // the copy wave's generator images depend on nothing but the kernel arguments
     v4d g0_img, gk_img[kMU];
+    double ell_w[2] = {0.0, 0.0};                   // ELL: the drives' rows (entries lane and 64 + lane of [drive][16]), to LDS with the hand-off
+    int ell_c[2] = {0, 0};
     if (role == 1) {
         g0_img = fu_load_GA(Gx, 0, lane);
 #pragma unroll
@@ -96,7 +137,21 @@ __global__ __launch_bounds__(kFuThreads, 2) void qc_mfma16_pade4_fused_kernel(co
             const int k = u < m ? u : (m > 0 ? m - 1 : 0);
             gk_img[u] = fu_load_GA(Gx, m > 0 ? k + 1 : 0, lane);
         }
+        if constexpr (ELL) {
+            typedef const __attribute__((address_space(1))) double* gdp;
+            typedef const __attribute__((address_space(1))) int* gip;
+            const gdp tw = (gdp)(unsigned long long)P.ell16;
+            const gip tc = (gip)(unsigned long long)((const char*)P.ell16 + 6 * 16 * 8);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int e = 64 * q + lane;
+                ell_w[q] = tw[e < 16 * m ? e : 0];
+                ell_c[q] = tc[e < 16 * m ? e : 0];
+            }
+        }
     }
+    double* __restrict__ const ellTW = sm + kLdsGk;                         // ELL: the image region holds the drives' rows instead
+    int* __restrict__ const ellTC = reinterpret_cast<int*>(sm + kLdsGk + 96);
     touch.consume();
     if ((int)blockIdx.x >= hot_n_int) return;
     const int g = lane >> 4, j = lane & 15, jj = j & 7;
@@ -170,9 +225,20 @@ __global__ __launch_bounds__(kFuThreads, 2) void qc_mfma16_pade4_fused_kernel(co
         fu_lds_put(sm + kLdsU0, lane, u0);
         fu_lds_put(sm + kLdsU1, lane, u1);
         fu_lds_put(sm + kLdsM, lane, mt);
+        if constexpr (ELL) {
 #pragma unroll
-        for (int u = 0; u < kMU; ++u)
-            if (u < m) fu_lds_put(sm + kLdsGk + u * 256, lane, gk_img[u]);
+            for (int q = 0; q < 2; ++q) {
+                const int e = 64 * q + lane;
+                if (e < 16 * kMU) {
+                    ellTW[e] = e < 16 * m ? ell_w[q] : 0.0;
+                    ellTC[e] = e < 16 * m ? ell_c[q] : 0;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < kMU; ++u)
+                if (u < m) fu_lds_put(sm + kLdsGk + u * 256, lane, gk_img[u]);
+        }
         if (lane == 0) {
             if constexpr (SACOPY) reinterpret_cast<int*>(sm + kLdsFlag)[0] = 0;
             scal_count[0] = 0;
@@ -201,11 +267,24 @@ __global__ __launch_bounds__(kFuThreads, 2) void qc_mfma16_pade4_fused_kernel(co
             double* pF = Jb + P.jo_F;
             double* pB = Jb + P.jo_B;
             const int ncop = P.copies;
+            if constexpr (ELL) {
+                // T_k by row gathers from a row-major copy of [M | c2 h^2 D] (in the hand-over region, which this wave fills afterwards):
+                // LDS reads, which issue beside the stores and cost the matrix pipe nothing
+                double* __restrict__ xs = sm + kLdsRedC;
+                fu_put_rows(xs, MD, g, j);
+                fu_lds_order();
+                v4d Tg[kMU];
+                fu_gather_all<kMU>(ellTW, ellTC, xs, g, j, Tg);
+#pragma unroll
+                for (int u = 0; u < kMU; ++u) acc[1 + u] = Tg[u];
+            }
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ga[kk], MD[kk], kk ? acc[0] : zero, 0, 0, 0);
+                if constexpr (!ELL) {
 #pragma unroll
-                for (int u = 0; u < kMU; ++u) acc[1 + u] = __builtin_amdgcn_mfma_f64_16x16x4f64(gk_img[u][kk], MD[kk], kk ? acc[1 + u] : zero, 0, 0, 0);
+                    for (int u = 0; u < kMU; ++u) acc[1 + u] = __builtin_amdgcn_mfma_f64_16x16x4f64(gk_img[u][kk], MD[kk], kk ? acc[1 + u] : zero, 0, 0, 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int q = 2 * kk; q < 2 * kk + 2; ++q) {
@@ -223,6 +302,7 @@ __global__ __launch_bounds__(kFuThreads, 2) void qc_mfma16_pade4_fused_kernel(co
 #pragma unroll
             for (int u = 0; u < kMU; ++u) Tq[u] = acc[1 + u];
             // hand-over to the compute wave's stage B: [-N_k | -N_k+1] per drive pair, and Y
+            if constexpr (ELL) fu_lds_order();     // (the gathers above have read the region)
             double* __restrict__ hand = sm + kLdsRedC;
 #pragma unroll
             for (int p2 = 0; p2 < kMU / 2; ++p2) fu_lds_put(hand + 256 * p2, lane, fu_sel(left, Tq[2 * p2], swap8(Tq[2 * p2 + 1])));
@@ -384,7 +464,21 @@ __global__ __launch_bounds__(kFuThreads, 2) void qc_mfma16_pade4_fused_kernel(co
         for (int r = 0; r < 4; ++r) Q[r] = left ? (-hc1 * W[r] + hc2 * P1sw[r]) : (hc2 * W[r]);
         constexpr int NB = kMU + 1;
         v4d sB[NB];                               // P2 = G P1sw, R_k = G_k Q
-        {
+        if constexpr (ELL) {
+            // R_k by row gathers from a row-major copy of Q (transpose scratch), beside the one dense chain G P1sw
+            fu_put_rows(scr, Q, g, j);
+            fu_lds_order();
+            const v4d zero = {0.0, 0.0, 0.0, 0.0};
+            v4d p2 = __builtin_amdgcn_mfma_f64_16x16x4f64(Ga[0], P1sw[0], zero, 0, 0, 0);
+#pragma unroll
+            for (int kk = 1; kk < 4; ++kk) p2 = __builtin_amdgcn_mfma_f64_16x16x4f64(Ga[kk], P1sw[kk], p2, 0, 0, 0);
+            v4d Rg[kMU];
+            fu_gather_all<kMU>(ellTW, ellTC, scr, g, j, Rg);
+            sB[0] = p2;
+#pragma unroll
+            for (int u = 0; u < kMU; ++u) sB[u + 1] = Rg[u];
+            fu_lds_order();                       // (the transposes below rewrite the scratch)
+        } else {
             v4d aB[NB], bB[NB];
             aB[0] = Ga;
             bB[0] = P1sw;
@@ -450,8 +544,10 @@ __global__ __launch_bounds__(kFuThreads, 2) void qc_mfma16_pade4_fused_kernel(co
         double* __restrict__ red = scr;               // the reduction rows alias the transpose scratch (read back before they are written)
         const v4d zero = {0.0, 0.0, 0.0, 0.0};
         v4d gA[kMU];
+        if constexpr (!ELL) {
 #pragma unroll
-        for (int u = 0; u < kMU; ++u) gA[u] = fu_lds_get(sm + kLdsGk + (u < m ? u : (m > 0 ? m - 1 : 0)) * 256, lane);
+            for (int u = 0; u < kMU; ++u) gA[u] = fu_lds_get(sm + kLdsGk + (u < m ? u : (m > 0 ? m - 1 : 0)) * 256, lane);
+        }
         const v4d mv = fu_lds_get(sm + kLdsM, lane);
         Ga = fu_lds_get(sm + kLdsGa, lane);
         u0 = fu_lds_get(sm + kLdsU0, lane);
@@ -523,15 +619,32 @@ __global__ __launch_bounds__(kFuThreads, 2) void qc_mfma16_pade4_fused_kernel(co
 #pragma unroll
                 for (int p2 = 0; p2 < kMU / 2; ++p2) Q[p2] = __builtin_amdgcn_mfma_f64_16x16x4f64(Gs[kk], PNn[p2][kk], Q[p2], 0, 0, 0);
             }
+            if constexpr (ELL) {
+                // + G_2p YL + G_2p+1 YR with YL = [y | 0], YR = [0 | y]: a left lane's accumulator takes the one term w_2p[a] y[c_2p[a]][j],
+                // a right lane's w_2p+1[a] y[c_2p+1[a]][j - 8]; every other term of the two dense chains is an exact zero
+                fu_put_rows(scr, YL, g, j);
+                fu_lds_order();
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
+                for (int p2 = 0; p2 < kMU / 2; ++p2) {
 #pragma unroll
-                for (int p2 = 0; p2 < kMU / 2; ++p2) Q[p2] = __builtin_amdgcn_mfma_f64_16x16x4f64(gA[2 * p2][kk], YL[kk], Q[p2], 0, 0, 0);
-            }
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = (left ? 2 * p2 : 2 * p2 + 1) * 16 + 4 * r + g;
+                        Q[p2][r] = __builtin_fma(ellTW[row], scr[ellTC[row] + jj], Q[p2][r]);
+                    }
+                }
+                fu_lds_order();                   // (the transposes below rewrite the scratch)
+                (void)YR;
+            } else {
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
+                for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
-                for (int p2 = 0; p2 < kMU / 2; ++p2) Q[p2] = __builtin_amdgcn_mfma_f64_16x16x4f64(gA[2 * p2 + 1][kk], YR[kk], Q[p2], 0, 0, 0);
+                    for (int p2 = 0; p2 < kMU / 2; ++p2) Q[p2] = __builtin_amdgcn_mfma_f64_16x16x4f64(gA[2 * p2][kk], YL[kk], Q[p2], 0, 0, 0);
+                }
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+                    for (int p2 = 0; p2 < kMU / 2; ++p2) Q[p2] = __builtin_amdgcn_mfma_f64_16x16x4f64(gA[2 * p2 + 1][kk], YR[kk], Q[p2], 0, 0, 0);
+                }
             }
         }
         QC_STAMP(P, b, lane, 6);                  // compute wave: stage B issued
@@ -648,6 +761,22 @@ __global__ __launch_bounds__(kFuThreads, 2) void qc_mfma16_pade4_fused_kernel(co
 
 }  // namespace
 
+// The row-gather form (ELL) serves trajectories of one to four device rounds (four workgroups per CU: 1024 intervals a round): there the
+// matrix pipes decide how fast workgroups retire and make room -- T = 1500 / 2000 / 3000 / 4000: 21.6 / 25.5 / 36.3 / 44.0 us against 22.7 /
+// 26.4 / 37.3 / 45.9 with the dense images, on every box measured -- while a single round follows its store stream and is 0.3 - 0.7 us
+// FASTER with the images (T = 1000: 12.8 against 13.5), and long streams are decided by the box: T = 6000 ... 32000 lose 2 - 4 % with the
+// gathers on two boxes and win 6 - 8 % (T = 16000: 143 - 148 against 155 - 156 us) on a third (profiles/r05_fused_ell16.txt: A/B inside one
+// process on the same buffers, profiles/fused_ab.py -- across processes long streams are bimodal).  QC_FUSED_ELL=0 / 1: never / always.
+constexpr int kFuEllMinIntervals = 1025, kFuEllMaxIntervals = 4096;
+bool qc_mfma16_fused_gathers(const QcParams& P) {
+#ifdef QC_FUSED_ELL_DYNAMIC      /* experiment builds: the switch is read at every launch (A/B inside one process, on the same buffers) */
+    const int mode = getenv("QC_FUSED_ELL") ? atoi(getenv("QC_FUSED_ELL")) : -1;
+#else
+    static const int mode = getenv("QC_FUSED_ELL") ? atoi(getenv("QC_FUSED_ELL")) : -1;
+#endif
+    return P.ell16 != nullptr && mode != 0 && (mode == 1 || (P.n_int >= kFuEllMinIntervals && P.n_int <= kFuEllMaxIntervals));
+}
+
 bool qc_mfma16_fused_supported(const QcParams& P) {
     return P.integrator == QC_PADE && P.p == 2 && P.n == 16 && P.nc == 8 && P.antisym && P.m >= 1 && P.m <= 6 && P.hess_nnz > 0 && P.store_mode == 2 &&
            (P.stamps == nullptr || (P.m > 4 && P.n_int <= kFuMaxStamped)) && P.dbg_skip == 0 && P.Gx != nullptr && P.copies == P.nc;
@@ -661,20 +790,51 @@ hipError_t qc_launch_mfma16_fused(const QcParams& P, const double* dZ, const dou
         double* Fp = dF ? dF + (size_t)b0 * P.F_stride : nullptr;
         double* Jp = dJ + (size_t)b0 * P.J_stride;
         double* Hp = dH + (size_t)b0 * P.H_stride;
-#define QC_FU(MU_, V_) hipLaunchKernelGGL((qc_mfma16_pade4_fused_kernel<MU_, V_>), dim3(n), dim3(kFuThreads), 0, st, P.Gx, Zt, mu0, n, P.zdim, P.off_a, P.off_dt, \
+#define QC_FU(MU_, V_) hipLaunchKernelGGL((qc_mfma16_pade4_fused_kernel<MU_, V_, false>), dim3(n), dim3(kFuThreads), 0, st, P.Gx, Zt, mu0, n, P.zdim, P.off_a, P.off_dt, \
+                                          P.m, P.off_U, (int)P.F_stride, P, Fp, Jp, Hp)
+#define QC_FU_ELL(MU_) hipLaunchKernelGGL((qc_mfma16_pade4_fused_kernel<MU_, 53, true>), dim3(n), dim3(kFuThreads), 0, st, P.Gx, Zt, mu0, n, P.zdim, P.off_a, P.off_dt, \
                                           P.m, P.off_U, (int)P.F_stride, P, Fp, Jp, Hp)
         // VAR bits: 1 S / D of the scalar blocks re-read from LDS (no scratch spills), 4 the (a, a) sums on the copy wave, 8 time stamps,
         // 16 no copy before the hand-off, 32 stage A on the copy wave.  QC_FUSED_VARIANT=0: the plain composition of the two kernels,
         // 21: everything but bit 32 -- for comparison.
         static const bool plain = getenv("QC_FUSED_VARIANT") && atoi(getenv("QC_FUSED_VARIANT")) == 0;
         static const int var = getenv("QC_FUSED_VARIANT") ? atoi(getenv("QC_FUSED_VARIANT")) : -1;
-        if (P.stamps != nullptr) QC_FU(6, 61);
+        const bool ell = qc_mfma16_fused_gathers(P) && var < 0;
+        if (P.stamps != nullptr && ell) hipLaunchKernelGGL((qc_mfma16_pade4_fused_kernel<6, 61, true>), dim3(n), dim3(kFuThreads), 0, st, P.Gx, Zt, mu0, n, P.zdim,
+                                                           P.off_a, P.off_dt, P.m, P.off_U, (int)P.F_stride, P, Fp, Jp, Hp);
+        else if (P.stamps != nullptr) QC_FU(6, 61);
+        else if (ell && P.m <= 2) QC_FU_ELL(2);
+        else if (ell && P.m <= 4) QC_FU_ELL(4);
+        else if (ell) QC_FU_ELL(6);
         else if (P.m <= 2) QC_FU(2, 53);
         else if (P.m <= 4) QC_FU(4, 53);
         else if (plain) QC_FU(6, 0);
         else if (var == 21) QC_FU(6, 21);
         else QC_FU(6, 53);
 #undef QC_FU
+#undef QC_FU_ELL
     }
     return hipGetLastError();
+}
+
+// Rows of the drive generators for the row-gather form: every drive generator of a handle the one-call kernel serves has at most ONE
+// entry per row.  blob = [6][16] weights (doubles), [6][16] columns x kXS (ints); unused rows / drives: weight 0, column 0.
+bool qc_mfma16_ell_build(const QcParams& P, const double* G, std::vector<char>* blob) {
+    if (P.integrator != QC_PADE || P.p != 2 || P.n != 16 || P.nc != 8 || !P.antisym || P.m < 1 || P.m > 6 || P.hess_nnz == 0) return false;
+    const int n = 16, m = P.m;
+    blob->assign(6 * 16 * 8 + 6 * 16 * 4, 0);
+    double* tw = reinterpret_cast<double*>(blob->data());
+    int* tc = reinterpret_cast<int*>(blob->data() + 6 * 16 * 8);
+    for (int k = 0; k < m; ++k)
+        for (int a = 0; a < n; ++a) {
+            int cnt = 0;
+            for (int c = 0; c < n; ++c) {
+                const double v = G[(size_t)(k + 1) * n * n + (size_t)c * n + a];      // drive k, row a, column c (column-major)
+                if (v == 0.0) continue;
+                if (++cnt > 1) return false;
+                tw[k * 16 + a] = v;
+                tc[k * 16 + a] = c * kXS;
+            }
+        }
+    return true;
 }

@@ -932,7 +932,8 @@ def test_host_path_with_non_finite_inputs_and_the_sentinel_pattern(qc, monkeypat
         assert np.array_equal(a.view(np.uint64), b.view(np.uint64))
 
 
-@pytest.mark.parametrize("case", ["cfg3", "cfg3_long", "cfg3_fixed_dt", "m1", "m2", "m3", "m4", "m5", "cfg5", "cfg1"])
+@pytest.mark.parametrize("case", ["cfg3", "cfg3_long", "cfg3_fixed_dt", "m1", "m2", "m3", "m4", "m5", "cfg5", "cfg1",
+                                  "pauli2_long", "pauli3_long_fixed_dt", "pauli4_long", "pauli5_long", "dense3_long"])
 def test_fused_launch_is_bit_identical(qc, case):
     """qc_eval_F_jac_hess_dev: dF and mu_d2F (and F) at one point in one call.  Where the fused kernel serves the handle (2N = 16,
     1 .. 6 drives, Hermitian Hamiltonians: BASELINE configs 3 / 4) it is ONE launch whose values equal the two launches' bit for bit;
@@ -942,7 +943,8 @@ def test_fused_launch_is_bit_identical(qc, case):
     if case == "cfg3":
         inp = qc.config_inputs(3, T=257)
     elif case == "cfg3_long":
-        inp = qc.config_inputs(3, T=1100)                  # more than one round of the device (1024 workgroups)
+        inp = qc.config_inputs(3, T=1100)                  # more than one round of the device (1024 workgroups): the row-gather form
+        fused_expected = "mfma16-pade4-fused-gather"
     elif case == "cfg3_fixed_dt":
         inp = qc.unitary_smooth_pulse_inputs(qc.multi_qubit_system(3), qc.GATES["TOFFOLI"], 40, free_time=False)
     elif case in ("m1", "m2", "m3", "m4", "m5"):
@@ -950,6 +952,18 @@ def test_fused_launch_is_bit_identical(qc, case):
         rng = np.random.default_rng(m)
         herm = lambda: (lambda A: (A + A.conj().T) / 2)(rng.standard_normal((8, 8)) + 1j * rng.standard_normal((8, 8)))
         inp = qc.unitary_smooth_pulse_inputs(qc.QuantumSystem(herm(), [herm() for _ in range(m)]), qc.GATES["TOFFOLI"], 31)
+    elif case.startswith("pauli"):
+        # Pauli drives on three qubits (one entry per generator row), more than one device round: the one-call launch takes its
+        # row-gather form (qc_mfma16_fused_gathers) -- the 2-, 4- and 6-drive instantiations, free and fixed time steps
+        m = int(case[5])
+        full = qc.multi_qubit_system(3)
+        sysm = qc.QuantumSystem(full.H_drift, list(full.H_drives)[:m])
+        inp = qc.unitary_smooth_pulse_inputs(sysm, qc.GATES["TOFFOLI"], 1030, free_time="fixed_dt" not in case)
+        fused_expected = "mfma16-pade4-fused-gather"
+    elif case == "dense3_long":          # dense drive generators keep the images at any length
+        rng = np.random.default_rng(33)
+        herm = lambda: (lambda A: (A + A.conj().T) / 2)(rng.standard_normal((8, 8)) + 1j * rng.standard_normal((8, 8)))
+        inp = qc.unitary_smooth_pulse_inputs(qc.QuantumSystem(herm(), [herm() for _ in range(3)]), qc.GATES["TOFFOLI"], 1030)
     elif case == "cfg5":
         inp, fused_expected = qc.config_inputs(5, T=20), "mfma32-pade4-fused-ell"      # Pauli drives: the row-gather kernels (qc_mfma32_ell.hip)
     else:
