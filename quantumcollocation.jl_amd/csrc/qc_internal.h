@@ -195,6 +195,7 @@ bool qc_mfma32_hess_supported(const QcParams& P);
 // sparse drive generators (at most 2 entries per row), 2N = 32, Hermitian Hamiltonians: qc_mfma32_ell.hip
 int qc_mfma32_ell_build(const QcParams& P, const double* G_host, std::vector<char>* blob, int* slots_out);
 bool qc_mfma16_ell_build(const QcParams& P, const double* G_host, std::vector<char>* blob);   // 2N = 16, one entry per drive row: qc_mfma_fused.hip
+bool qc_mfma16_hess_gathers(const QcParams& P);      // ... the mu_d2F launches (qc_mfma_hess.hip, qc_mfma_hess2.hip)
 bool qc_mfma16_fused_gathers(const QcParams& P);     // ... and whether the one-call launch of this handle takes the row-gather form
 hipError_t qc_launch_mfma32_ell_hess(const QcParams& P, const double* dZ, const double* dMu, double* dH, hipStream_t st);
 hipError_t qc_launch_mfma32_ell_F_jac(const QcParams& P, const double* dZ, double* dF, double* dJ, hipStream_t st);

@@ -55,34 +55,6 @@ constexpr int kFuMaxGrid = 1 << 24;
 constexpr int kFuMaxStamped = 1024;          // the time-stamped build (QC_STAMPS=1) records one round
 constexpr int kFuDF = 4;                     // derivative integrators served from registers (F + dF part)
 constexpr int kLdsGa = 0, kLdsU0 = 256, kLdsU1 = 512, kLdsM = 768, kLdsGk = 1024;
-constexpr int kXS = 17;                      // row stride of the row-major LDS copies the gathers read (doubles)
-
-// T_u = G_u X for every drive, G_u with one entry per row: lane (g, j) reg r = w_u[4 r + g] * X[c_u[4 r + g]][j], X from its row-major
-// copy xs (tw: [u][16] weights, tc: [u][16] columns x kXS, both in LDS; unused drive slots carry weight 0, column 0).  fma(w, x, +0):
-// what the dense product's accumulator chain holds.
-template <int kMU>
-__device__ __forceinline__ void fu_gather_all(const double* __restrict__ tw, const int* __restrict__ tc, const double* __restrict__ xs, int g, int j,
-                                              v4d (&out)[kMU]) {
-#pragma unroll
-    for (int u = 0; u < kMU; ++u) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = u * 16 + 4 * r + g;
-            out[u][r] = __builtin_fma(tw[row], xs[tc[row] + j], 0.0);
-        }
-    }
-}
-// lane (g, j) reg r = X[4 r + g][j]  ->  xs[(4 r + g) * kXS + j]
-__device__ __forceinline__ void fu_put_rows(double* __restrict__ xs, const v4d& x, int g, int j) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) xs[(4 * r + g) * kXS + j] = x[r];
-}
-__device__ __forceinline__ void fu_lds_order() {     // a wave's LDS operations execute in order; this keeps the compiler from reordering them
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 // Leading arguments = what the first load requests depend on; preloaded into scalar registers at wave launch (Makefile:
 // -amdgpu-kernarg-preload-count, as for the two kernels this one is made of).  Zt / mu0: the first knot / the first interval's
 // multipliers of THIS launch.

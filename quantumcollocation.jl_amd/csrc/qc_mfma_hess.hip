@@ -14,7 +14,7 @@
 // the transposes for the stores go through LDS.  MFMAs per interval: 8 + 8 m + 4 ceil(m/2) (68 for m = 6).
 #include <algorithm>
 
-#include "qc_mfma_common.h"
+#include "qc_mfma_hess_common.h"
 
 namespace {
 
@@ -312,7 +312,9 @@ __device__ __forceinline__ void st_off(double* __restrict__ ubase, unsigned byte
 // multipliers of this handle's first interval; f_stride = rows per interval.
 #define QC_HESS_HOT_ARGS(P) (P).Gx, dZ + (P).t_begin * (long long)(P).zdim, dMu + (P).t_begin * (P).F_stride + (P).F_off, (P).n_int, (P).zdim, (P).off_a, \
                             (P).off_dt, (P).m, (P).off_U, (int)(P).F_stride
-template <int kHM, bool KET, bool BATCH, bool ONCE, bool DIAG = false>
+// ELL: every drive generator has ONE entry per row (P.ell16; qc_mfma_hess_common.h): the 24 + 24 products with drive images become row
+// gathers from row-major LDS copies -- 20 instead of 68 f64 MFMAs per interval (64 cycles each in dependent chains), the same bits.
+template <int kHM, bool KET, bool BATCH, bool ONCE, bool DIAG = false, bool ELL = false>
 __global__ __launch_bounds__(64) void qc_mfma16_pade4_hess_anti_kernel(const double* __restrict__ hot_Gx, const double* __restrict__ hot_Zt,
                                                                        const double* __restrict__ hot_mu0, int hot_n_int,
                                                                        int hot_zdim, int hot_off_a, int hot_off_dt, int hot_m, int hot_off_U,
@@ -340,6 +342,9 @@ __global__ __launch_bounds__(64) void qc_mfma16_pade4_hess_anti_kernel(const dou
     constexpr int kScrLen = kScrTiles * 272 > R::kRows * kHStride ? kScrTiles * 272 : R::kRows * kHStride;
     __shared__ double tsave[kHM * 256];           // the stage-A tiles T_k, parked for the (a, a) sums (registers: see below)
     __shared__ double tscr[kScrLen];
+    __shared__ double ellTW[ELL ? 96 : 1];        // ELL: the drives' rows (weights; columns x kXS)
+    __shared__ int ellTC[ELL ? 96 : 1];
+    static_assert(!ELL || (!KET && !BATCH), "the row-gather form serves whole unitaries of one handle");
     double* __restrict__ red = tscr;
     const int lane = threadIdx.x;
     const int m = BATCH ? P.m : hot_m;
@@ -358,6 +363,10 @@ __global__ __launch_bounds__(64) void qc_mfma16_pade4_hess_anti_kernel(const dou
     for (int u = 0; u < kHM; ++u) {
         const int k = u < m ? u : (m > 0 ? m - 1 : 0);
         gA[u] = load_img(GxA, m > 0 ? k + 1 : 0, lane);
+    }
+    if constexpr (ELL) {
+        fu_load_tables(P.ell16, m, lane, ellTW, ellTC);
+        fu_lds_order();
     }
     int vb = blockIdx.x;
     if (vb >= h_n_int) return;
@@ -418,7 +427,17 @@ __global__ __launch_bounds__(64) void qc_mfma16_pade4_hess_anti_kernel(const dou
         }
         // ---- stage A: G MD and G_k MD, interleaved ----------------------------------------------------------------------
         v4d Y, T[kHM];
-        {
+        if constexpr (ELL) {
+            fu_put_rows(tscr, MD, g, j);          // row-major copy of [M | c2 h^2 D]
+            fu_lds_order();
+            {   // (mm16_multi's single accumulator chain: the bits of the dense-image form)
+                v4d a1[1] = {Ga}, b1[1] = {MD}, d1[1];
+                mm16_multi<1>(a1, b1, d1);
+                Y = d1[0];
+            }
+            fu_gather_all<kHM>(ellTW, ellTC, tscr, g, j, T);
+            fu_lds_order();                       // (stage B rewrites the copy)
+        } else {
             constexpr int NA = 1 + kHM;
             v4d aA[NA], bA[NA], dA[NA];
             aA[0] = Ga;
@@ -464,15 +483,24 @@ __global__ __launch_bounds__(64) void qc_mfma16_pade4_hess_anti_kernel(const dou
 #pragma unroll
                 for (int p2 = 0; p2 < kHM / 2; ++p2) Q[p2] = __builtin_amdgcn_mfma_f64_16x16x4f64(Gs[kk], PNn[p2][kk], Q[p2], 0, 0, 0);
             }
+            if constexpr (ELL) {
+                fu_put_rows(tscr, YL, g, j);      // row-major copy of [2 c2 h (-M1) | 0]
+                fu_lds_order();
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
+                for (int p2 = 0; p2 < kHM / 2; ++p2) fu_gather_pair(ellTW, ellTC, tscr, p2, left, g, jj, Q[p2]);
+                fu_lds_order();                   // (the transposes below rewrite the scratch)
+                (void)YR;
+            } else {
 #pragma unroll
-                for (int p2 = 0; p2 < kHM / 2; ++p2) Q[p2] = __builtin_amdgcn_mfma_f64_16x16x4f64(gA[2 * p2][kk], YL[kk], Q[p2], 0, 0, 0);
-            }
+                for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
+                    for (int p2 = 0; p2 < kHM / 2; ++p2) Q[p2] = __builtin_amdgcn_mfma_f64_16x16x4f64(gA[2 * p2][kk], YL[kk], Q[p2], 0, 0, 0);
+                }
 #pragma unroll
-                for (int p2 = 0; p2 < kHM / 2; ++p2) Q[p2] = __builtin_amdgcn_mfma_f64_16x16x4f64(gA[2 * p2 + 1][kk], YR[kk], Q[p2], 0, 0, 0);
+                for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+                    for (int p2 = 0; p2 < kHM / 2; ++p2) Q[p2] = __builtin_amdgcn_mfma_f64_16x16x4f64(gA[2 * p2 + 1][kk], YR[kk], Q[p2], 0, 0, 0);
+                }
             }
         }
         QC_STAMP(P, b, lane, 5);                  // stage B issued
@@ -656,6 +684,17 @@ hipError_t qc_launch_mfma16_hess_batch(const QcParams& P0, const QcParams* dPb, 
     return hipGetLastError();
 }
 
+// mu_d2F alone beyond one device round takes the row-gather form where the handle's drives allow it (P.ell16): the launch is one wave per
+// interval, a latency chain that is mostly the 68 dependent f64 MFMAs -- 20 with the gathers: T = 1500 / 4000 / 8000 11.0 / 23.5 / 41.7 us
+// against 11.9 / 26.8 / 46.6 (without the 48 drive products at all, timing only: 8.8 / 19.2 / 34.7).  Not in the two-wave kernel of
+// shorter trajectories (hess2: 5.8 / 7.0 / 9.0 us against 6.1 / 7.2 / 8.9 at T = 250 / 500 / 1000 -- not worth a second form) and not
+// between 1.5 and 2 device rounds, where the persistent instantiation runs (16.1 - 16.9 us against 15.3 - 15.9 with the images).
+// QC_HESS_ELL=0: never.  (profiles/r05_hess_long.txt)
+bool qc_mfma16_hess_gathers(const QcParams& P) {
+    static const bool off = getenv("QC_HESS_ELL") && atoi(getenv("QC_HESS_ELL")) == 0;
+    return !off && P.ell16 != nullptr && P.antisym && P.n == 16 && P.nc == 8 && P.m >= 1 && P.m <= 6 && P.stamps == nullptr;
+}
+
 template <int HM, bool KET>
 static void launch_hess16(const QcParams& P, const double* dZ, const double* dMu, double* dH, hipStream_t st, int grid) {
     const bool once = grid == P.n_int;      // one interval per workgroup: the loop-free instantiations
@@ -663,6 +702,12 @@ static void launch_hess16(const QcParams& P, const double* dZ, const double* dMu
         if constexpr (HM == 6 && !KET) {
             if (once && P.stamps != nullptr) {   // diagnostic timeline (QC_STAMPS=1)
                 hipLaunchKernelGGL((qc_mfma16_pade4_hess_anti_kernel<HM, KET, false, true, true>), dim3(grid), dim3(64), 0, st, QC_HESS_HOT_ARGS(P), P, dZ, dMu, dH, nullptr);
+                return;
+            }
+        }
+        if constexpr (!KET && HM <= 6) {
+            if (once && qc_mfma16_hess_gathers(P)) {      // drive generators with one entry per row: the row-gather instantiation (loop-free launches)
+                hipLaunchKernelGGL((qc_mfma16_pade4_hess_anti_kernel<HM, KET, false, true, false, true>), dim3(grid), dim3(64), 0, st, QC_HESS_HOT_ARGS(P), P, dZ, dMu, dH, nullptr);
                 return;
             }
         }

@@ -34,6 +34,64 @@ __device__ __forceinline__ void fu_st_off(double* __restrict__ ubase, unsigned b
     qc_st8m<2>(reinterpret_cast<double*>(reinterpret_cast<char*>(ubase) + byteoff), v);
 }
 
+// ---- drive generators with ONE entry per row (Pauli strings: BASELINE configs 3 / 4), qc_mfma16_ell_build's tables ----------------------
+// Every product with a drive image, G_u X, is then a row gather from a row-major LDS copy of X, with the SAME BITS as the dense-image
+// product (v_mfma_f64_16x16x4_f64 is an ascending-k chain of fused multiply-adds, tests/hip/mfma_f64_fma_probe.hip: fifteen exact zeros
+// and one fma(w, x, acc) per element).  Used by the one-call kernel (qc_mfma_fused.hip) and the mu_d2F kernels (qc_mfma_hess.hip, hess2).
+constexpr int kXS = 17;                      // row stride of the row-major LDS copies the gathers read (doubles)
+
+// T_u = G_u X for every drive, G_u with one entry per row: lane (g, j) reg r = w_u[4 r + g] * X[c_u[4 r + g]][j], X from its row-major
+// copy xs (tw: [u][16] weights, tc: [u][16] columns x kXS, both in LDS; unused drive slots carry weight 0, column 0).  fma(w, x, +0):
+// what the dense product's accumulator chain holds.
+template <int kMU>
+__device__ __forceinline__ void fu_gather_all(const double* __restrict__ tw, const int* __restrict__ tc, const double* __restrict__ xs, int g, int j,
+                                              v4d (&out)[kMU]) {
+#pragma unroll
+    for (int u = 0; u < kMU; ++u) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = u * 16 + 4 * r + g;
+            out[u][r] = __builtin_fma(tw[row], xs[tc[row] + j], 0.0);
+        }
+    }
+}
+// lane (g, j) reg r = X[4 r + g][j]  ->  xs[(4 r + g) * kXS + j]
+__device__ __forceinline__ void fu_put_rows(double* __restrict__ xs, const v4d& x, int g, int j) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xs[(4 * r + g) * kXS + j] = x[r];
+}
+__device__ __forceinline__ void fu_lds_order() {     // a wave's LDS operations execute in order; this keeps the compiler from reordering them
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// The tables from the handle's blob (P.ell16: [6][16] weights, [6][16] columns x kXS) into LDS: 96 entries, lanes l and 64 + l.
+__device__ __forceinline__ void fu_load_tables(const void* blob, int m, int lane, double* __restrict__ tw_lds, int* __restrict__ tc_lds) {
+    typedef const __attribute__((address_space(1))) double* gdp;
+    typedef const __attribute__((address_space(1))) int* gip;
+    const gdp tw = (gdp)(unsigned long long)blob;
+    const gip tc = (gip)(unsigned long long)((const char*)blob + 6 * 16 * 8);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int e = 64 * q + lane;
+        if (e < 96) {
+            tw_lds[e] = e < 16 * m ? tw[e] : 0.0;
+            tc_lds[e] = e < 16 * m ? tc[e] : 0;
+        }
+    }
+}
+// Stage B's drive terms, Q_p += G_2p [y | 0] + G_2p+1 [0 | y]: a left lane's accumulator takes the one term w_2p[a] y[c_2p[a]][j], a right
+// lane's w_2p+1[a] y[c_2p+1[a]][j - 8]; every other term of the two dense chains is an exact zero.  ys: the row-major copy of [y | 0].
+__device__ __forceinline__ void fu_gather_pair(const double* __restrict__ tw, const int* __restrict__ tc, const double* __restrict__ ys, int pair, bool left,
+                                               int g, int jj, v4d& Q) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = (left ? 2 * pair : 2 * pair + 1) * 16 + 4 * r + g;
+        Q[r] = __builtin_fma(tw[row], ys[tc[row] + jj], Q[r]);
+    }
+}
+
 template <int kMU>
 struct FuRows {
     static constexpr int kAA = kMU * (kMU + 1) / 2, kPair = kMU / 2, kRows = kAA + kPair + 1;

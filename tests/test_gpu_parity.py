@@ -521,6 +521,39 @@ def test_full_size_every_value_against_the_c_oracle(qc, cfg, align):
     dyn.close()
 
 
+@pytest.mark.parametrize("m", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("free_time", [True, False])
+def test_row_gather_forms_every_value_against_the_c_oracle(qc, m, free_time):
+    """Pauli drives on three qubits (one entry per generator row), 1 .. 6 of them, more than one device round (T = 1100): mu_d2F alone and
+    the one-call launch take their row-gather forms (qc_mfma16_hess_gathers / qc_mfma16_fused_gathers: the 2-, 4- and 6-drive
+    instantiations).  EVERY value against the C oracle, and the one call bit for bit against the two launches."""
+    import torch
+    import oracle.qc_oracle_c as oc
+    full = qc.multi_qubit_system(3)
+    inp = qc.unitary_smooth_pulse_inputs(qc.QuantumSystem(full.H_drift, list(full.H_drives)[:m]), qc.GATES["TOFFOLI"], 1100, free_time=free_time)
+    prob = problem_from_inputs(inp)
+    prob.hess_align = 1
+    co = oc.COracle(prob)
+    rng = np.random.default_rng(40 + m)
+    Z = inp.traj.datavec + 1e-2 * rng.standard_normal(inp.traj.datavec.size)
+    mu = rng.standard_normal(prob.n_rows)
+    dyn = qc.QuantumDynamics(inp.integrators, inp.traj)
+    assert dyn.fused_kernel_name == "mfma16-pade4-fused-gather" and dyn.kernel_names[1] == "mfma16-pade4-hess"
+    F, J = dyn.F_dF(Z)
+    H = dyn.mu_d2F(Z, mu)
+    Fr, Jr = co.F_dF(Z)
+    Hr = co.mu_d2F(Z, mu)
+    assert_close(F, Fr, f"{m} Pauli drives F")
+    assert_close(J, Jr, f"{m} Pauli drives dF")
+    assert_close_h(H, Hr, f"{m} Pauli drives mu_d2F")
+    dZ, dmu = torch.from_numpy(Z).cuda(), torch.from_numpy(mu).cuda()
+    dF, dJ, dH = (torch.empty(int(n), dtype=torch.float64, device="cuda") for n in (dyn.dims.F_len, dyn.dims.jac_nnz, dyn.dims.hess_nnz))
+    dyn.F_dF_mu_d2F_device(dZ, dmu, dF, dJ, dH)
+    torch.cuda.synchronize()
+    assert np.array_equal(dF.cpu().numpy(), F) and np.array_equal(dJ.cpu().numpy(), J) and np.array_equal(dH.cpu().numpy(), H)
+    dyn.close()
+
+
 # ------------------------------------------------------------------------------------------------
 #  Exponential integrator (SURVEY A.6): residual, Jacobian, structure; no analytic Hessian
 # ------------------------------------------------------------------------------------------------
