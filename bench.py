@@ -36,6 +36,8 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s me
 # library's default, exactly the reference's structural entries (1 832 per interval at config 3).  The metric (F + dF) has no
 # Hessian in it and is the same under both.
 DEVICE_HESS_ALIGN = 16
+SIDE_STEPS = 2000            # launches per timed side leg (mu_d2F alone, F alone, the one-call form): a 500-launch window reads 0.2 - 0.3 us
+                             # per launch high (the first launches after a synchronize: dispatch latency, clocks) -- profiles/fused_bench.py on the same box
 T_PER_GPU = 1000
 RING_BYTES = 640 << 20
 
@@ -679,11 +681,11 @@ def main():
         one()
     torch.cuda.synchronize()
     s0.record(stream)
-    for _ in range(500):
+    for _ in range(SIDE_STEPS):
         one()
     s1.record(stream)
     torch.cuda.synchronize()
-    extra["step_us_one_output_buffer"] = s0.elapsed_time(s1) * 1e3 / 500
+    extra["step_us_one_output_buffer"] = s0.elapsed_time(s1) * 1e3 / SIDE_STEPS
     if args.hessian and dims.hess_nnz:
         mu = torch.from_numpy(rng.standard_normal(int(dims.n_rows))).to(dev)
         # a ring of value vectors beyond 2 x the Infinity Cache, like the F + dF outputs (one vector would stay cache-resident)
@@ -699,21 +701,21 @@ def main():
         torch.cuda.synchronize()
         h0, h1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         h0.record(stream)
-        for i in range(500):
+        for i in range(SIDE_STEPS):
             status[0] |= hl[i % hp]()
         h1.record(stream)
         torch.cuda.synchronize()
-        hess_us = h0.elapsed_time(h1) * 1e3 / 500
+        hess_us = h0.elapsed_time(h1) * 1e3 / SIDE_STEPS
         for i in range(50):
             status[0] |= fl[i & 3]()
         torch.cuda.synchronize()
         f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         f0.record(stream)
-        for i in range(500):
+        for i in range(SIDE_STEPS):
             status[0] |= fl[i & 3]()
         f1.record(stream)
         torch.cuda.synchronize()
-        F_us = f0.elapsed_time(f1) * 1e3 / 500
+        F_us = f0.elapsed_time(f1) * 1e3 / SIDE_STEPS
         assert status[0] == 0, "a device-resident launch reported an error"
         # F + dF + mu_d2F of one accepted point in ONE call (qc_eval_F_jac_hess_dev: one launch where a fused kernel serves the
         # handle, the two launches otherwise), over the same rings of output vectors
@@ -724,11 +726,11 @@ def main():
         torch.cuda.synchronize()
         u0, u1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         u0.record(stream)
-        for i in range(500):
+        for i in range(SIDE_STEPS):
             status[0] |= ful[i % len(ful)]()
         u1.record(stream)
         torch.cuda.synchronize()
-        fused_us = u0.elapsed_time(u1) * 1e3 / 500
+        fused_us = u0.elapsed_time(u1) * 1e3 / SIDE_STEPS
         assert status[0] == 0, "qc_eval_F_jac_hess_dev reported an error"
         del Hbs, ful, hl
         extra["hess_us"] = hess_us
