@@ -123,6 +123,12 @@ __device__ inline void swap32_f64(double& a, double& b) {   // a: [a.0 a.1 b.0 b
     a = __hiloint2double((int)hi[0], (int)lo[0]);
     b = __hiloint2double((int)hi[1], (int)lo[1]);
 }
+// x of lane l ^ 32, without the LDS crossbar (what __shfl_xor(x, 32) compiles to is two ds_bpermute_b32: an LDS round trip)
+__device__ inline double xor32_f64(double x, int lane) {
+    double a = x, b = x;
+    swap32_f64(a, b);                     // a: [x.lo | x.lo], b: [x.hi | x.hi]  (32-lane halves)
+    return lane < 32 ? b : a;
+}
 __device__ inline void swap16_rows_f64(double& a, double& b) {   // a: [a.0 b.0 a.2 b.2], b: [a.1 b.1 a.3 b.3]
     const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
     const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);

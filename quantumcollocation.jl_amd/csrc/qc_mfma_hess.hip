@@ -625,7 +625,7 @@ __global__ __launch_bounds__(64) void qc_mfma16_pade4_hess_anti_kernel(const dou
                     a3 += rp[16 * i + 3] + rp[16 * i + 7];
                 }
                 const double own = (a0 + a1) + (a2 + a3);
-                const double both = own + __shfl_xor(own, 32, 64);
+                const double both = own + xor32_f64(own, lane);
                 if (wanted) {
                     if (row < naa) {
                         if (half == 0) Hb[P.ho_aa + row] = both;

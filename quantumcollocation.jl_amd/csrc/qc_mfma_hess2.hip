@@ -76,7 +76,7 @@ __device__ __forceinline__ void h2_reduce(const QcParams& P, const double* __res
         a3 += rp[16 * i + 3] + rp[16 * i + 7];
     }
     const double own = (a0 + a1) + (a2 + a3);
-    const double both = own + __shfl_xor(own, 32, 64);
+    const double both = own + xor32_f64(own, lane);
     if (wanted) {
         if (aa_row) {
             if (half == 0) Hb[P.ho_aa + slot] = both;

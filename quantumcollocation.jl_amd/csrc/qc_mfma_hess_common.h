@@ -121,7 +121,7 @@ __device__ __forceinline__ void fu_reduce_rows(const QcParams& P, const double* 
             a3 += rp[16 * i + 3] + rp[16 * i + 7];
         }
         const double own = (a0 + a1) + (a2 + a3);
-        const double both = own + __shfl_xor(own, 32, 64);
+        const double both = own + xor32_f64(own, lane);
         if (wanted) {
             // staged: the interval's scalar run [(a, a) | (a, h) | (h, h) | (dx, h) | padding] is collected in LDS (`scal`, P.ho_aa at
             // index 0) and stored in one piece by fu_scalar_run_store; otherwise the entries go out one by one.  (Two branches, not one
