@@ -36,8 +36,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s me
 # library's default, exactly the reference's structural entries (1 832 per interval at config 3).  The metric (F + dF) has no
 # Hessian in it and is the same under both.
 DEVICE_HESS_ALIGN = 16
-SIDE_STEPS = 2000            # launches per timed side leg (mu_d2F alone, F alone, the one-call form): a 500-launch window reads 0.2 - 0.3 us
-                             # per launch high (the first launches after a synchronize: dispatch latency, clocks) -- profiles/fused_bench.py on the same box
+SIDE_STEPS = 500             # launches per timed side leg (mu_d2F alone, F alone, the one-call form, one output buffer); --side-steps
 T_PER_GPU = 1000
 RING_BYTES = 640 << 20
 
@@ -524,6 +523,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--side-steps", type=int, default=SIDE_STEPS, help="launches per timed side leg (2000-launch windows read the same: profiles/NOTES.md)")
     ap.add_argument("--prewarm-seconds", type=float, default=0.25,
                     help="untimed launches before the W warm-up steps (output ring touched, clocks up); 0: one pass over the ring only")
     ap.add_argument("--config", type=int, default=3, help="BASELINE config id (3 = metric workload)")
@@ -544,6 +544,7 @@ def main():
     ap.add_argument("--config5", action=argparse.BooleanOptionalAction, default=True,
                     help="at N = 1 also run BASELINE config 5 on the device and report its HBM / MFMA fractions (`config5` object)")
     args = ap.parse_args()
+    globals()["SIDE_STEPS"] = max(1, args.side_steps)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus))      # started without a launcher: this process becomes the parent of N ranks (no GPU call so far)
