@@ -234,34 +234,66 @@ __device__ inline void store_T32_columns(double* __restrict__ p, const ColumnPai
 
 // The (a_lo, a_hi) entry of the Hessian is c2 h^2 <G_lo G_hi + G_hi G_lo, Q>, Q = M D^T.  With R entries per generator row,
 //   (G_x G_y)[a][d] = sum_{q, q'} w_x[q][a] w_y[q'][c] at d = c_y[q'][c], c = c_x[q][a],
-// so the sum runs over 2 * 32 * R^2 terms (both orders x rows x entry choices): lane = (order, row), R^2 terms per lane, every factor
-// made from the drives' rows in LDS (TW: weights, TCr: raw columns) right behind barrier A, while the state is still on its way
-// (pair_consts: a weight and an offset into the plain Gram matrix per term), and multiplied with Q's entries later.  (Rounds 3 - 4 tabulated the merged
-// entries of G_lo G_hi + G_hi G_lo per pair at create time and every workgroup fetched its 28 KB of them from L2 with its first
-// loads: a third of the bytes of the request phase, 1.35 us of the config-5 launch -- profiles/r05_ell32_load_volume.txt.)
-// Rows with fewer than R entries carry weight 0 and column 0: a zero term.
-template <int R>
-__device__ __forceinline__ void pair_consts(const double* __restrict__ TW, const int* __restrict__ TCr, int lo, int hi, int lane, double (&wq)[R * R], int (&oq)[R * R]) {
-    const int a = lane & 31;
-    const bool second = (lane & 32) != 0;
-    const int x = second ? hi : lo, y = second ? lo : hi;       // (G_x G_y): the first factor's drive, the second's
-#pragma unroll
-    for (int q = 0; q < R; ++q) {
-        const double w1 = TW[(x * R + q) * 32 + a];
-        const int c = TCr[(x * R + q) * 32 + a];
-#pragma unroll
-        for (int q2 = 0; q2 < R; ++q2) {
-            wq[q * R + q2] = w1 * TW[(y * R + q2) * 32 + c];
-            oq[q * R + q2] = a * kQS + TCr[(y * R + q2) * 32 + c];
-        }
-    }
-}
-// pair index p = hi (hi + 1) / 2 + lo, lo <= hi  ->  (lo, hi)   (wave-uniform)
-// (branch-free: a loop here would put every pair's LDS reads into a basic block of their own, one round trip after the other)
+// so a pair is a sum of 2 * 32 * R^2 terms (both orders x rows x entry choices), every factor read from the drives' rows in LDS (TW:
+// weights, TCr: raw columns; rows with fewer than R entries carry weight 0 and column 0: a zero term).
+// Round 5, second form: ONE LANE PER PAIR (at most 36 pairs: lane p < npairs).  A wave takes a block of four rows and adds up, for every
+// pair at once, the block's 8 R^2 terms in a fixed order; the eight block sums of a pair meet in LDS and the wave that arrives last adds
+// them in block order and stores all pairs with one instruction.  No sum across lanes at all.  (First form of the round: lane = (order,
+// row) for five pairs per wave, per-pair constants made from the tables, five 64-lane wave sums per wave -- 420 instructions in every
+// wave's tail, 3 us of issue slots per SIMD, 1.7 us of the config-5 launch: profiles/r05_ell32_tail.txt.  Rounds 3 - 4 tabulated the
+// merged entries per pair at create time and every workgroup fetched its 28 KB of them from L2: a third of the request phase's bytes.)
+// The drives' rows sit kTS entries apart (odd): lanes of different drives read different LDS banks.
+template <int R> constexpr int kTSof = R * 32 + 1;
+// pair index p = hi (hi + 1) / 2 + lo, lo <= hi  ->  (lo, hi), per lane
 __device__ __forceinline__ void pair_decode(int p, int& lo, int& hi) {
     static_assert(kEMax <= 8, "thresholds below: hi < 8");
     hi = (p >= 1) + (p >= 3) + (p >= 6) + (p >= 10) + (p >= 15) + (p >= 21) + (p >= 28);
     lo = p - hi * (hi + 1) / 2;
+}
+// Sum of the terms of rows [4 blk, 4 blk + 4) of the lane's pair (lo, hi): rows ascending, order (lo, hi) before (hi, lo), q before q'.
+// Eight terms at a time (four rows with one entry per row, one row with two): three LDS round trips per batch -- the first factors,
+// the second factors at the columns just read, Q's entries -- then the batch's products are added in term order.
+template <int R>
+__device__ __forceinline__ double pair_block_sum(const double* __restrict__ TW, const int* __restrict__ TCr, const double* __restrict__ Qp, int lo, int hi, int blk) {
+    constexpr int kTS = kTSof<R>;
+    constexpr int kRows = R == 1 ? 4 : 1;         // rows per batch
+    constexpr int kT = 2 * kRows * R * R;         // terms per batch
+    static_assert(kT == 8, "eight terms per batch");
+    double acc = 0.0;
+#pragma unroll
+    for (int i0 = 0; i0 < 4; i0 += kRows) {
+        double w1[2 * kRows * R], w2[kT], qv[kT];
+        int c1[2 * kRows * R], d2[kT];
+#pragma unroll
+        for (int i = 0; i < kRows; ++i) {
+#pragma unroll
+            for (int o = 0; o < 2; ++o) {
+#pragma unroll
+                for (int q = 0; q < R; ++q) {
+                    const int x = o ? hi : lo, at = x * kTS + q * 32 + 4 * blk + i0 + i;
+                    w1[(2 * i + o) * R + q] = TW[at];
+                    c1[(2 * i + o) * R + q] = TCr[at];
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int f = 0; f < 2 * kRows * R; ++f) {
+#pragma unroll
+            for (int q2 = 0; q2 < R; ++q2) {
+                const int y = ((f / R) & 1) ? lo : hi, at = y * kTS + q2 * 32 + c1[f];
+                w2[f * R + q2] = TW[at];
+                d2[f * R + q2] = TCr[at];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < kT; ++e) qv[e] = Qp[(4 * blk + i0 + e / (2 * R * R)) * kQS + d2[e]];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < kT; ++e) acc += (w1[e / R] * w2[e]) * qv[e];
+    }
+    return acc;
 }
 
 // Hand-offs between the waves of a workgroup through counters in LDS (the copy waves of the fused kernel must not stand at a
@@ -290,13 +322,11 @@ __global__ __launch_bounds__(kEThreads, 4) void qc_mfma32_ell_kernel(const doubl
                                                                      double* __restrict__ F, double* __restrict__ Jv, double* __restrict__ H) {
     constexpr int kFirst = JAC ? 2 : 0;           // first compute wave (waves 0, 1 of a JAC instantiation are the copy waves)
     constexpr int kCW = 8 - kFirst;               // compute waves
-    constexpr int kPairsPerWave = (kEMax * (kEMax + 1) / 2 + kCW - 1) / kCW;
     constexpr int kDrivesPerWave = (kEMax + kCW - 1) / kCW;
-    // The pair sums: their constants (pair_consts: LDS only, no loads) are made right behind barrier A.  mu_d2F alone with R = 1 holds
-    // them (one weight and one offset per pair) through its drives and sums at the very end, in one batched reduction with the (a_k, h)
-    // sums (measured: summing them before the first drive delays every drive's products by 1 us and the launch by 0.7).  The one-call
-    // form and R = 2 (four terms per lane and pair) have no registers for that: they sum EARLY, as soon as Q is there.
-    constexpr bool kEarlyPairs = HESS && (JAC || R != 1);
+    // The pair sums (pair_sums below) need Q only.  mu_d2F alone with R = 1 makes them at the very end, behind its drives (measured with the
+    // round's first form: summing them before the first drive delays every drive's products by 1 us and the launch by 0.7); the one-call
+    // form and R = 2 make them EARLY, as soon as Q is there (their drives have no registers to spare for anything held across them).
+    constexpr bool kEarlyPairs = HESS && (JAC || R != 1);      // (the one-call form with the sums at the end instead: the same 36.6 - 36.8 us)
     constexpr int kDF = 2;                        // derivative integrators whose data is requested early and parked in LDS (JAC): the templates have two
     QcKernargTouch<sizeof(QcParams) + 96> touch;
     touch.request();
@@ -305,9 +335,12 @@ __global__ __launch_bounds__(kEThreads, 4) void qc_mfma32_ell_kernel(const doubl
     // M, D, S, E = G M, G D, W = -c1 S + 2 c2 h G D
     __shared__ double Mp[32 * kPS], Dp[32 * kPS], Sp[32 * kPS], Ep[32 * kPS], GDp[32 * kPS], Wp[32 * kPS];
     __shared__ double Qp[32 * kQS];                                  // Q = M D^T
-    __shared__ double TW[kEMax * R * 32];                            // the drives' rows: weights ...
-    __shared__ int TC[kEMax * R * 32];                               // ... and columns (x kPS)
-    __shared__ int TCr[kEMax * R * 32];                              // ... and the raw columns (pair sums)
+    constexpr int kTS = kTSof<R>;                                    // entries between two drives' rows (odd: see pair_block_sum)
+    __shared__ double TW[kEMax * kTS];                               // the drives' rows: weights ...
+    __shared__ int TC[kEMax * kTS];                                  // ... and columns (x kPS)
+    __shared__ int TCr[kEMax * kTS];                                 // ... and the raw columns (pair sums)
+    __shared__ double PS[HESS ? 8 * 64 : 1];                         // the pairs' block sums: [block of four rows][pair]
+    __shared__ int ps_count;
     __shared__ int flags[FL_COUNT];
     __shared__ double DerL[2 * kDF * 64];                            // derivative-integrator data (JAC), parked from the first loads to the end
     const int tid = threadIdx.x;
@@ -397,9 +430,10 @@ __global__ __launch_bounds__(kEThreads, 4) void qc_mfma32_ell_kernel(const doubl
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int sl = 0; sl < SLOTS; ++sl) Gh += v2d{__shfl(amp, k0[sl]), __shfl(amp, k1[sl])} * wv[sl];
-        if (w < m && lane < 32 * R && !f_only) { TW[w * R * 32 + lane] = twv; TC[w * R * 32 + lane] = tcv; TCr[w * R * 32 + lane] = tcv / kPS; }
+        if (w < m && lane < 32 * R && !f_only) { TW[w * kTS + lane] = twv; TC[w * kTS + lane] = tcv; TCr[w * kTS + lane] = tcv / kPS; }
         reinterpret_cast<v2d*>(GL)[e0 >> 1] = Gh;
         if (tid < FL_COUNT) flags[tid] = 0;
+        if (tid == FL_COUNT) ps_count = 0;
     }
     touch.consume();
     double* __restrict__ Hb = HESS ? H + (size_t)b * P.H_stride + P.H_off : nullptr;
@@ -414,23 +448,25 @@ __global__ __launch_bounds__(kEThreads, 4) void qc_mfma32_ell_kernel(const doubl
     __syncthreads();                  // G, the tables and the zeroed counters; the state is still on its way
     const double hc1 = h * c1, hc2 = h * h * c2, c2h2 = 2.0 * c2 * h;
     QC_STAMP(P, b, lane, 2);
-    double wq[kPairsPerWave][R * R];      // this wave's pairs: the constants of their terms
-    int oq[kPairsPerWave][R * R];
-    auto make_pair_consts = [&]() {
+    // The pair sums (pair_block_sum above): this wave's blocks of rows for every pair (lane = pair), handed over through LDS; the wave
+    // that arrives last adds the eight block sums of each pair in block order and stores the pairs' run.  Needs Q (FL_Q).
+    auto pair_sums = [&]() {
+        int plo, phi;
+        pair_decode(lane < npairs ? lane : 0, plo, phi);       // (lanes beyond the last pair repeat pair 0: never stored)
+        flag_wait(flags, FL_Q, 1);
+        for (int blk = cw; blk < 8; blk += kCW) PS[blk * 64 + lane] = pair_block_sum<R>(TW, TCr, Qp, plo, phi, blk);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        int old = 0;
+        if (lane == 0) old = __hip_atomic_fetch_add(&ps_count, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+        old = __builtin_amdgcn_readfirstlane(old);
+        if (old == kCW - 1) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            double sum = PS[lane];
 #pragma unroll
-        for (int t = 0; t < kPairsPerWave; ++t) {
-            const int p = cw + kCW * t;
-            int lo, hi;
-            pair_decode(p < npairs ? p : 0, lo, hi);          // (clamped: the value of a pair beyond the last is never stored)
-            pair_consts<R>(TW, TCr, lo, hi, lane, wq[t], oq[t]);
+            for (int blk = 1; blk < 8; ++blk) sum += PS[blk * 64 + lane];
+            if (lane < npairs) Hb[P.ho_aa + lane] = hc2 * sum;
         }
     };
-    // Made right in front of their use, as straight-line code (the reads of all pairs batch up: three LDS round trips in all).  Making
-    // them early -- behind barrier A, in the shadow of the state's round trip -- was measured twice: as it stands the registers they go
-    // to are the destinations of loads still in flight (the late group), so the wave waits for those first and the state is published
-    // 1.1 us later; with those registers kept out of the allocator's hands up to the state flags the loader waves of the SECOND workgroup
-    // of the compute unit, which run in the issue slots the first one's waves leave, finish their constants only at 6.2 us and their drive
-    // as late as before: 13.5 - 13.6 against 13.6 - 13.8 us, not worth 27 registers (profiles/NOTES.md, round 5).
 
     if (JAC && cw < 0) {
         if (f_only) return;
@@ -526,27 +562,7 @@ __global__ __launch_bounds__(kEThreads, 4) void qc_mfma32_ell_kernel(const doubl
             }
             flag_signal(flags, FL_Q, lane);
         }
-        if constexpr (kEarlyPairs) {
-            // ---- this wave's share of the pair sums, early -----------------------------------------------------------------------------
-            make_pair_consts();
-            flag_wait(flags, FL_Q, 1);
-            double ps[kPairsPerWave];
-#pragma unroll
-            for (int t = 0; t < kPairsPerWave; ++t) {
-                double acc = wq[t][0] * Qp[oq[t][0]];
-#pragma unroll
-                for (int e = 1; e < R * R; ++e) acc += wq[t][e] * Qp[oq[t][e]];
-                ps[t] = acc;
-            }
-            wave_sum_multi<kPairsPerWave>(ps);
-            if (lane == 0) {
-#pragma unroll
-                for (int t = 0; t < kPairsPerWave; ++t) {
-                    const int p = cw + kCW * t;
-                    if (p < npairs) Hb[P.ho_aa + p] = hc2 * ps[t];
-                }
-            }
-        }
+        if constexpr (kEarlyPairs) pair_sums();      // early: as soon as Q is there (see kEarlyPairs)
         // ---- this wave's drives ---------------------------------------------------------------------------------------------
         double pv[kDrivesPerWave];
 #pragma unroll
@@ -554,8 +570,8 @@ __global__ __launch_bounds__(kEThreads, 4) void qc_mfma32_ell_kernel(const doubl
             pv[t] = 0.0;
             const int k = cw + kCW * t;
             if (k < m && !f_only) {
-                const double* __restrict__ tw = TW + k * R * 32;
-                const int* __restrict__ tc = TC + k * R * 32;
+                const double* __restrict__ tw = TW + k * kTS;
+                const int* __restrict__ tc = TC + k * kTS;
                 v4d Vk[2], Yk[2], TV[2], TY[2];
                 gather_rows_operand<R>(tw, tc, Dp, g, j, Vk);                   // V_k = G_k D
                 if constexpr (HESS) gather_rows_operand<R>(tw, tc, Mp, g, j, Yk);   // Y_k = G_k M
@@ -648,40 +664,18 @@ __global__ __launch_bounds__(kEThreads, 4) void qc_mfma32_ell_kernel(const doubl
             }
         }
         if constexpr (HESS && !JAC) __builtin_amdgcn_s_setprio(0);      // the tail (see the kernel's entry)
-        if constexpr (HESS) {     // the (a_k, h) of this wave's drives -- and, where they have not been summed early, its pair sums: one batched reduction
-            if constexpr (kEarlyPairs) {
-                if (ft) {
-                    wave_sum_multi<kDrivesPerWave>(pv);
-                    if (lane == 0) {
-#pragma unroll
-                        for (int t = 0; t < kDrivesPerWave; ++t) {
-                            const int k = cw + kCW * t;
-                            if (k < m) Hb[P.ho_ah + k] = pv[t];
-                        }
-                    }
-                }
-            } else {
-                double pq[kDrivesPerWave + kPairsPerWave];
-#pragma unroll
-                for (int t = 0; t < kDrivesPerWave; ++t) pq[t] = pv[t];
-                make_pair_consts();
-                flag_wait(flags, FL_Q, 1);
-#pragma unroll
-                for (int t = 0; t < kPairsPerWave; ++t) pq[kDrivesPerWave + t] = wq[t][0] * Qp[oq[t][0]];
-                wave_sum_multi<kDrivesPerWave + kPairsPerWave>(pq);
+        if constexpr (HESS) {     // the (a_k, h) of this wave's drives; the pair sums where they have not been made early
+            if (ft) {
+                wave_sum_multi<kDrivesPerWave>(pv);
                 if (lane == 0) {
 #pragma unroll
                     for (int t = 0; t < kDrivesPerWave; ++t) {
                         const int k = cw + kCW * t;
-                        if (ft && k < m) Hb[P.ho_ah + k] = pq[t];
-                    }
-#pragma unroll
-                    for (int t = 0; t < kPairsPerWave; ++t) {
-                        const int p = cw + kCW * t;
-                        if (p < npairs) Hb[P.ho_aa + p] = hc2 * pq[kDrivesPerWave + t];
+                        if (k < m) Hb[P.ho_ah + k] = pv[t];
                     }
                 }
             }
+            if constexpr (!kEarlyPairs) pair_sums();
         }
         // ---- the shared blocks ---------------------------------------------------------------------------------------------------
         if (JAC && cw == kCW - 1) {       // residual and d/dh: D - hc1 G S + hc2 G (G D);  -c1 G S + 2 c2 h G (G D)
