@@ -36,6 +36,8 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s me
 # library's default, exactly the reference's structural entries (1 832 per interval at config 3).  The metric (F + dF) has no
 # Hessian in it and is the same under both.
 DEVICE_HESS_ALIGN = 16
+SIDE_WARM = 1000             # untimed launches in front of every timed side leg: behind the light residual-only leg a 50-launch warm-up left the
+                             # one-call launch 0.4 - 0.5 us slow (13.05 against 12.6 us on the same box; profiles/fused_bench.py: 12.65)
 SIDE_STEPS = 500             # launches per timed side leg (mu_d2F alone, F alone, the one-call form, one output buffer); --side-steps
 T_PER_GPU = 1000
 RING_BYTES = 640 << 20
@@ -363,7 +365,7 @@ def config5_record(qc, dev_index, steps=300):
     st = torch.cuda.current_stream(dev)
 
     def timed(fn):
-        for i in range(20):
+        for i in range(200):     # (a short warm-up reads 0.3 - 0.5 us high behind a lighter leg: SIDE_WARM above)
             fn(i)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -467,7 +469,7 @@ def long_trajectory_record(qc, dev_index, T=8000, steps=200):
     status = [0]
 
     def timed(calls):
-        for i in range(10):
+        for i in range(60):
             status[0] |= calls[i % len(calls)]()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -697,7 +699,7 @@ def main():
         hp = int(nh * 4 // np.gcd(nh, 4))
         hl = [dyn.bind_mu_d2F_device(Zs[i & 3], mu, Hbs[i % nh], stream) for i in range(hp)]
         fl = [dyn.bind_F_dF_device(Zs[i & 3], Fb[0], None, stream) for i in range(4)]
-        for i in range(50):
+        for i in range(SIDE_WARM):
             status[0] |= hl[i % hp]()
         torch.cuda.synchronize()
         h0, h1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -707,8 +709,8 @@ def main():
         h1.record(stream)
         torch.cuda.synchronize()
         hess_us = h0.elapsed_time(h1) * 1e3 / SIDE_STEPS
-        for i in range(50):
-            status[0] |= fl[i & 3]()
+        for i in range(50):      # (not SIDE_WARM: a long run of these 4 us launches alone lets the device clock down -- 5.5 - 5.8 us; a line search's
+            status[0] |= fl[i & 3]()      #  residual calls sit between heavier ones)
         torch.cuda.synchronize()
         f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         f0.record(stream)
@@ -722,7 +724,7 @@ def main():
         # handle, the two launches otherwise), over the same rings of output vectors
         fp = int(np.lcm(np.lcm(nbuf, nh), 4))
         ful = [dyn.bind_F_dF_mu_d2F_device(Zs[i & 3], mu, Fb[i % nbuf], Jb[i % nbuf], Hbs[i % nh], stream) for i in range(min(fp, 4 * max(nbuf, nh)))]
-        for i in range(50):
+        for i in range(SIDE_WARM):
             status[0] |= ful[i % len(ful)]()
         torch.cuda.synchronize()
         u0, u1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
