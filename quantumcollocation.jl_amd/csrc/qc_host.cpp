@@ -540,6 +540,7 @@ extern "C" const char* qc_kernel_name(const qc_handle* h, int32_t which) {
     if (which == 2) return mfma && qc_mfma16_fused_supported(P) ? (qc_mfma16_fused_gathers(P) ? "mfma16-pade4-fused-gather" : "mfma16-pade4-fused") : (mfma && P.ell && P.hess_nnz ? "mfma32-pade4-fused-ell" : "two-launches");
     if (mfma && qc_mfma_hess_supported(P)) {
         if (qc_mfma16_padeP_hess_supported(P)) return "mfma16-padeP-hess";
+        if (P.n == 16 && qc_mfma16_hess_gathers(P)) return "mfma16-pade4-hess-gather";      // one entry per drive-generator row: the one-wave kernel's row-gather form
         if (qc_mfma16_hess2_supported(P)) return "mfma16-pade4-hess2";
         if (P.n > 16 && P.n <= 32 && P.ell) return "mfma32-pade4-hess-ell";
         return P.n > 32 ? "mfma64-pade4-hess" : (P.n > 16 ? "mfma32-pade4-hess" : "mfma16-pade4-hess");

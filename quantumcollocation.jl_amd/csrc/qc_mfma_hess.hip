@@ -340,7 +340,9 @@ __global__ __launch_bounds__(64) void qc_mfma16_pade4_hess_anti_kernel(const dou
     constexpr int kTrRound = 4;
     constexpr int kScrTiles = kHM + 1 < kTrRound ? kHM + 1 : kTrRound;
     constexpr int kScrLen = kScrTiles * 272 > R::kRows * kHStride ? kScrTiles * 272 : R::kRows * kHStride;
-    __shared__ double tsave[kHM * 256];           // the stage-A tiles T_k, parked for the (a, a) sums (registers: see below)
+    // (ELL keeps the T_k in registers -- it holds no drive image through stage B --: 14.6 KB of LDS, eight workgroups per CU)
+    constexpr bool kPark = !ELL;
+    __shared__ double tsave[kPark ? kHM * 256 : 1];   // the stage-A tiles T_k, parked for the (a, a) sums (registers: see below)
     __shared__ double tscr[kScrLen];
     __shared__ double ellTW[ELL ? 96 : 1];        // ELL: the drives' rows (weights; columns x kXS)
     __shared__ int ellTC[ELL ? 96 : 1];
@@ -459,7 +461,7 @@ __global__ __launch_bounds__(64) void qc_mfma16_pade4_hess_anti_kernel(const dou
 #pragma unroll
         for (int u = 0; u < kHM; ++u) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) tsave[(u * 4 + r) * 64 + lane] = T[u][r];
+            for (int r = 0; r < 4; ++r) { if constexpr (kPark) tsave[(u * 4 + r) * 64 + lane] = T[u][r]; }
         }
         // ---- stage B ------------------------------------------------------------------------------------------------------
         v4d PNn[kHM / 2], Q[kHM / 2], Y2;                   // [-N_k | -N_k+1], 2 c2 h [N'' + N' pairs], [M2 | .]
@@ -586,13 +588,13 @@ __global__ __launch_bounds__(64) void qc_mfma16_pade4_hess_anti_kernel(const dou
 #pragma unroll
             for (int u = 0; u < kHM; ++u) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) Tn[u][r] = -tsave[(u * 4 + r) * 64 + lane];
+                for (int r = 0; r < 4; ++r) Tn[u][r] = kPark ? -tsave[(u * 4 + r) * 64 + lane] : -T[u][r];
             }
 #pragma unroll
             for (int v = 0; v < kHM; ++v) {
                 v4d Tsw;                                    // swap8(T_v)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) Tsw[r] = tsave[(v * 4 + r) * 64 + (lane ^ 8)];
+                for (int r = 0; r < 4; ++r) Tsw[r] = kPark ? tsave[(v * 4 + r) * 64 + (lane ^ 8)] : swap8(T[v][r]);
 #pragma unroll
                 for (int u = 0; u <= v; ++u) red[(v * (v + 1) / 2 + u) * kHStride + lane] = dot4(Tn[u], Tsw);
             }
@@ -684,12 +686,11 @@ hipError_t qc_launch_mfma16_hess_batch(const QcParams& P0, const QcParams* dPb, 
     return hipGetLastError();
 }
 
-// mu_d2F alone beyond one device round takes the row-gather form where the handle's drives allow it (P.ell16): the launch is one wave per
-// interval, a latency chain that is mostly the 68 dependent f64 MFMAs -- 20 with the gathers: T = 1500 / 4000 / 8000 11.0 / 23.5 / 41.7 us
-// against 11.9 / 26.8 / 46.6 (without the 48 drive products at all, timing only: 8.8 / 19.2 / 34.7).  Not in the two-wave kernel of
-// shorter trajectories (hess2: 5.8 / 7.0 / 9.0 us against 6.1 / 7.2 / 8.9 at T = 250 / 500 / 1000 -- not worth a second form) and not
-// between 1.5 and 2 device rounds, where the persistent instantiation runs (16.1 - 16.9 us against 15.3 - 15.9 with the images).
-// QC_HESS_ELL=0: never.  (profiles/r05_hess_long.txt)
+// mu_d2F alone takes the row-gather form of the one-wave kernel wherever the handle's drives allow it (P.ell16): the launch is a latency
+// chain per interval, mostly the 68 dependent f64 MFMAs -- 20 with the gathers -- and, holding no drive image through stage B, the form
+// keeps its stage-A tiles in registers instead of LDS: 14 KB of LDS and 217 registers, EIGHT workgroups per CU (the dense-image form:
+// six; round 4: four).  T = 1000 / 2000 / 4000 / 8000 / 32000: 8.1 / 11.5 / 20.4 / 38.1 / 120 us against 8.7 (two-wave kernel) / 15.7 / 23.9 /
+// 42.3 / 140 with the gathers but six per CU, and 8.7 / 15.4 / 25.9 / 47.2 / 173 in round 4 (profiles/r05_hess_long.txt).  QC_HESS_ELL=0: never.
 bool qc_mfma16_hess_gathers(const QcParams& P) {
     static const bool off = getenv("QC_HESS_ELL") && atoi(getenv("QC_HESS_ELL")) == 0;
     return !off && P.ell16 != nullptr && P.antisym && P.n == 16 && P.nc == 8 && P.m >= 1 && P.m <= 6 && P.stamps == nullptr;
@@ -723,7 +724,9 @@ hipError_t qc_launch_mfma_hess(const QcParams& P, const double* dZ, const double
     if (qc_mfma16_padeP_hess_supported(P)) return qc_launch_mfma16_padeP_hess(P, dZ, dMu, dH, st);
     if (P.n > 32) return qc_launch_mfma64_hess(P, dZ, dMu, dH, st);
     if (P.n > 16) return P.ell ? qc_launch_mfma32_ell_hess(P, dZ, dMu, dH, st) : qc_launch_mfma32_hess(P, dZ, dMu, dH, st);
-    if (qc_mfma16_hess2_supported(P)) return qc_launch_mfma16_hess2(P, dZ, dMu, dH, st);     // two waves per interval, up to one round of the device (qc_mfma_hess2.hip)
+    // two waves per interval up to one round of the device (qc_mfma_hess2.hip) -- unless the drives allow the one-wave kernel's row-gather
+    // form, which keeps eight workgroups per CU resident and is faster at every length (T = 750 / 1000: 7.85 / 8.12 against 8.08 / 8.74 us)
+    if (qc_mfma16_hess2_supported(P) && !qc_mfma16_hess_gathers(P)) return qc_launch_mfma16_hess2(P, dZ, dMu, dH, st);
     // One interval per workgroup at any length (round 5: the loop-free instantiation needs 228 registers and 25.3 KB of LDS at six
     // drives -- six workgroups per CU, the hardware refilling each CU as its workgroups retire; the persistent loop's instantiation
     // needs 308 registers, four per CU).  T = 3000 / 4000 / 8000 / 32000: 20.1 / 25.8 / 45.9 / 156.9 us against 20.8 / 25.9 / 47.0 / 172.8
@@ -732,7 +735,7 @@ hipError_t qc_launch_mfma_hess(const QcParams& P, const double* dZ, const double
     static const int once_max = getenv("QC_HESS_ONCE_MAX") ? atoi(getenv("QC_HESS_ONCE_MAX")) : (1 << 30);
     // Six workgroups per CU live 8.2 instead of 6.5 - 7.4 us each: between 1.5 and 2 rounds of the device that is a loss (two rounds either
     // way: T = 2000 17.7 against 15.4 us) -- there the persistent instantiation (four per CU) with one round of workgroups stays.
-    const bool window = P.antisym && P.m > 4 && P.m <= 6 && P.n_int > 1536 && P.n_int <= 2048;
+    const bool window = P.antisym && P.m > 4 && P.m <= 6 && P.n_int > 1536 && P.n_int <= 2048 && !qc_mfma16_hess_gathers(P);   // (the row-gather form: eight per CU, one round)
     const int grid = (P.n_int <= once_max && !window) ? P.n_int : (P.n_int < grid_cap ? P.n_int : grid_cap);
     if (P.nc != 8 || P.n != 16) {
         if (P.m <= 2) launch_hess16<2, true>(P, dZ, dMu, dH, st, grid);

@@ -538,7 +538,7 @@ def test_row_gather_forms_every_value_against_the_c_oracle(qc, m, free_time):
     Z = inp.traj.datavec + 1e-2 * rng.standard_normal(inp.traj.datavec.size)
     mu = rng.standard_normal(prob.n_rows)
     dyn = qc.QuantumDynamics(inp.integrators, inp.traj)
-    assert dyn.fused_kernel_name == "mfma16-pade4-fused-gather" and dyn.kernel_names[1] == "mfma16-pade4-hess"
+    assert dyn.fused_kernel_name == "mfma16-pade4-fused-gather" and dyn.kernel_names[1] == "mfma16-pade4-hess-gather"
     F, J = dyn.F_dF(Z)
     H = dyn.mu_d2F(Z, mu)
     Fr, Jr = co.F_dF(Z)
@@ -1621,7 +1621,7 @@ def test_any_order_mfma_kernel_matches_oracle(qc, oracle, order, N, m, ncol, fre
 def test_kernel_names_of_the_baseline_configurations(qc):
     """Which device kernels serve BASELINE.json's configurations (qc_kernel_name): the tuned MFMA kernels, not a generic path."""
     expect = {1: ("mfma16-pade4", "mfma16-pade4-hess"), 2: ("mfma16-pade4", "mfma16-pade4-hess"),
-              3: ("mfma16-pade4", "mfma16-pade4-hess2"), 5: ("mfma32-pade4-ell", "mfma32-pade4-hess-ell")}     # (hess2: two waves per interval, <= 1024 intervals; ell: Pauli drives are row gathers)
+              3: ("mfma16-pade4", "mfma16-pade4-hess-gather"), 5: ("mfma32-pade4-ell", "mfma32-pade4-hess-ell")}     # (hess-gather: Pauli drives are row gathers in the one-wave kernel; hess2 = two waves per interval, <= 1024 intervals, dense drives; ell: Pauli drives are row gathers)
     for cfg, names in expect.items():
         inp = qc.config_inputs(cfg, T=5)
         dyn = qc.QuantumDynamics(inp.integrators, inp.traj)

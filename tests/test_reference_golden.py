@@ -25,7 +25,7 @@ EXPECTED_KERNELS = {
     "ref_fixture.json": ("mfma16-pade4", "mfma16-pade4-hess", "two-launches"),
     "ref_config1.json": ("mfma16-pade4", "mfma16-pade4-hess", "two-launches"),
     "ref_config2.json": ("mfma16-pade4", "mfma16-pade4-hess", "two-launches"),
-    "ref_toffoli3.json": ("mfma16-pade4", "mfma16-pade4-hess2", "mfma16-pade4-fused"),
+    "ref_toffoli3.json": ("mfma16-pade4", "mfma16-pade4-hess-gather", "mfma16-pade4-fused"),
     "ref_qft4.json": ("mfma32-pade4-ell", "mfma32-pade4-hess-ell", "mfma32-pade4-fused-ell"),
     "ref_order6.json": ("mfma16-padeP", "mfma16-padeP-hess", "two-launches"),
     "ref_bangbang.json": ("mfma16-padeP", "mfma16-padeP-hess", "two-launches"),
