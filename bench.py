@@ -699,6 +699,19 @@ def main():
         hp = int(nh * 4 // np.gcd(nh, 4))
         hl = [dyn.bind_mu_d2F_device(Zs[i & 3], mu, Hbs[i % nh], stream) for i in range(hp)]
         fl = [dyn.bind_F_dF_device(Zs[i & 3], Fb[0], None, stream) for i in range(4)]
+        # (the residual-only leg FIRST, right behind the F + dF launches above, and behind 50 untimed launches only: a long run of these 4 us
+        #  launches -- or of the lighter mu_d2F launches in front of them -- lets the device clock down, 5.1 - 5.8 us instead of 4.3 - 4.9;
+        #  a line search's residual calls sit between heavier ones)
+        for i in range(50):
+            status[0] |= fl[i & 3]()
+        torch.cuda.synchronize()
+        f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        f0.record(stream)
+        for i in range(SIDE_STEPS):
+            status[0] |= fl[i & 3]()
+        f1.record(stream)
+        torch.cuda.synchronize()
+        F_us = f0.elapsed_time(f1) * 1e3 / SIDE_STEPS
         for i in range(SIDE_WARM):
             status[0] |= hl[i % hp]()
         torch.cuda.synchronize()
@@ -709,16 +722,6 @@ def main():
         h1.record(stream)
         torch.cuda.synchronize()
         hess_us = h0.elapsed_time(h1) * 1e3 / SIDE_STEPS
-        for i in range(50):      # (not SIDE_WARM: a long run of these 4 us launches alone lets the device clock down -- 5.5 - 5.8 us; a line search's
-            status[0] |= fl[i & 3]()      #  residual calls sit between heavier ones)
-        torch.cuda.synchronize()
-        f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        f0.record(stream)
-        for i in range(SIDE_STEPS):
-            status[0] |= fl[i & 3]()
-        f1.record(stream)
-        torch.cuda.synchronize()
-        F_us = f0.elapsed_time(f1) * 1e3 / SIDE_STEPS
         assert status[0] == 0, "a device-resident launch reported an error"
         # F + dF + mu_d2F of one accepted point in ONE call (qc_eval_F_jac_hess_dev: one launch where a fused kernel serves the
         # handle, the two launches otherwise), over the same rings of output vectors
