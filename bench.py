@@ -521,6 +521,7 @@ def launch_ranks(n: int) -> int:
 
 
 def main():
+    global SIDE_STEPS
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
@@ -546,7 +547,7 @@ def main():
     ap.add_argument("--config5", action=argparse.BooleanOptionalAction, default=True,
                     help="at N = 1 also run BASELINE config 5 on the device and report its HBM / MFMA fractions (`config5` object)")
     args = ap.parse_args()
-    globals()["SIDE_STEPS"] = max(1, args.side_steps)
+    SIDE_STEPS = max(1, args.side_steps)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus))      # started without a launcher: this process becomes the parent of N ranks (no GPU call so far)
