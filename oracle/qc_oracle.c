@@ -15,7 +15,7 @@
  *   delta = B U_{t+1} - F U_t            README.md:74-80 / docstring :10-30
  *   d/dU blocks I_N (x) B, -I_N (x) F;  d/da_j, d/dh columns                      
  *   x_{t+1} - x_t - h dx_t               DerivativeIntegrator                       (:15-16,177-178)
- *   mu-contracted Hessian blocks                                                    
+ *   mu-contracted Hessian blocks                                                    (exponential: interval_hess_exp)
  * Value order = the canonical block order of oracle/qc_oracle.py::jac_structure_local.
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
@@ -91,11 +91,11 @@ int qco_jac_nnz(const qco_problem* P) {
     return o;
 }
 int qco_hess_nnz(const qco_problem* P) {
-    if (P->integrator != 0) return 0;
-    const int n = 2 * P->N, s = n * qco_nc(P), m = P->m, ft = P->off_dt >= 0;
-    int o = 2 * s * m + m * (m + 1) / 2;
+    /* the exponential integrator is linear in U_{t+1}: no (a, U_{t+1}), (h, U_{t+1}) blocks */
+    const int n = 2 * P->N, s = n * qco_nc(P), m = P->m, ft = P->off_dt >= 0, ub = P->integrator == 0 ? 2 : 1;
+    int o = ub * s * m + m * (m + 1) / 2;
     if (ft) {
-        o += m + 2 * s + 1;
+        o += m + ub * s + 1;
         for (int i = 0; i < P->n_deriv; ++i) o += P->ddim[i];
     }
     return o;
@@ -412,9 +412,167 @@ static void interval_hess(const qco_problem* P, const qco_ws* w, const double* z
     }
 }
 
+/* ---- Hessian of mu^T delta for the exponential integrator, delta = U1 - exp(h G(a)) U0 (README.md:79) -----------
+ * The reference solves `integrator=:exponential` problems with the Hessian left on
+ * (unitary_smooth_pulse_problem.jl:224-240,242-266; `eval_hessian=false` is spelled out where it is wanted,
+ * unitary_robustness_problem.jl:205,247).  delta is linear in U1: every U_{t+1} block vanishes.  With E = exp(hG),
+ * L_j = L_exp(hG; h G_j), L2_ij = the second Frechet derivative in the directions h G_i, h G_j, M = reshape(mu):
+ *     (U0, a_j) = -vec(L_j^T M)   (U0, h) = -vec((G E)^T M)   (a_i, a_j) = -<M, L2_ij U0>
+ *     (a_j, h) = -<M, (G_j E + G L_j) U0>   (h, h) = -<M, G^2 E U0>   (dx_i, h) = -mu_i
+ * Here by differentiating the scaled Taylor polynomial and the squarings term by term in FORWARD mode (one chain per
+ * drive, one per drive pair) -- oracle/qc_oracle.py takes the 3n x 3n block-triangular exponential instead, the HIP
+ * kernels a forward-over-reverse form: three routes to the same numbers. */
+#define QCO_EXP_HDEG 18
+
+static void interval_hess_exp(const qco_problem* P, const double* z0, const double* z1, const double* mu, double* Ho, double* W) {
+    const int n = 2 * P->N, N = qco_nc(P), s = n * N, m = P->m, ft = P->off_dt >= 0;
+    const size_t n2 = (size_t)n * n;
+    const int np = m * (m + 1) / 2;
+    const double h = ft ? z0[P->off_dt] : P->dt_fixed;
+    const double* U0 = z0 + P->off_U;
+    const double* a = z0 + P->off_a;
+    const double* M = mu;
+    (void)z1;
+    /* workspace carve-up */
+    double* G = W;               W += n2;
+    double* Y = W;               W += n2;
+    double* E = W;               W += n2;
+    double* A0 = W;              W += n2;
+    double* A1 = W;              W += n2;
+    double* T1 = W;              W += n2;
+    double* T2 = W;              W += n2;
+    double* L = W;               W += (size_t)m * n2;     /* running sums / squared values of the first derivatives */
+    double* D0 = W;              W += (size_t)m * n2;
+    double* D1 = W;              W += (size_t)m * n2;
+    double* L2 = W;              W += (size_t)np * n2;
+    double* S0 = W;              W += (size_t)np * n2;
+    double* S1 = W;              W += (size_t)np * n2;
+    double* X1 = W;              W += n2;
+    double* X2 = W;              W += n2;
+    memcpy(G, P->G_drift, n2 * 8);
+    for (int j = 0; j < m; ++j)
+        for (size_t e = 0; e < n2; ++e) G[e] += a[j] * P->G_drives[(size_t)j * n2 + e];
+    double nrm = 0.0;
+    for (int j = 0; j < n; ++j) {
+        double cs = 0.0;
+        for (int i = 0; i < n; ++i) cs += fabs(h * G[(size_t)j * n + i]);
+        if (cs > nrm) nrm = cs;
+    }
+    int sq = 0;
+    if (nrm > 0.25) { sq = (int)ceil(log2(nrm / 0.25)); if (sq < 0) sq = 0; }
+    const double sc = ldexp(1.0, -sq), hs = h * sc;    /* Y = hs G, directions hs G_j */
+    for (size_t e = 0; e < n2; ++e) { Y[e] = hs * G[e]; E[e] = 0.0; A0[e] = 0.0; }
+    for (int i = 0; i < n; ++i) { E[(size_t)i * n + i] = 1.0; A0[(size_t)i * n + i] = 1.0; }
+    memset(L, 0, (size_t)m * n2 * 8); memset(D0, 0, (size_t)m * n2 * 8);
+    memset(L2, 0, (size_t)np * n2 * 8); memset(S0, 0, (size_t)np * n2 * 8);
+    double *Ap = A0, *An = A1, *Dp = D0, *Dn = D1, *Sp = S0, *Sn = S1;
+    for (int k = 1; k <= QCO_EXP_HDEG; ++k) {
+        const double inv = 1.0 / k;
+        /* second-order terms first: they use the (k-1)-th first-order terms */
+        for (int j = 0; j < m; ++j)
+            for (int i = 0; i <= j; ++i) {
+                const size_t pi = (size_t)(j * (j + 1) / 2 + i) * n2;
+                mm(T1, Sp + pi, Y, n, n, n);
+                mm(T2, Dp + (size_t)i * n2, P->G_drives + (size_t)j * n2, n, n, n);
+                for (size_t e = 0; e < n2; ++e) T1[e] += hs * T2[e];
+                mm(T2, Dp + (size_t)j * n2, P->G_drives + (size_t)i * n2, n, n, n);
+                for (size_t e = 0; e < n2; ++e) { Sn[pi + e] = (T1[e] + hs * T2[e]) * inv; L2[pi + e] += Sn[pi + e]; }
+            }
+        for (int j = 0; j < m; ++j) {
+            mm(T1, Dp + (size_t)j * n2, Y, n, n, n);
+            mm(T2, Ap, P->G_drives + (size_t)j * n2, n, n, n);
+            for (size_t e = 0; e < n2; ++e) { Dn[(size_t)j * n2 + e] = (T1[e] + hs * T2[e]) * inv; L[(size_t)j * n2 + e] += Dn[(size_t)j * n2 + e]; }
+        }
+        mm(T1, Ap, Y, n, n, n);
+        for (size_t e = 0; e < n2; ++e) { An[e] = T1[e] * inv; E[e] += An[e]; }
+        double* t;
+        t = Ap; Ap = An; An = t;  t = Dp; Dp = Dn; Dn = t;  t = Sp; Sp = Sn; Sn = t;
+    }
+    for (int q = 0; q < sq; ++q) {
+        /* L2_ij <- E L2_ij + L2_ij E + L_i L_j + L_j L_i;  L_j <- E L_j + L_j E;  E <- E E */
+        for (int j = 0; j < m; ++j)
+            for (int i = 0; i <= j; ++i) {
+                const size_t pi = (size_t)(j * (j + 1) / 2 + i) * n2;
+                mm(T1, E, L2 + pi, n, n, n);
+                mm(T2, L2 + pi, E, n, n, n);
+                for (size_t e = 0; e < n2; ++e) T1[e] += T2[e];
+                mm(T2, L + (size_t)i * n2, L + (size_t)j * n2, n, n, n);
+                for (size_t e = 0; e < n2; ++e) T1[e] += T2[e];
+                mm(T2, L + (size_t)j * n2, L + (size_t)i * n2, n, n, n);
+                for (size_t e = 0; e < n2; ++e) S0[pi + e] = T1[e] + T2[e];
+            }
+        memcpy(L2, S0, (size_t)np * n2 * 8);
+        for (int j = 0; j < m; ++j) {
+            mm(T1, E, L + (size_t)j * n2, n, n, n);
+            mm(T2, L + (size_t)j * n2, E, n, n, n);
+            for (size_t e = 0; e < n2; ++e) D0[(size_t)j * n2 + e] = T1[e] + T2[e];
+        }
+        memcpy(L, D0, (size_t)m * n2 * 8);
+        mm(T1, E, E, n, n, n);
+        memcpy(E, T1, n2 * 8);
+    }
+    /* value order of hess_structure_local (exponential: no U_{t+1} blocks): (U, a) | (U, h) | (a, a) | (a, h) | (h, h) | (dx, h) */
+    const int o_Ua = 0, o_Uh = s * m, o_aa = o_Uh + (ft ? s : 0), o_ah = o_aa + np, o_hh = o_ah + (ft ? m : 0), o_d = o_hh + (ft ? 1 : 0);
+    mm(X1, E, U0, n, n, N);                 /* E U0 */
+    for (int j = 0; j < m; ++j) {
+        mtm(X2, L + (size_t)j * n2, M, n, n, N);
+        for (int e = 0; e < s; ++e) Ho[o_Ua + (size_t)j * s + e] = -X2[e];
+        for (int i = 0; i <= j; ++i) {
+            mm(X2, L2 + (size_t)(j * (j + 1) / 2 + i) * n2, U0, n, n, N);
+            Ho[o_aa + j * (j + 1) / 2 + i] = -dot(M, X2, s);
+        }
+        if (ft) {   /* (a_j, h) = -<M, G_j E U0 + G L_j U0> */
+            mm(X2, P->G_drives + (size_t)j * n2, X1, n, n, N);
+            double v = dot(M, X2, s);
+            mm(T1, L + (size_t)j * n2, U0, n, n, N);
+            mm(X2, G, T1, n, n, N);
+            Ho[o_ah + j] = -(v + dot(M, X2, s));
+        }
+    }
+    if (ft) {
+        mm(T1, G, E, n, n, n);              /* G E */
+        mtm(X2, T1, M, n, n, N);
+        for (int e = 0; e < s; ++e) Ho[o_Uh + e] = -X2[e];
+        mm(X2, G, X1, n, n, N);             /* G E U0 */
+        mm(T1, G, X2, n, n, N);             /* G^2 E U0 */
+        Ho[o_hh] = -dot(M, T1, s);
+        int r0 = s, o = o_d;
+        for (int d = 0; d < P->n_deriv; ++d) {
+            for (int i = 0; i < P->ddim[d]; ++i) Ho[o + i] = -mu[r0 + i];
+            r0 += P->ddim[d];
+            o += P->ddim[d];
+        }
+    }
+}
+
+static int qco_eval_hess_exp(const qco_problem* P, const double* Z, const double* mu, double* H, long long t_begin, long long t_end) {
+    const int n = 2 * P->N, m = P->m, ddim = qco_ddim(P), nnz = qco_hess_nnz(P);
+    const size_t n2 = (size_t)n * n, per = (9 + 3 * (size_t)m + 3 * (size_t)(m * (m + 1) / 2)) * n2;
+    int ok = 1;
+#pragma omp parallel
+    {
+        double* W = malloc(per * 8);
+        if (!W) {
+#pragma omp atomic write
+            ok = 0;
+        } else {
+#pragma omp for schedule(static)
+            for (long long t = t_begin; t < t_end; ++t) {
+                const double* z0 = Z + (size_t)t * P->zdim;
+                interval_hess_exp(P, z0, z0 + P->zdim, mu + (size_t)t * ddim, H + (size_t)(t - t_begin) * nnz, W);
+            }
+        }
+        free(W);
+    }
+    return ok ? 0 : -2;
+}
+
 int qco_eval_hess(const qco_problem* P, const double* Z, const double* mu, double* H, long long t_begin, long long t_end,
                   int nthreads) {
-    if (P->integrator != 0) return -1;
+#ifdef _OPENMP
+    if (P->integrator != 0 && nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+    if (P->integrator != 0) return qco_eval_hess_exp(P, Z, mu, H, t_begin, t_end);
     const int n = 2 * P->N, p = P->order / 2, ddim = qco_ddim(P), nnz = qco_hess_nnz(P);
     int ok = 1;
 #ifdef _OPENMP

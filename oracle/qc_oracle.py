@@ -197,6 +197,23 @@ def expm_frechet_block(X: np.ndarray, E: np.ndarray) -> Tuple[np.ndarray, np.nda
     return EA[:k, :k], EA[:k, k:]
 
 
+def expm_frechet2_block(X: np.ndarray, A: np.ndarray, B: np.ndarray) -> np.ndarray:
+    """Second Frechet derivative L2_exp(X; A, B) = d2/ds dt exp(X + sA + tB) at 0 (symmetric, bilinear).
+    The top-right block of exp([[X, A, 0], [0, X, B], [0, 0, X]]) is the ordered double integral with A to
+    the left of B; the derivative is that block plus the one with the directions swapped."""
+    k = X.shape[0]
+    dt = np.result_type(X, A, B)
+
+    def ordered(P, Q):
+        T = np.zeros((3 * k, 3 * k), dtype=dt)
+        T[:k, :k] = T[k:2 * k, k:2 * k] = T[2 * k:, 2 * k:] = X
+        T[:k, k:2 * k] = P
+        T[k:2 * k, 2 * k:] = Q
+        return expm_taylor(T)[:k, 2 * k:]
+
+    return ordered(A, B) + ordered(B, A)
+
+
 # --------------------------------------------------------------------------------------------
 #  Per-interval residual
 # --------------------------------------------------------------------------------------------
@@ -293,9 +310,58 @@ def interval_jacobian_dense(prob: Problem, z0: np.ndarray, z1: np.ndarray) -> np
 # --------------------------------------------------------------------------------------------
 #  Per-interval dense Hessian of mu^T delta (2*zdim x 2*zdim, full symmetric)
 # --------------------------------------------------------------------------------------------
+def _interval_hessian_dense_exp(prob: Problem, z0: np.ndarray, z1: np.ndarray, mu: np.ndarray) -> np.ndarray:
+    """Exponential integrator, delta = U1 - exp(h G(a)) U0 (reference README.md:79; the templates build
+    `PiccoloOptions(integrator=:exponential)` problems and solve them with the Hessian left on:
+    unitary_smooth_pulse_problem.jl:224-240,242-266 against `eval_hessian=false` spelled out at
+    unitary_robustness_problem.jl:205,247).  delta is linear in U1, so every U_{t+1} block vanishes; with
+    E = exp(hG), L_j = L_exp(hG; h G_j), M = reshape(mu, n, nc):
+        (a_i, a_j) = -<M, L2_exp(hG; h G_i, h G_j) U0>        (U0, a_j) = -vec(L_j^T M)
+        (a_j, h)   = -<M, (G_j E + G L_j) U0>                 (U0, h)   = -vec((G E)^T M)
+        (h, h)     = -<M, G^2 E U0>                           (dx_i, h) = -mu_i
+    [DERIVED]; certified by complex step of the Jacobian and an mpmath check (tests/test_oracle_math.py)."""
+    U0, U1, a, h = _split(prob, z0, z1)
+    G = _G_of(prob, a)
+    n, N, s, m, zd = prob.n, prob.nc, prob.s, prob.m, prob.zdim
+    M = mu[:s].reshape(n, N, order="F")
+    Gd = prob.G_drives
+    Hs = np.zeros((2 * zd, 2 * zd))
+
+    def sym_set(i, j, v):
+        Hs[i, j] += v
+        if i != j:
+            Hs[j, i] += v
+
+    iU0 = prob.off_U
+    E = expm_taylor(h * G)
+    Ls = [expm_frechet_block(h * G, h * Gd[j])[1] for j in range(m)]
+    for i in range(m):
+        for j in range(i, m):
+            L2 = expm_frechet2_block(h * G, h * Gd[i], h * Gd[j])
+            sym_set(prob.off_a + i, prob.off_a + j, -np.sum(M * (L2 @ U0)))
+    for j in range(m):
+        v = -_vec(Ls[j].T @ M)
+        for i in range(s):
+            sym_set(iU0 + i, prob.off_a + j, v[i])
+    if prob.free_time:
+        ih = prob.off_dt
+        for j in range(m):
+            sym_set(prob.off_a + j, ih, -np.sum(M * ((Gd[j] @ E + G @ Ls[j]) @ U0)))
+        sym_set(ih, ih, -np.sum(M * (G @ G @ E @ U0)))
+        v = -_vec((G @ E).T @ M)
+        for i in range(s):
+            sym_set(iU0 + i, ih, v[i])
+        r = s
+        for d in prob.derivs:
+            for i in range(d.dim):
+                sym_set(d.dx_off + i, ih, -mu[r + i])
+            r += d.dim
+    return Hs
+
+
 def interval_hessian_dense(prob: Problem, z0: np.ndarray, z1: np.ndarray, mu: np.ndarray) -> np.ndarray:
     if prob.integrator != PADE:
-        raise NotImplementedError("analytic Hessian only for the Pade integrator (SURVEY A.6)")
+        return _interval_hessian_dense_exp(prob, z0, z1, mu)
     U0, U1, a, h = _split(prob, z0, z1)
     G = _G_of(prob, a)
     n, N, s, m, zd = prob.n, prob.nc, prob.s, prob.m, prob.zdim
@@ -404,9 +470,9 @@ def jac_structure_local(prob: Problem) -> List[Tuple[int, int]]:
 
 
 def hess_structure_local(prob: Problem) -> List[Tuple[int, int]]:
-    """Upper-triangular (row <= col) local pairs over [z_t ; z_{t+1}] (size 2*zdim)."""
-    if prob.integrator != PADE:
-        return []
+    """Upper-triangular (row <= col) local pairs over [z_t ; z_{t+1}] (size 2*zdim).  The exponential
+    integrator is linear in U_{t+1}: its blocks 2 and 4 are structurally empty."""
+    pade = prob.integrator == PADE
     s, m, zd = prob.s, prob.m, prob.zdim
     st: List[Tuple[int, int]] = []
 
@@ -416,13 +482,13 @@ def hess_structure_local(prob: Problem) -> List[Tuple[int, int]]:
     for j in range(m):                       # 1. (U_t, a_j)
         for i in range(s):
             up(prob.off_U + i, prob.off_a + j)
-    for j in range(m):                       # 2. (a_j, U_{t+1})
+    for j in range(m if pade else 0):        # 2. (a_j, U_{t+1})
         for i in range(s):
             up(prob.off_a + j, zd + prob.off_U + i)
     if prob.free_time:
         for i in range(s):                   # 3. (U_t, h)
             up(prob.off_U + i, prob.off_dt)
-        for i in range(s):                   # 4. (h, U_{t+1})
+        for i in range(s if pade else 0):    # 4. (h, U_{t+1})
             up(prob.off_dt, zd + prob.off_U + i)
     for j in range(m):                       # 5. (a_i, a_j), i <= j
         for i in range(j + 1):

@@ -42,6 +42,28 @@ def test_c_oracle_layouts_and_exponential(oracle, coracle):
         np.testing.assert_allclose(J, oracle.dF(prob, Z), rtol=1e-11, atol=1e-12)
 
 
+@pytest.mark.parametrize("N,m", [(1, 1), (2, 2), (2, 3), (3, 2), (4, 4), (8, 6)])
+@pytest.mark.parametrize("free_time", [True, False])
+def test_c_oracle_exponential_hessian(oracle, coracle, N, m, free_time):
+    """Forward-mode chains through scaling and squaring (C) against the 3n x 3n block-triangular exponential (numpy)."""
+    T = 3 if N == 8 else 4
+    for layout in (("standard",) if N > 2 else ("standard", "shuffled", "script")):
+        prob, Z = random_problem(oracle, N=N, m=m, T=T, free_time=free_time, integrator=oracle.EXPONENTIAL, seed=70 + N + m, layout=layout)
+        co = coracle.COracle(prob, threads=2)
+        assert co.hess_nnz + co.hess_pad == oracle.hess_nnz_interval(prob) > 0
+        mu = np.random.default_rng(5).standard_normal(prob.n_rows)
+        np.testing.assert_allclose(co.mu_d2F(Z, mu), oracle.mu_d2F(prob, Z, mu), rtol=1e-11, atol=1e-12)
+    # a large step (several squarings) and non-Hermitian Hamiltonians
+    prob, Z = random_problem(oracle, N=N, m=m, T=3, free_time=free_time, integrator=oracle.EXPONENTIAL, seed=71, hermitian=False)
+    if free_time:
+        Z[prob.off_dt::prob.zdim] = 1.3
+    else:
+        prob.dt_fixed = 1.3
+    mu = np.random.default_rng(6).standard_normal(prob.n_rows)
+    ref = oracle.mu_d2F(prob, Z, mu)
+    np.testing.assert_allclose(coracle.COracle(prob).mu_d2F(Z, mu), ref, rtol=1e-10, atol=1e-11 * np.abs(ref).max())
+
+
 def test_oracles_reproduce_the_golden_vectors(oracle, coracle):
     import json
     fx = json.load(open(os.path.join(GOLD, "named_trajectory_type_1.json")))
@@ -88,9 +110,8 @@ def test_c_oracle_kets(oracle, coracle, K):
         np.testing.assert_allclose(F, oracle.F(prob, Z), rtol=1e-12, atol=1e-13)
         np.testing.assert_allclose(J, oracle.dF(prob, Z), rtol=1e-11, atol=1e-12)
         assert co.jac_nnz == oracle.jac_nnz_interval(prob)
-        if integ == oracle.PADE:
-            mu = np.random.default_rng(3).standard_normal(prob.n_rows)
-            np.testing.assert_allclose(co.mu_d2F(Z, mu), oracle.mu_d2F(prob, Z, mu), rtol=1e-11, atol=1e-12)
+        mu = np.random.default_rng(3).standard_normal(prob.n_rows)
+        np.testing.assert_allclose(co.mu_d2F(Z, mu), oracle.mu_d2F(prob, Z, mu), rtol=1e-11, atol=1e-12)
 
 
 def test_oracle_reproduces_the_8f_golden_vectors(oracle):

@@ -154,6 +154,102 @@ def test_exponential_integrator(oracle, free_time):
     np.testing.assert_allclose(E @ E.T, np.eye(prob.n), atol=1e-13)
 
 
+@pytest.mark.parametrize("free_time", [True, False])
+@pytest.mark.parametrize("layout", ["standard", "shuffled", "script"])
+@pytest.mark.parametrize("hermitian", [True, False])
+def test_exponential_hessian_vs_complex_step(oracle, free_time, layout, hermitian):
+    """mu_d2F of the exponential integrator (the reference solves :exponential problems with eval_hessian left on,
+    unitary_smooth_pulse_problem.jl:224-266): the second Frechet derivative through the 3n x 3n block matrix against a
+    complex step of the Jacobian, whose own Frechet derivatives come from the 2n x 2n block matrix."""
+    prob, Z = random_problem(oracle, N=2, m=3, T=2, free_time=free_time, integrator=oracle.EXPONENTIAL, seed=21, layout=layout,
+                             hermitian=hermitian)
+    zd = prob.zdim
+    zz = Z[:2 * zd]
+    mu = np.random.default_rng(22).standard_normal(prob.ddim)
+    Hd = oracle.interval_hessian_dense(prob, zz[:zd], zz[zd:], mu)
+    Hcs = complex_step_jac(lambda x: oracle.interval_jacobian_dense(prob, x[:zd], x[zd:]).T @ mu, zz)
+    np.testing.assert_allclose(Hd, Hcs, rtol=1e-11, atol=1e-12)
+    np.testing.assert_allclose(Hd, Hd.T, atol=0)
+    # delta is linear in U_{t+1}: every block that touches knot t+1 vanishes; so does (U_t, U_t)
+    assert not Hd[zd:, :].any() and not Hd[:, zd:].any()
+    iU0 = slice(prob.off_U, prob.off_U + prob.s)
+    assert not Hd[iU0, iU0].any()
+    # the structure covers every non-zero of the dense block
+    loc = np.array(oracle.hess_structure_local(prob))
+    mask = np.zeros_like(Hd, dtype=bool)
+    mask[loc[:, 0], loc[:, 1]] = True
+    assert not np.triu(Hd)[~mask].any()
+    s, m = prob.s, prob.m
+    assert len(loc) == s * m + m * (m + 1) // 2 + ((s + m + 1 + sum(d.dim for d in prob.derivs)) if free_time else 0)
+
+
+def test_second_frechet_derivative_vs_finite_differences_of_scipy(oracle):
+    """L2_exp(X; A, B) against a central second difference of scipy's expm_frechet (an independent implementation)."""
+    rng = np.random.default_rng(23)
+    for scale in (0.1, 1.0, 4.0):
+        X = rng.standard_normal((5, 5)) * scale
+        A, B = rng.standard_normal((5, 5)), rng.standard_normal((5, 5))
+        L2 = oracle.expm_frechet2_block(X, A, B)
+        np.testing.assert_allclose(L2, oracle.expm_frechet2_block(X, B, A), rtol=1e-12, atol=1e-13 * np.abs(L2).max())
+        eps = 1e-5
+        fd = (sla.expm_frechet(X + eps * B, A)[1] - sla.expm_frechet(X - eps * B, A)[1]) / (2 * eps)
+        np.testing.assert_allclose(L2, fd, rtol=2e-7, atol=2e-8 * np.abs(L2).max())
+
+
+def test_exponential_hessian_mpmath_spot_check(oracle):
+    """50-digit evaluation of the (a_i, a_j), (a_j, h) and (h, h) entries from the Taylor series of exp
+    (sum over ordered insertions of the directions) certifies the float64 oracle to 1e-12."""
+    import mpmath as mp
+
+    mp.mp.dps = 50
+    prob, Z = random_problem(oracle, N=2, m=2, T=2, integrator=oracle.EXPONENTIAL, seed=24)
+    zd = prob.zdim
+    z0, z1 = Z[:zd], Z[zd:]
+    n, N, s, m = prob.n, prob.N, prob.s, prob.m
+    mu = np.random.default_rng(25).standard_normal(prob.ddim)
+    Hd = oracle.interval_hessian_dense(prob, z0, z1, mu)
+    tom = lambda A: mp.matrix(A.tolist())
+    Gk = [tom(prob.G_drives[j]) for j in range(m)]
+    G = tom(prob.G_drift)
+    for j in range(m):
+        G = G + mp.mpf(float(z0[prob.off_a + j])) * Gk[j]
+    h = mp.mpf(float(z0[prob.off_dt]))
+    U0 = tom(z0[prob.off_U:prob.off_U + s].reshape(n, N, order="F"))
+    Mm = tom(mu[:s].reshape(n, N, order="F"))
+    inner = lambda A, B: sum(A[i, j] * B[i, j] for i in range(A.rows) for j in range(A.cols))
+    K = 40
+    X = h * G
+    Xp = [mp.eye(n)]
+    for k in range(K + 1):
+        Xp.append(Xp[-1] * X)
+    # exp, first and second directional derivatives of the series sum_k X^k / k!
+    def d1(A):
+        out = mp.zeros(n)
+        for k in range(1, K):
+            out += sum((Xp[i] * A * Xp[k - 1 - i] for i in range(k)), mp.zeros(n)) / mp.factorial(k)
+        return out
+    def d2(A, B):
+        out = mp.zeros(n)
+        for k in range(2, K):
+            acc = mp.zeros(n)
+            for al in range(k - 1):
+                for be in range(k - 1 - al):
+                    ga = k - 2 - al - be
+                    acc += Xp[al] * A * Xp[be] * B * Xp[ga] + Xp[al] * B * Xp[be] * A * Xp[ga]
+            out += acc / mp.factorial(k)
+        return out
+    E = mp.expm(X)
+    for i in range(m):
+        for j in range(i, m):
+            ref = -inner(Mm, d2(h * Gk[i], h * Gk[j]) * U0)
+            assert abs(float(ref) - Hd[prob.off_a + i, prob.off_a + j]) <= 1e-12 * max(1.0, abs(float(ref)))
+    for j in range(m):
+        ref = -inner(Mm, (Gk[j] * E + G * d1(h * Gk[j])) * U0)
+        assert abs(float(ref) - Hd[prob.off_a + j, prob.off_dt]) <= 1e-12 * max(1.0, abs(float(ref)))
+    ref = -inner(Mm, G * G * E * U0)
+    assert abs(float(ref) - Hd[prob.off_dt, prob.off_dt]) <= 1e-12 * max(1.0, abs(float(ref)))
+
+
 def test_nnz_formulas_match_survey_table(oracle):
     # SURVEY section 8 table: (N, m) -> (zdim, ddim, jac nnz, hess nnz)
     table = {(2, 2): (15, 12, 104, 58), (4, 4): (45, 40, 704, 343), (8, 6): (147, 140, 5040, 1832), (16, 8): (537, 528, 37440, 9277)}
@@ -183,7 +279,7 @@ def test_coo_assembly_equals_dense(oracle, integrator):
     for t in range(prob.T - 1):
         ref[t * dd:(t + 1) * dd, t * zd:(t + 2) * zd] = oracle.interval_jacobian_dense(prob, Z[t * zd:(t + 1) * zd], Z[(t + 1) * zd:(t + 2) * zd])
     np.testing.assert_array_equal(Jd, ref)   # structure covers every structural non-zero
-    if integ == oracle.PADE:
+    if True:   # both integrators have an analytic Hessian (round 6)
         mu = np.random.default_rng(13).standard_normal(prob.n_rows)
         hv = oracle.mu_d2F(prob, Z, mu)
         hr, hc = oracle.hess_structure(prob)
@@ -265,7 +361,7 @@ def test_ket_problem_derivatives(oracle, K, integrator):
     Jcs = complex_step_jac(lambda x: oracle.interval_residual(prob, x[:zd], x[zd:]), zz)
     np.testing.assert_allclose(J, Jcs, rtol=1e-11, atol=1e-12)
     assert oracle.jac_nnz_interval(prob) == (2 * K * 36 if integ == oracle.PADE else K * 36 + 6 * K) + 6 * K * 2 + 6 * K + 16
-    if integ == oracle.PADE:
+    if True:   # both integrators
         mu = np.random.default_rng(1).standard_normal(prob.ddim)
         Hd = oracle.interval_hessian_dense(prob, zz[:zd], zz[zd:], mu)
         Hcs = complex_step_jac(lambda x: oracle.interval_jacobian_dense(prob, x[:zd], x[zd:]).T @ mu, zz)
