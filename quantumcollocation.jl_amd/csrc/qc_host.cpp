@@ -177,16 +177,19 @@ int qc_build_params(const qc_desc* d, QcParams* P, qc_dims_t* dims, std::string*
     P->jo_d = o;
     for (int i = 0; i < P->n_deriv; ++i) o += (ft ? 4 : 3) * P->ddim_i[i];
     P->jac_nnz = o;
-    // Hessian block offsets (analytic Hessian: Pade only)
+    // Hessian block offsets.  The exponential integrator's residual U_t+1 - exp(h G) U_t is linear in U_t+1: its (a, U_t+1) and
+    // (h, U_t+1) blocks are structurally empty (the reference solves :exponential problems with the Hessian left on,
+    // unitary_smooth_pulse_problem.jl:224-266).
     o = 0;
-    if (P->integrator == QC_PADE) {
+    const int ub = P->integrator == QC_PADE ? 1 : 0;
+    {
         // the four kinds of matrix blocks first -- whole 128-byte lines each when the interval's block is line-aligned (hess_align = 16,
         // 2N x N a multiple of 16) --, then the scalar blocks as ONE contiguous run that the kernels assemble and store in one piece
         // (round 5: the scalar entries used to sit between the blocks; partly written lines at the tail of the one-call launch cost 0.7 us)
         P->ho_Ua = o;  o += s * m;
-        P->ho_aU = o;  o += s * m;
+        P->ho_aU = o;  o += ub * s * m;
         P->ho_Uh = o;  o += ft ? s : 0;
-        P->ho_hU = o;  o += ft ? s : 0;
+        P->ho_hU = o;  o += ft ? ub * s : 0;
         P->ho_aa = o;  o += m * (m + 1) / 2;
         P->ho_ah = o;  o += ft ? m : 0;
         P->ho_hh = o;  o += ft ? 1 : 0;
@@ -264,15 +267,14 @@ void qc_local_jac_structure(const QcParams& P, std::vector<int32_t>* R, std::vec
 
 void qc_local_hess_structure(const QcParams& P, std::vector<int32_t>* R, std::vector<int32_t>* C) {
     R->clear(); C->clear();
-    if (P.integrator != QC_PADE) return;
     const int s = P.s, m = P.m, zd = P.zdim;
-    const bool ft = P.off_dt >= 0;
+    const bool ft = P.off_dt >= 0, pade = P.integrator == QC_PADE;   // exponential: no entry touches knot t+1
     auto up = [&](int i, int j) { R->push_back(std::min(i, j)); C->push_back(std::max(i, j)); };
     for (int j = 0; j < m; ++j) for (int i = 0; i < s; ++i) up(P.off_U + i, P.off_a + j);
-    for (int j = 0; j < m; ++j) for (int i = 0; i < s; ++i) up(P.off_a + j, zd + P.off_U + i);
+    if (pade) for (int j = 0; j < m; ++j) for (int i = 0; i < s; ++i) up(P.off_a + j, zd + P.off_U + i);
     if (ft) {
         for (int i = 0; i < s; ++i) up(P.off_U + i, P.off_dt);
-        for (int i = 0; i < s; ++i) up(P.off_dt, zd + P.off_U + i);
+        if (pade) for (int i = 0; i < s; ++i) up(P.off_dt, zd + P.off_U + i);
     }
     for (int j = 0; j < m; ++j) for (int i = 0; i <= j; ++i) up(P.off_a + i, P.off_a + j);
     if (ft) {
@@ -536,7 +538,10 @@ extern "C" const char* qc_kernel_name(const qc_handle* h, int32_t which) {
         if (P.n > 16 && P.n <= 32 && P.ell) return "mfma32-pade4-ell";
         return P.n > 32 ? "mfma64-pade4" : (P.n > 16 ? "mfma32-pade4" : "mfma16-pade4");
     }
-    if (P.integrator != QC_PADE) return "none";
+    if (P.integrator != QC_PADE) {      // exponential integrator: mu_d2F alone; F + dF + mu_d2F as two launches
+        if (which == 2) return "two-launches";
+        return P.use_ws ? "lds-gws-exp-hess" : "lds-exp-hess";
+    }
     if (which == 2) return mfma && qc_mfma16_fused_supported(P) ? (qc_mfma16_fused_gathers(P) ? "mfma16-pade4-fused-gather" : "mfma16-pade4-fused") : (mfma && P.ell && P.hess_nnz ? "mfma32-pade4-fused-ell" : "two-launches");
     if (mfma && qc_mfma_hess_supported(P)) {
         if (qc_mfma16_padeP_hess_supported(P)) return "mfma16-padeP-hess";

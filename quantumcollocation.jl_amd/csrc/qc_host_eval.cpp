@@ -180,8 +180,6 @@ extern "C" int qc_eval_hess_dev_multi(qc_handle* const* hs, int32_t count, const
 extern "C" int qc_eval_hess_dev(qc_handle* h, const double* dZ, const double* dmu, double* dhvals, void* stream) {
     if (!h) return fail(nullptr, QC_ERR_INVALID, "qc_eval_hess_dev: NULL handle");
     QC_NOT_MULTI(h, "qc_eval_hess_dev");
-    if (h->prm.integrator != QC_PADE)
-        return fail(&h->err, QC_ERR_UNSUPPORTED, "no analytic Hessian for the exponential integrator (upstream has none either; use eval_hessian=false)");
     if (h->prm.hess_nnz == 0) return QC_OK;   // no drives and a fixed timestep: the constraint is linear
     if (!dZ || !dmu || !dhvals) return fail(&h->err, QC_ERR_INVALID, "qc_eval_hess_dev: NULL buffer");
     int rc;
@@ -209,8 +207,6 @@ extern "C" int qc_eval_hess_dev(qc_handle* h, const double* dZ, const double* dm
 extern "C" int qc_eval_F_jac_hess_dev(qc_handle* h, const double* dZ, const double* dmu, double* dF, double* dvals, double* dhvals, void* stream) {
     if (!h) return fail(nullptr, QC_ERR_INVALID, "qc_eval_F_jac_hess_dev: NULL handle");
     QC_NOT_MULTI(h, "qc_eval_F_jac_hess_dev");
-    if (h->prm.integrator != QC_PADE)
-        return fail(&h->err, QC_ERR_UNSUPPORTED, "no analytic Hessian for the exponential integrator (upstream has none either; use eval_hessian=false)");
     if (!dZ || !dvals || (h->prm.hess_nnz && (!dmu || !dhvals))) return fail(&h->err, QC_ERR_INVALID, "qc_eval_F_jac_hess_dev: NULL buffer");
     int rc;
     if ((rc = check_align(h, dZ, 8, "dZ")) || (rc = check_align(h, dmu, 8, "dmu")) || (rc = check_align(h, dF, 8, "dF")) ||
@@ -963,8 +959,6 @@ static int eval_host_chunked(qc_handle* h, const double* Z, double* F, double* v
 }
 
 static int hess_host(qc_handle* h, const double* Z, const double* mu, double* hvals, int shards) {
-    if (h->prm.integrator != QC_PADE)
-        return fail(&h->err, QC_ERR_UNSUPPORTED, "no analytic Hessian for the exponential integrator (upstream has none either; use eval_hessian=false)");
     if (h->prm.hess_nnz == 0) return QC_OK;   // no drives and a fixed timestep: the constraint is linear
     if (!Z || !mu || !hvals) return fail(&h->err, QC_ERR_INVALID, "qc_eval_hess: NULL buffer");
     if (shares_values(h)) return fail(&h->err, QC_ERR_UNSUPPORTED, "composed handles write into shared vectors: use the _dev entry points");
@@ -1339,8 +1333,6 @@ extern "C" int qc_eval_F_jac(qc_handle* h, const double* Z, double* F, double* v
 extern "C" int qc_eval_hess(qc_handle* h, const double* Z, const double* mu, double* hvals) {
     if (!h) return fail(nullptr, QC_ERR_INVALID, "qc_eval_hess: NULL handle");
     if (!is_multi(h)) return hess_host(h, Z, mu, hvals, 1);
-    if (h->prm.integrator != QC_PADE)
-        return fail(&h->err, QC_ERR_UNSUPPORTED, "no analytic Hessian for the exponential integrator (upstream has none either; use eval_hessian=false)");
     if (h->prm.hess_nnz == 0) return QC_OK;
     if (!Z || !mu || !hvals) return fail(&h->err, QC_ERR_INVALID, "qc_eval_hess: NULL buffer");
     const int n = (int)h->shards.size();
@@ -1539,9 +1531,6 @@ static int list_eval(qc_handle* const* hs, int32_t count, const double* Z, const
     const QcParams& P = h->prm;
     if (!Z || (!F && !vals && !hvals) || (hvals && !mu)) return fail(&h->err, QC_ERR_INVALID, std::string(who) + ": NULL buffer");
     if (hvals) {
-        for (int i = 0; i < count; ++i)
-            if (hs[i]->prm.integrator != QC_PADE)
-                return fail(&h->err, QC_ERR_UNSUPPORTED, "no analytic Hessian for the exponential integrator (upstream has none either; use eval_hessian=false)");
         for (int i = 1; i < count; ++i)
             if ((hs[i]->prm.hess_nnz != 0) != (P.hess_nnz != 0) || (P.hess_nnz && hs[i]->prm.H_stride != P.H_stride))
                 return fail(&h->err, QC_ERR_INVALID, std::string(who) + ": the handles do not share one per-interval Hessian block");

@@ -14,8 +14,9 @@
 
 // Per-interval value-block layout of the Jacobian (canonical order, DESIGN.md "COO order"):
 //   [ -F copies (N * n^2) | B copies (N * n^2)  or  identity (s) | d/da (s*m) | d/dh (s) | derivative integrators ]
-// and of the Hessian:
-//   [ (U_t,a) s*m | (a,U_t+1) s*m | (a,a) upper m(m+1)/2 | (a,h) m | (U_t,h) s | (h,U_t+1) s | (h,h) 1 | (dx,h) ... ]
+// and of the Hessian (qc_build_params: the matrix blocks first, then the scalar entries as one run):
+//   [ (U_t,a) s*m | (a,U_t+1) s*m | (U_t,h) s | (h,U_t+1) s | (a,a) upper m(m+1)/2 | (a,h) m | (h,h) 1 | (dx,h) ... ]
+// The exponential integrator is linear in U_t+1: its (a,U_t+1) and (h,U_t+1) blocks are structurally empty (length 0).
 struct QcParams {
     int N, n, s, m, zdim, ddim;
     int nc;                  // columns of the iso state matrix (N for a unitary, K for K kets); s = n * nc
@@ -162,6 +163,8 @@ size_t qc_lds_bytes_hess(const QcParams& P);
 hipError_t qc_launch_lds_F_jac(const QcParams& P, const double* dZ, double* dF, double* dJ, size_t lds, hipStream_t st);
 hipError_t qc_launch_lds_hess(const QcParams& P, const double* dZ, const double* dMu, double* dH, size_t lds,
                               hipStream_t st);
+size_t qc_lds_exp_hess_bytes(const QcParams& P);     // exponential integrator's mu_d2F, any size: qc_lds_exp_hess.hip
+hipError_t qc_launch_lds_exp_hess(const QcParams& P, const double* dZ, const double* dMu, double* dH, size_t lds, hipStream_t st);
 bool qc_mfma_supported(const QcParams& P);
 bool qc_mfma_hess_supported(const QcParams& P);
 bool qc_mfma_compact_supported(const QcParams& P);   // the F + dF kernel honours QcParams.copies (order-4 kernels, 2N <= 32)

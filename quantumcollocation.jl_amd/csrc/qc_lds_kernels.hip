@@ -779,12 +779,12 @@ static int hess_chunk(const QcParams& P) {
 }
 
 size_t qc_lds_bytes_hess(const QcParams& P) {
-    if (P.integrator != QC_PADE) return 0;
+    if (P.integrator != QC_PADE) return qc_lds_exp_hess_bytes(P);
     return (size_t)hess_layout(P, hess_chunk(P)).total * sizeof(double);
 }
 
 hipError_t qc_launch_lds_hess(const QcParams& P, const double* dZ, const double* dMu, double* dH, size_t lds, hipStream_t st) {
-    if (P.integrator != QC_PADE) return hipErrorNotSupported;
+    if (P.integrator != QC_PADE) return qc_launch_lds_exp_hess(P, dZ, dMu, dH, lds, st);
     const int cj = hess_chunk(P);
     if (P.use_ws) {
         hipLaunchKernelGGL(qc_lds_pade_hess_kernel<true>, dim3(P.n_int), dim3(kThreadsGws), 0, st, P, dZ, dMu, dH, cj);

@@ -29,3 +29,10 @@ def oracle():
     import __graft_entry__ as g
 
     return g.load_oracle()
+
+
+@pytest.fixture(scope="session")
+def coracle():
+    """oracle/qc_oracle_c.py: the C restatement's loader (test infrastructure)."""
+    import oracle.qc_oracle_c as oc
+    return oc

@@ -69,11 +69,16 @@ def test_density_descriptor_and_structure(qc, oracle, nq, free_time):
     assert desc.N == N * N and desc.state_cols == 1 and desc.integrator == qc._lib.QC_EXPONENTIAL
     prob = problem_from_inputs(inp)
     dims = qc.desc_dims(desc)
-    assert dims.ddim == prob.ddim == 2 * N * N + 2 * sys_.n_drives and dims.hess_nnz == 0
-    jr, jc, _, _ = qc.desc_structures(desc)
+    assert dims.ddim == prob.ddim == 2 * N * N + 2 * sys_.n_drives
+    jr, jc, hr, hc = qc.desc_structures(desc)
     rr, rc = oracle.jac_structure(prob)
     np.testing.assert_array_equal(jr, rr)
     np.testing.assert_array_equal(jc, rc)
+    # the Lindblad step is an exponential integrator with one state column: its Hessian has no entry at knot t+1
+    orr, oc = oracle.hess_structure(prob)
+    np.testing.assert_array_equal(hr, orr)
+    np.testing.assert_array_equal(hc, oc)
+    assert dims.hess_nnz_interval == oracle.hess_nnz_interval(prob) > 0
     # the oracle's residual vanishes on an exact Lindblad propagation
     Z = inp.traj.datavec.copy().reshape(inp.traj.T, inp.traj.dim)
     off = inp.traj.offset("ρ⃗̃")
@@ -105,4 +110,8 @@ def test_density_kernel_matches_oracle(qc, oracle, nq, T, free_time):
     rr, rc = oracle.jac_structure(prob)
     np.testing.assert_array_equal(jr, rr)
     np.testing.assert_array_equal(jc, rc)
+    # mu_d2F of the Lindblad step (density_operator_smooth_pulse_problem.jl:104-106 builds the integrator; :68 passes eval_hessian on)
+    mu = np.random.default_rng(nq).standard_normal(prob.n_rows)
+    Hr = oracle.mu_d2F(prob, Z, mu)
+    np.testing.assert_allclose(dyn.mu_d2F(Z, mu), Hr, rtol=RTOL, atol=1e-11 * max(1.0, np.abs(Hr).max()))
     dyn.close()

@@ -555,7 +555,8 @@ def test_row_gather_forms_every_value_against_the_c_oracle(qc, m, free_time):
 
 
 # ------------------------------------------------------------------------------------------------
-#  Exponential integrator: residual, Jacobian, structure; no analytic Hessian
+#  Exponential integrator: residual, Jacobian, structure; mu_d2F (round 6: the reference solves :exponential
+#  problems with the Hessian left on, unitary_smooth_pulse_problem.jl:224-266)
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("N,m", [(1, 1), (2, 2), (3, 3), (4, 4), (8, 6)])
 @pytest.mark.parametrize("free_time", [True, False])
@@ -572,11 +573,69 @@ def test_exponential_integrator_parity(qc, oracle, N, m, free_time):
     rr, rc = oracle.jac_structure(prob)
     np.testing.assert_array_equal(jr, rr)
     np.testing.assert_array_equal(jc, rc)
-    assert h.dims.hess_nnz == 0
-    with pytest.raises(qc.QCollocError) as e:
-        h.hess(Z, np.ones(prob.n_rows))
-    assert e.value.code == qc._lib.QC_ERR_UNSUPPORTED
+    assert h.dims.hess_nnz_interval == oracle.hess_nnz_interval(prob) > 0
     h.close()
+
+
+def hess_structure_of(h):
+    hr = np.empty(h.dims.hess_nnz, dtype=np.int64)
+    hc = np.empty(h.dims.hess_nnz, dtype=np.int64)
+    h.L.check(h.L.lib.qc_hess_structure(h.h, h.L.iptr(hr), h.L.iptr(hc), 0), h.h)
+    return hr, hc
+
+
+@pytest.mark.parametrize("N,m", [(1, 1), (2, 2), (3, 3), (4, 4), (5, 2), (8, 6), (8, 8), (8, 1)])
+@pytest.mark.parametrize("free_time", [True, False])
+def test_exponential_integrator_hessian_parity(qc, oracle, N, m, free_time):
+    """mu_d2F of the exponential integrator: every kernel that serves the descriptor against the numpy oracle (second Frechet
+    derivative through the 3n x 3n block-triangular exponential), structure with array_equal, mu = ones (the reference's script,
+    integrator_test_1qubit.jl:50) and random."""
+    prob, Z = random_problem(oracle, N=N, m=m, T=4, free_time=free_time, integrator=oracle.EXPONENTIAL, seed=740 + N + m)
+    rng = np.random.default_rng(5)
+    for mu in (np.ones(prob.n_rows), rng.standard_normal(prob.n_rows)):
+        ref = oracle.mu_d2F(prob, Z, mu)
+        for kernel in kernels_for(qc, prob):
+            h = RawHandle(qc, prob, kernel=kernel)
+            assert h.dims.hess_nnz == ref.size
+            assert_close_h(h.hess(Z, mu), ref, f"exp hessian {kernel} N={N} m={m}")
+            hr, hc = hess_structure_of(h)
+            rr, rc = oracle.hess_structure(prob)
+            np.testing.assert_array_equal(hr, rr)
+            np.testing.assert_array_equal(hc, rc)
+            assert (hc < (np.repeat(np.arange(prob.T - 1), h.dims.hess_nnz_interval) + 1) * prob.zdim).all()   # nothing touches knot t+1
+            h.close()
+
+
+@pytest.mark.parametrize("layout", ["shuffled", "script"])
+def test_exponential_integrator_hessian_layouts_large_steps_non_hermitian(qc, oracle, layout):
+    prob, Z = random_problem(oracle, N=3, m=2, T=4, integrator=oracle.EXPONENTIAL, seed=22, layout=layout)
+    Z[prob.off_dt::prob.zdim] = [0.01, 0.6, 2.5, 0.2]          # 0 .. 6 squarings
+    mu = np.random.default_rng(6).standard_normal(prob.n_rows)
+    ref = oracle.mu_d2F(prob, Z, mu)
+    for kernel in kernels_for(qc, prob):
+        h = RawHandle(qc, prob, kernel=kernel)
+        np.testing.assert_allclose(h.hess(Z, mu), ref, rtol=RTOL, atol=1e-10 * np.abs(ref).max(), err_msg=kernel)
+        h.close()
+    # generators that are not antisymmetric (non-Hermitian effective Hamiltonians): no formula may assume G^T = -G
+    prob, Z = random_problem(oracle, N=4, m=3, T=3, integrator=oracle.EXPONENTIAL, seed=23, layout=layout, hermitian=False)
+    mu = np.random.default_rng(7).standard_normal(prob.n_rows)
+    ref = oracle.mu_d2F(prob, Z, mu)
+    for kernel in kernels_for(qc, prob):
+        h = RawHandle(qc, prob, kernel=kernel)
+        np.testing.assert_allclose(h.hess(Z, mu), ref, rtol=RTOL, atol=1e-10 * np.abs(ref).max(), err_msg=kernel)
+        h.close()
+
+
+def test_exponential_integrator_hessian_16_levels_and_beyond(qc, oracle, coracle):
+    """N = 16 (2N = 32) and N = 20 (scratch beyond the MFMA tiles) against the C oracle's forward-mode chains."""
+    for N, m, T in ((16, 3, 3), (20, 2, 2)):
+        prob, Z = random_problem(oracle, N=N, m=m, T=T, integrator=oracle.EXPONENTIAL, seed=24 + N)
+        mu = np.random.default_rng(8).standard_normal(prob.n_rows)
+        ref = coracle.COracle(prob).mu_d2F(Z, mu)
+        for kernel in kernels_for(qc, prob):
+            h = RawHandle(qc, prob, kernel=kernel)
+            assert_close_h(h.hess(Z, mu), ref, f"exp hessian N={N} {kernel}")
+            h.close()
 
 
 def test_exponential_integrator_large_step_and_host_mirror(qc, oracle):
@@ -602,6 +661,9 @@ def test_exponential_integrator_large_step_and_host_mirror(qc, oracle):
     n = probm.n
     E = -J[:n * n].reshape(n, n, order="F")
     np.testing.assert_allclose(E @ E.T, np.eye(n), atol=1e-12)
+    # ... and its Hessian of the Lagrangian, as Ipopt asks for it (`dynamics.mu_d2F(Z.datavec, mu)`, integrator_test_1qubit.jl:50-52)
+    mu = np.random.default_rng(3).standard_normal(probm.n_rows)
+    assert_close_h(dyn.mu_d2F(Zv, mu), oracle.mu_d2F(probm, Zv, mu), "host mirror exp hessian")
     dyn.close()
 
 
@@ -623,9 +685,11 @@ def test_ket_problems(qc, oracle, N, K, m, integrator):
     rr, rc = oracle.jac_structure(prob)
     np.testing.assert_array_equal(jr, rr)
     np.testing.assert_array_equal(jc, rc)
-    if integ == oracle.PADE:
-        mu = np.random.default_rng(2).standard_normal(prob.n_rows)
-        assert_close_h(h.hess(Z, mu), oracle.mu_d2F(prob, Z, mu), "ket hessian")
+    mu = np.random.default_rng(2).standard_normal(prob.n_rows)
+    for kernel in kernels_for(qc, prob):
+        hk = RawHandle(qc, prob, kernel=kernel)
+        assert_close_h(hk.hess(Z, mu), oracle.mu_d2F(prob, Z, mu), f"ket hessian {integrator} {kernel}")
+        hk.close()
     h.close()
 
 

@@ -10,12 +10,6 @@ from oracle_bridge import random_problem
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
-@pytest.fixture(scope="module")
-def coracle():
-    import oracle.qc_oracle_c as oc
-    return oc
-
-
 @pytest.mark.parametrize("N,m,order", [(1, 1, 4), (2, 2, 2), (2, 3, 4), (3, 2, 6), (4, 4, 4), (2, 2, 12), (8, 6, 4)])
 @pytest.mark.parametrize("free_time", [True, False])
 def test_c_oracle_matches_numpy_oracle(oracle, coracle, N, m, order, free_time):

@@ -273,15 +273,18 @@ def test_list_entry_points_error_behaviour_and_new_x(qc, oracle):
     close(H2, ref.mu_d2F(Z, mu), "list hessian at the device's knots", atol=1e-11)
     np.testing.assert_array_equal(dyn.mu_d2F(Z, mu, fresh=True), H2)
     dyn.close()
-    # no analytic Hessian with an exponential integrator in the list (upstream has none either)
+    # a list with a Pade and an exponential member: both have a Hessian of the Lagrangian (round 6)
     p1, p2 = direct_sum_members(qc, False, T=6, exp_second=True)
     ds = qc.unitary_direct_sum_inputs([p1, p2])
-    dyn = qc.QuantumDynamics(ds.integrators, ds.traj, eval_hessian=False)
-    H = np.zeros(8)
-    mu = np.zeros(int(dyn.dims.n_rows))
-    assert L.lib.qc_eval_hess_list(dyn._handles, 2, L.dptr(ds.traj.datavec), L.dptr(mu), L.dptr(H)) == L.QC_ERR_UNSUPPORTED
-    with pytest.raises(L.QCollocError):
-        dyn.mu_d2F(ds.traj.datavec, mu)
+    ref = composed_oracle(ds)
+    dyn = qc.QuantumDynamics(ds.integrators, ds.traj)
+    Zm = ds.traj.datavec
+    mu = np.random.default_rng(1).standard_normal(int(dyn.dims.n_rows))
+    close(dyn.mu_d2F(Zm, mu), ref.mu_d2F(Zm, mu), "list hessian, Pade + exponential members", atol=1e-11)
+    hr, hc = dyn.mu_d2F_structure
+    orr, oc = ref.hess_structure()
+    np.testing.assert_array_equal(hr, orr)
+    np.testing.assert_array_equal(hc, oc)
     dyn.close()
 
 
