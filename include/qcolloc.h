@@ -86,7 +86,7 @@ enum {
     QC_ERR_INVALID = -1,    /* bad descriptor / argument */
     QC_ERR_NO_DEVICE = -2,  /* no HIP device, or not gfx950 */
     QC_ERR_HIP = -3,        /* a HIP runtime call failed */
-    QC_ERR_UNSUPPORTED = -4 /* valid request this build cannot serve (e.g. Hessian of QC_EXPONENTIAL) */
+    QC_ERR_UNSUPPORTED = -4 /* valid request this build cannot serve (e.g. qc_multi_all_gather_dev with two shards on one device) */
 };
 
 enum { QC_PADE = 0, QC_EXPONENTIAL = 1 };
@@ -224,10 +224,13 @@ const char* qc_last_error(const qc_handle* h);
 
 int qc_dims(const qc_handle* h, qc_dims_t* out);
 /* Names of the device kernels this handle's evaluations run on (diagnostic; static strings, never NULL):
- * which = 0: F / F + dF ("mfma16-pade4", "mfma16-padeP", "mfma32-pade4", "mfma64-pade4", "mfma16-exp", "mfma32-exp",
- * "lds", "lds-gws");  which = 1: mu_d2F ("mfma16-pade4-hess", "mfma16-padeP-hess", "mfma32-pade4-hess",
- * "mfma64-pade4-hess", "lds-hess", "lds-gws-hess", or "none" for the exponential integrator);  which = 2: qc_eval_F_jac_hess_dev
- * ("mfma16-pade4-fused", or "two-launches"). */
+ * which = 0: F / F + dF ("mfma16-pade4", "mfma16-padeP", "mfma32-pade4-ell" (sparse drive generators) / "mfma32-pade4",
+ * "mfma64-pade4", "mfma16-exp", "mfma32-exp", "lds", "lds-gws");
+ * which = 1: mu_d2F ("mfma16-pade4-hess-gather" (drive generators with one entry per row) / "mfma16-pade4-hess2" /
+ * "mfma16-pade4-hess", "mfma16-padeP-hess", "mfma32-pade4-hess-ell" / "mfma32-pade4-hess", "mfma64-pade4-hess", "lds-hess",
+ * "lds-gws-hess"; exponential integrator: "mfma16-exp-hess", "lds-exp-hess", "lds-gws-exp-hess");
+ * which = 2: qc_eval_F_jac_hess_dev ("mfma16-pade4-fused-gather" / "mfma16-pade4-fused", "mfma32-pade4-fused-ell", or
+ * "two-launches"). */
 const char* qc_kernel_name(const qc_handle* h, int32_t which);
 int qc_jac_structure(const qc_handle* h, int64_t* rows, int64_t* cols, int one_based);
 int qc_hess_structure(const qc_handle* h, int64_t* rows, int64_t* cols, int one_based);

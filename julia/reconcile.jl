@@ -131,12 +131,22 @@ rec["ket_fidelity"] = kf
 push!(verdicts, "ket fidelity" => (isapprox(kf, abs2(ψg' * ψ); rtol=1e-12) ? "|<goal|psi>|^2" : isapprox(kf, abs(ψg' * ψ); rtol=1e-12) ? "|<goal|psi>|" : "NEITHER: $kf"))
 open(io -> write(io, json(rec)), joinpath(out_dir, "ref_fixture.json"), "w")
 
-# ---- exponential integrator: has Core a Hessian for it? -----------------------------------------------------
+# ---- exponential integrator: Core's Hessian for it (the templates solve :exponential problems with eval_hessian on,
+#      unitary_smooth_pulse_problem.jl:224-266) and the structure it declares -------------------------------------------------
 dynE = QuantumDynamics([UnitaryExponentialIntegrator(:Ũ⃗, :a, sys1, traj), DerivativeIntegrator(:a, :da, traj),
                         DerivativeIntegrator(:da, :dda, traj)], traj)
-push!(verdicts, "Hessian of the exponential integrator is absent" => (dynE.μ∂²F === nothing))
 recE = Dict{String,Any}("Z" => traj.datavec, "F" => dynE.F(traj.datavec), "dF" => dynE.∂F(traj.datavec),
                         "dF_rows" => first.(dynE.∂F_structure), "dF_cols" => last.(dynE.∂F_structure))
+push!(verdicts, "Hessian of the exponential integrator is present" => (dynE.μ∂²F !== nothing))
+if dynE.μ∂²F !== nothing
+    μE = collect(range(0.5, 1.5; length=length(recE["F"])))
+    recE["mu"] = μE
+    recE["mu_d2F"] = dynE.μ∂²F(traj.datavec, μE)
+    recE["mu_d2F_rows"] = first.(dynE.μ∂²F_structure); recE["mu_d2F_cols"] = last.(dynE.μ∂²F_structure)
+    zd = traj.dim
+    touches_next = any(((r - 1) ÷ zd) != ((c - 1) ÷ zd) for (r, c) in dynE.μ∂²F_structure)
+    push!(verdicts, "exponential Hessian structure has entries at knot t+1 (this library: none; they would be explicit zeros)" => touches_next)
+end
 open(io -> write(io, json(recE)), joinpath(out_dir, "ref_fixture_exponential.json"), "w")
 
 # ---- BASELINE configs 1 and 2 ---------------------------------------------------------------------------------

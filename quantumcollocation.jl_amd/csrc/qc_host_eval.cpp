@@ -194,7 +194,9 @@ extern "C" int qc_eval_hess_dev(qc_handle* h, const double* dZ, const double* dm
         QC_HIP(h, hipMalloc((void**)&h->dHs, qc_mfma64_hess_scratch_doubles(h->prm) * sizeof(double)));
         h->prm.hs = h->dHs;
     }
-    if (h->kernel == QC_KERNEL_MFMA && qc_mfma_hess_supported(h->prm))
+    if (h->kernel == QC_KERNEL_MFMA && qc_mfma_exp_hess_supported(h->prm))
+        e = qc_launch_mfma_exp_hess(h->prm, dZ, dmu, dhvals, (hipStream_t)stream);
+    else if (h->kernel == QC_KERNEL_MFMA && qc_mfma_hess_supported(h->prm))
         e = qc_launch_mfma_hess(h->prm, dZ, dmu, dhvals, (hipStream_t)stream);
     else
         e = qc_launch_lds_hess(h->prm, dZ, dmu, dhvals, h->lds_bytes_hess, (hipStream_t)stream);
