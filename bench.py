@@ -43,6 +43,20 @@ T_PER_GPU = 1000
 RING_BYTES = 640 << 20
 
 
+def structural_hess_nnz(dyn) -> int:
+    """Entries per interval of the reference's mu_d2F_structure (1 832 at config 3, 9 277 at config 5), whatever padding
+    the handle's layout adds behind them (hess_align = 16: 1 840 / 9 280)."""
+    P = dyn._desc
+    n, nc, m = 2 * P.N, (P.state_cols or P.N), P.m
+    s, ft = n * nc, P.off_dt >= 0
+    ub = 2 if P.integrator == 0 else 1                  # the exponential integrator has no block at knot t+1
+    k = ub * s * m + m * (m + 1) // 2
+    if ft:
+        k += m + ub * s + 1 + sum(int(P.deriv_dim[i]) for i in range(P.n_deriv))
+    assert k <= int(dyn.dims.hess_nnz_interval) < k + 4096
+    return k
+
+
 def usable_cores() -> int:
     """Host cores this process may actually use: min(affinity mask, cgroup CPU quota)."""
     n = len(os.sched_getaffinity(0))
@@ -384,7 +398,7 @@ def config5_record(qc, dev_index, steps=300):
     both_us = timed(lambda i: both[i % len(both)]())
     zdim, ddim = inp.traj.dim, int(dims.ddim)
     jac_bytes = 8 * (zdim * (n_int + 1) + (ddim + int(dims.jac_nnz_interval)) * n_int)
-    hess_bytes = 8 * (zdim * (n_int + 1) + (ddim + int(dims.hess_nnz_interval)) * n_int)
+    hess_bytes = 8 * (zdim * (n_int + 1) + (ddim + structural_hess_nnz(dyn)) * n_int)     # structural entries: the padding of the line-aligned layout is not algorithmic
     peak_tf = 78.6       # f64 MFMA: 256 CUs x 4 SIMDs x 2048 FLOP / 64 cycles x 2.4 GHz
     rec = {"workload": qc.CONFIGS[5].description + f"; T={inp.traj.T}", "kernels": list(dyn.kernel_names),
            "F_dF_us": jac_us, "F_dF_hbm_frac": jac_bytes / (jac_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
@@ -486,8 +500,8 @@ def long_trajectory_record(qc, dev_index, T=8000, steps=200):
     assert status[0] == 0, "a device-resident launch of the T = 8000 record reported an error"
     zdim, ddim = inp.traj.dim, int(dims.ddim)
     jac_bytes = 8 * (zdim * (n_int + 1) + (ddim + int(dims.jac_nnz_interval)) * n_int)
-    hess_bytes = 8 * (zdim * (n_int + 1) + (ddim + int(dims.hess_nnz_interval)) * n_int)
-    both_bytes = jac_bytes + 8 * (ddim + int(dims.hess_nnz_interval)) * n_int
+    hess_bytes = 8 * (zdim * (n_int + 1) + (ddim + structural_hess_nnz(dyn)) * n_int)     # structural entries: the padding of the line-aligned layout is not algorithmic
+    both_bytes = jac_bytes + 8 * (ddim + structural_hess_nnz(dyn)) * n_int
     frac = lambda b, us: b / (us * 1e-6) / 1e9 / HBM_PEAK_GBS   # noqa: E731
     rec = {"workload": f"{qc.CONFIGS[4].description}; T={T} knots on ONE GPU", "kernels": list(dyn.kernel_names),
            "F_dF_us": jac_us, "hbm_frac": frac(jac_bytes, jac_us), "algorithmic_bytes_per_launch": jac_bytes,
@@ -744,10 +758,12 @@ def main():
         extra["F_only_us"] = F_us
         extra["F_dF_hess_one_call_us"] = fused_us
         extra["F_dF_hess_kernel"] = dyn.fused_kernel_name
-        # Ipopt iteration proxy: dF + mu_d2F at the accepted point (one call), one line-search F; solver algebra excluded.
-        # (`..._separate_launches`: round 2's definition, F + dF and mu_d2F as two launches.)
-        extra["ms_per_ipopt_iter_proxy_device"] = (fused_us + F_us) / 1e3
-        extra["ms_per_ipopt_iter_proxy_device_separate_launches"] = (kernel_us_stream + hess_us + F_us) / 1e3
+        # Ipopt iteration proxy, in MOI's call order: eval_constraint + eval_constraint_jacobian at the accepted point
+        # (F + dF), then eval_hessian_lagrangian (mu_d2F alone: mu reaches the evaluator only AFTER the Jacobian has returned), one
+        # line-search F; solver algebra excluded.  `..._custom_consumer`: the one-call launch (dF + mu_d2F with mu known up front) that
+        # a consumer other than MOI / Ipopt could issue -- no binding of this repository calls it.
+        extra["ms_per_ipopt_iter_proxy_device"] = (kernel_us_stream + hess_us + F_us) / 1e3
+        extra["ms_per_ipopt_iter_proxy_device_custom_consumer"] = (fused_us + F_us) / 1e3
     if args.streams > 1:
         # Independent evaluations (e.g. the systems of a sampling problem, or several line-search points) may overlap the
         # ~4 us of dispatch + write-back of one launch with the store phase of the next.  A serial Ipopt loop cannot.

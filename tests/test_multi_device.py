@@ -183,7 +183,74 @@ def test_multi_handle_device_resident_and_all_gather(qc, oracle):
 
 
 @pytest.mark.gpu
-def test_multi_handle_on_distinct_devices_with_rccl_all_gather(qc, oracle):
+def test_config4_partition_at_full_size_every_value_against_the_c_oracle(qc, coracle):
+    """BASELINE config 4 -- 3-qubit Toffoli, T = 8000, knot-sharded 8 ways -- with the eight shards on this box's one device
+    (`devices = [0] * 8`: the partition, the halo knots, the per-shard uploads / launches / slices are those of the 8-GPU handle;
+    only the links are shared).  Host path: F_dF, mu_d2F, F -- EVERY value against oracle/qc_oracle.c and bit-identical to the
+    single handle.  Device path: qc_multi_eval_F_jac_dev / _hess_dev write each shard's slice of full-length vectors.
+    (Intervals are independent given Z: unitary_smooth_pulse_problem.jl:14-16.)"""
+    from oracle_bridge import problem_from_inputs
+    L = qc._lib
+    shards = 8
+    inp = qc.config_inputs(4)
+    T = inp.traj.T
+    assert T == 8000
+    prob = problem_from_inputs(inp)
+    prob.hess_align = 1
+    co = coracle.COracle(prob)
+    rng = np.random.default_rng(4)
+    Z = inp.traj.datavec + 1e-2 * rng.standard_normal(inp.traj.datavec.size)
+    mu = rng.standard_normal(prob.n_rows)
+    Fr, Jr = co.F_dF(Z)
+    Hr = co.mu_d2F(Z, mu)
+
+    def close(got, ref, what, atol=1e-12):
+        scale = max(1.0, float(np.max(np.abs(ref))))
+        np.testing.assert_allclose(got, ref, rtol=1e-10, atol=atol * scale, err_msg=what)
+
+    many = qc.QuantumDynamics(inp.integrators, inp.traj, devices=[0] * shards)
+    assert many.n_shards == shards
+    chunk = -(-(T - 1) // shards)
+    assert [many.shard_info(i)[1:] for i in range(shards)] == [(min(i * chunk, T - 1), min((i + 1) * chunk, T - 1)) for i in range(shards)]
+    Fm, Jm = many.F_dF(Z)
+    Hm = many.mu_d2F(Z, mu)
+    F_only = many.F(Z)
+    close(Fm, Fr, "config 4, 8 shards: F")
+    close(Jm, Jr, "config 4, 8 shards: dF")
+    close(Hm, Hr, "config 4, 8 shards: mu_d2F", atol=1e-11)
+    np.testing.assert_array_equal(F_only, Fm)
+    del Fr, Jr, Hr
+    one = qc.QuantumDynamics(inp.integrators, inp.traj)
+    F1, J1 = one.F_dF(Z)
+    H1 = one.mu_d2F(Z, mu)
+    assert np.array_equal(F1, Fm) and np.array_equal(J1, Jm) and np.array_equal(H1, Hm)
+    assert np.array_equal(one.F(Z), F_only)
+    one.close()
+    # device-resident: every shard writes its own slice of its own full-length vector (here: eight vectors on one device)
+    nj, nf, nh = int(many.dims.jac_nnz_interval), int(many.dims.ddim), int(many.dims.hess_nnz_interval)
+    dZ, dmu = torch.from_numpy(Z).cuda(), torch.from_numpy(mu).cuda()
+    lens = {k: int(L.lib.qc_multi_padded_len(many._h, k)) for k in (nj, nf, nh)}
+    assert lens[nj] == chunk * shards * nj
+    dJ = [torch.full((lens[nj],), float("nan"), dtype=torch.float64, device="cuda") for _ in range(shards)]
+    dF = [torch.full((lens[nf],), float("nan"), dtype=torch.float64, device="cuda") for _ in range(shards)]
+    dH = [torch.full((lens[nh],), float("nan"), dtype=torch.float64, device="cuda") for _ in range(shards)]
+    torch.cuda.synchronize()
+    arr = lambda ts: (C.c_void_p * shards)(*[t.data_ptr() for t in ts])
+    L.check(L.lib.qc_multi_eval_F_jac_dev(many._h, arr([dZ] * shards), arr(dF), arr(dJ)), many._h)
+    L.check(L.lib.qc_multi_eval_hess_dev(many._h, arr([dZ] * shards), arr([dmu] * shards), arr(dH)), many._h)
+    L.check(L.lib.qc_multi_sync(many._h), many._h)
+    for i in range(shards):
+        lo, hi = min(i * chunk, T - 1), min((i + 1) * chunk, T - 1)
+        assert torch.equal(dJ[i][lo * nj:hi * nj].cpu(), torch.from_numpy(Jm[lo * nj:hi * nj])), f"shard {i}: dF slice"
+        assert torch.equal(dF[i][lo * nf:hi * nf].cpu(), torch.from_numpy(Fm[lo * nf:hi * nf])), f"shard {i}: F slice"
+        assert torch.equal(dH[i][lo * nh:hi * nh].cpu(), torch.from_numpy(Hm[lo * nh:hi * nh])), f"shard {i}: mu_d2F slice"
+        assert bool(torch.isnan(dJ[i][:lo * nj]).all()) and bool(torch.isnan(dJ[i][hi * nj:]).all()), f"shard {i} wrote outside its slice"
+    many.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("full_size", [False, True])
+def test_multi_handle_on_distinct_devices_with_rccl_all_gather(qc, oracle, full_size):
     """Runs wherever at least two GPUs are visible (the driver's 8-GPU box; skipped on the 1-GPU boxes): one shard per device,
     qc_multi_eval_*_dev on each device's own vectors, then the in-library RCCL all-gather with one rank per device -- afterwards
     EVERY device holds the full value vector, bit-identical to a single-device evaluation; the host-buffer entry points of the
@@ -204,7 +271,9 @@ def test_multi_handle_on_distinct_devices_with_rccl_all_gather(qc, oracle):
         except OSError:
             pass
     shards = min(ndev, 8)
-    T = 64 * shards + 1 + 5          # a short last shard
+    # full_size: BASELINE config 4's trajectory (T = 8000 over eight devices; 1000 knots per device on a smaller box) -- the first
+    # box with several GPUs finds the all-gather of 42.6 MB per device waiting at the size the metric is quoted on
+    T = (8000 if shards == 8 else 1000 * shards) if full_size else 64 * shards + 1 + 5          # (small: a short last shard)
     inp = qc.config_inputs(3, T=T)
     Z = inp.traj.datavec
     one = qc.QuantumDynamics(inp.integrators, inp.traj, device=0)
