@@ -1,5 +1,5 @@
 import os, sys, numpy as np, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as g
 qc = g.load_package()
 for T in [int(t) for t in sys.argv[1:]]:

@@ -23,13 +23,13 @@ n = dyn.dims.n_intervals
 out = np.zeros(n * 16, dtype=np.uint64)
 qc._lib.check(qc._lib.lib.qc_debug_read_stamps(dyn._h, out.ctypes.data_as(C.POINTER(C.c_uint64)), out.size), dyn._h)
 st = out.reshape(n, 16).astype(np.int64)
-names = {0: "entry", 11: "first two loads requested", 1: "every load requested", 2: "loads back", 3: "stage A issued", 5: "stage B issued",
-         6: "tiles transposed", 7: "matrix blocks' stores issued", 8: "every store issued", 9: "drained"}
+names = {0: "entry", 11: "first two loads requested", 1: "every load requested", 2: "loads back", 3: "stage A issued", 5: "stage B issued", 4: "(a, a) stored (g2 kernel)",
+         6: "tiles transposed (g2: first pair stored)", 7: "matrix blocks' stores issued", 8: "every store issued", 9: "drained"}
 t0 = st[:, 0][st[:, 0] > 0].min()
 rel = (st - t0) * 10.0 / 1e3
 print(f"T={T}: kernel {dyn.kernel_names[1]}; launch-to-launch (stamped) {e0.elapsed_time(e1) * 1e3 / 160:.2f} us; span {rel[:, 9].max():.2f} us")
 prev = None
-for k in [0, 11, 1, 2, 3, 5, 6, 7, 8, 9]:
+for k in [0, 11, 1, 2, 3, 5, 4, 6, 7, 8, 9]:
     ok = st[:, k] > 0
     if not ok.any(): continue
     col = rel[:, k][ok]

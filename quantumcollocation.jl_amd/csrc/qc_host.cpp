@@ -432,6 +432,7 @@ extern "C" int qc_create(const qc_desc* d, qc_handle** out) {
         }
         std::vector<char> blob16;
         if (!no_ell && qc_mfma16_ell_build(h->prm, G.data(), &blob16)) {
+            qc_mfma16_ell_pair_table(h->prm, &blob16);
             QC_HIP_C(hipMalloc(&h->dEll16, blob16.size()));
             QC_HIP_C(hipMemcpy(h->dEll16, blob16.data(), blob16.size(), hipMemcpyHostToDevice));
             h->prm.ell16 = h->dEll16;

@@ -724,6 +724,7 @@ hipError_t qc_launch_mfma_hess(const QcParams& P, const double* dZ, const double
     if (qc_mfma16_padeP_hess_supported(P)) return qc_launch_mfma16_padeP_hess(P, dZ, dMu, dH, st);
     if (P.n > 32) return qc_launch_mfma64_hess(P, dZ, dMu, dH, st);
     if (P.n > 16) return P.ell ? qc_launch_mfma32_ell_hess(P, dZ, dMu, dH, st) : qc_launch_mfma32_hess(P, dZ, dMu, dH, st);
+    if (qc_mfma16_hess_g2(P)) return qc_launch_mfma16_hess_g2(P, dZ, dMu, dH, st);       // one entry per drive-generator row: qc_mfma_hess_g2.hip (round 6)
     // two waves per interval up to one round of the device (qc_mfma_hess2.hip) -- unless the drives allow the one-wave kernel's row-gather
     // form, which keeps eight workgroups per CU resident and is faster at every length (T = 750 / 1000: 7.85 / 8.12 against 8.08 / 8.74 us)
     if (qc_mfma16_hess2_supported(P) && !qc_mfma16_hess_gathers(P)) return qc_launch_mfma16_hess2(P, dZ, dMu, dH, st);

@@ -162,3 +162,32 @@ def composed_oracle(inp, hess_align=1):
         return np.concatenate(rs, axis=1).reshape(-1), np.concatenate(cs, axis=1).reshape(-1)
 
     return SimpleNamespace(F=F, dF=dF, structure=structure, mu_d2F=mu_d2F, hess_structure=hess_structure, rows=rows, probs=probs)
+
+
+def aa_columns(dyn):
+    """Columns of the per-interval Hessian value block that hold (a_i, a_j) entries (for every member of a composed handle).
+    Round 6: mu_d2F ALONE takes these from the Gram matrix M D^T where the handle's drives have one entry per row
+    (qc_mfma_hess_g2.hip), the one-call / batched launches from the stage-A tiles: the same numbers to rounding, not the same sums."""
+    descs = [p[0] for p in dyn._parts] if hasattr(dyn, "_parts") else [dyn._desc]
+    stride = int(dyn.dims.hess_nnz_interval)
+    mask = np.zeros(stride, dtype=bool)
+    for d in descs:
+        if d.integrator != 0:
+            continue
+        s = 2 * d.N * (d.state_cols or d.N)
+        ft = d.off_dt >= 0
+        o = int(d.hess_offset) + 2 * s * d.m + (2 * s if ft else 0)
+        mask[o:o + d.m * (d.m + 1) // 2] = True
+    return mask
+
+
+def assert_same_hessian_values(Ha, Hb, dyn, what=""):
+    """Bit for bit outside the (a, a) columns; there to rounding (1e-12 of the block's scale: sums of at most 256 terms)."""
+    Ha, Hb = np.asarray(Ha), np.asarray(Hb)
+    assert Ha.shape == Hb.shape, what
+    mask = aa_columns(dyn)
+    A, B = Ha.reshape(-1, mask.size), Hb.reshape(-1, mask.size)
+    rest = np.array_equal(A[:, ~mask], B[:, ~mask])
+    assert rest, f"{what}: {(A[:, ~mask] != B[:, ~mask]).sum()} values outside the (a, a) block differ"
+    scale = max(1.0, float(np.abs(B[:, mask]).max())) if mask.any() and B.size else 1.0
+    np.testing.assert_allclose(A[:, mask], B[:, mask], rtol=1e-11, atol=1e-12 * scale, err_msg=f"{what}: (a, a) block")
