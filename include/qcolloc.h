@@ -79,7 +79,7 @@ extern "C" {
 #endif
 
 #define QC_VERSION_MAJOR 0
-#define QC_VERSION_MINOR 5
+#define QC_VERSION_MINOR 6
 
 enum {
     QC_OK = 0,
@@ -103,6 +103,14 @@ enum { QC_KERNEL_AUTO = 0, QC_KERNEL_LDS = 1, QC_KERNEL_MFMA = 2 };
 enum { QC_ROWS_STACKED = 0, QC_ROWS_BY_COMPONENT = 1 };
 
 typedef struct qc_handle qc_handle;
+
+/* Value blocks of an interval (qc_desc.jac_block_order / hess_block_order; the enumerators' order is the default order).
+ * Jacobian: d/dU_t = -I (x) F (N dense n x n blocks) | d/dU_t+1 = I (x) B (exponential integrator: the identity, s entries) | d/da
+ * (s x m, column-major) | d/ddt (s; free timestep) | the derivative integrators' entries.
+ * Hessian (upper triangle): (U_t, a) | (a, U_t+1) | (U_t, dt) | (dt, U_t+1) | (a, a) upper | (a, dt) | (dt, dt) | (dx, dt);
+ * blocks that do not exist for a handle (fixed timestep; exponential integrator: nothing touches knot t+1) have length 0. */
+enum { QC_JB_F = 0, QC_JB_B = 1, QC_JB_A = 2, QC_JB_H = 3, QC_JB_D = 4, QC_JAC_BLOCKS = 5 };
+enum { QC_HB_UA = 0, QC_HB_AU = 1, QC_HB_UH = 2, QC_HB_HU = 3, QC_HB_AA = 4, QC_HB_AH = 5, QC_HB_HH = 6, QC_HB_D = 7, QC_HESS_BLOCKS = 8 };
 
 /* Problem descriptor.  Offsets are 0-based positions inside one knot vector z_t of length zdim
  * (reference component order [U~, a, da, dda, dt]: trajectory_initialization.jl:357-382; other
@@ -168,6 +176,16 @@ typedef struct qc_desc {
     int32_t hess_tail_zeros;    /* composed handles only: explicit zero entries this handle appends after its own Hessian
                                  * values (the composer pads the shared per-interval block through its last handle) */
     int32_t deriv_row_off[QC_MAX_DERIV];
+    /* Order of the value blocks INSIDE an interval (ABI 0.6).  The values of an interval are a sequence of blocks; which block comes
+     * where is this library's choice, and the reference's own intra-knot COO order is not known here ("keep a
+     * permutation hook").  Once `julia/reconcile.jl` has printed Core's order, a binding that wants the value vectors in THAT order --
+     * without a 40 MB gather on the host per dF call -- names it here: a permutation of QC_JB_* / QC_HB_* (all zeros = the default
+     * order, the enumerators' order).  Structures, block offsets and every kernel follow it; the order of the entries inside a block
+     * (column-major) and of the derivative integrators' pieces stays.  Costs: the host-buffer Jacobian path sends one copy of the
+     * replicated blocks over PCIe only in the default order (another order: the full values), and the one-call launch stores the
+     * scalar Hessian entries one by one unless the four scalar kinds close the block in the default order. */
+    int32_t jac_block_order[QC_JAC_BLOCKS];
+    int32_t hess_block_order[QC_HESS_BLOCKS];
 } qc_desc;
 
 typedef struct qc_dims_t {

@@ -14,7 +14,7 @@ using Libdl
 
 const LIB = Ref{String}(get(ENV, "QCOLLOC_HIP_LIB", "libqcolloc_hip.so"))
 const QC_MAX_DERIV = 8
-const QC_ABI_VERSION = 5      # QC_VERSION_MAJOR * 1000 + QC_VERSION_MINOR of the include/qcolloc.h these mirrors were written against
+const QC_ABI_VERSION = 6      # QC_VERSION_MAJOR * 1000 + QC_VERSION_MINOR of the include/qcolloc.h these mirrors were written against
 
 # mirror of `qc_desc` (include/qcolloc.h); field order and types must match the header -- `__init__` checks the sizes against
 # the library's own `sizeof` (qc_sizeof_desc / qc_sizeof_dims / qc_sizeof_terms_desc) when the module is loaded
@@ -32,6 +32,8 @@ struct QCDesc
     row_placement::Int32                    # 0 = rows stacked in integrator order, 1 = rows at the state components' positions
     hess_tail_zeros::Int32
     deriv_row_off::NTuple{QC_MAX_DERIV,Int32}
+    jac_block_order::NTuple{5,Int32}        # order of the value blocks inside an interval (ABI 0.6): permutations of QC_JB_* / QC_HB_*,
+    hess_block_order::NTuple{8,Int32}       # all zeros = the library's default order (what `julia/reconcile.jl` prints is Core's)
 end
 
 struct QCDims
@@ -145,6 +147,10 @@ function state_row_offset(traj, name)
     error("no state component $name")
 end
 
+# qc_desc.jac_block_order / hess_block_order: `nothing` = the library's default order (all zeros), else a permutation of 0:n-1
+block_order(order, n::Int) = isnothing(order) ? ntuple(_ -> Int32(0), n) :
+    (sort(collect(order)) == collect(0:n-1) || error("block order must be a permutation of 0:$(n-1)"); ntuple(i -> Int32(order[i]), n))
+
 """
     dynamics(integrators, traj, system; device=0, devices=nothing, eval_hessian=true, rows=:stacked, padded=false, result_ring=0)
 
@@ -161,11 +167,15 @@ device-resident consumers: every interval's value block padded to whole cache li
 consumer sums away -- a host-buffer call is bound by PCIe and gains nothing from it.
 `set_new_x!(dyn, false)` is Ipopt's `new_x = false`: the following calls reuse the knots already on the device.
 `result_ring`: 0 (default) = `F` / `∂F` / `μ∂²F` return fresh vectors; n >= 3 = rings of n pinned result vectors per closure (see `HIPDynamics`).
+`jac_block_order` / `hess_block_order`: the order of the value blocks inside an interval (`qc_desc.jac_block_order`, ABI 0.6) -- a
+permutation of `0:4` (−F copies, B copies / identity, ∂a, ∂Δt, derivative integrators) / `0:7` ((Ũ_t,a), (a,Ũ_t+1), (Ũ_t,Δt),
+(Δt,Ũ_t+1), (a,a), (a,Δt), (Δt,Δt), (dx,Δt)); `julia/reconcile.jl` prints the order QuantumCollocationCore's structures have.
 """
 function dynamics(integrators, traj, system; device::Int=0, devices=nothing, eval_hessian::Bool=true,
                   state_name=:Ũ⃗, control_name=:a, pade_order::Int=4, exponential::Bool=false,
                   derivative_pairs=[(:a, :da), (:da, :dda)], n_kets::Int=0, rows::Symbol=:stacked, hess_align::Int=0,
-                  padded::Bool=false, result_ring::Int=0, offsets=nothing, generators=nothing)
+                  padded::Bool=false, result_ring::Int=0, offsets=nothing, generators=nothing,
+                  jac_block_order=nothing, hess_block_order=nothing)
     (result_ring == 0 || result_ring >= 3) || error("result_ring must be 0 (fresh vectors) or at least 3")
     padded && (hess_align = 16)
     # `offsets` (0-based positions inside a knot, keyed by name) and `generators` = (G_drift, [G_1 .. G_m]) override what is read from
@@ -190,7 +200,8 @@ function dynamics(integrators, traj, system; device::Int=0, devices=nothing, eva
                           pad8(xs), pad8(dxs), pad8(dms), pointer(G0), pointer(Gd),
                           isempty(devs) ? device : devs[1], 0, 0, 0, n_kets, hess_align,
                           bycomp ? traj.dims.states : 0, bycomp ? state_row_offset(traj, state_name) : 0, 0, 0, 0, 0,
-                          bycomp ? 1 : 0, 0, bycomp ? pad8([state_row_offset(traj, p[1]) for p in derivative_pairs]) : pad8(Int[])))
+                          bycomp ? 1 : 0, 0, bycomp ? pad8([state_row_offset(traj, p[1]) for p in derivative_pairs]) : pad8(Int[]),
+                          block_order(jac_block_order, 5), block_order(hess_block_order, 8)))
         if isempty(devs)
             check(ccall((:qc_create, LIB[]), Cint, (Ref{QCDesc}, Ref{Ptr{Cvoid}}), desc, h))
         else
@@ -260,10 +271,19 @@ function component_at(traj, first_index::Integer)
     end
     error("QCollocHIP.QuantumDynamics: no trajectory component starts at knot position $first_index")
 end
-# (G_drift, [G_1 .. G_m]) from the integrator's generator closure G(a) = G_drift + sum_j a_j G_j (affine in a: m + 1 evaluations)
+# (G_drift, [G_1 .. G_m]) from the integrator's generator closure G(a) = G_drift + sum_j a_j G_j (affine in a: m + 1 evaluations),
+# and ONE more evaluation at a generic point that checks the assumption: a closure that is not affine in a (a nonlinear drive, a
+# time-dependent frame) would otherwise be replaced by its linearisation without a word (ADVICE round 5)
 function generators_from_closure(G, m::Integer)
     G0 = Matrix{Float64}(G(zeros(m)))
-    return G0, [Matrix{Float64}(G([j == k ? 1.0 : 0.0 for k in 1:m])) - G0 for j in 1:m]
+    Gs = [Matrix{Float64}(G([j == k ? 1.0 : 0.0 for k in 1:m])) - G0 for j in 1:m]
+    a = [0.37 + 0.21 * k - 0.05 * k^2 for k in 1:m]
+    model = m == 0 ? G0 : G0 + sum(a[k] * Gs[k] for k in 1:m)
+    err = maximum(abs, Matrix{Float64}(G(a)) - model; init=0.0)
+    err <= 1e-12 * max(1.0, maximum(abs, model; init=0.0)) ||
+        error("QCollocHIP.QuantumDynamics: the integrator's generator closure G(a) is not affine in a (deviation $err at a test point): " *
+              "this library evaluates G(a) = G_drift + sum_j a_j G_j only; pass `system = ...` if the closure is not the system's")
+    return G0, Gs
 end
 
 """
@@ -283,6 +303,8 @@ Everything `dynamics(integrators, traj, system; ...)` needs is read from the int
 | Padé order                     | `P.order` (an `...ExponentialIntegrator` type name selects the exponential)    | `pade_order`         |
 | derivative integrators         | `D.variable_components` / `D.derivative_components`, or `D.variable` / `D.derivative` names, of every element whose type name contains `DerivativeIntegrator` | `derivative_pairs` |
 
+NOT YET A VERIFIED DROP-IN: this constructor has never run against QuantumCollocationCore (no Julia in the build image; ADVICE
+round 5) -- `julia/reconcile.jl` is the first thing to run on a machine that has both.
 The field names are those recalled for QuantumCollocationCore 0.3.x (not vendored with the reference, SURVEY Appendix B): a field that
 is absent under every listed name raises an error naming the keyword that supplies it.  Lists with several state integrators (sampling
 and direct-sum problems) go to `dynamics_list`.  Remaining keywords (`device`, `devices`, `eval_hessian`, `rows`, `padded`,
@@ -351,6 +373,9 @@ function QuantumDynamics(integrators::AbstractVector, traj; system=nothing, stat
             push!(parts, (system=(G_drift=gens[1], G_drives=gens[2], levels=size(gens[1], 1) ÷ 2), state_name=sname, control_name=cname,
                           derivative_pairs=Tuple{Symbol,Symbol}[], pade_order=expo ? 4 : ord, exponential=expo, n_kets=kets_of(I)))
         else
+            isempty(parts) && error("QCollocHIP.QuantumDynamics: a DerivativeIntegrator comes before every state integrator of the list; " *
+                                    "rows are stacked in list order behind the state integrator a derivative integrator follows " *
+                                    "(unitary_smooth_pulse_problem.jl:175-179): put the Padé / exponential integrator first")
             k = count(is_derivative_integrator, integrators[1:i])
             push!(parts[end].derivative_pairs, dpairs[k])
         end
@@ -400,7 +425,8 @@ function dynamics_list(parts, traj; device::Int=0, devices=nothing, eval_hessian
                       expo ? 1 : 0, expo ? 0 : opt(p, :pade_order, 4), length(dpairs),
                       pad8(xs), pad8(dxs), pad8(dms), pointer(G0), pointer(Gd),
                       device, 0, 0, 0, opt(p, :n_kets, 0), 1,
-                      place[1], place[2], place[3], place[4], place[5], place[6], 0, place[7], pad8(Int[]))
+                      place[1], place[2], place[3], place[4], place[5], place[6], 0, place[7], pad8(Int[]),
+                      block_order(nothing, 5), block_order(nothing, 8))
     end
     # pass 1: every part's own sizes (no device work), hence its slot in the shared per-interval blocks
     own = QCDims[]

@@ -111,6 +111,27 @@ rec, dyn = reference_record(sys1, traj; name="fixture")
 push!(verdicts, "rows of an interval: length(F) == Z.dims.states * (T - 1)" => (length(rec["F"]) == rec["rows_declared"]))
 push!(verdicts, "COO order inside an interval: first 6 (row, col) of dF_structure" => collect(zip(rec["dF_rows"][1:6], rec["dF_cols"][1:6])))
 push!(verdicts, "Hessian structure is upper-triangular" => all(r <= c for (r, c) in zip(rec["mu_d2F_rows"], rec["mu_d2F_cols"])))
+# The order of the value BLOCKS inside an interval, as Core's structures have it: what to pass as `jac_block_order` / `hess_block_order`
+# (qc_desc, ABI 0.6) so that the library's value vectors come in Core's order without a gather on the host.  Kinds as in include/qcolloc.h:
+# Jacobian 0 dU_t, 1 dU_t+1, 2 da, 3 dDt, 4 derivative integrators; Hessian 0 (U_t,a) 1 (a,U_t+1) 2 (U_t,Dt) 3 (Dt,U_t+1) 4 (a,a) 5 (a,Dt)
+# 6 (Dt,Dt) 7 (dx,Dt).  An order with a kind appearing in several runs is not a block order: the binding then needs a permutation.
+let zd = traj.dim, sU = length(traj.components[:Ũ⃗]), cU = traj.components[:Ũ⃗], ca = traj.components[:a], cdt = traj.components[:Δt]
+    knot(c) = (c - 1) ÷ zd; pos(c) = (c - 1) % zd + 1
+    jkind(r, c) = (r - 1) % traj.dims.states + 1 > sU ? 4 :
+                  (pos(c) in cU ? (knot(c) == 0 ? 0 : 1) : pos(c) in ca ? 2 : pos(c) in cdt ? 3 : -1)
+    runs(ks) = [ks[i] for i in eachindex(ks) if i == 1 || ks[i] != ks[i-1]]
+    nj = length(rec["dF_rows"]) ÷ (traj.T - 1)
+    jk = [jkind(r, c) for (r, c) in zip(rec["dF_rows"][1:nj], rec["dF_cols"][1:nj])]
+    push!(verdicts, "order of the Jacobian value blocks inside an interval (jac_block_order)" => runs(jk))
+    hkind(r, c) = begin
+        pr, pc, kc = pos(r), pos(c), knot(c)
+        pr in cU && pc in ca ? 0 : pr in ca && pc in cU && kc == 1 ? 1 : pr in cU && pc in cdt ? 2 : pr in cdt && pc in cU && kc == 1 ? 3 :
+        pr in ca && pc in ca ? 4 : pr in ca && pc in cdt ? 5 : pr in cdt && pc in cdt ? 6 : pc in cdt ? 7 : -1
+    end
+    nh = length(rec["mu_d2F_rows"]) ÷ (traj.T - 1)
+    hk = [hkind(r, c) for (r, c) in zip(rec["mu_d2F_rows"][1:nh], rec["mu_d2F_cols"][1:nh])]
+    push!(verdicts, "order of the Hessian value blocks inside an interval (hess_block_order)" => runs(hk))
+end
 # scalar definitions (INTEGRATION.md table)
 a = traj.a; Δt = vec(traj.Δt)
 L = QuadraticRegularizer(:a, traj, 1.0; timestep_name=:Δt).L(traj.datavec, traj)

@@ -30,6 +30,11 @@ QC_ERR_HIP = -3
 QC_ERR_UNSUPPORTED = -4
 QC_PADE = 0
 QC_EXPONENTIAL = 1
+# value blocks of an interval (qc_desc.jac_block_order / hess_block_order: permutations of these, all zeros = this order)
+QC_JB_F, QC_JB_B, QC_JB_A, QC_JB_H, QC_JB_D = range(5)
+QC_JAC_BLOCKS = 5
+QC_HB_UA, QC_HB_AU, QC_HB_UH, QC_HB_HU, QC_HB_AA, QC_HB_AH, QC_HB_HH, QC_HB_D = range(8)
+QC_HESS_BLOCKS = 8
 QC_KERNEL_AUTO = 0
 QC_KERNEL_LDS = 1
 QC_KERNEL_MFMA = 2
@@ -38,7 +43,7 @@ QC_HESS_ALIGN_LINE = 16     # qc_desc.hess_align of the line-aligned (padded) He
 QC_FID_UNITARY, QC_FID_KET, QC_FID_DENSITY = 0, 1, 2
 QC_REG_DT_SCALED = 2       # (0 and 1 are retired values: the library refuses them)
 QC_REG_PLAIN = 3
-QC_ABI_VERSION = 5          # QC_VERSION_MAJOR * 1000 + QC_VERSION_MINOR of the include/qcolloc.h this file mirrors
+QC_ABI_VERSION = 6          # QC_VERSION_MAJOR * 1000 + QC_VERSION_MINOR of the include/qcolloc.h this file mirrors
 QC_FID_FORM_ABS, QC_FID_FORM_ABS2 = 0, 1
 QC_ROWS_STACKED = 0
 QC_ROWS_BY_COMPONENT = 1
@@ -81,6 +86,8 @@ class qc_desc(C.Structure):
         ("row_placement", C.c_int32),
         ("hess_tail_zeros", C.c_int32),
         ("deriv_row_off", C.c_int32 * QC_MAX_DERIV),
+        ("jac_block_order", C.c_int32 * QC_JAC_BLOCKS),
+        ("hess_block_order", C.c_int32 * QC_HESS_BLOCKS),
     ]
 
 

@@ -168,33 +168,51 @@ int qc_build_params(const qc_desc* d, QcParams* P, qc_dims_t* dims, std::string*
 
     const int n2 = P->n * P->n, s = P->s, m = P->m;
     const bool ft = P->off_dt >= 0;
+    // Block orders (ABI 0.6): permutations of the block kinds; all zeros = the default order
+    int jord[QC_JAC_BLOCKS], hord[QC_HESS_BLOCKS];
+    {
+        bool jzero = true, hzero = true;
+        for (int i = 0; i < QC_JAC_BLOCKS; ++i) jzero = jzero && d->jac_block_order[i] == 0;
+        for (int i = 0; i < QC_HESS_BLOCKS; ++i) hzero = hzero && d->hess_block_order[i] == 0;
+        unsigned seen = 0;
+        for (int i = 0; i < QC_JAC_BLOCKS; ++i) {
+            jord[i] = jzero ? i : d->jac_block_order[i];
+            if (jord[i] < 0 || jord[i] >= QC_JAC_BLOCKS || (seen & (1u << jord[i]))) return fail(err, QC_ERR_INVALID, "jac_block_order is not a permutation of QC_JB_*");
+            seen |= 1u << jord[i];
+        }
+        seen = 0;
+        for (int i = 0; i < QC_HESS_BLOCKS; ++i) {
+            hord[i] = hzero ? i : d->hess_block_order[i];
+            if (hord[i] < 0 || hord[i] >= QC_HESS_BLOCKS || (seen & (1u << hord[i]))) return fail(err, QC_ERR_INVALID, "hess_block_order is not a permutation of QC_HB_*");
+            seen |= 1u << hord[i];
+        }
+    }
     // Jacobian block offsets
     int o = 0;
-    P->jo_F = o;  o += P->nc * n2;
-    P->jo_B = o;  o += (P->integrator == QC_PADE) ? P->nc * n2 : s;
-    P->jo_a = o;  o += s * m;
-    P->jo_h = o;  o += ft ? s : 0;
-    P->jo_d = o;
-    for (int i = 0; i < P->n_deriv; ++i) o += (ft ? 4 : 3) * P->ddim_i[i];
+    {
+        int dlen = 0;
+        for (int i = 0; i < P->n_deriv; ++i) dlen += (ft ? 4 : 3) * P->ddim_i[i];
+        const int len[QC_JAC_BLOCKS] = {P->nc * n2, (P->integrator == QC_PADE) ? P->nc * n2 : s, s * m, ft ? s : 0, dlen};
+        int* const off[QC_JAC_BLOCKS] = {&P->jo_F, &P->jo_B, &P->jo_a, &P->jo_h, &P->jo_d};
+        for (int i = 0; i < QC_JAC_BLOCKS; ++i) { *off[jord[i]] = o; o += len[jord[i]]; }
+    }
     P->jac_nnz = o;
     // Hessian block offsets.  The exponential integrator's residual U_t+1 - exp(h G) U_t is linear in U_t+1: its (a, U_t+1) and
     // (h, U_t+1) blocks are structurally empty (the reference solves :exponential problems with the Hessian left on,
     // unitary_smooth_pulse_problem.jl:224-266).
+    // Default order: the four kinds of matrix blocks first -- whole 128-byte lines each when the interval's block is line-aligned
+    // (hess_align = 16, 2N x N a multiple of 16) --, then the scalar blocks as ONE contiguous run that the one-call kernel assembles and
+    // stores in one piece (round 5: the scalar entries used to sit between the blocks; partly written lines at the tail of that launch
+    // cost 0.7 us)
     o = 0;
     const int ub = P->integrator == QC_PADE ? 1 : 0;
     {
-        // the four kinds of matrix blocks first -- whole 128-byte lines each when the interval's block is line-aligned (hess_align = 16,
-        // 2N x N a multiple of 16) --, then the scalar blocks as ONE contiguous run that the kernels assemble and store in one piece
-        // (round 5: the scalar entries used to sit between the blocks; partly written lines at the tail of the one-call launch cost 0.7 us)
-        P->ho_Ua = o;  o += s * m;
-        P->ho_aU = o;  o += ub * s * m;
-        P->ho_Uh = o;  o += ft ? s : 0;
-        P->ho_hU = o;  o += ft ? ub * s : 0;
-        P->ho_aa = o;  o += m * (m + 1) / 2;
-        P->ho_ah = o;  o += ft ? m : 0;
-        P->ho_hh = o;  o += ft ? 1 : 0;
-        P->ho_d = o;
-        if (ft) for (int i = 0; i < P->n_deriv; ++i) o += P->ddim_i[i];
+        int dlen = 0;
+        if (ft) for (int i = 0; i < P->n_deriv; ++i) dlen += P->ddim_i[i];
+        const int len[QC_HESS_BLOCKS] = {s * m, ub * s * m, ft ? s : 0, ft ? ub * s : 0, m * (m + 1) / 2, ft ? m : 0, ft ? 1 : 0, dlen};
+        int* const off[QC_HESS_BLOCKS] = {&P->ho_Ua, &P->ho_aU, &P->ho_Uh, &P->ho_hU, &P->ho_aa, &P->ho_ah, &P->ho_hh, &P->ho_d};
+        for (int i = 0; i < QC_HESS_BLOCKS; ++i) { *off[hord[i]] = o; o += len[hord[i]]; }
+        P->scal_run = hord[4] == QC_HB_AA && hord[5] == QC_HB_AH && hord[6] == QC_HB_HH && hord[7] == QC_HB_D;
     }
     P->hess_nnz = o;
     // placement inside the problem's vectors
@@ -205,7 +223,7 @@ int qc_build_params(const qc_desc* d, QcParams* P, qc_dims_t* dims, std::string*
     P->J_stride = d->jac_per_interval > 0 ? d->jac_per_interval : P->jac_nnz;
     P->J_off = d->jac_offset;
     // Line alignment of the per-interval Hessian blocks: explicit zeros after the handle's own values.
-    if (d->hess_align < 0 || d->hess_align > 4096) return fail(err, QC_ERR_INVALID, "hess_align must be in 0..4096");
+    if (d->hess_align < 0 || d->hess_align > 64) return fail(err, QC_ERR_INVALID, "hess_align must be in 0..64 (16 = whole 128-byte lines)");
     if (d->hess_tail_zeros < 0 || d->hess_tail_zeros > 4096) return fail(err, QC_ERR_INVALID, "hess_tail_zeros must be in 0..4096");
     if (d->hess_per_interval > 0) {
         P->h_pad = P->hess_nnz ? d->hess_tail_zeros : 0;
@@ -236,54 +254,70 @@ int qc_build_params(const qc_desc* d, QcParams* P, qc_dims_t* dims, std::string*
     return QC_OK;
 }
 
-// Local structure: rows in [0, ddim), cols in [0, 2*zdim) with col >= zdim meaning knot t+1.
+// Local structure: rows in [0, ddim), cols in [0, 2*zdim) with col >= zdim meaning knot t+1.  Every block is written at ITS offset
+// (P.jo_* / P.ho_*: qc_desc.jac_block_order / hess_block_order decide where the blocks sit; inside a block the order is fixed).
 void qc_local_jac_structure(const QcParams& P, std::vector<int32_t>* R, std::vector<int32_t>* C) {
-    R->clear(); C->clear();
-    R->reserve(P.jac_nnz); C->reserve(P.jac_nnz);
+    R->assign(P.jac_nnz, 0); C->assign(P.jac_nnz, 0);
     const int n = P.n, N = P.nc, s = P.s, m = P.m, zd = P.zdim;
     const bool ft = P.off_dt >= 0;
+    int o = 0;
+    auto put = [&](int r, int c) { (*R)[o] = r; (*C)[o] = c; ++o; };
+    o = P.jo_F;
     for (int q = 0; q < N; ++q)
         for (int c = 0; c < n; ++c)
-            for (int r = 0; r < n; ++r) { R->push_back(q * n + r); C->push_back(P.off_U + q * n + c); }
+            for (int r = 0; r < n; ++r) put(q * n + r, P.off_U + q * n + c);
+    o = P.jo_B;
     if (P.integrator == QC_PADE) {
         for (int q = 0; q < N; ++q)
             for (int c = 0; c < n; ++c)
-                for (int r = 0; r < n; ++r) { R->push_back(q * n + r); C->push_back(zd + P.off_U + q * n + c); }
+                for (int r = 0; r < n; ++r) put(q * n + r, zd + P.off_U + q * n + c);
     } else {
-        for (int i = 0; i < s; ++i) { R->push_back(i); C->push_back(zd + P.off_U + i); }
+        for (int i = 0; i < s; ++i) put(i, zd + P.off_U + i);
     }
+    o = P.jo_a;
     for (int j = 0; j < m; ++j)
-        for (int i = 0; i < s; ++i) { R->push_back(i); C->push_back(P.off_a + j); }
+        for (int i = 0; i < s; ++i) put(i, P.off_a + j);
+    o = P.jo_h;
     if (ft)
-        for (int i = 0; i < s; ++i) { R->push_back(i); C->push_back(P.off_dt); }
+        for (int i = 0; i < s; ++i) put(i, P.off_dt);
+    o = P.jo_d;
     for (int d = 0; d < P.n_deriv; ++d) {
         const int dim = P.ddim_i[d], r0 = P.drow[d];   // relative to the handle's row block (F_off is added by the caller)
-        for (int i = 0; i < dim; ++i) { R->push_back(r0 + i); C->push_back(P.x_off[d] + i); }
-        for (int i = 0; i < dim; ++i) { R->push_back(r0 + i); C->push_back(zd + P.x_off[d] + i); }
-        for (int i = 0; i < dim; ++i) { R->push_back(r0 + i); C->push_back(P.dx_off[d] + i); }
-        if (ft) for (int i = 0; i < dim; ++i) { R->push_back(r0 + i); C->push_back(P.off_dt); }
+        for (int i = 0; i < dim; ++i) put(r0 + i, P.x_off[d] + i);
+        for (int i = 0; i < dim; ++i) put(r0 + i, zd + P.x_off[d] + i);
+        for (int i = 0; i < dim; ++i) put(r0 + i, P.dx_off[d] + i);
+        if (ft) for (int i = 0; i < dim; ++i) put(r0 + i, P.off_dt);
     }
 }
 
 void qc_local_hess_structure(const QcParams& P, std::vector<int32_t>* R, std::vector<int32_t>* C) {
-    R->clear(); C->clear();
+    R->assign(P.hess_nnz + P.h_pad, 0); C->assign(P.hess_nnz + P.h_pad, 0);
     const int s = P.s, m = P.m, zd = P.zdim;
     const bool ft = P.off_dt >= 0, pade = P.integrator == QC_PADE;   // exponential: no entry touches knot t+1
-    auto up = [&](int i, int j) { R->push_back(std::min(i, j)); C->push_back(std::max(i, j)); };
+    int o = 0;
+    auto up = [&](int i, int j) { (*R)[o] = std::min(i, j); (*C)[o] = std::max(i, j); ++o; };
+    o = P.ho_Ua;
     for (int j = 0; j < m; ++j) for (int i = 0; i < s; ++i) up(P.off_U + i, P.off_a + j);
+    o = P.ho_aU;
     if (pade) for (int j = 0; j < m; ++j) for (int i = 0; i < s; ++i) up(P.off_a + j, zd + P.off_U + i);
     if (ft) {
+        o = P.ho_Uh;
         for (int i = 0; i < s; ++i) up(P.off_U + i, P.off_dt);
+        o = P.ho_hU;
         if (pade) for (int i = 0; i < s; ++i) up(P.off_dt, zd + P.off_U + i);
     }
+    o = P.ho_aa;
     for (int j = 0; j < m; ++j) for (int i = 0; i <= j; ++i) up(P.off_a + i, P.off_a + j);
     if (ft) {
+        o = P.ho_ah;
         for (int j = 0; j < m; ++j) up(P.off_a + j, P.off_dt);
+        o = P.ho_hh;
         up(P.off_dt, P.off_dt);
+        o = P.ho_d;
         for (int d = 0; d < P.n_deriv; ++d) for (int i = 0; i < P.ddim_i[d]; ++i) up(P.dx_off[d] + i, P.off_dt);
     }
     // alignment padding: explicit zeros, recorded as duplicates of the first entry (COO duplicates are summed)
-    for (int i = 0; i < P.h_pad; ++i) { R->push_back((*R)[0]); C->push_back((*C)[0]); }
+    for (int i = 0; i < P.h_pad; ++i) { (*R)[P.hess_nnz + i] = (*R)[0]; (*C)[P.hess_nnz + i] = (*C)[0]; }
 }
 
 static void expand_structure(const QcParams& P, const std::vector<int32_t>& lr, const std::vector<int32_t>& lc,

@@ -57,12 +57,61 @@ static int timed_out(qc_handle* h, const char* what) {
                                          " ms waiting for " + what + " on the device (QC_HOST_TIMEOUT_MS)");
 }
 
-// first thing of every host-buffer call (device selected): finish what a timed-out call left on the streams
+// first thing of every host-buffer call (device selected): finish what a timed-out call left on the streams.  Polled against the
+// same deadline: on a device that is still hung the call returns QC_ERR_HIP again and the handle keeps the flag -- an
+// unbounded hipStreamSynchronize here would have made the deadline work once per handle only.
+static int drain_stream(qc_handle* h, hipStream_t st, bool foreign = false) {
+    if (!st) return QC_OK;
+    const double t0 = now_us();
+    for (unsigned spins = 0;; ++spins) {
+        const hipError_t e = hipStreamQuery(st);
+        if (e == hipSuccess) return QC_OK;
+        if (foreign && e != hipErrorNotReady) { (void)hipGetLastError(); return QC_OK; }   // the leader is gone: qc_destroy waited for its streams
+        if (e != hipErrorNotReady) return fail(&h->err, QC_ERR_HIP, std::string("hipStreamQuery: ") + hipGetErrorString(e));
+        if ((spins & 63) == 63 && now_us() - t0 > qc_team::timeout_us())
+            return fail(&h->err, QC_ERR_HIP, "the device has still not finished the work of a call that timed out (QC_HOST_TIMEOUT_MS): "
+                                               "keep that call's buffers allocated and call again, or destroy the handle");
+        cpu_pause();
+    }
+}
 static int drain_if_needed(qc_handle* h) {
     if (!h->needs_drain) return QC_OK;
-    QC_HIP(h, hipStreamSynchronize(h->stream));
-    if (h->stream2) QC_HIP(h, hipStreamSynchronize(h->stream2));
+    int rc;
+    if ((rc = drain_stream(h, h->stream)) || (rc = drain_stream(h, h->stream2))) return rc;      // (needs_drain stays set)
     h->needs_drain = false;
+    return QC_OK;
+}
+// A list call runs on its LEADER's streams and staging but writes the caller's arrays for every member: after a time-out every
+// member must drain the leader's streams before its own next call reuses or releases anything.
+static int drain_leader_if_needed(qc_handle* h) {
+    if (h->drain_dev < 0) return QC_OK;
+    qc_device_guard guard(h->drain_dev);
+    QC_HIP(h, guard.err);
+    int rc;
+    if ((rc = drain_stream(h, h->drain_s1, true)) || (rc = drain_stream(h, h->drain_s2, true))) return rc;
+    h->drain_dev = -1;
+    return QC_OK;
+}
+static void mark_members(qc_handle* const* hs, int count) {      // (the leader's streams by value: the leader may be destroyed first)
+    for (int i = 1; i < count; ++i) {
+        hs[i]->drain_s1 = hs[0]->stream;
+        hs[i]->drain_s2 = hs[0]->stream2;
+        hs[i]->drain_dev = hs[0]->device;
+    }
+}
+// dF / dJ / dH are zeroed when they are made and hold the rows / values of ONE layout at a time: the handle's own host-buffer calls
+// (tag 1) or a list it leads (a hash of the members).  Another layout zeroes them again: rows that the new layout's kernels never
+// write (QC_ROWS_BY_COMPONENT; other members' rows) must not show the previous layout's numbers.
+static int claim_plain(qc_handle* h, unsigned long long tag) {
+    if (h->plain_tag == tag) return QC_OK;
+    const QcParams& P = h->prm;
+    const size_t n_int = (size_t)P.n_int;
+    if (h->plain_tag != 0) {      // (fresh buffers are zeroed by ensure_zeroed)
+        if (h->dF) QC_HIP(h, hipMemsetAsync(h->dF, 0, n_int * (size_t)P.F_stride * sizeof(double), h->stream));
+        if (h->dJ) QC_HIP(h, hipMemsetAsync(h->dJ, 0, n_int * (size_t)P.J_stride * sizeof(double), h->stream));
+        if (h->dH) QC_HIP(h, hipMemsetAsync(h->dH, 0, n_int * (size_t)P.H_stride * sizeof(double), h->stream));
+    }
+    h->plain_tag = tag;
     return QC_OK;
 }
 
@@ -810,7 +859,7 @@ static int eval_host(qc_handle* h, const double* Z, double* F, double* vals, int
     qc_device_guard guard(h->device);
     QC_HIP(h, guard.err);
     int rc;
-    if ((rc = drain_if_needed(h))) return rc;
+    if ((rc = drain_if_needed(h)) || (rc = drain_leader_if_needed(h))) return rc;
     if ((rc = upload_knots(h, Z))) return rc;
     if (!vals) {
         // residuals only (a line-search trial): kernel -> HBM -> one copy into the caller's array.  (Rows no kernel writes --
@@ -826,7 +875,7 @@ static int eval_host(qc_handle* h, const double* Z, double* F, double* vals, int
             if (host_trace()) fprintf(stderr, "qcolloc host trace (residuals only, written in place): done +%.0f us\n", now_us() - t_begin);
             return rc;
         }
-        if ((rc = ensure_zeroed(h, &h->dF, (size_t)h->dims.F_len))) return rc;
+        if ((rc = claim_plain(h, 1)) || (rc = ensure_zeroed(h, &h->dF, (size_t)h->dims.F_len))) return rc;
         if ((rc = qc_eval_F_jac_dev(h, h->dZ, h->dF, nullptr, h->stream))) return rc;
         QC_HIP(h, hipMemcpyAsync(F, h->dF, (size_t)h->dims.F_len * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         QC_HIP(h, hipEventRecord(h->ev_done, h->stream));
@@ -883,7 +932,7 @@ static int eval_host_chunked(qc_handle* h, const double* Z, double* F, double* v
     qc_device_guard guard(h->device);
     QC_HIP(h, guard.err);
     int rc;
-    if ((rc = drain_if_needed(h))) return rc;
+    if ((rc = drain_if_needed(h)) || (rc = drain_leader_if_needed(h)) || (rc = claim_plain(h, 1))) return rc;
     // Only the knots this handle touches cross PCIe: [t_begin, t_end] inclusive, through a pinned staging buffer (an
     // asynchronous copy from pageable memory is staged by the runtime in small pieces and blocks the calling thread).
     const size_t z0 = (size_t)P.t_begin * P.zdim;
@@ -970,7 +1019,7 @@ static int hess_host(qc_handle* h, const double* Z, const double* mu, double* hv
     qc_device_guard guard(h->device);
     QC_HIP(h, guard.err);
     int rc;
-    if ((rc = drain_if_needed(h))) return rc;
+    if ((rc = drain_if_needed(h)) || (rc = drain_leader_if_needed(h)) || (rc = claim_plain(h, 1))) return rc;
     if ((rc = ensure(h, &h->dMu, (size_t)h->dims.n_rows))) return rc;
     if ((rc = ensure(h, &h->dH, (size_t)h->dims.hess_nnz))) return rc;
     if ((rc = upload_knots(h, Z))) return rc;
@@ -1544,26 +1593,24 @@ static int list_eval(qc_handle* const* hs, int32_t count, const double* Z, const
     const size_t n_int = (size_t)P.n_int;
     const size_t nF = n_int * (size_t)P.F_stride, nJ = n_int * (size_t)P.J_stride, nH = hvals ? n_int * (size_t)P.H_stride : 0;
     if ((rc = drain_if_needed(h))) return rc;
+    for (int i = 1; i < count; ++i) if ((rc = drain_leader_if_needed(hs[i]))) return rc;
     if ((rc = upload_knots(h, Z))) return rc;
     if (vals) {
-        if ((rc = list_eval_landing(hs, count, F, vals, shards)) < 0) return rc;
+        if ((rc = list_eval_landing(hs, count, F, vals, shards)) < 0) {
+            if (h->needs_drain) mark_members(hs, count);
+            return rc;
+        }
         if (rc == 1) {
             if (!hvals) return QC_OK;
             vals = nullptr;
             F = nullptr;
         }
     }
-    {   // dF / dJ / dH are zeroed when they are made; a DIFFERENT list led by this handle (other members: other rows and values
-        // owned) must not see the previous one's numbers where it writes nothing
+    {   // a DIFFERENT list led by this handle (other members: other rows and values owned), or the handle's own calls before
         unsigned long long tag = 1469598103934665603ull;
         for (int i = 0; i < count; ++i) tag = (tag ^ hs[i]->serial) * 1099511628211ull;
         tag |= 2ull;
-        if (h->plain_tag != tag) {
-            if (h->dF) QC_HIP(h, hipMemsetAsync(h->dF, 0, nF * sizeof(double), h->stream));
-            if (h->dJ) QC_HIP(h, hipMemsetAsync(h->dJ, 0, nJ * sizeof(double), h->stream));
-            if (h->dH) QC_HIP(h, hipMemsetAsync(h->dH, 0, n_int * (size_t)P.H_stride * sizeof(double), h->stream));
-            h->plain_tag = tag;
-        }
+        if ((rc = claim_plain(h, tag))) return rc;
     }
     if (F && (rc = ensure_zeroed(h, &h->dF, nF))) return rc;       // rows no handle of the list owns stay 0
     if (vals && (rc = ensure_zeroed(h, &h->dJ, nJ))) return rc;
@@ -1582,7 +1629,9 @@ static int list_eval(qc_handle* const* hs, int32_t count, const double* Z, const
         QC_HIP(h, hipMemcpyAsync(hvals, h->dH, nH * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     }
     QC_HIP(h, hipEventRecord(h->ev_done, h->stream));
-    return wait_done(h, shards);
+    rc = wait_done(h, shards);
+    if (h->needs_drain) mark_members(hs, count);      // timed out: the members' caller-owned arrays may still be written by the leader's streams
+    return rc;
 }
 
 extern "C" int qc_eval_F_list(qc_handle* const* hs, int32_t count, const double* Z, double* F) {

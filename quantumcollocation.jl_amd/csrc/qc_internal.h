@@ -41,6 +41,8 @@ struct QcParams {
     long long F_stride, F_off, J_stride, J_off, H_stride, H_off;
     int jo_F, jo_B, jo_a, jo_h, jo_d;                           // Jacobian sub-block offsets (doubles)
     int ho_Ua, ho_aU, ho_aa, ho_ah, ho_Uh, ho_hU, ho_hh, ho_d;  // Hessian sub-block offsets
+    int scal_run;            // the Hessian block's four scalar kinds [(a,a) | (a,h) | (h,h) | (dx,h)] close the block in this order (the default;
+                             // qc_desc.hess_block_order may say otherwise): the one-call kernel stages them in LDS and stores them in one piece
     int jchunk;              // LDS kernel: drives processed per phase
     int store_mode;          // 0 plain, 1 write-through (sc1), 2 non-temporal; see qc_st8
     int dbg_skip;            // diagnostic ablation (QC_DEBUG_SKIP): bit0 skip copy wave, bit1 skip compute wave
@@ -113,8 +115,11 @@ struct qc_handle {
     // layout's kernels never write must not show the previous layout's values.
     unsigned long long stage_tag = 0;
     size_t stage_cap = 0;
-    unsigned long long plain_tag = 0;   // the list (members) whose rows / values dF, dJ, dH hold: zeroed again when another list takes them
+    unsigned long long plain_tag = 0;   // whose rows / values dF, dJ, dH hold (0: nobody's yet, 1: the handle's own host-buffer calls, else the hash of a list
+                                        // it leads): zeroed again when another layout takes them (claim_plain)
     bool needs_drain = false;  // a wait on the device ran into QC_HOST_TIMEOUT_MS: the streams still hold that call's work -- the next call drains them first
+    hipStream_t drain_s1 = nullptr, drain_s2 = nullptr;   // ... and the same for a MEMBER of a list whose leader's call timed out: the leader's
+    int drain_dev = -1;                                   //     streams (by value: the leader may be destroyed before the member's next call)
     int new_x = 1;             // qc_set_new_x: 0 = the knots on the device are current, Z is not read
     bool z_valid = false;      // dZ holds this handle's knots of SOME host-buffer call
     unsigned long long z_gen = 0;    // uploads of the knots so far (qc_knot_generation: what a binding that elides uploads compares)

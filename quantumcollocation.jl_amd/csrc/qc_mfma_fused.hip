@@ -142,7 +142,7 @@ __global__ __launch_bounds__(kFuThreads, 2) void qc_mfma16_pade4_fused_kernel(co
     // the Hessian block's scalar entries leave in one piece (fu_scalar_run_store) where the copy wave's register path serves the
     // derivative integrators' entries; otherwise one by one, as qc_mfma16_pade4_hess_anti_kernel stores them
     const bool hfast = ft && P.n_deriv <= 2 && P.ddim_i[0] <= 64 && P.ddim_i[1] <= 64;
-    const bool staged = hfast && fu_scalar_run_len(P) <= kFuScalMax;
+    const bool staged = hfast && P.scal_run && fu_scalar_run_len(P) <= kFuScalMax;      // (scal_run: the scalar kinds close the block in the default order)
     double* __restrict__ scal = sm + kLdsScal;
     int* __restrict__ scal_count = reinterpret_cast<int*>(sm + kLdsFlag) + 1;
 

@@ -12,8 +12,9 @@ Every evaluation is a call into libqcolloc_hip.so; this class only builds the C 
 RESULT LIFETIME of the vector-returning calls (the only shape the reference's evaluator uses, script lines 45-52): a returned
 vector is the caller's for as long as the caller holds it (or any view of it), exactly as with the reference's closures, which
 return a fresh vector.  What is recycled is only what the caller has LET GO OF: each closure keeps up to `result_ring` (default 3)
-pinned, already-faulted-in vectors and hands one out again once nothing outside the ring refers to it any more (its reference
-count says so); while every vector of the ring is still held -- `[dyn.F(Z + h * e_i) for i in ...]` -- the call returns a newly
+pinned, already-faulted-in vectors and hands one out again once the array of its last hand-out and every view of it have been
+garbage-collected (a lease object under each hand-out, asked through a weak reference: explicit ownership, no reference counts;
+holders of a raw address are invisible to it); while every vector of the ring is still held -- `[dyn.F(Z + h * e_i) for i in ...]` -- the call returns a newly
 allocated array instead.  The evaluator's pattern (copy into Ipopt's buffer, drop) therefore never pays the 2.7 - 4 ms of
 first-touch page faults a fresh 40 MB vector costs at config 3, ten times the evaluation, and nobody ever sees a result change
 under their hands.  `fresh=True` on a call (or `result_ring=0` at construction) always allocates; `out=` writes into the caller's
@@ -24,6 +25,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import sys
+import weakref
 from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -93,6 +95,33 @@ def pinned_zeros(n: int) -> np.ndarray:
     return out
 
 
+class _Lease:
+    """One hand-out of a ring vector: the array the caller receives is made over this object (array interface), so this object is the
+    ultimate `.base` of that array and of every view derived from it, and it dies exactly when the last of them does.  The ring asks a
+    weak reference whether the lease is still alive -- explicit ownership instead of CPython reference counts (free-
+    threaded builds and PyPy count differently).  Holders of a raw address (`.ctypes.data`) are invisible to either scheme."""
+    __slots__ = ("__array_interface__", "owner", "__weakref__")
+
+    def __init__(self, owner: np.ndarray):
+        self.owner = owner           # keeps the (pinned) block alive while the lease is
+        self.__array_interface__ = {"shape": owner.shape, "typestr": "<f8", "data": (owner.ctypes.data, False), "version": 3}
+
+
+class _RingSlot:
+    __slots__ = ("owner", "lease", "quarantined")
+
+    def __init__(self, owner: np.ndarray):
+        self.owner, self.lease, self.quarantined = owner, None, False
+
+    def free(self) -> bool:
+        return not self.quarantined and (self.lease is None or self.lease() is None)
+
+    def lend(self) -> np.ndarray:
+        lease = _Lease(self.owner)
+        self.lease = weakref.ref(lease)
+        return np.asarray(lease)
+
+
 def split_groups(integrators: Sequence):
     """Integrator list -> groups, one per unitary integrator (or run of ket integrators of one system); derivative
     integrators go with the state integrator they follow, so that their rows follow its rows.  Covers the lists the
@@ -144,7 +173,7 @@ def state_row_offset(traj: NamedTrajectory, name: str) -> int:
 
 def make_desc(integrators: Sequence, traj: NamedTrajectory, *, device: int = 0, kernel: str = "auto",
               t_range: Optional[Tuple[int, int]] = None, placement: Optional[dict] = None, rows: str = "stacked",
-              hess_align: int = 0):
+              hess_align: int = 0, jac_block_order: Optional[Sequence[int]] = None, hess_block_order: Optional[Sequence[int]] = None):
     """Translate (integrators, traj) into a qc_desc.  Returns (desc, keepalive).
 
     rows = "stacked": rows of an interval are the integrators' rows in integrator order (default; what every problem
@@ -152,7 +181,9 @@ def make_desc(integrators: Sequence, traj: NamedTrajectory, *, device: int = 0, 
     every integrator's rows sit at its state component's position inside Z.dims.states rows per interval; state components
     without an integrator leave structurally empty rows (qc_desc.row_placement = QC_ROWS_BY_COMPONENT).
     hess_align: qc_desc.hess_align (0 / 1 = exactly the structural entries, the reference's structure and the default; 16 = every
-    interval's value block padded to whole 128-byte lines with explicit zero duplicates, for device-resident consumers)."""
+    interval's value block padded to whole 128-byte lines with explicit zero duplicates, for device-resident consumers).
+    jac_block_order / hess_block_order: qc_desc's (ABI 0.6) -- permutations of _lib.QC_JB_* / QC_HB_*, the order of the value blocks
+    inside an interval; None = the library's default order."""
     if not integrators or not isinstance(integrators[0], (_UnitaryIntegrator, _KetIntegrator, DensityOperatorExponentialIntegrator)):
         raise NotImplementedError("the first integrator must be the unitary (or the first ket) integrator "
                                   "(row order of reference unitary_smooth_pulse_problem.jl:175-179)")
@@ -215,6 +246,12 @@ def make_desc(integrators: Sequence, traj: NamedTrajectory, *, device: int = 0, 
     d.device = device
     d.kernel = _KERNELS[kernel]
     d.hess_align = int(hess_align)
+    for name, order, n in (("jac_block_order", jac_block_order, _lib.QC_JAC_BLOCKS), ("hess_block_order", hess_block_order, _lib.QC_HESS_BLOCKS)):
+        if order is not None:
+            if sorted(int(x) for x in order) != list(range(n)):
+                raise ValueError(f"{name} must be a permutation of 0..{n - 1}")
+            for i, x in enumerate(order):
+                getattr(d, name)[i] = int(x)
     if rows == "by_component":
         if placement:
             raise NotImplementedError("rows='by_component' with several unitary integrators")
@@ -264,12 +301,14 @@ class QuantumDynamics:
 
     def __init__(self, integrators: Sequence, traj: NamedTrajectory, *, device: int = 0, kernel: str = "auto",
                  t_range: Optional[Tuple[int, int]] = None, eval_hessian: bool = True, devices: Optional[Sequence[int]] = None,
-                 rows: str = "stacked", hess_align: int = 0, result_ring: int = 3):
+                 rows: str = "stacked", hess_align: int = 0, result_ring: int = 3,
+                 jac_block_order: Optional[Sequence[int]] = None, hess_block_order: Optional[Sequence[int]] = None):
         """devices = [d0, d1, ...]: ONE evaluator over several GPUs (qc_create_multi): the interval range is split into
         len(devices) contiguous shards, shard i on HIP device devices[i] (ordinals may repeat); F / dF / mu_d2F behave
         exactly as on one device and return the same arrays.
         result_ring: vectors per closure that the vector-returning calls recycle once the caller has let go of them (module
-        docstring); 0 = a fresh vector per call."""
+        docstring); 0 = a fresh vector per call.
+        jac_block_order / hess_block_order: the order of the value blocks inside an interval (make_desc)."""
         self.integrators = list(integrators)
         self.traj = traj
         self.eval_hessian = eval_hessian
@@ -279,7 +318,8 @@ class QuantumDynamics:
             if not self.devices:
                 raise ValueError("devices must name at least one device")
             device = self.devices[0]
-        self._desc, self._keep = make_desc(integrators, traj, device=device, kernel=kernel, t_range=t_range, rows=rows, hess_align=hess_align)
+        self._desc, self._keep = make_desc(integrators, traj, device=device, kernel=kernel, t_range=t_range, rows=rows, hess_align=hess_align,
+                                           jac_block_order=jac_block_order, hess_block_order=hess_block_order)
         self._h = C.c_void_p()
         if self.devices is None:
             _lib.check(_lib.lib.qc_create(C.byref(self._desc), C.byref(self._h)))
@@ -373,7 +413,9 @@ class QuantumDynamics:
         if int(result_ring) < 0:
             raise ValueError("result_ring must be 0 (a fresh vector per call) or the number of recycled vectors per closure")
         self.result_ring = int(result_ring)
-        self._rings = {}           # closure slot -> [vectors]  (at most result_ring each, built as they are needed)
+        self._rings = {}           # closure slot -> [_RingSlot]  (at most result_ring each, built as they are needed)
+        self._lent_now = []        # slots handed out for the call in progress
+        self._quarantine = False
 
     def _drop_rings(self) -> None:
         self._rings = {}           # vectors the caller still holds live on; the pinned blocks go with their last view
@@ -391,32 +433,52 @@ class QuantumDynamics:
             return np.empty(n)
         ring = self._rings.setdefault(slot or name, [])
         for k in range(len(ring)):
-            # references to a free vector: the ring's list, and getrefcount's own argument (views count: their base is the vector)
-            if sys.getrefcount(ring[k]) == 2:
+            if ring[k].free():                 # nobody holds the array of its last hand-out (nor a view of it) any more
                 ring.append(ring.pop(k))       # least recently handed out first
-                return ring[-1]
+                self._lent_now.append(ring[-1])
+                return ring[-1].lend()
         if len(ring) < self.result_ring:
-            ring.append(pinned_zeros(n))
-            return ring[-1]
+            ring.append(_RingSlot(pinned_zeros(n)))
+            self._lent_now.append(ring[-1])
+            return ring[-1].lend()
         return np.empty(n)
+
+    def _check(self, rc: int, h=None) -> None:
+        """_lib.check for the host-buffer calls.  A call that came back with QC_ERR_HIP (a wait on the device ran into
+        QC_HOST_TIMEOUT_MS) may have left work queued that still writes into its result vectors: their ring slots are quarantined until
+        a later call on the handle has succeeded, i.e. the library has drained its streams."""
+        lent, self._lent_now = self._lent_now, []
+        try:
+            _lib.check(rc, self._h if h is None else h)
+        except _lib.QCollocError as e:
+            if e.code == _lib.QC_ERR_HIP:
+                for ent in lent:
+                    ent.quarantined = True
+                self._quarantine = True
+            raise
+        if self._quarantine:
+            for ring in self._rings.values():
+                for ent in ring:
+                    ent.quarantined = False
+            self._quarantine = False
 
     def F(self, Z, out: Optional[np.ndarray] = None, *, fresh: bool = False) -> np.ndarray:
         Z = self._Z(Z)
         out = self._out("F", int(self.dims.F_len), out, fresh)
-        _lib.check(_lib.lib.qc_eval_F(self._h, _lib.dptr(Z), _lib.dptr(out)), self._h)
+        self._check(_lib.lib.qc_eval_F(self._h, _lib.dptr(Z), _lib.dptr(out)))
         return out
 
     def dF(self, Z, out: Optional[np.ndarray] = None, *, fresh: bool = False) -> np.ndarray:
         Z = self._Z(Z)
         out = self._out("J", int(self.dims.jac_nnz), out, fresh)
-        _lib.check(_lib.lib.qc_eval_jac(self._h, _lib.dptr(Z), _lib.dptr(out)), self._h)
+        self._check(_lib.lib.qc_eval_jac(self._h, _lib.dptr(Z), _lib.dptr(out)))
         return out
 
     def F_dF(self, Z, out: Optional[Tuple[np.ndarray, np.ndarray]] = None, *, fresh: bool = False):
         Z = self._Z(Z)
         F = self._out("F", int(self.dims.F_len), None if out is None else out[0], fresh)
         J = self._out("J", int(self.dims.jac_nnz), None if out is None else out[1], fresh)
-        _lib.check(_lib.lib.qc_eval_F_jac(self._h, _lib.dptr(Z), _lib.dptr(F), _lib.dptr(J)), self._h)
+        self._check(_lib.lib.qc_eval_F_jac(self._h, _lib.dptr(Z), _lib.dptr(F), _lib.dptr(J)))
         return F, J
 
     def mu_d2F(self, Z, mu, out: Optional[np.ndarray] = None, *, fresh: bool = False) -> np.ndarray:
@@ -425,32 +487,48 @@ class QuantumDynamics:
         if mu.size != self.dims.n_rows:
             raise ValueError(f"mu has length {mu.size}, expected {self.dims.n_rows}")
         out = self._out("H", int(self.dims.hess_nnz), out, fresh)
-        _lib.check(_lib.lib.qc_eval_hess(self._h, _lib.dptr(Z), _lib.dptr(mu), _lib.dptr(out)), self._h)
+        self._check(_lib.lib.qc_eval_hess(self._h, _lib.dptr(Z), _lib.dptr(mu), _lib.dptr(out)))
         return out
 
     def bind_host(self, which: str, Z: np.ndarray, *, mu: Optional[np.ndarray] = None, F: Optional[np.ndarray] = None,
                   J: Optional[np.ndarray] = None, H: Optional[np.ndarray] = None):
         """Pre-validated host-buffer call: a zero-argument callable returning the C status code, for timing loops (the per-call
         argument checks and pointer conversions of `F` / `dF` / `F_dF` / `mu_d2F` cost 8 - 10 us in Python, a tenth of a residual
-        evaluation; a `ccall` from Julia has none of that).  which = "F" | "dF" | "F_dF" | "mu_d2F"; the arrays must outlive it."""
+        evaluation; a `ccall` from Julia has none of that).  which = "F" | "dF" | "F_dF" | "mu_d2F"; the callable keeps its arrays
+        alive (`fn.keep`)."""
         import functools
         Z = self._Z(Z)
         if Z.ctypes.data % 8:
             raise ValueError("Z must be 8-byte aligned")
         zp = _lib.dptr(Z)
+        # arrays the caller did not pass are the callable's own (never the closures' rings: a raw address is invisible to the rings'
+        # ownership) and live as long as it does
+        own = lambda given, n: given if given is not None else pinned_zeros(int(n))
+        chk = lambda a, n, what: self._out(what, int(n), a)          # validates a caller's array
         if which == "F":
-            return functools.partial(_lib.lib.qc_eval_F, self._h, zp, _lib.dptr(self._out("F", int(self.dims.F_len), F)))
+            F = chk(own(F, self.dims.F_len), self.dims.F_len, "F")
+            fn = functools.partial(_lib.lib.qc_eval_F, self._h, zp, _lib.dptr(F))
+            fn.keep = (Z, F)
+            return fn
         if which == "dF":
-            return functools.partial(_lib.lib.qc_eval_jac, self._h, zp, _lib.dptr(self._out("J", int(self.dims.jac_nnz), J)))
+            J = chk(own(J, self.dims.jac_nnz), self.dims.jac_nnz, "J")
+            fn = functools.partial(_lib.lib.qc_eval_jac, self._h, zp, _lib.dptr(J))
+            fn.keep = (Z, J)
+            return fn
         if which == "F_dF":
-            return functools.partial(_lib.lib.qc_eval_F_jac, self._h, zp, _lib.dptr(self._out("F", int(self.dims.F_len), F)),
-                                     _lib.dptr(self._out("J", int(self.dims.jac_nnz), J)))
+            F = chk(own(F, self.dims.F_len), self.dims.F_len, "F")
+            J = chk(own(J, self.dims.jac_nnz), self.dims.jac_nnz, "J")
+            fn = functools.partial(_lib.lib.qc_eval_F_jac, self._h, zp, _lib.dptr(F), _lib.dptr(J))
+            fn.keep = (Z, F, J)
+            return fn
         if which == "mu_d2F":
             mu = np.ascontiguousarray(mu, dtype=np.float64)
             if mu.size != self.dims.n_rows:
                 raise ValueError(f"mu has length {mu.size}, expected {self.dims.n_rows}")
-            self._keep_mu = mu
-            return functools.partial(_lib.lib.qc_eval_hess, self._h, zp, _lib.dptr(mu), _lib.dptr(self._out("H", int(self.dims.hess_nnz), H)))
+            H = chk(own(H, self.dims.hess_nnz), self.dims.hess_nnz, "H")
+            fn = functools.partial(_lib.lib.qc_eval_hess, self._h, zp, _lib.dptr(mu), _lib.dptr(H))
+            fn.keep = (Z, mu, H)
+            return fn
         raise ValueError(which)
 
     def set_new_x(self, new_x: bool) -> None:
@@ -691,19 +769,19 @@ class ComposedQuantumDynamics(QuantumDynamics):
         Z = self._Z(Z)
         F = self._out("F", int(self.dims.F_len), None if out is None else out[0], fresh)
         J = self._out("J", int(self.dims.jac_nnz), None if out is None else out[1], fresh)
-        _lib.check(_lib.lib.qc_eval_F_jac_list(self._handles, len(self._parts), _lib.dptr(Z), _lib.dptr(F), _lib.dptr(J)), self._parts[0][2])
+        self._check(_lib.lib.qc_eval_F_jac_list(self._handles, len(self._parts), _lib.dptr(Z), _lib.dptr(F), _lib.dptr(J)), self._parts[0][2])
         return F, J
 
     def F(self, Z, out=None, *, fresh: bool = False):
         Z = self._Z(Z)
         F = self._out("F", int(self.dims.F_len), out, fresh)
-        _lib.check(_lib.lib.qc_eval_F_list(self._handles, len(self._parts), _lib.dptr(Z), _lib.dptr(F)), self._parts[0][2])
+        self._check(_lib.lib.qc_eval_F_list(self._handles, len(self._parts), _lib.dptr(Z), _lib.dptr(F)), self._parts[0][2])
         return F
 
     def dF(self, Z, out=None, *, fresh: bool = False):
         Z = self._Z(Z)
         J = self._out("J", int(self.dims.jac_nnz), out, fresh)
-        _lib.check(_lib.lib.qc_eval_jac_list(self._handles, len(self._parts), _lib.dptr(Z), _lib.dptr(J)), self._parts[0][2])
+        self._check(_lib.lib.qc_eval_jac_list(self._handles, len(self._parts), _lib.dptr(Z), _lib.dptr(J)), self._parts[0][2])
         return J
 
     def mu_d2F(self, Z, mu, out=None, *, fresh: bool = False):
@@ -714,7 +792,7 @@ class ComposedQuantumDynamics(QuantumDynamics):
         if mu.size != self.dims.n_rows:
             raise ValueError(f"mu has length {mu.size}, expected {self.dims.n_rows}")
         H = self._out("H", int(self.dims.hess_nnz), out, fresh)
-        _lib.check(_lib.lib.qc_eval_hess_list(self._handles, len(self._parts), _lib.dptr(Z), _lib.dptr(mu), _lib.dptr(H)), self._parts[0][2])
+        self._check(_lib.lib.qc_eval_hess_list(self._handles, len(self._parts), _lib.dptr(Z), _lib.dptr(mu), _lib.dptr(H)), self._parts[0][2])
         return H
 
     def knot_generation(self) -> int:

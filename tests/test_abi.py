@@ -458,8 +458,9 @@ def test_julia_struct_mirrors_match_the_ctypes_mirrors(qc):
             fname, ftype = [x.strip() for x in decl.split("::")]
             if ftype.startswith("Ptr{"):
                 ct = "ptr"
-            elif ftype.startswith("NTuple{QC_MAX_DERIV,"):
-                ct = tmap[ftype[len("NTuple{QC_MAX_DERIV,"):-1]] * L.QC_MAX_DERIV
+            elif ftype.startswith("NTuple{"):
+                count, elem = ftype[len("NTuple{"):-1].split(",")
+                ct = tmap[elem.strip()] * (L.QC_MAX_DERIV if count.strip() == "QC_MAX_DERIV" else int(count))
             else:
                 ct = tmap[ftype]
             out.append((fname, ct))
@@ -543,3 +544,48 @@ def test_julia_ccalls_match_the_header():
             assert [jkind(a) for a in jargs] == cargs, (fn, name, jargs, cargs)
             seen += 1
     assert seen >= 20, seen
+
+
+def test_block_orders_permute_the_structure_blockwise(qc, oracle):
+    """qc_desc.jac_block_order / hess_block_order (ABI 0.6; SURVEY 7 "permutation hook"): the value blocks of an interval in any order --
+    the same COO set, every block contiguous and internally unchanged, the blocks in the order asked for; descriptors that are not
+    permutations are refused."""
+    import ctypes as C
+    L = qc._lib
+    rng = np.random.default_rng(11)
+    for integ in ("pade", "exponential"):
+        for free_time in (True, False):
+            inp = qc.unitary_smooth_pulse_inputs(qc.multi_qubit_system(2), qc.GATES["CNOT"], 5, free_time=free_time, integrator=integ)
+            d0, _k0 = qc.make_desc(inp.integrators, inp.traj)
+            jr0, jc0, hr0, hc0 = qc.desc_structures(d0)
+            n_int = inp.traj.T - 1
+            dims0 = qc.desc_dims(d0)
+            for trial in range(4):
+                jo, ho = rng.permutation(L.QC_JAC_BLOCKS), rng.permutation(L.QC_HESS_BLOCKS)
+                d1, _k1 = qc.make_desc(inp.integrators, inp.traj, jac_block_order=jo, hess_block_order=ho)
+                dims1 = qc.desc_dims(d1)
+                assert (dims1.jac_nnz, dims1.hess_nnz, dims1.n_rows) == (dims0.jac_nnz, dims0.hess_nnz, dims0.n_rows)
+                jr1, jc1, hr1, hc1 = qc.desc_structures(d1)
+                for (r0, c0, r1, c1, order, what) in ((jr0, jc0, jr1, jc1, jo, "dF"), (hr0, hc0, hr1, hc1, ho, "mu_d2F")):
+                    a = np.stack([r0, c0], 1).reshape(n_int, -1, 2)[0]
+                    b = np.stack([r1, c1], 1).reshape(n_int, -1, 2)[0]
+                    assert sorted(map(tuple, a)) == sorted(map(tuple, b)), what            # the same COO set
+                    # default-order block lengths from the default structure: cut a at its block boundaries, reassemble in `order`
+                    prob = problem_from_inputs(inp)
+                    s, m, ft, pade = prob.s, prob.m, prob.free_time, prob.integrator == oracle.PADE
+                    dl = sum(dv.dim for dv in prob.derivs)
+                    if what == "dF":
+                        lens = [prob.nc * prob.n ** 2, prob.nc * prob.n ** 2 if pade else s, s * m, s if ft else 0, (4 if ft else 3) * dl]
+                    else:
+                        ub = 1 if pade else 0
+                        lens = [s * m, ub * s * m, s if ft else 0, ub * s if ft else 0, m * (m + 1) // 2, m if ft else 0, 1 if ft else 0, dl if ft else 0]
+                    assert sum(lens) == a.shape[0], what
+                    starts = np.concatenate([[0], np.cumsum(lens)])
+                    want = np.concatenate([a[starts[k]:starts[k + 1]] for k in order]) if a.size else a
+                    np.testing.assert_array_equal(b, want, err_msg=f"{what} {integ} ft={free_time} order={list(order)}")
+    bad, _ = qc.make_desc(inp.integrators, inp.traj)
+    bad.jac_block_order[0] = 1                     # (1, 0, 0, 0, 0): not a permutation
+    out = L.qc_dims_t()
+    assert L.lib.qc_desc_dims(C.byref(bad), C.byref(out)) == L.QC_ERR_INVALID and b"permutation" in L.lib.qc_last_error(None)
+    with pytest.raises(ValueError):
+        qc.make_desc(inp.integrators, inp.traj, hess_block_order=[0, 1, 2])

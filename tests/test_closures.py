@@ -17,7 +17,7 @@ def test_retired_regulariser_ids_are_refused(qc):
     the descriptor check runs before anything touches a device)."""
     import ctypes as C
     L = qc._lib
-    assert (L.QC_REG_DT_SCALED, L.QC_REG_PLAIN) == (2, 3) and L.lib.qc_abi_version() == 5
+    assert (L.QC_REG_DT_SCALED, L.QC_REG_PLAIN) == (2, 3) and L.lib.qc_abi_version() == 6
     idx = np.array([8, 9], dtype=np.int32)
     R = np.ones(2)
     d = L.qc_terms_desc()

@@ -1905,3 +1905,65 @@ def test_derivative_integrator_counts_and_sizes(qc, oracle, N, m, dims):
         rr, rc = oracle.jac_structure(prob)
         assert np.array_equal(jr, rr) and np.array_equal(jc, rc)
         h.close()
+
+
+@pytest.mark.parametrize("case", ["cfg3", "cfg3_long", "cfg2_fixed_dt", "cfg5", "exp3", "order6", "qutrit_lds"])
+def test_shuffled_value_blocks_give_the_same_values_blockwise(qc, oracle, case):
+    """qc_desc.jac_block_order / hess_block_order: every kernel family writes its blocks at the offsets the descriptor's order implies
+    -- F, dF, mu_d2F and the one-call form of a handle with shuffled blocks equal the default handle's entry for entry (matched through
+    the structures), bit for bit; the host-buffer Jacobian path leaves its compact form where the replicated blocks do not lead."""
+    import torch
+    from oracle_bridge import assert_same_hessian_values
+    kw = {}
+    if case == "cfg3":
+        inp = qc.config_inputs(3, T=40)
+    elif case == "cfg3_long":
+        inp = qc.config_inputs(3, T=1100)
+    elif case == "cfg2_fixed_dt":
+        inp = qc.unitary_smooth_pulse_inputs(qc.multi_qubit_system(2), qc.GATES["CNOT"], 30, free_time=False)
+    elif case == "cfg5":
+        inp = qc.config_inputs(5, T=12)
+    elif case == "exp3":
+        inp = qc.unitary_smooth_pulse_inputs(qc.multi_qubit_system(3), qc.GATES["TOFFOLI"], 20, integrator="exponential")
+    elif case == "order6":
+        inp = qc.unitary_smooth_pulse_inputs(qc.multi_qubit_system(2), qc.GATES["CNOT"], 20, pade_order=6)
+    else:
+        rng0 = np.random.default_rng(3)
+        herm = lambda: (lambda A: (A + A.conj().T) / 2)(rng0.standard_normal((3, 3)) + 1j * rng0.standard_normal((3, 3)))
+        inp = qc.unitary_smooth_pulse_inputs(qc.QuantumSystem(herm(), [herm(), herm()]), np.eye(3, dtype=complex), 12)
+        kw = dict(kernel="lds")
+    rng = np.random.default_rng(17)
+    Z = inp.traj.datavec + 1e-2 * rng.standard_normal(inp.traj.datavec.size)
+    ref = qc.QuantumDynamics(inp.integrators, inp.traj, **kw)
+    mu = rng.standard_normal(int(ref.dims.n_rows))
+    F0, J0 = ref.F_dF(Z, fresh=True)
+    H0 = ref.mu_d2F(Z, mu, fresh=True)
+    (jr0, jc0), (hr0, hc0) = ref.dF_structure, ref.mu_d2F_structure
+    key = lambda r, c: r.astype(np.int64) * (int(ref.dims.n_cols) + 1) + c
+    for jo, ho in (([4, 2, 0, 3, 1], [7, 4, 0, 5, 2, 6, 1, 3]), ([1, 0, 3, 2, 4], [1, 0, 3, 2, 5, 4, 6, 7])):
+        dyn = qc.QuantumDynamics(inp.integrators, inp.traj, jac_block_order=jo, hess_block_order=ho, **kw)
+        assert dyn.kernel_names == ref.kernel_names
+        F1, J1 = dyn.F_dF(Z, fresh=True)
+        H1 = dyn.mu_d2F(Z, mu, fresh=True)
+        (jr1, jc1), (hr1, hc1) = dyn.dF_structure, dyn.mu_d2F_structure
+        np.testing.assert_array_equal(F1, F0)
+        # entries are unique: sort both by (row, col) and compare values
+        p0, p1 = np.argsort(key(jr0, jc0), kind="stable"), np.argsort(key(jr1, jc1), kind="stable")
+        np.testing.assert_array_equal(key(jr0, jc0)[p0], key(jr1, jc1)[p1])
+        np.testing.assert_array_equal(J1[p1], J0[p0])
+        q0, q1 = np.argsort(key(hr0, hc0), kind="stable"), np.argsort(key(hr1, hc1), kind="stable")
+        np.testing.assert_array_equal(key(hr0, hc0)[q0], key(hr1, hc1)[q1])
+        np.testing.assert_array_equal(H1[q1], H0[q0])
+        np.testing.assert_array_equal(dyn.dF(Z, fresh=True), J1)
+        # device-resident: the two launches and the one call
+        dZ, dmu = torch.from_numpy(Z).cuda(), torch.from_numpy(mu).cuda()
+        dF, dJ, dH = (torch.full((int(n),), float("nan"), dtype=torch.float64, device="cuda") for n in (dyn.dims.F_len, dyn.dims.jac_nnz, dyn.dims.hess_nnz))
+        dyn.F_dF_mu_d2F_device(dZ, dmu, dF, dJ, dH)
+        torch.cuda.synchronize()
+        assert np.array_equal(dF.cpu().numpy(), F1) and np.array_equal(dJ.cpu().numpy(), J1)
+        Hd = dH.cpu().numpy()
+        assert np.isfinite(Hd).all()
+        # (one call against two launches: bit for bit but the (a, a) sums; compared through the default handle's column mask, permuted)
+        np.testing.assert_allclose(Hd[q1], H0[q0], rtol=1e-11, atol=1e-12 * max(1.0, np.abs(H0).max()))
+        dyn.close()
+    ref.close()

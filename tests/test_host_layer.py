@@ -75,7 +75,7 @@ def test_result_vectors_are_recycled_only_when_the_caller_let_go(qc):
         J[:] = 100 + k
         held.append(J)
     assert len({x.ctypes.data for x in held}) == 7 and [int(x[0]) for x in held] == [100 + k for k in range(7)]
-    ring_ptrs = {v.ctypes.data for v in obj._rings["J"]}
+    ring_ptrs = {v.owner.ctypes.data for v in obj._rings["J"]}
     assert len(ring_ptrs) == 3 and seen <= ring_ptrs and sum(x.ctypes.data in ring_ptrs for x in held) == 3   # the ring's three, then fresh arrays
     view = held[0][2:5]                                                        # a view keeps its vector out of circulation ...
     p0 = held[0].ctypes.data
@@ -97,6 +97,20 @@ def test_result_vectors_are_recycled_only_when_the_caller_let_go(qc):
     qc.QuantumDynamics._init_ring(none, 0)
     x, y = qc.QuantumDynamics._out(none, "J", 10), qc.QuantumDynamics._out(none, "J", 10)
     assert not np.shares_memory(x, y)
+    # a call that timed out on the device (QC_ERR_HIP) quarantines the vectors it was given: queued work may still write into them; a
+    # later successful call on the handle (the library has drained its streams by then) releases them
+    q = types.SimpleNamespace(_h=None)
+    qc.QuantumDynamics._init_ring(q, 2)
+    a = qc.QuantumDynamics._out(q, "J", 10)
+    pa = a.ctypes.data
+    with pytest.raises(qc._lib.QCollocError):
+        qc.QuantumDynamics._check(q, qc._lib.QC_ERR_HIP)
+    del a
+    b = qc.QuantumDynamics._out(q, "J", 10)
+    assert b.ctypes.data != pa                                                 # not the quarantined vector, although nobody holds it
+    qc.QuantumDynamics._check(q, qc._lib.QC_OK)
+    del b
+    assert pa in {qc.QuantumDynamics._out(q, "J", 10).ctypes.data for _ in range(2)}
     with pytest.raises(ValueError):
         qc.QuantumDynamics._init_ring(types.SimpleNamespace(), -1)
     qc.QuantumDynamics._drop_rings(obj)

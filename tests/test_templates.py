@@ -422,3 +422,48 @@ def test_a_shorter_list_never_sees_the_longer_lists_values(qc, oracle):
         np.testing.assert_array_equal(dyn.mu_d2F(Z, mu, fresh=True), H)
         np.testing.assert_array_equal(dyn.F(Z, fresh=True), F)
     dyn.close()
+
+
+@pytest.mark.gpu
+def test_own_call_after_leading_a_by_component_list_sees_structural_zeros(qc):
+    """two QC_ROWS_BY_COMPONENT handles (C API only: every handle's rows at its state component's position inside
+    Z.dims.states rows per interval) evaluated as a LIST leave the members' rows in the leader's zeroed-once device vector; the leader's
+    OWN residual call afterwards must deliver structural zeros there, not the other member's rows of the list call."""
+    import ctypes as C
+    L = qc._lib
+    s1 = qc.multi_qubit_system(1)
+    s1b = qc.QuantumSystem(1.3 * s1.H_drift, s1.H_drives)
+    inp = qc.unitary_sampling_inputs([s1, s1b], qc.GATES["H"], 9)
+    groups = qc.split_groups(inp.integrators)
+    assert len(groups) == 2
+    hs = (C.c_void_p * 2)()
+    keep = []
+    for k, grp in enumerate(groups):
+        d, ka = qc.make_desc(grp[:1], inp.traj, rows="by_component")     # the two unitary integrators alone: equal value blocks, as a list needs
+        keep.append(ka)
+        h = C.c_void_p()
+        L.check(L.lib.qc_create(C.byref(d), C.byref(h)))
+        hs[k] = h
+    dims = L.qc_dims_t()
+    L.check(L.lib.qc_dims(hs[0], C.byref(dims)), hs[0])
+    rows = int(inp.traj.dims.states)
+    n_int = inp.traj.T - 1
+    assert dims.F_len == rows * n_int
+    Z = inp.traj.datavec
+    F_own_before = np.full(dims.F_len, 7.0)
+    L.check(L.lib.qc_eval_F(hs[0], L.dptr(Z), L.dptr(F_own_before)), hs[0])
+    F_list = np.full(dims.F_len, 7.0)
+    assert L.lib.qc_eval_F_list(hs, 2, L.dptr(Z), L.dptr(F_list)) == L.QC_OK
+    F_own_after = np.full(dims.F_len, 7.0)
+    L.check(L.lib.qc_eval_F(hs[0], L.dptr(Z), L.dptr(F_own_after)), hs[0])
+    np.testing.assert_array_equal(F_own_after, F_own_before)
+    own = 8                                                       # the first system's iso-vec rows
+    a, b = F_own_after.reshape(n_int, rows), F_list.reshape(n_int, rows)
+    np.testing.assert_array_equal(a[:, :own], b[:, :own])
+    assert not a[:, own:].any() and b[:, own:2 * own].any()       # the list wrote the second member's rows; the own call shows zeros there
+    # ... and the list again behind the own call
+    F_list2 = np.full(dims.F_len, 7.0)
+    assert L.lib.qc_eval_F_list(hs, 2, L.dptr(Z), L.dptr(F_list2)) == L.QC_OK
+    np.testing.assert_array_equal(F_list2, F_list)
+    for k in range(2):
+        L.lib.qc_destroy(hs[k])
