@@ -55,7 +55,7 @@ for trial in range(trials):
         # (the exponential integrator's residual-only launch scales exp(dt G) by the norm of dt G alone, the F + dF launch by the norm of
         #  the augmented Frechet matrix: the same residuals to the last bits, not bit for bit; the Pade kernels' are identical)
         same([h.F(Z) for _ in range(REP)] + ([outs[0][0]] if integ == o.PADE else []), (tag, kernel, "F alone"))
-        if integ == o.PADE and h.dims.hess_nnz and (N <= 16 or order == 4):
+        if h.dims.hess_nnz and ((integ == o.PADE and (N <= 16 or order == 4)) or (integ == o.EXPONENTIAL and N <= 8)):
             same([h.hess(Z, mu) for _ in range(REP)], (tag, kernel, "mu_d2F"))
         h.close()
         count["handles"] += 1
