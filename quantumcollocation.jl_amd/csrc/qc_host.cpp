@@ -576,6 +576,7 @@ extern "C" const char* qc_kernel_name(const qc_handle* h, int32_t which) {
     if (P.integrator != QC_PADE) {      // exponential integrator: mu_d2F alone; F + dF + mu_d2F as two launches
         if (which == 2) return "two-launches";
         if (mfma && qc_mfma_exp_hess_supported(P)) return "mfma16-exp-hess";
+        if (mfma && qc_mfma32_exp_hess_supported(P)) return "mfma32-exp-hess";
         return P.use_ws ? "lds-gws-exp-hess" : "lds-exp-hess";
     }
     if (which == 2) return mfma && qc_mfma16_fused_supported(P) ? (qc_mfma16_fused_gathers(P) ? "mfma16-pade4-fused-gather" : "mfma16-pade4-fused") : (mfma && P.ell && P.hess_nnz ? "mfma32-pade4-fused-ell" : "two-launches");

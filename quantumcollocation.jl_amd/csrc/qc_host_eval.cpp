@@ -245,6 +245,8 @@ extern "C" int qc_eval_hess_dev(qc_handle* h, const double* dZ, const double* dm
     }
     if (h->kernel == QC_KERNEL_MFMA && qc_mfma_exp_hess_supported(h->prm))
         e = qc_launch_mfma_exp_hess(h->prm, dZ, dmu, dhvals, (hipStream_t)stream);
+    else if (h->kernel == QC_KERNEL_MFMA && qc_mfma32_exp_hess_supported(h->prm))
+        e = qc_launch_mfma32_exp_hess(h->prm, dZ, dmu, dhvals, (hipStream_t)stream);
     else if (h->kernel == QC_KERNEL_MFMA && qc_mfma_hess_supported(h->prm))
         e = qc_launch_mfma_hess(h->prm, dZ, dmu, dhvals, (hipStream_t)stream);
     else

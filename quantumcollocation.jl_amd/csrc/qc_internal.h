@@ -199,6 +199,8 @@ bool qc_mfma_exp_supported(const QcParams& P);
 hipError_t qc_launch_mfma_exp(const QcParams& P, const double* dZ, double* dF, double* dJ, hipStream_t st);
 bool qc_mfma_exp_hess_supported(const QcParams& P);   // mu_d2F of the exponential integrator, 2N <= 16: qc_mfma_exp_hess.hip
 hipError_t qc_launch_mfma_exp_hess(const QcParams& P, const double* dZ, const double* dMu, double* dH, hipStream_t st);
+bool qc_mfma32_exp_hess_supported(const QcParams& P);  // ... 16 < 2N <= 32: qc_mfma32_exp_hess.hip
+hipError_t qc_launch_mfma32_exp_hess(const QcParams& P, const double* dZ, const double* dMu, double* dH, hipStream_t st);
 bool qc_mfma32_exp_supported(const QcParams& P);
 hipError_t qc_launch_mfma32_exp(const QcParams& P, const double* dZ, double* dF, double* dJ, hipStream_t st);
 bool qc_mfma32_hess_supported(const QcParams& P);

@@ -629,8 +629,9 @@ def test_exponential_integrator_hessian_layouts_large_steps_non_hermitian(qc, or
 
 
 def test_exponential_integrator_hessian_16_levels_and_beyond(qc, oracle, coracle):
-    """N = 16 (2N = 32) and N = 20 (scratch beyond the MFMA tiles) against the C oracle's forward-mode chains."""
-    for N, m, T in ((16, 3, 3), (20, 2, 2)):
+    """N = 9 .. 16 (2 x 2 tiles: qc_mfma32_exp_hess.hip; 1 .. 8 drives: every wave role) and N = 20 (the generic kernel alone) against
+    the C oracle's forward-mode chains; both kernels where both serve."""
+    for N, m, T in ((16, 3, 3), (16, 8, 3), (16, 1, 2), (12, 7, 3), (9, 4, 2), (20, 2, 2)):
         prob, Z = random_problem(oracle, N=N, m=m, T=T, integrator=oracle.EXPONENTIAL, seed=24 + N)
         mu = np.random.default_rng(8).standard_normal(prob.n_rows)
         ref = coracle.COracle(prob).mu_d2F(Z, mu)
@@ -1715,7 +1716,7 @@ def test_kernel_names_of_the_baseline_configurations(qc):
     assert dyn.kernel_names == ("lds-gws", "lds-gws-hess")
     inp4 = qc.unitary_smooth_pulse_inputs(qc.multi_qubit_system(4), np.eye(16, dtype=complex), 4, integrator="exponential")
     d4 = qc.QuantumDynamics(inp4.integrators, inp4.traj)
-    assert d4.kernel_names == ("mfma32-exp", "lds-exp-hess") and d4.fused_kernel_name == "two-launches"
+    assert d4.kernel_names == ("mfma32-exp", "mfma32-exp-hess") and d4.fused_kernel_name == "two-launches"
     d4.close()
     dyn.close()
 
