@@ -154,16 +154,12 @@ open(io -> write(io, json(rec)), joinpath(out_dir, "ref_fixture.json"), "w")
 
 # ---- exponential integrator: Core's Hessian for it (the templates solve :exponential problems with eval_hessian on,
 #      unitary_smooth_pulse_problem.jl:224-266) and the structure it declares -------------------------------------------------
-dynE = QuantumDynamics([UnitaryExponentialIntegrator(:Ũ⃗, :a, sys1, traj), DerivativeIntegrator(:a, :da, traj),
-                        DerivativeIntegrator(:da, :dda, traj)], traj)
-recE = Dict{String,Any}("Z" => traj.datavec, "F" => dynE.F(traj.datavec), "dF" => dynE.∂F(traj.datavec),
-                        "dF_rows" => first.(dynE.∂F_structure), "dF_cols" => last.(dynE.∂F_structure))
+recE, dynE = reference_record(sys1, traj; name="fixture_exponential",
+                              integrators=[UnitaryExponentialIntegrator(:Ũ⃗, :a, sys1, traj), DerivativeIntegrator(:a, :da, traj),
+                                           DerivativeIntegrator(:da, :dda, traj)])
+recE["integrator"] = "exponential"          # tests/test_reference_golden.py builds the mirror's UnitaryExponentialIntegrator from this
 push!(verdicts, "Hessian of the exponential integrator is present" => (dynE.μ∂²F !== nothing))
 if dynE.μ∂²F !== nothing
-    μE = collect(range(0.5, 1.5; length=length(recE["F"])))
-    recE["mu"] = μE
-    recE["mu_d2F"] = dynE.μ∂²F(traj.datavec, μE)
-    recE["mu_d2F_rows"] = first.(dynE.μ∂²F_structure); recE["mu_d2F_cols"] = last.(dynE.μ∂²F_structure)
     zd = traj.dim
     touches_next = any(((r - 1) ÷ zd) != ((c - 1) ÷ zd) for (r, c) in dynE.μ∂²F_structure)
     push!(verdicts, "exponential Hessian structure has entries at knot t+1 (this library: none; they would be explicit zeros)" => touches_next)

@@ -16,13 +16,14 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, "tests", "golden")
-FILES = sorted(f for f in glob.glob(os.path.join(GOLD, "ref_*.json")) if not f.endswith("_exponential.json"))
+FILES = sorted(glob.glob(os.path.join(GOLD, "ref_*.json")))
 RTOL = 1e-10
 needs_files = pytest.mark.skipif(not FILES, reason="no tests/golden/ref_*.json: run julia/reconcile.jl where Julia and QuantumCollocationCore 0.3 exist")
 # which device kernels a reconcile.jl record must have been served by (F + dF, mu_d2F, the one-call form): the point of the small
 # Toffoli / QFT / order-6 records is to pin the MFMA kernels of the metric workloads, not the generic path
 EXPECTED_KERNELS = {
     "ref_fixture.json": ("mfma16-pade4", "mfma16-pade4-hess", "two-launches"),
+    "ref_fixture_exponential.json": ("mfma16-exp", "mfma16-exp-hess", "two-launches"),
     "ref_config1.json": ("mfma16-pade4", "mfma16-pade4-hess", "two-launches"),
     "ref_config2.json": ("mfma16-pade4", "mfma16-pade4-hess", "two-launches"),
     "ref_toffoli3.json": ("mfma16-pade4", "mfma16-pade4-hess-gather", "mfma16-pade4-fused"),
@@ -52,7 +53,7 @@ def assert_coo_equal(ours, ref, what, scale):
     assert not missing, f"{what}: {len(missing)} non-zero reference positions are not in this library's structure, e.g. {missing[:3]}"
 
 
-def assert_structure_equal(rows, cols, ref_rows, ref_cols, what):
+def assert_structure_equal(rows, cols, ref_rows, ref_cols, what, ref_vals=None, zdim=None):
     """north_star: "bit-exact on sparsity structure".  The two structure vectors must have the same LENGTH and, sorted, be EQUAL
     entry for entry (the order of the entries inside an interval is Core's own business: the values are compared position by position
     above); `length(dynamics.mu_d2F_structure)` is observable at the boundary (reference test/scripts/integrator_test_1qubit.jl:48-52).
@@ -60,6 +61,14 @@ def assert_structure_equal(rows, cols, ref_rows, ref_cols, what):
     zeros of B / F for sparse generators -- so that the value comparison can still be read while that is being settled."""
     ours = sorted(zip(np.asarray(rows).tolist(), np.asarray(cols).tolist()))
     ref = sorted((int(r) - 1, int(c) - 1) for r, c in zip(ref_rows, ref_cols))
+    if zdim is not None:
+        # the exponential integrator's residual is LINEAR in the state at knot t+1, so this library lists nothing there (DESIGN 4);
+        # should Core list those positions (one structure for both integrators), they must all hold exact zeros, and are then left
+        # out of the entry-for-entry comparison -- reconcile.jl prints which of the two it is
+        nxt = {(int(r) - 1, int(c) - 1) for r, c, v in zip(ref_rows, ref_cols, ref_vals) if (int(r) - 1) // zdim != (int(c) - 1) // zdim}
+        bad = [(int(r) - 1, int(c) - 1) for r, c, v in zip(ref_rows, ref_cols, ref_vals) if (int(r) - 1, int(c) - 1) in nxt and v != 0.0]
+        assert not bad, f"{what}: the reference holds non-zero values across knots, e.g. {bad[:3]}"
+        ref = [k for k in ref if k not in nxt]
     if os.environ.get("QC_STRUCTURE_NESTED_OK"):
         so, sr = set(ours), set(ref)
         assert sr <= so or so <= sr, f"{what}: structures are not even nested"
@@ -68,6 +77,13 @@ def assert_structure_equal(rows, cols, ref_rows, ref_cols, what):
     assert len(ours) == len(ref), (f"{what}: this library lists {len(ours)} structure entries, the reference {len(ref)}; "
                                    f"{len(diff)} positions are in one and not the other, e.g. {diff[:4]}")
     assert ours == ref, f"{what}: same length, different positions ({len(diff)} differ), e.g. {diff[:4]}"
+
+
+def cross_knot_zeros_kw(rec):
+    """Keyword arguments of assert_structure_equal for a record of the exponential integrator (see there); {} for Pade records."""
+    if rec.get("integrator", "pade") != "exponential":
+        return {}
+    return {"ref_vals": rec["mu_d2F"], "zdim": int(rec["dim"])}
 
 
 def problem_from_record(qc, rec):
@@ -105,9 +121,11 @@ def problem_from_record(qc, rec):
             else:
                 raise ValueError(f"unknown integrator kind {d['kind']!r} in the record")
         return integ, traj, Z
-    integ = [qc.UnitaryPadeIntegrator("Ũ⃗", "a", system, traj, order=int(rec["pade_order"])), qc.DerivativeIntegrator("a", "da", traj),
-             qc.DerivativeIntegrator("da", "dda", traj)]
-    return integ, traj, Z
+    if rec.get("integrator", "pade") == "exponential":      # unitary_smooth_pulse_problem.jl:168-170 (integrator = :exponential)
+        unitary = qc.UnitaryExponentialIntegrator("Ũ⃗", "a", system, traj)
+    else:
+        unitary = qc.UnitaryPadeIntegrator("Ũ⃗", "a", system, traj, order=int(rec["pade_order"]))
+    return [unitary, qc.DerivativeIntegrator("a", "da", traj), qc.DerivativeIntegrator("da", "dda", traj)], traj, Z
 
 
 def oracle_of_record(qc, oracle, integ, traj):
@@ -145,7 +163,7 @@ def test_oracle_against_reference_outputs(qc, oracle, path):
         Hr = np.asarray(rec["mu_d2F"], dtype=float)
         assert_coo_equal(coo_sum(hr, hc, ref.mu_d2F(Z, mu), False), coo_sum(rec["mu_d2F_rows"], rec["mu_d2F_cols"], Hr, True), "mu_d2F",
                          np.abs(Hr).max())
-        assert_structure_equal(hr, hc, rec["mu_d2F_rows"], rec["mu_d2F_cols"], "mu_d2F_structure (oracle)")
+        assert_structure_equal(hr, hc, rec["mu_d2F_rows"], rec["mu_d2F_cols"], "mu_d2F_structure (oracle)", **cross_knot_zeros_kw(rec))
 
 
 def check_hip_path_against_record(qc, path):
@@ -167,7 +185,7 @@ def check_hip_path_against_record(qc, path):
         Hr = np.asarray(rec["mu_d2F"], dtype=float)
         assert_coo_equal(coo_sum(hr, hc, dyn.mu_d2F(Z, mu), False), coo_sum(rec["mu_d2F_rows"], rec["mu_d2F_cols"], Hr, True), "mu_d2F", np.abs(Hr).max())
         # bit-exact sparsity structure, as north_star words it: same length, and equal entry for entry once sorted
-        assert_structure_equal(hr, hc, rec["mu_d2F_rows"], rec["mu_d2F_cols"], "mu_d2F_structure")
+        assert_structure_equal(hr, hc, rec["mu_d2F_rows"], rec["mu_d2F_cols"], "mu_d2F_structure", **cross_knot_zeros_kw(rec))
         if isinstance(dyn, qc.ComposedQuantumDynamics):       # (lists have no one-call form)
             dyn.close()
             return
@@ -191,13 +209,13 @@ def test_hip_path_against_reference_outputs(qc, path):
     check_hip_path_against_record(qc, path)
 
 
-def write_mock_record(qc, oracle, path, n_qubits, gate, T, order, shuffle_seed):
+def write_mock_record(qc, oracle, path, n_qubits, gate, T, order, shuffle_seed, integrator="pade", cross_knot_zeros=False):
     """A record in reconcile.jl's schema whose numbers come from THIS repository's CPU oracle ("MOCK: build oracle, not reference
     output"), with the COO entries of every interval in a shuffled order -- Core's order need not be this library's.  Only to prove
     that the machinery above (schema, 1-based structures, COO-set comparison, kernel expectations) works before anybody has Julia."""
     from oracle_bridge import problem_from_inputs
     system = qc.multi_qubit_system(n_qubits)
-    inp = qc.unitary_smooth_pulse_inputs(system, gate, T, pade_order=order)
+    inp = qc.unitary_smooth_pulse_inputs(system, gate, T, pade_order=order, integrator=integrator)
     traj, Z = inp.traj, inp.traj.datavec
     prob = problem_from_inputs(inp)
     prob.hess_align = 1
@@ -206,11 +224,15 @@ def write_mock_record(qc, oracle, path, n_qubits, gate, T, order, shuffle_seed):
     jr, jc = oracle.jac_structure(prob)
     hr, hc = oracle.hess_structure(prob)
     J, H = oracle.dF(prob, Z), oracle.mu_d2F(prob, Z, mu)
+    if cross_knot_zeros:       # what Core might do for the exponential integrator: list the (knot t, knot t+1) state positions, holding zeros
+        n2 = traj.components["Ũ⃗"].stop - traj.components["Ũ⃗"].start
+        er = np.concatenate([t * traj.dim + np.arange(n2) for t in range(traj.T - 1)])
+        hr, hc, H = np.concatenate([hr, er]), np.concatenate([hc, er + traj.dim]), np.concatenate([H, np.zeros(er.size)])
     pj, ph = rng.permutation(J.size), rng.permutation(H.size)
     col = lambda M: np.asarray(M).reshape(-1, order="F")
     rec = {"MOCK": "numbers of this repository's CPU oracle, NOT reference output", "T": traj.T, "dim": traj.dim, "global_dim": 0,
            "names": list(traj.names), "components": {n: [int(i) + 1 for i in range(r.start, r.stop)] for n, r in traj.components.items()},
-           "timestep": traj.timestep, "pade_order": order, "levels": system.levels,
+           "timestep": traj.timestep, "pade_order": order, "levels": system.levels, "integrator": integrator,
            "H_drift_re": col(system.H_drift.real).tolist(), "H_drift_im": col(system.H_drift.imag).tolist(),
            "H_drives_re": [col(Hk.real).tolist() for Hk in system.H_drives], "H_drives_im": [col(Hk.imag).tolist() for Hk in system.H_drives],
            "Z": Z.tolist(), "mu": mu.tolist(), "F": oracle.F(prob, Z).tolist(), "rows_declared": int(prob.n_rows),
@@ -228,6 +250,37 @@ def test_reference_record_machinery_with_mock_records(qc, oracle, tmp_path, name
     path = str(tmp_path / name)
     write_mock_record(qc, oracle, path, n_qubits, qc.GATES[gate], T, order, shuffle_seed=len(name))
     check_hip_path_against_record(qc, path)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cross_knot_zeros", [False, True])
+def test_exponential_record_machinery_with_a_mock_record(qc, oracle, tmp_path, cross_knot_zeros):
+    """ref_fixture_exponential.json (reconcile.jl writes it in the same schema, "integrator": "exponential"): F, dF and mu_d2F of the
+    exponential integrator against the record, whether or not the record lists the (knot t, knot t+1) positions as explicit zeros."""
+    path = str(tmp_path / "ref_fixture_exponential.json")
+    write_mock_record(qc, oracle, path, 1, qc.GATES["H"], 10, 4, shuffle_seed=3, integrator="exponential", cross_knot_zeros=cross_knot_zeros)
+    check_hip_path_against_record(qc, path)
+
+
+@pytest.mark.parametrize("cross_knot_zeros", [False, True])
+def test_exponential_record_schema_against_the_oracle(qc, oracle, tmp_path, cross_knot_zeros):
+    """The same on the CPU: the record's schema and the structure comparison for the exponential integrator (the numbers are the
+    oracle's own, so only the plumbing is under test); a NON-zero value across knots in a record must fail."""
+    path = str(tmp_path / "ref_fixture_exponential.json")
+    write_mock_record(qc, oracle, path, 1, qc.GATES["H"], 6, 4, shuffle_seed=4, integrator="exponential", cross_knot_zeros=cross_knot_zeros)
+    rec = json.load(open(path))
+    integ, traj, Z = problem_from_record(qc, rec)
+    assert type(integ[0]).__name__ == "UnitaryExponentialIntegrator"
+    ref = oracle_of_record(qc, oracle, integ, traj)
+    hr, hc = ref.hess_structure()
+    assert_coo_equal(coo_sum(hr, hc, ref.mu_d2F(Z, np.asarray(rec["mu"])), False), coo_sum(rec["mu_d2F_rows"], rec["mu_d2F_cols"], rec["mu_d2F"], True),
+                     "mu_d2F", np.abs(rec["mu_d2F"]).max())
+    assert_structure_equal(hr, hc, rec["mu_d2F_rows"], rec["mu_d2F_cols"], "mu_d2F_structure", **cross_knot_zeros_kw(rec))
+    if cross_knot_zeros:
+        k = next(i for i, (r, c) in enumerate(zip(rec["mu_d2F_rows"], rec["mu_d2F_cols"])) if (r - 1) // rec["dim"] != (c - 1) // rec["dim"])
+        rec["mu_d2F"][k] = 1e-3
+        with pytest.raises(AssertionError, match="across knots"):
+            assert_structure_equal(hr, hc, rec["mu_d2F_rows"], rec["mu_d2F_cols"], "mu_d2F_structure", **cross_knot_zeros_kw(rec))
 
 
 def write_mock_list_record(qc, oracle, path, kind, shuffle_seed):
