@@ -95,14 +95,16 @@ def test_multi_create_fails_loudly_without_a_device(qc):
 #  GPU
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.gpu
-@pytest.mark.parametrize("cfg,T,shards,full_from", [(3, 100, 3, None), (3, 5, 8, None), (1, 50, 2, None), (5, 21, 3, None), (2, 37, 4, None), (3, 150, 4, "1")])
-def test_multi_handle_equals_single_handle(qc, oracle, cfg, T, shards, full_from, monkeypatch):
+@pytest.mark.parametrize("cfg,T,shards,full_from,integrator", [(3, 100, 3, None, "pade"), (3, 5, 8, None, "pade"), (1, 50, 2, None, "pade"),
+                                                               (5, 21, 3, None, "pade"), (2, 37, 4, None, "pade"), (3, 150, 4, "1", "pade"),
+                                                               (3, 40, 3, None, "exponential"), (5, 9, 2, None, "exponential")])
+def test_multi_handle_equals_single_handle(qc, oracle, cfg, T, shards, full_from, integrator, monkeypatch):
     """device_ids = [0] * shards: F, dF, mu_d2F, structures and dims bit-identical to the single-device handle (T = 5 with
     8 shards leaves empty trailing shards).  full_from: QC_HOST_MULTI_FULL -- the shards copy the Jacobian values in full (what a
     handle over four or more distinct devices does by default: N links beat one host's replication) instead of in the compact form."""
     if full_from is not None:
         monkeypatch.setenv("QC_HOST_MULTI_FULL", full_from)
-    inp = qc.config_inputs(cfg, T=T)
+    inp = qc.config_inputs(cfg, T=T, integrator=integrator)     # (exponential: its mu_d2F too, round 6)
     Z = inp.traj.datavec
     one = qc.QuantumDynamics(inp.integrators, inp.traj)
     many = qc.QuantumDynamics(inp.integrators, inp.traj, devices=[0] * shards)
@@ -131,6 +133,9 @@ def test_multi_handle_equals_single_handle(qc, oracle, cfg, T, shards, full_from
     # and against the oracle
     prob = problem_from_inputs(inp)
     np.testing.assert_allclose(F2, oracle.F(prob, Z), rtol=1e-10, atol=1e-12)
+    if integrator == "exponential" and T <= 12:
+        H = oracle.mu_d2F(prob, Z, mu)
+        np.testing.assert_allclose(many.mu_d2F(Z, mu), H, rtol=1e-10, atol=1e-11 * max(1.0, np.abs(H).max()))
     one.close()
     many.close()
 

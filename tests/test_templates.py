@@ -150,14 +150,14 @@ def test_bang_bang_problem_parity(qc, oracle, nq, order, free_time, integrator):
     r, c = oracle.jac_structure(prob)
     np.testing.assert_array_equal(jr, r)
     np.testing.assert_array_equal(jc, c)
-    if integrator == "pade":            # no analytic Hessian of the exponential integrator upstream
-        rng = np.random.default_rng(2)
-        for mu in (np.ones(prob.n_rows), rng.standard_normal(prob.n_rows)):
-            close(dyn.mu_d2F(Z, mu, fresh=True), oracle.mu_d2F(prob, Z, mu), "bang-bang hessian", atol=1e-11)
-        hr, hc = dyn.mu_d2F_structure
-        orr, oc = oracle.hess_structure(prob)
-        np.testing.assert_array_equal(hr, orr)
-        np.testing.assert_array_equal(hc, oc)
+    # (the exponential integrator too, round 6: the templates solve it with the Hessian on, unitary_bang_bang_problem.jl:164-174)
+    rng = np.random.default_rng(2)
+    for mu in (np.ones(prob.n_rows), rng.standard_normal(prob.n_rows)):
+        close(dyn.mu_d2F(Z, mu, fresh=True), oracle.mu_d2F(prob, Z, mu), "bang-bang hessian", atol=1e-11)
+    hr, hc = dyn.mu_d2F_structure
+    orr, oc = oracle.hess_structure(prob)
+    np.testing.assert_array_equal(hr, orr)
+    np.testing.assert_array_equal(hc, oc)
     dyn.close()
 
 
@@ -167,7 +167,7 @@ def test_bang_bang_problem_parity(qc, oracle, nq, order, free_time, integrator):
 def test_direct_sum_problem_parity(qc, oracle, free_time, orders, exp_second):
     p1, p2 = direct_sum_members(qc, free_time, T=11, orders=orders, exp_second=exp_second)
     ds = qc.unitary_direct_sum_inputs([p1, p2])
-    dyn = qc.QuantumDynamics(ds.integrators, ds.traj, eval_hessian=not exp_second)
+    dyn = qc.QuantumDynamics(ds.integrators, ds.traj)
     assert isinstance(dyn, qc.ComposedQuantumDynamics) and len(dyn._parts) == 2
     ref = composed_oracle(ds)
     Z = ds.traj.datavec
@@ -183,18 +183,17 @@ def test_direct_sum_problem_parity(qc, oracle, free_time, orders, exp_second):
     T = ds.traj.T
     own = []
     for p in (p1, p2):
-        d1 = qc.QuantumDynamics(p.integrators, p.traj, eval_hessian=not exp_second)
+        d1 = qc.QuantumDynamics(p.integrators, p.traj)
         own.append(d1.F(p.traj.datavec, fresh=True).reshape(T - 1, -1))
         d1.close()
     np.testing.assert_array_equal(F, np.concatenate(own, axis=1).reshape(-1))
-    if not exp_second:
-        rng = np.random.default_rng(4)
-        mu = rng.standard_normal(dyn.dims.n_rows)
-        close(dyn.mu_d2F(Z, mu, fresh=True), ref.mu_d2F(Z, mu), "direct sum hessian", atol=1e-11)
-        hr, hc = dyn.mu_d2F_structure
-        orr, oc = ref.hess_structure()
-        np.testing.assert_array_equal(hr, orr)
-        np.testing.assert_array_equal(hc, oc)
+    rng = np.random.default_rng(4)            # (a Pade and an exponential member: both have their Hessian, round 6)
+    mu = rng.standard_normal(dyn.dims.n_rows)
+    close(dyn.mu_d2F(Z, mu, fresh=True), ref.mu_d2F(Z, mu), "direct sum hessian", atol=1e-11)
+    hr, hc = dyn.mu_d2F_structure
+    orr, oc = ref.hess_structure()
+    np.testing.assert_array_equal(hr, orr)
+    np.testing.assert_array_equal(hc, oc)
     dyn.close()
 
 
