@@ -24,14 +24,16 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as g
 
 
-def solve(max_iter: int = 80, T: int = 50, verbose: bool = True, tol: float = 1e-6, drift_scales=None):
+def solve(max_iter: int = 80, T: int = 50, verbose: bool = True, tol: float = 1e-6, drift_scales=None, integrator: str = "pade"):
     """drift_scales = None: BASELINE config 1.  drift_scales = (0.7, 1.3, ...): a `UnitarySamplingProblem` over copies of the config-1
     system whose drifts are scaled so (reference unitary_sampling_problem.jl:44-167: one pulse that makes the gate on EVERY system) --
     an integrator list with several state integrators, evaluated through qc_eval_*_list, one infidelity objective per system."""
     qc = g.load_package()
     U_goal = qc.GATES["H"]
     if drift_scales is None:
-        inp = qc.config_inputs(1, T=T)
+        # integrator = "exponential": `PiccoloOptions(integrator=:exponential)`, which the reference solves with the Hessian left on
+        # (unitary_smooth_pulse_problem.jl:224-240): mu_d2F of the exponential integrator in a converging solve
+        inp = qc.config_inputs(1, T=T, integrator=integrator)
         state_names = ["Ũ⃗"]
     else:
         base = qc.multi_qubit_system(1)

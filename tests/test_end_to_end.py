@@ -35,6 +35,18 @@ def test_interior_point_solve_with_exact_hessians(qc):
 
 
 @pytest.mark.gpu
+def test_interior_point_solve_with_the_exponential_integrator(qc):
+    """`PiccoloOptions(integrator=:exponential)` with the Hessian on, as the reference's own test solves it
+    (unitary_smooth_pulse_problem.jl:224-240): F, dF and mu_d2F of the exponential integrator drive the same solve to the gate."""
+    sys.path.insert(0, os.path.join(ROOT, "examples"))
+    import ipm_solve
+    before, after, viol, stats = ipm_solve.solve(max_iter=60, T=30, verbose=False, integrator="exponential")
+    assert after > before and after > 0.99, (before, after)
+    assert viol < 1e-2
+    assert stats["F_dF"] + stats["dF"] == stats["mu_d2F"] and 10 <= stats["mu_d2F"] <= 60
+
+
+@pytest.mark.gpu
 def test_interior_point_solve_of_a_sampling_problem(qc):
     """A two-system `UnitarySamplingProblem` (reference unitary_sampling_problem.jl:44-167; its own test: "Sample robustness test", :204)
     through the same solve: the integrator list [U_1, U_2, D, D] evaluated by qc_eval_*_list, one infidelity objective per system,
