@@ -246,7 +246,8 @@ int qc_dims(const qc_handle* h, qc_dims_t* out);
  * "mfma64-pade4", "mfma16-exp", "mfma32-exp", "lds", "lds-gws");
  * which = 1: mu_d2F ("mfma16-pade4-hess-gather" (drive generators with one entry per row) / "mfma16-pade4-hess2" /
  * "mfma16-pade4-hess", "mfma16-padeP-hess", "mfma32-pade4-hess-ell" / "mfma32-pade4-hess", "mfma64-pade4-hess", "lds-hess",
- * "lds-gws-hess"; exponential integrator: "mfma16-exp-hess", "mfma32-exp-hess", "lds-exp-hess", "lds-gws-exp-hess");
+ * "lds-gws-hess"; exponential integrator: "mfma16-exp-hess", "mfma16-exp-hess-gather"
+ * (drive generators with one entry per row: Pauli strings), "mfma32-exp-hess", "lds-exp-hess", "lds-gws-exp-hess");
  * which = 2: qc_eval_F_jac_hess_dev ("mfma16-pade4-fused-gather" / "mfma16-pade4-fused", "mfma32-pade4-fused-ell", or
  * "two-launches"). */
 const char* qc_kernel_name(const qc_handle* h, int32_t which);

@@ -470,6 +470,10 @@ extern "C" int qc_create(const qc_desc* d, qc_handle** out) {
             QC_HIP_C(hipMalloc(&h->dEll16, blob16.size()));
             QC_HIP_C(hipMemcpy(h->dEll16, blob16.data(), blob16.size(), hipMemcpyHostToDevice));
             h->prm.ell16 = h->dEll16;
+        } else if (!no_ell && qc_mfma16_exp_ell_build(h->prm, G.data(), &blob16)) {      // the exponential integrator's mu_d2F at 2N <= 16
+            QC_HIP_C(hipMalloc(&h->dEll16, blob16.size()));
+            QC_HIP_C(hipMemcpy(h->dEll16, blob16.data(), blob16.size(), hipMemcpyHostToDevice));
+            h->prm.ell16 = h->dEll16;
         }
     }
     // LDS budget of the LDS kernels
@@ -575,7 +579,7 @@ extern "C" const char* qc_kernel_name(const qc_handle* h, int32_t which) {
     }
     if (P.integrator != QC_PADE) {      // exponential integrator: mu_d2F alone; F + dF + mu_d2F as two launches
         if (which == 2) return "two-launches";
-        if (mfma && qc_mfma_exp_hess_supported(P)) return "mfma16-exp-hess";
+        if (mfma && qc_mfma_exp_hess_supported(P)) return P.ell16 != nullptr ? "mfma16-exp-hess-gather" : "mfma16-exp-hess";
         if (mfma && qc_mfma32_exp_hess_supported(P)) return "mfma32-exp-hess";
         return P.use_ws ? "lds-gws-exp-hess" : "lds-exp-hess";
     }

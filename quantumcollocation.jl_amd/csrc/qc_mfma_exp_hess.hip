@@ -25,6 +25,10 @@
 // so the factors h / 2^sq (per G_j) and 1 / 2^sq (V) are applied once to the outputs.  Blocks leave transposed (lane <-> row,
 // whole lines per store): (M^T L_j), (M^T G E) with the B-layout tile of M as the A operand.
 // MFMAs per interval (m = 6, one wave, 4 squarings): 10 x 132 + 4 x 156 + 56 = 2000.
+#include <stdlib.h>
+
+#include <vector>
+
 #include "qc_mfma_common.h"
 
 namespace {
@@ -53,6 +57,20 @@ __device__ inline double xsum64(double c) {
     c += xdpp<0x122>(c);
     c += xdpp<0x121>(c);
     return (xreadlane(c, 0) + xreadlane(c, 16)) + (xreadlane(c, 32) + xreadlane(c, 48));
+}
+// N such sums at once, stage by stage (no instruction waits for its predecessor); per value the additions of xsum64: the same bits
+template <int N>
+__device__ __forceinline__ void xsum64_multi(double (&x)[N]) {
+#pragma unroll
+    for (int q = 0; q < N; ++q) x[q] += xdpp<0x128>(x[q]);
+#pragma unroll
+    for (int q = 0; q < N; ++q) x[q] += xdpp<0x124>(x[q]);
+#pragma unroll
+    for (int q = 0; q < N; ++q) x[q] += xdpp<0x122>(x[q]);
+#pragma unroll
+    for (int q = 0; q < N; ++q) x[q] += xdpp<0x121>(x[q]);
+#pragma unroll
+    for (int q = 0; q < N; ++q) x[q] = (xreadlane(x[q], 0) + xreadlane(x[q], 16)) + (xreadlane(x[q], 32) + xreadlane(x[q], 48));
 }
 __device__ inline double dot4(const v4d& a, const v4d& b) { return (a[0] * b[0] + a[1] * b[1]) + (a[2] * b[2] + a[3] * b[3]); }
 
@@ -99,13 +117,22 @@ __device__ __forceinline__ v4d scr_get_T(const double* __restrict__ scr, int q, 
     for (int r = 0; r < 4; ++r) y[r] = scr[q * 272 + j * 17 + 4 * r + g];
     return y;
 }
+// the tile's values in vector registers HERE (an MFMA result otherwise stays in its accumulation registers until the compiler
+// finds it convenient to copy it, and the next phase's accumulators take new ones)
+__device__ __forceinline__ void pin_v(v4d& x) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(x[r]));
+}
 __device__ __forceinline__ void lds_order() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int kMU, int kW>
+// ELL: every drive generator has at most ONE entry per row (Pauli strings; P.ell16 = qc_mfma16_exp_ell_build's tables): the two products
+// with a drive image in every Horner step, G_j R and G_j QV, are row gathers from row-major LDS copies of R and QV -- 3 + 3 kMU products
+// a step instead of 3 + 5 kMU.  fma(w, x, acc) per element: what the dense product adds besides exact zeros.
+template <int kMU, int kW, bool ELL>
 __global__ __launch_bounds__(64 * kW) void qc_mfma16_exp_hess_kernel(const QcParams P, const double* __restrict__ Z, const double* __restrict__ Mu,
                                                                      double* __restrict__ H) {
     qc_kernarg_touch<sizeof(QcParams) + 64>();
@@ -151,6 +178,8 @@ __global__ __launch_bounds__(64 * kW) void qc_mfma16_exp_hess_kernel(const QcPar
         }
     }
     v4d Gj[kMU];
+    double tw[kMU][4];                                        // ELL: weight and LDS offset (column x 17 + j) of rows 4 r + g of the wave's drives
+    int tc[kMU][4];
     v4d Ga = ximg(Gx, 0, lane);
     {   // G = G_0 + sum over ALL drives (every wave assembles it); unconditional clamped loads, one batch
         v4d img[kXHMmax];
@@ -161,16 +190,31 @@ __global__ __launch_bounds__(64 * kW) void qc_mfma16_exp_hess_kernel(const QcPar
             img[u] = ximg(Gx, m > 0 ? k + 1 : 0, lane);
             ak[u] = (u < m) ? z0[P.off_a + k] : 0.0;
         }
+        if constexpr (ELL) {   // rows 4 r + g of the wave's drives (unused drive slots: weight 0, column 0 -- their chains stay zero)
+            const double* __restrict__ bw = reinterpret_cast<const double*>(P.ell16);
+            const int* __restrict__ bc = reinterpret_cast<const int*>(reinterpret_cast<const char*>(P.ell16) + kXHMmax * 16 * 8);
 #pragma unroll
-        for (int u = 0; u < kMU; ++u) {
-            const int k = d0 + u;
-            Gj[u] = ximg(Gx, k < m ? k + 1 : 0, lane);
+            for (int u = 0; u < kMU; ++u) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    tw[u][r] = bw[(d0 + u) * 16 + 4 * r + g];
+                    tc[u][r] = bc[(d0 + u) * 16 + 4 * r + g] + j;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < kMU; ++u) {
+                const int k = d0 + u;
+                Gj[u] = ximg(Gx, k < m ? k + 1 : 0, lane);
+            }
         }
 #pragma unroll
         for (int u = 0; u < kXHMmax; ++u) Ga += ak[u] * img[u];
     }
+    if constexpr (!ELL) {
 #pragma unroll
-    for (int u = 0; u < kMU; ++u) if (d0 + u >= m) Gj[u] = zero;       // unused drive slots: their chains stay zero
+        for (int u = 0; u < kMU; ++u) if (d0 + u >= m) Gj[u] = zero;   // unused drive slots: their chains stay zero
+    }
 
     // ---- ||h G||_1 = largest column sum -> squaring count (as qc_mfma_exp.hip) ------------------------------------------------
     int sq = 0;
@@ -218,14 +262,66 @@ __global__ __launch_bounds__(64 * kW) void qc_mfma16_exp_hess_kernel(const QcPar
 #pragma unroll 1
     for (int k = kXHDeg; k >= 1; --k) {
         ck *= (double)k;                                      // 1/(k-1)!
+        if constexpr (ELL) {
+            scr_put(scr, 0, R, g, j);                             // row-major copies of R_k+1 and QV_k+1 for the gathers
+            scr_put(scr, 1, QV, g, j);
+            lds_order();
+            // Two phases, each: the gathers REQUESTED (all of them, before the products -- left to itself the compiler, at the edge of
+            // the second wave per SIMD, reads one value at a time into one register pair: 24 LDS round trips a step), the products,
+            // then the gathered terms added.  The phases' accumulators and gathered values share registers.
+            {   // P_j <- V Q_j + Y P_j + G_j QV
+                double x[kMU][4];
+#pragma unroll
+                for (int u = 0; u < kMU; ++u) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) x[u][r] = scr[272 + tc[u][r]];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                v4d acc[kMU];
+                mma1<kMU, true>(Wd, Q, acc);
+                mma1<kMU, false>(Y, Pm, acc);
+#pragma unroll
+                for (int u = 0; u < kMU; ++u) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Pm[u][r] = __builtin_fma(tw[u][r], x[u][r], acc[u][r]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {   // Q_j <- Y Q_j + G_j R;   QV <- V R + Y QV;   R <- Y R + I/(k-1)!
+                double x[kMU][4];
+#pragma unroll
+                for (int u = 0; u < kMU; ++u) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) x[u][r] = scr[tc[u][r]];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                v4d a2[2] = {Wd, Y}, b2[2] = {R, R}, o2[2];
+                mma<2, true>(a2, b2, o2);                         // V R, Y R
+                v4d accq[kMU + 1], bq[kMU + 1];
+#pragma unroll
+                for (int u = 0; u < kMU; ++u) bq[u] = Q[u];
+                bq[kMU] = QV;
+                mma1<kMU + 1, true>(Y, bq, accq);                 // Y Q_j, Y QV
+#pragma unroll
+                for (int u = 0; u < kMU; ++u) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Q[u][r] = __builtin_fma(tw[u][r], x[u][r], accq[u][r]);
+                }
+                QV = accq[kMU] + o2[0];
+                R = o2[1] + ck * IdB;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            lds_order();                                          // the next step's copies follow this step's gathers
+        } else {
         {   // second-order chains first: they read the old Q, QV
             v4d acc[kMU];
             mma1<kMU, true>(Wd, Q, acc);                      // V Q_j
             mmb<kMU, false>(Gj, QV, acc);                     // + G_j QV
             mma1<kMU, false>(Y, Pm, acc);                     // + Y P_j
 #pragma unroll
-            for (int u = 0; u < kMU; ++u) Pm[u] = acc[u];
+            for (int u = 0; u < kMU; ++u) { Pm[u] = acc[u]; pin_v(Pm[u]); }
         }
+        __builtin_amdgcn_sched_barrier(0);
         {
             v4d acc[kMU + 2], bb[kMU + 2], aa[kMU + 2];
             // G_j R (kMU), V R, Y R, then + Y Q_j, + Y QV
@@ -244,6 +340,7 @@ __global__ __launch_bounds__(64 * kW) void qc_mfma16_exp_hess_kernel(const QcPar
             QV = acc2[kMU];
             R = acc[kMU + 1] + ck * IdB;
         }
+        }
     }
     // ---- squarings --------------------------------------------------------------------------------------------------------------
     for (int q = 0; q < sq; ++q) {
@@ -253,6 +350,8 @@ __global__ __launch_bounds__(64 * kW) void qc_mfma16_exp_hess_kernel(const QcPar
         for (int u = 0; u < kMU; ++u) { scr_put(scr, 2 + u, Q[u], g, j); scr_put(scr, 2 + kMU + u, Pm[u], g, j); }
         lds_order();
         const v4d Et = scr_get_T(scr, 0, g, j), LVt = scr_get_T(scr, 1, g, j);
+        // (three phases with scheduling fences between them: their accumulators share registers -- interleaved by the compiler they
+        //  take eight tiles of accumulation registers, and with those the kernel loses its second wave per SIMD)
         {
             v4d acc[kMU], at[kMU];
             mma1<kMU, true>(Et, Pm, acc);                     // E P_j
@@ -264,14 +363,16 @@ __global__ __launch_bounds__(64 * kW) void qc_mfma16_exp_hess_kernel(const QcPar
             for (int u = 0; u < kMU; ++u) at[u] = scr_get_T(scr, 2 + u, g, j);
             mmb<kMU, false>(at, QV, acc);                     // + L_j LV
 #pragma unroll
-            for (int u = 0; u < kMU; ++u) Pm[u] = acc[u];
+            for (int u = 0; u < kMU; ++u) { Pm[u] = acc[u]; pin_v(Pm[u]); }
+            __builtin_amdgcn_sched_barrier(0);
             // L_j <- E L_j + L_j E (at still holds L_j^T)
             v4d accl[kMU];
             mma1<kMU, true>(Et, Q, accl);
             mmb<kMU, false>(at, R, accl);
 #pragma unroll
-            for (int u = 0; u < kMU; ++u) Q[u] = accl[u];
+            for (int u = 0; u < kMU; ++u) { Q[u] = accl[u]; pin_v(Q[u]); }
         }
+        __builtin_amdgcn_sched_barrier(0);
         {
             v4d a2[2] = {Et, Et}, b2[2] = {QV, R}, acc2[2];
             mma<2, true>(a2, b2, acc2);                       // E LV, E E
@@ -280,6 +381,7 @@ __global__ __launch_bounds__(64 * kW) void qc_mfma16_exp_hess_kernel(const QcPar
             QV = acc1[0];
             R = acc2[1];
         }
+        __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_wave_barrier();
     }
     // ---- outputs ------------------------------------------------------------------------------------------------------------------
@@ -297,18 +399,34 @@ __global__ __launch_bounds__(64 * kW) void qc_mfma16_exp_hess_kernel(const QcPar
             }
         }
     }
-    // (a_i, a_j) = -h (h / 4^sq) <G_j^T, P_i> for the wave's drives i and every j >= i: the A-layout image of G_j, lane for lane
+    // The scalar blocks: every per-lane partial first, ONE batched reduction, one store instruction (lane q stores sum q).  One at a time
+    // -- an image load, a 64-lane sum and a store per pair, up to 15 in a row on the first wave -- they were a chain of round trips at
+    // the end of every wave's life, and at T = 1000 the launch IS one wave's life (profiles/r06_exp_hess.txt).
+    //   (a_i, a_j) = -h (h / 4^sq) <G_j^T, P_i> for the wave's drives i and every j >= i: the A-layout image of G_j, lane for lane
+    //   (a_j, h)   = -( <G_j^T, E V> + (h/2^sq) <G^T W, L_j> )                  (h, h) = -<G^T W, G E>
     const double faa = -(h * hs * sc);
 #pragma unroll
-    for (int u = 0; u < kMU; ++u) {
-        const int i = d0 + u;
-        if (i < m) {
-            for (int jd = i; jd < m; ++jd) {
-                const v4d gj = ximg(Gx, jd + 1, lane);
-                const double v = xsum64(dot4(gj, Pm[u]));
-                if (lane == 0) Hb[P.ho_aa + jd * (jd + 1) / 2 + i] = faa * v;
+    for (int half = 0; half < 2; ++half) {                    // (four images at a time: all eight cost the second wave per SIMD in registers)
+        constexpr int kNA = 4 * kMU;
+        double pv[kNA];
+        {
+            v4d img[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) img[q] = ximg(Gx, 4 * half + q < m ? 4 * half + q + 1 : 0, lane);
+#pragma unroll
+            for (int u = 0; u < kMU; ++u) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) pv[4 * u + q] = dot4(img[q], Pm[u]);
             }
         }
+        xsum64_multi<kNA>(pv);
+        double mine = 0.0;
+#pragma unroll
+        for (int q = 0; q < kNA; ++q) mine = lane == q ? pv[q] : mine;
+        const int u = lane >> 2, jd = 4 * half + (lane & 3), i = d0 + u;
+        if (lane < kNA && i < m && jd >= i && jd < m) Hb[P.ho_aa + jd * (jd + 1) / 2 + i] = faa * mine;
+        __builtin_amdgcn_sched_barrier(0);                    // (the second half's images are not requested next to the first's)
+        if (m <= 4) break;
     }
     if (ft) {
         // T2 = G^T W (A = the D-layout tile of G, acting as G^T), E V (A = E^T), G E
@@ -317,22 +435,29 @@ __global__ __launch_bounds__(64 * kW) void qc_mfma16_exp_hess_kernel(const QcPar
         v4d a3[3] = {Gd, Et, Ga}, b3[3] = {Wd, Vd, R}, o3[3];
         mma<3, true>(a3, b3, o3);
         const v4d T2 = o3[0], EV = o3[1], GE = o3[2];
-        // (a_j, h) = -( <G_j^T, E V> + (h/2^sq) <G^T W, L_j> )
+        if constexpr (ELL) {
 #pragma unroll
-        for (int u = 0; u < kMU; ++u) {
-            if (d0 + u < m) {
-                const double v = xsum64(dot4(Gj[u], EV) + hs * dot4(T2, Q[u]));
-                if (lane == 0) Hb[P.ho_ah + d0 + u] = -v;
-            }
+            for (int u = 0; u < kMU; ++u) Gj[u] = ximg(Gx, d0 + u < m ? d0 + u + 1 : 0, lane);
         }
+        double pv[kMU + 1];
+#pragma unroll
+        for (int u = 0; u < kMU; ++u) pv[u] = dot4(Gj[u], EV) + hs * dot4(T2, Q[u]);
+        pv[kMU] = dot4(T2, GE);
         if (wv == 0) {
-            // (U_t, h) = -(G E)^T M, transposed: M^T (G E);  (h, h) = -<G^T W, G E>
+            // (U_t, h) = -(G E)^T M, transposed: M^T (G E)
             const v4d XT = mm16(bM, GE);
 #pragma unroll
             for (int r = 0; r < 2; ++r)
                 if (4 * r + g < nc && j < nr) qc_st8m<2>(Hb + P.ho_Uh + (4 * r + g) * nr + j, -XT[r]);
-            const double v = xsum64(dot4(T2, GE));
-            if (lane == 0) Hb[P.ho_hh] = -v;
+        }
+        xsum64_multi<kMU + 1>(pv);
+        double mine = 0.0;
+#pragma unroll
+        for (int q = 0; q <= kMU; ++q) mine = lane == q ? pv[q] : mine;
+        if (lane < kMU) {
+            if (d0 + lane < m) Hb[P.ho_ah + d0 + lane] = -mine;
+        } else if (lane == kMU && wv == 0) {
+            Hb[P.ho_hh] = -mine;
         }
     }
     if (wv == kW - 1) qc_hess_tail(P, mu, Hb, lane, 64);
@@ -344,9 +469,35 @@ bool qc_mfma_exp_hess_supported(const QcParams& P) {
     return P.integrator == QC_EXPONENTIAL && P.n <= 16 && P.nc <= 8 && P.m <= kXHMmax && P.hess_nnz > 0 && P.Gx != nullptr;
 }
 
+// Rows of the drive generators of an exponential-integrator handle at 2N <= 16 whose drives have at most ONE entry per row:
+// blob = [8][16] weights (doubles), [8][16] columns x 17 (ints: offsets into the 17-double rows of the LDS copies); unused rows and
+// drive slots: weight 0, column 0.  (P.ell16 of a Pade handle is qc_mfma16_ell_build's table; the two never meet: the integrator decides.)
+bool qc_mfma16_exp_ell_build(const QcParams& P, const double* G, std::vector<char>* blob) {
+    if (P.integrator != QC_EXPONENTIAL || P.n > 16 || P.m < 1 || P.m > kXHMmax) return false;
+    const int n = P.n, m = P.m;
+    blob->assign(kXHMmax * 16 * 8 + kXHMmax * 16 * 4, 0);
+    double* tw = reinterpret_cast<double*>(blob->data());
+    int* tc = reinterpret_cast<int*>(blob->data() + kXHMmax * 16 * 8);
+    for (int k = 0; k < m; ++k)
+        for (int a = 0; a < n; ++a) {
+            int cnt = 0;
+            for (int c = 0; c < n; ++c) {
+                const double v = G[(size_t)(k + 1) * n * n + (size_t)c * n + a];      // drive k, row a, column c (column-major)
+                if (v == 0.0) continue;
+                if (++cnt > 1) return false;
+                tw[k * 16 + a] = v;
+                tc[k * 16 + a] = c * 17;
+            }
+        }
+    return true;
+}
+
 hipError_t qc_launch_mfma_exp_hess(const QcParams& P, const double* dZ, const double* dMu, double* dH, hipStream_t st) {
     const int grid = P.n_int;
-#define QC_XH(MU_, W_) hipLaunchKernelGGL((qc_mfma16_exp_hess_kernel<MU_, W_>), dim3(grid), dim3(64 * W_), 0, st, P, dZ, dMu, dH)
+    static const bool ell_off = getenv("QC_EXP_ELL") && atoi(getenv("QC_EXP_ELL")) == 0;      // A/B diagnostics
+    const bool ell = P.ell16 != nullptr && !ell_off;
+#define QC_XH(MU_, W_) do { if (ell) hipLaunchKernelGGL((qc_mfma16_exp_hess_kernel<MU_, W_, true>), dim3(grid), dim3(64 * W_), 0, st, P, dZ, dMu, dH); \
+                            else hipLaunchKernelGGL((qc_mfma16_exp_hess_kernel<MU_, W_, false>), dim3(grid), dim3(64 * W_), 0, st, P, dZ, dMu, dH); } while (0)
     // Measured at config 3 (T = 1000, m = 6; profiles/r06_exp_hess.txt): two waves of three drives 70.6 us = 0.81 of the f64 MFMA peak
     // counting the shared chains both waves run (0.74 counting them once), one wave of six drives 70.9 us (2000 MFMAs per interval,
     // 0.74 of peak, 300 registers), three waves of two 93.9 us (the shared chains three times): the launch is bound by the matrix pipes.
