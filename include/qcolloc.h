@@ -243,7 +243,7 @@ const char* qc_last_error(const qc_handle* h);
 int qc_dims(const qc_handle* h, qc_dims_t* out);
 /* Names of the device kernels this handle's evaluations run on (diagnostic; static strings, never NULL):
  * which = 0: F / F + dF ("mfma16-pade4", "mfma16-padeP", "mfma32-pade4-ell" (sparse drive generators) / "mfma32-pade4",
- * "mfma64-pade4", "mfma16-exp", "mfma32-exp", "lds", "lds-gws");
+ * "mfma64-pade4", "mfma16-exp" / "mfma16-exp-gather" (drive generators with one entry per row), "mfma32-exp", "lds", "lds-gws");
  * which = 1: mu_d2F ("mfma16-pade4-hess-gather" (drive generators with one entry per row) / "mfma16-pade4-hess2" /
  * "mfma16-pade4-hess", "mfma16-padeP-hess", "mfma32-pade4-hess-ell" / "mfma32-pade4-hess", "mfma64-pade4-hess", "lds-hess",
  * "lds-gws-hess"; exponential integrator: "mfma16-exp-hess", "mfma16-exp-hess-gather"

@@ -572,7 +572,7 @@ extern "C" const char* qc_kernel_name(const qc_handle* h, int32_t which) {
     const bool mfma = h->kernel == QC_KERNEL_MFMA;
     if (which == 0) {
         if (!mfma) return P.use_ws ? "lds-gws" : "lds";
-        if (P.integrator == QC_EXPONENTIAL) return P.n > 16 ? "mfma32-exp" : "mfma16-exp";
+        if (P.integrator == QC_EXPONENTIAL) return P.n > 16 ? "mfma32-exp" : (P.ell16 != nullptr ? "mfma16-exp-gather" : "mfma16-exp");
         if (qc_mfma16_padeP_supported(P)) return "mfma16-padeP";
         if (P.n > 16 && P.n <= 32 && P.ell) return "mfma32-pade4-ell";
         return P.n > 32 ? "mfma64-pade4" : (P.n > 16 ? "mfma32-pade4" : "mfma16-pade4");

@@ -15,6 +15,8 @@
 // once to the outputs.  Outputs leave transposed (lane <-> row, whole 128-byte lines per store): the copies of -E
 // from E^T, the drive columns as (L_j U_t)^T = U_t^T L_j^T (A = U_t tile, B = L_j^T), residual and d/dh through LDS.
 // MFMAs per interval (m = 6, 4 squarings): 8 x 52 + 4 x 52 + 8 + 24 = 656;  the LDS kernel spends 463 us on config 3.
+#include <stdlib.h>
+
 #include "qc_mfma_common.h"
 
 namespace {
@@ -73,6 +75,43 @@ __device__ __forceinline__ void horner_step(const v4d& Y, const v4d (&Gj)[M], v4
     R = accR;
 }
 
+// The same step for drive generators with at most ONE entry per row (P.ell16 = qc_mfma16_exp_ell_build's tables, qc_mfma_exp_hess.hip):
+// G_j R is a row gather from a row-major LDS copy of R -- 4 + 4 m MFMAs a step instead of 4 + 8 m.  The gathers are requested before
+// the products and added behind them: fma(w, x, acc), what the dense product adds besides exact zeros.
+template <int M>
+__device__ __forceinline__ void horner_step_ell(const v4d& Y, const double (&tw)[M][4], const int (&tc)[M][4], double* __restrict__ scr, v4d& R,
+                                                v4d (&Q)[M], const v4d& cI, int g, int j) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) scr[(4 * r + g) * 17 + j] = R[r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double x[M][4];
+#pragma unroll
+    for (int q = 0; q < M; ++q) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[q][r] = scr[tc[q][r]];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const v4d z = {0.0, 0.0, 0.0, 0.0};
+    v4d accR = cI, acc[M];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        accR = __builtin_amdgcn_mfma_f64_16x16x4f64(Y[kk], R[kk], accR, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < M; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(Y[kk], Q[q][kk], kk == 0 ? z : acc[q], 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < M; ++q) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Q[q][r] = __builtin_fma(tw[q][r], x[q][r], acc[q][r]);
+    }
+    R = accR;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the next step's copy follows this step's gathers
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // squaring: E <- Et^T E (= E E),  L_j <- Et^T L_j + Kt_j^T E (= E L_j + L_j E);  Et, Kt_j are the transposed tiles
 template <int M, bool JAC>
 __device__ __forceinline__ void square_step(const v4d& Et, const v4d (&Kt)[M], v4d& E, v4d (&L)[M]) {
@@ -102,7 +141,7 @@ __device__ __forceinline__ void square_step(const v4d& Et, const v4d (&Kt)[M], v
 // waves never exchange data: no barrier.  Two waves per interval fill the chip on short trajectories (T = 200: 18.3 -> 11.9 us);
 // at T = 1000 one wave per interval already occupies every SIMD and the kernel is bound by MFMA issue at the clock the
 // device sustains under FP64 matrix load (two waves there: 30.8 vs 30.3 us, the redundant R chain costs what the overlap gains).
-template <bool JAC, int kMU, int kW>
+template <bool JAC, int kMU, int kW, bool ELL = false>
 __global__ __launch_bounds__(64 * kW, kW) void qc_mfma16_exp_kernel(const QcParams P, const double* __restrict__ Z, double* __restrict__ F,
                                                                     double* __restrict__ J) {
     qc_kernarg_touch<sizeof(QcParams) + 64>();   // one batch of scalar-cache misses instead of one per use (qc_internal.h)
@@ -140,6 +179,8 @@ __global__ __launch_bounds__(64 * kW, kW) void qc_mfma16_exp_kernel(const QcPara
             u1[r] = row < nr ? z1[P.off_U + jc * nr + row] : 0.0;
         }
         v4d Gj[kMU];
+        double tw[kMU][4];                                        // ELL: weight and LDS offset (column x 17 + j) of rows 4 r + g of the wave's drives
+        int tc[kMU][4];
         v4d Ga = ximg(Gx, 0, lane);
         {   // G = G_0 + sum over ALL drives (every wave assembles it); unconditional clamped loads, one batch
             constexpr int kMA = kXMmax;       // every drive enters G, whatever subset this wave differentiates
@@ -151,16 +192,31 @@ __global__ __launch_bounds__(64 * kW, kW) void qc_mfma16_exp_kernel(const QcPara
                 img[u] = ximg(Gx, m > 0 ? k + 1 : 0, lane);
                 ak[u] = (u < m) ? z0[P.off_a + k] : 0.0;
             }
+            if constexpr (ELL) {   // rows 4 r + g of the wave's drives (unused drive slots: weight 0, column 0 -- their chains stay zero)
+                const double* __restrict__ bw = reinterpret_cast<const double*>(P.ell16);
+                const int* __restrict__ bc = reinterpret_cast<const int*>(reinterpret_cast<const char*>(P.ell16) + kXMmax * 16 * 8);
 #pragma unroll
-            for (int u = 0; u < kMU; ++u) {
-                const int k = d0 + u;                              // this wave's drives (their own loads: no dynamic register index)
-                Gj[u] = ximg(Gx, k < m ? k + 1 : 0, lane);
+                for (int u = 0; u < kMU; ++u) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        tw[u][r] = bw[(d0 + u) * 16 + 4 * r + g];
+                        tc[u][r] = bc[(d0 + u) * 16 + 4 * r + g] + j;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < kMU; ++u) {
+                    const int k = d0 + u;                          // this wave's drives (their own loads: no dynamic register index)
+                    Gj[u] = ximg(Gx, k < m ? k + 1 : 0, lane);
+                }
             }
 #pragma unroll
             for (int u = 0; u < kMA; ++u) Ga += ak[u] * img[u];
         }
+        if constexpr (!ELL) {
 #pragma unroll
-        for (int u = 0; u < kMU; ++u) if (d0 + u >= m) Gj[u] = zero;   // unused drive slots: their chains stay zero
+            for (int u = 0; u < kMU; ++u) if (d0 + u >= m) Gj[u] = zero;   // unused drive slots: their chains stay zero
+        }
 
         // ---- ||h G||_1 = largest column sum: lane (g, i) reg kk holds G[i][4kk+g]; rows of 16 lanes share a column ------
         int sq = 0;
@@ -204,7 +260,8 @@ __global__ __launch_bounds__(64 * kW, kW) void qc_mfma16_exp_kernel(const QcPara
 #pragma unroll 1
         for (int k = kXDeg; k >= 1; --k) {
             ck *= (double)k;                                        // 1/(k-1)!
-            horner_step<kMU, JAC>(Y, Gj, R, Q, ck * IdB);
+            if constexpr (ELL) horner_step_ell<kMU>(Y, tw, tc, scr, R, Q, ck * IdB, g, j);
+            else horner_step<kMU, JAC>(Y, Gj, R, Q, ck * IdB);
         }
         // ---- squarings ------------------------------------------------------------------------------------------------
         for (int q = 0; q < sq; ++q) {
@@ -276,21 +333,26 @@ bool qc_mfma_exp_supported(const QcParams& P) {
 
 hipError_t qc_launch_mfma_exp(const QcParams& P, const double* dZ, double* dF, double* dJ, hipStream_t st) {
     const int grid = P.n_int;
+    static const bool ell_off = getenv("QC_EXP_ELL") && atoi(getenv("QC_EXP_ELL")) == 0;      // A/B diagnostics
+    const bool ell = P.ell16 != nullptr && !ell_off;      // drive generators with one entry per row: the row-gather form of the Horner steps
+#define QC_XJ(MU_, W_) do { if (ell) hipLaunchKernelGGL((qc_mfma16_exp_kernel<true, MU_, W_, true>), dim3(grid), dim3(64 * W_), 0, st, P, dZ, dF, dJ); \
+                            else hipLaunchKernelGGL((qc_mfma16_exp_kernel<true, MU_, W_, false>), dim3(grid), dim3(64 * W_), 0, st, P, dZ, dF, dJ); } while (0)
     if (!dJ) {   // residual only: no Frechet chains, one wave
         hipLaunchKernelGGL((qc_mfma16_exp_kernel<false, 1, 1>), dim3(grid), dim3(64), 0, st, P, dZ, dF, dJ);
     } else if (P.m <= 1) {
-        hipLaunchKernelGGL((qc_mfma16_exp_kernel<true, 1, 1>), dim3(grid), dim3(64), 0, st, P, dZ, dF, dJ);
+        QC_XJ(1, 1);
     } else if (P.n_int >= 768) {   // enough intervals to put a wave on (nearly) every SIMD: one wave per interval, no redundant R chain
-        if (P.m <= 2) hipLaunchKernelGGL((qc_mfma16_exp_kernel<true, 2, 1>), dim3(grid), dim3(64), 0, st, P, dZ, dF, dJ);
-        else if (P.m <= 4) hipLaunchKernelGGL((qc_mfma16_exp_kernel<true, 4, 1>), dim3(grid), dim3(64), 0, st, P, dZ, dF, dJ);
-        else if (P.m <= 6) hipLaunchKernelGGL((qc_mfma16_exp_kernel<true, 6, 1>), dim3(grid), dim3(64), 0, st, P, dZ, dF, dJ);
-        else hipLaunchKernelGGL((qc_mfma16_exp_kernel<true, 8, 1>), dim3(grid), dim3(64), 0, st, P, dZ, dF, dJ);
+        if (P.m <= 2) QC_XJ(2, 1);
+        else if (P.m <= 4) QC_XJ(4, 1);
+        else if (P.m <= 6) QC_XJ(6, 1);
+        else QC_XJ(8, 1);
     } else {     // short trajectories: two waves per interval, ceil(m/2) drives each (config 2, T = 200: 18.3 -> 11.9 us)
         const int mh = (P.m + 1) / 2;
-        if (mh == 1) hipLaunchKernelGGL((qc_mfma16_exp_kernel<true, 1, 2>), dim3(grid), dim3(128), 0, st, P, dZ, dF, dJ);
-        else if (mh == 2) hipLaunchKernelGGL((qc_mfma16_exp_kernel<true, 2, 2>), dim3(grid), dim3(128), 0, st, P, dZ, dF, dJ);
-        else if (mh == 3) hipLaunchKernelGGL((qc_mfma16_exp_kernel<true, 3, 2>), dim3(grid), dim3(128), 0, st, P, dZ, dF, dJ);
-        else hipLaunchKernelGGL((qc_mfma16_exp_kernel<true, 4, 2>), dim3(grid), dim3(128), 0, st, P, dZ, dF, dJ);
+        if (mh == 1) QC_XJ(1, 2);
+        else if (mh == 2) QC_XJ(2, 2);
+        else if (mh == 3) QC_XJ(3, 2);
+        else QC_XJ(4, 2);
     }
+#undef QC_XJ
     return hipGetLastError();
 }

@@ -630,9 +630,9 @@ def test_exponential_integrator_hessian_layouts_large_steps_non_hermitian(qc, or
 
 @pytest.mark.parametrize("nq,T,free_time", [(1, 7, True), (2, 6, True), (3, 5, True), (3, 4, False)])
 def test_exponential_integrator_hessian_row_gather_form(qc, oracle, monkeypatch, nq, T, free_time):
-    """Pauli-string drives (one entry per generator row: BASELINE's systems) with `integrator=:exponential`: the row-gather form of
-    qc_mfma_exp_hess.hip (the products G_j R, G_j QV of every Horner step as gathers) against the numpy oracle and against the
-    dense-image form of the same kernel (QC_NO_ELL=1 at create time), steps from 0 to 5 squarings."""
+    """Pauli-string drives (one entry per generator row: BASELINE's systems) with `integrator=:exponential`: the row-gather forms of
+    qc_mfma_exp.hip and qc_mfma_exp_hess.hip (the products G_j R, G_j QV of every Horner step as gathers) against the numpy oracle and
+    against the dense-image forms of the same kernels (QC_NO_ELL=1 at create time), steps from 0 to 5 squarings."""
     gate = {1: "H", 2: "CNOT", 3: "TOFFOLI"}[nq]
     inp = qc.unitary_smooth_pulse_inputs(qc.multi_qubit_system(nq), qc.GATES[gate], T, integrator="exponential", free_time=free_time)
     prob = problem_from_inputs(inp)
@@ -641,11 +641,18 @@ def test_exponential_integrator_hessian_row_gather_form(qc, oracle, monkeypatch,
         Z[prob.off_dt::prob.zdim] = np.resize([0.2, 0.01, 1.1, 0.45, 2.0], T)
     rng = np.random.default_rng(31 + nq)
     gather = qc.QuantumDynamics(inp.integrators, inp.traj)
-    assert gather.kernel_names[1] == "mfma16-exp-hess-gather"
+    assert gather.kernel_names == ("mfma16-exp-gather", "mfma16-exp-hess-gather")
     monkeypatch.setenv("QC_NO_ELL", "1")
     dense = qc.QuantumDynamics(inp.integrators, inp.traj)
     monkeypatch.delenv("QC_NO_ELL")
-    assert dense.kernel_names[1] == "mfma16-exp-hess"
+    assert dense.kernel_names == ("mfma16-exp", "mfma16-exp-hess")
+    # F + dF: the Horner steps of qc_mfma_exp.hip in both forms
+    Fo, Jo = oracle.F(prob, Z), oracle.dF(prob, Z)
+    for dyn, what in ((gather, "row gathers"), (dense, "dense images")):
+        F, J = dyn.F_dF(Z, fresh=True)
+        np.testing.assert_allclose(F, Fo, rtol=1e-10, atol=1e-12, err_msg=what)
+        np.testing.assert_allclose(J, Jo, rtol=1e-10, atol=1e-11 * max(1.0, np.abs(Jo).max()), err_msg=what)
+        np.testing.assert_array_equal(dyn.F(Z, fresh=True), F)           # (the residual-only launch: no chains, the same E)
     for mu in (np.ones(prob.n_rows), rng.standard_normal(prob.n_rows)):
         ref = oracle.mu_d2F(prob, Z, mu)
         Hg, Hd = gather.mu_d2F(Z, mu, fresh=True), dense.mu_d2F(Z, mu, fresh=True)
@@ -654,6 +661,23 @@ def test_exponential_integrator_hessian_row_gather_form(qc, oracle, monkeypatch,
         np.testing.assert_allclose(Hg, Hd, rtol=1e-12, atol=1e-13 * np.abs(ref).max())
     gather.close()
     dense.close()
+
+
+@pytest.mark.parametrize("nq", [1, 2, 3])
+def test_exponential_integrator_row_gather_one_wave_instantiations(qc, coracle, nq):
+    """Launches of 768 intervals and more take the one-wave-per-interval instantiations of qc_mfma_exp.hip (2, 4 and 6 drives to a wave):
+    their row-gather Horner steps, every value of F + dF at T = 800 against the C oracle."""
+    gate = {1: "H", 2: "CNOT", 3: "TOFFOLI"}[nq]
+    inp = qc.unitary_smooth_pulse_inputs(qc.multi_qubit_system(nq), qc.GATES[gate], 800, integrator="exponential")
+    prob = problem_from_inputs(inp)
+    Z = inp.traj.datavec
+    dyn = qc.QuantumDynamics(inp.integrators, inp.traj)
+    assert dyn.kernel_names[0] == "mfma16-exp-gather"
+    Fo, Jo = coracle.COracle(prob).F_dF(Z)
+    F, J = dyn.F_dF(Z, fresh=True)
+    np.testing.assert_allclose(F, Fo, rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(J, Jo, rtol=1e-10, atol=1e-11 * max(1.0, np.abs(Jo).max()))
+    dyn.close()
 
 
 def test_exponential_integrator_hessian_16_levels_and_beyond(qc, oracle, coracle):
@@ -1731,7 +1755,7 @@ def test_kernel_names_of_the_baseline_configurations(qc):
         assert dyn.kernel_names == names, (cfg, dyn.kernel_names)
         dyn.close()
     s3 = qc.multi_qubit_system(3)
-    for kw, names in [(dict(integrator="exponential"), ("mfma16-exp", "mfma16-exp-hess-gather")), (dict(pade_order=12), ("mfma16-padeP", "mfma16-padeP-hess"))]:
+    for kw, names in [(dict(integrator="exponential"), ("mfma16-exp-gather", "mfma16-exp-hess-gather")), (dict(pade_order=12), ("mfma16-padeP", "mfma16-padeP-hess"))]:
         inp = qc.unitary_smooth_pulse_inputs(s3, qc.GATES["TOFFOLI"], 5, **kw)
         dyn = qc.QuantumDynamics(inp.integrators, inp.traj)
         assert dyn.kernel_names == names, (kw, dyn.kernel_names)

@@ -23,7 +23,7 @@ needs_files = pytest.mark.skipif(not FILES, reason="no tests/golden/ref_*.json: 
 # Toffoli / QFT / order-6 records is to pin the MFMA kernels of the metric workloads, not the generic path
 EXPECTED_KERNELS = {
     "ref_fixture.json": ("mfma16-pade4", "mfma16-pade4-hess", "two-launches"),
-    "ref_fixture_exponential.json": ("mfma16-exp", "mfma16-exp-hess-gather", "two-launches"),
+    "ref_fixture_exponential.json": ("mfma16-exp-gather", "mfma16-exp-hess-gather", "two-launches"),
     "ref_config1.json": ("mfma16-pade4", "mfma16-pade4-hess", "two-launches"),
     "ref_config2.json": ("mfma16-pade4", "mfma16-pade4-hess", "two-launches"),
     "ref_toffoli3.json": ("mfma16-pade4", "mfma16-pade4-hess-gather", "mfma16-pade4-fused"),
