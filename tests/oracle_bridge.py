@@ -68,12 +68,13 @@ def random_problem(o, N, m, T, order=4, free_time=True, integrator=None, seed=0,
     return prob, Z
 
 
-def sparse_drive_problem(o, m, T, R=1, free_time=True, layout="standard", seed=0, N=16, dense_drift=True, kinds=("real", "imag", "diag")):
+def sparse_drive_problem(o, m, T, R=1, free_time=True, layout="standard", seed=0, N=16, dense_drift=True, kinds=("real", "imag", "diag"),
+                         integrator=None):
     """Like random_problem, with SPARSE Hermitian drive Hamiltonians whose real-iso generators have exactly R entries per row:
     R = 1: a perfect matching of the N levels with real or imaginary couplings (a Pauli-string-like signed permutation) or a real
     diagonal; R = 2: complex couplings on a matching, or two matchings (a ladder pair a + a^dagger has this shape).  The drift
     is dense unless dense_drift=False."""
-    prob, Z = random_problem(o, N=N, m=m, T=T, order=4, free_time=free_time, layout=layout, seed=seed)
+    prob, Z = random_problem(o, N=N, m=m, T=T, order=4, free_time=free_time, layout=layout, seed=seed, integrator=integrator)
     rng = np.random.default_rng(1000 + seed)
 
     def matching_H(kind):

@@ -38,6 +38,12 @@ for trial in range(trials):
                                        seed=int(rng.integers(1 << 30)), dense_drift=bool(rng.random() < 0.7),
                                        kinds=tuple(rng.choice(["real", "imag", "diag"], size=3)))
         m = prob.m
+    sparse_exp = integ == o.EXPONENTIAL and N <= 8 and m >= 1 and ncol == 0 and rng.random() < 0.5
+    if sparse_exp:  # one entry per drive-generator row with the exponential integrator: the row-gather Horner steps of qc_mfma_exp*.hip
+        prob, Z = sparse_drive_problem(o, m=min(m, 8), T=T, R=1, N=N, free_time=free_time, layout=str(rng.choice(["standard", "shuffled"])),
+                                       seed=int(rng.integers(1 << 30)), dense_drift=bool(rng.random() < 0.7),
+                                       kinds=tuple(rng.choice(["real", "imag", "diag"], size=3)), integrator=o.EXPONENTIAL)
+        m = prob.m
     if m == 0:
         prob.m = 0
         prob.G_drives = prob.G_drives[:0]
@@ -72,6 +78,9 @@ for trial in range(trials):
             worst[key] = max(worst.get(key, 0.0), eH)
         if cross_h and int(h.dims.hess_nnz):
             Hk[kernel] = h.hess(Z, mu)
+        if sparse_exp and kernel == "mfma":
+            assert qc._lib.lib.qc_kernel_name(h.h, 0) == b"mfma16-exp-gather" and qc._lib.lib.qc_kernel_name(h.h, 1) == b"mfma16-exp-hess-gather", tag
+            count["mfma16-exp-gather"] = count.get("mfma16-exp-gather", 0) + 1
         if sparse and kernel == "mfma":
             ell = qc._lib.lib.qc_kernel_name(h.h, 1) == b"mfma32-pade4-hess-ell"       # (not when five drives share an entry of G)
             count["mfma32-ell"] = count.get("mfma32-ell", 0) + int(ell)
