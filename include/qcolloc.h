@@ -243,11 +243,11 @@ const char* qc_last_error(const qc_handle* h);
 int qc_dims(const qc_handle* h, qc_dims_t* out);
 /* Names of the device kernels this handle's evaluations run on (diagnostic; static strings, never NULL):
  * which = 0: F / F + dF ("mfma16-pade4", "mfma16-padeP", "mfma32-pade4-ell" (sparse drive generators) / "mfma32-pade4",
- * "mfma64-pade4", "mfma16-exp" / "mfma16-exp-gather" (drive generators with one entry per row), "mfma32-exp", "lds", "lds-gws");
+ * "mfma64-pade4", "mfma16-exp" / "mfma16-exp-gather" (drive generators with one entry per row), "mfma32-exp" / "mfma32-exp-gather", "lds", "lds-gws");
  * which = 1: mu_d2F ("mfma16-pade4-hess-gather" (drive generators with one entry per row) / "mfma16-pade4-hess2" /
  * "mfma16-pade4-hess", "mfma16-padeP-hess", "mfma32-pade4-hess-ell" / "mfma32-pade4-hess", "mfma64-pade4-hess", "lds-hess",
  * "lds-gws-hess"; exponential integrator: "mfma16-exp-hess", "mfma16-exp-hess-gather"
- * (drive generators with one entry per row: Pauli strings), "mfma32-exp-hess", "lds-exp-hess", "lds-gws-exp-hess");
+ * (drive generators with one entry per row: Pauli strings), "mfma32-exp-hess" / "mfma32-exp-hess-gather", "lds-exp-hess", "lds-gws-exp-hess");
  * which = 2: qc_eval_F_jac_hess_dev ("mfma16-pade4-fused-gather" / "mfma16-pade4-fused", "mfma32-pade4-fused-ell", or
  * "two-launches"). */
 const char* qc_kernel_name(const qc_handle* h, int32_t which);

@@ -470,7 +470,7 @@ extern "C" int qc_create(const qc_desc* d, qc_handle** out) {
             QC_HIP_C(hipMalloc(&h->dEll16, blob16.size()));
             QC_HIP_C(hipMemcpy(h->dEll16, blob16.data(), blob16.size(), hipMemcpyHostToDevice));
             h->prm.ell16 = h->dEll16;
-        } else if (!no_ell && qc_mfma16_exp_ell_build(h->prm, G.data(), &blob16)) {      // the exponential integrator's mu_d2F at 2N <= 16
+        } else if (!no_ell && qc_exp_ell_build(h->prm, G.data(), &blob16)) {      // the exponential integrator's MFMA kernels (2N <= 32)
             QC_HIP_C(hipMalloc(&h->dEll16, blob16.size()));
             QC_HIP_C(hipMemcpy(h->dEll16, blob16.data(), blob16.size(), hipMemcpyHostToDevice));
             h->prm.ell16 = h->dEll16;
@@ -572,7 +572,7 @@ extern "C" const char* qc_kernel_name(const qc_handle* h, int32_t which) {
     const bool mfma = h->kernel == QC_KERNEL_MFMA;
     if (which == 0) {
         if (!mfma) return P.use_ws ? "lds-gws" : "lds";
-        if (P.integrator == QC_EXPONENTIAL) return P.n > 16 ? "mfma32-exp" : (P.ell16 != nullptr ? "mfma16-exp-gather" : "mfma16-exp");
+        if (P.integrator == QC_EXPONENTIAL) return P.n > 16 ? (P.ell16 != nullptr ? "mfma32-exp-gather" : "mfma32-exp") : (P.ell16 != nullptr ? "mfma16-exp-gather" : "mfma16-exp");
         if (qc_mfma16_padeP_supported(P)) return "mfma16-padeP";
         if (P.n > 16 && P.n <= 32 && P.ell) return "mfma32-pade4-ell";
         return P.n > 32 ? "mfma64-pade4" : (P.n > 16 ? "mfma32-pade4" : "mfma16-pade4");
@@ -580,7 +580,7 @@ extern "C" const char* qc_kernel_name(const qc_handle* h, int32_t which) {
     if (P.integrator != QC_PADE) {      // exponential integrator: mu_d2F alone; F + dF + mu_d2F as two launches
         if (which == 2) return "two-launches";
         if (mfma && qc_mfma_exp_hess_supported(P)) return P.ell16 != nullptr ? "mfma16-exp-hess-gather" : "mfma16-exp-hess";
-        if (mfma && qc_mfma32_exp_hess_supported(P)) return "mfma32-exp-hess";
+        if (mfma && qc_mfma32_exp_hess_supported(P)) return P.ell16 != nullptr ? "mfma32-exp-hess-gather" : "mfma32-exp-hess";
         return P.use_ws ? "lds-gws-exp-hess" : "lds-exp-hess";
     }
     if (which == 2) return mfma && qc_mfma16_fused_supported(P) ? (qc_mfma16_fused_gathers(P) ? "mfma16-pade4-fused-gather" : "mfma16-pade4-fused") : (mfma && P.ell && P.hess_nnz ? "mfma32-pade4-fused-ell" : "two-launches");

@@ -207,7 +207,7 @@ bool qc_mfma32_hess_supported(const QcParams& P);
 // sparse drive generators (at most 2 entries per row), 2N = 32, Hermitian Hamiltonians: qc_mfma32_ell.hip
 int qc_mfma32_ell_build(const QcParams& P, const double* G_host, std::vector<char>* blob, int* slots_out);
 bool qc_mfma16_ell_build(const QcParams& P, const double* G_host, std::vector<char>* blob);   // 2N = 16, one entry per drive row: qc_mfma_fused.hip
-bool qc_mfma16_exp_ell_build(const QcParams& P, const double* G_host, std::vector<char>* blob);   // exponential integrator, 2N <= 16, one entry per drive row: qc_mfma_exp_hess.hip
+bool qc_exp_ell_build(const QcParams& P, const double* G_host, std::vector<char>* blob);   // exponential integrator, 2N <= 32, at most one entry per drive row: qc_mfma_exp_hess.hip
 void qc_mfma16_ell_pair_table(const QcParams& P, std::vector<char>* blob);                    // ... its pair table for the (a, a) block: qc_mfma_hess_g2.hip
 bool qc_mfma16_hess_g2(const QcParams& P);
 hipError_t qc_launch_mfma16_hess_g2(const QcParams& P, const double* dZ, const double* dMu, double* dH, hipStream_t st);

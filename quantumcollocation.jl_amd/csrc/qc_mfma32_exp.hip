@@ -15,6 +15,8 @@
 // whole 128-byte lines): wave w stores copies w and w + 8 of -E from the transposed tiles of E, its drive's columns as
 // (L_j U_t)^T = U_t^T L_j^T; wave 0 the residual and d/dh.  About 7200 MFMAs per interval at m = 8 with 3 squarings:
 // MFMA-pipe-bound (~110 us floor for config 5 at T = 500); the LDS kernel needs 4.1 ms for the same problem.
+#include <stdlib.h>
+
 #include "qc_mfma_common.h"
 
 namespace {
@@ -94,12 +96,18 @@ __device__ inline void e32_store_T(double* __restrict__ p, const v4d& x, int ld,
         if (colbase + 4 * r + g < ld && rowbase + j < ld) qc_st8m<2>(p + (size_t)(colbase + 4 * r + g) * ld + rowbase + j, x[r]);
 }
 
-template <bool JAC>
+// ELL: every drive generator has at most ONE entry per row (Pauli strings; P.ell16 = qc_exp_ell_build's tables, qc_mfma_exp_hess.hip): the
+// product G_j R of a Horner step is a row gather from a row-major copy of R that the owners of R publish next to the tiles -- 32 MFMAs
+// per drive wave and step instead of 64.  fma(w, x, acc) per element: what the dense product adds besides exact zeros.
+constexpr int kRS = 33;             // row stride of the row-major copies (doubles): the lanes of a gather fall on distinct banks
+
+template <bool JAC, bool ELL = false>
 __global__ __launch_bounds__(kE32Threads, 1) void qc_mfma32_exp_kernel(const QcParams P, const double* __restrict__ Z,
                                                                        double* __restrict__ F, double* __restrict__ J) {
     qc_kernarg_touch<sizeof(QcParams) + 64>();   // one batch of scalar-cache misses instead of one per use (qc_internal.h)
     __shared__ __attribute__((aligned(16))) double GL[4 * 256];          // G (unscaled), A-layout tiles 2I+K
     __shared__ __attribute__((aligned(16))) double RL[2][4 * 256];       // the shared chain R / E, D-layout tiles 2K+J, double-buffered
+    __shared__ double RR[ELL ? 2 : 1][ELL ? 32 * kRS : 1];               // ELL: R row-major (the gathers' source), double-buffered
     __shared__ double TS[8 * 16 * 17];                                   // per-wave transpose scratch
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -123,7 +131,22 @@ __global__ __launch_bounds__(kE32Threads, 1) void qc_mfma32_exp_kernel(const QcP
 
     // ---- loads: this wave's half tile of the generator images (assembly), its drive's images, U_t ---------------------
     v4d Gj[4];
-    {
+    double tw[2][4];                                                     // ELL: weight and source offset (column x kRS + j) of rows 16 I + 4 r + g of this wave's drive
+    int tc[2][4];
+    if constexpr (ELL) {
+        const double* __restrict__ bw = reinterpret_cast<const double*>(P.ell16);
+        const int* __restrict__ bc = reinterpret_cast<const int*>(reinterpret_cast<const char*>(P.ell16) + kE32Mmax * 32 * 8);
+        const int k = drive ? w : 0;
+#pragma unroll
+        for (int I = 0; I < 2; ++I) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double wt = bw[k * 32 + 16 * I + 4 * r + g];
+                tw[I][r] = drive ? wt : 0.0;
+                tc[I][r] = bc[k * 32 + 16 * I + 4 * r + g] * kRS + j;
+            }
+        }
+    } else {
         const int kmat = drive ? w + 1 : 0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) Gj[q] = e32_tile(GxA + (size_t)kmat * 1024, q, lane);
@@ -151,6 +174,15 @@ __global__ __launch_bounds__(kE32Threads, 1) void qc_mfma32_exp_kernel(const QcP
 #pragma unroll
         for (int u = 0; u < kE32Mmax; ++u) Gh += (u < m ? ak[u] : 0.0) * img[u + 1];
         reinterpret_cast<v2d*>(GL)[(w >> 1) * 128 + (w & 1) * 64 + lane] = Gh;
+    }
+    if constexpr (ELL) {   // R_deg+1 = I/deg! row-major for the first step's gathers (tile (I, J) by wave 2 I + J)
+        if (w < 4) {
+            double f0 = 1.0;
+#pragma unroll
+            for (int k = 2; k <= kE32Deg; ++k) f0 *= (double)k;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) RR[0][(16 * (w >> 1) + 4 * r + g) * kRS + 16 * (w & 1) + j] = ((w >> 1) == (w & 1) && 4 * r + g == j) ? 1.0 / f0 : 0.0;
+        }
     }
     __syncthreads();
 
@@ -207,8 +239,39 @@ __global__ __launch_bounds__(kE32Threads, 1) void qc_mfma32_exp_kernel(const QcP
             const v4d c0 = I == Jt ? ck * IdB : zero;
             const v4d rn = e32_mac2(Y[2 * I], R[Jt], Y[2 * I + 1], R[2 + Jt], c0);
             e32_put(RL[cur ^ 1], w, lane, rn);
+            if constexpr (ELL) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) RR[cur ^ 1][(16 * I + 4 * r + g) * kRS + 16 * Jt + j] = rn[r];
+            }
         }
-        if (drive) e32_chain4(Gj, R, Y, Q, Q);
+        if constexpr (ELL) {
+            if (drive) {   // Q_j <- Y Q_j + G_j R: the gathers requested, the products, the gathered terms added
+                const double* __restrict__ rr = RR[cur];
+                double x[4][4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) x[t][r] = rr[tc[t >> 1][r] + 16 * (t & 1)];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                v4d acc[4] = {zero, zero, zero, zero};
+#pragma unroll
+                for (int K = 0; K < 2; ++K) {
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(Y[2 * (t >> 1) + K][kk], Q[2 * K + (t & 1)][kk], acc[t], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Q[t][r] = __builtin_fma(tw[t >> 1][r], x[t][r], acc[t][r]);
+                }
+            }
+        } else {
+            if (drive) e32_chain4(Gj, R, Y, Q, Q);
+        }
         __syncthreads();
         cur ^= 1;
 #pragma unroll
@@ -307,7 +370,9 @@ bool qc_mfma32_exp_supported(const QcParams& P) {
 }
 
 hipError_t qc_launch_mfma32_exp(const QcParams& P, const double* dZ, double* dF, double* dJ, hipStream_t st) {
-    if (dJ) hipLaunchKernelGGL(qc_mfma32_exp_kernel<true>, dim3(P.n_int), dim3(kE32Threads), 0, st, P, dZ, dF, dJ);
+    static const bool ell_off = getenv("QC_EXP_ELL") && atoi(getenv("QC_EXP_ELL")) == 0;      // A/B diagnostics
+    if (dJ && P.ell16 != nullptr && !ell_off) hipLaunchKernelGGL((qc_mfma32_exp_kernel<true, true>), dim3(P.n_int), dim3(kE32Threads), 0, st, P, dZ, dF, dJ);
+    else if (dJ) hipLaunchKernelGGL(qc_mfma32_exp_kernel<true>, dim3(P.n_int), dim3(kE32Threads), 0, st, P, dZ, dF, dJ);
     else hipLaunchKernelGGL(qc_mfma32_exp_kernel<false>, dim3(P.n_int), dim3(kE32Threads), 0, st, P, dZ, dF, dJ);
     return hipGetLastError();
 }

@@ -13,6 +13,8 @@
 // factors of the squarings); Y, V and the shared chains are read from LDS where a product needs them (a tile is 2 KB: 16 cycles of
 // LDS against 256 of the matrix pipe).  One barrier per Horner step / squaring.  About 2570 MFMAs per drive wave at 4 squarings --
 // 20 k per interval at eight drives: the matrix pipes' (qc_mfma32_exp.hip, F + dF: 7200).
+#include <stdlib.h>
+
 #include "qc_mfma_common.h"
 
 namespace {
@@ -76,9 +78,21 @@ __device__ __forceinline__ void x_prod4(FA a_of, FB b_of, v4d (&acc)[4]) {
     }
 }
 
+// ELL: every drive generator has at most ONE entry per row (Pauli strings; P.ell16 = qc_exp_ell_build's tables, qc_mfma_exp_hess.hip): the
+// products G_j R and G_j QV of a Horner step are row gathers from row-major copies of R and QV that their owners publish next to the
+// tiles -- 96 MFMAs per drive wave and step instead of 160.  fma(w, x, acc) per element: what the dense product adds besides exact zeros.
+constexpr int kRS = 33;             // row stride of the row-major copies (doubles): the lanes of a gather fall on distinct banks
+__device__ __forceinline__ void x_pin(v4d& x) {       // the tile's values in vector registers HERE (qc_mfma_exp_hess.hip, pin_v)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(x[r]));
+}
+
+template <bool ELL>
 __global__ __launch_bounds__(kXThreads, 1) void qc_mfma32_exp_hess_kernel(const QcParams P, const double* __restrict__ Z, const double* __restrict__ Mu,
                                                                           double* __restrict__ H) {
     qc_kernarg_touch<sizeof(QcParams) + 64>();
+    __shared__ double RR[ELL ? 2 : 1][ELL ? 32 * kRS : 1];              // ELL: R and QV row-major (the gathers' sources), double-buffered
+    __shared__ double QR[ELL ? 2 : 1][ELL ? 32 * kRS : 1];
     // tile index of a 32 x 32 matrix: 2 * (row block) + (column block)
     __shared__ __attribute__((aligned(16))) double GL[4 * 256];          // G (unscaled), A-layout tiles
     __shared__ __attribute__((aligned(16))) double YL[4 * 256];          // Y = (h / 2^sq) G, A-layout tiles
@@ -113,7 +127,22 @@ __global__ __launch_bounds__(kXThreads, 1) void qc_mfma32_exp_hess_kernel(const 
 
     // ---- loads: this wave's drive images, its half tile of the generator assembly; the owners: M and U_t in the A layout --------------
     v4d Gj[4];
-    {
+    double tw[2][4];                                                     // ELL: weight and source offset (column x kRS + j) of rows 16 I + 4 r + g of this wave's drive
+    int tc[2][4];
+    if constexpr (ELL) {
+        const double* __restrict__ bw = reinterpret_cast<const double*>(P.ell16);
+        const int* __restrict__ bc = reinterpret_cast<const int*>(reinterpret_cast<const char*>(P.ell16) + kXMmax * 32 * 8);
+        const int k = drive ? w : 0;
+#pragma unroll
+        for (int I = 0; I < 2; ++I) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double wt = bw[k * 32 + 16 * I + 4 * r + g];
+                tw[I][r] = drive ? wt : 0.0;
+                tc[I][r] = bc[k * 32 + 16 * I + 4 * r + g] * kRS + j;
+            }
+        }
+    } else {
         const int kmat = drive ? w + 1 : 0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) Gj[q] = x_gtile(GxA + (size_t)kmat * 1024, q, lane);
@@ -212,6 +241,13 @@ __global__ __launch_bounds__(kXThreads, 1) void qc_mfma32_exp_hess_kernel(const 
         x_put(RT[0], w, lane, r0);                                        // (a multiple of the identity: its own transpose)
         x_put(QL[0], w, lane, zero);
         x_put(QT[0], w, lane, zero);
+        if constexpr (ELL) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                RR[0][(16 * oI + 4 * r + g) * kRS + 16 * oJ + j] = r0[r];
+                QR[0][(16 * oI + 4 * r + g) * kRS + 16 * oJ + j] = 0.0;
+            }
+        }
     }
     __syncthreads();                                                      // (YL and the chains' start)
     v4d Q[4] = {zero, zero, zero, zero}, Pm[4] = {zero, zero, zero, zero};
@@ -237,11 +273,59 @@ __global__ __launch_bounds__(kXThreads, 1) void qc_mfma32_exp_hess_kernel(const 
             }
             x_put(RL[cur ^ 1], w, lane, rn);
             x_put(QL[cur ^ 1], w, lane, qn);
+            if constexpr (ELL) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    RR[cur ^ 1][(16 * oI + 4 * r + g) * kRS + 16 * oJ + j] = rn[r];
+                    QR[cur ^ 1][(16 * oI + 4 * r + g) * kRS + 16 * oJ + j] = qn[r];
+                }
+            }
             if (k == 1) {                                                 // the squarings (and the outputs) read the transposed tiles
                 x_put(RT[cur ^ 1], w, lane, lds_transpose16(scr, rn, g, j));
                 x_put(QT[cur ^ 1], w, lane, lds_transpose16(scr, qn, g, j));
             }
         }
+        if constexpr (ELL) {
+            if (drive) {   // two phases, each: its gathers requested, its products, the gathered terms added (qc_mfma_exp_hess.hip)
+                {
+                    const double* __restrict__ qr = QR[cur];
+                    double x[4][4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) x[t][r] = qr[tc[t >> 1][r] + 16 * (t & 1)];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    v4d acc[4] = {zero, zero, zero, zero};
+                    x_prod4(Vt, [&](int K, int J) { return Q[2 * K + J]; }, acc);      // V Q_j
+                    x_prod4(Yt, [&](int K, int J) { return Pm[2 * K + J]; }, acc);     // + Y P_j
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) Pm[t][r] = __builtin_fma(tw[t >> 1][r], x[t][r], acc[t][r]);      // + G_j QV
+                        x_pin(Pm[t]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                {
+                    const double* __restrict__ rr = RR[cur];
+                    double x[4][4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) x[t][r] = rr[tc[t >> 1][r] + 16 * (t & 1)];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    v4d acq[4] = {zero, zero, zero, zero};
+                    x_prod4(Yt, [&](int K, int J) { return Q[2 * K + J]; }, acq);      // Y Q_j
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) Q[t][r] = __builtin_fma(tw[t >> 1][r], x[t][r], acq[t][r]);       // + G_j R
+                    }
+                }
+            }
+        } else {
         if (drive) {
             v4d acc[4] = {zero, zero, zero, zero};
             x_prod4(Vt, [&](int K, int J) { return Q[2 * K + J]; }, acc);      // V Q_j
@@ -254,6 +338,7 @@ __global__ __launch_bounds__(kXThreads, 1) void qc_mfma32_exp_hess_kernel(const 
             x_prod4(Yt, [&](int K, int J) { return Q[2 * K + J]; }, acq);      // + Y Q_j
 #pragma unroll
             for (int q = 0; q < 4; ++q) Q[q] = acq[q];
+        }
         }
         __syncthreads();
         cur ^= 1;
@@ -392,6 +477,8 @@ bool qc_mfma32_exp_hess_supported(const QcParams& P) {
 }
 
 hipError_t qc_launch_mfma32_exp_hess(const QcParams& P, const double* dZ, const double* dMu, double* dH, hipStream_t st) {
-    hipLaunchKernelGGL(qc_mfma32_exp_hess_kernel, dim3(P.n_int), dim3(kXThreads), 0, st, P, dZ, dMu, dH);
+    static const bool ell_off = getenv("QC_EXP_ELL") && atoi(getenv("QC_EXP_ELL")) == 0;      // A/B diagnostics
+    if (P.ell16 != nullptr && !ell_off) hipLaunchKernelGGL(qc_mfma32_exp_hess_kernel<true>, dim3(P.n_int), dim3(kXThreads), 0, st, P, dZ, dMu, dH);
+    else hipLaunchKernelGGL(qc_mfma32_exp_hess_kernel<false>, dim3(P.n_int), dim3(kXThreads), 0, st, P, dZ, dMu, dH);
     return hipGetLastError();
 }

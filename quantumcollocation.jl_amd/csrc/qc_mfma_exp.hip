@@ -75,7 +75,7 @@ __device__ __forceinline__ void horner_step(const v4d& Y, const v4d (&Gj)[M], v4
     R = accR;
 }
 
-// The same step for drive generators with at most ONE entry per row (P.ell16 = qc_mfma16_exp_ell_build's tables, qc_mfma_exp_hess.hip):
+// The same step for drive generators with at most ONE entry per row (P.ell16 = qc_exp_ell_build's tables, qc_mfma_exp_hess.hip):
 // G_j R is a row gather from a row-major LDS copy of R -- 4 + 4 m MFMAs a step instead of 4 + 8 m.  The gathers are requested before
 // the products and added behind them: fma(w, x, acc), what the dense product adds besides exact zeros.
 template <int M>
@@ -194,13 +194,13 @@ __global__ __launch_bounds__(64 * kW, kW) void qc_mfma16_exp_kernel(const QcPara
             }
             if constexpr (ELL) {   // rows 4 r + g of the wave's drives (unused drive slots: weight 0, column 0 -- their chains stay zero)
                 const double* __restrict__ bw = reinterpret_cast<const double*>(P.ell16);
-                const int* __restrict__ bc = reinterpret_cast<const int*>(reinterpret_cast<const char*>(P.ell16) + kXMmax * 16 * 8);
+                const int* __restrict__ bc = reinterpret_cast<const int*>(reinterpret_cast<const char*>(P.ell16) + kXMmax * 32 * 8);
 #pragma unroll
                 for (int u = 0; u < kMU; ++u) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        tw[u][r] = bw[(d0 + u) * 16 + 4 * r + g];
-                        tc[u][r] = bc[(d0 + u) * 16 + 4 * r + g] + j;
+                        tw[u][r] = bw[(d0 + u) * 32 + 4 * r + g];
+                        tc[u][r] = bc[(d0 + u) * 32 + 4 * r + g] * 17 + j;
                     }
                 }
             } else {

@@ -129,11 +129,13 @@ __device__ __forceinline__ void lds_order() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// ELL: every drive generator has at most ONE entry per row (Pauli strings; P.ell16 = qc_mfma16_exp_ell_build's tables): the two products
+// ELL: every drive generator has at most ONE entry per row (Pauli strings; P.ell16 = qc_exp_ell_build's tables): the two products
 // with a drive image in every Horner step, G_j R and G_j QV, are row gathers from row-major LDS copies of R and QV -- 3 + 3 kMU products
 // a step instead of 3 + 5 kMU.  fma(w, x, acc) per element: what the dense product adds besides exact zeros.
+// (Two waves per SIMD up to three drives a wave -- 256 registers -- is what the launch's time rests on: demanded of the compiler, which
+//  otherwise lands on either side of the line with any small change: 252 -> 264 registers when the tables' layout changed, 61.5 -> 71.2 us.)
 template <int kMU, int kW, bool ELL>
-__global__ __launch_bounds__(64 * kW) void qc_mfma16_exp_hess_kernel(const QcParams P, const double* __restrict__ Z, const double* __restrict__ Mu,
+__global__ __launch_bounds__(64 * kW) __attribute__((amdgpu_waves_per_eu(kMU <= 3 ? 2 : 1))) void qc_mfma16_exp_hess_kernel(const QcParams P, const double* __restrict__ Z, const double* __restrict__ Mu,
                                                                      double* __restrict__ H) {
     qc_kernarg_touch<sizeof(QcParams) + 64>();
     constexpr int kTiles = 2 * kMU + 2;                       // E, LV, L_j, P_j
@@ -192,13 +194,13 @@ __global__ __launch_bounds__(64 * kW) void qc_mfma16_exp_hess_kernel(const QcPar
         }
         if constexpr (ELL) {   // rows 4 r + g of the wave's drives (unused drive slots: weight 0, column 0 -- their chains stay zero)
             const double* __restrict__ bw = reinterpret_cast<const double*>(P.ell16);
-            const int* __restrict__ bc = reinterpret_cast<const int*>(reinterpret_cast<const char*>(P.ell16) + kXHMmax * 16 * 8);
+            const int* __restrict__ bc = reinterpret_cast<const int*>(reinterpret_cast<const char*>(P.ell16) + kXHMmax * 32 * 8);
 #pragma unroll
             for (int u = 0; u < kMU; ++u) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    tw[u][r] = bw[(d0 + u) * 16 + 4 * r + g];
-                    tc[u][r] = bc[(d0 + u) * 16 + 4 * r + g] + j;
+                    tw[u][r] = bw[(d0 + u) * 32 + 4 * r + g];
+                    tc[u][r] = bc[(d0 + u) * 32 + 4 * r + g] * 17 + j;
                 }
             }
         } else {
@@ -469,15 +471,16 @@ bool qc_mfma_exp_hess_supported(const QcParams& P) {
     return P.integrator == QC_EXPONENTIAL && P.n <= 16 && P.nc <= 8 && P.m <= kXHMmax && P.hess_nnz > 0 && P.Gx != nullptr;
 }
 
-// Rows of the drive generators of an exponential-integrator handle at 2N <= 16 whose drives have at most ONE entry per row:
-// blob = [8][16] weights (doubles), [8][16] columns x 17 (ints: offsets into the 17-double rows of the LDS copies); unused rows and
-// drive slots: weight 0, column 0.  (P.ell16 of a Pade handle is qc_mfma16_ell_build's table; the two never meet: the integrator decides.)
-bool qc_mfma16_exp_ell_build(const QcParams& P, const double* G, std::vector<char>* blob) {
-    if (P.integrator != QC_EXPONENTIAL || P.n > 16 || P.m < 1 || P.m > kXHMmax) return false;
+// Rows of the drive generators of an exponential-integrator handle at 2N <= 32 whose drives have at most ONE entry per row:
+// blob = [8][32] weights (doubles), [8][32] columns (ints); unused rows and drive slots: weight 0, column 0.  Read by the four MFMA
+// kernels of the exponential integrator (qc_mfma_exp*.hip, qc_mfma32_exp*.hip).  (P.ell16 of a Pade handle is qc_mfma16_ell_build's
+// table; the two never meet: the integrator decides.)
+bool qc_exp_ell_build(const QcParams& P, const double* G, std::vector<char>* blob) {
+    if (P.integrator != QC_EXPONENTIAL || P.n > 32 || P.m < 1 || P.m > kXHMmax) return false;
     const int n = P.n, m = P.m;
-    blob->assign(kXHMmax * 16 * 8 + kXHMmax * 16 * 4, 0);
+    blob->assign(kXHMmax * 32 * 8 + kXHMmax * 32 * 4, 0);
     double* tw = reinterpret_cast<double*>(blob->data());
-    int* tc = reinterpret_cast<int*>(blob->data() + kXHMmax * 16 * 8);
+    int* tc = reinterpret_cast<int*>(blob->data() + kXHMmax * 32 * 8);
     for (int k = 0; k < m; ++k)
         for (int a = 0; a < n; ++a) {
             int cnt = 0;
@@ -485,8 +488,8 @@ bool qc_mfma16_exp_ell_build(const QcParams& P, const double* G, std::vector<cha
                 const double v = G[(size_t)(k + 1) * n * n + (size_t)c * n + a];      // drive k, row a, column c (column-major)
                 if (v == 0.0) continue;
                 if (++cnt > 1) return false;
-                tw[k * 16 + a] = v;
-                tc[k * 16 + a] = c * 17;
+                tw[k * 32 + a] = v;
+                tc[k * 32 + a] = c;
             }
         }
     return true;

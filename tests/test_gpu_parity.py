@@ -680,6 +680,35 @@ def test_exponential_integrator_row_gather_one_wave_instantiations(qc, coracle, 
     dyn.close()
 
 
+@pytest.mark.parametrize("T,free_time,gate", [(4, True, "QFT16"), (3, False, "QFT16")])
+def test_exponential_integrator_row_gather_form_four_qubits(qc, coracle, monkeypatch, T, free_time, gate):
+    """The same at 2N = 32 (qc_mfma32_exp.hip, qc_mfma32_exp_hess.hip: the owners of the shared chains publish row-major copies of R and
+    QV, the drive waves gather from them): four qubits with eight Pauli drives, F + dF and mu_d2F against the C oracle and against the
+    dense-image forms, steps from 0 to 5 squarings."""
+    inp = qc.unitary_smooth_pulse_inputs(qc.multi_qubit_system(4), qc.GATES[gate], T, integrator="exponential", free_time=free_time)
+    prob = problem_from_inputs(inp)
+    Z = inp.traj.datavec.copy()
+    if free_time:
+        Z[prob.off_dt::prob.zdim] = np.resize([0.2, 0.01, 1.3, 0.5], T)
+    mu = np.random.default_rng(41).standard_normal(prob.n_rows)
+    gather = qc.QuantumDynamics(inp.integrators, inp.traj)
+    assert gather.kernel_names == ("mfma32-exp-gather", "mfma32-exp-hess-gather")
+    monkeypatch.setenv("QC_NO_ELL", "1")
+    dense = qc.QuantumDynamics(inp.integrators, inp.traj)
+    monkeypatch.delenv("QC_NO_ELL")
+    assert dense.kernel_names == ("mfma32-exp", "mfma32-exp-hess")
+    C = coracle.COracle(prob)
+    Fo, Jo = C.F_dF(Z)
+    Ho = C.mu_d2F(Z, mu)
+    for dyn, what in ((gather, "row gathers"), (dense, "dense images")):
+        F, J = dyn.F_dF(Z, fresh=True)
+        np.testing.assert_allclose(F, Fo, rtol=1e-10, atol=1e-12, err_msg=what)
+        np.testing.assert_allclose(J, Jo, rtol=1e-10, atol=1e-11 * max(1.0, np.abs(Jo).max()), err_msg=what)
+        assert_close_h(dyn.mu_d2F(Z, mu, fresh=True), Ho, f"exp hessian, four qubits, {what}")
+    gather.close()
+    dense.close()
+
+
 def test_exponential_integrator_hessian_16_levels_and_beyond(qc, oracle, coracle):
     """N = 9 .. 16 (2 x 2 tiles: qc_mfma32_exp_hess.hip; 1 .. 8 drives: every wave role) and N = 20 (the generic kernel alone) against
     the C oracle's forward-mode chains; both kernels where both serve."""
@@ -1768,7 +1797,7 @@ def test_kernel_names_of_the_baseline_configurations(qc):
     assert dyn.kernel_names == ("lds-gws", "lds-gws-hess")
     inp4 = qc.unitary_smooth_pulse_inputs(qc.multi_qubit_system(4), np.eye(16, dtype=complex), 4, integrator="exponential")
     d4 = qc.QuantumDynamics(inp4.integrators, inp4.traj)
-    assert d4.kernel_names == ("mfma32-exp", "mfma32-exp-hess") and d4.fused_kernel_name == "two-launches"
+    assert d4.kernel_names == ("mfma32-exp-gather", "mfma32-exp-hess-gather") and d4.fused_kernel_name == "two-launches"
     d4.close()
     dyn.close()
 
