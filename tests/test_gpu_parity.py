@@ -709,6 +709,27 @@ def test_exponential_integrator_row_gather_form_four_qubits(qc, coracle, monkeyp
     dense.close()
 
 
+@pytest.mark.parametrize("N,m,free_time", [(12, 5, True), (9, 8, False), (16, 3, True), (6, 4, True), (3, 7, False)])
+def test_exponential_integrator_row_gather_forms_any_size(qc, oracle, coracle, N, m, free_time):
+    """Random sparse drive Hamiltonians (a matching of the levels with real or imaginary couplings, or a diagonal: one entry per generator
+    row) at sizes that pad the tiles -- 2N = 6 .. 32 -- with the exponential integrator: F + dF and mu_d2F of the row-gather kernels
+    against the C oracle."""
+    prob, Z = sparse_drive_problem(oracle, m=m, T=4, R=1, N=N, free_time=free_time, seed=90 + N, integrator=oracle.EXPONENTIAL)
+    mu = np.random.default_rng(N).standard_normal(prob.n_rows)
+    C = coracle.COracle(prob)
+    Fo, Jo = C.F_dF(Z)
+    Ho = C.mu_d2F(Z, mu)
+    h = RawHandle(qc, prob, kernel="mfma")
+    big = 2 * N > 16
+    assert qc._lib.lib.qc_kernel_name(h.h, 0) == (b"mfma32-exp-gather" if big else b"mfma16-exp-gather")
+    assert qc._lib.lib.qc_kernel_name(h.h, 1) == (b"mfma32-exp-hess-gather" if big else b"mfma16-exp-hess-gather")
+    F, J = h.F_jac(Z)
+    np.testing.assert_allclose(F, Fo, rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(J, Jo, rtol=1e-10, atol=1e-11 * max(1.0, np.abs(Jo).max()))
+    assert_close_h(h.hess(Z, mu), Ho, f"exp hessian, row gathers, N={N} m={m}")
+    h.close()
+
+
 def test_exponential_integrator_hessian_16_levels_and_beyond(qc, oracle, coracle):
     """N = 9 .. 16 (2 x 2 tiles: qc_mfma32_exp_hess.hip; 1 .. 8 drives: every wave role) and N = 20 (the generic kernel alone) against
     the C oracle's forward-mode chains; both kernels where both serve."""
