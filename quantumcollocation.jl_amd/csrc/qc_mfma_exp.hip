@@ -341,11 +341,14 @@ hipError_t qc_launch_mfma_exp(const QcParams& P, const double* dZ, double* dF, d
         hipLaunchKernelGGL((qc_mfma16_exp_kernel<false, 1, 1>), dim3(grid), dim3(64), 0, st, P, dZ, dF, dJ);
     } else if (P.m <= 1) {
         QC_XJ(1, 1);
-    } else if (P.n_int >= 768) {   // enough intervals to put a wave on (nearly) every SIMD: one wave per interval, no redundant R chain
-        if (P.m <= 2) QC_XJ(2, 1);
-        else if (P.m <= 4) QC_XJ(4, 1);
-        else if (P.m <= 6) QC_XJ(6, 1);
-        else QC_XJ(8, 1);
+    } else if (!ell && P.n_int >= 768) {   // enough intervals to put a wave on (nearly) every SIMD: one wave per interval, no redundant R chain
+        // (dense drive images only.  The row-gather form keeps two waves per interval at every length: with the drive products gone the
+        //  duplicated R chain costs less than what the second wave hides of the gathers' round trips -- T = 1000 / 8000: 24.6 / 150.2
+        //  against 24.9 / 157.3 us)
+        if (P.m <= 2) hipLaunchKernelGGL((qc_mfma16_exp_kernel<true, 2, 1>), dim3(grid), dim3(64), 0, st, P, dZ, dF, dJ);
+        else if (P.m <= 4) hipLaunchKernelGGL((qc_mfma16_exp_kernel<true, 4, 1>), dim3(grid), dim3(64), 0, st, P, dZ, dF, dJ);
+        else if (P.m <= 6) hipLaunchKernelGGL((qc_mfma16_exp_kernel<true, 6, 1>), dim3(grid), dim3(64), 0, st, P, dZ, dF, dJ);
+        else hipLaunchKernelGGL((qc_mfma16_exp_kernel<true, 8, 1>), dim3(grid), dim3(64), 0, st, P, dZ, dF, dJ);
     } else {     // short trajectories: two waves per interval, ceil(m/2) drives each (config 2, T = 200: 18.3 -> 11.9 us)
         const int mh = (P.m + 1) / 2;
         if (mh == 1) QC_XJ(1, 2);

@@ -664,9 +664,9 @@ def test_exponential_integrator_hessian_row_gather_form(qc, oracle, monkeypatch,
 
 
 @pytest.mark.parametrize("nq", [1, 2, 3])
-def test_exponential_integrator_row_gather_one_wave_instantiations(qc, coracle, nq):
-    """Launches of 768 intervals and more take the one-wave-per-interval instantiations of qc_mfma_exp.hip (2, 4 and 6 drives to a wave):
-    their row-gather Horner steps, every value of F + dF at T = 800 against the C oracle."""
+def test_exponential_integrator_row_gather_long_trajectory(qc, coracle, nq):
+    """Launches of 768 intervals and more: the dense-image form of qc_mfma_exp.hip goes to one wave per interval there, the row-gather
+    form keeps its two waves -- every value of F + dF at T = 800 against the C oracle."""
     gate = {1: "H", 2: "CNOT", 3: "TOFFOLI"}[nq]
     inp = qc.unitary_smooth_pulse_inputs(qc.multi_qubit_system(nq), qc.GATES[gate], 800, integrator="exponential")
     prob = problem_from_inputs(inp)
