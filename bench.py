@@ -428,6 +428,62 @@ def config5_record(qc, dev_index, steps=300):
     return rec
 
 
+def exponential_record(qc, dev_index, steps=200):
+    """The metric workload with `PiccoloOptions(integrator=:exponential)` (SURVEY 8 rows a6 / a6'; the reference solves such problems with
+    the Hessian on, unitary_smooth_pulse_problem.jl:224-266): device times of F + dF, mu_d2F and the residual alone, and the Ipopt-order
+    proxy built from them.  These launches are bound by the f64 matrix pipes; the MFMA instruction counts per launch come from the newest
+    profiles/r*_mfma_util.json (external, labelled) when it holds these kernels."""
+    inp = qc.config_inputs(3, T=T_PER_GPU, integrator="exponential")
+    dyn = qc.QuantumDynamics(inp.integrators, inp.traj, device=dev_index)
+    dev = torch.device("cuda", dev_index)
+    dims = dyn.dims
+    rng = np.random.default_rng(6)
+    Z = torch.from_numpy(inp.traj.datavec).to(dev)
+    mu = torch.from_numpy(rng.standard_normal(int(dims.n_rows))).to(dev)
+    nb = max(2, -(-RING_BYTES // (8 * int(dims.jac_nnz))))
+    nh = max(2, -(-RING_BYTES // (8 * max(1, int(dims.hess_nnz)))))
+    Fb = [torch.empty(int(dims.F_len), dtype=torch.float64, device=dev) for _ in range(nb)]
+    Jb = [torch.empty(int(dims.jac_nnz), dtype=torch.float64, device=dev) for _ in range(nb)]
+    Hb = [torch.empty(int(dims.hess_nnz), dtype=torch.float64, device=dev) for _ in range(nh)]
+    st = torch.cuda.current_stream(dev)
+
+    def timed(fn):
+        for i in range(30):
+            fn(i)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        for i in range(steps):
+            fn(i)
+        e1.record(st)
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / steps
+
+    jl = [dyn.bind_F_dF_device(Z, Fb[i], Jb[i], st) for i in range(nb)]
+    hl = [dyn.bind_mu_d2F_device(Z, mu, Hb[i], st) for i in range(nh)]
+    fl = [dyn.bind_F_dF_device(Z, Fb[i], None, st) for i in range(nb)]      # (the residual alone: a line-search trial)
+    jac_us, hess_us, f_us = timed(lambda i: jl[i % nb]()), timed(lambda i: hl[i % nh]()), timed(lambda i: fl[i % nb]())
+    peak_tf = 78.6
+    rec = {"workload": f"3-qubit Toffoli UnitarySmoothPulseProblem, integrator = :exponential, T={inp.traj.T}", "kernels": list(dyn.kernel_names),
+           "F_dF_us": jac_us, "hess_us": hess_us, "F_only_us": f_us, "ms_per_ipopt_iter_proxy_device": (jac_us + hess_us + f_us) * 1e-3,
+           "hess_nnz_interval": int(dims.hess_nnz_interval), "bound": "mfma", "mfma_peak_TFLOPs": peak_tf}
+    counters, src = _mfma_counters()
+    if counters:
+        ext = {"source": src, "note": "external: rocprofv3 --pmc passes recorded in that file, not measured by this run"}
+        for name, us, key in (("F_dF", jac_us, "config3 exponential qc_mfma16_exp_kernel<true"), ("hess", hess_us, "config3 exponential qc_mfma16_exp_hess_kernel<")):
+            hits = [v for k, v in counters.items() if k.startswith(key)]
+            if len(hits) != 1:
+                continue
+            c = hits[0]
+            ext[name + "_mfma_instructions_per_launch"] = c["SQ_INSTS_VALU_MFMA_F64"]
+            ext[name + "_MfmaUtil_percent"] = c["MfmaUtil_percent"]
+            rec[name + "_mfma_frac"] = c["SQ_INSTS_VALU_MFMA_F64"] * 2048 / (us * 1e-6) / 1e12 / peak_tf
+        if len(ext) > 2:
+            rec["mfma_counters"] = ext
+    dyn.close()
+    return rec
+
+
 KERNEL_SOURCES = ("quantumcollocation.jl_amd/csrc/qc_mfma_kernels.hip", "quantumcollocation.jl_amd/csrc/qc_mfma_common.h",
                   "quantumcollocation.jl_amd/csrc/qc_internal.h")
 
@@ -558,6 +614,8 @@ def main():
                     help="also time the host-buffer entry points (PCIe-inclusive; the `host_visible` object, never `value`)")
     ap.add_argument("--config4", action=argparse.BooleanOptionalAction, default=True,
                     help="at N = 1 also run BASELINE config 4's T = 8000 trajectory on the one device (`config4_one_gpu` object)")
+    ap.add_argument("--exponential", action=argparse.BooleanOptionalAction, default=True,
+                    help="at N = 1 also time the metric workload with the exponential integrator (`exponential_integrator` object)")
     ap.add_argument("--config5", action=argparse.BooleanOptionalAction, default=True,
                     help="at N = 1 also run BASELINE config 5 on the device and report its HBM / MFMA fractions (`config5` object)")
     args = ap.parse_args()
@@ -859,6 +917,13 @@ def main():
         except Exception as exc:   # noqa: BLE001
             c5 = {"error": repr(exc)[:300]}
 
+    cx = None
+    if args.exponential and world == 1 and rank == 0 and args.config in (3, 4):
+        try:
+            cx = exponential_record(qc, dev_index)
+        except Exception as exc:   # noqa: BLE001
+            cx = {"error": repr(exc)[:300]}
+
     c4 = None
     if args.config4 and world == 1 and rank == 0 and args.config in (3, 4) and t_per_gpu == T_PER_GPU:
         try:
@@ -927,6 +992,8 @@ def main():
             line["config4_one_gpu"] = c4
         if c5 is not None:
             line["config5"] = c5
+        if cx is not None:
+            line["exponential_integrator"] = cx
         if cpu_rec is not None:
             line["cpu_baseline"] = cpu_rec
             if "ms_per_ipopt_iter" in cpu_rec and "ms_per_ipopt_iter_proxy_device" in line:

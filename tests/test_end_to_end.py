@@ -78,6 +78,8 @@ def test_bench_line_keeps_the_driver_contract():
     assert d["n_gpus"] == 1 and d["steps"] == 7 and d["warmup"] == 3 and d["higher_is_better"] is True and d["scaling"] == "weak"
     assert d["dtype"] == "f64" and d["vs_baseline"] is None and d["data"].startswith("synthetic") and "workload" in d["config"]
     assert d["value"] > 1e4 and abs(d["value"] * d["ms_per_step"] * 1e-3 - 1.0) < 1e-6          # evals/s x s/step = 1 at N = 1
+    x = d["exponential_integrator"]                                                           # (rows a6 / a6' of SURVEY 8 in the driver's line)
+    assert x["kernels"] == ["mfma16-exp-gather", "mfma16-exp-hess-gather"] and 5 < x["F_dF_us"] < 200 and 10 < x["hess_us"] < 500
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
     assert 0.2 < rf["frac"] < 1.0 and (rf["traffic"] is None or rf["traffic"] > 4e7)
