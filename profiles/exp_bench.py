@@ -20,7 +20,11 @@ dyn = qc.QuantumDynamics(inp.integrators, inp.traj)
 d = dyn.dims
 dev = torch.device("cuda", 0)
 rng = np.random.default_rng(0)
-Z = torch.from_numpy(inp.traj.datavec).to(dev)
+Zh = inp.traj.datavec.copy()
+if os.environ.get("QC_EXP_BENCH_DT"):      # every timestep set to this value: the squaring count follows ||dt G||_1 (0 squarings below 1/8)
+    off = inp.traj.components["Δt"].start
+    Zh[off::inp.traj.dim][:inp.traj.T] = float(os.environ["QC_EXP_BENCH_DT"])
+Z = torch.from_numpy(Zh).to(dev)
 mu = torch.from_numpy(rng.standard_normal(int(d.n_rows))).to(dev)
 nb = max(2, -(-(640 << 20) // (8 * int(d.jac_nnz))))
 nh = max(2, -(-(640 << 20) // (8 * int(d.hess_nnz))))

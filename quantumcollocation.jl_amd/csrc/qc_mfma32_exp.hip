@@ -108,6 +108,7 @@ __global__ __launch_bounds__(kE32Threads, 1) void qc_mfma32_exp_kernel(const QcP
     __shared__ __attribute__((aligned(16))) double GL[4 * 256];          // G (unscaled), A-layout tiles 2I+K
     __shared__ __attribute__((aligned(16))) double RL[2][4 * 256];       // the shared chain R / E, D-layout tiles 2K+J, double-buffered
     __shared__ double RR[ELL ? 2 : 1][ELL ? 32 * kRS : 1];               // ELL: R row-major (the gathers' source), double-buffered
+    __shared__ __attribute__((aligned(16))) double RT[2][4 * 256];       // E transposed tile by tile (read as an A operand: acts as the tile), by its owners
     __shared__ double TS[8 * 16 * 17];                                   // per-wave transpose scratch
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -243,6 +244,7 @@ __global__ __launch_bounds__(kE32Threads, 1) void qc_mfma32_exp_kernel(const QcP
 #pragma unroll
                 for (int r = 0; r < 4; ++r) RR[cur ^ 1][(16 * I + 4 * r + g) * kRS + 16 * Jt + j] = rn[r];
             }
+            if (k == 1) e32_put(RT[cur ^ 1], w, lane, lds_transpose16(scr, rn, g, j));      // the squarings and the outputs read the transposed tiles
         }
         if constexpr (ELL) {
             if (drive) {   // Q_j <- Y Q_j + G_j R: the gathers requested, the products, the gathered terms added
@@ -274,28 +276,54 @@ __global__ __launch_bounds__(kE32Threads, 1) void qc_mfma32_exp_kernel(const QcP
         }
         __syncthreads();
         cur ^= 1;
+        if constexpr (ELL) {              // (the drive chains gather from RR: only the owners need tiles of R, column block Jt, until the last step)
+            if (k > 1) {
+                if (w < 4) { R[w & 1] = e32_tile(RL[cur], w & 1, lane); R[2 + (w & 1)] = e32_tile(RL[cur], 2 + (w & 1), lane); }
+            } else {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) R[q] = e32_tile(RL[cur], q, lane);
-    }
-    // ---- squarings: E <- E E, L_j <- E L_j + L_j E (left factors = LDS-transposed tiles) -------------------------------------
-    for (int s = 0; s < sq; ++s) {
-        v4d Et[4], Lt[4];
+                for (int q = 0; q < 4; ++q) R[q] = e32_tile(RL[cur], q, lane);
+            }
+        } else {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) Et[q] = lds_transpose16(scr, R[q], g, j);     // Et[2I+K] read as A acts as E[I][K]
-        if (drive) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) Lt[q] = lds_transpose16(scr, Q[q], g, j);
+            for (int q = 0; q < 4; ++q) R[q] = e32_tile(RL[cur], q, lane);
         }
+    }
+    // ---- squarings: E <- E E, L_j <- E L_j + L_j E (left factors: E^T tiles published by E's owners, L_j^T by LDS transposes) ---------
+    for (int s = 0; s < sq; ++s) {
+        v4d Et[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Et[q] = e32_tile(RT[cur], q, lane);           // Et[2I+K] read as A acts as E[I][K]
         if (w < 4) {
             const int I = w >> 1, Jt = w & 1;
             const v4d en = e32_mac2(Et[2 * I], R[Jt], Et[2 * I + 1], R[2 + Jt], zero);
             e32_put(RL[cur ^ 1], w, lane, en);
+            e32_put(RT[cur ^ 1], w, lane, lds_transpose16(scr, en, g, j));
         }
         if (drive) {
-            v4d Ln[4];
-            e32_chain4(Et, Q, Lt, R, Ln);                  // E L_j + L_j E
+            // E L_j first (its operands are there), the transposes of L_j in its shadow, then L_j E
+            const v4d z = {0.0, 0.0, 0.0, 0.0};
+            v4d acc[4] = {z, z, z, z};
 #pragma unroll
-            for (int q = 0; q < 4; ++q) Q[q] = Ln[q];
+            for (int K = 0; K < 2; ++K) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(Et[2 * (t >> 1) + K][kk], Q[2 * K + (t & 1)][kk], acc[t], 0, 0, 0);
+                }
+            }
+            v4d Lt[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Lt[q] = lds_transpose16(scr, Q[q], g, j);
+#pragma unroll
+            for (int K = 0; K < 2; ++K) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(Lt[2 * (t >> 1) + K][kk], R[2 * K + (t & 1)][kk], acc[t], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Q[q] = acc[q];
         }
         __syncthreads();
         cur ^= 1;
@@ -306,7 +334,7 @@ __global__ __launch_bounds__(kE32Threads, 1) void qc_mfma32_exp_kernel(const QcP
     // ---- outputs -----------------------------------------------------------------------------------------------------------
     v4d Et[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) Et[q] = lds_transpose16(scr, R[q], g, j);         // transposed tiles: A operands acting as E[I][K], and what is stored
+    for (int q = 0; q < 4; ++q) Et[q] = e32_tile(RT[cur], q, lane);               // transposed tiles: A operands acting as E[I][K], and what is stored
     if constexpr (JAC) {
         // copies w and w + 8 of -E:  Et[2K+J] lane (g, j) reg r = E[16K+j][16J+4r+g]
         double* pF = Jb + P.jo_F;
