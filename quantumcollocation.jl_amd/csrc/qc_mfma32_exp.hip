@@ -108,6 +108,7 @@ __global__ __launch_bounds__(kE32Threads, 1) void qc_mfma32_exp_kernel(const QcP
     __shared__ __attribute__((aligned(16))) double GL[4 * 256];          // G (unscaled), A-layout tiles 2I+K
     __shared__ __attribute__((aligned(16))) double RL[2][4 * 256];       // the shared chain R / E, D-layout tiles 2K+J, double-buffered
     __shared__ double RR[ELL ? 2 : 1][ELL ? 32 * kRS : 1];               // ELL: R row-major (the gathers' source), double-buffered
+    __shared__ __attribute__((aligned(16))) double U1L[2 * 256];         // U_t+1 (wave 0), parked from the first loads to the residual
     __shared__ __attribute__((aligned(16))) double RT[2][4 * 256];       // E transposed tile by tile (read as an A operand: acts as the tile), by its owners
     __shared__ double TS[8 * 16 * 17];                                   // per-wave transpose scratch
     const int tid = threadIdx.x;
@@ -123,6 +124,14 @@ __global__ __launch_bounds__(kE32Threads, 1) void qc_mfma32_exp_kernel(const QcP
     double* __restrict__ scr = TS + w * (16 * 17);
 
     const int b = qc_xcd_remap((int)blockIdx.x, P.n_int);
+#ifdef QC_X32_STAMPS      // diagnostic variant build (profiles/stamps_exp32.py): wave 0 -> slots 0-7, wave 5 -> slots 8-15
+    constexpr bool DIAG = true;
+    QC_STAMP_DECL;
+#define X32_STAMP(k) QC_STAMP(P, b, lane, k)
+    X32_STAMP(0);
+#else
+#define X32_STAMP(k)
+#endif
     const long long t = P.t_begin + b;
     const double* __restrict__ z0 = Z + t * (long long)P.zdim;
     const double* __restrict__ z1 = z0 + P.zdim;
@@ -163,6 +172,17 @@ __global__ __launch_bounds__(kE32Threads, 1) void qc_mfma32_exp_kernel(const QcP
 #pragma unroll
         for (int r = 0; r < 4; ++r) { const int row = 16 * I + 4 * r + g; U[I][r] = row < nr ? z0[P.off_U + jc * nr + row] : 0.0; }
     }
+    // U_t+1 for the residual: requested HERE by the wave that needs it at the end and parked in LDS (a load issued behind the interval's
+    // stores waits for all of them -- it sat in wave 0's tail, the longest of the workgroup)
+    if (w == 0 && Fb) {
+#pragma unroll
+        for (int I = 0; I < 2; ++I) {
+            v4d u1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const int row = 16 * I + 4 * r + g; u1[r] = row < nr ? z1[P.off_U + jc * nr + row] : 0.0; }
+            e32_put(U1L, I, lane, u1);
+        }
+    }
     {
         const v2d* __restrict__ ab = reinterpret_cast<const v2d*>(GxA) + (w >> 1) * 128 + (w & 1) * 64 + lane;
         v2d img[kE32Mmax + 1];
@@ -176,16 +196,22 @@ __global__ __launch_bounds__(kE32Threads, 1) void qc_mfma32_exp_kernel(const QcP
         for (int u = 0; u < kE32Mmax; ++u) Gh += (u < m ? ak[u] : 0.0) * img[u + 1];
         reinterpret_cast<v2d*>(GL)[(w >> 1) * 128 + (w & 1) * 64 + lane] = Gh;
     }
-    if constexpr (ELL) {   // R_deg+1 = I/deg! row-major for the first step's gathers (tile (I, J) by wave 2 I + J)
-        if (w < 4) {
-            double f0 = 1.0;
+    if (w < 4) {           // R_deg+1 = I/deg!, tile (I, J) by wave 2 I + J: the owners read their operand tiles of R from LDS in every step
+        double f0 = 1.0;   // (indexing the register copy R[] with the wave's tile index put the array into scratch memory: four
+#pragma unroll             //  scratch loads inside every owner chain -- 2.8 instead of 2.0 us per Horner step, profiles/r06_exp_hess.txt)
+        for (int k = 2; k <= kE32Deg; ++k) f0 *= (double)k;
+        v4d r0;
 #pragma unroll
-            for (int k = 2; k <= kE32Deg; ++k) f0 *= (double)k;
+        for (int r = 0; r < 4; ++r) r0[r] = ((w >> 1) == (w & 1) && 4 * r + g == j) ? 1.0 / f0 : 0.0;
+        e32_put(RL[0], w, lane, r0);
+        if constexpr (ELL) {   // ... and row-major for the first step's gathers
 #pragma unroll
-            for (int r = 0; r < 4; ++r) RR[0][(16 * (w >> 1) + 4 * r + g) * kRS + 16 * (w & 1) + j] = ((w >> 1) == (w & 1) && 4 * r + g == j) ? 1.0 / f0 : 0.0;
+            for (int r = 0; r < 4; ++r) RR[0][(16 * (w >> 1) + 4 * r + g) * kRS + 16 * (w & 1) + j] = r0[r];
         }
     }
+    X32_STAMP(1);
     __syncthreads();
+    X32_STAMP(2);
 
     // ---- ||h G||_1 (every wave, redundantly): lane (g, i) reg kk of tile (I, K) holds G[16I+i][16K+4kk+g] ---------------
     v4d Y[4];
@@ -232,13 +258,15 @@ __global__ __launch_bounds__(kE32Threads, 1) void qc_mfma32_exp_kernel(const QcP
     v4d R[4] = {ck * IdB, zero, zero, ck * IdB};          // tiles (0,0), (0,1), (1,0), (1,1)
     v4d Q[4] = {zero, zero, zero, zero};
     int cur = 0;
+    X32_STAMP(3);
 #pragma unroll 1
     for (int k = kE32Deg; k >= 1; --k) {
         ck *= (double)k;                                   // 1/(k-1)!
         if (w < 4) {                                       // tile (I, J) of R_k = Y R_k+1 + ck I
             const int I = w >> 1, Jt = w & 1;
             const v4d c0 = I == Jt ? ck * IdB : zero;
-            const v4d rn = e32_mac2(Y[2 * I], R[Jt], Y[2 * I + 1], R[2 + Jt], c0);
+            const v4d yA = I ? Y[2] : Y[0], yB = I ? Y[3] : Y[1];      // (selects, not Y[2 * I]: see above)
+            const v4d rn = e32_mac2(yA, e32_tile(RL[cur], Jt, lane), yB, e32_tile(RL[cur], 2 + Jt, lane), c0);
             e32_put(RL[cur ^ 1], w, lane, rn);
             if constexpr (ELL) {
 #pragma unroll
@@ -276,18 +304,12 @@ __global__ __launch_bounds__(kE32Threads, 1) void qc_mfma32_exp_kernel(const QcP
         }
         __syncthreads();
         cur ^= 1;
-        if constexpr (ELL) {              // (the drive chains gather from RR: only the owners need tiles of R, column block Jt, until the last step)
-            if (k > 1) {
-                if (w < 4) { R[w & 1] = e32_tile(RL[cur], w & 1, lane); R[2 + (w & 1)] = e32_tile(RL[cur], 2 + (w & 1), lane); }
-            } else {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) R[q] = e32_tile(RL[cur], q, lane);
-            }
-        } else {
+        if (!ELL || k == 1) {             // (the row-gather form's drive chains gather from RR: no wave needs R in registers until the last step)
 #pragma unroll
             for (int q = 0; q < 4; ++q) R[q] = e32_tile(RL[cur], q, lane);
         }
     }
+    X32_STAMP(4);
     // ---- squarings: E <- E E, L_j <- E L_j + L_j E (left factors: E^T tiles published by E's owners, L_j^T by LDS transposes) ---------
     for (int s = 0; s < sq; ++s) {
         v4d Et[4];
@@ -295,7 +317,8 @@ __global__ __launch_bounds__(kE32Threads, 1) void qc_mfma32_exp_kernel(const QcP
         for (int q = 0; q < 4; ++q) Et[q] = e32_tile(RT[cur], q, lane);           // Et[2I+K] read as A acts as E[I][K]
         if (w < 4) {
             const int I = w >> 1, Jt = w & 1;
-            const v4d en = e32_mac2(Et[2 * I], R[Jt], Et[2 * I + 1], R[2 + Jt], zero);
+            const v4d en = e32_mac2(e32_tile(RT[cur], 2 * I, lane), e32_tile(RL[cur], Jt, lane), e32_tile(RT[cur], 2 * I + 1, lane),
+                                    e32_tile(RL[cur], 2 + Jt, lane), zero);      // (operand tiles from LDS by tile index: no register array is indexed)
             e32_put(RL[cur ^ 1], w, lane, en);
             e32_put(RT[cur ^ 1], w, lane, lds_transpose16(scr, en, g, j));
         }
@@ -331,10 +354,35 @@ __global__ __launch_bounds__(kE32Threads, 1) void qc_mfma32_exp_kernel(const QcP
         for (int q = 0; q < 4; ++q) R[q] = e32_tile(RL[cur], q, lane);
     }
 
+    X32_STAMP(5);
     // ---- outputs -----------------------------------------------------------------------------------------------------------
     v4d Et[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) Et[q] = e32_tile(RT[cur], q, lane);               // transposed tiles: A operands acting as E[I][K], and what is stored
+    if (w == 0) {
+        // E U_t, the residual, d/dh = -G E U_t (transposed for the stores through the LDS scratch) -- in front of this wave's copies of -E
+        // and its drive's block: the residual and d/dh are a chain of products and transposes, the longest tail of the workgroup when last
+        v4d EU[2];
+#pragma unroll
+        for (int I = 0; I < 2; ++I) EU[I] = e32_mac2(Et[2 * I], U[0], Et[2 * I + 1], U[1], zero);
+        if (Fb) {
+#pragma unroll
+            for (int I = 0; I < 2; ++I) {
+                const v4d dT = lds_transpose16(scr, e32_tile(U1L, I, lane) - EU[I], g, j);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (4 * r + g < nc && 16 * I + j < nr) qc_st8m<2>(Fb + (4 * r + g) * nr + 16 * I + j, dT[r]);
+            }
+        }
+        if (JAC && ft) {
+#pragma unroll
+            for (int I = 0; I < 2; ++I) {
+                const v4d ge = e32_mac2(e32_tile(GL, 2 * I, lane), EU[0], e32_tile(GL, 2 * I + 1, lane), EU[1], zero);
+                const v4d hT = lds_transpose16(scr, -ge, g, j);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (4 * r + g < nc && 16 * I + j < nr) qc_st8m<2>(Jb + P.jo_h + (4 * r + g) * nr + 16 * I + j, hT[r]);
+            }
+        }
+    }
     if constexpr (JAC) {
         // copies w and w + 8 of -E:  Et[2K+J] lane (g, j) reg r = E[16K+j][16J+4r+g]
         double* pF = Jb + P.jo_F;
@@ -362,33 +410,16 @@ __global__ __launch_bounds__(kE32Threads, 1) void qc_mfma32_exp_kernel(const QcP
             }
         }
     }
-    if (w == 0) {
-        // E U_t, the residual, d/dh = -G E U_t (transposed for the stores through the LDS scratch)
-        v4d EU[2];
-#pragma unroll
-        for (int I = 0; I < 2; ++I) EU[I] = e32_mac2(Et[2 * I], U[0], Et[2 * I + 1], U[1], zero);
-        if (Fb) {
-#pragma unroll
-            for (int I = 0; I < 2; ++I) {
-                v4d u1;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { const int row = 16 * I + 4 * r + g; u1[r] = row < nr ? z1[P.off_U + jc * nr + row] : 0.0; }
-                const v4d dT = lds_transpose16(scr, u1 - EU[I], g, j);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) if (4 * r + g < nc && 16 * I + j < nr) qc_st8m<2>(Fb + (4 * r + g) * nr + 16 * I + j, dT[r]);
-            }
-        }
-        if (JAC && ft) {
-#pragma unroll
-            for (int I = 0; I < 2; ++I) {
-                const v4d ge = e32_mac2(e32_tile(GL, 2 * I, lane), EU[0], e32_tile(GL, 2 * I + 1, lane), EU[1], zero);
-                const v4d hT = lds_transpose16(scr, -ge, g, j);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) if (4 * r + g < nc && 16 * I + j < nr) qc_st8m<2>(Jb + P.jo_h + (4 * r + g) * nr + 16 * I + j, hT[r]);
-            }
-        }
-    }
     if (w == 6) deriv_rows_generic(P, z0, z1, h, Fb, Jb, lane, false);
+#ifdef QC_X32_STAMPS
+    X32_STAMP(6);
+    __builtin_amdgcn_s_waitcnt(0);        // (every store acknowledged)
+    X32_STAMP(7);
+    if (P.stamps != nullptr && lane == 0 && (w == 0 || w == 5)) {
+#pragma unroll
+        for (int k_ = 0; k_ < 8; ++k_) P.stamps[(size_t)b * 16 + (w == 0 ? 0 : 8) + k_] = qc_ts_[k_];
+    }
+#endif
 }
 
 }  // namespace
