@@ -118,6 +118,14 @@ __global__ __launch_bounds__(kXThreads, 1) void qc_mfma32_exp_hess_kernel(const 
     double* __restrict__ scr = TS + w * (16 * 17);
 
     const int b = qc_xcd_remap((int)blockIdx.x, P.n_int);
+#ifdef QC_X32_STAMPS      // diagnostic variant build (profiles/stamps_exp32.py hess): wave 0 -> slots 0-7, wave 7 -> slots 8-15
+    constexpr bool DIAG = true;
+    QC_STAMP_DECL;
+#define X32_STAMP(k) QC_STAMP(P, b, lane, k)
+    X32_STAMP(0);
+#else
+#define X32_STAMP(k)
+#endif
     const long long t = P.t_begin + b;
     const double* __restrict__ z0 = Z + t * (long long)P.zdim;
     const double* __restrict__ mu = Mu + t * P.F_stride + P.F_off;
@@ -252,6 +260,7 @@ __global__ __launch_bounds__(kXThreads, 1) void qc_mfma32_exp_hess_kernel(const 
     __syncthreads();                                                      // (YL and the chains' start)
     v4d Q[4] = {zero, zero, zero, zero}, Pm[4] = {zero, zero, zero, zero};
     int cur = 0;
+    X32_STAMP(1);
     auto Yt = [&](int I, int K) { return x_tile(YL, 2 * I + K, lane); };  // A operand Y(I, K)
     auto Vt = [&](int I, int K) { return x_tile(WL, 2 * K + I, lane); };  // A operand V(I, K) = the D-layout tile W(K, I)
     auto Gt = [&](int I, int K) { return Gj[2 * I + K]; };
@@ -343,6 +352,7 @@ __global__ __launch_bounds__(kXThreads, 1) void qc_mfma32_exp_hess_kernel(const 
         __syncthreads();
         cur ^= 1;
     }
+    X32_STAMP(2);
     // ---- squarings ------------------------------------------------------------------------------------------------------------------
     for (int s = 0; s < sq; ++s) {
         const double* __restrict__ Rc = RL[cur];
@@ -392,6 +402,7 @@ __global__ __launch_bounds__(kXThreads, 1) void qc_mfma32_exp_hess_kernel(const 
         __syncthreads();
         cur ^= 1;
     }
+    X32_STAMP(3);
     // ---- shared outputs: E V, G^T W, G E (tile (oI, oJ) each) into the buffers the chains no longer use -----------------------------
     double* __restrict__ EVL = QL[cur ^ 1];
     double* __restrict__ T2L = QT[cur ^ 1];
@@ -411,6 +422,7 @@ __global__ __launch_bounds__(kXThreads, 1) void qc_mfma32_exp_hess_kernel(const 
         x_put(GEL, w, lane, ge);
     }
     __syncthreads();
+    X32_STAMP(4);
     // ---- this drive's blocks -------------------------------------------------------------------------------------------------------
     if (drive) {
         // (U_t, a_w) = -(h / 2^sq) L_w^T M, stored transposed: (M^T L_w)[c][16 J + j] = sum_K (M_K)^T L_w(K, J)
@@ -423,6 +435,7 @@ __global__ __launch_bounds__(kXThreads, 1) void qc_mfma32_exp_hess_kernel(const 
 #pragma unroll
             for (int r = 0; r < 4; ++r) if (4 * r + g < nc && 16 * Jt + j < nr) qc_st8m<2>(pa + (4 * r + g) * nr + 16 * Jt + j, -hs * x[r]);
         }
+        X32_STAMP(5);
         // (a_w, a_jd), jd >= w: -h (h / 4^sq) <G_jd^T, P_w>; the A-layout tile (J', K') of G_jd, lane for lane, IS the D-layout tile (K', J') of G_jd^T
         const double faa = -(h * hs * sc);
         for (int jd = w; jd < m; ++jd) {
@@ -435,6 +448,7 @@ __global__ __launch_bounds__(kXThreads, 1) void qc_mfma32_exp_hess_kernel(const 
             v = x_sum64(v);
             if (lane == 0) Hb[P.ho_aa + jd * (jd + 1) / 2 + w] = faa * v;
         }
+        X32_STAMP(6);
         if (ft) {   // (a_w, h) = -( <G_w^T, E V> + (h / 2^sq) <G^T W, L_w> )
             double v = 0.0;
 #pragma unroll
@@ -468,6 +482,13 @@ __global__ __launch_bounds__(kXThreads, 1) void qc_mfma32_exp_hess_kernel(const 
         }
         qc_hess_tail(P, mu, Hb, lane, 64);
     }
+#ifdef QC_X32_STAMPS
+    X32_STAMP(7);
+    if (P.stamps != nullptr && lane == 0 && (w == 0 || w == 7)) {
+#pragma unroll
+        for (int k_ = 0; k_ < 8; ++k_) P.stamps[(size_t)b * 16 + (w == 0 ? 0 : 8) + k_] = qc_ts_[k_];
+    }
+#endif
 }
 
 }  // namespace
