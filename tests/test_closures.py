@@ -271,7 +271,7 @@ KNOBS = ["QC_HOST_COMPACT", "QC_FUSED_VARIANT", "QC_STORE_MODE", "QC_NO_FUSED", 
          "QC_HOST_TAPER", "QC_HOST_TAIL_SPLIT", "QC_HOST_STREAMS", "QC_HOST_REARM_JOBS", "QC_HOST_REARM", "QC_HOST_PIECE_KB", "QC_HOST_PIECES",
          "QC_HOST_NT", "QC_HOST_NOWATCH", "QC_HOST_NBUF", "QC_HOST_MULTI_FULL", "QC_HOST_LANDING", "QC_HOST_HESS_CHUNKS", "QC_HOST_F_DIRECT",
          "QC_HOST_F_CHUNKS", "QC_HOST_FILL_NT", "QC_HOST_CHUNKS", "QC_HOST_AFFINITY", "QC_HESS_TWO_WAVES", "QC_HESS_GRID", "QC_ELL_JAC",
-         "QC_DEBUG_SKIP", "QC_HOST_TIMEOUT_MS", "QC_HOST_TRACE"]
+         "QC_DEBUG_SKIP", "QC_HOST_TIMEOUT_MS", "QC_HOST_TRACE", "QC_EXP_ELL", "QC_HESS_G2", "QC_HESS_ELL", "QC_FUSED_ELL", "QC_LIST_BATCH"]
 _KNOB_SCRIPT = r"""
 import sys, json
 sys.path[:0] = [%(root)r, %(tests)r]
@@ -302,6 +302,15 @@ dyn = qc.QuantumDynamics(lst.integrators, lst.traj)
 F, J = dyn.F_dF(lst.traj.datavec, fresh=True)
 out["list"] = [float(np.sum(F * (1 + np.arange(F.size) %% 7))), float(np.sum(J * (1 + np.arange(J.size) %% 11)))]
 dyn.close()
+for nq in (2, 4):          # the exponential integrator (round 6: row-gather / dense-image forms, 2N = 8 and 32)
+    inp = qc.unitary_smooth_pulse_inputs(qc.multi_qubit_system(nq), qc.GATES["CNOT" if nq == 2 else "QFT16"], 5, integrator="exponential")
+    dyn = qc.QuantumDynamics(inp.integrators, inp.traj)
+    Z = inp.traj.datavec
+    F, J = dyn.F_dF(Z, fresh=True)
+    H = dyn.mu_d2F(Z, np.cos(np.arange(dyn.dims.n_rows)), fresh=True)
+    w = lambda a, k: float(np.sum(a * (1 + np.arange(a.size) %% k)))
+    out["exp%%d" %% nq] = [w(F, 7), w(J, 11), w(H, 13)]
+    dyn.close()
 print("RESULT " + json.dumps(out))
 """
 
