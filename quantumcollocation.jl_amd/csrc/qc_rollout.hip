@@ -10,6 +10,7 @@
 // so the dependent chain is ~3 sqrt(T) small products instead of T.  FP64 VALU/LDS throughout (n = 2N <= 64); this is a
 // few MFLOP per trajectory and runs once per solve or callback, not per Ipopt iteration.
 #include <string>
+#include <type_traits>
 
 #include "qc_internal.h"
 
@@ -24,20 +25,47 @@ struct RollParams {
     const double* G;
 };
 
-// C (n x p) = A (n x n) * B (n x p), all column-major in LDS; C must not alias A or B
-__device__ inline void mm_lds(double* __restrict__ C, const double* __restrict__ A, const double* __restrict__ B, int n, int p, int tid) {
+// C (n x p) = A (n x n) * B (n x p), all column-major in LDS; C must not alias A or B.
+// NT = n at compile time (0: any n): with the inner loop unrolled its 2 n LDS reads go out together; with a run-time trip count every
+// fused multiply-add waited for its own pair of reads -- 16 dependent LDS round trips per product at 2N = 16, 0.9 us of every 1.3 us step
+// of the chains below (profiles/r06_variants.txt: 122 -> 55 us for a T = 1000 rollout).  Same operations in the same order: same bits.
+template <int NT>
+__device__ __forceinline__ void mm_lds(double* __restrict__ C, const double* __restrict__ A, const double* __restrict__ B, int n_rt, int p, int tid) {
+    const int n = NT ? NT : n_rt;
     for (int idx = tid; idx < n * p; idx += kRT) {
         const int r = idx % n, c = idx / n;
         double acc = 0.0;
-        for (int q = 0; q < n; ++q) acc = fma(A[r + n * q], B[q + n * c], acc);
+        if constexpr (NT != 0) {
+#pragma unroll
+            for (int q = 0; q < NT; ++q) acc = fma(A[r + NT * q], B[q + NT * c], acc);
+        } else {
+            for (int q = 0; q < n; ++q) acc = fma(A[r + n * q], B[q + n * c], acc);
+        }
         C[idx] = acc;
     }
 }
 
+// The chains of kernels 2 - 4 read one matrix per step from global memory.  Requested inside the step, every step paid an L2 round trip
+// between two barriers (~1.5 us: 122 us for a T = 1000 rollout at 2N = 16, of which ~75 were these waits); here the NEXT matrix is
+// requested into registers before the current product and written to LDS behind it.  Same arithmetic in the same order: same bits.
+constexpr int kRPre = 16;           // matrix entries per thread: n <= 64 -> n^2 / kRT <= 16
+struct RollPrefetch {
+    double v[kRPre];
+    __device__ __forceinline__ void fetch(const double* __restrict__ src, int n2, int tid) {
+#pragma unroll
+        for (int i = 0; i < kRPre; ++i) { const int idx = tid + i * kRT; v[i] = idx < n2 ? src[idx] : 0.0; }
+    }
+    __device__ __forceinline__ void commit(double* __restrict__ dst, int n2, int tid) const {
+#pragma unroll
+        for (int i = 0; i < kRPre; ++i) { const int idx = tid + i * kRT; if (idx < n2) dst[idx] = v[i]; }
+    }
+};
+
+template <int NT>
 __global__ __launch_bounds__(kRT) void qc_rollout_prop_kernel(RollParams R, const double* __restrict__ Z, double* __restrict__ E) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     __shared__ double red[kRT / 64];
-    const int tid = threadIdx.x, n = R.n, n2 = n * n;
+    const int tid = threadIdx.x, n = NT ? NT : R.n, n2 = n * n;
     double* Y = sm;
     double* A0 = sm + n2;
     double* A1 = sm + 2 * n2;
@@ -88,7 +116,12 @@ __global__ __launch_bounds__(kRT) void qc_rollout_prop_kernel(RollParams R, cons
         for (int idx = tid; idx < n2; idx += kRT) {
             const int r = idx % n, c = idx / n;
             double acc = 0.0;
-            for (int q = 0; q < n; ++q) acc = fma(Ap[r + n * q], Y[q + n * c], acc);
+            if constexpr (NT != 0) {
+#pragma unroll
+                for (int q = 0; q < NT; ++q) acc = fma(Ap[r + NT * q], Y[q + NT * c], acc);
+            } else {
+                for (int q = 0; q < n; ++q) acc = fma(Ap[r + n * q], Y[q + n * c], acc);
+            }
             acc *= inv;
             An[idx] = acc;
             Em[idx] += acc;
@@ -96,7 +129,7 @@ __global__ __launch_bounds__(kRT) void qc_rollout_prop_kernel(RollParams R, cons
         __syncthreads();
     }
     for (int q = 0; q < sq; ++q) {
-        mm_lds(A0, Em, Em, n, n, tid);
+        mm_lds<NT>(A0, Em, Em, n, n, tid);
         __syncthreads();
         for (int idx = tid; idx < n2; idx += kRT) Em[idx] = A0[idx];
         __syncthreads();
@@ -106,9 +139,10 @@ __global__ __launch_bounds__(kRT) void qc_rollout_prop_kernel(RollParams R, cons
 }
 
 // Q_c = E_{last} ... E_{first} of chunk c
+template <int NT>
 __global__ __launch_bounds__(kRT) void qc_rollout_total_kernel(RollParams R, const double* __restrict__ E, double* __restrict__ Q) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    const int tid = threadIdx.x, n = R.n, n2 = n * n;
+    const int tid = threadIdx.x, n = NT ? NT : R.n, n2 = n * n;
     double* Qa = sm;
     double* Qb = sm + n2;
     double* Et = sm + 2 * n2;
@@ -118,10 +152,13 @@ __global__ __launch_bounds__(kRT) void qc_rollout_total_kernel(RollParams R, con
     __syncthreads();
     double* cur = Qa;
     double* nxt = Qb;
+    RollPrefetch pre;
+    if (t0 + 1 < t1) pre.fetch(E + (size_t)(t0 + 1) * n2, n2, tid);
     for (int t = t0 + 1; t < t1; ++t) {
-        for (int idx = tid; idx < n2; idx += kRT) Et[idx] = E[(size_t)t * n2 + idx];
+        pre.commit(Et, n2, tid);
         __syncthreads();
-        mm_lds(nxt, Et, cur, n, n, tid);
+        if (t + 1 < t1) pre.fetch(E + (size_t)(t + 1) * n2, n2, tid);      // in flight during the product
+        mm_lds<NT>(nxt, Et, cur, n, n, tid);
         __syncthreads();
         double* tmp = cur; cur = nxt; nxt = tmp;
     }
@@ -129,10 +166,11 @@ __global__ __launch_bounds__(kRT) void qc_rollout_total_kernel(RollParams R, con
 }
 
 // S_0 = init, S_{c+1} = Q_c S_c
+template <int NT>
 __global__ __launch_bounds__(kRT) void qc_rollout_starts_kernel(RollParams R, const double* __restrict__ Q, const double* __restrict__ init,
                                                                 double* __restrict__ S) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    const int tid = threadIdx.x, n = R.n, n2 = n * n, ns = n * R.nc;
+    const int tid = threadIdx.x, n = NT ? NT : R.n, n2 = n * n, ns = n * R.nc;
     double* Xa = sm;
     double* Xb = sm + ns;
     double* Qt = sm + 2 * ns;
@@ -140,10 +178,13 @@ __global__ __launch_bounds__(kRT) void qc_rollout_starts_kernel(RollParams R, co
     __syncthreads();
     double* cur = Xa;
     double* nxt = Xb;
+    RollPrefetch pre;
+    if (R.n_chunks > 1) pre.fetch(Q, n2, tid);
     for (int c = 0; c + 1 < R.n_chunks; ++c) {
-        for (int idx = tid; idx < n2; idx += kRT) Qt[idx] = Q[(size_t)c * n2 + idx];
+        pre.commit(Qt, n2, tid);
         __syncthreads();
-        mm_lds(nxt, Qt, cur, n, R.nc, tid);
+        if (c + 2 < R.n_chunks) pre.fetch(Q + (size_t)(c + 1) * n2, n2, tid);
+        mm_lds<NT>(nxt, Qt, cur, n, R.nc, tid);
         __syncthreads();
         for (int idx = tid; idx < ns; idx += kRT) S[(size_t)(c + 1) * ns + idx] = nxt[idx];
         double* tmp = cur; cur = nxt; nxt = tmp;
@@ -151,10 +192,11 @@ __global__ __launch_bounds__(kRT) void qc_rollout_starts_kernel(RollParams R, co
 }
 
 // x at every knot of chunk c from its start state; out is (n nc) x T, one column per knot
+template <int NT>
 __global__ __launch_bounds__(kRT) void qc_rollout_states_kernel(RollParams R, const double* __restrict__ E, const double* __restrict__ S,
                                                                 double* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    const int tid = threadIdx.x, n = R.n, n2 = n * n, ns = n * R.nc;
+    const int tid = threadIdx.x, n = NT ? NT : R.n, n2 = n * n, ns = n * R.nc;
     double* Xa = sm;
     double* Xb = sm + ns;
     double* Et = sm + 2 * ns;
@@ -170,10 +212,13 @@ __global__ __launch_bounds__(kRT) void qc_rollout_states_kernel(RollParams R, co
     __syncthreads();
     double* cur = Xa;
     double* nxt = Xb;
+    RollPrefetch pre;
+    if (t0 < t1) pre.fetch(E + (size_t)t0 * n2, n2, tid);
     for (int t = t0; t < t1; ++t) {
-        for (int idx = tid; idx < n2; idx += kRT) Et[idx] = E[(size_t)t * n2 + idx];
+        pre.commit(Et, n2, tid);
         __syncthreads();
-        mm_lds(nxt, Et, cur, n, R.nc, tid);
+        if (t + 1 < t1) pre.fetch(E + (size_t)(t + 1) * n2, n2, tid);
+        mm_lds<NT>(nxt, Et, cur, n, R.nc, tid);
         __syncthreads();
         for (int idx = tid; idx < ns; idx += kRT) out[(size_t)(t + 1) * ns + idx] = nxt[idx];
         double* tmp = cur; cur = nxt; nxt = tmp;
@@ -226,24 +271,35 @@ hipError_t qc_launch_rollout(const QcParams& P, long long T, const double* dZ, c
     qc_rollout_scratch(P, T, &nE, &nQ, &nS, &R.chunk, &R.n_chunks);
     const size_t n2 = (size_t)P.n * P.n, ns = (size_t)P.n * P.nc;
     const size_t lds_prop = 4 * n2 * 8, lds_tot = 3 * n2 * 8, lds_st = (2 * ns + n2) * 8;
-    hipError_t e;
-    if (lds_prop > 64 * 1024) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qc_rollout_prop_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_prop);
-        if (e != hipSuccess) return e;
+    // the matrix size at compile time for the common ones (1 - 4 qubits: 2N = 4, 8, 16, 32): the products' inner loops unroll
+    auto run = [&](auto nt) -> hipError_t {
+        constexpr int NT = decltype(nt)::value;
+        hipError_t e;
+        if (lds_prop > 64 * 1024) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qc_rollout_prop_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_prop);
+            if (e != hipSuccess) return e;
+        }
+        if (lds_tot > 64 * 1024) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qc_rollout_total_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tot);
+            if (e != hipSuccess) return e;
+        }
+        if (lds_st > 64 * 1024) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qc_rollout_starts_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_st);
+            if (e != hipSuccess) return e;
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qc_rollout_states_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_st);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(qc_rollout_prop_kernel<NT>, dim3(R.n_int), dim3(kRT), lds_prop, st, R, dZ, dE);
+        if (R.n_chunks > 1) hipLaunchKernelGGL(qc_rollout_total_kernel<NT>, dim3(R.n_chunks - 1), dim3(kRT), lds_tot, st, R, dE, dQ);
+        hipLaunchKernelGGL(qc_rollout_starts_kernel<NT>, dim3(1), dim3(kRT), lds_st, st, R, dQ, dinit, dS);
+        hipLaunchKernelGGL(qc_rollout_states_kernel<NT>, dim3(R.n_chunks), dim3(kRT), lds_st, st, R, dE, dS, dout);
+        return hipGetLastError();
+    };
+    switch (P.n) {
+        case 4: return run(std::integral_constant<int, 4>());
+        case 8: return run(std::integral_constant<int, 8>());
+        case 16: return run(std::integral_constant<int, 16>());
+        case 32: return run(std::integral_constant<int, 32>());
+        default: return run(std::integral_constant<int, 0>());
     }
-    if (lds_tot > 64 * 1024) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qc_rollout_total_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tot);
-        if (e != hipSuccess) return e;
-    }
-    if (lds_st > 64 * 1024) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qc_rollout_starts_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_st);
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qc_rollout_states_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_st);
-        if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL(qc_rollout_prop_kernel, dim3(R.n_int), dim3(kRT), lds_prop, st, R, dZ, dE);
-    if (R.n_chunks > 1) hipLaunchKernelGGL(qc_rollout_total_kernel, dim3(R.n_chunks - 1), dim3(kRT), lds_tot, st, R, dE, dQ);
-    hipLaunchKernelGGL(qc_rollout_starts_kernel, dim3(1), dim3(kRT), lds_st, st, R, dQ, dinit, dS);
-    hipLaunchKernelGGL(qc_rollout_states_kernel, dim3(R.n_chunks), dim3(kRT), lds_st, st, R, dE, dS, dout);
-    return hipGetLastError();
 }
