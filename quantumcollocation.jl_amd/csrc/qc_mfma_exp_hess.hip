@@ -152,6 +152,14 @@ __global__ __launch_bounds__(64 * kW) __attribute__((amdgpu_waves_per_eu(kMU <= 
     const v4d zero = {0.0, 0.0, 0.0, 0.0};
 
     const int b = qc_xcd_remap((int)blockIdx.x, P.n_int);
+#ifdef QC_XH_STAMPS       // diagnostic variant build (profiles/stamps_exp16.py): wave 0 -> slots 0-7, wave 1 -> slots 8-15
+    constexpr bool DIAG = true;
+    QC_STAMP_DECL;
+#define XH_STAMP(k) QC_STAMP(P, b, lane, k)
+    XH_STAMP(0);
+#else
+#define XH_STAMP(k)
+#endif
     const long long t = P.t_begin + b;
     const double* __restrict__ z0 = Z + t * (long long)P.zdim;
     const double* __restrict__ mu = Mu + t * P.F_stride + P.F_off;
@@ -252,6 +260,7 @@ __global__ __launch_bounds__(64 * kW) __attribute__((amdgpu_waves_per_eu(kMU <= 
     const v4d Wd = mm16(aM, aU);
     const v4d Vd = mm16(aU, aM);
 
+    XH_STAMP(1);
     // ---- Horner: R_deg+1 = I/deg!, every derivative chain 0 -------------------------------------------------------------------
     double fact = 1.0;
 #pragma unroll
@@ -344,6 +353,7 @@ __global__ __launch_bounds__(64 * kW) __attribute__((amdgpu_waves_per_eu(kMU <= 
         }
         }
     }
+    XH_STAMP(2);
     // ---- squarings --------------------------------------------------------------------------------------------------------------
     for (int q = 0; q < sq; ++q) {
         scr_put(scr, 0, R, g, j);
@@ -386,6 +396,7 @@ __global__ __launch_bounds__(64 * kW) __attribute__((amdgpu_waves_per_eu(kMU <= 
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_wave_barrier();
     }
+    XH_STAMP(3);
     // ---- outputs ------------------------------------------------------------------------------------------------------------------
     // (U_t, a_j) = -(h/2^sq) L_j^T M, stored transposed: M^T L_j  (A = the B-layout tile of M, acting as M^T)
     {
@@ -401,6 +412,7 @@ __global__ __launch_bounds__(64 * kW) __attribute__((amdgpu_waves_per_eu(kMU <= 
             }
         }
     }
+    XH_STAMP(4);
     // The scalar blocks: every per-lane partial first, ONE batched reduction, one store instruction (lane q stores sum q).  One at a time
     // -- an image load, a 64-lane sum and a store per pair, up to 15 in a row on the first wave -- they were a chain of round trips at
     // the end of every wave's life, and at T = 1000 the launch IS one wave's life (profiles/r06_exp_hess.txt).
@@ -463,6 +475,15 @@ __global__ __launch_bounds__(64 * kW) __attribute__((amdgpu_waves_per_eu(kMU <= 
         }
     }
     if (wv == kW - 1) qc_hess_tail(P, mu, Hb, lane, 64);
+#ifdef QC_XH_STAMPS
+    XH_STAMP(5);
+    __builtin_amdgcn_s_waitcnt(0);
+    XH_STAMP(6);
+    if (P.stamps != nullptr && lane == 0 && wv < 2) {
+#pragma unroll
+        for (int k_ = 0; k_ < 8; ++k_) P.stamps[(size_t)b * 16 + 8 * wv + k_] = qc_ts_[k_];
+    }
+#endif
 }
 
 }  // namespace
