@@ -141,14 +141,18 @@ __device__ __forceinline__ void square_step(const v4d& Et, const v4d (&Kt)[M], v
 // waves never exchange data: no barrier.  Two waves per interval fill the chip on short trajectories (T = 200: 18.3 -> 11.9 us);
 // at T = 1000 one wave per interval already occupies every SIMD and the kernel is bound by MFMA issue at the clock the
 // device sustains under FP64 matrix load (two waves there: 30.8 vs 30.3 us, the redundant R chain costs what the overlap gains).
-template <bool JAC, int kMU, int kW, bool ELL = false>
-__global__ __launch_bounds__(64 * kW, kW) void qc_mfma16_exp_kernel(const QcParams P, const double* __restrict__ Z, double* __restrict__ F,
+// (Two-wave forms: TWO intervals per four-wave workgroup -- placement only, the waves never synchronise: a four-wave workgroup takes
+//  one wave slot on each SIMD of its CU, where two-wave workgroups left SIMDs empty at 257 - 512 intervals; qc_mfma_exp_hess.hip.)
+template <bool JAC, int kMU, int kW, bool ELL = false, int kIPW = 1>
+__global__ __launch_bounds__(64 * kW * kIPW, kW) void qc_mfma16_exp_kernel(const QcParams P, const double* __restrict__ Z, double* __restrict__ F,
                                                                     double* __restrict__ J) {
     qc_kernarg_touch<sizeof(QcParams) + 64>();   // one batch of scalar-cache misses instead of one per use (qc_internal.h)
-    __shared__ double scr_all[kW * (kMU + 1) * 16 * 17];      // per-wave transpose scratch: E and the kMU L_j tiles in one LDS round trip
+    static_assert(kIPW == 1 || kW == 2, "two intervals per workgroup: the two-wave forms");
+    __shared__ double scr_all[kIPW * kW * (kMU + 1) * 16 * 17];      // per-wave transpose scratch: E and the kMU L_j tiles in one LDS round trip
     const int lane = threadIdx.x & 63;
-    const int wv = kW > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
-    double* __restrict__ scr = scr_all + wv * ((kMU + 1) * 16 * 17);
+    const int wq = kIPW * kW > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;      // wave of the workgroup
+    const int wv = kW > 1 ? wq % kW : 0;                      // wave of its interval
+    double* __restrict__ scr = scr_all + wq * ((kMU + 1) * 16 * 17);
     const int d0 = wv * kMU;                          // first drive of this wave
     const int m = P.m;
     const int g = lane >> 4, j = lane & 15, jj = j & 7;
@@ -159,7 +163,8 @@ __global__ __launch_bounds__(64 * kW, kW) void qc_mfma16_exp_kernel(const QcPara
 
     {   // one interval per workgroup: a grid-stride loop lets the compiler hoist interval-invariant tiles (the twelve scaled
         // identities, 96 VGPRs) out of the body and spill
-        const int b = qc_xcd_remap((int)blockIdx.x, P.n_int);
+        const int b = qc_xcd_remap((int)blockIdx.x, (P.n_int + kIPW - 1) / kIPW) * kIPW + wq / kW;
+        if (b >= P.n_int) return;                             // (an odd interval count: the last workgroup's second pair has nothing to do)
         const long long t = P.t_begin + b;
         const double* __restrict__ z0 = Z + t * (long long)P.zdim;
         const double* __restrict__ z1 = z0 + P.zdim;
@@ -335,8 +340,11 @@ hipError_t qc_launch_mfma_exp(const QcParams& P, const double* dZ, double* dF, d
     const int grid = P.n_int;
     static const bool ell_off = getenv("QC_EXP_ELL") && atoi(getenv("QC_EXP_ELL")) == 0;      // A/B diagnostics
     const bool ell = P.ell16 != nullptr && !ell_off;      // drive generators with one entry per row: the row-gather form of the Horner steps
-#define QC_XJ(MU_, W_) do { if (ell) hipLaunchKernelGGL((qc_mfma16_exp_kernel<true, MU_, W_, true>), dim3(grid), dim3(64 * W_), 0, st, P, dZ, dF, dJ); \
-                            else hipLaunchKernelGGL((qc_mfma16_exp_kernel<true, MU_, W_, false>), dim3(grid), dim3(64 * W_), 0, st, P, dZ, dF, dJ); } while (0)
+#define QC_XJ1(MU_, W_, I_) do { const int wgs = (grid + I_ - 1) / I_; \
+                            if (ell) hipLaunchKernelGGL((qc_mfma16_exp_kernel<true, MU_, W_, true, I_>), dim3(wgs), dim3(64 * W_ * I_), 0, st, P, dZ, dF, dJ); \
+                            else hipLaunchKernelGGL((qc_mfma16_exp_kernel<true, MU_, W_, false, I_>), dim3(wgs), dim3(64 * W_ * I_), 0, st, P, dZ, dF, dJ); } while (0)
+    // two-wave forms beyond one workgroup per CU: two intervals per (four-wave) workgroup (up to 256 intervals the pairing would only leave CUs empty)
+#define QC_XJ(MU_, W_) do { if (W_ == 2 && grid > 256) QC_XJ1(MU_, W_, (W_ == 2 ? 2 : 1)); else QC_XJ1(MU_, W_, 1); } while (0)
     if (!dJ) {   // residual only: no Frechet chains, one wave
         hipLaunchKernelGGL((qc_mfma16_exp_kernel<false, 1, 1>), dim3(grid), dim3(64), 0, st, P, dZ, dF, dJ);
     } else if (P.m <= 1) {
@@ -357,5 +365,6 @@ hipError_t qc_launch_mfma_exp(const QcParams& P, const double* dZ, double* dF, d
         else QC_XJ(4, 2);
     }
 #undef QC_XJ
+#undef QC_XJ1
     return hipGetLastError();
 }

@@ -134,15 +134,22 @@ __device__ __forceinline__ void lds_order() {
 // a step instead of 3 + 5 kMU.  fma(w, x, acc) per element: what the dense product adds besides exact zeros.
 // (Two waves per SIMD up to three drives a wave -- 256 registers -- is what the launch's time rests on: demanded of the compiler, which
 //  otherwise lands on either side of the line with any small change: 252 -> 264 registers when the tables' layout changed, 61.5 -> 71.2 us.)
-template <int kMU, int kW, bool ELL>
-__global__ __launch_bounds__(64 * kW) __attribute__((amdgpu_waves_per_eu(kMU <= 3 ? 2 : 1))) void qc_mfma16_exp_hess_kernel(const QcParams P, const double* __restrict__ Z, const double* __restrict__ Mu,
+// Two-wave forms put TWO intervals into one four-wave workgroup (the waves of an interval never synchronise: the pairing is placement
+// only).  The dispatcher gives the first wave of a two-wave workgroup the SIMD behind the previous workgroup's FIRST wave: at 257 - 512
+// intervals 243 waves shared a SIMD while as many SIMDs stayed empty -- T = 500 took 58 us, T = 1000 60.5 (profiles/r06_exp16_timeline.txt).
+// A four-wave workgroup takes one wave slot on each SIMD of its CU.  (Up to 256 intervals -- one workgroup per CU or fewer -- the pairing
+// would only leave CUs empty: kIPW = 1 there.  T = 500: 58.0 -> 35.6 us; T = 200, config 2: 23.1 with one interval per workgroup, 24.5 with two.)
+template <int kMU, int kW, bool ELL, int kIPW = 1>
+__global__ __launch_bounds__(64 * kW * kIPW) __attribute__((amdgpu_waves_per_eu(kMU <= 3 ? 2 : 1))) void qc_mfma16_exp_hess_kernel(const QcParams P, const double* __restrict__ Z, const double* __restrict__ Mu,
                                                                      double* __restrict__ H) {
     qc_kernarg_touch<sizeof(QcParams) + 64>();
     constexpr int kTiles = 2 * kMU + 2;                       // E, LV, L_j, P_j
-    __shared__ double scr_all[kW * kTiles * 272];
+    static_assert(kIPW == 1 || kW == 2, "two intervals per workgroup: the two-wave forms");
+    __shared__ double scr_all[kIPW * kW * kTiles * 272];
     const int lane = threadIdx.x & 63;
-    const int wv = kW > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
-    double* __restrict__ scr = scr_all + wv * (kTiles * 272);
+    const int wq = kIPW * kW > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;      // wave of the workgroup
+    const int wv = kW > 1 ? wq % kW : 0;                      // wave of its interval
+    double* __restrict__ scr = scr_all + wq * (kTiles * 272);
     const int d0 = wv * kMU;                                  // first drive of this wave
     const int m = P.m;
     const int g = lane >> 4, j = lane & 15, jj = j & 7;
@@ -151,7 +158,8 @@ __global__ __launch_bounds__(64 * kW) __attribute__((amdgpu_waves_per_eu(kMU <= 
     const v4d IdB = identity_B(g, j);
     const v4d zero = {0.0, 0.0, 0.0, 0.0};
 
-    const int b = qc_xcd_remap((int)blockIdx.x, P.n_int);
+    const int b = qc_xcd_remap((int)blockIdx.x, (P.n_int + kIPW - 1) / kIPW) * kIPW + wq / kW;
+    if (b >= P.n_int) return;                                 // (an odd interval count: the last workgroup's second pair has nothing to do)
 #ifdef QC_XH_STAMPS       // diagnostic variant build (profiles/stamps_exp16.py): wave 0 -> slots 0-7, wave 1 -> slots 8-15
     constexpr bool DIAG = true;
     QC_STAMP_DECL;
@@ -520,8 +528,11 @@ hipError_t qc_launch_mfma_exp_hess(const QcParams& P, const double* dZ, const do
     const int grid = P.n_int;
     static const bool ell_off = getenv("QC_EXP_ELL") && atoi(getenv("QC_EXP_ELL")) == 0;      // A/B diagnostics
     const bool ell = P.ell16 != nullptr && !ell_off;
-#define QC_XH(MU_, W_) do { if (ell) hipLaunchKernelGGL((qc_mfma16_exp_hess_kernel<MU_, W_, true>), dim3(grid), dim3(64 * W_), 0, st, P, dZ, dMu, dH); \
-                            else hipLaunchKernelGGL((qc_mfma16_exp_hess_kernel<MU_, W_, false>), dim3(grid), dim3(64 * W_), 0, st, P, dZ, dMu, dH); } while (0)
+#define QC_XH1(MU_, W_, I_) do { const int wgs = (grid + I_ - 1) / I_; \
+                            if (ell) hipLaunchKernelGGL((qc_mfma16_exp_hess_kernel<MU_, W_, true, I_>), dim3(wgs), dim3(64 * W_ * I_), 0, st, P, dZ, dMu, dH); \
+                            else hipLaunchKernelGGL((qc_mfma16_exp_hess_kernel<MU_, W_, false, I_>), dim3(wgs), dim3(64 * W_ * I_), 0, st, P, dZ, dMu, dH); } while (0)
+    // two-wave forms beyond one workgroup per CU: two intervals per (four-wave) workgroup -- see the kernel
+#define QC_XH(MU_, W_) do { if (W_ == 2 && grid > 256) QC_XH1(MU_, W_, (W_ == 2 ? 2 : 1)); else QC_XH1(MU_, W_, 1); } while (0)
     // Measured at config 3 (T = 1000, m = 6; profiles/r06_exp_hess.txt): two waves of three drives 70.6 us = 0.81 of the f64 MFMA peak
     // counting the shared chains both waves run (0.74 counting them once), one wave of six drives 70.9 us (2000 MFMAs per interval,
     // 0.74 of peak, 300 registers), three waves of two 93.9 us (the shared chains three times): the launch is bound by the matrix pipes.
@@ -532,5 +543,6 @@ hipError_t qc_launch_mfma_exp_hess(const QcParams& P, const double* dZ, const do
     else if (P.m <= 6) QC_XH(3, 2);
     else QC_XH(4, 2);
 #undef QC_XH
+#undef QC_XH1
     return hipGetLastError();
 }
